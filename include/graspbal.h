@@ -1,0 +1,140 @@
+/*
+ * graspbal.h — C-ABI of libgraspbal_hip.so, the MI355X (gfx950) implementation of the
+ * GraspBalance point-cloud hot path.
+ *
+ * Every entry point replaces one raw-pointer launcher of the reference's two CUDA
+ * extensions (paths relative to the reference tree):
+ *   PN-ext = PointNet/_ext_src        (python module pointnet2._ext,        bindings.cpp:12-26)
+ *   PB-ext = pointnet2_batch/src      (python module pointnet2_batch_cuda,  pointnet2_api.cpp:10-24)
+ *   KNN    = KNN/Pytorch_CUDA_KNN     (python module KNN._C,                vision.cpp:3-5)
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (hipMalloc / torch CUDA storage), contiguous, fp32 data,
+ *     int32 indices (int64, 1-based for gb_knn) — the reference's dtype contract
+ *     (_ext_src/include/utils.h:10-30);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); launches are
+ *     asynchronous, the library never synchronises, allocates, or keeps mutable global state,
+ *     so it is re-entrant from autograd worker threads like the reference launchers;
+ *   - return value: GB_OK (0) or a negative GB_E* code; the library never calls exit() and never
+ *     throws (the reference does fprintf+exit(-1), cuda_utils.h:38-47);
+ *   - outputs are fully written by the kernels unless stated otherwise ("accumulates into" means
+ *     the caller zero-fills first, exactly like torch::zeros in the reference wrappers);
+ *   - distances use the no-FMA evaluation order ((dx*dx)+(dy*dy))+(dz*dz); the library is built
+ *     with -ffp-contract=off so results are bit-identical to the CPU oracle in oracle/.
+ */
+#ifndef GRASPBAL_H
+#define GRASPBAL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GB_ABI_VERSION 1
+
+enum {
+  GB_OK = 0,
+  GB_EINVAL = -1,   /* bad dimension / null pointer / unsupported flag combination */
+  GB_ELAUNCH = -2,  /* hipLaunchKernel reported an error (hipGetLastError text via gb_last_error) */
+  GB_ERANGE = -3    /* a dimension exceeds what the kernels index with int32 */
+};
+
+/* ---- gb_fps flags -------------------------------------------------------------------------- */
+/* skip points with x*x+y*y+z*z <= 1e-3 (PN-ext sampling_gpu.cu:105-106); PB-ext has no skip.   */
+#define GB_FPS_SKIP_NEAR_ORIGIN 0x1u
+/* tie-break among exactly equal maxima:
+ *   GB_FPS_TIE_LOWEST : lowest point index wins (the reference's torch fallback,
+ *                       TrainModel/pointnet2_util.py:41)
+ *   GB_FPS_TIE_TREE512: winner of the reference's strided scan + shared-memory tree with
+ *                       block_size = min(2^floor(log2 n), 512)   (PN-ext sampling_gpu.cu:64-178)
+ *   GB_FPS_TIE_TREE1024: same with the PB-ext cap of 1024         (pointnet2_batch sampling_gpu.cu:65-181)
+ * All three coincide when no two candidates tie exactly.                                        */
+#define GB_FPS_TIE_LOWEST   0x00u
+#define GB_FPS_TIE_TREE512  0x10u
+#define GB_FPS_TIE_TREE1024 0x20u
+#define GB_FPS_TIE_MASK     0x30u
+
+int gb_abi_version(void);
+/* last launch error text of the calling thread ("" if none) */
+const char *gb_last_error(void);
+
+/* Furthest point sampling, start index 0.
+ * replaces furthest_point_sampling_kernel_wrapper (PN-ext sampling_gpu.cu:180-234) and
+ *          furthest_point_sampling_kernel_launcher (PB-ext sampling_gpu.cu:183-220).
+ * xyz (b,n,3) f32; idx (b,m) i32 out.
+ * temp (b,n) f32 running min-distance: may be NULL (the library then starts from 1e10 like
+ * sampling.cpp:78-80); if non-NULL it is read as the initial state and the final state is written
+ * back (PB-ext caller-allocated contract, subsample.py:76-79).                                   */
+int gb_fps(const float *xyz, float *temp, int32_t *idx, int b, int n, int m, unsigned flags,
+           void *stream);
+
+/* out[b,c,j] = points[b,c,idx[b,j]]  — gather_points_kernel_wrapper (PN sampling_gpu.cu:27-35),
+ * gather_points_kernel_launcher_fast (PB sampling_gpu.cu:21-33). points (b,c,n), idx (b,m).      */
+int gb_gather(const float *points, const int32_t *idx, float *out, int b, int c, int n, int m,
+              void *stream);
+/* grad_points[b,c,idx[b,j]] += grad_out[b,c,j]; accumulates into grad_points (b,c,n).
+ * gather_points_grad_kernel_wrapper (PN sampling_gpu.cu:54-62), PB sampling_gpu.cu:50-62.        */
+int gb_gather_grad(const float *grad_out, const int32_t *idx, float *grad_points, int b, int c,
+                   int n, int m, void *stream);
+
+/* Ball query: for each centre the first `nsample` points in index order with d2 < radius^2
+ * (strict), row padded with the first hit, all-zero row when there is no hit.
+ * query_ball_point_kernel_wrapper (PN ball_query_gpu.cu:46-54),
+ * ball_query_kernel_launcher_fast (PB ball_query_gpu.cu:45-58).
+ * new_xyz (b,m,3), xyz (b,n,3), idx (b,m,nsample) out (every element written).
+ * scanned (b,m) i32 may be NULL; if given it receives, per centre, the number of points the
+ * reference's serial scan would have visited (min(n, 1 + position of the nsample-th hit)) — the
+ * algorithmic pair count used for roofline accounting.                                           */
+int gb_ball_query(const float *new_xyz, const float *xyz, int32_t *idx, int32_t *scanned, int b,
+                  int n, int m, float radius, int nsample, void *stream);
+
+/* Cylinder query (PN cylinder_query_gpu.cu:20-78): p = xyz - centre, rotated by the centre's
+ * row-major 3x3 `rot` as p^T R; accept if y'^2+z'^2 < radius^2 and hmin < x' < hmax.
+ * rot (b,m,9). Same ordering / padding / zero-row rules as gb_ball_query.                       */
+int gb_cylinder_query(const float *new_xyz, const float *xyz, const float *rot, int32_t *idx,
+                      int32_t *scanned, int b, int n, int m, float radius, float hmin, float hmax,
+                      int nsample, void *stream);
+
+/* The nr x nh cylinder queries of GraspPoseStage2 (TrainModel/graspbalance.py:84-87,
+ * modules.py:99-101) in one pass over xyz: query (ir,ih) uses radii[ir], hmin, hmaxs[ih] and
+ * writes idx[(ir*nh+ih)][b][m][nsample]. radii / hmaxs are HOST arrays (nr, nh <= 4).
+ * Results are bit-identical to nr*nh separate gb_cylinder_query calls.                          */
+int gb_cylinder_query_multi(const float *new_xyz, const float *xyz, const float *rot,
+                            int32_t *idx, int b, int n, int m, const float *radii, int nr,
+                            float hmin, const float *hmaxs, int nh, int nsample, void *stream);
+
+/* out[b,c,j,k] = points[b,c,idx[b,j,k]] — group_points_kernel_wrapper (PN group_points_gpu.cu:46-55),
+ * PB group_points_gpu.cu:57-70. points (b,c,n), idx (b,m,ns), out (b,c,m,ns).                    */
+int gb_group(const float *points, const int32_t *idx, float *out, int b, int c, int n, int m,
+             int nsample, void *stream);
+/* grad_points[b,c,idx[b,j,k]] += grad_out[b,c,j,k]; accumulates into grad_points (b,c,n).
+ * PN group_points_gpu.cu:92-101, PB group_points_gpu.cu:24-37.                                   */
+int gb_group_grad(const float *grad_out, const int32_t *idx, float *grad_points, int b, int c,
+                  int n, int m, int nsample, void *stream);
+
+/* Three nearest `known` points of every `unknown` point: squared distances ascending + indices;
+ * ties keep the lower index (strict <, PN interpolate_gpu.cu:14-64, PB interpolate_gpu.cu:16-59).
+ * unknown (b,n,3), known (b,m,3), dist2 (b,n,3) f32, idx (b,n,3) i32. With m < 3 the missing
+ * slots are (+inf, 0) like the reference's 1e40 -> float conversion.                            */
+int gb_three_nn(const float *unknown, const float *known, float *dist2, int32_t *idx, int b, int n,
+                int m, void *stream);
+/* out[b,c,j] = sum_t points[b,c,idx[b,j,t]] * weight[b,j,t], evaluated (p1*w1 + p2*w2) + p3*w3.
+ * PN interpolate_gpu.cu:77-116, PB :84-117. points (b,c,m), idx/weight (b,n,3), out (b,c,n).      */
+int gb_three_interpolate(const float *points, const int32_t *idx, const float *weight, float *out,
+                         int b, int c, int m, int n, void *stream);
+/* grad_points[b,c,idx[b,j,t]] += grad_out[b,c,j]*weight[b,j,t]; accumulates into (b,c,m).
+ * PN interpolate_gpu.cu:121-159, PB :127-168.                                                    */
+int gb_three_interpolate_grad(const float *grad_out, const int32_t *idx, const float *weight,
+                              float *grad_points, int b, int c, int n, int m, void *stream);
+
+/* Brute-force 1-NN in `dim` dimensions (KNN/Pytorch_CUDA_KNN/knn.h:11-59 with k = 1, the only k
+ * the reference calls: label_generation.py:58,84). ref (b,dim,nref), query (b,dim,nq) f32,
+ * idx (b,1,nq) int64, 1-BASED; the lowest reference index wins ties (stable sort of knn_cpu.cpp). */
+int gb_knn1(const float *ref, const float *query, int64_t *idx, int b, int dim, int nref, int nq,
+            void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRASPBAL_H */

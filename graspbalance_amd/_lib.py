@@ -1,0 +1,90 @@
+"""ctypes binding of libgraspbal_hip.so (C-ABI: include/graspbal.h).
+
+The library is hand-written HIP for gfx950 built in-tree by ``graspbalance_amd/csrc/Makefile``
+(``__graft_entry__.build()``).  There is NO fallback: if the shared object is missing or a symbol
+is absent, importing an op raises — the product never routes through a CPU path.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libgraspbal_hip.so")
+ABI_VERSION = 1
+
+GB_OK = 0
+_ERRNAMES = {-1: "GB_EINVAL", -2: "GB_ELAUNCH", -3: "GB_ERANGE"}
+
+FPS_SKIP_NEAR_ORIGIN = 0x1
+FPS_TIE_LOWEST = 0x00
+FPS_TIE_TREE512 = 0x10
+FPS_TIE_TREE1024 = 0x20
+
+_c = ctypes
+_P, _I, _F, _U = _c.c_void_p, _c.c_int, _c.c_float, _c.c_uint
+
+# name -> argtypes; every function returns int.  Kept in one table so tests can check that the
+# shared object exports exactly what include/graspbal.h declares.
+SIGNATURES = {
+    "gb_fps": [_P, _P, _P, _I, _I, _I, _U, _P],
+    "gb_gather": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "gb_gather_grad": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "gb_ball_query": [_P, _P, _P, _P, _I, _I, _I, _F, _I, _P],
+    "gb_cylinder_query": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _I, _P],
+    "gb_cylinder_query_multi": [_P, _P, _P, _P, _I, _I, _I, _P, _I, _F, _P, _I, _I, _P],
+    "gb_group": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "gb_group_grad": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "gb_three_nn": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "gb_three_interpolate": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "gb_three_interpolate_grad": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "gb_knn1": [_P, _P, _P, _I, _I, _I, _I, _P],
+}
+
+
+def build(verbose=False):
+    """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4"]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+    return SO_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded shared object; raises (never falls back) when it is missing or stale."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise ImportError(
+                "graspbalance_amd: %s not found - build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % SO_PATH)
+        handle = ctypes.CDLL(SO_PATH)
+        handle.gb_abi_version.restype = _I
+        if handle.gb_abi_version() != ABI_VERSION:
+            raise ImportError("graspbalance_amd: %s has ABI %d, expected %d - rebuild"
+                              % (SO_PATH, handle.gb_abi_version(), ABI_VERSION))
+        handle.gb_last_error.restype = _c.c_char_p
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.argtypes = argtypes
+            fn.restype = _I
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != GB_OK:
+        msg = lib().gb_last_error().decode() if rc == -2 else ""
+        raise RuntimeError("%s failed: %s %s" % (what, _ERRNAMES.get(rc, rc), msg))
+
+
+def ptr(t):
+    return _c.c_void_p(t.data_ptr()) if t is not None else _c.c_void_p(0)
+
+
+def current_stream(device):
+    import torch
+    return _c.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,233 @@
+// Furthest point sampling for gfx950 — replaces furthest_point_sampling_kernel of both reference
+// extensions (PointNet/_ext_src/src/sampling_gpu.cu:75-234, pointnet2_batch/src/sampling_gpu.cu:74-220).
+//
+// Design (one workgroup per cloud, the whole cloud REGISTER-resident):
+//   * thread t owns points k = t + p*BLOCK (p < P); x,y,z and the running min-distance live in
+//     4*P VGPRs, so an iteration touches no memory except one scalar load of the new sample's xyz;
+//   * per iteration: P x (3 sub, 3 mul, 2 add, min, cmp, 2 select) VALU, then a wave64 argmax on
+//     DPP (float max, then min tie-key among the lanes holding the max), one LDS slot per wave,
+//     ONE barrier (slots are double-buffered), a 16-lane DPP reduce of the slots by every wave;
+//   * ties are resolved through an explicit key so the result is the reference's for each of the
+//     three rules in graspbal.h (lowest index; strided scan + shared-memory tree with block 512/1024):
+//     tree winner = smallest bit-reversed (k mod BS), then smallest k div BS.
+//     BLOCK is always a multiple of BS, so one thread's points share k mod BS and the strict '>' of
+//     the in-thread scan already picks the smallest k div BS.
+//   * arithmetic is the no-FMA order ((dx*dx)+(dy*dy))+(dz*dz) (file built with -ffp-contract=off).
+// Clouds that do not fit the register file of one CU (n > 24576) go through fps_stream_kernel,
+// which keeps the min-distances in the caller's `temp` buffer (L2-resident) instead.
+#include "gb_common.h"
+
+namespace gb {
+
+#define GB_FPS_KEY_SHIFT 22
+
+struct FpsTie {
+  int bs_log2;  // log2(reference block size), <0 => lowest-index rule
+};
+
+__device__ __forceinline__ unsigned fps_key(int k, int bs_log2) {
+  if (bs_log2 < 0) return (unsigned)k;
+  const unsigned r = (unsigned)k & ((1u << bs_log2) - 1u);
+  const unsigned q = (unsigned)k >> bs_log2;
+  const unsigned rev = bs_log2 == 0 ? 0u : (__brev(r) >> (32 - bs_log2));
+  return (rev << GB_FPS_KEY_SHIFT) | q;
+}
+__device__ __forceinline__ int fps_unkey(unsigned key, int bs_log2) {
+  if (bs_log2 < 0) return (int)key;
+  const unsigned rev = key >> GB_FPS_KEY_SHIFT;
+  const unsigned q = key & ((1u << GB_FPS_KEY_SHIFT) - 1u);
+  const unsigned r = bs_log2 == 0 ? 0u : (__brev(rev) >> (32 - bs_log2));
+  return (int)((q << bs_log2) | r);
+}
+
+// Block-wide argmax of (d, key): returns the winning point index (wave-uniform in every wave).
+// d < 0 marks "no candidate"; if nobody has one the reference's tree returns index 0.
+template <int BLOCK>
+__device__ __forceinline__ int block_argmax(float d, unsigned key, int bs_log2, float *s_d,
+                                            unsigned *s_key, int buf) {
+  constexpr int W = BLOCK / 64;
+  float wmax = wave_max_f32(d);
+  unsigned wkey = wave_min_u32(d == wmax ? key : 0xFFFFFFFFu);
+  if constexpr (W > 1) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+      s_d[buf * 16 + wave] = wmax;
+      s_key[buf * 16 + wave] = wkey;
+    }
+    __syncthreads();
+    float dd = -2.0f;
+    unsigned kk = 0xFFFFFFFFu;
+    if (lane < W) {
+      dd = s_d[buf * 16 + lane];
+      kk = s_key[buf * 16 + lane];
+    }
+    // W <= 16 slots sit in row 0 of the wave; lanes >= W carry (-2, MAX) and never win
+    const float rmax = row_max_f32(dd);
+    const unsigned rkey = row_min_u32(dd == rmax ? kk : 0xFFFFFFFFu);
+    wmax = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(rmax)));
+    wkey = (unsigned)__builtin_amdgcn_readfirstlane((int)rkey);
+  }
+  return wmax < 0.0f ? 0 : fps_unkey(wkey, bs_log2);
+}
+
+template <int BLOCK, int P>
+__global__ __launch_bounds__(BLOCK) void fps_reg_kernel(const float *__restrict__ xyz,
+                                                         float *__restrict__ temp_io,
+                                                         int32_t *__restrict__ idx, int n, int m,
+                                                         int skip, int bs_log2) {
+  __shared__ float s_d[32];
+  __shared__ unsigned s_key[32];
+  const int tid = threadIdx.x;
+  const float *pts = xyz + (size_t)blockIdx.x * n * 3;
+  int32_t *out = idx + (size_t)blockIdx.x * m;
+  float *tio = temp_io ? temp_io + (size_t)blockIdx.x * n : nullptr;
+
+  float px[P], py[P], pz[P], pt[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int k = tid + p * BLOCK;
+    float x = 0.f, y = 0.f, z = 0.f, t = -1.0f;  // t = -1: never a candidate (d2 = min(d,-1) = -1)
+    if (k < n) {
+      const f3 v = reinterpret_cast<const f3 *>(pts)[k];
+      x = v.x; y = v.y; z = v.z;
+      t = tio ? tio[k] : 1e10f;
+      if (skip) {
+        const float mag = ((x * x) + (y * y)) + (z * z);
+        if (mag < 1e-3f) t = -1.0f;  // == (double)mag <= 1e-3 of sampling_gpu.cu:106 (1e-3f rounds up)
+      }
+    }
+    px[p] = x; py[p] = y; pz[p] = z; pt[p] = t;
+  }
+  // my tie key for p = 0; p only adds to the low (k div BS) field / to k itself
+  const unsigned key0 = fps_key(tid, bs_log2);
+  const unsigned keystep = bs_log2 < 0 ? (unsigned)BLOCK : ((unsigned)BLOCK >> bs_log2);
+
+  int old = 0;
+  if (tid == 0) out[0] = 0;
+  for (int j = 1; j < m; ++j) {
+    // wave-uniform address -> scalar loads
+    const float x1 = pts[old * 3 + 0], y1 = pts[old * 3 + 1], z1 = pts[old * 3 + 2];
+    float best = -1.0f;
+    int bestp = 0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const float dx = px[p] - x1, dy = py[p] - y1, dz = pz[p] - z1;
+      const float d = ((dx * dx) + (dy * dy)) + (dz * dz);
+      const float d2 = __builtin_fminf(d, pt[p]);
+      pt[p] = d2;
+      const bool gt = d2 > best;
+      best = gt ? d2 : best;
+      bestp = gt ? p : bestp;
+    }
+    const unsigned key = key0 + (unsigned)bestp * keystep;
+    old = block_argmax<BLOCK>(best, key, bs_log2, s_d, s_key, j & 1);
+    if (tid == 0) out[j] = old;
+  }
+  if (tio) {
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int k = tid + p * BLOCK;
+      if (k < n && pt[p] >= 0.0f) tio[k] = pt[p];  // skipped points keep their input value
+    }
+  }
+}
+
+// Fallback for clouds larger than one CU's register file: min-distances stay in `temp` (global).
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void fps_stream_kernel(const float *__restrict__ xyz,
+                                                            float *__restrict__ temp,
+                                                            int32_t *__restrict__ idx, int n, int m,
+                                                            int skip, int bs_log2) {
+  __shared__ float s_d[32];
+  __shared__ unsigned s_key[32];
+  const int tid = threadIdx.x;
+  const float *pts = xyz + (size_t)blockIdx.x * n * 3;
+  int32_t *out = idx + (size_t)blockIdx.x * m;
+  float *t = temp + (size_t)blockIdx.x * n;
+  int old = 0;
+  if (tid == 0) out[0] = 0;
+  for (int j = 1; j < m; ++j) {
+    const float x1 = pts[old * 3 + 0], y1 = pts[old * 3 + 1], z1 = pts[old * 3 + 2];
+    float best = -1.0f;
+    int bestk = 0;
+    for (int k = tid; k < n; k += BLOCK) {
+      const f3 v = reinterpret_cast<const f3 *>(pts)[k];
+      if (skip) {
+        const float mag = ((v.x * v.x) + (v.y * v.y)) + (v.z * v.z);
+        if (mag < 1e-3f) continue;
+      }
+      const float dx = v.x - x1, dy = v.y - y1, dz = v.z - z1;
+      const float d = ((dx * dx) + (dy * dy)) + (dz * dz);
+      const float tk = t[k];
+      const float d2 = __builtin_fminf(d, tk);
+      t[k] = d2;
+      if (d2 > best) { best = d2; bestk = k; }
+    }
+    old = block_argmax<BLOCK>(best, fps_key(bestk, bs_log2), bs_log2, s_d, s_key, j & 1);
+    if (tid == 0) out[j] = old;
+  }
+}
+
+static int floor_log2(int v) {
+  int l = 0;
+  while ((2 << l) <= v) ++l;
+  return l;
+}
+
+template <int BLOCK, int P>
+static void launch_reg(const float *xyz, float *temp, int32_t *idx, int b, int n, int m, int skip,
+                       int bs_log2, hipStream_t s) {
+  hipLaunchKernelGGL((fps_reg_kernel<BLOCK, P>), dim3(b), dim3(BLOCK), 0, s, xyz, temp, idx, n, m,
+                     skip, bs_log2);
+}
+
+template <int BLOCK>
+static bool dispatch_p(int p_need, const float *xyz, float *temp, int32_t *idx, int b, int n, int m,
+                       int skip, int bs_log2, hipStream_t s) {
+#define GB_CASE(PV)                                                            \
+  if (p_need <= PV) {                                                          \
+    launch_reg<BLOCK, PV>(xyz, temp, idx, b, n, m, skip, bs_log2, s);          \
+    return true;                                                               \
+  }
+  GB_CASE(1) GB_CASE(2) GB_CASE(4) GB_CASE(8)
+  if constexpr (BLOCK == 1024) { GB_CASE(12) GB_CASE(16) GB_CASE(20) GB_CASE(24) }
+  else { GB_CASE(16) }
+#undef GB_CASE
+  return false;
+}
+
+}  // namespace gb
+
+extern "C" int gb_fps(const float *xyz, float *temp, int32_t *idx, int b, int n, int m,
+                      unsigned flags, void *stream) {
+  using namespace gb;
+  if (b < 0 || n < 1 || m < 0 || !xyz || !idx) return GB_EINVAL;
+  if ((long long)n * 3 > 0x7fffffffLL) return GB_ERANGE;
+  if (b == 0 || m == 0) return GB_OK;
+  const unsigned tie = flags & GB_FPS_TIE_MASK;
+  if (tie != GB_FPS_TIE_LOWEST && tie != GB_FPS_TIE_TREE512 && tie != GB_FPS_TIE_TREE1024)
+    return GB_EINVAL;
+  const int skip = (flags & GB_FPS_SKIP_NEAR_ORIGIN) ? 1 : 0;
+  int bs_log2 = -1;
+  if (tie != GB_FPS_TIE_LOWEST) {
+    const int cap = tie == GB_FPS_TIE_TREE512 ? 9 : 10;
+    bs_log2 = floor_log2(n) < cap ? floor_log2(n) : cap;
+    if ((n >> bs_log2) >= (1 << GB_FPS_KEY_SHIFT)) return GB_ERANGE;
+  }
+  hipStream_t s = as_stream(stream);
+  // block size: small clouds are latency-bound on the reduction -> fewer waves; it must be a
+  // multiple of the reference block size whose tie-break is reproduced.
+  int block = n <= 4096 ? 256 : 1024;
+  if (bs_log2 >= 0 && (1 << bs_log2) > block) block = 1 << bs_log2;
+  bool done = false;
+  const int p_need = ceil_div(n, block);
+  if (block == 256) done = dispatch_p<256>(p_need, xyz, temp, idx, b, n, m, skip, bs_log2, s);
+  else if (block == 512) done = dispatch_p<512>(p_need, xyz, temp, idx, b, n, m, skip, bs_log2, s);
+  else done = dispatch_p<1024>(p_need, xyz, temp, idx, b, n, m, skip, bs_log2, s);
+  if (!done) {
+    if (!temp) return GB_EINVAL;  // the streaming path needs the caller's (b,n) scratch
+    hipLaunchKernelGGL((fps_stream_kernel<1024>), dim3(b), dim3(1024), 0, s, xyz, temp, idx, n, m,
+                       skip, bs_log2);
+  }
+  return check_launch("gb_fps");
+}

@@ -1,0 +1,75 @@
+// Shared helpers of libgraspbal_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/graspbal.h"
+
+namespace gb {
+
+void set_last_error(const char *what, hipError_t err);
+void clear_last_error();
+
+// returns GB_OK / GB_ELAUNCH after a kernel launch on `stream`
+inline int check_launch(const char *what) {
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    set_last_error(what, err);
+    return GB_ELAUNCH;
+  }
+  return GB_OK;
+}
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+__host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ---- wave64 reductions on DPP (no LDS): idempotent ops only (max / min) ----------------------
+// One VOP2-DPP instruction per step: v = op(dpp(v), v).  quad_perm xor1, xor2, row_half_mirror,
+// row_mirror leave the row result in all 16 lanes of each row; row_bcast:15 (rows 1,3) and
+// row_bcast:31 (rows 2,3) fold the four rows into lane 63.  Lanes a step does not write keep
+// their value (the register is tied in/out).  hipcc pads nothing inside asm, so every DPP read
+// carries the two wait states it needs after the VALU write of its source (s_nop 1).
+#define GB_DPP_STEP(OP, V, CTRL) \
+  asm volatile("s_nop 1\n\t" OP " %0, %0, %0 " CTRL : "+v"(V))
+
+__device__ __forceinline__ float row_max_f32(float v) {  // result in every lane of each 16-lane row
+  GB_DPP_STEP("v_max_f32_dpp", v, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+  GB_DPP_STEP("v_max_f32_dpp", v, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+  GB_DPP_STEP("v_max_f32_dpp", v, "row_half_mirror row_mask:0xf bank_mask:0xf");
+  GB_DPP_STEP("v_max_f32_dpp", v, "row_mirror row_mask:0xf bank_mask:0xf");
+  return v;
+}
+__device__ __forceinline__ unsigned row_min_u32(unsigned v) {
+  GB_DPP_STEP("v_min_u32_dpp", v, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+  GB_DPP_STEP("v_min_u32_dpp", v, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+  GB_DPP_STEP("v_min_u32_dpp", v, "row_half_mirror row_mask:0xf bank_mask:0xf");
+  GB_DPP_STEP("v_min_u32_dpp", v, "row_mirror row_mask:0xf bank_mask:0xf");
+  return v;
+}
+__device__ __forceinline__ float wave_max_f32(float v) {  // wave-uniform result
+  v = row_max_f32(v);
+  GB_DPP_STEP("v_max_f32_dpp", v, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+  GB_DPP_STEP("v_max_f32_dpp", v, "row_bcast:31 row_mask:0xc bank_mask:0xf");
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+  v = row_min_u32(v);
+  GB_DPP_STEP("v_min_u32_dpp", v, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+  GB_DPP_STEP("v_min_u32_dpp", v, "row_bcast:31 row_mask:0xc bank_mask:0xf");
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ int lane_id() {
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+// number of set bits of `mask` strictly below this lane
+__device__ __forceinline__ int prefix_popc(unsigned long long mask) {
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+struct __attribute__((packed, aligned(4))) f3 {
+  float x, y, z;
+};
+
+}  // namespace gb

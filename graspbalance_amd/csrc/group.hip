@@ -1,0 +1,313 @@
+// gather_points / group_points (+ grads), three_nn, three_interpolate (+ grad), knn1 for gfx950.
+// Replace PointNet/_ext_src/src/{sampling_gpu.cu:13-61, group_points_gpu.cu:17-101,
+// interpolate_gpu.cu:14-159} and their pointnet2_batch/src "_fast" twins, plus the k = 1 use of
+// KNN/Pytorch_CUDA_KNN/cuda/knn.cu.
+//
+// These are HBM-bound index/copy kernels: one thread per output element with the channel loop
+// inside (the index is read once, reused for every channel), 16-byte stores where the row length
+// allows, fp32 scatter-adds as no-return global_atomic_add_f32 (-munsafe-fp-atomics).
+#include "gb_common.h"
+
+namespace gb {
+
+constexpr int TPB = 256;
+constexpr int CCHUNK = 8;  // channels per thread
+
+// out[b,c,e] = points[b,c,idx[b,e]]   for e in [0, L): gather (L = m) and group (L = m*nsample)
+template <int VEC>
+__global__ __launch_bounds__(TPB) void gather_rows_kernel(const float *__restrict__ points,
+                                                           const int32_t *__restrict__ idx,
+                                                           float *__restrict__ out, int c, int n,
+                                                           int L) {
+  const int e = (blockIdx.x * TPB + threadIdx.x) * VEC;
+  if (e >= L) return;
+  const int bi = blockIdx.z;
+  const int cbeg = blockIdx.y * CCHUNK;
+  const int cend = cbeg + CCHUNK < c ? cbeg + CCHUNK : c;
+  const int32_t *ix = idx + (size_t)bi * L + e;
+  int32_t id[VEC];
+  if constexpr (VEC == 4) {
+    const int4 v = *reinterpret_cast<const int4 *>(ix);
+    id[0] = v.x; id[1] = v.y; id[2] = v.z; id[3] = v.w;
+  } else {
+    id[0] = ix[0];
+  }
+  for (int l = cbeg; l < cend; ++l) {
+    const float *src = points + ((size_t)bi * c + l) * n;
+    float *dst = out + ((size_t)bi * c + l) * L + e;
+    if constexpr (VEC == 4) {
+      float4 v;
+      v.x = src[id[0]]; v.y = src[id[1]]; v.z = src[id[2]]; v.w = src[id[3]];
+      *reinterpret_cast<float4 *>(dst) = v;
+    } else {
+      dst[0] = src[id[0]];
+    }
+  }
+}
+
+// grad_points[b,c,idx[b,e]] += grad_out[b,c,e]
+template <int VEC>
+__global__ __launch_bounds__(TPB) void scatter_rows_kernel(const float *__restrict__ grad_out,
+                                                            const int32_t *__restrict__ idx,
+                                                            float *__restrict__ grad_points, int c,
+                                                            int n, int L) {
+  const int e = (blockIdx.x * TPB + threadIdx.x) * VEC;
+  if (e >= L) return;
+  const int bi = blockIdx.z;
+  const int cbeg = blockIdx.y * CCHUNK;
+  const int cend = cbeg + CCHUNK < c ? cbeg + CCHUNK : c;
+  const int32_t *ix = idx + (size_t)bi * L + e;
+  int32_t id[VEC];
+  if constexpr (VEC == 4) {
+    const int4 v = *reinterpret_cast<const int4 *>(ix);
+    id[0] = v.x; id[1] = v.y; id[2] = v.z; id[3] = v.w;
+  } else {
+    id[0] = ix[0];
+  }
+  for (int l = cbeg; l < cend; ++l) {
+    float *dst = grad_points + ((size_t)bi * c + l) * n;
+    const float *src = grad_out + ((size_t)bi * c + l) * L + e;
+    if constexpr (VEC == 4) {
+      const float4 v = *reinterpret_cast<const float4 *>(src);
+      atomicAdd(dst + id[0], v.x);
+      atomicAdd(dst + id[1], v.y);
+      atomicAdd(dst + id[2], v.z);
+      atomicAdd(dst + id[3], v.w);
+    } else {
+      atomicAdd(dst + id[0], src[0]);
+    }
+  }
+}
+
+static int launch_gather_rows(const float *points, const int32_t *idx, float *out, int b, int c,
+                              int n, long long L, hipStream_t s, const char *what) {
+  if (b == 0 || c == 0 || L == 0) return GB_OK;
+  if (L > 0x7fffffffLL || b > 65535 || ceil_div(c, CCHUNK) > 65535) return GB_ERANGE;
+  const bool vec = (L % 4 == 0) && ((reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(out)) % 16 == 0);
+  if (vec) {
+    dim3 grid(ceil_div((int)(L / 4), TPB), ceil_div(c, CCHUNK), b);
+    hipLaunchKernelGGL((gather_rows_kernel<4>), grid, dim3(TPB), 0, s, points, idx, out, c, n, (int)L);
+  } else {
+    dim3 grid(ceil_div((int)L, TPB), ceil_div(c, CCHUNK), b);
+    hipLaunchKernelGGL((gather_rows_kernel<1>), grid, dim3(TPB), 0, s, points, idx, out, c, n, (int)L);
+  }
+  return check_launch(what);
+}
+
+static int launch_scatter_rows(const float *grad_out, const int32_t *idx, float *grad_points, int b,
+                               int c, int n, long long L, hipStream_t s, const char *what) {
+  if (b == 0 || c == 0 || L == 0) return GB_OK;
+  if (L > 0x7fffffffLL || b > 65535 || ceil_div(c, CCHUNK) > 65535) return GB_ERANGE;
+  const bool vec = (L % 4 == 0) && ((reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(grad_out)) % 16 == 0);
+  if (vec) {
+    dim3 grid(ceil_div((int)(L / 4), TPB), ceil_div(c, CCHUNK), b);
+    hipLaunchKernelGGL((scatter_rows_kernel<4>), grid, dim3(TPB), 0, s, grad_out, idx, grad_points, c, n, (int)L);
+  } else {
+    dim3 grid(ceil_div((int)L, TPB), ceil_div(c, CCHUNK), b);
+    hipLaunchKernelGGL((scatter_rows_kernel<1>), grid, dim3(TPB), 0, s, grad_out, idx, grad_points, c, n, (int)L);
+  }
+  return check_launch(what);
+}
+
+// ---- three_nn: one thread per unknown point, known points streamed through LDS ---------------
+constexpr int NN_TILE = 1024;
+
+__global__ __launch_bounds__(TPB) void three_nn_kernel(const float *__restrict__ unknown,
+                                                        const float *__restrict__ known,
+                                                        float *__restrict__ dist2,
+                                                        int32_t *__restrict__ idx, int n, int m) {
+  __shared__ float s_k[NN_TILE * 3];
+  const int bi = blockIdx.y;
+  const int j = blockIdx.x * TPB + threadIdx.x;
+  const float *kn = known + (size_t)bi * m * 3;
+  float ux = 0.f, uy = 0.f, uz = 0.f;
+  if (j < n) {
+    const f3 u = reinterpret_cast<const f3 *>(unknown + (size_t)bi * n * 3)[j];
+    ux = u.x; uy = u.y; uz = u.z;
+  }
+  // The reference keeps the bests in double initialised to 1e40 and compares the float distance
+  // against them with '<' (interpolate_gpu.cu:32-51).  Every stored best is a float value, so
+  // float bests initialised to +inf decide identically, and (float)1e40 == +inf on output.
+  float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+  int i1 = 0, i2 = 0, i3 = 0;
+  for (int base = 0; base < m; base += NN_TILE) {
+    const int cntk = m - base < NN_TILE ? m - base : NN_TILE;
+    __syncthreads();
+    for (int t = threadIdx.x; t < cntk * 3; t += TPB) s_k[t] = kn[(size_t)base * 3 + t];
+    __syncthreads();
+    if (j < n) {
+      for (int k = 0; k < cntk; ++k) {
+        const float dx = ux - s_k[k * 3 + 0], dy = uy - s_k[k * 3 + 1], dz = uz - s_k[k * 3 + 2];
+        const float d = ((dx * dx) + (dy * dy)) + (dz * dz);
+        const int kk = base + k;
+        if (d < b1) {
+          b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = kk;
+        } else if (d < b2) {
+          b3 = b2; i3 = i2; b2 = d; i2 = kk;
+        } else if (d < b3) {
+          b3 = d; i3 = kk;
+        }
+      }
+    }
+  }
+  if (j < n) {
+    float *od = dist2 + ((size_t)bi * n + j) * 3;
+    int32_t *oi = idx + ((size_t)bi * n + j) * 3;
+    od[0] = b1; od[1] = b2; od[2] = b3;
+    oi[0] = i1; oi[1] = i2; oi[2] = i3;
+  }
+}
+
+// out[b,c,j] = (p[i1]*w1 + p[i2]*w2) + p[i3]*w3
+__global__ __launch_bounds__(TPB) void three_interpolate_kernel(const float *__restrict__ points,
+                                                                 const int32_t *__restrict__ idx,
+                                                                 const float *__restrict__ weight,
+                                                                 float *__restrict__ out, int c, int m,
+                                                                 int n) {
+  const int j = blockIdx.x * TPB + threadIdx.x;
+  if (j >= n) return;
+  const int bi = blockIdx.z;
+  const int cbeg = blockIdx.y * CCHUNK;
+  const int cend = cbeg + CCHUNK < c ? cbeg + CCHUNK : c;
+  const int32_t *ix = idx + ((size_t)bi * n + j) * 3;
+  const float *w = weight + ((size_t)bi * n + j) * 3;
+  const int a0 = ix[0], a1 = ix[1], a2 = ix[2];
+  const float w0 = w[0], w1 = w[1], w2 = w[2];
+  for (int l = cbeg; l < cend; ++l) {
+    const float *src = points + ((size_t)bi * c + l) * m;
+    out[((size_t)bi * c + l) * n + j] = ((src[a0] * w0) + (src[a1] * w1)) + (src[a2] * w2);
+  }
+}
+
+__global__ __launch_bounds__(TPB) void three_interpolate_grad_kernel(
+    const float *__restrict__ grad_out, const int32_t *__restrict__ idx,
+    const float *__restrict__ weight, float *__restrict__ grad_points, int c, int n, int m) {
+  const int j = blockIdx.x * TPB + threadIdx.x;
+  if (j >= n) return;
+  const int bi = blockIdx.z;
+  const int cbeg = blockIdx.y * CCHUNK;
+  const int cend = cbeg + CCHUNK < c ? cbeg + CCHUNK : c;
+  const int32_t *ix = idx + ((size_t)bi * n + j) * 3;
+  const float *w = weight + ((size_t)bi * n + j) * 3;
+  const int a0 = ix[0], a1 = ix[1], a2 = ix[2];
+  const float w0 = w[0], w1 = w[1], w2 = w[2];
+  for (int l = cbeg; l < cend; ++l) {
+    float *dst = grad_points + ((size_t)bi * c + l) * m;
+    const float g = grad_out[((size_t)bi * c + l) * n + j];
+    atomicAdd(dst + a0, g * w0);
+    atomicAdd(dst + a1, g * w1);
+    atomicAdd(dst + a2, g * w2);
+  }
+}
+
+// ---- knn1: nearest reference column of each query column, 1-based int64 ----------------------
+constexpr int KNN_TILE = 512;
+constexpr int KNN_MAXDIM = 8;
+
+__global__ __launch_bounds__(TPB) void knn1_kernel(const float *__restrict__ ref,
+                                                    const float *__restrict__ query,
+                                                    int64_t *__restrict__ idx, int dim, int nref,
+                                                    int nq) {
+  __shared__ float s_r[KNN_MAXDIM * KNN_TILE];
+  const int bi = blockIdx.y;
+  const int q = blockIdx.x * TPB + threadIdx.x;
+  const float *r = ref + (size_t)bi * dim * nref;
+  const float *qq = query + (size_t)bi * dim * nq;
+  float qv[KNN_MAXDIM];
+#pragma unroll
+  for (int h = 0; h < KNN_MAXDIM; ++h) qv[h] = (h < dim && q < nq) ? qq[(size_t)h * nq + q] : 0.f;
+  float best = INFINITY;
+  int besti = 0;
+  for (int base = 0; base < nref; base += KNN_TILE) {
+    const int cntk = nref - base < KNN_TILE ? nref - base : KNN_TILE;
+    __syncthreads();
+    for (int t = threadIdx.x; t < dim * KNN_TILE; t += TPB) {
+      const int h = t / KNN_TILE, k = t % KNN_TILE;
+      s_r[t] = k < cntk ? r[(size_t)h * nref + base + k] : 0.f;
+    }
+    __syncthreads();
+    if (q < nq) {
+      for (int k = 0; k < cntk; ++k) {
+        float d = 0.0f;
+#pragma unroll
+        for (int h = 0; h < KNN_MAXDIM; ++h)
+          if (h < dim) {
+            const float t = s_r[h * KNN_TILE + k] - qv[h];
+            d = d + (t * t);
+          }
+        if ((base + k) == 0 || d < best) { best = d; besti = base + k; }
+      }
+    }
+  }
+  if (q < nq) idx[(size_t)bi * nq + q] = (int64_t)besti + 1;
+}
+
+}  // namespace gb
+
+using namespace gb;
+
+extern "C" int gb_gather(const float *points, const int32_t *idx, float *out, int b, int c, int n,
+                         int m, void *stream) {
+  if (b < 0 || c < 0 || n < 1 || m < 0 || !points || !idx || !out) return GB_EINVAL;
+  return launch_gather_rows(points, idx, out, b, c, n, m, as_stream(stream), "gb_gather");
+}
+
+extern "C" int gb_gather_grad(const float *grad_out, const int32_t *idx, float *grad_points, int b,
+                              int c, int n, int m, void *stream) {
+  if (b < 0 || c < 0 || n < 1 || m < 0 || !grad_out || !idx || !grad_points) return GB_EINVAL;
+  return launch_scatter_rows(grad_out, idx, grad_points, b, c, n, m, as_stream(stream), "gb_gather_grad");
+}
+
+extern "C" int gb_group(const float *points, const int32_t *idx, float *out, int b, int c, int n,
+                        int m, int nsample, void *stream) {
+  if (b < 0 || c < 0 || n < 1 || m < 0 || nsample < 0 || !points || !idx || !out) return GB_EINVAL;
+  return launch_gather_rows(points, idx, out, b, c, n, (long long)m * nsample, as_stream(stream), "gb_group");
+}
+
+extern "C" int gb_group_grad(const float *grad_out, const int32_t *idx, float *grad_points, int b,
+                             int c, int n, int m, int nsample, void *stream) {
+  if (b < 0 || c < 0 || n < 1 || m < 0 || nsample < 0 || !grad_out || !idx || !grad_points) return GB_EINVAL;
+  return launch_scatter_rows(grad_out, idx, grad_points, b, c, n, (long long)m * nsample,
+                             as_stream(stream), "gb_group_grad");
+}
+
+extern "C" int gb_three_nn(const float *unknown, const float *known, float *dist2, int32_t *idx,
+                           int b, int n, int m, void *stream) {
+  if (b < 0 || n < 0 || m < 0 || !unknown || !known || !dist2 || !idx) return GB_EINVAL;
+  if (b == 0 || n == 0) return GB_OK;
+  if (b > 65535 || (long long)n * 3 > 0x7fffffffLL || (long long)m * 3 > 0x7fffffffLL) return GB_ERANGE;
+  hipLaunchKernelGGL(three_nn_kernel, dim3(ceil_div(n, TPB), b), dim3(TPB), 0, as_stream(stream),
+                     unknown, known, dist2, idx, n, m);
+  return check_launch("gb_three_nn");
+}
+
+extern "C" int gb_three_interpolate(const float *points, const int32_t *idx, const float *weight,
+                                    float *out, int b, int c, int m, int n, void *stream) {
+  if (b < 0 || c < 0 || m < 1 || n < 0 || !points || !idx || !weight || !out) return GB_EINVAL;
+  if (b == 0 || c == 0 || n == 0) return GB_OK;
+  if (b > 65535 || ceil_div(c, CCHUNK) > 65535) return GB_ERANGE;
+  hipLaunchKernelGGL(three_interpolate_kernel, dim3(ceil_div(n, TPB), ceil_div(c, CCHUNK), b),
+                     dim3(TPB), 0, as_stream(stream), points, idx, weight, out, c, m, n);
+  return check_launch("gb_three_interpolate");
+}
+
+extern "C" int gb_three_interpolate_grad(const float *grad_out, const int32_t *idx,
+                                         const float *weight, float *grad_points, int b, int c,
+                                         int n, int m, void *stream) {
+  if (b < 0 || c < 0 || m < 1 || n < 0 || !grad_out || !idx || !weight || !grad_points) return GB_EINVAL;
+  if (b == 0 || c == 0 || n == 0) return GB_OK;
+  if (b > 65535 || ceil_div(c, CCHUNK) > 65535) return GB_ERANGE;
+  hipLaunchKernelGGL(three_interpolate_grad_kernel, dim3(ceil_div(n, TPB), ceil_div(c, CCHUNK), b),
+                     dim3(TPB), 0, as_stream(stream), grad_out, idx, weight, grad_points, c, n, m);
+  return check_launch("gb_three_interpolate_grad");
+}
+
+extern "C" int gb_knn1(const float *ref, const float *query, int64_t *idx, int b, int dim, int nref,
+                       int nq, void *stream) {
+  if (b < 0 || dim < 1 || dim > KNN_MAXDIM || nref < 1 || nq < 0 || !ref || !query || !idx) return GB_EINVAL;
+  if (b == 0 || nq == 0) return GB_OK;
+  if (b > 65535) return GB_ERANGE;
+  hipLaunchKernelGGL(knn1_kernel, dim3(ceil_div(nq, TPB), b), dim3(TPB), 0, as_stream(stream), ref,
+                     query, idx, dim, nref, nq);
+  return check_launch("gb_knn1");
+}

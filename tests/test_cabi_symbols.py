@@ -1,0 +1,68 @@
+"""The C-ABI library must load and export every symbol include/graspbal.h declares (CPU-only:
+no compute call is made), and the product must not import the oracle."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "graspbal.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gb_\w+)\s*\(", text)))
+
+
+def test_header_declares_expected_entry_points():
+    names = _declared()
+    for n in ["gb_fps", "gb_gather", "gb_gather_grad", "gb_ball_query", "gb_cylinder_query",
+              "gb_cylinder_query_multi", "gb_group", "gb_group_grad", "gb_three_nn", "gb_three_interpolate",
+              "gb_three_interpolate_grad", "gb_knn1", "gb_abi_version", "gb_last_error"]:
+        assert n in names
+
+
+def test_library_exports_every_declared_symbol():
+    from graspbalance_amd import _lib
+    if not os.path.exists(_lib.SO_PATH):
+        _lib.build()
+    handle = ctypes.CDLL(_lib.SO_PATH)
+    for name in _declared():
+        assert hasattr(handle, name), "libgraspbal_hip.so does not export %s" % name
+    handle.gb_abi_version.restype = ctypes.c_int
+    assert handle.gb_abi_version() == _lib.ABI_VERSION
+    # the ctypes signature table covers exactly the compute entry points of the header
+    assert sorted(_lib.SIGNATURES) == sorted(n for n in _declared() if n not in ("gb_abi_version", "gb_last_error"))
+
+
+def test_argument_validation_needs_no_gpu():
+    """Bad dimensions / null pointers are rejected on the host before any launch."""
+    from graspbalance_amd import _lib
+    L = _lib.lib()
+    assert L.gb_fps(None, None, None, 1, 10, 2, 0, None) == -1
+    assert L.gb_fps(ctypes.c_void_p(8), None, ctypes.c_void_p(8), 1, 0, 2, 0, None) == -1
+    assert L.gb_fps(ctypes.c_void_p(8), None, ctypes.c_void_p(8), 1, 10, 2, 0x30, None) == -1  # bad tie mode
+    assert L.gb_fps(ctypes.c_void_p(8), None, ctypes.c_void_p(8), 0, 10, 2, 0, None) == 0  # empty batch: no launch
+    assert L.gb_ball_query(ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8), None, 1, 10, 0, 0.1, 4, None) == 0
+    assert L.gb_ball_query(ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8), None, 1, 10, 4, 0.1, 0, None) == -1
+    assert L.gb_knn1(ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8), 1, 9, 10, 10, None) == -1
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "graspbalance_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "libgraspbal_oracle" not in src, f
+
+
+def test_cpu_tensors_raise_like_the_reference():
+    import torch
+    from graspbalance_amd.pointnet2 import _ext
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        _ext.ball_query(torch.rand(1, 2, 3), torch.rand(1, 8, 3), 0.1, 4)
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        _ext.three_nn(torch.rand(1, 2, 3), torch.rand(1, 8, 3))

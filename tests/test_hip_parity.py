@@ -1,0 +1,282 @@
+"""GPU parity: libgraspbal_hip.so (through the pointnet2._ext / pointnet2_batch_cuda shims, i.e.
+through the C-ABI) against the CPU oracle on the same seeded inputs, against the committed golden
+fixtures, and at full size through size-independent properties.
+
+Bar: bit-exact for every index output and for pure copies / un-fused fp32 arithmetic; scatter-add
+gradients (atomic order is undefined, as in the reference) within 1e-5 relative.
+"""
+import numpy as np
+import pytest
+import torch
+
+from graspbalance_amd.scene import make_scene, make_batch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ext():
+    from graspbalance_amd.pointnet2 import _ext
+    return _ext
+
+
+@pytest.fixture(scope="module")
+def pb():
+    from graspbalance_amd import pointnet2_batch_cuda
+    return pointnet2_batch_cuda
+
+
+def _rot(golden, m, B):
+    r = torch.from_numpy(golden.load("g9_views")["rot"])
+    reps = (m + r.shape[0] - 1) // r.shape[0]
+    return r.repeat(reps, 1, 1)[:m].unsqueeze(0).repeat(B, 1, 1, 1).contiguous()
+
+
+# ------------------------------------------- FPS ----------------------------------------------
+@pytest.mark.parametrize("B,N,m", [(2, 4096, 1024), (1, 20000, 1024), (3, 2048, 1024), (2, 1024, 512),
+                                   (2, 512, 256), (2, 300, 100), (1, 77, 77), (2, 9, 4), (1, 1, 1),
+                                   (1, 5000, 64), (2, 24576, 33), (1, 30000, 40)])
+def test_fps_matches_oracle_pn(ext, orc, B, N, m):
+    torch.manual_seed(N + m)
+    xyz = torch.rand(B, N, 3) + 0.1
+    got = ext.furthest_point_sampling(xyz.to(DEV), m).cpu()
+    want = orc.furthest_point_sampling(xyz, m, orc.FPS_SKIP_NEAR_ORIGIN | orc.FPS_TIE_TREE512)
+    assert got.dtype == torch.int32 and torch.equal(got, want)
+
+
+def test_fps_golden_c1_and_scene(ext, golden):
+    torch.manual_seed(0)
+    xyz = torch.rand(2, 4096, 3)
+    mag = (xyz * xyz).sum(-1)
+    xyz_dev = xyz.to(DEV)
+    from graspbalance_amd import _lib
+    idx = torch.zeros(2, 1024, dtype=torch.int32, device=DEV)
+    # no skip (C1 has near-origin points, the fallback has no skip rule), every tie mode
+    for tie in (_lib.FPS_TIE_LOWEST, _lib.FPS_TIE_TREE512, _lib.FPS_TIE_TREE1024):
+        _lib.check(_lib.lib().gb_fps(_lib.ptr(xyz_dev), None, _lib.ptr(idx), 2, 4096, 1024, tie, None), "gb_fps")
+        torch.cuda.synchronize()
+        assert torch.equal(idx.cpu(), torch.from_numpy(golden.load("g1_fps_c1")["fps"]))
+    assert bool((mag <= 1e-3).any())
+    cloud = torch.from_numpy(make_scene(0, 20000))[None].to(DEV)
+    idx = torch.zeros(1, 1024, dtype=torch.int32, device=DEV)
+    _lib.check(_lib.lib().gb_fps(_lib.ptr(cloud), None, _lib.ptr(idx), 1, 20000, 1024, _lib.FPS_TIE_LOWEST, None), "gb_fps")
+    torch.cuda.synchronize()
+    assert torch.equal(idx.cpu(), torch.from_numpy(golden.load("g3_scene0")["fps"]))
+
+
+@pytest.mark.parametrize("tie", ["lowest", "tree512", "tree1024"])
+@pytest.mark.parametrize("skip", [0, 1])
+def test_fps_ties_duplicates_and_skip(orc, tie, skip):
+    """Heavy exact ties (integer lattice + duplicated points) and near-origin points: every rule."""
+    from graspbalance_amd import _lib
+    g = torch.Generator().manual_seed(7)
+    for (B, N, m) in [(2, 700, 200), (1, 3000, 300), (1, 6000, 128), (2, 64, 64)]:
+        xyz = torch.randint(0, 6, (B, N, 3), generator=g).float() * 0.25
+        third = N // 3
+        xyz[:, N - third:] = xyz[:, :third]  # exact duplicates
+        flags = {"lowest": _lib.FPS_TIE_LOWEST, "tree512": _lib.FPS_TIE_TREE512, "tree1024": _lib.FPS_TIE_TREE1024}[tie]
+        flags |= skip
+        dev = xyz.to(DEV)
+        idx = torch.zeros(B, m, dtype=torch.int32, device=DEV)
+        temp = torch.full((B, N), 1e10, device=DEV)
+        _lib.check(_lib.lib().gb_fps(_lib.ptr(dev), _lib.ptr(temp), _lib.ptr(idx), B, N, m, flags, None), "gb_fps")
+        torch.cuda.synchronize()
+        temp_o = torch.full((B, N), 1e10)
+        want = orc.furthest_point_sampling(xyz, m, flags, temp=temp_o)
+        assert torch.equal(idx.cpu(), want), (tie, skip, B, N, m)
+        assert torch.equal(temp.cpu(), temp_o), "running min-distance state differs"
+
+
+def test_fps_pb_wrapper_and_full_size_properties(pb, orc):
+    # PB-ext: caller-allocated temp/idx, no skip, tree1024
+    xyz = torch.from_numpy(make_batch([0, 1, 2, 3], 20000))
+    dev = xyz.to(DEV)
+    temp = torch.full((4, 20000), 1e10, device=DEV)
+    idx = torch.zeros(4, 2048, dtype=torch.int32, device=DEV)
+    assert pb.furthest_point_sampling_wrapper(4, 20000, 2048, dev, temp, idx) == 1
+    idx = idx.cpu()
+    want = orc.furthest_point_sampling(xyz, 2048, orc.FPS_TIE_TREE1024)
+    assert torch.equal(idx, want)
+    # size-independent properties: starts at 0, no index repeated unless its point is a duplicate,
+    # running min distance to the chosen set is non-increasing along the sample order
+    assert bool((idx[:, 0] == 0).all())
+    pts = torch.gather(xyz, 1, idx.long()[:, :, None].expand(-1, -1, 3))
+    for b in range(4):
+        assert len(set(idx[b].tolist())) == 2048
+        d = torch.cdist(pts[b].double(), pts[b].double())
+        gaps = torch.stack([d[j, :j].min() for j in range(1, 2048)])
+        assert bool((gaps[1:] <= gaps[:-1] + 1e-9).all())
+
+
+# --------------------------------------- ball / cylinder ---------------------------------------
+@pytest.mark.parametrize("B,N,m,r,ns", [(2, 4096, 512, 0.1, 32), (2, 4096, 512, 0.04, 32), (2, 4096, 512, 0.2, 64),
+                                        (1, 20000, 1024, 0.04, 32), (3, 1000, 37, 0.15, 5), (1, 50, 50, 10.0, 64),
+                                        (2, 130, 3, 0.3, 200), (1, 64, 1, 0.0, 4), (4, 20000, 2048, 0.04, 64),
+                                        (8, 5000, 2048, 0.1, 16)])
+def test_ball_query_matches_oracle(ext, pb, orc, B, N, m, r, ns):
+    torch.manual_seed(N * 3 + m)
+    if N == 20000:
+        xyz = torch.from_numpy(make_batch(range(B), N))
+    else:
+        xyz = torch.rand(B, N, 3)
+    new_xyz = xyz[:, torch.randperm(N)[:m]].contiguous()
+    want, scanned = orc.ball_query(new_xyz, xyz, r, ns, return_scanned=True)
+    got = ext.ball_query(new_xyz.to(DEV), xyz.to(DEV), r, ns).cpu()
+    assert torch.equal(got, want)
+    idx = torch.full((B, m, ns), -7, dtype=torch.int32, device=DEV)  # PB: caller allocated, garbage-filled
+    assert pb.ball_query_wrapper(B, N, m, r, ns, new_xyz.to(DEV), xyz.to(DEV), idx) == 1
+    assert torch.equal(idx.cpu(), want)
+    # scanned-pair counts (roofline accounting) through the raw C-ABI
+    from graspbalance_amd import _lib
+    sc = torch.zeros(B, m, dtype=torch.int32, device=DEV)
+    idx2 = torch.zeros(B, m, ns, dtype=torch.int32, device=DEV)
+    nx, x = new_xyz.to(DEV), xyz.to(DEV)
+    _lib.check(_lib.lib().gb_ball_query(_lib.ptr(nx), _lib.ptr(x), _lib.ptr(idx2), _lib.ptr(sc), B, N, m, r, ns, None), "bq")
+    torch.cuda.synchronize()
+    assert torch.equal(idx2.cpu(), want) and torch.equal(sc.cpu(), scanned)
+
+
+def test_ball_query_golden(ext, golden):
+    torch.manual_seed(0)
+    xyz = torch.rand(2, 4096, 3)
+    fps = torch.from_numpy(golden.load("g1_fps_c1")["fps"]).long()
+    new_xyz = torch.gather(xyz, 1, fps[:, :512, None].expand(-1, -1, 3)).contiguous()
+    for (r, ns) in [(0.1, 32), (0.04, 32), (0.2, 64)]:
+        want = torch.from_numpy(golden.load("g2_ball_c1")["idx_r%g_ns%d" % (r, ns)]).clone()
+        want[want == 4096] = 0
+        assert torch.equal(ext.ball_query(new_xyz.to(DEV), xyz.to(DEV), r, ns).cpu(), want)
+
+
+@pytest.mark.parametrize("B,N,m,ns", [(2, 3000, 64, 16), (1, 20000, 1024, 64), (2, 500, 300, 7)])
+def test_cylinder_query_matches_oracle(ext, orc, golden, B, N, m, ns):
+    torch.manual_seed(N + 11)
+    xyz = torch.from_numpy(make_batch(range(B), N)) if N == 20000 else torch.rand(B, N, 3) * 0.3
+    new_xyz = xyz[:, :m].contiguous()
+    rot = _rot(golden, m, B)
+    for (r, hmin, hmax) in [(0.05, -0.02, 0.04), (0.02, -0.02, 0.01), (0.08, -0.02, 0.03)]:
+        want = orc.cylinder_query(new_xyz, xyz, rot.view(B, m, 9), r, hmin, hmax, ns)
+        got = ext.cylinder_query(new_xyz.to(DEV), xyz.to(DEV), rot.view(B, m, 9).to(DEV), r, hmin, hmax, ns).cpu()
+        assert torch.equal(got, want)
+
+
+def test_cylinder_query_multi_equals_16_single_queries(orc, golden):
+    from graspbalance_amd import _lib
+    import ctypes
+    B, N, m, ns = 2, 20000, 1024, 64
+    xyz = torch.from_numpy(make_batch([5, 6], N))
+    new_xyz = xyz[:, :m].contiguous()
+    rot = _rot(golden, m, B).view(B, m, 9)
+    radii = [0.02, 0.04, 0.06, 0.08]
+    hmaxs = [0.01, 0.02, 0.03, 0.04]
+    out = torch.full((4, 4, B, m, ns), -1, dtype=torch.int32, device=DEV)
+    nx, x, rt = new_xyz.to(DEV), xyz.to(DEV), rot.to(DEV)
+    ra = (ctypes.c_float * 4)(*radii)
+    ha = (ctypes.c_float * 4)(*hmaxs)
+    _lib.check(_lib.lib().gb_cylinder_query_multi(_lib.ptr(nx), _lib.ptr(x), _lib.ptr(rt), _lib.ptr(out), B, N, m,
+                                                  ctypes.cast(ra, ctypes.c_void_p), 4, -0.02,
+                                                  ctypes.cast(ha, ctypes.c_void_p), 4, ns, None), "multi")
+    torch.cuda.synchronize()
+    out = out.cpu()
+    for ir, r in enumerate(radii):
+        for ih, h in enumerate(hmaxs):
+            want = orc.cylinder_query(new_xyz, xyz, rot, r, -0.02, h, ns)
+            assert torch.equal(out[ir, ih], want), (r, h)
+
+
+# ------------------------------------- gather / group ------------------------------------------
+@pytest.mark.parametrize("B,C,N,m,ns", [(2, 3, 4096, 512, 32), (2, 128, 2048, 2048, 64), (1, 5, 33, 7, 3), (3, 1, 10, 4, 1)])
+def test_group_and_gather_fwd_bwd(ext, pb, orc, B, C, N, m, ns):
+    torch.manual_seed(C + N)
+    pts = torch.randn(B, C, N)
+    idx = torch.randint(0, N, (B, m, ns), dtype=torch.int32)
+    idx[:, :, ns // 2:] = idx[:, :, :1]  # padded rows -> heavy duplicate scatter targets
+    got = ext.group_points(pts.to(DEV), idx.to(DEV)).cpu()
+    assert torch.equal(got, orc.group_points(pts, idx))
+    out = torch.empty(B, C, m, ns, device=DEV)
+    pb.group_points_wrapper(B, C, N, m, ns, pts.to(DEV), idx.to(DEV), out)
+    assert torch.equal(out.cpu(), got)
+    g = torch.randn(B, C, m, ns)
+    gg = ext.group_points_grad(g.to(DEV), idx.to(DEV), N).cpu()
+    ref = orc.group_points_grad(g.double().float(), idx, N)
+    ref64 = torch.zeros(B, C, N, dtype=torch.float64).scatter_add_(
+        2, idx.long().view(B, 1, -1).expand(-1, C, -1), g.double().view(B, C, -1))
+    scale = ref64.abs().max().item() + 1e-12
+    assert float((gg.double() - ref64).abs().max()) / scale < 1e-5
+    assert float((ref.double() - ref64).abs().max()) / scale < 1e-5
+    acc = torch.zeros(B, C, N, device=DEV)
+    pb.group_points_grad_wrapper(B, C, N, m, ns, g.to(DEV), idx.to(DEV), acc)
+    assert float((acc.cpu().double() - ref64).abs().max()) / scale < 1e-5
+    # gather
+    idx1 = idx[:, :, 0].contiguous()
+    ga = ext.gather_points(pts.to(DEV), idx1.to(DEV)).cpu()
+    assert torch.equal(ga, orc.gather_points(pts, idx1))
+    g1 = torch.randn(B, C, m)
+    gag = ext.gather_points_grad(g1.to(DEV), idx1.to(DEV), N).cpu()
+    r1 = torch.zeros(B, C, N, dtype=torch.float64).scatter_add_(2, idx1.long().view(B, 1, -1).expand(-1, C, -1), g1.double())
+    assert float((gag.double() - r1).abs().max()) / (r1.abs().max().item() + 1e-12) < 1e-5
+
+
+# --------------------------------- three_nn / interpolate --------------------------------------
+@pytest.mark.parametrize("B,n,m,C", [(2, 1024, 512, 16), (4, 512, 256, 256), (1, 20000, 1024, 8), (2, 10, 2, 3), (1, 7, 1, 2), (1, 3000, 2500, 4)])
+def test_three_nn_and_interpolate(ext, pb, orc, B, n, m, C):
+    torch.manual_seed(n + m)
+    unknown, known = torch.rand(B, n, 3), torch.rand(B, m, 3)
+    d2, idx = ext.three_nn(unknown.to(DEV), known.to(DEV))
+    wd2, widx = orc.three_nn(unknown, known)
+    assert torch.equal(idx.cpu(), widx) and torch.equal(d2.cpu(), wd2)
+    d2b = torch.empty(B, n, 3, device=DEV)
+    idxb = torch.empty(B, n, 3, dtype=torch.int32, device=DEV)
+    pb.three_nn_wrapper(B, n, m, unknown.to(DEV), known.to(DEV), d2b, idxb)
+    assert torch.equal(idxb.cpu(), widx) and torch.equal(d2b.cpu(), wd2)
+    if m < 3:
+        return
+    feats = torch.randn(B, C, m)
+    w = torch.rand(B, n, 3)
+    w = w / w.sum(-1, keepdim=True)
+    out = ext.three_interpolate(feats.to(DEV), idx, w.to(DEV)).cpu()
+    assert torch.equal(out, orc.three_interpolate(feats, widx, w))  # same un-fused evaluation order
+    g = torch.randn(B, C, n)
+    gp = ext.three_interpolate_grad(g.to(DEV), idx, w.to(DEV), m).cpu()
+    ref = orc.three_interpolate_grad(g, widx, w, m)
+    assert float((gp - ref).abs().max()) / (ref.abs().max().item() + 1e-12) < 1e-5
+
+
+def test_three_nn_golden(ext, golden):
+    g = golden.load("g5_three_nn")
+    torch.manual_seed(5)
+    unknown, known = torch.rand(2, 1024, 3), torch.rand(2, 512, 3)
+    d2, idx = ext.three_nn(unknown.to(DEV), known.to(DEV))
+    assert torch.equal(idx.cpu(), torch.from_numpy(g["idx"])) and torch.equal(d2.cpu(), torch.from_numpy(g["dist2"]))
+
+
+# ----------------------------------------- knn1 ------------------------------------------------
+def test_knn1(orc, golden):
+    from graspbalance_amd import _lib
+    g = golden.load("g8_knn")
+    torch.manual_seed(8)
+    ref, query = torch.rand(1, 3, 300), torch.rand(1, 3, 300)
+    ref2, query2 = torch.rand(2, 3, 700), torch.rand(2, 3, 1024)
+    for (r, q, want) in [(ref, query, g["inds"]), (ref2, query2, g["inds2"])]:
+        out = torch.zeros(r.shape[0], 1, q.shape[2], dtype=torch.int64, device=DEV)
+        rd, qd = r.to(DEV), q.to(DEV)
+        _lib.check(_lib.lib().gb_knn1(_lib.ptr(rd), _lib.ptr(qd), _lib.ptr(out), r.shape[0], 3, r.shape[2], q.shape[2], None), "knn")
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), torch.from_numpy(want))
+        assert torch.equal(out.cpu(), orc.knn1(r, q))
+
+
+# --------------------------------- error behaviour of the shims --------------------------------
+def test_error_contract(ext):
+    x = torch.rand(1, 8, 3)
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        ext.furthest_point_sampling(x, 2)
+    with pytest.raises(RuntimeError, match="must be a float tensor"):
+        ext.furthest_point_sampling(x.double().to(DEV), 2)
+    with pytest.raises(RuntimeError, match="must be a contiguous tensor"):
+        ext.gather_points(torch.rand(1, 8, 3, device=DEV).transpose(1, 2), torch.zeros(1, 2, dtype=torch.int32, device=DEV))
+    with pytest.raises(RuntimeError, match="must be an int tensor"):
+        ext.gather_points(torch.rand(1, 3, 8, device=DEV), torch.zeros(1, 2, dtype=torch.int64, device=DEV))
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        ext.gather_points(torch.rand(1, 3, 8, device=DEV), torch.zeros(1, 2, dtype=torch.int32))

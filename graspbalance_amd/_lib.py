@@ -75,6 +75,48 @@ def lib():
     return _lib
 
 
+class KernelTimer:
+    """Optional HIP-event timing of C-ABI launches (bench.py's roofline leg).  While active, shims
+    that call ``timed(name, fn)`` bracket the launch with events on the launch stream."""
+
+    active = None
+
+    def __init__(self, names):
+        self.names = set(names)
+        self.events = {n: [] for n in names}
+
+    def __enter__(self):
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *exc):
+        KernelTimer.active = None
+
+    def summary(self):
+        """name -> (launches, mean ms) ; call after torch.cuda.synchronize()."""
+        out = {}
+        for n, evs in self.events.items():
+            if evs:
+                ms = [a.elapsed_time(b) for a, b, _ in evs]
+                out[n] = {"launches": len(ms), "mean_ms": sum(ms) / len(ms), "meta": [m for _, _, m in evs][0]}
+        return out
+
+
+def timed(name, device, meta, launch):
+    """Run ``launch()`` (a C-ABI call returning rc); time it when a KernelTimer wants `name`."""
+    t = KernelTimer.active
+    if t is None or name not in t.names:
+        return launch()
+    import torch
+    s = torch.cuda.current_stream(device)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(s)
+    rc = launch()
+    b.record(s)
+    t.events[name].append((a, b, meta))
+    return rc
+
+
 def check(rc, what):
     if rc != GB_OK:
         msg = lib().gb_last_error().decode() if rc == -2 else ""

@@ -1,0 +1,160 @@
+"""DRP backbone (the one GraspBalance uses): the PointNet++ SA/FP skeleton of backbone.py with
+3/6/3/3 inverted-residual MLP blocks after SA1-4 (reference TrainModel/drp.py: get_reduction_fn :20,
+LocalAggregation :32, InvResMLP :70, ResBlock :120, DRP :150).  Module / parameter names follow the
+reference so checkpoints load: e.g. ``InvResMLP_blocks1.2.pwconv.0.0.weight`` is (512,128,1)."""
+import logging
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from .backbone import break_up_pc, make_sa
+from .modified_net_tools.activation import CHANNEL_MAP, create_act
+from .modified_net_tools.conv import create_convblock1d, create_convblock2d
+from .modified_net_tools.group import create_grouper, get_aggregation_feautres
+from .pointnet2_modules import PointnetFPModule
+
+
+def get_reduction_fn(reduction):
+    reduction = 'mean' if reduction.lower() == 'avg' else reduction
+    assert reduction in ['sum', 'max', 'mean']
+    if reduction == 'max':
+        return lambda x: torch.max(x, dim=-1, keepdim=False)[0]
+    if reduction == 'mean':
+        return lambda x: torch.mean(x, dim=-1, keepdim=False)
+    return lambda x: torch.sum(x, dim=-1, keepdim=False)
+
+
+class LocalAggregation(nn.Module):
+    """ball-query group -> [dp, fj] -> 1x1 conv stack -> pool over the neighbours."""
+
+    def __init__(self, channels: List[int], norm_args={'norm': 'bn1d'}, act_args={'act': 'relu'},
+                 group_args={'NAME': 'ballquery', 'radius': 0.1, 'nsample': 16}, conv_args=None,
+                 feature_type='dp_fj', reduction='max', last_act=True, **kwargs):
+        super().__init__()
+        if kwargs:
+            logging.warning(f"kwargs: {kwargs} are not used in {__class__.__name__}")
+        channels[0] = CHANNEL_MAP[feature_type](channels[0])
+        last = len(channels) - 2
+        self.convs = nn.Sequential(*[
+            create_convblock2d(channels[i], channels[i + 1], norm_args=norm_args,
+                               act_args=None if (i == last and not last_act) else act_args, **conv_args)
+            for i in range(len(channels) - 1)])
+        self.grouper = create_grouper(group_args)
+        self.reduction = reduction.lower()
+        self.pool = get_reduction_fn(self.reduction)
+        self.feature_type = feature_type
+
+    def forward(self, pf) -> torch.Tensor:
+        p, f = pf
+        dp, fj = self.grouper(p, p, f)
+        fj = get_aggregation_feautres(p, dp, f, fj, self.feature_type)
+        return self.pool(self.convs(fj))
+
+
+def _pointwise(channels, norm_args, act_args, conv_args, less_act):
+    last = len(channels) - 2
+    return nn.Sequential(*[
+        create_convblock1d(channels[i], channels[i + 1], norm_args=norm_args,
+                           act_args=act_args if (i != last and not less_act) else None, **conv_args)
+        for i in range(len(channels) - 1)])
+
+
+class InvResMLP(nn.Module):
+    """LocalAggregation(C->C) -> pointwise C->expansion*C->C -> residual add -> act."""
+
+    def __init__(self, in_channels, norm_args=None, act_args=None,
+                 aggr_args={'feature_type': 'dp_fj', "reduction": 'max'}, group_args={'NAME': 'ballquery'},
+                 conv_args=None, expansion=1, use_res=True, num_posconvs=2, less_act=False, **kwargs):
+        super().__init__()
+        self.use_res = use_res
+        mid_channels = int(in_channels * expansion)
+        self.convs = LocalAggregation([in_channels, in_channels], norm_args=norm_args,
+                                      act_args=act_args if num_posconvs > 0 else None, group_args=group_args,
+                                      conv_args=conv_args, **aggr_args, **kwargs)
+        if num_posconvs < 1:
+            channels = []
+        elif num_posconvs == 1:
+            channels = [in_channels, in_channels]
+        else:
+            channels = [in_channels, mid_channels, in_channels]
+        self.pwconv = _pointwise(channels, norm_args, act_args, conv_args, less_act)
+        self.act = create_act(act_args)
+
+    def forward(self, pf):
+        p, f = pf
+        identity = f
+        f = self.pwconv(self.convs([p, f]))
+        if f.shape[-1] == identity.shape[-1] and self.use_res:
+            f += identity
+        return [p, self.act(f)]
+
+
+class ResBlock(nn.Module):
+    def __init__(self, in_channels, norm_args=None, act_args=None,
+                 aggr_args={'feature_type': 'dp_fj', "reduction": 'max'}, group_args={'NAME': 'ballquery'},
+                 conv_args=None, expansion=1, use_res=True, **kwargs):
+        super().__init__()
+        self.use_res = use_res
+        mid_channels = in_channels * expansion
+        self.convs = LocalAggregation([in_channels, in_channels, mid_channels, in_channels], norm_args=norm_args,
+                                      act_args=None, group_args=group_args, conv_args=conv_args, **aggr_args,
+                                      **kwargs)
+        self.act = create_act(act_args)
+
+    def forward(self, pf):
+        p, f = pf
+        identity = f
+        f = self.convs([p, f])
+        if f.shape[-1] == identity.shape[-1] and self.use_res:
+            f += identity
+        return [p, self.act(f)]
+
+
+# (channels, ball radius, nsample, number of InvResMLP blocks) after SA1..SA4 (drp.py:167-262)
+STAGE_SPECS = ((128, 0.08, 64, 3), (256, 0.2, 32, 6), (256, 0.4, 16, 3), (256, 0.6, 16, 3))
+
+
+class DRP(nn.Module):
+    def __init__(self, input_feature_dim=0):
+        super().__init__()
+        self.aggr_args = {'feature_type': 'dp_fj', "reduction": 'max'}
+        self.norm_args = {'norm': 'bn'}
+        self.act_args = {'act': 'relu'}
+        self.conv_args = {'order': 'conv-norm-act'}
+        self.use_res = True
+        self.expansion = 4
+        for level, (channels, radius, nsample, depth) in enumerate(STAGE_SPECS):
+            setattr(self, 'sa%d' % (level + 1), make_sa(level, input_feature_dim))
+            group_args = {'NAME': 'ballquery', 'radius': radius, 'nsample': nsample}
+            blocks = [InvResMLP(in_channels=channels, aggr_args=self.aggr_args, norm_args=self.norm_args,
+                                act_args=self.act_args, group_args=group_args, conv_args=self.conv_args,
+                                expansion=self.expansion, use_res=self.use_res) for _ in range(depth)]
+            setattr(self, 'InvResMLP_blocks%d' % (level + 1), nn.Sequential(*blocks))
+        self.fp1 = PointnetFPModule(mlp=[256 + 256, 256, 256])
+        self.fp2 = PointnetFPModule(mlp=[256 + 256, 256, 256])
+
+    def _break_up_pc(self, pc):
+        return break_up_pc(pc)
+
+    def forward(self, pointcloud: torch.Tensor, end_points=None):
+        if not end_points:
+            end_points = {}
+        xyz, features = break_up_pc(pointcloud)
+        end_points['input_xyz'] = xyz
+        end_points['input_features'] = features
+        for level in (1, 2, 3, 4):
+            xyz, features, fps_inds = getattr(self, 'sa%d' % level)(xyz, features)
+            xyz, features = getattr(self, 'InvResMLP_blocks%d' % level)([xyz, features])
+            if level <= 2:
+                end_points['sa%d_inds' % level] = fps_inds
+            end_points['sa%d_xyz' % level] = xyz
+            end_points['sa%d_features' % level] = features
+        features = self.fp1(end_points['sa3_xyz'], end_points['sa4_xyz'], end_points['sa3_features'],
+                            end_points['sa4_features'])
+        features = self.fp2(end_points['sa2_xyz'], end_points['sa3_xyz'], end_points['sa2_features'], features)
+        end_points['fp2_features'] = features
+        end_points['fp2_xyz'] = end_points['sa2_xyz']
+        num_seed = end_points['fp2_xyz'].shape[1]
+        end_points['fp2_inds'] = end_points['sa1_inds'][:, 0:num_seed]
+        return features, end_points['fp2_xyz'], end_points

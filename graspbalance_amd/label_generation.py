@@ -1,0 +1,101 @@
+"""Training-time label matching with the semantics of the reference's label_generation.py
+(process_grasp_labels :18-126, match_grasp_view_and_label :129-157): object-frame grasp labels are
+moved into the camera frame, template views are re-assigned by 1-NN, and every seed takes the labels
+of its nearest grasp point.  The two nearest-neighbour searches run on the HIP ``gb_knn1`` kernel
+(``knn_modules.myknn``, 1-based indices like KNN._C).
+"""
+import torch
+
+from .knn_modules import myknn
+from .loss_utils import (GRASP_MAX_WIDTH, batch_viewpoint_params_to_matrix, generate_grasp_views,
+                         transform_point_cloud)
+
+
+def _nearest(ref_points, query_points):
+    """Index (0-based) of the nearest row of ref_points (R,3) for each row of query_points (Q,3)."""
+    ref = ref_points.transpose(0, 1).contiguous().unsqueeze(0)
+    query = query_points.transpose(0, 1).contiguous().unsqueeze(0)
+    return myknn(ref, query, k=1).view(-1) - 1
+
+
+def process_grasp_labels(end_points):
+    seed_xyzs = end_points['fp2_xyz']  # (B,Ns,3)
+    batch_size, num_samples, _ = seed_xyzs.size()
+    per_cloud = {k: [] for k in ('point', 'view', 'view_rot', 'label', 'offset', 'tolerance')}
+    for i in range(len(end_points['input_xyz'])):
+        merged = {k: [] for k in per_cloud}
+        for obj_idx, pose in enumerate(end_points['object_poses_list'][i]):
+            grasp_points = end_points['grasp_points_list'][i][obj_idx]        # (Np,3)
+            grasp_labels = end_points['grasp_labels_list'][i][obj_idx]        # (Np,V,A,D)
+            grasp_offsets = end_points['grasp_offsets_list'][i][obj_idx]      # (Np,V,A,D,3)
+            grasp_tolerance = end_points['grasp_tolerance_list'][i][obj_idx]  # (Np,V,A,D)
+            _, V, A, D = grasp_labels.size()
+            num_grasp_points = grasp_points.size(0)
+            # template views and their rotations, moved by the object pose
+            grasp_views = generate_grasp_views(V).to(pose.device)
+            grasp_points_trans = transform_point_cloud(grasp_points, pose, '3x4')
+            grasp_views_trans = transform_point_cloud(grasp_views, pose[:3, :3], '3x3')
+            angles = torch.zeros(V, dtype=grasp_views.dtype, device=grasp_views.device)
+            grasp_views_rot = batch_viewpoint_params_to_matrix(-grasp_views, angles)
+            grasp_views_rot_trans = torch.matmul(pose[:3, :3], grasp_views_rot)
+            # each template view takes the labels of the nearest transformed view
+            view_inds = _nearest(grasp_views_trans, grasp_views)
+            merged['point'].append(grasp_points_trans)
+            merged['view'].append(torch.index_select(grasp_views_trans, 0, view_inds)
+                                  .unsqueeze(0).expand(num_grasp_points, -1, -1))
+            merged['view_rot'].append(torch.index_select(grasp_views_rot_trans, 0, view_inds)
+                                      .unsqueeze(0).expand(num_grasp_points, -1, -1, -1))
+            merged['label'].append(torch.index_select(grasp_labels, 1, view_inds))
+            merged['offset'].append(torch.index_select(grasp_offsets, 1, view_inds))
+            merged['tolerance'].append(torch.index_select(grasp_tolerance, 1, view_inds))
+        merged = {k: torch.cat(v, dim=0) for k, v in merged.items()}  # (Np', ...)
+        nn_inds = _nearest(merged['point'], seed_xyzs[i])  # (Ns,)
+        for k in per_cloud:
+            per_cloud[k].append(torch.index_select(merged[k], 0, nn_inds))
+    batch = {k: torch.stack(v, 0) for k, v in per_cloud.items()}
+    labels = batch['label']  # (B,Ns,V,A,D)
+    V, A, D = labels.shape[2:]
+    widths = batch['offset'][:, :, :, :, :, 2]
+    label_mask = (labels > 0) & (widths <= GRASP_MAX_WIDTH)
+    u_max = labels.max()
+    labels[label_mask] = torch.log(u_max / labels[label_mask])
+    labels[~label_mask] = 0
+    view_scores, _ = labels.view(batch_size, num_samples, V, A * D).max(dim=-1)
+    end_points['batch_grasp_point'] = batch['point']
+    end_points['batch_grasp_view'] = batch['view']
+    end_points['batch_grasp_view_rot'] = batch['view_rot']
+    end_points['batch_grasp_label'] = labels
+    end_points['batch_grasp_offset'] = batch['offset']
+    end_points['batch_grasp_tolerance'] = batch['tolerance']
+    end_points['batch_grasp_view_label'] = view_scores.float()
+    return end_points
+
+
+def _take_view(t, top_view_inds):
+    """t (B,Ns,V,...) -> (B,Ns,...) selecting view top_view_inds[b,s]."""
+    B, Ns = top_view_inds.shape
+    tail = t.shape[3:]
+    index = top_view_inds.view(B, Ns, 1, *([1] * len(tail))).expand(B, Ns, 1, *tail)
+    return torch.gather(t, 2, index).squeeze(2)
+
+
+def match_grasp_view_and_label(end_points):
+    top_view_inds = end_points['grasp_top_view_inds']       # (B,Ns)
+    template_views_rot = end_points['batch_grasp_view_rot']  # (B,Ns,V,3,3)
+    template_views = end_points['batch_grasp_view']          # (B,Ns,V,3)
+    grasp_labels = end_points['batch_grasp_label']           # (B,Ns,V,A,D)
+    grasp_offsets = end_points['batch_grasp_offset']         # (B,Ns,V,A,D,3)
+    grasp_tolerance = end_points['batch_grasp_tolerance']    # (B,Ns,V,A,D)
+    top_rot = _take_view(template_views_rot, top_view_inds)
+    top_labels = _take_view(grasp_labels, top_view_inds)
+    top_offsets = _take_view(grasp_offsets, top_view_inds)
+    top_tolerance = _take_view(grasp_tolerance, top_view_inds)
+    end_points['batch_grasp_view_rot'] = top_rot
+    end_points['batch_grasp_view'] = _take_view(template_views, top_view_inds)
+    end_points['batch_grasp_view_all'] = template_views
+    end_points['batch_grasp_label'] = top_labels
+    end_points['batch_grasp_label_all'] = grasp_labels
+    end_points['batch_grasp_offset'] = top_offsets
+    end_points['batch_grasp_offset_all'] = grasp_offsets
+    end_points['batch_grasp_tolerance'] = top_tolerance
+    return top_rot, top_labels, top_offsets, top_tolerance, end_points

@@ -1,0 +1,148 @@
+"""Training loss with the terms of the reference's TrainModel/loss.py (generate_reweight_mask :29,
+get_loss :44, compute_robust_graspable_loss :55, compute_weighted_view_loss :80,
+compute_weighted_grasp_loss :118): objectness CE + scale-reweighted view MSE + 0.2 x (score Huber +
+angle CE + width Huber + tolerance Huber).
+
+The reference loads its object-scale prior from ScaleDistribution/objects_scales.npy at import time
+and ``.cuda()``s it (loss.py:18-26); that data file is not part of this repo, so the prior is an
+argument: ``ScalePrior.uniform()`` (all weights 1, used with synthetic data) or ``ScalePrior.from_npy``.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .loss_utils import GRASP_MAX_TOLERANCE, GRASP_MAX_WIDTH, THRESH_BAD, THRESH_GOOD, huber_loss
+
+
+class ScalePrior:
+    """Per-width-bin loss weights ``1 - log(count / max count)`` over 32 bins of grasp width."""
+
+    def __init__(self, num, interval):
+        num = torch.as_tensor(np.asarray(num), dtype=torch.float32)
+        self.intervals = [float(v) for v in np.asarray(interval).tolist()]
+        self.weights = -(num / num.max()).log() + 1
+
+    @classmethod
+    def uniform(cls, bins=32, max_width=GRASP_MAX_WIDTH):
+        return cls(np.ones(bins), np.linspace(max_width / (bins + 1), max_width, bins + 1))
+
+    @classmethod
+    def from_npy(cls, path):
+        d = np.load(path, allow_pickle=True).item()
+        return cls(d['num'], d['interval'])
+
+    def lookup(self, widths):
+        idx = torch.zeros(widths.shape, dtype=torch.long, device=widths.device)
+        for b in range(len(self.intervals) - 1):
+            idx[(self.intervals[b] < widths) & (self.intervals[b + 1] > widths)] = b
+        return self.weights.to(widths.device)[idx]
+
+
+_DEFAULT_PRIOR = ScalePrior.uniform()
+
+
+def generate_reweight_mask(end_points, prior=None):
+    prior = prior or _DEFAULT_PRIOR
+    labels = end_points['batch_grasp_label_all']
+    B, Ns = labels.shape[:2]
+    widths = end_points['batch_grasp_offset_all'][:, :, :, :, :, 2].reshape(B, Ns, -1)
+    best = torch.argmax(labels.reshape(B, Ns, -1), dim=2, keepdim=True)
+    return prior.lookup(torch.gather(widths, 2, best).squeeze(2))
+
+
+def _seed_objectness(end_points):
+    return torch.gather(end_points['objectness_label'], 1, end_points['fp2_inds'].long())
+
+
+def _graspable_label(end_points, objectness_label):
+    labels = end_points['batch_grasp_label_all']
+    B, Ns, V = labels.shape[:3]
+    per_view = labels.view(B, Ns, V, -1).max(3)[0]
+    graspable_cnt = torch.sum((per_view > THRESH_BAD).long(), dim=2)
+    return (graspable_cnt > 10) * objectness_label
+
+
+def compute_robust_graspable_loss(end_points):
+    objectness_score = end_points['objectness_score']
+    graspable_label = _graspable_label(end_points, _seed_objectness(end_points))
+    end_points['graspable_mask'] = graspable_label
+    loss = nn.functional.cross_entropy(objectness_score, graspable_label, reduction='mean')
+    end_points['loss/stage1_graspable_loss'] = loss
+    pred = torch.argmax(objectness_score, 1)
+    correct = pred == graspable_label.long()
+    end_points['stage1_graspable_acc'] = correct.float().mean()
+    end_points['stage1_graspable_prec'] = correct[pred == 1].float().mean()
+    end_points['stage1_graspable_recall'] = correct[graspable_label == 1].float().mean()
+    return loss, end_points
+
+
+def compute_weighted_view_loss(end_points, weight_mask, width_weight_mask=None):
+    view_score = end_points['view_score']
+    view_label = end_points['batch_grasp_view_label']
+    V = view_label.size(2)
+    objectness_label = _seed_objectness(end_points)
+    graspable_label = _graspable_label(end_points, objectness_label) * objectness_label
+    objectness_mask = (graspable_label > 0).unsqueeze(-1).repeat(1, 1, V)
+    if width_weight_mask is not None:
+        weight_mask = weight_mask * width_weight_mask
+    loss_mask = objectness_mask.float() * weight_mask.unsqueeze(-1).repeat(1, 1, V)
+    loss = nn.functional.mse_loss(view_score, view_label, reduction='none')
+    loss = torch.sum(loss * loss_mask) / (loss_mask.sum() + 1e-6)
+    end_points['loss/stage1_view_loss'] = loss
+    end_points['stage1_pos_view_pred_count'] = ((view_score >= THRESH_GOOD) & objectness_mask).long().sum()
+    return loss, end_points
+
+
+def compute_weighted_grasp_loss(end_points, weight_mask):
+    objectness_mask = _seed_objectness(end_points).bool()
+    labels = end_points['batch_grasp_label']       # (B,Ns,A,D) of the top view
+    offsets = end_points['batch_grasp_offset']     # (B,Ns,A,D,3)
+    tolerance = end_points['batch_grasp_tolerance']
+    A = labels.size(2)
+    widths = offsets[:, :, :, :, 2]
+    best_angle = torch.argmax(labels, dim=2, keepdim=True)  # (B,Ns,1,D)
+    target_labels = torch.gather(labels, 2, best_angle).squeeze(2)
+    target_widths = torch.gather(widths, 2, best_angle).squeeze(2)
+    target_tolerance = torch.gather(tolerance, 2, best_angle).squeeze(2)
+    graspable_mask = target_labels > THRESH_BAD
+    loss_mask = (objectness_mask.unsqueeze(-1).expand_as(graspable_mask) & graspable_mask).float() \
+        * weight_mask.unsqueeze(-1).expand_as(graspable_mask)
+
+    def masked_mean(x, mask):
+        return torch.sum(x * mask) / (mask.sum() + 1e-6)
+
+    # 1. grasp score (every depth of a seed counts as soon as one depth is graspable)
+    depth_loss_mask = loss_mask.max(dim=2)[0].unsqueeze(-1).expand_as(loss_mask)
+    pick = best_angle.transpose(1, 2)  # (B,1,Ns,D)
+    grasp_score = torch.gather(end_points['grasp_score_pred'], 1, pick).squeeze(1)
+    grasp_score_loss = masked_mean(huber_loss(grasp_score - target_labels, delta=1.0), depth_loss_mask)
+    end_points['loss/stage2_grasp_score_loss'] = grasp_score_loss
+    # 2. in-plane rotation class
+    target_angles_cls = best_angle.squeeze(2)
+    angle_scores = end_points['grasp_angle_cls_pred']
+    angle_loss = masked_mean(nn.functional.cross_entropy(angle_scores, target_angles_cls, reduction='none'), loss_mask)
+    end_points['loss/stage2_grasp_angle_class_loss'] = angle_loss
+    angle_pred = torch.argmax(angle_scores, 1)
+    diff = torch.abs(angle_pred - target_angles_cls)
+    sel = loss_mask.bool()
+    end_points['stage2_grasp_angle_class_acc/0_degree'] = (angle_pred == target_angles_cls)[sel].float().mean()
+    end_points['stage2_grasp_angle_class_acc/15_degree'] = ((diff <= 1) | (diff >= A - 1))[sel].float().mean()
+    end_points['stage2_grasp_angle_class_acc/30_degree'] = ((diff <= 2) | (diff >= A - 2))[sel].float().mean()
+    # 3. width, 4. tolerance
+    width_pred = torch.gather(end_points['grasp_width_pred'], 1, pick).squeeze(1)
+    width_loss = masked_mean(huber_loss((width_pred - target_widths) / GRASP_MAX_WIDTH, delta=1), loss_mask)
+    end_points['loss/stage2_grasp_width_loss'] = width_loss
+    tol_pred = torch.gather(end_points['grasp_tolerance_pred'], 1, pick).squeeze(1)
+    tol_loss = masked_mean(huber_loss((tol_pred - target_tolerance) / GRASP_MAX_TOLERANCE, delta=1), loss_mask)
+    end_points['loss/stage2_grasp_tolerance_loss'] = tol_loss
+    return grasp_score_loss + angle_loss + width_loss + tol_loss, end_points
+
+
+def get_loss(end_points, prior=None):
+    reweight_mask = generate_reweight_mask(end_points, prior)
+    objectness_loss, end_points = compute_robust_graspable_loss(end_points)
+    view_loss, end_points = compute_weighted_view_loss(end_points, reweight_mask.clone())
+    grasp_loss, end_points = compute_weighted_grasp_loss(end_points, reweight_mask.clone())
+    loss = objectness_loss + view_loss + 0.2 * grasp_loss
+    end_points['loss/overall_loss'] = loss
+    return loss, end_points

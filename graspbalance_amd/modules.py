@@ -1,0 +1,164 @@
+"""Grasp heads and seed re-sampling with the names / parameters of the reference's
+TrainModel/modules.py (ForegroundSampling :19, GraspableDetection :49, GraspWidthGrouping :89,
+GraspPoseParametersDetection :127, ToleranceNet :155, ObjectBalanceSampling :178)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import pytorch_utils as pt_utils
+from .loss_utils import batch_viewpoint_params_to_matrix, generate_grasp_views
+from .pointnet2_utils import CylinderQueryAndGroup, furthest_point_sample
+
+
+def _resample_seeds(end_points, per_cloud_indices):
+    """Replace the FPS seeds by the given per-cloud index sets (list of (1024,) int64 tensors)."""
+    points = end_points['point_clouds']
+    features = end_points['up_sample_features'].permute(0, 2, 1)  # (B,N,256)
+    fp2_inds = torch.stack(per_cloud_indices, 0)
+    end_points['fp2_inds_fps'] = end_points['fp2_inds']
+    end_points['fp2_inds'] = fp2_inds.int()
+    end_points['fp2_xyz'] = torch.gather(points, 1, fp2_inds.unsqueeze(-1).expand(-1, -1, 3))
+    end_points['fp2_features'] = torch.gather(
+        features, 1, fp2_inds.unsqueeze(-1).expand(-1, -1, features.size(-1))).permute(0, 2, 1)
+    return end_points
+
+
+def _fps_within(points, mask_inds, count):
+    """FPS of `count` points among points[mask_inds]; returns indices into `points`."""
+    picked = furthest_point_sample(points[mask_inds].unsqueeze(0).contiguous(), count)[0].long()
+    return torch.gather(mask_inds, 0, picked)
+
+
+def ForegroundSampling(end_points):
+    """1024 seeds by FPS over the points labelled foreground (seed_cluster == 1)."""
+    seg = end_points["seed_cluster"]
+    picks = [_fps_within(end_points['point_clouds'][i], torch.where(seg[i] == 1)[0], 1024)
+             for i in range(seg.shape[0])]
+    return _resample_seeds(end_points, picks)
+
+
+def ObjectBalanceSampling(end_points):
+    """1024 seeds split evenly over the segmented objects (label 0 = background), FPS inside each."""
+    seg = end_points["seed_cluster"]
+    picks = []
+    for i in range(seg.shape[0]):
+        labels = [j for j in torch.unique(seg[i]) if j != 0]
+        share = [1024 // len(labels)] * len(labels)
+        share[-1] += 1024 % len(labels)
+        picks.append(torch.cat([_fps_within(end_points['point_clouds'][i], torch.where(seg[i] == j)[0], n)
+                                for j, n in zip(labels, share)], 0))
+    return _resample_seeds(end_points, picks)
+
+
+class GraspableDetection(nn.Module):
+    """Per-seed objectness (2) + approach-view scores (num_view); picks the top view's rotation."""
+
+    def __init__(self, num_view, seed_feature_dim):
+        super().__init__()
+        self.num_view = num_view
+        self.in_dim = seed_feature_dim
+        self.conv1 = nn.Conv1d(self.in_dim, self.in_dim, 1)
+        self.conv2 = nn.Conv1d(self.in_dim, 2 + self.num_view, 1)
+        self.conv3 = nn.Conv1d(2 + self.num_view, 2 + self.num_view, 1)
+        self.bn1 = nn.BatchNorm1d(self.in_dim)
+        self.bn2 = nn.BatchNorm1d(2 + self.num_view)
+
+    def forward(self, seed_xyz, seed_features, end_points, record=True):
+        B, num_seed, _ = seed_xyz.size()
+        features = F.relu(self.bn1(self.conv1(seed_features)), inplace=True)
+        features = F.relu(self.bn2(self.conv2(features)), inplace=True)
+        features = self.conv3(features)
+        if record == False:  # noqa: E712  (the reference tests equality with False)
+            return features
+        view_score = features[:, 2:2 + self.num_view, :].transpose(1, 2).contiguous()
+        end_points['objectness_score'] = features[:, :2, :]
+        end_points['view_score'] = view_score
+        top_view_scores, top_view_inds = torch.max(view_score, dim=2)
+        template_views = generate_grasp_views(self.num_view).to(features.device)  # (V,3)
+        vp_xyz = template_views[top_view_inds]  # (B,num_seed,3) == gather of the expanded templates
+        batch_angle = torch.zeros(B * num_seed, dtype=vp_xyz.dtype, device=vp_xyz.device)
+        vp_rot = batch_viewpoint_params_to_matrix(-vp_xyz.view(-1, 3), batch_angle).view(B, num_seed, 3, 3)
+        end_points['grasp_top_view_inds'] = top_view_inds
+        end_points['grasp_top_view_score'] = top_view_scores
+        end_points['grasp_top_view_xyz'] = vp_xyz
+        end_points['grasp_top_view_rot'] = vp_rot
+        return end_points
+
+
+class GraspWidthGrouping(nn.Module):
+    """Cylinder grouping at `len(hmax_list)` depths around every seed -> SharedMLP -> max over samples."""
+
+    def __init__(self, nsample, seed_feature_dim, cylinder_radius=0.05, hmin=-0.02,
+                 hmax_list=[0.01, 0.02, 0.03, 0.04]):
+        super().__init__()
+        self.nsample = nsample
+        self.in_dim = seed_feature_dim
+        self.cylinder_radius = cylinder_radius
+        self.hmin = hmin
+        self.hmax_list = list(hmax_list)
+        # a plain python list (not ModuleList) as in the reference: groupers add no state_dict keys
+        self.groupers = [CylinderQueryAndGroup(cylinder_radius, hmin, hmax, nsample, use_xyz=True)
+                         for hmax in hmax_list]
+        self.mlps = pt_utils.SharedMLP([self.in_dim, 64, 128, 256], bn=True)
+
+    def forward(self, seed_xyz, pointcloud, vp_rot, idx=None):
+        """idx: optional precomputed neighbour indices (num_depth,B,num_seed,nsample) from the fused
+        multi-query kernel; None runs one cylinder query per depth like the reference."""
+        B, num_seed, _, _ = vp_rot.size()
+        num_depth = len(self.groupers)
+        if idx is None:
+            grouped = [g(pointcloud, seed_xyz, vp_rot) for g in self.groupers]
+        else:
+            grouped = [g.group(pointcloud, seed_xyz, vp_rot, idx[d])[1] for d, g in enumerate(self.groupers)]
+        grouped_features = torch.stack(grouped, dim=3).view(B, -1, num_seed * num_depth, self.nsample)
+        vp_features = self.mlps(grouped_features)
+        vp_features = F.max_pool2d(vp_features, kernel_size=[1, vp_features.size(3)])
+        return vp_features.view(B, -1, num_seed, num_depth)
+
+
+class _DepthHead(nn.Module):
+    """Conv1d 256 -> 128 -> 128 -> out over the (seed, depth) grid."""
+
+    def __init__(self, out_channels):
+        super().__init__()
+        self.conv1 = nn.Conv1d(256, 128, 1)
+        self.conv2 = nn.Conv1d(128, 128, 1)
+        self.conv3 = nn.Conv1d(128, out_channels, 1)
+        self.bn1 = nn.BatchNorm1d(128)
+        self.bn2 = nn.BatchNorm1d(128)
+
+    def _run(self, vp_features):
+        B, _, num_seed, num_depth = vp_features.size()
+        x = vp_features.view(B, -1, num_seed * num_depth)
+        x = F.relu(self.bn1(self.conv1(x)), inplace=True)
+        x = F.relu(self.bn2(self.conv2(x)), inplace=True)
+        return self.conv3(x).view(B, -1, num_seed, num_depth)
+
+
+class GraspPoseParametersDetection(_DepthHead):
+    def __init__(self, num_angle, num_depth):
+        super().__init__(3 * num_angle)
+        self.num_angle = num_angle
+        self.num_depth = num_depth
+
+    def forward(self, vp_features, end_points, record=True):
+        out = self._run(vp_features)
+        if not record:
+            return out
+        A = self.num_angle
+        end_points['grasp_score_pred'] = out[:, 0:A]
+        end_points['grasp_angle_cls_pred'] = out[:, A:2 * A]
+        end_points['grasp_width_pred'] = out[:, 2 * A:3 * A]
+        return end_points
+
+
+class ToleranceNet(_DepthHead):
+    def __init__(self, num_angle, num_depth):
+        super().__init__(num_angle)
+
+    def forward(self, vp_features, end_points, record=True):
+        out = self._run(vp_features)
+        if not record:
+            return out
+        end_points['grasp_tolerance_pred'] = out
+        return end_points

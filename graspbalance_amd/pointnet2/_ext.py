@@ -49,8 +49,10 @@ def furthest_point_sampling(points, nsamples):
     output = torch.zeros((B, nsamples), dtype=torch.int32, device=points.device)
     tmp = torch.full((B, N), 1e10, dtype=torch.float32, device=points.device)
     with torch.cuda.device(points.device):
-        _lib.check(_lib.lib().gb_fps(_lib.ptr(points), _lib.ptr(tmp), _lib.ptr(output), B, N, nsamples,
-                                     FPS_FLAGS, _lib.current_stream(points.device)),
+        stream = _lib.current_stream(points.device)
+        _lib.check(_lib.timed("gb_fps", points.device, {"b": B, "n": N, "m": nsamples},
+                              lambda: _lib.lib().gb_fps(_lib.ptr(points), _lib.ptr(tmp), _lib.ptr(output), B, N,
+                                                        nsamples, FPS_FLAGS, stream)),
                    "furthest_point_sampling")
     return output
 

@@ -1,0 +1,50 @@
+"""Training harness with the loop semantics of the reference's train.py (Adam :94, OneCycleLR
+:107-108, BN-momentum schedule :110-113, per-batch body :138-155) on the GraspBalance model, plus the
+RCCL data-parallel gradient reduction.  (The reference script itself cannot run as shipped: it imports
+the absent ``graspnet.GraspNet_MSCQ`` and dataset class names that do not exist — SURVEY.md §0.)
+"""
+import torch
+import torch.optim as optim
+from torch.optim.lr_scheduler import OneCycleLR
+
+from .data_parallel import FlatGradAllReduce, broadcast_module
+from .graspbalance import GraspBalance
+from .loss import get_loss
+from .pytorch_utils import BNMomentumScheduler
+
+BN_MOMENTUM_INIT = 0.5
+BN_MOMENTUM_MAX = 0.001
+
+
+class Trainer:
+    def __init__(self, device, learning_rate=0.001, weight_decay=0.0, bn_decay_step=2, bn_decay_rate=0.5,
+                 steps_per_epoch=100, max_epoch=18, num_view=300, seed=1234, distributed=False,
+                 bucket_mb=16.0, model=None):
+        torch.manual_seed(seed)
+        self.device = torch.device(device)
+        self.net = model if model is not None else GraspBalance(
+            input_feature_dim=0, num_view=num_view, num_angle=12, num_depth=4, cylinder_radius=0.08,
+            hmin=-0.02, hmax_list=[0.01, 0.02, 0.03, 0.04])
+        self.net.to(self.device)
+        if distributed:
+            broadcast_module(self.net)
+        self.optimizer = optim.Adam(self.net.parameters(), lr=learning_rate, weight_decay=weight_decay)
+        self.scheduler = OneCycleLR(self.optimizer, max_lr=learning_rate, steps_per_epoch=steps_per_epoch,
+                                    epochs=max_epoch)
+        bn_lbmd = lambda it: max(BN_MOMENTUM_INIT * bn_decay_rate ** (int(it / bn_decay_step)), BN_MOMENTUM_MAX)
+        self.bnm_scheduler = BNMomentumScheduler(self.net, bn_lambda=bn_lbmd, last_epoch=-1)
+        self.grads = FlatGradAllReduce(self.net, bucket_mb=bucket_mb)
+        self.bnm_scheduler.step()
+        self.net.train()
+
+    def train_step(self, batch):
+        """forward -> loss -> backward -> gradient all-reduce -> Adam step -> LR step.  Returns the
+        loss tensor (no host sync here; the reference's per-key .item() logging is the caller's)."""
+        end_points = self.net(dict(batch))  # the network adds its outputs to the dict it is given
+        loss, end_points = get_loss(end_points)
+        loss.backward()
+        self.grads.reduce()
+        self.optimizer.step()
+        self.grads.zero_grad()  # optimizer.zero_grad() would drop the flat-bucket views
+        self.scheduler.step()
+        return loss

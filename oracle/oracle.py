@@ -181,3 +181,58 @@ class ExtBackend:
     three_nn = staticmethod(lambda u, k: list(three_nn(u, k)))
     three_interpolate = staticmethod(three_interpolate)
     three_interpolate_grad = staticmethod(three_interpolate_grad)
+
+
+class PBBackend:
+    """The 9-function surface of ``pointnet2_batch_cuda`` (caller-allocated outputs) on the oracle."""
+
+    fps_flags = FPS_TIE_TREE1024
+
+    @staticmethod
+    def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
+        idx.copy_(ball_query(new_xyz, xyz, radius, nsample))
+        return 1
+
+    @staticmethod
+    def group_points_wrapper(b, c, n, npoints, nsample, points, idx, out):
+        out.copy_(group_points(points, idx))
+        return 1
+
+    @staticmethod
+    def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_points):
+        grad_points.add_(group_points_grad(grad_out, idx, n))
+        return 1
+
+    @staticmethod
+    def gather_points_wrapper(b, c, n, npoints, points, idx, out):
+        out.copy_(gather_points(points, idx))
+        return 1
+
+    @staticmethod
+    def gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points):
+        grad_points.add_(gather_points_grad(grad_out, idx, n))
+        return 1
+
+    def furthest_point_sampling_wrapper(self, b, n, m, points, temp, idx):
+        idx.copy_(furthest_point_sampling(points, m, self.fps_flags, temp=temp))
+        return 1
+
+    @staticmethod
+    def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
+        d, i = three_nn(unknown, known)
+        dist2.copy_(d)
+        idx.copy_(i)
+
+    @staticmethod
+    def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):
+        out.copy_(three_interpolate(points, idx, weight))
+
+    @staticmethod
+    def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_points):
+        grad_points.add_(three_interpolate_grad(grad_out, idx, weight, m))
+
+
+def knn_into(ref, query, idx):
+    """KNN._C.knn signature (writes 1-based int64 indices into idx)."""
+    idx.copy_(knn1(ref, query))
+    return 1

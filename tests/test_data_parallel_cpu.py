@@ -1,0 +1,77 @@
+"""world_size-2 gloo rehearsal of the RCCL data-parallel path (graspbalance_amd/data_parallel.py):
+flat-bucket gradient all-reduce == mean of the per-rank gradients, replicas stay identical after the
+optimizer step, BatchNorm statistics stay per rank, nested ``*_list`` labels are sharded by item."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import cpu_backend
+    from tests.test_model_cpu import _tiny_batch, _tiny_net
+    from graspbalance_amd.data_parallel import FlatGradAllReduce, broadcast_module, shard_batch
+    from graspbalance_amd.loss import get_loss
+    cpu_backend.install()
+    net = _tiny_net()
+    if rank == 1:  # de-synchronise on purpose: broadcast must repair it
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(1.0)
+    broadcast_module(net)
+    net.train()
+    full = _tiny_batch(B=2)
+    mine = shard_batch(full, rank, world)
+    assert mine['point_clouds'].shape[0] == 1 and len(mine['grasp_points_list']) == 1
+    grads = FlatGradAllReduce(net, bucket_mb=0.5)
+    assert len(grads.buckets) > 1
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    loss, _ = get_loss(net(mine))
+    loss.backward()
+    local = [p.grad.clone() for p in net.parameters()]
+    grads.reduce()
+    reduced = [p.grad.clone() for p in net.parameters()]
+    opt.step()
+    torch.save({"local": local, "reduced": reduced, "params": [p.detach().clone() for p in net.parameters()],
+                "bn_mean": net.view_estimator.FeatureExtraction.sa1.mlp_module.layer0.bn.bn.running_mean.clone()},
+               os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_flat_bucket_allreduce_world2(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "rank1.pt"))
+    for a, b, m0, m1 in zip(r0["local"], r1["local"], r0["reduced"], r1["reduced"]):
+        assert torch.equal(m0, m1)  # every rank holds the same reduced gradient
+        assert torch.allclose(m0, (a + b) / 2, rtol=1e-6, atol=1e-8)
+    assert any(not torch.equal(a, b) for a, b in zip(r0["local"], r1["local"]))  # shards really differ
+    for p0, p1 in zip(r0["params"], r1["params"]):
+        assert torch.equal(p0, p1)  # replicas identical after the step
+    assert not torch.equal(r0["bn_mean"], r1["bn_mean"])  # BatchNorm statistics are per rank (no SyncBN)
+
+
+def test_shard_batch_chunks_like_list_scatter():
+    from graspbalance_amd.data_parallel import shard_batch
+    batch = {"point_clouds": torch.arange(5).view(5, 1), "grasp_points_list": [[i] for i in range(5)]}
+    sizes = [len(shard_batch(batch, r, 2)["grasp_points_list"]) for r in range(2)]
+    assert sizes == [3, 2]  # chunk = ceil(5/2), the reference's list_scatter rule (data_parallel.py:31)
+    assert shard_batch(batch, 1, 2)["point_clouds"].flatten().tolist() == [3, 4]

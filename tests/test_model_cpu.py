@@ -1,0 +1,139 @@
+"""Model-level host logic on CPU (oracle-backed extension hooks): parameter inventory pinned by the
+reference (tests/golden/manifest.json G7), forward/backward at reduced size."""
+import numpy as np
+import pytest
+import torch
+
+from graspbalance_amd.synthetic import make_training_batch
+
+
+@pytest.fixture()
+def cpu(monkeypatch):
+    from tests import cpu_backend
+    cpu_backend.install(monkeypatch)
+
+
+def _count(m):
+    return sum(p.numel() for p in m.parameters())
+
+
+def test_parameter_inventory_matches_reference(golden):
+    from graspbalance_amd.backbone import Pointnet2Backbone
+    from graspbalance_amd.drp import DRP, InvResMLP
+    from graspbalance_amd.graspbalance import GraspBalance
+    from graspbalance_amd import modules
+    g7 = golden.manifest["G7"]
+    built = {"Pointnet2Backbone": Pointnet2Backbone(),
+             "GraspableDetection": modules.GraspableDetection(300, 256),
+             "GraspWidthGrouping": modules.GraspWidthGrouping(64, 3, 0.08, -0.02, [0.01, 0.02, 0.03, 0.04]),
+             "GraspPoseParametersDetection": modules.GraspPoseParametersDetection(12, 4),
+             "ToleranceNet": modules.ToleranceNet(12, 4)}
+    for name, mod in built.items():
+        assert _count(mod) == g7[name]["num_params"], name
+        assert {k: list(v.shape) for k, v in mod.state_dict().items()} == g7[name]["state_dict"], name
+    # numbers the survey verified by instantiating the reference classes
+    assert _count(Pointnet2Backbone()) == 641856
+    drp = DRP()
+    assert _count(drp) == 8213952 == 641856 + 3 * 149376 + 12 * 593664
+    blk = InvResMLP(128, norm_args={'norm': 'bn'}, act_args={'act': 'relu'},
+                    group_args={'NAME': 'ballquery', 'radius': 0.08, 'nsample': 64},
+                    conv_args={'order': 'conv-norm-act'}, expansion=4)
+    assert _count(blk) == 149376
+    net = GraspBalance()
+    sd = net.state_dict()
+    assert _count(net) == 9052396
+    assert len(list(net.parameters())) == 253 and len(sd) == 490
+    for key, shape in [("view_estimator.FeatureExtraction.sa1.mlp_module.layer0.conv.weight", (64, 3, 1, 1)),
+                       ("view_estimator.FeatureExtraction.sa1.mlp_module.layer0.bn.bn.running_mean", (64,)),
+                       ("view_estimator.FeatureExtraction.InvResMLP_blocks1.2.pwconv.0.0.weight", (512, 128, 1)),
+                       ("view_estimator.FeatureExtraction.InvResMLP_blocks2.5.convs.convs.0.0.weight", (256, 259, 1, 1)),
+                       ("grasp_generator.fuse_multi_scale.weight", (256, 1024, 1)),
+                       ("grasp_generator.gate_fusion.0.weight", (256, 256, 1)),
+                       ("grasp_generator.WidthGroup3.mlps.layer2.conv.weight", (256, 128, 1, 1)),
+                       ("view_estimator.GraspableClasification.conv2.weight", (302, 256, 1))]:
+        assert tuple(sd[key].shape) == shape, key
+
+
+def test_views_match_reference(golden):
+    from graspbalance_amd import loss_utils
+    g = golden.load("g9_views")
+    views = loss_utils.generate_grasp_views(300)
+    assert np.array_equal(views.numpy(), g["views"])
+    rot = loss_utils.batch_viewpoint_params_to_matrix(-views, torch.zeros(300))
+    np.testing.assert_allclose(rot.numpy(), g["rot"], rtol=0, atol=1e-7)
+    rot2 = loss_utils.batch_viewpoint_params_to_matrix(views, torch.linspace(0, 3.0, 300))
+    np.testing.assert_allclose(rot2.numpy(), g["rot_ang"], rtol=0, atol=1e-6)
+
+
+class TinyGraspBalance(torch.nn.Module):
+    """GraspBalance wiring at toy sizes (few points / seeds / views) so a CPU step takes seconds."""
+
+
+def _tiny_batch(B=2, N=1500, objects=2, Np=20, V=30):
+    return make_training_batch(range(B), num_point=N, num_objects=objects, grasp_points_per_object=Np, num_view=V)
+
+
+def _tiny_net(V=30, training=True):
+    """The real GraspBalance class with shrunken SA levels (npoint 1024 would exceed a toy cloud)."""
+    from graspbalance_amd import backbone, graspbalance
+    saved = backbone.SA_SPECS
+    backbone.SA_SPECS = ((256, 0.08, 16, (None, 16, 16, 128)), (128, 0.15, 8, (128, 32, 32, 256)),
+                         (64, 0.3, 8, (256, 32, 32, 256)), (32, 0.5, 8, (256, 32, 32, 256)))
+    try:
+        torch.manual_seed(0)
+        net = graspbalance.GraspBalance(num_view=V, is_training=training)
+    finally:
+        backbone.SA_SPECS = saved
+    return net
+
+
+def test_training_forward_backward_and_loss(cpu):
+    from graspbalance_amd.loss import get_loss
+    net = _tiny_net()
+    net.train()
+    batch = _tiny_batch()
+    end_points = net(batch)
+    B, Ns = 2, 128
+    assert end_points['objectness_score'].shape == (B, 2, Ns)
+    assert end_points['view_score'].shape == (B, Ns, 30)
+    assert end_points['grasp_score_pred'].shape == (B, 12, Ns, 4)
+    assert end_points['grasp_tolerance_pred'].shape == (B, 12, Ns, 4)
+    assert end_points['batch_grasp_label'].shape == (B, Ns, 12, 4)
+    assert end_points['batch_grasp_offset_all'].shape == (B, Ns, 30, 12, 4, 3)
+    loss, end_points = get_loss(end_points)
+    assert bool(torch.isfinite(loss))
+    loss.backward()
+    missing = [n for n, p in net.named_parameters() if p.grad is None]
+    assert not missing, missing
+    assert all(bool(torch.isfinite(p.grad).all()) for p in net.parameters())
+
+
+def test_eval_forward_fused_equals_separate_cylinder_queries_and_decode(cpu):
+    from graspbalance_amd.graspbalance import pred_decode
+    net = _tiny_net(training=False)
+    net.eval()
+    batch = {'point_clouds': _tiny_batch()['point_clouds']}
+    with torch.no_grad():
+        a = net(dict(batch))
+        net.grasp_generator.fused_cylinder = False
+        b = net(dict(batch))
+    for k in ('grasp_score_pred', 'grasp_width_pred', 'grasp_tolerance_pred', 'objectness_score'):
+        assert torch.equal(a[k], b[k]), k
+    preds = pred_decode(a)
+    assert len(preds) == 2 and all(p.shape[1] == 17 for p in preds)
+
+
+def test_label_matching_against_bruteforce(cpu):
+    from graspbalance_amd.label_generation import process_grasp_labels
+    from graspbalance_amd.loss_utils import transform_point_cloud
+    batch = _tiny_batch(B=1, N=800, objects=2, Np=10, V=12)
+    ep = dict(batch)
+    ep['input_xyz'] = batch['point_clouds']
+    ep['fp2_xyz'] = batch['point_clouds'][:, :50].contiguous()
+    out = process_grasp_labels(ep)
+    pts = torch.cat([transform_point_cloud(batch['grasp_points_list'][0][k], batch['object_poses_list'][0][k], '3x4')
+                     for k in range(2)], 0)
+    nn = torch.cdist(ep['fp2_xyz'][0], pts).argmin(1)
+    assert torch.allclose(out['batch_grasp_point'][0], pts[nn])
+    assert out['batch_grasp_view_label'].shape == (1, 50, 12)
+    assert float(out['batch_grasp_label'].min()) >= 0.0

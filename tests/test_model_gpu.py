@@ -1,0 +1,79 @@
+"""GPU: the whole network on the HIP path against the same network on the CPU oracle path (same
+weights, same inputs): indices bit-exact, head outputs within 1e-4 (fp32 conv/BN on different BLAS
+back ends; the geometry feeding them is bit-identical)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _nets():
+    from tests.test_model_cpu import _tiny_net
+    cpu_net = _tiny_net(training=False)
+    gpu_net = _tiny_net(training=False)
+    gpu_net.load_state_dict(cpu_net.state_dict())
+    return cpu_net.eval(), gpu_net.to(DEV).eval()
+
+
+def test_eval_forward_matches_cpu_oracle_path(monkeypatch):
+    from tests.test_model_cpu import _tiny_batch
+    from tests import cpu_backend
+    cpu_net, gpu_net = _nets()
+    clouds = _tiny_batch(B=2, N=3000)['point_clouds']
+    with torch.no_grad():
+        got = gpu_net({'point_clouds': clouds.to(DEV)})
+        got_sep = None
+        gpu_net.grasp_generator.fused_cylinder = False
+        got_sep = gpu_net({'point_clouds': clouds.to(DEV)})
+    with monkeypatch.context() as mp:
+        cpu_backend.install(mp)
+        with torch.no_grad():
+            want = cpu_net({'point_clouds': clouds})
+    for k in ('sa1_inds', 'sa2_inds', 'fp2_inds', 'grasp_top_view_inds'):
+        assert torch.equal(got[k].cpu(), want[k]), k
+    for k in ('sa1_xyz', 'sa4_xyz', 'fp2_xyz'):
+        assert torch.equal(got[k].cpu(), want[k]), k
+    for k in ('fp2_features', 'objectness_score', 'view_score', 'grasp_score_pred', 'grasp_angle_cls_pred',
+              'grasp_width_pred', 'grasp_tolerance_pred'):
+        err = float((got[k].cpu() - want[k]).abs().max())
+        assert err < 1e-4, (k, err)
+        assert torch.equal(got[k], got_sep[k]), k  # fused 16-query kernel == 16 separate queries
+
+
+def test_train_step_runs_and_updates(monkeypatch):
+    from tests.test_model_cpu import _tiny_net
+    from graspbalance_amd.synthetic import make_training_batch
+    from graspbalance_amd.train import Trainer
+    net = _tiny_net()
+    trainer = Trainer(DEV, num_view=30, model=net, steps_per_epoch=10, max_epoch=2)
+    batch = make_training_batch(range(2), num_point=3000, num_objects=2, grasp_points_per_object=20, num_view=30,
+                                device=DEV)
+    before = [p.detach().clone() for p in trainer.net.parameters()]
+    losses = [float(trainer.train_step(batch)) for _ in range(3)]
+    assert all(l == l for l in losses)
+    changed = sum(int(not torch.equal(a, b)) for a, b in zip(before, trainer.net.parameters()))
+    assert changed > 200
+
+
+def test_full_size_forward_properties():
+    """Config 3 shapes (B=2 here): full-size GraspBalance eval forward; size-independent checks."""
+    from graspbalance_amd.graspbalance import GraspBalance, pred_decode
+    from graspbalance_amd.scene import make_batch
+    torch.manual_seed(1234)
+    net = GraspBalance(is_training=False).to(DEV).eval()
+    clouds = torch.from_numpy(make_batch([0, 1], 20000)).to(DEV)
+    with torch.no_grad():
+        out = net({'point_clouds': clouds})
+    assert out['fp2_features'].shape == (2, 256, 1024)
+    assert out['grasp_score_pred'].shape == (2, 12, 1024, 4) and out['view_score'].shape == (2, 1024, 300)
+    assert torch.equal(out['fp2_inds'], out['sa1_inds'][:, :1024])
+    # FPS prefix property: seeds are the first 1024 FPS picks of the input cloud
+    assert torch.equal(out['fp2_xyz'], torch.gather(clouds, 1, out['fp2_inds'].long()[:, :, None].expand(-1, -1, 3)))
+    for k in ('grasp_score_pred', 'grasp_width_pred', 'grasp_tolerance_pred', 'objectness_score'):
+        assert bool(torch.isfinite(out[k]).all())
+    rot = out['grasp_top_view_rot']
+    eye = torch.matmul(rot, rot.transpose(-1, -2))
+    assert float((eye - torch.eye(3, device=DEV)).abs().max()) < 1e-5  # rotations stay orthonormal
+    preds = pred_decode(out)
+    assert len(preds) == 2 and preds[0].shape[1] == 17

@@ -18,10 +18,24 @@ def _nearest(ref_points, query_points):
     return myknn(ref, query, k=1).view(-1) - 1
 
 
+def _assign_views(poses, V):
+    """For every object pose (K,3,4): index of the transformed template view nearest to each template
+    view, (K,V) — the reference's per-object 300x300 kNN (label_generation.py:56-58), as ONE batched
+    launch over all objects of the batch."""
+    views = generate_grasp_views(V).to(poses.device)                     # (V,3)
+    trans = torch.matmul(poses[:, :3, :3], views.T)                      # (K,3,V) == (R v)^T per object
+    query = views.T.contiguous().unsqueeze(0).expand(poses.size(0), -1, -1).contiguous()
+    return myknn(trans.contiguous(), query, k=1).view(poses.size(0), V) - 1
+
+
 def process_grasp_labels(end_points):
     seed_xyzs = end_points['fp2_xyz']  # (B,Ns,3)
     batch_size, num_samples, _ = seed_xyzs.size()
     per_cloud = {k: [] for k in ('point', 'view', 'view_rot', 'label', 'offset', 'tolerance')}
+    all_poses = torch.stack([p for poses in end_points['object_poses_list'] for p in poses], 0)
+    V_all = end_points['grasp_labels_list'][0][0].size(1)
+    all_view_inds = _assign_views(all_poses, V_all)
+    flat_obj = 0
     for i in range(len(end_points['input_xyz'])):
         merged = {k: [] for k in per_cloud}
         for obj_idx, pose in enumerate(end_points['object_poses_list'][i]):
@@ -39,7 +53,8 @@ def process_grasp_labels(end_points):
             grasp_views_rot = batch_viewpoint_params_to_matrix(-grasp_views, angles)
             grasp_views_rot_trans = torch.matmul(pose[:3, :3], grasp_views_rot)
             # each template view takes the labels of the nearest transformed view
-            view_inds = _nearest(grasp_views_trans, grasp_views)
+            view_inds = all_view_inds[flat_obj]
+            flat_obj += 1
             merged['point'].append(grasp_points_trans)
             merged['view'].append(torch.index_select(grasp_views_trans, 0, view_inds)
                                   .unsqueeze(0).expand(num_grasp_points, -1, -1))

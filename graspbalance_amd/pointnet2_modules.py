@@ -29,7 +29,9 @@ def _sample_centres(xyz, npoint, inds=None):
 
 
 def _max_over_samples(x):
-    return F.max_pool2d(x, kernel_size=[1, x.size(3)])
+    """(B,C,npoint,nsample) -> (B,C,npoint,1): F.max_pool2d(kernel=[1,nsample]) of the reference; the
+    dim-reduction kernel is ~10x faster than the NCHW pooling kernel on ROCm and gives the same values."""
+    return torch.max(x, dim=3, keepdim=True)[0]
 
 
 def _pool(features, grouped_xyz, pooling, sigma, nsample):

@@ -21,7 +21,7 @@ FPS_TIE_TREE512 = 0x10
 FPS_TIE_TREE1024 = 0x20
 
 _c = ctypes
-_P, _I, _F, _U = _c.c_void_p, _c.c_int, _c.c_float, _c.c_uint
+_P, _I, _F, _U, _L = _c.c_void_p, _c.c_int, _c.c_float, _c.c_uint, _c.c_longlong
 
 # name -> argtypes; every function returns int.  Kept in one table so tests can check that the
 # shared object exports exactly what include/graspbal.h declares.
@@ -38,6 +38,16 @@ SIGNATURES = {
     "gb_three_interpolate": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gb_three_interpolate_grad": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gb_knn1": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "gb_group_concat_cl": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
+    "gb_group_concat_cl_grad": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "gb_col_stats": [_P, _L, _I, _P, _P],
+    "gb_bn_finalize": [_P, _L, _I, _P, _P, _F, _F, _P, _P, _P, _I, _P],
+    "gb_affine_act": [_P, _P, _P, _P, _L, _I, _I, _P],
+    "gb_affine_relu_maxpool": [_P, _P, _P, _P, _L, _I, _I, _P],
+    "gb_bn_bwd_stats": [_P, _P, _P, _P, _L, _I, _I, _P, _P],
+    "gb_bn_bwd_apply": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P],
+    "gb_bn_bwd_stats_pool": [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P],
+    "gb_bn_bwd_apply_pool": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P],
 }
 
 

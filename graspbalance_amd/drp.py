@@ -11,7 +11,8 @@ import torch.nn as nn
 from .backbone import break_up_pc, make_sa
 from .modified_net_tools.activation import CHANNEL_MAP, create_act
 from .modified_net_tools.conv import create_convblock1d, create_convblock2d
-from .modified_net_tools.group import create_grouper, get_aggregation_feautres
+from . import fused_mlp
+from .modified_net_tools.group import QueryAndGroup, ball_query, create_grouper, get_aggregation_feautres
 from .pointnet2_modules import PointnetFPModule
 
 
@@ -81,13 +82,65 @@ class InvResMLP(nn.Module):
         self.pwconv = _pointwise(channels, norm_args, act_args, conv_args, less_act)
         self.act = create_act(act_args)
 
+    def fusable(self):
+        """The configuration DRP builds: dp_fj features, max reduction, plain ball-query grouper,
+        one conv+BN+ReLU aggregation layer, conv+BN+ReLU -> conv+BN pointwise pair, residual, ReLU."""
+        la = self.convs
+        g = la.grouper
+        def is_block(seq, with_act):
+            mods = list(seq.children())
+            want = 3 if with_act else 2
+            return (len(mods) == want and isinstance(mods[0], (nn.Conv1d, nn.Conv2d)) and mods[0].bias is None
+                    and isinstance(mods[1], (nn.BatchNorm1d, nn.BatchNorm2d))
+                    and (not with_act or isinstance(mods[2], nn.ReLU)))
+        return (la.feature_type == 'dp_fj' and la.reduction == 'max' and isinstance(g, QueryAndGroup)
+                and g.relative_xyz and not g.normalize_dp and not g.return_only_idx
+                and len(la.convs) == 1 and is_block(la.convs[0], True) and len(self.pwconv) == 2
+                and is_block(self.pwconv[0], True) and is_block(self.pwconv[1], False) and self.use_res
+                and isinstance(self.act, nn.ReLU))
+
+    def forward_cl(self, p, f_cl, idx=None):
+        """Channel-last execution: f_cl (B,N,C) -> (B,N,C).  `idx` (B,N,ns) may be shared by all blocks
+        of a stage (same points, same radius)."""
+        B, N, C = f_cl.shape
+        g = self.convs.grouper
+        if idx is None:
+            idx = ball_query(g.radius, g.nsample, p, p)
+        x0 = fused_mlp.group_concat_cl(p, p, idx, f_cl, mode=0)               # [dp, fj] rows
+        agg_conv, agg_bn = self.convs.convs[0][0], self.convs.convs[0][1]
+        agg = fused_mlp.conv_bn_act(x0, agg_conv, agg_bn, relu=True, pool_ns=g.nsample)   # (B*N, C)
+        h = fused_mlp.conv_bn_act(agg, self.pwconv[0][0], self.pwconv[0][1], relu=True)   # (B*N, 4C)
+        out = fused_mlp.conv_bn_act(h, self.pwconv[1][0], self.pwconv[1][1], relu=True,
+                                    residual=f_cl.reshape(B * N, C))                       # act(bn(.) + identity)
+        return out.view(B, N, C)
+
     def forward(self, pf):
         p, f = pf
+        if fused_mlp.enabled(f) and self.fusable():
+            out = self.forward_cl(p, f.transpose(1, 2).contiguous())
+            return [p, out.transpose(1, 2).contiguous()]
         identity = f
         f = self.pwconv(self.convs([p, f]))
         if f.shape[-1] == identity.shape[-1] and self.use_res:
             f += identity
         return [p, self.act(f)]
+
+
+def run_stage(blocks, p, f):
+    """A Sequential of InvResMLP blocks over the same points: on the fused path the features stay
+    channel-last across the blocks and the ball query (same p, same radius) is done once."""
+    blocks = list(blocks)
+    if not (fused_mlp.enabled(f) and blocks and all(isinstance(b, InvResMLP) and b.fusable() for b in blocks)):
+        for blk in blocks:
+            p, f = blk([p, f])
+        return p, f
+    g0 = blocks[0].convs.grouper
+    same = all(b.convs.grouper.radius == g0.radius and b.convs.grouper.nsample == g0.nsample for b in blocks)
+    idx = ball_query(g0.radius, g0.nsample, p, p) if same else None
+    f_cl = f.transpose(1, 2).contiguous()
+    for blk in blocks:
+        f_cl = blk.forward_cl(p, f_cl, idx)
+    return p, f_cl.transpose(1, 2).contiguous()
 
 
 class ResBlock(nn.Module):
@@ -145,7 +198,7 @@ class DRP(nn.Module):
         end_points['input_features'] = features
         for level in (1, 2, 3, 4):
             xyz, features, fps_inds = getattr(self, 'sa%d' % level)(xyz, features)
-            xyz, features = getattr(self, 'InvResMLP_blocks%d' % level)([xyz, features])
+            xyz, features = run_stage(getattr(self, 'InvResMLP_blocks%d' % level), xyz, features)
             if level <= 2:
                 end_points['sa%d_inds' % level] = fps_inds
             end_points['sa%d_xyz' % level] = xyz

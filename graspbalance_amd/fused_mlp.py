@@ -1,0 +1,176 @@
+"""Channel-last fused execution of the SharedMLP stacks (1x1 conv + BatchNorm + ReLU [+ max over
+nsample]) that the reference runs as separate torch passes over (B,C,m,ns) tensors
+(pytorch_utils.py:5-182, pointnet2_modules.py:148-188, drp.py:62-117, modules.py:104-124).
+
+Activations are rows ``act[p, c]`` with ``p = (b*m + j)*nsample + k``.  One layer =
+GEMM (P,Cin)x(Cin,Cout) -> column statistics -> (affine + ReLU [+ max over ns]) in one pass;
+backward = two column reductions + one apply pass + two GEMMs.  The element-wise / reduction
+passes are the HIP kernels of csrc/mlp_cl.hip; the GEMMs are ``torch.mm`` here (rocBLAS fp32 MFMA).
+The modules keep the reference's parameters (conv weight (Cout,Cin,1,1), BatchNorm affine + running
+statistics), so state_dicts are unchanged; results equal the unfused path to fp32 rounding.
+
+``enabled()`` is False on CPU tensors: the python layers then run their plain torch composition
+(which only works with an extension bound for CPU, i.e. in the tests).
+"""
+import torch
+from torch.autograd import Function
+
+from . import _lib
+
+_ENABLED = True
+
+
+def set_enabled(flag):
+    global _ENABLED
+    _ENABLED = bool(flag)
+
+
+def enabled(t):
+    return _ENABLED and t.is_cuda
+
+
+def _s(t):
+    return _lib.current_stream(t.device)
+
+
+def _call(name, dev, *args):
+    with torch.cuda.device(dev):
+        _lib.check(getattr(_lib.lib(), name)(*args), name)
+
+
+class GroupConcatCL(Function):
+    """(xyz (B,N,3), new_xyz (B,m,3), idx (B,m,ns), feat_cl (B,N,C)|None) -> X0 (B*m*ns, 3+C)."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, idx, feat_cl, mode, scale, rot):
+        B, N, _ = xyz.shape
+        m, ns = idx.shape[1], idx.shape[2]
+        C = 0 if feat_cl is None else feat_cl.shape[2]
+        out = torch.empty((B * m * ns, 3 + C), dtype=torch.float32, device=xyz.device)
+        rot9 = rot.reshape(B, m, 9).contiguous() if rot is not None else None
+        _call("gb_group_concat_cl", xyz.device, _lib.ptr(xyz), _lib.ptr(new_xyz), _lib.ptr(idx),
+              _lib.ptr(feat_cl), _lib.ptr(rot9), _lib.ptr(out), B, N, m, ns, C, int(mode), float(scale), _s(xyz))
+        ctx.dims = (B, N, m, ns, C)
+        ctx.save_for_backward(idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, dx0):
+        B, N, m, ns, C = ctx.dims
+        dfeat = None
+        if C > 0 and ctx.needs_input_grad[3]:
+            (idx,) = ctx.saved_tensors
+            dx0 = dx0.contiguous()
+            dfeat = torch.zeros((B, N, C), dtype=torch.float32, device=dx0.device)
+            _call("gb_group_concat_cl_grad", dx0.device, _lib.ptr(dx0), _lib.ptr(idx), _lib.ptr(dfeat), B, N, m, ns,
+                  C, _s(dx0))
+        return None, None, None, dfeat, None, None, None
+
+
+def group_concat_cl(xyz, new_xyz, idx, feat_cl=None, mode=0, scale=1.0, rot=None):
+    return GroupConcatCL.apply(xyz.contiguous(), new_xyz.contiguous(), idx.contiguous(),
+                               None if feat_cl is None else feat_cl.contiguous(), mode, scale, rot)
+
+
+class LinearBNAct(Function):
+    """X (P,Cin) -> act(BN(X W^T)) (P,Cout), or its max over groups of `pool_ns` rows (P/ns,Cout).
+
+    forward args: X, W (Cout,Cin), gamma, beta, residual|None, then non-tensor state:
+    running_mean, running_var (updated in place in training), momentum, eps, training, relu, pool_ns.
+    """
+
+    @staticmethod
+    def forward(ctx, X, W, gamma, beta, residual, running_mean, running_var, momentum, eps, training, relu,
+                pool_ns):
+        dev = X.device
+        P, Cout = X.shape[0], W.shape[0]
+        Y = torch.mm(X, W.t())
+        ab = torch.empty(4 * Cout, dtype=torch.float32, device=dev)
+        stats = None
+        if training:
+            stats = torch.zeros(2 * Cout, dtype=torch.float64, device=dev)
+            _call("gb_col_stats", dev, _lib.ptr(Y), P, Cout, _lib.ptr(stats), _s(Y))
+        _call("gb_bn_finalize", dev, _lib.ptr(stats), P, Cout, _lib.ptr(gamma), _lib.ptr(beta), float(eps),
+              float(momentum), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(ab), int(training), _s(Y))
+        ctx.cfg = (P, Cout, bool(training), bool(relu), int(pool_ns))
+        if pool_ns:
+            R = P // pool_ns
+            out = torch.empty((R, Cout), dtype=torch.float32, device=dev)
+            arg = torch.empty((R, Cout), dtype=torch.int32, device=dev)
+            _call("gb_affine_relu_maxpool", dev, _lib.ptr(Y), _lib.ptr(ab), _lib.ptr(out), _lib.ptr(arg), R,
+                  pool_ns, Cout, _s(Y))
+            ctx.save_for_backward(X, W, Y, ab, out, arg)
+            return out
+        Z = torch.empty_like(Y)
+        _call("gb_affine_act", dev, _lib.ptr(Y), _lib.ptr(ab), _lib.ptr(residual), _lib.ptr(Z), P, Cout, int(relu),
+              _s(Y))
+        ctx.save_for_backward(X, W, Y, ab, residual)
+        return Z
+
+    @staticmethod
+    def backward(ctx, dout):
+        P, Cout, training, relu, pool_ns = ctx.cfg
+        dout = dout.contiguous()
+        dev = dout.device
+        dstats = torch.zeros(2 * Cout, dtype=torch.float64, device=dev)
+        dres = None
+        if pool_ns:
+            X, W, Y, ab, out, arg = ctx.saved_tensors
+            R = P // pool_ns
+            dY = torch.empty_like(Y)
+            _call("gb_bn_bwd_stats_pool", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(Y),
+                  _lib.ptr(ab), R, pool_ns, Cout, _lib.ptr(dstats), _s(Y))
+            _call("gb_bn_bwd_apply_pool", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(Y),
+                  _lib.ptr(ab), _lib.ptr(dstats), R, pool_ns, Cout, int(training), _lib.ptr(dY), _s(Y))
+        else:
+            X, W, Y, ab, residual = ctx.saved_tensors
+            dY = torch.empty_like(Y)
+            if residual is not None and ctx.needs_input_grad[4]:
+                dres = torch.empty_like(Y)
+            _call("gb_bn_bwd_stats", dev, _lib.ptr(dout), _lib.ptr(Y), _lib.ptr(ab), _lib.ptr(residual), P, Cout,
+                  int(relu), _lib.ptr(dstats), _s(Y))
+            _call("gb_bn_bwd_apply", dev, _lib.ptr(dout), _lib.ptr(Y), _lib.ptr(ab), _lib.ptr(residual),
+                  _lib.ptr(dstats), P, Cout, int(relu), int(training), _lib.ptr(dY), _lib.ptr(dres), _s(Y))
+        dgamma = dbeta = None
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            # dgamma = sum dA*xhat, dbeta = sum dA — exactly the two column sums of pass 1
+            dbeta = dstats[:Cout].float()
+            dgamma = dstats[Cout:].float()
+        dW = torch.mm(dY.t(), X) if ctx.needs_input_grad[1] else None
+        dX = torch.mm(dY, W) if ctx.needs_input_grad[0] else None
+        return dX, dW, dgamma, dbeta, dres, None, None, None, None, None, None, None
+
+
+def conv_bn_act(X, conv, bn, relu=True, pool_ns=0, residual=None):
+    """Apply a 1x1 ``conv`` (Conv1d/Conv2d without bias) + ``bn`` (BatchNorm1d/2d) + optional ReLU to
+    channel-last rows X (P,Cin), with the modules' own parameters and running statistics."""
+    W = conv.weight.view(conv.weight.shape[0], -1)
+    if conv.bias is not None:
+        raise NotImplementedError("fused path expects bias-free convs followed by BatchNorm")
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    momentum = 0.0 if bn.momentum is None else bn.momentum
+    training = bn.training or not bn.track_running_stats
+    return LinearBNAct.apply(X, W, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, momentum, bn.eps,
+                             training, relu, pool_ns)
+
+
+def shared_mlp_cl(X, shared_mlp, pool_ns=0):
+    """Run a ``pytorch_utils.SharedMLP`` (layer0..layerK of conv+bn+ReLU) on channel-last rows; the
+    last layer is fused with the max over `pool_ns` consecutive rows when pool_ns > 0."""
+    layers = list(shared_mlp.children())
+    for i, layer in enumerate(layers):
+        last = i == len(layers) - 1
+        X = conv_bn_act(X, layer.conv, layer.bn.bn, relu=True, pool_ns=pool_ns if last else 0)
+    return X
+
+
+def supports(shared_mlp):
+    """True when every layer is conv(no bias) -> bn -> ReLU (the layout SharedMLP(bn=True) builds)."""
+    for layer in shared_mlp.children():
+        names = [n for n, _ in layer.named_children()]
+        if names != ["conv", "bn", "activation"] or layer.conv.bias is not None:
+            return False
+        if not isinstance(layer.activation, torch.nn.ReLU):
+            return False
+    return True

@@ -5,6 +5,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import fused_mlp
 from . import pytorch_utils as pt_utils
 from .loss_utils import batch_viewpoint_params_to_matrix, generate_grasp_views
 from .pointnet2_utils import CylinderQueryAndGroup, furthest_point_sample
@@ -106,6 +107,14 @@ class GraspWidthGrouping(nn.Module):
         multi-query kernel; None runs one cylinder query per depth like the reference."""
         B, num_seed, _, _ = vp_rot.size()
         num_depth = len(self.groupers)
+        if idx is not None and fused_mlp.enabled(pointcloud) and fused_mlp.supports(self.mlps) \
+                and all(g.use_xyz and g.rotate_xyz and not g.normalize_xyz for g in self.groupers):
+            # channel-last: rows ordered (b, seed, depth, sample) exactly like the reference's stacked view
+            rows = [fused_mlp.group_concat_cl(pointcloud, seed_xyz, idx[d], None, mode=2, rot=vp_rot)
+                    .view(B, num_seed, self.nsample, 3) for d in range(num_depth)]
+            x0 = torch.stack(rows, dim=2).view(-1, 3)
+            out = fused_mlp.shared_mlp_cl(x0, self.mlps, pool_ns=self.nsample)  # (B*seed*depth, 256)
+            return out.view(B, num_seed, num_depth, -1).permute(0, 3, 1, 2).contiguous()
         if idx is None:
             grouped = [g(pointcloud, seed_xyz, vp_rot) for g in self.groupers]
         else:

@@ -9,10 +9,12 @@ class are factored into helpers.
 """
 from typing import List
 
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import fused_mlp
 from . import pointnet2_utils
 from . import pytorch_utils as pt_utils
 
@@ -137,6 +139,25 @@ class PointnetSAModuleVotes(_VotesBase):
             mlp_spec[0] += 3
         self.mlp_module = pt_utils.SharedMLP(mlp_spec, bn=bn)
 
+    def _fused_ok(self, xyz):
+        g = self.grouper
+        return (fused_mlp.enabled(xyz) and self.npoint is not None and self.pooling == 'max'
+                and self.use_xyz and not self.ret_unique_cnt and not getattr(g, "sample_uniformly", True)
+                and fused_mlp.supports(self.mlp_module))
+
+    def _forward_fused(self, xyz, new_xyz, features):
+        """Same values as grouper -> SharedMLP -> max_pool2d, executed channel-last: the grouped
+        (B,3+C,m,ns) tensor, its BN / ReLU copies and the pooling pass are never materialised."""
+        B, m = new_xyz.shape[0], new_xyz.shape[1]
+        idx = pointnet2_utils.ball_query(self.radius, self.nsample, xyz, new_xyz)
+        feat_cl = features.transpose(1, 2).contiguous() if features is not None else None
+        # torch evaluates `grouped_xyz /= radius` on the GPU as a multiply by the fp32 reciprocal
+        scale = float(np.float32(1.0) / np.float32(self.radius)) if self.normalize_xyz else 1.0
+        x0 = fused_mlp.group_concat_cl(xyz, new_xyz, idx, feat_cl, mode=1 if self.normalize_xyz else 0,
+                                       scale=scale)
+        out = fused_mlp.shared_mlp_cl(x0, self.mlp_module, pool_ns=self.nsample)  # (B*m, C_out)
+        return out.view(B, m, -1).transpose(1, 2).contiguous()
+
     def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, inds: torch.Tensor = None):
         if self.npoint is not None:
             new_xyz, inds = _sample_centres(xyz, self.npoint, inds)
@@ -144,6 +165,8 @@ class PointnetSAModuleVotes(_VotesBase):
             new_xyz = None
             if inds is None:
                 inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+        if self._fused_ok(xyz):
+            return new_xyz, self._forward_fused(xyz, new_xyz, features), inds
         grouped_features, grouped_xyz, unique_cnt = self._group(xyz, new_xyz, features)
         new_features = _pool(self.mlp_module(grouped_features), grouped_xyz, self.pooling, self.sigma,
                              self.nsample)

@@ -134,6 +134,50 @@ int gb_three_interpolate_grad(const float *grad_out, const int32_t *idx, const f
 int gb_knn1(const float *ref, const float *query, int64_t *idx, int b, int dim, int nref, int nq,
             void *stream);
 
+/* ---- channel-last fused pieces of the SharedMLP (1x1 conv + BatchNorm + ReLU + max over nsample) ----
+ * No reference launcher corresponds one-to-one: these replace the torch passes the reference runs
+ * around its cuBLAS/cuDNN GEMMs — QueryAndGroup's cat / sub / div (pointnet2_utils.py:178-192),
+ * CylinderQueryAndGroup's matmul (:281-284), BatchNorm2d + ReLU (pytorch_utils.py:33-59,96-110),
+ * F.max_pool2d (pointnet2_modules.py:165-169) and their autograd mirrors.
+ * Activations are position-major rows act[p][c], p = (b*m + j)*nsample + k.                        */
+
+/* X0[p] = [ g(xyz[b,idx[p]] - new_xyz[b,j]) , feat[b,idx[p],:] ],  out (b*m*ns, 3+c).
+ * feat (b,n,c) channel-last (may be NULL when c == 0).  mode 0: g = identity; 1: g = * scale
+ * (normalize_xyz, scale = 1/radius); 2: g = rotation by rot (b,m,9), p^T R.                       */
+int gb_group_concat_cl(const float *xyz, const float *new_xyz, const int32_t *idx, const float *feat,
+                       const float *rot, float *out, int b, int n, int m, int ns, int c, int mode,
+                       float scale, void *stream);
+/* dfeat[b, idx[p], :] += dx0[p, 3:]   (accumulates into dfeat (b,n,c)) */
+int gb_group_concat_cl_grad(const float *dx0, const int32_t *idx, float *dfeat, int b, int n, int m,
+                            int ns, int c, void *stream);
+/* stats[0:C] += column sums of y (P,C), stats[C:2C] += column sums of y*y; fp64, caller zeroes */
+int gb_col_stats(const float *y, long long P, int C, double *stats, void *stream);
+/* ab[0:C] = a = gamma*rstd, ab[C:2C] = b = beta - mean*a, ab[2C:3C] = mean, ab[3C:4C] = rstd.
+ * training: batch statistics from `stats` (biased variance) and running_* updated with `momentum`
+ * (unbiased variance), as nn.BatchNorm does; otherwise the running statistics are used.           */
+int gb_bn_finalize(const double *stats, long long P, int C, const float *gamma, const float *beta,
+                   float eps, float momentum, float *running_mean, float *running_var, float *ab,
+                   int training, void *stream);
+/* z = act(a*y + b (+ residual)), act = ReLU when relu != 0 */
+int gb_affine_act(const float *y, const float *ab, const float *residual, float *z, long long P, int C,
+                  int relu, void *stream);
+/* out[r,c] = max_k relu(a*y[r*ns+k,c] + b), arg[r,c] = first k attaining it;  R = P/ns rows */
+int gb_affine_relu_maxpool(const float *y, const float *ab, float *out, int32_t *arg, long long R, int ns,
+                           int C, void *stream);
+/* BatchNorm(+ReLU)(+residual) backward. dstats[0:C] += dbeta, dstats[C:2C] += dgamma (fp64, zeroed by
+ * the caller); then dy = a*(dA - dbeta/P - xhat*dgamma/P) (training) or a*dA (eval); dres (optional)
+ * receives dA = dout*[z>0].  The *_pool forms take the (R,C) gradient of the max-pooled output.     */
+int gb_bn_bwd_stats(const float *dout, const float *y, const float *ab, const float *residual, long long P,
+                    int C, int relu, double *dstats, void *stream);
+int gb_bn_bwd_apply(const float *dout, const float *y, const float *ab, const float *residual,
+                    const double *dstats, long long P, int C, int relu, int training, float *dy, float *dres,
+                    void *stream);
+int gb_bn_bwd_stats_pool(const float *dout, const float *out, const int32_t *arg, const float *y,
+                         const float *ab, long long R, int ns, int C, double *dstats, void *stream);
+int gb_bn_bwd_apply_pool(const float *dout, const float *out, const int32_t *arg, const float *y,
+                         const float *ab, const double *dstats, long long R, int ns, int C, int training,
+                         float *dy, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

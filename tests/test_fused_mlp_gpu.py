@@ -1,0 +1,175 @@
+"""GPU: the channel-last fused SharedMLP path (csrc/mlp_cl.hip + fused_mlp.py) against the plain torch
+composition the reference uses (grouping -> cat -> Conv2d -> BatchNorm2d -> ReLU -> max), same
+parameters, same inputs: forward values, running statistics and every gradient.
+
+Tolerance: 1e-5 of the tensor's scale for forward values (fp32, different summation order in the BN
+statistics), 1e-4 for gradients.
+"""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _close(a, b, tol, what):
+    scale = float(b.abs().max()) + 1e-12
+    err = float((a - b).abs().max()) / scale
+    assert err < tol, (what, err)
+
+
+def _run(module_fused, module_plain, call, tol_fwd=1e-5, tol_grad=1e-4):
+    from graspbalance_amd import fused_mlp
+    outs = {}
+    for name, mod, flag in (("fused", module_fused, True), ("plain", module_plain, False)):
+        fused_mlp.set_enabled(flag)
+        try:
+            mod.zero_grad(set_to_none=True)
+            out, leaves = call(mod)
+            torch.manual_seed(99)
+            w = torch.randn_like(out)
+            (out * w).sum().backward()
+            outs[name] = (out.detach(), [l.grad.detach().clone() for l in leaves],
+                          {k: v.grad.detach().clone() for k, v in mod.named_parameters() if v.grad is not None},
+                          {k: v.detach().clone() for k, v in mod.named_buffers()})
+        finally:
+            fused_mlp.set_enabled(True)
+    f, p = outs["fused"], outs["plain"]
+    _close(f[0], p[0], tol_fwd, "forward")
+    for i, (a, b) in enumerate(zip(f[1], p[1])):
+        _close(a, b, tol_grad, "input grad %d" % i)
+    assert set(f[2]) == set(p[2])
+    for k in p[2]:
+        _close(f[2][k], p[2][k], tol_grad, "grad " + k)
+    for k in p[3]:
+        if p[3][k].dtype.is_floating_point:
+            _close(f[3][k], p[3][k], 1e-5, "buffer " + k)
+        else:
+            assert torch.equal(f[3][k], p[3][k]), k
+
+
+@pytest.mark.parametrize("normalize,with_feat", [(True, True), (False, True), (True, False)])
+def test_sa_module_fused_equals_plain(normalize, with_feat):
+    from graspbalance_amd import pointnet2_modules as pm
+    from graspbalance_amd.scene import make_batch
+    torch.manual_seed(3)
+    cin = 16 if with_feat else 0
+    plain = pm.PointnetSAModuleVotes(npoint=512, radius=0.08, nsample=32, mlp=[cin, 32, 32, 64], use_xyz=True,
+                                     normalize_xyz=normalize).to(DEV).train()
+    fused = copy.deepcopy(plain)
+    xyz = torch.from_numpy(make_batch([0, 1], 4096)).to(DEV)
+    feat0 = torch.randn(2, cin, 4096, device=DEV) if with_feat else None
+
+    def call(mod):
+        feat = feat0.clone().requires_grad_(True) if with_feat else None
+        new_xyz, new_feat, inds = mod(xyz, feat)
+        return new_feat, ([feat] if with_feat else [])
+    _run(fused, plain, call)
+
+
+def test_grouped_xyz_bits_match_torch_division():
+    """normalize_xyz: the fused kernel multiplies by the fp32 reciprocal exactly like torch's
+    `grouped_xyz /= radius` does on the GPU."""
+    from graspbalance_amd import fused_mlp, pointnet2_utils as pu
+    from graspbalance_amd.scene import make_batch
+    import numpy as np
+    xyz = torch.from_numpy(make_batch([3], 4096)).to(DEV)
+    new_xyz = xyz[:, :256].contiguous()
+    feat = torch.randn(1, 5, 4096, device=DEV)
+    for radius in (0.04, 0.1, 0.3):
+        qg = pu.QueryAndGroup(radius, 16, use_xyz=True, normalize_xyz=True)
+        want = qg(xyz, new_xyz, feat)                                    # (B,3+C,m,ns)
+        idx = pu.ball_query(radius, 16, xyz, new_xyz)
+        got = fused_mlp.group_concat_cl(xyz, new_xyz, idx, feat.transpose(1, 2).contiguous(), mode=1,
+                                        scale=float(np.float32(1.0) / np.float32(radius)))
+        assert torch.equal(got.view(1, 256, 16, 8).permute(0, 3, 1, 2), want)
+
+
+def test_invresmlp_stage_fused_equals_plain():
+    from graspbalance_amd.drp import InvResMLP, run_stage
+    from graspbalance_amd.scene import make_batch
+    import torch.nn as nn
+    torch.manual_seed(4)
+    blocks = nn.Sequential(*[InvResMLP(in_channels=32, aggr_args={'feature_type': 'dp_fj', "reduction": 'max'},
+                                       norm_args={'norm': 'bn'}, act_args={'act': 'relu'},
+                                       group_args={'NAME': 'ballquery', 'radius': 0.1, 'nsample': 16},
+                                       conv_args={'order': 'conv-norm-act'}, expansion=4, use_res=True)
+                             for _ in range(2)]).to(DEV).train()
+    fused = copy.deepcopy(blocks)
+    p = torch.from_numpy(make_batch([0, 1], 1024)).to(DEV)
+    f0 = torch.randn(2, 32, 1024, device=DEV)
+
+    def call(mod):
+        f = f0.clone().requires_grad_(True)
+        _, out = run_stage(mod, p, f)
+        return out, [f]
+    _run(fused, blocks, call)
+
+
+def test_grasp_width_grouping_fused_equals_plain(golden):
+    from graspbalance_amd import fused_ops
+    from graspbalance_amd.modules import GraspWidthGrouping
+    from graspbalance_amd.scene import make_batch
+    torch.manual_seed(5)
+    plain = GraspWidthGrouping(32, 3, 0.06, -0.02, [0.01, 0.02, 0.03, 0.04]).to(DEV).train()
+    fused = copy.deepcopy(plain)
+    cloud = torch.from_numpy(make_batch([0, 1], 8000)).to(DEV)
+    seeds = cloud[:, :128].contiguous()
+    rot = torch.from_numpy(golden.load("g9_views")["rot"])[:128].unsqueeze(0).repeat(2, 1, 1, 1).contiguous().to(DEV)
+    idx = fused_ops.cylinder_query_multi(cloud, seeds, rot, [0.06], -0.02, [0.01, 0.02, 0.03, 0.04], 32)[0]
+
+    def call(mod):
+        return mod(seeds, cloud, rot, idx=idx), []
+    _run(fused, plain, call)
+
+
+def test_eval_mode_uses_running_statistics():
+    from graspbalance_amd import fused_mlp, pointnet2_modules as pm
+    from graspbalance_amd.scene import make_batch
+    torch.manual_seed(6)
+    sa = pm.PointnetSAModuleVotes(npoint=256, radius=0.1, nsample=16, mlp=[0, 16, 32], use_xyz=True,
+                                  normalize_xyz=True).to(DEV)
+    xyz = torch.from_numpy(make_batch([2], 2048)).to(DEV)
+    sa.train()
+    for _ in range(3):
+        sa(xyz)  # populate running statistics
+    sa.eval()
+    before = {k: v.clone() for k, v in sa.named_buffers()}
+    with torch.no_grad():
+        a = sa(xyz)[1]
+        fused_mlp.set_enabled(False)
+        try:
+            b = sa(xyz)[1]
+        finally:
+            fused_mlp.set_enabled(True)
+    _close(a, b, 1e-5, "eval forward")
+    for k, v in sa.named_buffers():
+        assert torch.equal(v, before[k]), "eval must not touch " + k
+
+
+def test_whole_network_train_step_fused_equals_plain():
+    from tests.test_model_cpu import _tiny_net
+    from graspbalance_amd import fused_mlp
+    from graspbalance_amd.loss import get_loss
+    from graspbalance_amd.synthetic import make_training_batch
+    batch = make_training_batch(range(2), num_point=3000, num_objects=2, grasp_points_per_object=20, num_view=30,
+                                device=DEV)
+    results = {}
+    for flag in (True, False):
+        net = _tiny_net().to(DEV).train()
+        fused_mlp.set_enabled(flag)
+        try:
+            loss, ep = get_loss(net(dict(batch)))
+            loss.backward()
+        finally:
+            fused_mlp.set_enabled(True)
+        results[flag] = (float(loss), {k: v.grad.clone() for k, v in net.named_parameters()},
+                         ep['grasp_score_pred'].detach().clone(), ep['fp2_features'].detach().clone())
+    assert abs(results[True][0] - results[False][0]) < 1e-4 * max(1.0, abs(results[False][0]))
+    _close(results[True][3], results[False][3], 1e-4, "fp2_features")
+    _close(results[True][2], results[False][2], 1e-3, "grasp_score_pred")
+    worst = max(float((results[True][1][k] - results[False][1][k]).abs().max()) /
+                (float(results[False][1][k].abs().max()) + 1e-6) for k in results[False][1])
+    assert worst < 5e-2, worst  # deep BN stacks amplify fp32 rounding; per-module tests hold 1e-4

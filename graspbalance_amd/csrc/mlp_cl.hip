@@ -82,51 +82,83 @@ __global__ __launch_bounds__(CL_TPB) void group_concat_cl_grad_kernel(
 // Column reductions over a (P, C) row-major matrix.  A block owns ROWS_PER_BLOCK rows; threads are
 // laid out (row lane, column) so a wave reads contiguous row segments; per-thread fp64 partials,
 // LDS reduce over the row lanes, one fp64 atomic per column per block.
-constexpr int ROWS_PER_BLOCK = 1024;
+// HBM-bound: each thread owns VEC (4 when C % 4 == 0) adjacent columns and reads them with one 16-byte
+// load per row; 4 rows are in flight per thread (independent fp32 accumulators, flushed to fp64 after
+// at most ROWS_PER_BLOCK / row-lanes rows, i.e. <= 64 terms per fp32 partial).
+constexpr int ROWS_PER_BLOCK = 512;
 
-template <class F>  // F(row, col) -> (v1, v2) contributions
-__device__ __forceinline__ void col_reduce2(long long P, int C, double *__restrict__ out1,
+template <int VEC, class F>  // F(row, col, v1[VEC], v2[VEC]) -> contributions of columns col..col+VEC-1
+__device__ __forceinline__ void col_reduce2(long long P, int C, int rpb, double *__restrict__ out1,
                                             double *__restrict__ out2, F f) {
-  __shared__ double s1[CL_TPB], s2[CL_TPB];
-  const long long row0 = (long long)blockIdx.x * ROWS_PER_BLOCK;
-  const long long row1 = row0 + ROWS_PER_BLOCK < P ? row0 + ROWS_PER_BLOCK : P;
-  for (int cbase = 0; cbase < C; cbase += CL_TPB) {
-    const int cols = C - cbase < CL_TPB ? C - cbase : CL_TPB;  // columns handled this round
-    int rl = CL_TPB / cols;                                     // row lanes
-    if (rl < 1) rl = 1;
-    const int col = threadIdx.x % cols;
+  __shared__ double s1[CL_TPB * VEC], s2[CL_TPB * VEC];
+  const long long row0 = (long long)blockIdx.x * rpb;
+  const long long row1 = row0 + rpb < P ? row0 + rpb : P;
+  const int CV = C / VEC;  // column groups
+  for (int cbase = 0; cbase < CV; cbase += CL_TPB) {
+    const int cols = CV - cbase < CL_TPB ? CV - cbase : CL_TPB;  // column groups handled this round
+    const int rl = CL_TPB / cols;                                 // row lanes (>= 1)
+    const int cg = threadIdx.x % cols;
     const int lane_r = threadIdx.x / cols;
-    double a1 = 0.0, a2 = 0.0;
+    const int col = (cbase + cg) * VEC;
+    float p1[4][VEC], p2[4][VEC];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) { p1[u][t] = 0.f; p2[u][t] = 0.f; }
     if (lane_r < rl) {
-      for (long long r = row0 + lane_r; r < row1; r += rl) {
-        float v1, v2;
-        f(r, cbase + col, v1, v2);
-        a1 += (double)v1;
-        a2 += (double)v2;
+      long long r = row0 + lane_r;
+      for (; r + 3LL * rl < row1; r += 4LL * rl) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float v1[VEC], v2[VEC];
+          f(r + (long long)u * rl, col, v1, v2);
+#pragma unroll
+          for (int t = 0; t < VEC; ++t) { p1[u][t] += v1[t]; p2[u][t] += v2[t]; }
+        }
+      }
+      for (; r < row1; r += rl) {
+        float v1[VEC], v2[VEC];
+        f(r, col, v1, v2);
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) { p1[0][t] += v1[t]; p2[0][t] += v2[t]; }
       }
     }
-    s1[threadIdx.x] = a1;
-    s2[threadIdx.x] = a2;
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) {
+      s1[threadIdx.x * VEC + t] = ((double)p1[0][t] + (double)p1[1][t]) + ((double)p1[2][t] + (double)p1[3][t]);
+      s2[threadIdx.x * VEC + t] = ((double)p2[0][t] + (double)p2[1][t]) + ((double)p2[2][t] + (double)p2[3][t]);
+    }
     __syncthreads();
-    if (threadIdx.x < cols) {
+    for (int o = threadIdx.x; o < cols * VEC; o += CL_TPB) {  // o = cg*VEC + t
       double t1 = 0.0, t2 = 0.0;
       for (int l = 0; l < rl; ++l) {
-        t1 += s1[l * cols + threadIdx.x];
-        t2 += s2[l * cols + threadIdx.x];
+        t1 += s1[l * cols * VEC + o];
+        t2 += s2[l * cols * VEC + o];
       }
-      atomicAdd(out1 + cbase + threadIdx.x, t1);
-      atomicAdd(out2 + cbase + threadIdx.x, t2);
+      atomicAdd(out1 + cbase * VEC + o, t1);
+      atomicAdd(out2 + cbase * VEC + o, t2);
     }
     __syncthreads();
   }
 }
 
-__global__ __launch_bounds__(CL_TPB) void col_stats_kernel(const float *__restrict__ y, long long P, int C,
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float *p, float *v) {
+  if constexpr (VEC == 4) {
+    const float4 t = *reinterpret_cast<const float4 *>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+    v[0] = p[0];
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(CL_TPB) void col_stats_kernel(const float *__restrict__ y, long long P, int C, int rpb,
                                                             double *__restrict__ sum, double *__restrict__ sumsq) {
-  col_reduce2(P, C, sum, sumsq, [&](long long r, int c, float &v1, float &v2) {
-    const float v = y[r * C + c];
-    v1 = v;
-    v2 = v * v;
+  col_reduce2<VEC>(P, C, rpb, sum, sumsq, [&](long long r, int c, float *v1, float *v2) {
+    load_vec<VEC>(y + r * C + c, v1);
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) v2[t] = v1[t] * v1[t];
   });
 }
 
@@ -218,26 +250,35 @@ __global__ __launch_bounds__(CL_TPB) void affine_relu_maxpool_kernel(const float
 }
 
 // dense BN(+ReLU)(+residual) backward, pass 1: dA = dOut * [z > 0]; dbeta = sum dA, dgamma = sum dA*xhat
+template <int VEC>
 __global__ __launch_bounds__(CL_TPB) void bn_bwd_stats_kernel(const float *__restrict__ dout,
                                                                const float *__restrict__ y,
                                                                const float *__restrict__ ab,
                                                                const float *__restrict__ residual, long long P,
-                                                               int C, int relu, double *__restrict__ dbeta,
+                                                               int C, int rpb, int relu,
+                                                               double *__restrict__ dbeta,
                                                                double *__restrict__ dgamma) {
-  col_reduce2(P, C, dbeta, dgamma, [&](long long r, int c, float &v1, float &v2) {
-    const float yy = y[r * C + c];
-    float g = dout[r * C + c];
-    if (relu) {
-      float z = ab[c] * yy + ab[C + c];
-      if (residual) z += residual[r * C + c];
-      if (!(z > 0.f)) g = 0.f;
+  col_reduce2<VEC>(P, C, rpb, dbeta, dgamma, [&](long long r, int c, float *v1, float *v2) {
+    float yy[VEC], g[VEC], rs[VEC];
+    load_vec<VEC>(y + r * C + c, yy);
+    load_vec<VEC>(dout + r * C + c, g);
+    if (residual) load_vec<VEC>(residual + r * C + c, rs);
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) {
+      float gg = g[t];
+      if (relu) {
+        float z = ab[c + t] * yy[t] + ab[C + c + t];
+        if (residual) z += rs[t];
+        if (!(z > 0.f)) gg = 0.f;
+      }
+      v1[t] = gg;
+      v2[t] = gg * ((yy[t] - ab[2 * C + c + t]) * ab[3 * C + c + t]);
     }
-    v1 = g;
-    v2 = g * ((yy - ab[2 * C + c]) * ab[3 * C + c]);
   });
 }
 
 // pass 2: dy = a*(dA - dbeta/P - xhat*dgamma/P)  (training) or a*dA (eval); optionally dA out (residual grad)
+template <int VEC>
 __global__ __launch_bounds__(CL_TPB) void bn_bwd_apply_kernel(const float *__restrict__ dout,
                                                                const float *__restrict__ y,
                                                                const float *__restrict__ ab,
@@ -245,66 +286,119 @@ __global__ __launch_bounds__(CL_TPB) void bn_bwd_apply_kernel(const float *__res
                                                                const double *__restrict__ dstats, long long P,
                                                                int C, int relu, int training,
                                                                float *__restrict__ dy, float *__restrict__ dres) {
-  const long long e = (long long)blockIdx.x * CL_TPB + threadIdx.x;
+  const long long e = ((long long)blockIdx.x * CL_TPB + threadIdx.x) * VEC;
   if (e >= P * C) return;
   const int c = (int)(e % C);
-  const float yy = y[e];
-  float g = dout[e];
-  if (relu) {
-    float z = ab[c] * yy + ab[C + c];
-    if (residual) z += residual[e];
-    if (!(z > 0.f)) g = 0.f;
+  const double invP = 1.0 / (double)P;
+  float yy[VEC], g[VEC], rs[VEC], d[VEC];
+  load_vec<VEC>(y + e, yy);
+  load_vec<VEC>(dout + e, g);
+  if (residual) load_vec<VEC>(residual + e, rs);
+#pragma unroll
+  for (int t = 0; t < VEC; ++t) {
+    if (relu) {
+      float z = ab[c + t] * yy[t] + ab[C + c + t];
+      if (residual) z += rs[t];
+      if (!(z > 0.f)) g[t] = 0.f;
+    }
+    float dd = g[t];
+    if (training) {
+      const float xhat = (yy[t] - ab[2 * C + c + t]) * ab[3 * C + c + t];
+      dd = g[t] - (float)(dstats[c + t] * invP) - xhat * (float)(dstats[C + c + t] * invP);
+    }
+    d[t] = ab[c + t] * dd;
   }
-  if (dres) dres[e] = g;
-  float d = g;
-  if (training) {
-    const float xhat = (yy - ab[2 * C + c]) * ab[3 * C + c];
-    d = g - (float)(dstats[c] / (double)P) - xhat * (float)(dstats[C + c] / (double)P);
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<float4 *>(dy + e) = make_float4(d[0], d[1], d[2], d[3]);
+    if (dres) *reinterpret_cast<float4 *>(dres + e) = make_float4(g[0], g[1], g[2], g[3]);
+  } else {
+    dy[e] = d[0];
+    if (dres) dres[e] = g[0];
   }
-  dy[e] = ab[c] * d;
 }
 
 // pooled variants: dOut is (R,C); the gradient reaches only the arg-max sample and only if out > 0
+template <int VEC>
 __global__ __launch_bounds__(CL_TPB) void bn_bwd_stats_pool_kernel(const float *__restrict__ dout,
                                                                     const float *__restrict__ out,
                                                                     const int32_t *__restrict__ arg,
                                                                     const float *__restrict__ y,
                                                                     const float *__restrict__ ab, long long R,
-                                                                    int ns, int C, double *__restrict__ dbeta,
+                                                                    int ns, int C, int rpb,
+                                                                    double *__restrict__ dbeta,
                                                                     double *__restrict__ dgamma) {
-  col_reduce2(R, C, dbeta, dgamma, [&](long long r, int c, float &v1, float &v2) {
-    const float g = out[r * C + c] > 0.f ? dout[r * C + c] : 0.f;
-    const float yy = y[(r * ns + arg[r * C + c]) * C + c];
-    v1 = g;
-    v2 = g * ((yy - ab[2 * C + c]) * ab[3 * C + c]);
+  col_reduce2<VEC>(R, C, rpb, dbeta, dgamma, [&](long long r, int c, float *v1, float *v2) {
+    float o[VEC], g[VEC];
+    load_vec<VEC>(out + r * C + c, o);
+    load_vec<VEC>(dout + r * C + c, g);
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) {
+      const float gg = o[t] > 0.f ? g[t] : 0.f;
+      const float yy = y[(r * ns + arg[r * C + c + t]) * C + c + t];
+      v1[t] = gg;
+      v2[t] = gg * ((yy - ab[2 * C + c + t]) * ab[3 * C + c + t]);
+    }
   });
 }
 
+// one thread per (pooled row r, VEC channels): the row's gradient / arg-max are read once, then the
+// ns samples of the row are streamed (16-byte loads and stores)
+template <int VEC>
 __global__ __launch_bounds__(CL_TPB) void bn_bwd_apply_pool_kernel(const float *__restrict__ dout,
                                                                     const float *__restrict__ out,
                                                                     const int32_t *__restrict__ arg,
                                                                     const float *__restrict__ y,
                                                                     const float *__restrict__ ab,
-                                                                    const double *__restrict__ dstats, long long P,
+                                                                    const double *__restrict__ dstats, long long R,
                                                                     int ns, int C, int training,
                                                                     float *__restrict__ dy) {
-  const long long e = (long long)blockIdx.x * CL_TPB + threadIdx.x;
-  if (e >= P * C) return;
-  const int c = (int)(e % C);
-  const long long p = e / C;
-  const long long r = p / ns;
-  const int k = (int)(p % ns);
-  const long long rc = r * C + c;
-  float g = (arg[rc] == k && out[rc] > 0.f) ? dout[rc] : 0.f;
-  float d = g;
-  if (training) {
-    const float xhat = (y[e] - ab[2 * C + c]) * ab[3 * C + c];
-    d = g - (float)(dstats[c] / (double)P) - xhat * (float)(dstats[C + c] / (double)P);
+  const int CV = C / VEC;
+  const long long gid = (long long)blockIdx.x * CL_TPB + threadIdx.x;
+  if (gid >= R * CV) return;
+  const long long r = gid / CV;
+  const int c = (int)(gid % CV) * VEC;
+  const double invP = 1.0 / ((double)R * ns);
+  float g[VEC], a[VEC], mean[VEC], rstd[VEC], m1[VEC], m2[VEC];
+  int ak[VEC];
+  {
+    float o[VEC];
+    load_vec<VEC>(out + r * C + c, o);
+    load_vec<VEC>(dout + r * C + c, g);
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) {
+      if (!(o[t] > 0.f)) g[t] = 0.f;
+      ak[t] = arg[r * C + c + t];
+      a[t] = ab[c + t];
+      mean[t] = ab[2 * C + c + t];
+      rstd[t] = ab[3 * C + c + t];
+      m1[t] = training ? (float)(dstats[c + t] * invP) : 0.f;
+      m2[t] = training ? (float)(dstats[C + c + t] * invP) : 0.f;
+    }
   }
-  dy[e] = ab[c] * d;
+  const float *src = y + (r * ns) * C + c;
+  float *dst = dy + (r * ns) * C + c;
+  for (int k = 0; k < ns; ++k) {
+    float yy[VEC], d[VEC];
+    load_vec<VEC>(src + (size_t)k * C, yy);
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) {
+      const float gg = ak[t] == k ? g[t] : 0.f;
+      d[t] = training ? a[t] * (gg - m1[t] - ((yy[t] - mean[t]) * rstd[t]) * m2[t]) : a[t] * gg;
+    }
+    if constexpr (VEC == 4) *reinterpret_cast<float4 *>(dst + (size_t)k * C) = make_float4(d[0], d[1], d[2], d[3]);
+    else dst[(size_t)k * C] = d[0];
+  }
 }
 
 static inline unsigned blocks_for(long long work) { return (unsigned)((work + CL_TPB - 1) / CL_TPB); }
+
+// rows per reduction block: enough blocks (~2048) to fill 256 CUs, at most ROWS_PER_BLOCK rows each
+static inline int rows_per_block(long long rows) {
+  long long rpb = (rows + 2047) / 2048;
+  if (rpb < 16) rpb = 16;
+  if (rpb > ROWS_PER_BLOCK) rpb = ROWS_PER_BLOCK;
+  return (int)rpb;
+}
 
 }  // namespace gb
 
@@ -339,8 +433,12 @@ extern "C" int gb_group_concat_cl_grad(const float *dx0, const int32_t *idx, flo
 extern "C" int gb_col_stats(const float *y, long long P, int C, double *stats, void *stream) {
   if (P < 0 || C < 1 || !y || !stats) return GB_EINVAL;
   if (P == 0) return GB_OK;
-  hipLaunchKernelGGL(col_stats_kernel, dim3((unsigned)((P + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(CL_TPB), 0,
-                     as_stream(stream), y, P, C, stats, stats + C);
+  const int rpb = rows_per_block(P);
+  const dim3 grid((unsigned)((P + rpb - 1) / rpb));
+  if (C % 4 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0)
+    hipLaunchKernelGGL((col_stats_kernel<4>), grid, dim3(CL_TPB), 0, as_stream(stream), y, P, C, rpb, stats, stats + C);
+  else
+    hipLaunchKernelGGL((col_stats_kernel<1>), grid, dim3(CL_TPB), 0, as_stream(stream), y, P, C, rpb, stats, stats + C);
   return check_launch("gb_col_stats");
 }
 
@@ -384,8 +482,16 @@ extern "C" int gb_bn_bwd_stats(const float *dout, const float *y, const float *a
                                long long P, int C, int relu, double *dstats, void *stream) {
   if (P < 0 || C < 1 || !dout || !y || !ab || !dstats) return GB_EINVAL;
   if (P == 0) return GB_OK;
-  hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3((unsigned)((P + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(CL_TPB),
-                     0, as_stream(stream), dout, y, ab, residual, P, C, relu, dstats, dstats + C);
+  const int rpb = rows_per_block(P);
+  const dim3 grid((unsigned)((P + rpb - 1) / rpb));
+  const bool vec = C % 4 == 0 && (reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dout) |
+                                  reinterpret_cast<uintptr_t>(residual)) % 16 == 0;
+  if (vec)
+    hipLaunchKernelGGL((bn_bwd_stats_kernel<4>), grid, dim3(CL_TPB), 0, as_stream(stream), dout, y, ab, residual, P,
+                       C, rpb, relu, dstats, dstats + C);
+  else
+    hipLaunchKernelGGL((bn_bwd_stats_kernel<1>), grid, dim3(CL_TPB), 0, as_stream(stream), dout, y, ab, residual, P,
+                       C, rpb, relu, dstats, dstats + C);
   return check_launch("gb_bn_bwd_stats");
 }
 
@@ -394,8 +500,15 @@ extern "C" int gb_bn_bwd_apply(const float *dout, const float *y, const float *a
                                float *dres, void *stream) {
   if (P < 0 || C < 1 || !dout || !y || !ab || !dy || (training && !dstats)) return GB_EINVAL;
   if (P == 0) return GB_OK;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(P * C)), dim3(CL_TPB), 0, as_stream(stream), dout, y, ab,
-                     residual, dstats, P, C, relu, training, dy, dres);
+  const bool vec = C % 4 == 0 && (reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dout) |
+                                  reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(dy) |
+                                  reinterpret_cast<uintptr_t>(dres)) % 16 == 0;
+  if (vec)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(blocks_for(P * C / 4)), dim3(CL_TPB), 0, as_stream(stream), dout,
+                       y, ab, residual, dstats, P, C, relu, training, dy, dres);
+  else
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(blocks_for(P * C)), dim3(CL_TPB), 0, as_stream(stream), dout, y,
+                       ab, residual, dstats, P, C, relu, training, dy, dres);
   return check_launch("gb_bn_bwd_apply");
 }
 
@@ -403,8 +516,15 @@ extern "C" int gb_bn_bwd_stats_pool(const float *dout, const float *out, const i
                                     const float *ab, long long R, int ns, int C, double *dstats, void *stream) {
   if (R < 0 || ns < 1 || C < 1 || !dout || !out || !arg || !y || !ab || !dstats) return GB_EINVAL;
   if (R == 0) return GB_OK;
-  hipLaunchKernelGGL(bn_bwd_stats_pool_kernel, dim3((unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)),
-                     dim3(CL_TPB), 0, as_stream(stream), dout, out, arg, y, ab, R, ns, C, dstats, dstats + C);
+  const int rpb = rows_per_block(R);
+  const dim3 grid((unsigned)((R + rpb - 1) / rpb));
+  const bool vec = C % 4 == 0 && (reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(dout)) % 16 == 0;
+  if (vec)
+    hipLaunchKernelGGL((bn_bwd_stats_pool_kernel<4>), grid, dim3(CL_TPB), 0, as_stream(stream), dout, out, arg, y, ab,
+                       R, ns, C, rpb, dstats, dstats + C);
+  else
+    hipLaunchKernelGGL((bn_bwd_stats_pool_kernel<1>), grid, dim3(CL_TPB), 0, as_stream(stream), dout, out, arg, y, ab,
+                       R, ns, C, rpb, dstats, dstats + C);
   return check_launch("gb_bn_bwd_stats_pool");
 }
 
@@ -413,7 +533,13 @@ extern "C" int gb_bn_bwd_apply_pool(const float *dout, const float *out, const i
                                     int training, float *dy, void *stream) {
   if (R < 0 || ns < 1 || C < 1 || !dout || !out || !arg || !y || !ab || !dy || (training && !dstats)) return GB_EINVAL;
   if (R == 0) return GB_OK;
-  hipLaunchKernelGGL(bn_bwd_apply_pool_kernel, dim3(blocks_for(R * ns * C)), dim3(CL_TPB), 0, as_stream(stream), dout,
-                     out, arg, y, ab, dstats, R * ns, ns, C, training, dy);
+  const bool vec = C % 4 == 0 && (reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dout) |
+                                  reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(dy)) % 16 == 0;
+  if (vec)
+    hipLaunchKernelGGL((bn_bwd_apply_pool_kernel<4>), dim3(blocks_for(R * (C / 4))), dim3(CL_TPB), 0, as_stream(stream),
+                       dout, out, arg, y, ab, dstats, R, ns, C, training, dy);
+  else
+    hipLaunchKernelGGL((bn_bwd_apply_pool_kernel<1>), dim3(blocks_for(R * C)), dim3(CL_TPB), 0, as_stream(stream), dout,
+                       out, arg, y, ab, dstats, R, ns, C, training, dy);
   return check_launch("gb_bn_bwd_apply_pool");
 }

@@ -38,6 +38,18 @@ def _call(name, dev, *args):
         _lib.check(getattr(_lib.lib(), name)(*args), name)
 
 
+def _wgrad(dY, X):
+    """dW (Cout,Cin) = dY^T X with the reduction over P rows split into S batched slices: a plain
+    (Cout x P) x (P x Cin) GEMM has only Cout*Cin/tile^2 output tiles (4 for 64x64), i.e. 4 busy CUs."""
+    P = dY.shape[0]
+    S = 1
+    while S < 64 and P % (2 * S) == 0 and P // (2 * S) >= 2048:
+        S *= 2
+    if S == 1:
+        return torch.mm(dY.t(), X)
+    return torch.bmm(dY.view(S, P // S, -1).transpose(1, 2), X.view(S, P // S, -1)).sum(0)
+
+
 class GroupConcatCL(Function):
     """(xyz (B,N,3), new_xyz (B,m,3), idx (B,m,ns), feat_cl (B,N,C)|None) -> X0 (B*m*ns, 3+C)."""
 
@@ -136,7 +148,7 @@ class LinearBNAct(Function):
             # dgamma = sum dA*xhat, dbeta = sum dA — exactly the two column sums of pass 1
             dbeta = dstats[:Cout].float()
             dgamma = dstats[Cout:].float()
-        dW = torch.mm(dY.t(), X) if ctx.needs_input_grad[1] else None
+        dW = _wgrad(dY, X) if ctx.needs_input_grad[1] else None
         dX = torch.mm(dY, W) if ctx.needs_input_grad[0] else None
         return dX, dW, dgamma, dbeta, dres, None, None, None, None, None, None, None
 

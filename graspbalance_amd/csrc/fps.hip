@@ -107,18 +107,32 @@ __global__ __launch_bounds__(BLOCK) void fps_reg_kernel(const float *__restrict_
   for (int j = 1; j < m; ++j) {
     // wave-uniform address -> scalar loads
     const float x1 = pts[old * 3 + 0], y1 = pts[old * 3 + 1], z1 = pts[old * 3 + 2];
-    float best = -1.0f;
-    int bestp = 0;
+    // NACC independent (best, argbest) chains over p mod NACC: the compare/select recurrence of a
+    // single chain is 3 dependent VALU ops per point, which 4 waves per SIMD cannot fully hide
+    constexpr int NACC = P >= 4 ? 4 : 1;
+    float bq[NACC];
+    int bpq[NACC];
+#pragma unroll
+    for (int q = 0; q < NACC; ++q) { bq[q] = -1.0f; bpq[q] = q; }
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const float dx = px[p] - x1, dy = py[p] - y1, dz = pz[p] - z1;
       const float d = ((dx * dx) + (dy * dy)) + (dz * dz);
       const float d2 = __builtin_fminf(d, pt[p]);
       pt[p] = d2;
-      const bool gt = d2 > best;
-      best = gt ? d2 : best;
-      bestp = gt ? p : bestp;
+      const bool gt = d2 > bq[p % NACC];
+      bq[p % NACC] = gt ? d2 : bq[p % NACC];
+      bpq[p % NACC] = gt ? p : bpq[p % NACC];
     }
+    float best = bq[0];
+    int bestp = bpq[0];
+#pragma unroll
+    for (int q = 1; q < NACC; ++q) {  // the strict '>' of a single scan == larger value, then lower p
+      const bool take = bq[q] > best || (bq[q] == best && bpq[q] < bestp);
+      best = take ? bq[q] : best;
+      bestp = take ? bpq[q] : bestp;
+    }
+    if (best < 0.0f) bestp = 0;
     const unsigned key = key0 + (unsigned)bestp * keystep;
     old = block_argmax<BLOCK>(best, key, bs_log2, s_d, s_key, j & 1);
     if (tid == 0) out[j] = old;

@@ -1,0 +1,298 @@
+// fp32 MFMA GEMMs for the channel-last SharedMLP path (gfx950, v_mfma_f32_32x32x2_f32: exact fp32,
+// bit-for-bit a k-ordered fmaf chain, 64 FLOP/clk/SIMD).  Replaces the cuBLAS/cuDNN 1x1-convolution
+// calls the reference makes through torch (pytorch_utils.py:61-113) for
+//
+//   forward   Y[p,n]  = sum_k f(X[p,k]) W[n,k]     f = identity | relu(a_k x + b_k)  (previous layer's
+//                                                   BatchNorm+ReLU applied while loading, so the
+//                                                   normalised activation is never materialised)
+//             + epilogue: per-column sum / sum of squares of Y (the BatchNorm batch statistics) as
+//               fp64 atomics, one per column per workgroup
+//   dgrad     dX[p,k] = sum_n dY[p,n] Wt[k,n]      (Wt = W^T, K x N row-major, made by the caller)
+//   wgrad     dW[n,k] += sum_p dY[p,n] X[p,k]      reduction over the P rows split across workgroups,
+//                                                   fp32 atomics into dW (N x K, tiny)
+//
+// Tiling: 128 x 128 output tile per 256-thread workgroup (4 waves as 2 x 2, 64 x 64 each = 2 x 2 MFMA
+// tiles, 64 accumulator VGPRs), reduction step 16.  Both operand tiles live in LDS as [row][17] (pitch
+// 17 floats: the 32 lanes of a half-wave read one column of 32 rows -> 32 distinct banks), double
+// buffered, filled through registers one step ahead of the MFMAs.  The contraction is compute-bound
+// (16 KB of operands per 4.2 MFLOP), so plain ds_read_b32 operand fetches are off the critical path.
+#include "gb_common.h"
+
+namespace gb {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int GK = 16, GPITCH = GK + 1;  // block tile BM x BN (64 or 128 each) is a template parameter
+constexpr int GTPB = 256;
+
+// how an operand tile element (row r of the tile, reduction index k) is fetched from global memory
+enum { OP_KC = 0,     // src[(row0 + r) * ld + k]      (reduction index contiguous)
+       OP_RC = 1 };   // src[k * ld + (row0 + r)]      (tile-row index contiguous: transposed read)
+
+struct Operand {
+  const float *src;
+  long long rows;   // valid tile-row indices  [0, rows)
+  long long red;    // valid reduction indices [0, red)
+  long long ld;
+  const float *aff; // optional [a(red), b(red)]: value = relu(a_k * x + b_k)   (OP_KC only)
+};
+
+// registers holding one thread's share (ROWS/16 floats... i.e. 4 or 8) of a ROWS x 16 operand tile
+struct Frag { float v[8]; };
+
+template <int KIND, bool VEC, int ROWS>
+__device__ __forceinline__ void load_frag(const Operand &op, long long row0, long long k0, Frag &f) {
+  const int t = threadIdx.x;
+  constexpr int TPK = ROWS / 4;        // OP_RC: threads covering the tile rows of one reduction index
+  constexpr int KPP = GTPB / TPK;      // OP_RC: reduction indices per pass (8 or 16)
+#pragma unroll
+  for (int h = 0; h < ROWS / 64; ++h) {
+    if constexpr (KIND == OP_KC) {
+      const int r = (t >> 2) + 64 * h;          // 4 threads cover the 16 reduction indices of a row
+      const long long row = row0 + r;
+      const long long k = k0 + 4 * (t & 3);
+      const float *p = op.src + row * op.ld + k;
+      const bool rok = row < op.rows;
+      if (VEC && rok && k + 3 < op.red) {
+        const float4 q = *reinterpret_cast<const float4 *>(p);
+        f.v[4 * h + 0] = q.x; f.v[4 * h + 1] = q.y; f.v[4 * h + 2] = q.z; f.v[4 * h + 3] = q.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f.v[4 * h + e] = (rok && k + e < op.red) ? p[e] : 0.f;
+      }
+      if (op.aff) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (rok && k + e < op.red) {
+            const float z = op.aff[k + e] * f.v[4 * h + e] + op.aff[op.red + k + e];
+            f.v[4 * h + e] = z > 0.f ? z : 0.f;
+          }
+        }
+      }
+    } else {
+      const long long k = k0 + (t / TPK) + KPP * h;
+      const long long row = row0 + 4 * (t % TPK);
+      const float *p = op.src + k * op.ld + row;
+      const bool kok = k < op.red;
+      if (VEC && kok && row + 3 < op.rows) {
+        const float4 q = *reinterpret_cast<const float4 *>(p);
+        f.v[4 * h + 0] = q.x; f.v[4 * h + 1] = q.y; f.v[4 * h + 2] = q.z; f.v[4 * h + 3] = q.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f.v[4 * h + e] = (kok && row + e < op.rows) ? p[e] : 0.f;
+      }
+    }
+  }
+}
+
+template <int KIND, int ROWS>
+__device__ __forceinline__ void store_frag(float *lds, const Frag &f) {
+  const int t = threadIdx.x;
+  constexpr int TPK = ROWS / 4;
+  constexpr int KPP = GTPB / TPK;
+#pragma unroll
+  for (int h = 0; h < ROWS / 64; ++h) {
+    if constexpr (KIND == OP_KC) {
+      float *d = lds + ((t >> 2) + 64 * h) * GPITCH + 4 * (t & 3);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] = f.v[4 * h + e];
+    } else {
+      float *d = lds + (4 * (t % TPK)) * GPITCH + (t / TPK) + KPP * h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e * GPITCH] = f.v[4 * h + e];
+    }
+  }
+}
+
+enum { EPI_STORE = 0, EPI_STORE_STATS = 1, EPI_ATOMIC = 2 };
+
+// D[i,j] = sum_k A[i,k] B[j,k] over k in [kbeg, kend);  D is (a.rows x b.rows) with leading dim ldd
+template <int KA, int KB, bool VA, bool VB, int EPI, int GM, int GN>
+__global__ __launch_bounds__(GTPB) void gemm_cl_kernel(Operand a, Operand b, float *__restrict__ d, long long ldd,
+                                                        double *__restrict__ stats, long long kchunk,
+                                                        int tiles_n) {
+  __shared__ float lds_a[2][GM * GPITCH];
+  __shared__ float lds_b[2][GN * GPITCH];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const long long m0 = (long long)(blockIdx.x / tiles_n) * GM;
+  const long long n0 = (long long)(blockIdx.x % tiles_n) * GN;
+  const long long kbeg = (long long)blockIdx.y * kchunk;
+  long long kend = kbeg + kchunk;
+  if (kend > a.red) kend = a.red;
+
+  constexpr int MT = GM / 64, NT = GN / 64;  // 32x32 MFMA tiles per wave (waves are 2 x 2)
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  Frag fa, fb;
+  load_frag<KA, VA, GM>(a, m0, kbeg, fa);
+  load_frag<KB, VB, GN>(b, n0, kbeg, fb);
+  store_frag<KA, GM>(lds_a[0], fa);
+  store_frag<KB, GN>(lds_b[0], fb);
+  __syncthreads();
+  int buf = 0;
+  for (long long k0 = kbeg; k0 < kend; k0 += GK) {
+    const bool more = k0 + GK < kend;
+    if (more) {
+      load_frag<KA, VA, GM>(a, m0, k0 + GK, fa);
+      load_frag<KB, VB, GN>(b, n0, k0 + GK, fb);
+    }
+    const float *pa = lds_a[buf] + (wm * (GM / 2) + (lane & 31)) * GPITCH + (lane >> 5);
+    const float *pb = lds_b[buf] + (wn * (GN / 2) + (lane & 31)) * GPITCH + (lane >> 5);
+#pragma unroll
+    for (int s = 0; s < GK / 2; ++s) {
+      float av[MT], bv[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) av[i] = pa[i * 32 * GPITCH + 2 * s];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bv[j] = pb[j * 32 * GPITCH + 2 * s];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      store_frag<KA, GM>(lds_a[buf ^ 1], fa);
+      store_frag<KB, GN>(lds_b[buf ^ 1], fb);
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // epilogue: acc[mt][nt][reg] is D[m0 + wm*64 + mt*32 + (reg&3) + 8*(reg>>2) + 4*(lane>>5)][n0 + wn*64 + nt*32 + (lane&31)]
+  float csum[NT], csq[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const long long col = n0 + wn * (GN / 2) + nt * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long long row = m0 + wm * (GM / 2) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const float v = acc[mt][nt][r];
+        if (row < a.rows && col < b.rows) {
+          if constexpr (EPI == EPI_ATOMIC) atomicAdd(d + row * ldd + col, v);
+          else d[row * ldd + col] = v;
+        }
+        if constexpr (EPI == EPI_STORE_STATS) { csum[nt] += v; csq[nt] += v * v; }  // padded rows/cols are exact zeros
+      }
+    }
+  if constexpr (EPI == EPI_STORE_STATS) {
+    // column partials: lanes l and l+32 hold the same column; then the two M-waves (wm) via LDS
+    __shared__ float s_col[2][2][GN];  // [sum|sq][wm][col in tile]
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      csum[nt] += __shfl_xor(csum[nt], 32);
+      csq[nt] += __shfl_xor(csq[nt], 32);
+      if (lane < 32) {
+        s_col[0][wm][wn * (GN / 2) + nt * 32 + lane] = csum[nt];
+        s_col[1][wm][wn * (GN / 2) + nt * 32 + lane] = csq[nt];
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < GN) {
+      const long long col = n0 + threadIdx.x;
+      if (col < b.rows) {
+        atomicAdd(stats + col, (double)s_col[0][0][threadIdx.x] + (double)s_col[0][1][threadIdx.x]);
+        atomicAdd(stats + b.rows + col, (double)s_col[1][0][threadIdx.x] + (double)s_col[1][1][threadIdx.x]);
+      }
+    }
+  }
+}
+
+static inline bool aligned16(const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
+
+template <int KA, int KB, int EPI, int BM, int BN>
+static void launch_tile(const Operand &a, const Operand &b, bool va, bool vb, float *d, long long ldd, double *stats,
+                        long long kchunk, unsigned chunks, hipStream_t s) {
+  const int tiles_n = (int)((b.rows + BN - 1) / BN);
+  const long long tiles_m = (a.rows + BM - 1) / BM;
+  const dim3 grid((unsigned)(tiles_m * tiles_n), chunks);
+#define GB_L(VA_, VB_)                                                                                          \
+  hipLaunchKernelGGL((gemm_cl_kernel<KA, KB, VA_, VB_, EPI, BM, BN>), grid, dim3(GTPB), 0, s, a, b, d, ldd, stats, \
+                     kchunk, tiles_n)
+  if (va && vb) GB_L(true, true);
+  else if (va) GB_L(true, false);
+  else if (vb) GB_L(false, true);
+  else GB_L(false, false);
+#undef GB_L
+}
+
+// tile choice: 64-wide where the dimension is <= 64 (a 128 tile would waste half of its MFMAs) and
+// 64-tall when 128-tall tiles would leave most of the 256 CUs without a workgroup
+template <int KA, int KB, int EPI>
+static void launch_gemm(const Operand &a, const Operand &b, bool va, bool vb, float *d, long long ldd, double *stats,
+                        long long kchunk, unsigned chunks, hipStream_t s) {
+  const bool bn64 = b.rows <= 64;
+  const long long blocks128 = ((a.rows + 127) / 128) * ((b.rows + (bn64 ? 63 : 127)) / (bn64 ? 64 : 128)) * chunks;
+  const bool bm64 = a.rows <= 64 || blocks128 < 512;
+  if (bm64 && bn64) launch_tile<KA, KB, EPI, 64, 64>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s);
+  else if (bm64) launch_tile<KA, KB, EPI, 64, 128>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s);
+  else if (bn64) launch_tile<KA, KB, EPI, 128, 64>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s);
+  else launch_tile<KA, KB, EPI, 128, 128>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s);
+}
+
+}  // namespace gb
+
+using namespace gb;
+
+// Y (P,N) = f(X (P,K)) W(N,K)^T ; aff (optional) = [a(K), b(K)] -> f = relu(a*x+b); stats (optional,
+// fp64 [2N], caller-zeroed) += column sums / sums of squares of Y
+extern "C" int gb_gemm_fwd(const float *x, const float *w, const float *aff, float *y, double *stats,
+                           long long P, int K, int N, void *stream) {
+  if (P < 0 || K < 1 || N < 1 || !x || !w || !y) return GB_EINVAL;
+  if (P == 0) return GB_OK;
+  if (P / 64 * ((N + 63) / 64) > 0x7fffffffLL) return GB_ERANGE;
+  Operand a = {x, P, K, K, aff};
+  Operand b = {w, N, K, K, nullptr};
+  const bool v = (K % 4 == 0) && aligned16(x) && aligned16(w);
+  const long long kchunk = (K + GK - 1) / GK * GK;
+  if (stats) launch_gemm<OP_KC, OP_KC, EPI_STORE_STATS>(a, b, v, v, y, N, stats, kchunk, 1, as_stream(stream));
+  else launch_gemm<OP_KC, OP_KC, EPI_STORE>(a, b, v, v, y, N, stats, kchunk, 1, as_stream(stream));
+  return check_launch("gb_gemm_fwd");
+}
+
+// dX (P,K) = dY (P,N) Wt(K,N)^T   with Wt = W^T stored (K,N) row-major
+extern "C" int gb_gemm_dgrad(const float *dy, const float *wt, float *dx, long long P, int K, int N,
+                             void *stream) {
+  if (P < 0 || K < 1 || N < 1 || !dy || !wt || !dx) return GB_EINVAL;
+  if (P == 0) return GB_OK;
+  if (P / 64 * ((K + 63) / 64) > 0x7fffffffLL) return GB_ERANGE;
+  Operand a = {dy, P, N, N, nullptr};
+  Operand b = {wt, K, N, N, nullptr};
+  const bool v = (N % 4 == 0) && aligned16(dy) && aligned16(wt);
+  launch_gemm<OP_KC, OP_KC, EPI_STORE>(a, b, v, v, dx, K, nullptr, (N + GK - 1) / GK * GK, 1, as_stream(stream));
+  return check_launch("gb_gemm_dgrad");
+}
+
+// dW (N,K) += dY (P,N)^T X (P,K) ; dW must be zeroed by the caller (accumulates with fp32 atomics)
+extern "C" int gb_gemm_wgrad(const float *dy, const float *x, float *dw, long long P, int K, int N,
+                             void *stream) {
+  if (P < 0 || K < 1 || N < 1 || !dy || !x || !dw) return GB_EINVAL;
+  if (P == 0) return GB_OK;
+  Operand a = {dy, N, P, N, nullptr};  // tile rows = n, reduction = p, element (n,p) at dy[p*N + n]
+  Operand b = {x, K, P, K, nullptr};   // tile rows = k, reduction = p, element (k,p) at x[p*K + k]
+  const long long tiles = (long long)((N + (N <= 64 ? 63 : 127)) / (N <= 64 ? 64 : 128)) *
+                          ((K + (K <= 64 ? 63 : 127)) / (K <= 64 ? 64 : 128));
+  // split the P reduction so that ~1024 workgroups exist, chunks a multiple of the reduction step
+  long long chunks = 1024 / tiles;
+  if (chunks < 1) chunks = 1;
+  long long kchunk = (P + chunks - 1) / chunks;
+  kchunk = (kchunk + GK - 1) / GK * GK;
+  if (kchunk < 256) kchunk = 256;
+  chunks = (P + kchunk - 1) / kchunk;
+  if (chunks > 65535) return GB_ERANGE;
+  const bool va = (N % 4 == 0) && aligned16(dy);
+  const bool vb = (K % 4 == 0) && aligned16(x);
+  launch_gemm<OP_RC, OP_RC, EPI_ATOMIC>(a, b, va, vb, dw, K, nullptr, kchunk, (unsigned)chunks, as_stream(stream));
+  return check_launch("gb_gemm_wgrad");
+}

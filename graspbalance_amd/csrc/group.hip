@@ -328,9 +328,45 @@ __global__ __launch_bounds__(TPB) void knn1_kernel(const float *__restrict__ ref
   if (q < nq) idx[(size_t)bi * nq + q] = (int64_t)besti + 1;
 }
 
+// ---- grasp-label gather (label_generation.py:60-99): for every seed r, with o = obj[r] (which
+// object's label tensor) and j = pt[r] (which grasp point of that object):
+//     out[r, v, :] = src_o[j, view_inds[o, v], :]          W floats per (point, view)
+// The reference first permutes EVERY object tensor along the view axis (index_select, 52 MB per
+// object) and then selects the seeds' rows; this composes the two index maps and touches only the
+// rows that are kept.  One workgroup per seed, 16-byte copies.
+__global__ __launch_bounds__(TPB) void label_gather_kernel(const float *const *__restrict__ srcs,
+                                                            const int32_t *__restrict__ obj,
+                                                            const int32_t *__restrict__ pt,
+                                                            const int64_t *__restrict__ view_inds,
+                                                            float *__restrict__ out, int V, int W) {
+  const int r = blockIdx.x;
+  const int o = obj[r];
+  const float *src = srcs[o] + (size_t)pt[r] * V * W;
+  const int64_t *vi = view_inds + (size_t)o * V;
+  float *dst = out + (size_t)r * V * W;
+  if ((W & 3) == 0) {
+    const int w4 = W >> 2;
+    for (int e = threadIdx.x; e < V * w4; e += TPB) {
+      const int v = e / w4, q = e % w4;
+      reinterpret_cast<float4 *>(dst)[e] = reinterpret_cast<const float4 *>(src + (size_t)vi[v] * W)[q];
+    }
+  } else {
+    for (int e = threadIdx.x; e < V * W; e += TPB) dst[e] = src[(size_t)vi[e / W] * W + e % W];
+  }
+}
+
 }  // namespace gb
 
 using namespace gb;
+
+extern "C" int gb_label_gather(const float *const *srcs, const int32_t *obj, const int32_t *pt,
+                               const int64_t *view_inds, float *out, int R, int V, int W, void *stream) {
+  if (R < 0 || V < 1 || W < 1 || !srcs || !obj || !pt || !view_inds || !out) return GB_EINVAL;
+  if (R == 0) return GB_OK;
+  hipLaunchKernelGGL(label_gather_kernel, dim3(R), dim3(TPB), 0, as_stream(stream), srcs, obj, pt, view_inds, out,
+                     V, W);
+  return check_launch("gb_label_gather");
+}
 
 extern "C" int gb_gather(const float *points, const int32_t *idx, float *out, int b, int c, int n,
                          int m, void *stream) {

@@ -18,11 +18,17 @@ from torch.autograd import Function
 from . import _lib
 
 _ENABLED = True
+_OWN_GEMM = True  # hand-written MFMA GEMMs (csrc/gemm_cl.hip); False = torch.mm (rocBLAS) for A/B timing
 
 
 def set_enabled(flag):
     global _ENABLED
     _ENABLED = bool(flag)
+
+
+def set_own_gemm(flag):
+    global _OWN_GEMM
+    _OWN_GEMM = bool(flag)
 
 
 def enabled(t):
@@ -96,12 +102,19 @@ class LinearBNAct(Function):
                 pool_ns):
         dev = X.device
         P, Cout = X.shape[0], W.shape[0]
-        Y = torch.mm(X, W.t())
         ab = torch.empty(4 * Cout, dtype=torch.float32, device=dev)
-        stats = None
-        if training:
-            stats = torch.zeros(2 * Cout, dtype=torch.float64, device=dev)
-            _call("gb_col_stats", dev, _lib.ptr(Y), P, Cout, _lib.ptr(stats), _s(Y))
+        stats = torch.zeros(2 * Cout, dtype=torch.float64, device=dev) if training else None
+        if _OWN_GEMM:
+            # hand-written fp32 MFMA GEMM; the BatchNorm column statistics come out of its epilogue
+            X = X.contiguous()
+            Wc = W.contiguous()
+            Y = torch.empty((P, Cout), dtype=torch.float32, device=dev)
+            _call("gb_gemm_fwd", dev, _lib.ptr(X), _lib.ptr(Wc), None, _lib.ptr(Y), _lib.ptr(stats), P, X.shape[1],
+                  Cout, _s(X))
+        else:
+            Y = torch.mm(X, W.t())
+            if training:
+                _call("gb_col_stats", dev, _lib.ptr(Y), P, Cout, _lib.ptr(stats), _s(Y))
         _call("gb_bn_finalize", dev, _lib.ptr(stats), P, Cout, _lib.ptr(gamma), _lib.ptr(beta), float(eps),
               float(momentum), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(ab), int(training), _s(Y))
         ctx.cfg = (P, Cout, bool(training), bool(relu), int(pool_ns))
@@ -148,8 +161,19 @@ class LinearBNAct(Function):
             # dgamma = sum dA*xhat, dbeta = sum dA — exactly the two column sums of pass 1
             dbeta = dstats[:Cout].float()
             dgamma = dstats[Cout:].float()
-        dW = _wgrad(dY, X) if ctx.needs_input_grad[1] else None
-        dX = torch.mm(dY, W) if ctx.needs_input_grad[0] else None
+        dW = dX = None
+        if _OWN_GEMM:
+            Cin = X.shape[1]
+            if ctx.needs_input_grad[1]:
+                dW = torch.zeros((Cout, Cin), dtype=torch.float32, device=dev)
+                _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(X), _lib.ptr(dW), P, Cin, Cout, _s(dY))
+            if ctx.needs_input_grad[0]:
+                Wt = W.t().contiguous()
+                dX = torch.empty((P, Cin), dtype=torch.float32, device=dev)
+                _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(Wt), _lib.ptr(dX), P, Cin, Cout, _s(dY))
+        else:
+            dW = _wgrad(dY, X) if ctx.needs_input_grad[1] else None
+            dX = torch.mm(dY, W) if ctx.needs_input_grad[0] else None
         return dX, dW, dgamma, dbeta, dres, None, None, None, None, None, None, None
 
 

@@ -28,7 +28,115 @@ def _assign_views(poses, V):
     return myknn(trans.contiguous(), query, k=1).view(poses.size(0), V) - 1
 
 
+_PTR_CACHE = {}
+
+
+def _pointer_table(tensors, device):
+    """Device array of the tensors' data pointers (cached while the same tensors are reused)."""
+    key = tuple(t.data_ptr() for t in tensors)
+    tab = _PTR_CACHE.get(key)
+    if tab is None:
+        if len(_PTR_CACHE) > 64:
+            _PTR_CACHE.clear()
+        tab = torch.tensor(key, dtype=torch.int64, device=device)
+        _PTR_CACHE[key] = tab
+    return tab
+
+
+def _label_gather(tensors, obj, pt, view_inds, V, W):
+    """out[r,v,:] = tensors[obj[r]][pt[r], view_inds[obj[r], v], :] through the fused HIP gather."""
+    from . import _lib
+    dev = obj.device
+    out = torch.empty((obj.numel(), V, W), dtype=torch.float32, device=dev)
+    tab = _pointer_table(tensors, dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().gb_label_gather(_lib.ptr(tab), _lib.ptr(obj), _lib.ptr(pt), _lib.ptr(view_inds),
+                                              _lib.ptr(out), obj.numel(), V, W, _lib.current_stream(dev)),
+                   "label_gather")
+    return out
+
+
+def _finish_labels(end_points, batch, batch_size, num_samples):
+    labels = batch['label']  # (B,Ns,V,A,D)
+    V, A, D = labels.shape[2:]
+    widths = batch['offset'][:, :, :, :, :, 2]
+    label_mask = (labels > 0) & (widths <= GRASP_MAX_WIDTH)
+    u_max = labels.max()
+    # == labels[mask] = log(u_max / labels[mask]); labels[~mask] = 0   (no boolean-index host sync)
+    labels = torch.where(label_mask, torch.log(u_max / labels.clamp_min(1e-30)), torch.zeros_like(labels))
+    view_scores, _ = labels.view(batch_size, num_samples, V, A * D).max(dim=-1)
+    end_points['batch_grasp_point'] = batch['point']
+    end_points['batch_grasp_view'] = batch['view']
+    end_points['batch_grasp_view_rot'] = batch['view_rot']
+    end_points['batch_grasp_label'] = labels
+    end_points['batch_grasp_offset'] = batch['offset']
+    end_points['batch_grasp_tolerance'] = batch['tolerance']
+    end_points['batch_grasp_view_label'] = view_scores.float()
+    return end_points
+
+
+def _process_grasp_labels_fused(end_points):
+    """Same results as the per-object composition below with the two index maps (view permutation, then
+    nearest grasp point per seed) composed: only the (B,Ns) rows that are kept are ever copied."""
+    seed_xyzs = end_points['fp2_xyz']
+    B, Ns, _ = seed_xyzs.shape
+    dev = seed_xyzs.device
+    poses_l = end_points['object_poses_list']
+    labels_l = [t for per in end_points['grasp_labels_list'] for t in per]
+    offsets_l = [t for per in end_points['grasp_offsets_list'] for t in per]
+    tol_l = [t for per in end_points['grasp_tolerance_list'] for t in per]
+    all_poses = torch.stack([p for poses in poses_l for p in poses], 0)          # (Kt,3,4)
+    _, V, A, D = labels_l[0].shape
+    view_inds = _assign_views(all_poses, V).contiguous()                         # (Kt,V) int64
+    views = generate_grasp_views(V).to(dev)
+    rot_template = batch_viewpoint_params_to_matrix(-views, torch.zeros(V, dtype=views.dtype, device=dev))
+    R = all_poses[:, :3, :3]
+    views_trans = torch.matmul(R, views.T).transpose(1, 2)                       # (Kt,V,3)
+    rot_trans = torch.matmul(R.unsqueeze(1), rot_template.unsqueeze(0))          # (Kt,V,3,3)
+    views_sel = torch.gather(views_trans, 1, view_inds.unsqueeze(-1).expand(-1, -1, 3))
+    rot_sel = torch.gather(rot_trans, 1, view_inds.view(-1, V, 1, 1).expand(-1, -1, 3, 3))
+    obj_of_seed, pt_of_seed, points = [], [], []
+    k0 = 0
+    for i in range(B):
+        pts, oid, loc = [], [], []
+        for k, pose in enumerate(poses_l[i]):
+            gp = end_points['grasp_points_list'][i][k]
+            pts.append(transform_point_cloud(gp, pose, '3x4'))
+            oid.append(torch.full((gp.size(0),), k0 + k, dtype=torch.int32, device=dev))
+            loc.append(torch.arange(gp.size(0), dtype=torch.int32, device=dev))
+        k0 += len(poses_l[i])
+        pts, oid, loc = torch.cat(pts, 0), torch.cat(oid, 0), torch.cat(loc, 0)
+        nn_inds = _nearest(pts, seed_xyzs[i])
+        points.append(torch.index_select(pts, 0, nn_inds))
+        obj_of_seed.append(torch.index_select(oid, 0, nn_inds))
+        pt_of_seed.append(torch.index_select(loc, 0, nn_inds))
+    obj = torch.cat(obj_of_seed, 0).contiguous()
+    pt = torch.cat(pt_of_seed, 0).contiguous()
+    objl = obj.long()
+    batch = {
+        'point': torch.stack(points, 0),
+        'view': torch.index_select(views_sel, 0, objl).view(B, Ns, V, 3),
+        'view_rot': torch.index_select(rot_sel, 0, objl).view(B, Ns, V, 3, 3),
+        'label': _label_gather(labels_l, obj, pt, view_inds, V, A * D).view(B, Ns, V, A, D),
+        'offset': _label_gather(offsets_l, obj, pt, view_inds, V, A * D * 3).view(B, Ns, V, A, D, 3),
+        'tolerance': _label_gather(tol_l, obj, pt, view_inds, V, A * D).view(B, Ns, V, A, D),
+    }
+    return _finish_labels(end_points, batch, B, Ns)
+
+
+def _fusable(end_points):
+    if not end_points['fp2_xyz'].is_cuda:
+        return False
+    ts = [t for key in ('grasp_labels_list', 'grasp_offsets_list', 'grasp_tolerance_list')
+          for per in end_points[key] for t in per]
+    shape = ts[0].shape[1:4]
+    return all(t.is_contiguous() and t.dtype == torch.float32 and t.data_ptr() % 16 == 0 for t in ts) \
+        and all(t.shape[1:4] == shape for t in ts)
+
+
 def process_grasp_labels(end_points):
+    if _fusable(end_points):
+        return _process_grasp_labels_fused(end_points)
     seed_xyzs = end_points['fp2_xyz']  # (B,Ns,3)
     batch_size, num_samples, _ = seed_xyzs.size()
     per_cloud = {k: [] for k in ('point', 'view', 'view_rot', 'label', 'offset', 'tolerance')}
@@ -68,22 +176,7 @@ def process_grasp_labels(end_points):
         for k in per_cloud:
             per_cloud[k].append(torch.index_select(merged[k], 0, nn_inds))
     batch = {k: torch.stack(v, 0) for k, v in per_cloud.items()}
-    labels = batch['label']  # (B,Ns,V,A,D)
-    V, A, D = labels.shape[2:]
-    widths = batch['offset'][:, :, :, :, :, 2]
-    label_mask = (labels > 0) & (widths <= GRASP_MAX_WIDTH)
-    u_max = labels.max()
-    labels[label_mask] = torch.log(u_max / labels[label_mask])
-    labels[~label_mask] = 0
-    view_scores, _ = labels.view(batch_size, num_samples, V, A * D).max(dim=-1)
-    end_points['batch_grasp_point'] = batch['point']
-    end_points['batch_grasp_view'] = batch['view']
-    end_points['batch_grasp_view_rot'] = batch['view_rot']
-    end_points['batch_grasp_label'] = labels
-    end_points['batch_grasp_offset'] = batch['offset']
-    end_points['batch_grasp_tolerance'] = batch['tolerance']
-    end_points['batch_grasp_view_label'] = view_scores.float()
-    return end_points
+    return _finish_labels(end_points, batch, batch_size, num_samples)
 
 
 def _take_view(t, top_view_inds):

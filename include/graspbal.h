@@ -134,6 +134,14 @@ int gb_three_interpolate_grad(const float *grad_out, const int32_t *idx, const f
 int gb_knn1(const float *ref, const float *query, int64_t *idx, int b, int dim, int nref, int nq,
             void *stream);
 
+/* Grasp-label gather for the training-time label matching (label_generation.py:60-99):
+ *   out[r, v, :] = srcs[obj[r]][pt[r], view_inds[obj[r], v], :]     (W floats per (point, view))
+ * srcs: DEVICE array of device pointers, one (Np_o, V, W) tensor per object; obj/pt (R) int32;
+ * view_inds (n_objects, V) int64; out (R, V, W).  Composes the reference's two index_selects (views
+ * then seeds) so only the kept rows are copied.                                                   */
+int gb_label_gather(const float *const *srcs, const int32_t *obj, const int32_t *pt,
+                    const int64_t *view_inds, float *out, int R, int V, int W, void *stream);
+
 /* ---- channel-last fused pieces of the SharedMLP (1x1 conv + BatchNorm + ReLU + max over nsample) ----
  * No reference launcher corresponds one-to-one: these replace the torch passes the reference runs
  * around its cuBLAS/cuDNN GEMMs — QueryAndGroup's cat / sub / div (pointnet2_utils.py:178-192),
@@ -177,6 +185,18 @@ int gb_bn_bwd_stats_pool(const float *dout, const float *out, const int32_t *arg
 int gb_bn_bwd_apply_pool(const float *dout, const float *out, const int32_t *arg, const float *y,
                          const float *ab, const double *dstats, long long R, int ns, int C, int training,
                          float *dy, void *stream);
+
+/* ---- fp32 MFMA GEMMs of the channel-last SharedMLP (csrc/gemm_cl.hip) — replace the cuBLAS/cuDNN
+ * 1x1 convolutions the reference reaches through torch (pytorch_utils.py:61-113) ------------------- */
+/* Y (P,N) = f(X (P,K)) W(N,K)^T.  aff (optional) = [a(K), b(K)]: f(x) = relu(a_k x + b_k), i.e. the
+ * previous layer's BatchNorm + ReLU applied while loading.  stats (optional, fp64 [2N], caller-zeroed)
+ * += column sums and sums of squares of Y (BatchNorm batch statistics).                            */
+int gb_gemm_fwd(const float *x, const float *w, const float *aff, float *y, double *stats, long long P,
+                int K, int N, void *stream);
+/* dX (P,K) = dY (P,N) W(N,K), given Wt = W^T stored (K,N) row-major */
+int gb_gemm_dgrad(const float *dy, const float *wt, float *dx, long long P, int K, int N, void *stream);
+/* dW (N,K) += dY (P,N)^T X (P,K); accumulates (fp32 atomics, reduction over P split across workgroups) */
+int gb_gemm_wgrad(const float *dy, const float *x, float *dw, long long P, int K, int N, void *stream);
 
 #ifdef __cplusplus
 }

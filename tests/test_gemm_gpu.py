@@ -1,0 +1,58 @@
+"""GPU: the hand-written fp32 MFMA GEMMs (csrc/gemm_cl.hip) against fp64 torch references.
+fp32 MFMA is an exact k-ordered fmaf chain, so the error bound is the usual fp32 dot-product bound."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+SHAPES = [(1000, 3, 64), (4096, 64, 64), (5000, 131, 128), (777, 259, 256), (2048, 128, 512), (130, 512, 128),
+          (8192, 16, 8), (1, 5, 3), (33000, 64, 128)]
+
+
+def _lib():
+    from graspbalance_amd import _lib
+    return _lib
+
+
+@pytest.mark.parametrize("P,K,N", SHAPES)
+def test_gemm_fwd_stats_and_affine(P, K, N):
+    L = _lib()
+    torch.manual_seed(P + K + N)
+    X = torch.randn(P, K, device=DEV)
+    W = torch.randn(N, K, device=DEV) / K ** 0.5
+    Y = torch.empty(P, N, device=DEV)
+    stats = torch.zeros(2 * N, dtype=torch.float64, device=DEV)
+    L.check(L.lib().gb_gemm_fwd(L.ptr(X), L.ptr(W), None, L.ptr(Y), L.ptr(stats), P, K, N, None), "fwd")
+    torch.cuda.synchronize()
+    ref = X.double() @ W.double().t()
+    scale = float(ref.abs().max()) + 1e-12
+    assert float((Y.double() - ref).abs().max()) / scale < 2e-6
+    assert torch.allclose(stats[:N], Y.double().sum(0), rtol=1e-6, atol=1e-6 * P ** 0.5)
+    assert torch.allclose(stats[N:], (Y.double() ** 2).sum(0), rtol=1e-6, atol=1e-9)
+    # fused BatchNorm+ReLU prologue of the next layer
+    aff = torch.cat([torch.randn(K, device=DEV), torch.randn(K, device=DEV)])
+    Y2 = torch.empty(P, N, device=DEV)
+    L.check(L.lib().gb_gemm_fwd(L.ptr(X), L.ptr(W), L.ptr(aff), L.ptr(Y2), None, P, K, N, None), "fwd aff")
+    torch.cuda.synchronize()
+    ref2 = torch.relu(aff[:K] * X + aff[K:]).double() @ W.double().t()
+    assert float((Y2.double() - ref2).abs().max()) / (float(ref2.abs().max()) + 1e-12) < 2e-6
+
+
+@pytest.mark.parametrize("P,K,N", SHAPES)
+def test_gemm_dgrad_and_wgrad(P, K, N):
+    L = _lib()
+    torch.manual_seed(P * 3 + K + N)
+    X = torch.randn(P, K, device=DEV)
+    W = torch.randn(N, K, device=DEV)
+    dY = torch.randn(P, N, device=DEV)
+    Wt = W.t().contiguous()
+    dX = torch.empty(P, K, device=DEV)
+    L.check(L.lib().gb_gemm_dgrad(L.ptr(dY), L.ptr(Wt), L.ptr(dX), P, K, N, None), "dgrad")
+    dW = torch.zeros(N, K, device=DEV)
+    L.check(L.lib().gb_gemm_wgrad(L.ptr(dY), L.ptr(X), L.ptr(dW), P, K, N, None), "wgrad")
+    torch.cuda.synchronize()
+    rx = dY.double() @ W.double()
+    rw = dY.double().t() @ X.double()
+    assert float((dX.double() - rx).abs().max()) / (float(rx.abs().max()) + 1e-12) < 2e-6
+    assert float((dW.double() - rw).abs().max()) / (float(rw.abs().max()) + 1e-12) < 1e-5

@@ -77,3 +77,23 @@ def test_full_size_forward_properties():
     assert float((eye - torch.eye(3, device=DEV)).abs().max()) < 1e-5  # rotations stay orthonormal
     preds = pred_decode(out)
     assert len(preds) == 2 and preds[0].shape[1] == 17
+
+
+def test_fused_label_matching_equals_per_object_composition(monkeypatch):
+    """gb_label_gather path of process_grasp_labels == the reference-style two-stage index_select."""
+    from graspbalance_amd import label_generation as lg
+    from graspbalance_amd.synthetic import make_training_batch
+    batch = make_training_batch(range(2), num_point=6000, num_objects=3, grasp_points_per_object=40, num_view=60,
+                                device=DEV)
+    ep = dict(batch)
+    ep['input_xyz'] = batch['point_clouds']
+    ep['fp2_xyz'] = batch['point_clouds'][:, :256].contiguous()
+    assert lg._fusable(ep)
+    fused = lg.process_grasp_labels(dict(ep))
+    monkeypatch.setattr(lg, "_fusable", lambda e: False)
+    plain = lg.process_grasp_labels(dict(ep))
+    for k in ('batch_grasp_point', 'batch_grasp_label', 'batch_grasp_offset', 'batch_grasp_tolerance',
+              'batch_grasp_view_label'):
+        assert torch.equal(fused[k], plain[k]), k
+    for k in ('batch_grasp_view', 'batch_grasp_view_rot'):
+        assert torch.allclose(fused[k], plain[k], rtol=0, atol=1e-6), k

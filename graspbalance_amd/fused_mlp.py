@@ -39,9 +39,10 @@ def _s(t):
     return _lib.current_stream(t.device)
 
 
-def _call(name, dev, *args):
+def _call(name, dev, *args, meta=None):
     with torch.cuda.device(dev):
-        _lib.check(getattr(_lib.lib(), name)(*args), name)
+        fn = getattr(_lib.lib(), name)
+        _lib.check(_lib.timed(name, dev, meta, lambda: fn(*args)), name)
 
 
 def _wgrad(dY, X):
@@ -110,7 +111,7 @@ class LinearBNAct(Function):
             Wc = W.contiguous()
             Y = torch.empty((P, Cout), dtype=torch.float32, device=dev)
             _call("gb_gemm_fwd", dev, _lib.ptr(X), _lib.ptr(Wc), None, _lib.ptr(Y), _lib.ptr(stats), P, X.shape[1],
-                  Cout, _s(X))
+                  Cout, _s(X), meta={"flop": 2.0 * P * X.shape[1] * Cout})
         else:
             Y = torch.mm(X, W.t())
             if training:
@@ -166,11 +167,13 @@ class LinearBNAct(Function):
             Cin = X.shape[1]
             if ctx.needs_input_grad[1]:
                 dW = torch.zeros((Cout, Cin), dtype=torch.float32, device=dev)
-                _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(X), _lib.ptr(dW), P, Cin, Cout, _s(dY))
+                _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(X), _lib.ptr(dW), P, Cin, Cout, _s(dY),
+                      meta={"flop": 2.0 * P * Cin * Cout})
             if ctx.needs_input_grad[0]:
                 Wt = W.t().contiguous()
                 dX = torch.empty((P, Cin), dtype=torch.float32, device=dev)
-                _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(Wt), _lib.ptr(dX), P, Cin, Cout, _s(dY))
+                _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(Wt), _lib.ptr(dX), P, Cin, Cout, _s(dY),
+                      meta={"flop": 2.0 * P * Cin * Cout})
         else:
             dW = _wgrad(dY, X) if ctx.needs_input_grad[1] else None
             dX = torch.mm(dY, W) if ctx.needs_input_grad[0] else None

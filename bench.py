@@ -35,6 +35,17 @@ def fps_algorithmic_bytes(b, n, m):
     return b * (20.0 * n * (m - 1) + 4.0 * m)
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 corrections applied);
+    None when the file is absent.  Counters cannot be collected from inside this process."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return round(json.load(f)[kernel]["hbm_bytes_per_launch"], 1)
+    except Exception:
+        return None
+
+
 def cpu_baseline(num_threads):
     """The same train step on the host cores, with the CPU oracle (oracle/graspbal_oracle.c) standing
     in for the HIP extension and torch-CPU for the MLPs: a bounded sample of ONE step on ONE cloud."""
@@ -130,7 +141,7 @@ def main():
             achieved = flop / (ms * 1e-3) / 1e12
             roofline = {"kernel": "gemm_cl_kernel (v_mfma_f32_32x32x2_f32; fwd+stats, dgrad, wgrad)", "bound": "mfma",
                         "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                        "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic("gemm_cl_kernel"),
                         "launch_ms": round(ms / len(gemm), 4), "launches": len(gemm),
                         "ms_per_step": round(ms / args.steps, 3), "gflop_per_launch": round(flop / len(gemm) / 1e9, 3)}
         # largest single launch of the step: the first-level FPS (HBM class, streaming-model bytes)
@@ -142,7 +153,7 @@ def main():
             achieved = fps_algorithmic_bytes(meta["b"], meta["n"], meta["m"]) / (mean_ms * 1e-3) / 1e9
             roofline_fps = {"kernel": "fps_reg_kernel<1024,20> (gb_fps %d->%d, b=%d)" % (meta["n"], meta["m"], meta["b"]),
                             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("fps_reg_kernel<1024, 20>"),
                             "launch_ms": round(mean_ms, 4), "launches": len(big)}
         out = {
             "metric": "point-clouds/sec fwd+bwd, 20k-pt GraspNet scene",

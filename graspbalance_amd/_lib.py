@@ -41,7 +41,7 @@ SIGNATURES = {
     "gb_group_concat_cl": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
     "gb_group_concat_cl_grad": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gb_col_stats": [_P, _L, _I, _P, _P],
-    "gb_bn_finalize": [_P, _L, _I, _P, _P, _F, _F, _P, _P, _P, _I, _P],
+    "gb_bn_finalize": [_P, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _I, _P],
     "gb_affine_act": [_P, _P, _P, _P, _L, _I, _I, _P],
     "gb_affine_relu_maxpool": [_P, _P, _P, _P, _L, _I, _I, _P],
     "gb_bn_bwd_stats": [_P, _P, _P, _P, _L, _I, _I, _P, _P],
@@ -49,7 +49,7 @@ SIGNATURES = {
     "gb_bn_bwd_stats_pool": [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P],
     "gb_bn_bwd_apply_pool": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P],
     "gb_label_gather": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
-    "gb_gemm_fwd": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "gb_gemm_fwd": [_P, _P, _P, _P, _P, _I, _L, _I, _I, _P],
     "gb_gemm_dgrad": [_P, _P, _P, _L, _I, _I, _P],
     "gb_gemm_wgrad": [_P, _P, _P, _L, _I, _I, _P],
 }

@@ -97,9 +97,9 @@ __device__ __forceinline__ void store_frag(float *lds, const Frag &f) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) d[e] = f.v[4 * h + e];
     } else {
-      float *d = lds + (4 * (t % TPK)) * GPITCH + (t / TPK) + KPP * h;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) d[e * GPITCH] = f.v[4 * h + e];
+      // row-contiguous operands keep the global order in LDS: [k][ROWS + 4], one 16-byte store
+      float *d = lds + ((t / TPK) + KPP * h) * (ROWS + 4) + 4 * (t % TPK);
+      *reinterpret_cast<float4 *>(d) = make_float4(f.v[4 * h + 0], f.v[4 * h + 1], f.v[4 * h + 2], f.v[4 * h + 3]);
     }
   }
 }
@@ -110,9 +110,14 @@ enum { EPI_STORE = 0, EPI_STORE_STATS = 1, EPI_ATOMIC = 2 };
 template <int KA, int KB, bool VA, bool VB, int EPI, int GM, int GN>
 __global__ __launch_bounds__(GTPB) void gemm_cl_kernel(Operand a, Operand b, float *__restrict__ d, long long ldd,
                                                         double *__restrict__ stats, long long kchunk,
-                                                        int tiles_n) {
-  __shared__ float lds_a[2][GM * GPITCH];
-  __shared__ float lds_b[2][GN * GPITCH];
+                                                        int tiles_n, int stat_slots) {
+  // LDS image per operand kind: OP_KC [row][17] (element (r,k) at r*17 + k), OP_RC [k][rows+4]
+  constexpr int A_RS = KA == OP_KC ? GPITCH : 1, A_KS = KA == OP_KC ? 1 : GM + 4;  // row / k strides
+  constexpr int B_RS = KB == OP_KC ? GPITCH : 1, B_KS = KB == OP_KC ? 1 : GN + 4;
+  constexpr int A_SZ = KA == OP_KC ? GM * GPITCH : GK * (GM + 4);
+  constexpr int B_SZ = KB == OP_KC ? GN * GPITCH : GK * (GN + 4);
+  __shared__ __attribute__((aligned(16))) float lds_a[2][A_SZ];
+  __shared__ __attribute__((aligned(16))) float lds_b[2][B_SZ];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const long long m0 = (long long)(blockIdx.x / tiles_n) * GM;
@@ -143,15 +148,15 @@ __global__ __launch_bounds__(GTPB) void gemm_cl_kernel(Operand a, Operand b, flo
       load_frag<KA, VA, GM>(a, m0, k0 + GK, fa);
       load_frag<KB, VB, GN>(b, n0, k0 + GK, fb);
     }
-    const float *pa = lds_a[buf] + (wm * (GM / 2) + (lane & 31)) * GPITCH + (lane >> 5);
-    const float *pb = lds_b[buf] + (wn * (GN / 2) + (lane & 31)) * GPITCH + (lane >> 5);
+    const float *pa = lds_a[buf] + (wm * (GM / 2) + (lane & 31)) * A_RS + (lane >> 5) * A_KS;
+    const float *pb = lds_b[buf] + (wn * (GN / 2) + (lane & 31)) * B_RS + (lane >> 5) * B_KS;
 #pragma unroll
     for (int s = 0; s < GK / 2; ++s) {
       float av[MT], bv[NT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) av[i] = pa[i * 32 * GPITCH + 2 * s];
+      for (int i = 0; i < MT; ++i) av[i] = pa[i * 32 * A_RS + 2 * s * A_KS];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bv[j] = pb[j * 32 * GPITCH + 2 * s];
+      for (int j = 0; j < NT; ++j) bv[j] = pb[j * 32 * B_RS + 2 * s * B_KS];
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -202,8 +207,11 @@ __global__ __launch_bounds__(GTPB) void gemm_cl_kernel(Operand a, Operand b, flo
     if (threadIdx.x < GN) {
       const long long col = n0 + threadIdx.x;
       if (col < b.rows) {
-        atomicAdd(stats + col, (double)s_col[0][0][threadIdx.x] + (double)s_col[0][1][threadIdx.x]);
-        atomicAdd(stats + b.rows + col, (double)s_col[1][0][threadIdx.x] + (double)s_col[1][1][threadIdx.x]);
+        // stats is [stat_slots][2N]: row tiles spread over the slots so that thousands of workgroups
+        // do not serialise on the same 2N addresses (same-address atomics run ~14x slower on MI355X)
+        double *st = stats + (size_t)((blockIdx.x / tiles_n) % stat_slots) * 2 * b.rows;
+        atomicAdd(st + col, (double)s_col[0][0][threadIdx.x] + (double)s_col[0][1][threadIdx.x]);
+        atomicAdd(st + b.rows + col, (double)s_col[1][0][threadIdx.x] + (double)s_col[1][1][threadIdx.x]);
       }
     }
   }
@@ -213,13 +221,13 @@ static inline bool aligned16(const void *p) { return reinterpret_cast<uintptr_t>
 
 template <int KA, int KB, int EPI, int BM, int BN>
 static void launch_tile(const Operand &a, const Operand &b, bool va, bool vb, float *d, long long ldd, double *stats,
-                        long long kchunk, unsigned chunks, hipStream_t s) {
+                        long long kchunk, unsigned chunks, hipStream_t s, int stat_slots) {
   const int tiles_n = (int)((b.rows + BN - 1) / BN);
   const long long tiles_m = (a.rows + BM - 1) / BM;
   const dim3 grid((unsigned)(tiles_m * tiles_n), chunks);
 #define GB_L(VA_, VB_)                                                                                          \
   hipLaunchKernelGGL((gemm_cl_kernel<KA, KB, VA_, VB_, EPI, BM, BN>), grid, dim3(GTPB), 0, s, a, b, d, ldd, stats, \
-                     kchunk, tiles_n)
+                     kchunk, tiles_n, stat_slots)
   if (va && vb) GB_L(true, true);
   else if (va) GB_L(true, false);
   else if (vb) GB_L(false, true);
@@ -231,14 +239,14 @@ static void launch_tile(const Operand &a, const Operand &b, bool va, bool vb, fl
 // 64-tall when 128-tall tiles would leave most of the 256 CUs without a workgroup
 template <int KA, int KB, int EPI>
 static void launch_gemm(const Operand &a, const Operand &b, bool va, bool vb, float *d, long long ldd, double *stats,
-                        long long kchunk, unsigned chunks, hipStream_t s) {
+                        long long kchunk, unsigned chunks, hipStream_t s, int stat_slots = 1) {
   const bool bn64 = b.rows <= 64;
   const long long blocks128 = ((a.rows + 127) / 128) * ((b.rows + (bn64 ? 63 : 127)) / (bn64 ? 64 : 128)) * chunks;
   const bool bm64 = a.rows <= 64 || blocks128 < 512;
-  if (bm64 && bn64) launch_tile<KA, KB, EPI, 64, 64>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s);
-  else if (bm64) launch_tile<KA, KB, EPI, 64, 128>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s);
-  else if (bn64) launch_tile<KA, KB, EPI, 128, 64>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s);
-  else launch_tile<KA, KB, EPI, 128, 128>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s);
+  if (bm64 && bn64) launch_tile<KA, KB, EPI, 64, 64>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots);
+  else if (bm64) launch_tile<KA, KB, EPI, 64, 128>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots);
+  else if (bn64) launch_tile<KA, KB, EPI, 128, 64>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots);
+  else launch_tile<KA, KB, EPI, 128, 128>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots);
 }
 
 }  // namespace gb
@@ -246,17 +254,17 @@ static void launch_gemm(const Operand &a, const Operand &b, bool va, bool vb, fl
 using namespace gb;
 
 // Y (P,N) = f(X (P,K)) W(N,K)^T ; aff (optional) = [a(K), b(K)] -> f = relu(a*x+b); stats (optional,
-// fp64 [2N], caller-zeroed) += column sums / sums of squares of Y
+// fp64 [stat_slots][2N], caller-zeroed) += column sums / sums of squares of Y (summed over slots by gb_bn_finalize)
 extern "C" int gb_gemm_fwd(const float *x, const float *w, const float *aff, float *y, double *stats,
-                           long long P, int K, int N, void *stream) {
-  if (P < 0 || K < 1 || N < 1 || !x || !w || !y) return GB_EINVAL;
+                           int stat_slots, long long P, int K, int N, void *stream) {
+  if (P < 0 || K < 1 || N < 1 || !x || !w || !y || (stats && stat_slots < 1)) return GB_EINVAL;
   if (P == 0) return GB_OK;
   if (P / 64 * ((N + 63) / 64) > 0x7fffffffLL) return GB_ERANGE;
   Operand a = {x, P, K, K, aff};
   Operand b = {w, N, K, K, nullptr};
   const bool v = (K % 4 == 0) && aligned16(x) && aligned16(w);
   const long long kchunk = (K + GK - 1) / GK * GK;
-  if (stats) launch_gemm<OP_KC, OP_KC, EPI_STORE_STATS>(a, b, v, v, y, N, stats, kchunk, 1, as_stream(stream));
+  if (stats) launch_gemm<OP_KC, OP_KC, EPI_STORE_STATS>(a, b, v, v, y, N, stats, kchunk, 1, as_stream(stream), stat_slots);
   else launch_gemm<OP_KC, OP_KC, EPI_STORE>(a, b, v, v, y, N, stats, kchunk, 1, as_stream(stream));
   return check_launch("gb_gemm_fwd");
 }

@@ -328,6 +328,48 @@ __global__ __launch_bounds__(TPB) void knn1_kernel(const float *__restrict__ ref
   if (q < nq) idx[(size_t)bi * nq + q] = (int64_t)besti + 1;
 }
 
+// dim == 3 (the only case GraspBalance uses): one WAVE per 4 queries, the 64 lanes split the reference
+// columns (coalesced reads, no LDS), then a DPP arg-min with lowest-index tie-break.  The generic kernel
+// above gives a query to one thread, which leaves a 300 x 300 problem on 2 workgroups.
+constexpr int KNN_QW = 4;
+
+__global__ __launch_bounds__(TPB) void knn1_dim3_kernel(const float *__restrict__ ref,
+                                                         const float *__restrict__ query,
+                                                         int64_t *__restrict__ idx, int nref, int nq) {
+  const int bi = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int q0 = (blockIdx.x * (TPB / 64) + (threadIdx.x >> 6)) * KNN_QW;
+  if (q0 >= nq) return;
+  const float *r = ref + (size_t)bi * 3 * nref;
+  const float *qq = query + (size_t)bi * 3 * nq;
+  float qx[KNN_QW], qy[KNN_QW], qz[KNN_QW], best[KNN_QW];
+  int besti[KNN_QW];
+#pragma unroll
+  for (int j = 0; j < KNN_QW; ++j) {
+    const int q = q0 + j < nq ? q0 + j : nq - 1;
+    qx[j] = qq[q]; qy[j] = qq[nq + q]; qz[j] = qq[2 * (size_t)nq + q];
+    best[j] = INFINITY;
+    besti[j] = 0x7fffffff;
+  }
+  for (int k = lane; k < nref; k += 64) {
+    const float rx = r[k], ry = r[nref + k], rz = r[2 * (size_t)nref + k];
+#pragma unroll
+    for (int j = 0; j < KNN_QW; ++j) {
+      const float tx = rx - qx[j], ty = ry - qy[j], tz = rz - qz[j];
+      const float d = ((tx * tx) + (ty * ty)) + (tz * tz);  // == ((0 + tx^2) + ty^2) + tz^2 of knn_cpu.cpp
+      if (d < best[j]) { best[j] = d; besti[j] = k; }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < KNN_QW; ++j) {
+    const float dmin = -wave_max_f32(-best[j]);
+    const unsigned cand = (best[j] == dmin) ? (unsigned)besti[j] : 0xFFFFFFFFu;
+    unsigned win = wave_min_u32(cand);
+    if (win >= (unsigned)nref) win = 0;  // nothing finite: the serial scan keeps index 0
+    if (lane == 0 && q0 + j < nq) idx[(size_t)bi * nq + q0 + j] = (int64_t)win + 1;
+  }
+}
+
 // ---- grasp-label gather (label_generation.py:60-99): for every seed r, with o = obj[r] (which
 // object's label tensor) and j = pt[r] (which grasp point of that object):
 //     out[r, v, :] = src_o[j, view_inds[o, v], :]          W floats per (point, view)
@@ -429,6 +471,11 @@ extern "C" int gb_knn1(const float *ref, const float *query, int64_t *idx, int b
   if (b < 0 || dim < 1 || dim > KNN_MAXDIM || nref < 1 || nq < 0 || !ref || !query || !idx) return GB_EINVAL;
   if (b == 0 || nq == 0) return GB_OK;
   if (b > 65535) return GB_ERANGE;
+  if (dim == 3) {
+    hipLaunchKernelGGL(knn1_dim3_kernel, dim3(ceil_div(nq, (TPB / 64) * KNN_QW), b), dim3(TPB), 0, as_stream(stream),
+                       ref, query, idx, nref, nq);
+    return check_launch("gb_knn1");
+  }
   hipLaunchKernelGGL(knn1_kernel, dim3(ceil_div(nq, TPB), b), dim3(TPB), 0, as_stream(stream), ref,
                      query, idx, dim, nref, nq);
   return check_launch("gb_knn1");

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(CL_TPB) void col_stats_kernel(const float *__restri
 }
 
 // stats: [sum(C), sumsq(C)] fp64 in;  ab: [a(C), b(C), mean(C), rstd(C)] fp32 out
-__global__ void bn_finalize_kernel(const double *__restrict__ stats, long long P, int C,
+__global__ void bn_finalize_kernel(const double *__restrict__ stats, int slots, long long P, int C,
                                    const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
                                    float momentum, float *__restrict__ running_mean,
                                    float *__restrict__ running_var, float *__restrict__ ab, int training) {
@@ -171,8 +171,13 @@ __global__ void bn_finalize_kernel(const double *__restrict__ stats, long long P
   if (c >= C) return;
   float mean, var;
   if (training) {
-    const double m = stats[c] / (double)P;
-    double v = stats[C + c] / (double)P - m * m;  // biased variance (normalisation)
+    double s1 = 0.0, s2 = 0.0;
+    for (int sl = 0; sl < slots; ++sl) {  // partial sums of the GEMM epilogue's slot rows
+      s1 += stats[(size_t)sl * 2 * C + c];
+      s2 += stats[(size_t)sl * 2 * C + C + c];
+    }
+    const double m = s1 / (double)P;
+    double v = s2 / (double)P - m * m;  // biased variance (normalisation)
     if (v < 0.0) v = 0.0;
     mean = (float)m;
     var = (float)v;
@@ -442,13 +447,13 @@ extern "C" int gb_col_stats(const float *y, long long P, int C, double *stats, v
   return check_launch("gb_col_stats");
 }
 
-extern "C" int gb_bn_finalize(const double *stats, long long P, int C, const float *gamma, const float *beta,
+extern "C" int gb_bn_finalize(const double *stats, int slots, long long P, int C, const float *gamma, const float *beta,
                               float eps, float momentum, float *running_mean, float *running_var, float *ab,
                               int training, void *stream) {
   if (C < 1 || !gamma || !beta || !ab) return GB_EINVAL;
-  if (training && (!stats || P < 1)) return GB_EINVAL;
+  if (training && (!stats || P < 1 || slots < 1)) return GB_EINVAL;
   if (!training && (!running_mean || !running_var)) return GB_EINVAL;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), stats, P, C, gamma,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), stats, slots, P, C, gamma,
                      beta, eps, momentum, running_mean, running_var, ab, training);
   return check_launch("gb_bn_finalize");
 }

@@ -18,6 +18,7 @@ from torch.autograd import Function
 from . import _lib
 
 _ENABLED = True
+STAT_SLOTS = 32   # rows of the BN-statistics buffer the GEMM epilogue spreads its fp64 atomics over
 _OWN_GEMM = True  # hand-written MFMA GEMMs (csrc/gemm_cl.hip); False = torch.mm (rocBLAS) for A/B timing
 
 
@@ -104,19 +105,20 @@ class LinearBNAct(Function):
         dev = X.device
         P, Cout = X.shape[0], W.shape[0]
         ab = torch.empty(4 * Cout, dtype=torch.float32, device=dev)
-        stats = torch.zeros(2 * Cout, dtype=torch.float64, device=dev) if training else None
+        slots = STAT_SLOTS if (_OWN_GEMM and P >= 16384) else 1
+        stats = torch.zeros(slots * 2 * Cout, dtype=torch.float64, device=dev) if training else None
         if _OWN_GEMM:
             # hand-written fp32 MFMA GEMM; the BatchNorm column statistics come out of its epilogue
             X = X.contiguous()
             Wc = W.contiguous()
             Y = torch.empty((P, Cout), dtype=torch.float32, device=dev)
-            _call("gb_gemm_fwd", dev, _lib.ptr(X), _lib.ptr(Wc), None, _lib.ptr(Y), _lib.ptr(stats), P, X.shape[1],
+            _call("gb_gemm_fwd", dev, _lib.ptr(X), _lib.ptr(Wc), None, _lib.ptr(Y), _lib.ptr(stats), slots, P, X.shape[1],
                   Cout, _s(X), meta={"flop": 2.0 * P * X.shape[1] * Cout})
         else:
             Y = torch.mm(X, W.t())
             if training:
                 _call("gb_col_stats", dev, _lib.ptr(Y), P, Cout, _lib.ptr(stats), _s(Y))
-        _call("gb_bn_finalize", dev, _lib.ptr(stats), P, Cout, _lib.ptr(gamma), _lib.ptr(beta), float(eps),
+        _call("gb_bn_finalize", dev, _lib.ptr(stats), slots, P, Cout, _lib.ptr(gamma), _lib.ptr(beta), float(eps),
               float(momentum), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(ab), int(training), _s(Y))
         ctx.cfg = (P, Cout, bool(training), bool(relu), int(pool_ns))
         if pool_ns:

@@ -161,9 +161,11 @@ int gb_group_concat_cl_grad(const float *dx0, const int32_t *idx, float *dfeat, 
 /* stats[0:C] += column sums of y (P,C), stats[C:2C] += column sums of y*y; fp64, caller zeroes */
 int gb_col_stats(const float *y, long long P, int C, double *stats, void *stream);
 /* ab[0:C] = a = gamma*rstd, ab[C:2C] = b = beta - mean*a, ab[2C:3C] = mean, ab[3C:4C] = rstd.
+ * `stats` is [slots][2C] (slot rows are summed; gb_col_stats fills one row, gb_gemm_fwd spreads its
+ * epilogue atomics over `stat_slots` rows).
  * training: batch statistics from `stats` (biased variance) and running_* updated with `momentum`
  * (unbiased variance), as nn.BatchNorm does; otherwise the running statistics are used.           */
-int gb_bn_finalize(const double *stats, long long P, int C, const float *gamma, const float *beta,
+int gb_bn_finalize(const double *stats, int slots, long long P, int C, const float *gamma, const float *beta,
                    float eps, float momentum, float *running_mean, float *running_var, float *ab,
                    int training, void *stream);
 /* z = act(a*y + b (+ residual)), act = ReLU when relu != 0 */
@@ -189,10 +191,11 @@ int gb_bn_bwd_apply_pool(const float *dout, const float *out, const int32_t *arg
 /* ---- fp32 MFMA GEMMs of the channel-last SharedMLP (csrc/gemm_cl.hip) — replace the cuBLAS/cuDNN
  * 1x1 convolutions the reference reaches through torch (pytorch_utils.py:61-113) ------------------- */
 /* Y (P,N) = f(X (P,K)) W(N,K)^T.  aff (optional) = [a(K), b(K)]: f(x) = relu(a_k x + b_k), i.e. the
- * previous layer's BatchNorm + ReLU applied while loading.  stats (optional, fp64 [2N], caller-zeroed)
- * += column sums and sums of squares of Y (BatchNorm batch statistics).                            */
-int gb_gemm_fwd(const float *x, const float *w, const float *aff, float *y, double *stats, long long P,
-                int K, int N, void *stream);
+ * previous layer's BatchNorm + ReLU applied while loading.  stats (optional, fp64 [stat_slots][2N],
+ * caller-zeroed) += column sums and sums of squares of Y (BatchNorm batch statistics), spread over the
+ * slot rows to avoid same-address atomic contention; gb_bn_finalize sums the rows.                 */
+int gb_gemm_fwd(const float *x, const float *w, const float *aff, float *y, double *stats, int stat_slots,
+                long long P, int K, int N, void *stream);
 /* dX (P,K) = dY (P,N) W(N,K), given Wt = W^T stored (K,N) row-major */
 int gb_gemm_dgrad(const float *dy, const float *wt, float *dx, long long P, int K, int N, void *stream);
 /* dW (N,K) += dY (P,N)^T X (P,K); accumulates (fp32 atomics, reduction over P split across workgroups) */

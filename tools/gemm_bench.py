@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from graspbalance_amd import _lib as L
 DEV = "cuda:0"
+SLOTS = int(os.environ.get("SLOTS", "32"))
 
 def timeit(fn, iters=10, warm=2):
     for _ in range(warm): fn()
@@ -23,10 +24,10 @@ tot = {"own": 0.0, "blas": 0.0}
 for name, P, K, N in SHAPES:
     X = torch.randn(P, K, device=DEV); W = torch.randn(N, K, device=DEV); dY = torch.randn(P, N, device=DEV)
     Y = torch.empty(P, N, device=DEV); dX = torch.empty(P, K, device=DEV); dW = torch.zeros(N, K, device=DEV)
-    Wt = W.t().contiguous(); st = torch.zeros(2 * N, dtype=torch.float64, device=DEV)
+    Wt = W.t().contiguous(); st = torch.zeros(SLOTS * 2 * N, dtype=torch.float64, device=DEV)
     fl = 2.0 * P * K * N
     r = {}
-    r["fwd own"] = timeit(lambda: lib.gb_gemm_fwd(L.ptr(X), L.ptr(W), None, L.ptr(Y), L.ptr(st), P, K, N, None))
+    r["fwd own"] = timeit(lambda: lib.gb_gemm_fwd(L.ptr(X), L.ptr(W), None, L.ptr(Y), L.ptr(st), SLOTS, P, K, N, None))
     r["fwd blas"] = timeit(lambda: torch.mm(X, W.t(), out=Y))
     r["dgrad own"] = timeit(lambda: lib.gb_gemm_dgrad(L.ptr(dY), L.ptr(Wt), L.ptr(dX), P, K, N, None))
     r["dgrad blas"] = timeit(lambda: torch.mm(dY, W, out=dX))

@@ -92,22 +92,26 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no GPU visible)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # GB_FORCE_DIST=1 runs the RCCL path (broadcast, flat-bucket all-reduce, barriers) even with one rank
+    use_dist = world > 1 or os.environ.get("GB_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from graspbalance_amd import _lib
     from graspbalance_amd.synthetic import make_training_batch
     from graspbalance_amd.train import Trainer
     _lib.lib()  # fail loudly if the HIP library is missing
 
-    trainer = Trainer(device, distributed=world > 1)
+    trainer = Trainer(device, distributed=use_dist)
     seeds = [1000 * rank + i for i in range(BATCH_PER_GPU)]
     batch = make_training_batch(seeds, NUM_POINT, device=device)
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -122,7 +126,7 @@ def main():
         elapsed = time.perf_counter() - t0
     assert bool(torch.isfinite(loss)), "training diverged"
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -170,7 +174,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 32))
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -50,8 +50,8 @@ SIGNATURES = {
     "gb_bn_bwd_apply_pool": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P],
     "gb_label_gather": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "gb_gemm_fwd": [_P, _P, _P, _P, _P, _I, _L, _I, _I, _P],
-    "gb_gemm_dgrad": [_P, _P, _P, _L, _I, _I, _P],
-    "gb_gemm_wgrad": [_P, _P, _P, _L, _I, _I, _P],
+    "gb_gemm_dgrad": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P],
+    "gb_gemm_wgrad": [_P, _P, _P, _P, _L, _I, _I, _P],
 }
 
 

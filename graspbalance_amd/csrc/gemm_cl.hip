@@ -38,7 +38,7 @@ struct Operand {
 };
 
 // registers holding one thread's share (ROWS/16 floats... i.e. 4 or 8) of a ROWS x 16 operand tile
-struct Frag { float v[8]; };
+struct Frag { float v[8]; float ca[4], cb[4]; bool ok[2]; };  // data, the affine (a,b) of its 4 channels, row/step validity
 
 template <int KIND, bool VEC, int ROWS>
 __device__ __forceinline__ void load_frag(const Operand &op, long long row0, long long k0, Frag &f) {
@@ -53,6 +53,7 @@ __device__ __forceinline__ void load_frag(const Operand &op, long long row0, lon
       const long long k = k0 + 4 * (t & 3);
       const float *p = op.src + row * op.ld + k;
       const bool rok = row < op.rows;
+      f.ok[h] = rok;
       if (VEC && rok && k + 3 < op.red) {
         const float4 q = *reinterpret_cast<const float4 *>(p);
         f.v[4 * h + 0] = q.x; f.v[4 * h + 1] = q.y; f.v[4 * h + 2] = q.z; f.v[4 * h + 3] = q.w;
@@ -60,13 +61,12 @@ __device__ __forceinline__ void load_frag(const Operand &op, long long row0, lon
 #pragma unroll
         for (int e = 0; e < 4; ++e) f.v[4 * h + e] = (rok && k + e < op.red) ? p[e] : 0.f;
       }
-      if (op.aff) {
+      if (op.aff && h == 0) {  // channel = reduction index; the same 4 channels for every h
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          if (rok && k + e < op.red) {
-            const float z = op.aff[k + e] * f.v[4 * h + e] + op.aff[op.red + k + e];
-            f.v[4 * h + e] = z > 0.f ? z : 0.f;
-          }
+          const bool ok = k + e < op.red;
+          f.ca[e] = ok ? op.aff[k + e] : 0.f;
+          f.cb[e] = ok ? op.aff[op.red + k + e] : 0.f;
         }
       }
     } else {
@@ -74,6 +74,7 @@ __device__ __forceinline__ void load_frag(const Operand &op, long long row0, lon
       const long long row = row0 + 4 * (t % TPK);
       const float *p = op.src + k * op.ld + row;
       const bool kok = k < op.red;
+      f.ok[h] = kok;
       if (VEC && kok && row + 3 < op.rows) {
         const float4 q = *reinterpret_cast<const float4 *>(p);
         f.v[4 * h + 0] = q.x; f.v[4 * h + 1] = q.y; f.v[4 * h + 2] = q.z; f.v[4 * h + 3] = q.w;
@@ -81,8 +82,30 @@ __device__ __forceinline__ void load_frag(const Operand &op, long long row0, lon
 #pragma unroll
         for (int e = 0; e < 4; ++e) f.v[4 * h + e] = (kok && row + e < op.rows) ? p[e] : 0.f;
       }
+      if (op.aff && h == 0) {  // channel = tile-row index here: aff = [a(rows), b(rows)]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool ok = row + e < op.rows;
+          f.ca[e] = ok ? op.aff[row + e] : 0.f;
+          f.cb[e] = ok ? op.aff[op.rows + row + e] : 0.f;
+        }
+      }
     }
   }
+}
+
+// relu(a*x + b) on a fetched fragment.  Called AFTER the MFMA block of the step (right before the LDS
+// store), so the global loads issued by load_frag stay in flight behind the MFMAs; padding elements have
+// a = b = 0 and stay exact zeros.
+template <int ROWS>
+__device__ __forceinline__ void apply_aff(Frag &f) {
+#pragma unroll
+  for (int h = 0; h < ROWS / 64; ++h)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float z = f.ca[e] * f.v[4 * h + e] + f.cb[e];
+      f.v[4 * h + e] = (f.ok[h] && z > 0.f) ? z : 0.f;
+    }
 }
 
 template <int KIND, int ROWS>
@@ -104,13 +127,19 @@ __device__ __forceinline__ void store_frag(float *lds, const Frag &f) {
   }
 }
 
-enum { EPI_STORE = 0, EPI_STORE_STATS = 1, EPI_ATOMIC = 2 };
+enum { EPI_STORE = 0,
+       EPI_STORE_STATS = 1,   // + column sums of D and D^2                     (BatchNorm batch statistics)
+       EPI_ATOMIC = 2,        // D accumulated with fp32 atomics                 (split-K wgrad)
+       EPI_STORE_BNBWD = 3 }; // + column sums of g and g*xhat, g = D*[a*y+b>0]  (BatchNorm-backward statistics
+                              //   of the layer whose pre-BN output y has D's shape: dgrad of the next layer)
 
 // D[i,j] = sum_k A[i,k] B[j,k] over k in [kbeg, kend);  D is (a.rows x b.rows) with leading dim ldd
 template <int KA, int KB, bool VA, bool VB, int EPI, int GM, int GN>
 __global__ __launch_bounds__(GTPB) void gemm_cl_kernel(Operand a, Operand b, float *__restrict__ d, long long ldd,
                                                         double *__restrict__ stats, long long kchunk,
-                                                        int tiles_n, int stat_slots) {
+                                                        int tiles_n, int stat_slots,
+                                                        const float *__restrict__ epi_y,
+                                                        const float *__restrict__ epi_ab) {
   // LDS image per operand kind: OP_KC [row][17] (element (r,k) at r*17 + k), OP_RC [k][rows+4]
   constexpr int A_RS = KA == OP_KC ? GPITCH : 1, A_KS = KA == OP_KC ? 1 : GM + 4;  // row / k strides
   constexpr int B_RS = KB == OP_KC ? GPITCH : 1, B_KS = KB == OP_KC ? 1 : GN + 4;
@@ -138,6 +167,8 @@ __global__ __launch_bounds__(GTPB) void gemm_cl_kernel(Operand a, Operand b, flo
   Frag fa, fb;
   load_frag<KA, VA, GM>(a, m0, kbeg, fa);
   load_frag<KB, VB, GN>(b, n0, kbeg, fb);
+  if (a.aff) apply_aff<GM>(fa);
+  if (b.aff) apply_aff<GN>(fb);
   store_frag<KA, GM>(lds_a[0], fa);
   store_frag<KB, GN>(lds_b[0], fb);
   __syncthreads();
@@ -164,6 +195,8 @@ __global__ __launch_bounds__(GTPB) void gemm_cl_kernel(Operand a, Operand b, flo
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
     if (more) {
+      if (a.aff) apply_aff<GM>(fa);
+      if (b.aff) apply_aff<GN>(fb);
       store_frag<KA, GM>(lds_a[buf ^ 1], fa);
       store_frag<KB, GN>(lds_b[buf ^ 1], fb);
     }
@@ -180,6 +213,12 @@ __global__ __launch_bounds__(GTPB) void gemm_cl_kernel(Operand a, Operand b, flo
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const long long col = n0 + wn * (GN / 2) + nt * 32 + (lane & 31);
+      float ea = 0.f, eb = 0.f, emean = 0.f, erstd = 0.f;
+      if constexpr (EPI == EPI_STORE_BNBWD) {
+        if (col < b.rows) {
+          ea = epi_ab[col]; eb = epi_ab[b.rows + col]; emean = epi_ab[2 * b.rows + col]; erstd = epi_ab[3 * b.rows + col];
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const long long row = m0 + wm * (GM / 2) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -187,11 +226,17 @@ __global__ __launch_bounds__(GTPB) void gemm_cl_kernel(Operand a, Operand b, flo
         if (row < a.rows && col < b.rows) {
           if constexpr (EPI == EPI_ATOMIC) atomicAdd(d + row * ldd + col, v);
           else d[row * ldd + col] = v;
+          if constexpr (EPI == EPI_STORE_BNBWD) {
+            const float y = epi_y[row * ldd + col];
+            const float g = (ea * y + eb) > 0.f ? v : 0.f;
+            csum[nt] += g;
+            csq[nt] += g * ((y - emean) * erstd);
+          }
         }
         if constexpr (EPI == EPI_STORE_STATS) { csum[nt] += v; csq[nt] += v * v; }  // padded rows/cols are exact zeros
       }
     }
-  if constexpr (EPI == EPI_STORE_STATS) {
+  if constexpr (EPI == EPI_STORE_STATS || EPI == EPI_STORE_BNBWD) {
     // column partials: lanes l and l+32 hold the same column; then the two M-waves (wm) via LDS
     __shared__ float s_col[2][2][GN];  // [sum|sq][wm][col in tile]
 #pragma unroll
@@ -221,13 +266,14 @@ static inline bool aligned16(const void *p) { return reinterpret_cast<uintptr_t>
 
 template <int KA, int KB, int EPI, int BM, int BN>
 static void launch_tile(const Operand &a, const Operand &b, bool va, bool vb, float *d, long long ldd, double *stats,
-                        long long kchunk, unsigned chunks, hipStream_t s, int stat_slots) {
+                        long long kchunk, unsigned chunks, hipStream_t s, int stat_slots, const float *epi_y,
+                        const float *epi_ab) {
   const int tiles_n = (int)((b.rows + BN - 1) / BN);
   const long long tiles_m = (a.rows + BM - 1) / BM;
   const dim3 grid((unsigned)(tiles_m * tiles_n), chunks);
 #define GB_L(VA_, VB_)                                                                                          \
   hipLaunchKernelGGL((gemm_cl_kernel<KA, KB, VA_, VB_, EPI, BM, BN>), grid, dim3(GTPB), 0, s, a, b, d, ldd, stats, \
-                     kchunk, tiles_n, stat_slots)
+                     kchunk, tiles_n, stat_slots, epi_y, epi_ab)
   if (va && vb) GB_L(true, true);
   else if (va) GB_L(true, false);
   else if (vb) GB_L(false, true);
@@ -239,14 +285,15 @@ static void launch_tile(const Operand &a, const Operand &b, bool va, bool vb, fl
 // 64-tall when 128-tall tiles would leave most of the 256 CUs without a workgroup
 template <int KA, int KB, int EPI>
 static void launch_gemm(const Operand &a, const Operand &b, bool va, bool vb, float *d, long long ldd, double *stats,
-                        long long kchunk, unsigned chunks, hipStream_t s, int stat_slots = 1) {
+                        long long kchunk, unsigned chunks, hipStream_t s, int stat_slots = 1,
+                        const float *epi_y = nullptr, const float *epi_ab = nullptr) {
   const bool bn64 = b.rows <= 64;
   const long long blocks128 = ((a.rows + 127) / 128) * ((b.rows + (bn64 ? 63 : 127)) / (bn64 ? 64 : 128)) * chunks;
   const bool bm64 = a.rows <= 64 || blocks128 < 512;
-  if (bm64 && bn64) launch_tile<KA, KB, EPI, 64, 64>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots);
-  else if (bm64) launch_tile<KA, KB, EPI, 64, 128>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots);
-  else if (bn64) launch_tile<KA, KB, EPI, 128, 64>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots);
-  else launch_tile<KA, KB, EPI, 128, 128>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots);
+  if (bm64 && bn64) launch_tile<KA, KB, EPI, 64, 64>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots, epi_y, epi_ab);
+  else if (bm64) launch_tile<KA, KB, EPI, 64, 128>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots, epi_y, epi_ab);
+  else if (bn64) launch_tile<KA, KB, EPI, 128, 64>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots, epi_y, epi_ab);
+  else launch_tile<KA, KB, EPI, 128, 128>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots, epi_y, epi_ab);
 }
 
 }  // namespace gb
@@ -269,26 +316,38 @@ extern "C" int gb_gemm_fwd(const float *x, const float *w, const float *aff, flo
   return check_launch("gb_gemm_fwd");
 }
 
-// dX (P,K) = dY (P,N) Wt(K,N)^T   with Wt = W^T stored (K,N) row-major
-extern "C" int gb_gemm_dgrad(const float *dy, const float *wt, float *dx, long long P, int K, int N,
+// dX (P,K) = dY (P,N) Wt(K,N)^T   with Wt = W^T stored (K,N) row-major.
+// Optional fused BatchNorm-backward statistics of the PREVIOUS layer (whose post-ReLU activation is this
+// GEMM's input, i.e. dX is its dZ): y_prev (P,K) pre-BN output, ab_prev = [a,b,mean,rstd](K),
+// dstats fp64 [stat_slots][2K] (caller-zeroed) += [sum dA, sum dA*xhat],  dA = dX * [a*y+b > 0].
+extern "C" int gb_gemm_dgrad(const float *dy, const float *wt, float *dx, const float *y_prev,
+                             const float *ab_prev, double *dstats, int stat_slots, long long P, int K, int N,
                              void *stream) {
   if (P < 0 || K < 1 || N < 1 || !dy || !wt || !dx) return GB_EINVAL;
+  if (dstats && (!y_prev || !ab_prev || stat_slots < 1)) return GB_EINVAL;
   if (P == 0) return GB_OK;
   if (P / 64 * ((K + 63) / 64) > 0x7fffffffLL) return GB_ERANGE;
   Operand a = {dy, P, N, N, nullptr};
   Operand b = {wt, K, N, N, nullptr};
   const bool v = (N % 4 == 0) && aligned16(dy) && aligned16(wt);
-  launch_gemm<OP_KC, OP_KC, EPI_STORE>(a, b, v, v, dx, K, nullptr, (N + GK - 1) / GK * GK, 1, as_stream(stream));
+  const long long kchunk = (N + GK - 1) / GK * GK;
+  if (dstats)
+    launch_gemm<OP_KC, OP_KC, EPI_STORE_BNBWD>(a, b, v, v, dx, K, dstats, kchunk, 1, as_stream(stream), stat_slots,
+                                               y_prev, ab_prev);
+  else
+    launch_gemm<OP_KC, OP_KC, EPI_STORE>(a, b, v, v, dx, K, nullptr, kchunk, 1, as_stream(stream));
   return check_launch("gb_gemm_dgrad");
 }
 
 // dW (N,K) += dY (P,N)^T X (P,K) ; dW must be zeroed by the caller (accumulates with fp32 atomics)
-extern "C" int gb_gemm_wgrad(const float *dy, const float *x, float *dw, long long P, int K, int N,
-                             void *stream) {
+// x_aff (optional) = [a(K), b(K)]: X is used as relu(a_k x + b_k) (the materialisation-free form of the
+// previous layer's BatchNorm + ReLU, matching gb_gemm_fwd's prologue)
+extern "C" int gb_gemm_wgrad(const float *dy, const float *x, const float *x_aff, float *dw, long long P, int K,
+                             int N, void *stream) {
   if (P < 0 || K < 1 || N < 1 || !dy || !x || !dw) return GB_EINVAL;
   if (P == 0) return GB_OK;
   Operand a = {dy, N, P, N, nullptr};  // tile rows = n, reduction = p, element (n,p) at dy[p*N + n]
-  Operand b = {x, K, P, K, nullptr};   // tile rows = k, reduction = p, element (k,p) at x[p*K + k]
+  Operand b = {x, K, P, K, x_aff};     // tile rows = k, reduction = p, element (k,p) at x[p*K + k]
   const long long tiles = (long long)((N + (N <= 64 ? 63 : 127)) / (N <= 64 ? 64 : 128)) *
                           ((K + (K <= 64 ? 63 : 127)) / (K <= 64 ? 64 : 128));
   // split the P reduction so that ~1024 workgroups exist, chunks a multiple of the reduction step

@@ -58,7 +58,7 @@ class FlatGradAllReduce:
             flat.zero_()
 
     def reduce(self):
-        if self.world_size == 1:
+        if not dist.is_initialized():
             return
         works = [dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                  for flat in self.flat]
@@ -69,7 +69,7 @@ class FlatGradAllReduce:
 
 def broadcast_module(module, src=0, process_group=None):
     """Make every rank start from rank `src`'s parameters and buffers."""
-    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+    if not dist.is_initialized():
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src, group=process_group)

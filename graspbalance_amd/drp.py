@@ -109,9 +109,10 @@ class InvResMLP(nn.Module):
         x0 = fused_mlp.group_concat_cl(p, p, idx, f_cl, mode=0)               # [dp, fj] rows
         agg_conv, agg_bn = self.convs.convs[0][0], self.convs.convs[0][1]
         agg = fused_mlp.conv_bn_act(x0, agg_conv, agg_bn, relu=True, pool_ns=g.nsample)   # (B*N, C)
-        h = fused_mlp.conv_bn_act(agg, self.pwconv[0][0], self.pwconv[0][1], relu=True)   # (B*N, 4C)
-        out = fused_mlp.conv_bn_act(h, self.pwconv[1][0], self.pwconv[1][1], relu=True,
-                                    residual=f_cl.reshape(B * N, C))                       # act(bn(.) + identity)
+        # C -> 4C -> C pointwise pair as one fused stack; act(bn(.) + identity) at the end
+        out = fused_mlp.conv_bn_act_chain(agg, [(self.pwconv[0][0], self.pwconv[0][1]),
+                                                (self.pwconv[1][0], self.pwconv[1][1])],
+                                          residual=f_cl.reshape(B * N, C), relu_last=True)
         return out.view(B, N, C)
 
     def forward(self, pf):

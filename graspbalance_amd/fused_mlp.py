@@ -12,6 +12,8 @@ statistics), so state_dicts are unchanged; results equal the unfused path to fp3
 ``enabled()`` is False on CPU tensors: the python layers then run their plain torch composition
 (which only works with an extension bound for CPU, i.e. in the tests).
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -19,6 +21,7 @@ from . import _lib
 
 _ENABLED = True
 STAT_SLOTS = 32   # rows of the BN-statistics buffer the GEMM epilogue spreads its fp64 atomics over
+_DGRAD_BN_MAX = int(os.environ.get("GB_DGRAD_BN_MAX", 1 << 26))  # rows*cols above which dgrad's fused BN-backward sums lose to a separate pass
 _OWN_GEMM = True  # hand-written MFMA GEMMs (csrc/gemm_cl.hip); False = torch.mm (rocBLAS) for A/B timing
 
 
@@ -169,12 +172,12 @@ class LinearBNAct(Function):
             Cin = X.shape[1]
             if ctx.needs_input_grad[1]:
                 dW = torch.zeros((Cout, Cin), dtype=torch.float32, device=dev)
-                _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(X), _lib.ptr(dW), P, Cin, Cout, _s(dY),
+                _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(X), None, _lib.ptr(dW), P, Cin, Cout, _s(dY),
                       meta={"flop": 2.0 * P * Cin * Cout})
             if ctx.needs_input_grad[0]:
                 Wt = W.t().contiguous()
                 dX = torch.empty((P, Cin), dtype=torch.float32, device=dev)
-                _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(Wt), _lib.ptr(dX), P, Cin, Cout, _s(dY),
+                _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(Wt), _lib.ptr(dX), None, None, None, 0, P, Cin, Cout, _s(dY),
                       meta={"flop": 2.0 * P * Cin * Cout})
         else:
             dW = _wgrad(dY, X) if ctx.needs_input_grad[1] else None
@@ -182,9 +185,156 @@ class LinearBNAct(Function):
         return dX, dW, dgamma, dbeta, dres, None, None, None, None, None, None, None
 
 
+class _LayerCfg:
+    __slots__ = ("running_mean", "running_var", "momentum", "eps", "training")
+
+    def __init__(self, bn):
+        self.running_mean, self.running_var = bn.running_mean, bn.running_var
+        self.momentum = 0.0 if bn.momentum is None else float(bn.momentum)
+        self.eps = float(bn.eps)
+        self.training = bool(bn.training or not bn.track_running_stats)
+
+
+class MLPStack(Function):
+    """A whole stack  X0 -> [conv -> BN -> ReLU] x (L-1) -> conv -> BN -> (ReLU | +residual, ReLU | max over
+    pool_ns rows)  as ONE autograd node on the hand-written GEMMs:
+
+    * forward: layer l's GEMM reads the PRE-BatchNorm output of layer l-1 and applies relu(a*y+b) while
+      loading (gb_gemm_fwd prologue), and emits its own BN column statistics from its epilogue — the
+      normalised activations are never written;
+    * backward: wgrad re-forms relu(a*y+b) in its operand loader, dgrad's epilogue accumulates the
+      BatchNorm-backward sums (dbeta, dgamma) of layer l-1 while it writes that layer's dZ, so the only
+      element-wise pass per layer is dy = a*(dA - dbeta/P - xhat*dgamma/P).
+
+    forward(ctx, X0, residual|None, layers: list[_LayerCfg], pool_ns, relu_last, W0, g0, b0, W1, g1, b1, ...)
+    """
+
+    @staticmethod
+    def forward(ctx, X0, residual, layers, pool_ns, relu_last, *params):
+        dev = X0.device
+        L = len(layers)
+        X0 = X0.contiguous()
+        P = X0.shape[0]
+        Ws, Ys, abs_ = [], [], []
+        src, aff = X0, None
+        for l, cfg in enumerate(layers):
+            W = params[3 * l].contiguous()
+            gamma, beta = params[3 * l + 1], params[3 * l + 2]
+            K, N = src.shape[1], W.shape[0]
+            slots = STAT_SLOTS if P >= 16384 else 1
+            stats = torch.zeros(slots * 2 * N, dtype=torch.float64, device=dev) if cfg.training else None
+            Y = torch.empty((P, N), dtype=torch.float32, device=dev)
+            _call("gb_gemm_fwd", dev, _lib.ptr(src), _lib.ptr(W), _lib.ptr(aff), _lib.ptr(Y), _lib.ptr(stats), slots,
+                  P, K, N, _s(X0), meta={"flop": 2.0 * P * K * N})
+            ab = torch.empty(4 * N, dtype=torch.float32, device=dev)
+            _call("gb_bn_finalize", dev, _lib.ptr(stats), slots, P, N, _lib.ptr(gamma), _lib.ptr(beta), cfg.eps,
+                  cfg.momentum, _lib.ptr(cfg.running_mean), _lib.ptr(cfg.running_var), _lib.ptr(ab),
+                  int(cfg.training), _s(X0))
+            Ws.append(W); Ys.append(Y); abs_.append(ab)
+            src, aff = Y, ab  # ab[:2N] = [a, b] is exactly the next GEMM's prologue table
+        N = Ws[-1].shape[0]
+        ctx.cfg = (L, P, int(pool_ns), bool(relu_last), [c.training for c in layers], residual is not None)
+        if pool_ns:
+            R = P // pool_ns
+            out = torch.empty((R, N), dtype=torch.float32, device=dev)
+            arg = torch.empty((R, N), dtype=torch.int32, device=dev)
+            _call("gb_affine_relu_maxpool", dev, _lib.ptr(Ys[-1]), _lib.ptr(abs_[-1]), _lib.ptr(out), _lib.ptr(arg), R,
+                  pool_ns, N, _s(X0))
+            ctx.save_for_backward(X0, out, arg, *Ws, *Ys, *abs_)
+            return out
+        if residual is not None:
+            residual = residual.contiguous()
+        out = torch.empty((P, N), dtype=torch.float32, device=dev)
+        _call("gb_affine_act", dev, _lib.ptr(Ys[-1]), _lib.ptr(abs_[-1]), _lib.ptr(residual), _lib.ptr(out), P, N,
+              int(relu_last), _s(X0))
+        ctx.save_for_backward(X0, residual if residual is not None else X0.new_empty(0), X0.new_empty(0), *Ws, *Ys, *abs_)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L, P, pool_ns, relu_last, training, has_res = ctx.cfg
+        saved = ctx.saved_tensors
+        X0, s1, s2 = saved[0], saved[1], saved[2]
+        Ws, Ys, abs_ = saved[3:3 + L], saved[3 + L:3 + 2 * L], saved[3 + 2 * L:3 + 3 * L]
+        dev = dout.device
+        dout = dout.contiguous()
+        N = Ws[-1].shape[0]
+        dstats = torch.zeros(2 * N, dtype=torch.float64, device=dev)
+        dres = None
+        dY = torch.empty((P, N), dtype=torch.float32, device=dev)
+        if pool_ns:
+            out, arg = s1, s2
+            R = P // pool_ns
+            _call("gb_bn_bwd_stats_pool", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(Ys[-1]),
+                  _lib.ptr(abs_[-1]), R, pool_ns, N, _lib.ptr(dstats), _s(dout))
+            _call("gb_bn_bwd_apply_pool", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(Ys[-1]),
+                  _lib.ptr(abs_[-1]), _lib.ptr(dstats), R, pool_ns, N, int(training[-1]), _lib.ptr(dY), _s(dout))
+        else:
+            residual = s1 if has_res else None
+            if has_res and ctx.needs_input_grad[1]:
+                dres = torch.empty((P, N), dtype=torch.float32, device=dev)
+            _call("gb_bn_bwd_stats", dev, _lib.ptr(dout), _lib.ptr(Ys[-1]), _lib.ptr(abs_[-1]), _lib.ptr(residual), P, N,
+                  int(relu_last), _lib.ptr(dstats), _s(dout))
+            _call("gb_bn_bwd_apply", dev, _lib.ptr(dout), _lib.ptr(Ys[-1]), _lib.ptr(abs_[-1]), _lib.ptr(residual),
+                  _lib.ptr(dstats), P, N, int(relu_last), int(training[-1]), _lib.ptr(dY), _lib.ptr(dres), _s(dout))
+        grads = [None] * (3 * L)
+        dX0 = None
+        for l in range(L - 1, -1, -1):
+            W = Ws[l]
+            N, K = W.shape
+            src, aff = (X0, None) if l == 0 else (Ys[l - 1], abs_[l - 1])
+            if ctx.needs_input_grad[5 + 3 * l]:
+                dW = torch.zeros((N, K), dtype=torch.float32, device=dev)
+                _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(src), _lib.ptr(aff), _lib.ptr(dW), P, K, N, _s(dout),
+                      meta={"flop": 2.0 * P * K * N})
+                grads[3 * l] = dW.view_as(W)
+            grads[3 * l + 1] = dstats[N:].float()   # dgamma = sum dA*xhat
+            grads[3 * l + 2] = dstats[:N].float()   # dbeta  = sum dA
+            if l == 0:
+                if ctx.needs_input_grad[0]:
+                    dX0 = torch.empty((P, K), dtype=torch.float32, device=dev)
+                    _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W.t().contiguous()), _lib.ptr(dX0), None, None,
+                          None, 0, P, K, N, _s(dout), meta={"flop": 2.0 * P * K * N})
+                break
+            # gradient of layer l-1's post-ReLU output + that layer's BatchNorm-backward sums in one launch
+            dZ = torch.empty((P, K), dtype=torch.float32, device=dev)
+            if K * P <= _DGRAD_BN_MAX:
+                slots = STAT_SLOTS if P >= 16384 else 1
+                dst = torch.zeros(slots * 2 * K, dtype=torch.float64, device=dev)
+                _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W.t().contiguous()), _lib.ptr(dZ),
+                      _lib.ptr(Ys[l - 1]), _lib.ptr(abs_[l - 1]), _lib.ptr(dst), slots, P, K, N, _s(dout),
+                      meta={"flop": 2.0 * P * K * N})
+                dstats = dst.view(slots, 2 * K).sum(0) if slots > 1 else dst
+            else:
+                # wide + long outputs: the fused epilogue measured slower than a separate column pass
+                _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W.t().contiguous()), _lib.ptr(dZ), None, None,
+                      None, 0, P, K, N, _s(dout), meta={"flop": 2.0 * P * K * N})
+                dstats = torch.zeros(2 * K, dtype=torch.float64, device=dev)
+                _call("gb_bn_bwd_stats", dev, _lib.ptr(dZ), _lib.ptr(Ys[l - 1]), _lib.ptr(abs_[l - 1]), None, P, K, 1,
+                      _lib.ptr(dstats), _s(dout))
+            dY = torch.empty((P, K), dtype=torch.float32, device=dev)
+            _call("gb_bn_bwd_apply", dev, _lib.ptr(dZ), _lib.ptr(Ys[l - 1]), _lib.ptr(abs_[l - 1]), None,
+                  _lib.ptr(dstats), P, K, 1, int(training[l - 1]), _lib.ptr(dY), None, _s(dout))
+        return (dX0, dres, None, None, None, *grads)
+
+
+def _stack(X, convs_bns, pool_ns=0, residual=None, relu_last=True):
+    params, layers = [], []
+    for conv, bn in convs_bns:
+        if conv.bias is not None:
+            raise NotImplementedError("fused path expects bias-free convs followed by BatchNorm")
+        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        params += [conv.weight.view(conv.weight.shape[0], -1), bn.weight, bn.bias]
+        layers.append(_LayerCfg(bn))
+    return MLPStack.apply(X, residual, layers, pool_ns, relu_last, *params)
+
+
 def conv_bn_act(X, conv, bn, relu=True, pool_ns=0, residual=None):
     """Apply a 1x1 ``conv`` (Conv1d/Conv2d without bias) + ``bn`` (BatchNorm1d/2d) + optional ReLU to
     channel-last rows X (P,Cin), with the modules' own parameters and running statistics."""
+    if _OWN_GEMM:
+        return _stack(X, [(conv, bn)], pool_ns=pool_ns, residual=residual, relu_last=relu)
     W = conv.weight.view(conv.weight.shape[0], -1)
     if conv.bias is not None:
         raise NotImplementedError("fused path expects bias-free convs followed by BatchNorm")
@@ -196,14 +346,23 @@ def conv_bn_act(X, conv, bn, relu=True, pool_ns=0, residual=None):
                              training, relu, pool_ns)
 
 
+def conv_bn_act_chain(X, convs_bns, residual=None, relu_last=True, pool_ns=0):
+    """Consecutive conv+BN(+ReLU) layers (ReLU after every layer but optionally the last) as one fused stack."""
+    if _OWN_GEMM:
+        return _stack(X, convs_bns, pool_ns=pool_ns, residual=residual, relu_last=relu_last)
+    n = len(convs_bns)
+    for i, (conv, bn) in enumerate(convs_bns):
+        last = i == n - 1
+        X = conv_bn_act(X, conv, bn, relu=relu_last if last else True, pool_ns=pool_ns if last else 0,
+                        residual=residual if last else None)
+    return X
+
+
 def shared_mlp_cl(X, shared_mlp, pool_ns=0):
     """Run a ``pytorch_utils.SharedMLP`` (layer0..layerK of conv+bn+ReLU) on channel-last rows; the
     last layer is fused with the max over `pool_ns` consecutive rows when pool_ns > 0."""
-    layers = list(shared_mlp.children())
-    for i, layer in enumerate(layers):
-        last = i == len(layers) - 1
-        X = conv_bn_act(X, layer.conv, layer.bn.bn, relu=True, pool_ns=pool_ns if last else 0)
-    return X
+    layers = [(layer.conv, layer.bn.bn) for layer in shared_mlp.children()]
+    return conv_bn_act_chain(X, layers, pool_ns=pool_ns)
 
 
 def supports(shared_mlp):

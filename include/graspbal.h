@@ -196,10 +196,16 @@ int gb_bn_bwd_apply_pool(const float *dout, const float *out, const int32_t *arg
  * slot rows to avoid same-address atomic contention; gb_bn_finalize sums the rows.                 */
 int gb_gemm_fwd(const float *x, const float *w, const float *aff, float *y, double *stats, int stat_slots,
                 long long P, int K, int N, void *stream);
-/* dX (P,K) = dY (P,N) W(N,K), given Wt = W^T stored (K,N) row-major */
-int gb_gemm_dgrad(const float *dy, const float *wt, float *dx, long long P, int K, int N, void *stream);
-/* dW (N,K) += dY (P,N)^T X (P,K); accumulates (fp32 atomics, reduction over P split across workgroups) */
-int gb_gemm_wgrad(const float *dy, const float *x, float *dw, long long P, int K, int N, void *stream);
+/* dX (P,K) = dY (P,N) W(N,K), given Wt = W^T stored (K,N) row-major.  Optional fused BatchNorm-backward
+ * statistics of the previous layer (dX is the gradient of its post-ReLU output): y_prev (P,K) its pre-BN
+ * output, ab_prev = [a,b,mean,rstd](K), dstats fp64 [stat_slots][2K] (caller-zeroed) += [sum dA,
+ * sum dA*xhat] with dA = dX*[a*y+b > 0].  Pass NULLs / 0 to skip.                                  */
+int gb_gemm_dgrad(const float *dy, const float *wt, float *dx, const float *y_prev, const float *ab_prev,
+                  double *dstats, int stat_slots, long long P, int K, int N, void *stream);
+/* dW (N,K) += dY (P,N)^T f(X (P,K)); accumulates (fp32 atomics, reduction over P split across
+ * workgroups).  x_aff (optional) = [a(K), b(K)]: f(x) = relu(a_k x + b_k), as in gb_gemm_fwd.      */
+int gb_gemm_wgrad(const float *dy, const float *x, const float *x_aff, float *dw, long long P, int K, int N,
+                  void *stream);
 
 #ifdef __cplusplus
 }

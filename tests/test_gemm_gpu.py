@@ -48,9 +48,9 @@ def test_gemm_dgrad_and_wgrad(P, K, N):
     dY = torch.randn(P, N, device=DEV)
     Wt = W.t().contiguous()
     dX = torch.empty(P, K, device=DEV)
-    L.check(L.lib().gb_gemm_dgrad(L.ptr(dY), L.ptr(Wt), L.ptr(dX), P, K, N, None), "dgrad")
+    L.check(L.lib().gb_gemm_dgrad(L.ptr(dY), L.ptr(Wt), L.ptr(dX), None, None, None, 0, P, K, N, None), "dgrad")
     dW = torch.zeros(N, K, device=DEV)
-    L.check(L.lib().gb_gemm_wgrad(L.ptr(dY), L.ptr(X), L.ptr(dW), P, K, N, None), "wgrad")
+    L.check(L.lib().gb_gemm_wgrad(L.ptr(dY), L.ptr(X), None, L.ptr(dW), P, K, N, None), "wgrad")
     torch.cuda.synchronize()
     rx = dY.double() @ W.double()
     rw = dY.double().t() @ X.double()

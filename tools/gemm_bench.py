@@ -29,9 +29,9 @@ for name, P, K, N in SHAPES:
     r = {}
     r["fwd own"] = timeit(lambda: lib.gb_gemm_fwd(L.ptr(X), L.ptr(W), None, L.ptr(Y), L.ptr(st), SLOTS, P, K, N, None))
     r["fwd blas"] = timeit(lambda: torch.mm(X, W.t(), out=Y))
-    r["dgrad own"] = timeit(lambda: lib.gb_gemm_dgrad(L.ptr(dY), L.ptr(Wt), L.ptr(dX), P, K, N, None))
+    r["dgrad own"] = timeit(lambda: lib.gb_gemm_dgrad(L.ptr(dY), L.ptr(Wt), L.ptr(dX), None, None, None, 0, P, K, N, None))
     r["dgrad blas"] = timeit(lambda: torch.mm(dY, W, out=dX))
-    r["wgrad own"] = timeit(lambda: lib.gb_gemm_wgrad(L.ptr(dY), L.ptr(X), L.ptr(dW), P, K, N, None))
+    r["wgrad own"] = timeit(lambda: lib.gb_gemm_wgrad(L.ptr(dY), L.ptr(X), None, L.ptr(dW), P, K, N, None))
     from graspbalance_amd.fused_mlp import _wgrad
     r["wgrad blas"] = timeit(lambda: _wgrad(dY, X))
     print("%-9s P=%7d K=%4d N=%4d | " % (name, P, K, N) + " | ".join("%s %7.1f us %5.1f TF" % (k, v, fl / v / 1e6) for k, v in r.items()))

@@ -48,6 +48,7 @@ SIGNATURES = {
     "gb_bn_bwd_apply": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P],
     "gb_bn_bwd_stats_pool": [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P],
     "gb_bn_bwd_apply_pool": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P],
+    "gb_bn_bwd_reduce": [_P, _I, _I, _P, _P, _P, _P],
     "gb_label_gather": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "gb_gemm_fwd": [_P, _P, _P, _P, _P, _I, _L, _I, _I, _P],
     "gb_gemm_dgrad": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P],

@@ -316,26 +316,27 @@ extern "C" int gb_gemm_fwd(const float *x, const float *w, const float *aff, flo
   return check_launch("gb_gemm_fwd");
 }
 
-// dX (P,K) = dY (P,N) Wt(K,N)^T   with Wt = W^T stored (K,N) row-major.
+// dX (P,K) = dY (P,N) W(N,K)   with W in its natural (N,K) row-major layout (no transposed copy).
 // Optional fused BatchNorm-backward statistics of the PREVIOUS layer (whose post-ReLU activation is this
 // GEMM's input, i.e. dX is its dZ): y_prev (P,K) pre-BN output, ab_prev = [a,b,mean,rstd](K),
 // dstats fp64 [stat_slots][2K] (caller-zeroed) += [sum dA, sum dA*xhat],  dA = dX * [a*y+b > 0].
-extern "C" int gb_gemm_dgrad(const float *dy, const float *wt, float *dx, const float *y_prev,
+extern "C" int gb_gemm_dgrad(const float *dy, const float *w, float *dx, const float *y_prev,
                              const float *ab_prev, double *dstats, int stat_slots, long long P, int K, int N,
                              void *stream) {
-  if (P < 0 || K < 1 || N < 1 || !dy || !wt || !dx) return GB_EINVAL;
+  if (P < 0 || K < 1 || N < 1 || !dy || !w || !dx) return GB_EINVAL;
   if (dstats && (!y_prev || !ab_prev || stat_slots < 1)) return GB_EINVAL;
   if (P == 0) return GB_OK;
   if (P / 64 * ((K + 63) / 64) > 0x7fffffffLL) return GB_ERANGE;
   Operand a = {dy, P, N, N, nullptr};
-  Operand b = {wt, K, N, N, nullptr};
-  const bool v = (N % 4 == 0) && aligned16(dy) && aligned16(wt);
+  Operand b = {w, K, N, K, nullptr};  // tile rows = k, reduction = n, element (k,n) at w[n*K + k]
+  const bool va = (N % 4 == 0) && aligned16(dy);
+  const bool vb = (K % 4 == 0) && aligned16(w);
   const long long kchunk = (N + GK - 1) / GK * GK;
   if (dstats)
-    launch_gemm<OP_KC, OP_KC, EPI_STORE_BNBWD>(a, b, v, v, dx, K, dstats, kchunk, 1, as_stream(stream), stat_slots,
+    launch_gemm<OP_KC, OP_RC, EPI_STORE_BNBWD>(a, b, va, vb, dx, K, dstats, kchunk, 1, as_stream(stream), stat_slots,
                                                y_prev, ab_prev);
   else
-    launch_gemm<OP_KC, OP_KC, EPI_STORE>(a, b, v, v, dx, K, nullptr, kchunk, 1, as_stream(stream));
+    launch_gemm<OP_KC, OP_RC, EPI_STORE>(a, b, va, vb, dx, K, nullptr, kchunk, 1, as_stream(stream));
   return check_launch("gb_gemm_dgrad");
 }
 

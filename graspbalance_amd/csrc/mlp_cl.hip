@@ -198,6 +198,19 @@ __global__ void bn_finalize_kernel(const double *__restrict__ stats, int slots, 
   ab[3 * C + c] = rstd;
 }
 
+// dst: fp64 [slots][2C] partial BatchNorm-backward sums -> dstats fp64 [2C] (their total, the form
+// gb_bn_bwd_apply reads) and the parameter gradients dbeta = sum dA, dgamma = sum dA*xhat in fp32.
+__global__ void bn_bwd_reduce_kernel(const double *__restrict__ dst, int slots, int C, double *__restrict__ dstats,
+                                     float *__restrict__ dbeta, float *__restrict__ dgamma) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= 2 * C) return;
+  double s = 0.0;
+  for (int sl = 0; sl < slots; ++sl) s += dst[(size_t)sl * 2 * C + j];
+  if (dstats) dstats[j] = s;
+  if (j < C) dbeta[j] = (float)s;
+  else dgamma[j - C] = (float)s;
+}
+
 // z = act(a*y + b + residual)
 template <int VEC>
 __global__ __launch_bounds__(CL_TPB) void affine_act_kernel(const float *__restrict__ y,
@@ -456,6 +469,14 @@ extern "C" int gb_bn_finalize(const double *stats, int slots, long long P, int C
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), stats, slots, P, C, gamma,
                      beta, eps, momentum, running_mean, running_var, ab, training);
   return check_launch("gb_bn_finalize");
+}
+
+extern "C" int gb_bn_bwd_reduce(const double *dst, int slots, int C, double *dstats, float *dbeta, float *dgamma,
+                                void *stream) {
+  if (C < 1 || slots < 1 || !dst || !dbeta || !dgamma) return GB_EINVAL;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((2 * C + 127) / 128), dim3(128), 0, as_stream(stream), dst, slots, C,
+                     dstats, dbeta, dgamma);
+  return check_launch("gb_bn_bwd_reduce");
 }
 
 extern "C" int gb_affine_act(const float *y, const float *ab, const float *residual, float *z, long long P,

@@ -23,14 +23,19 @@ def shard_batch(batch, rank, world_size):
 
 
 class FlatGradAllReduce:
-    """Views every parameter's ``.grad`` into a handful of contiguous fp32 buckets and all-reduces
-    the buckets (sum, then divide by world size).  Buckets follow reverse registration order so the
-    first bucket is complete early in backward; ``reduce()`` is called after backward."""
+    """All-reduces the whole gradient as a handful of contiguous fp32 buckets (sum, then divide by world
+    size).  Buckets follow reverse registration order (the order backward produces gradients in).
+
+    Gradients are NOT accumulated into the buckets during backward: ``zero_grad()`` sets every ``.grad`` to
+    None so autograd just hands each parameter its freshly computed gradient (no per-parameter add kernel),
+    and ``reduce()`` packs them with one multi-tensor copy per bucket, points ``.grad`` at the bucket views,
+    and launches the collectives.  Single process: ``reduce()`` is a no-op."""
 
     def __init__(self, module, bucket_mb=16.0, process_group=None):
         self.group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         params = [p for p in module.parameters() if p.requires_grad]
+        self.params = list(params)
         params.reverse()
         cap = int(bucket_mb * 1024 * 1024 / 4)
         self.buckets = []
@@ -43,25 +48,37 @@ class FlatGradAllReduce:
             cur_n += p.numel()
         if cur:
             self.buckets.append(cur)
-        self.flat = []
+        self.flat, self.views = [], []
+        if not dist.is_initialized():
+            return
         for bucket in self.buckets:
             total = sum(p.numel() for p in bucket)
             flat = torch.zeros(total, dtype=torch.float32, device=bucket[0].device)
-            off = 0
+            views, off = [], 0
             for p in bucket:
-                p.grad = flat[off:off + p.numel()].view_as(p)  # grads accumulate straight into the bucket
+                views.append(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
             self.flat.append(flat)
+            self.views.append(views)
 
     def zero_grad(self):
-        for flat in self.flat:
-            flat.zero_()
+        for p in self.params:
+            p.grad = None
 
     def reduce(self):
         if not dist.is_initialized():
             return
-        works = [dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                 for flat in self.flat]
+        works = []
+        for bucket, views, flat in zip(self.buckets, self.views, self.flat):
+            have = [(v, p.grad) for v, p in zip(views, bucket) if p.grad is not None]
+            for v, p in zip(views, bucket):
+                if p.grad is None:
+                    v.zero_()  # a parameter this rank's graph did not reach still takes part in the sum
+            if have:
+                torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+            for v, p in zip(views, bucket):
+                p.grad = v
+            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for w, flat in zip(works, self.flat):
             w.wait()
             flat.div_(self.world_size)

@@ -116,7 +116,7 @@ class LinearBNAct(Function):
             Wc = W.contiguous()
             Y = torch.empty((P, Cout), dtype=torch.float32, device=dev)
             _call("gb_gemm_fwd", dev, _lib.ptr(X), _lib.ptr(Wc), None, _lib.ptr(Y), _lib.ptr(stats), slots, P, X.shape[1],
-                  Cout, _s(X), meta={"flop": 2.0 * P * X.shape[1] * Cout})
+                  Cout, _s(X), meta={"flop": 2.0 * P * X.shape[1] * Cout, "pkn": (P, X.shape[1], Cout)})
         else:
             Y = torch.mm(X, W.t())
             if training:
@@ -173,12 +173,12 @@ class LinearBNAct(Function):
             if ctx.needs_input_grad[1]:
                 dW = torch.zeros((Cout, Cin), dtype=torch.float32, device=dev)
                 _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(X), None, _lib.ptr(dW), P, Cin, Cout, _s(dY),
-                      meta={"flop": 2.0 * P * Cin * Cout})
+                      meta={"flop": 2.0 * P * Cin * Cout, "pkn": (P, Cin, Cout)})
             if ctx.needs_input_grad[0]:
-                Wt = W.t().contiguous()
                 dX = torch.empty((P, Cin), dtype=torch.float32, device=dev)
-                _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(Wt), _lib.ptr(dX), None, None, None, 0, P, Cin, Cout, _s(dY),
-                      meta={"flop": 2.0 * P * Cin * Cout})
+                W = W.contiguous()
+                _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dX), None, None, None, 0, P, Cin, Cout, _s(dY),
+                      meta={"flop": 2.0 * P * Cin * Cout, "pkn": (P, Cin, Cout)})
         else:
             dW = _wgrad(dY, X) if ctx.needs_input_grad[1] else None
             dX = torch.mm(dY, W) if ctx.needs_input_grad[0] else None
@@ -215,24 +215,32 @@ class MLPStack(Function):
         L = len(layers)
         X0 = X0.contiguous()
         P = X0.shape[0]
+        slots = STAT_SLOTS if P >= 16384 else 1
+        widths = [params[3 * l].shape[0] for l in range(L)]
+        # one zero-filled fp64 arena for every layer's statistics slots, one fp32 arena for the (a,b,mean,rstd) tables
+        stat_off = [0]
+        for l, cfg in enumerate(layers):
+            stat_off.append(stat_off[-1] + (slots * 2 * widths[l] if cfg.training else 0))
+        stat_arena = torch.zeros(stat_off[-1], dtype=torch.float64, device=dev) if stat_off[-1] else None
+        ab_arena = torch.empty(4 * sum(widths), dtype=torch.float32, device=dev)
         Ws, Ys, abs_ = [], [], []
-        src, aff = X0, None
+        src, aff, ab_off = X0, None, 0
         for l, cfg in enumerate(layers):
             W = params[3 * l].contiguous()
             gamma, beta = params[3 * l + 1], params[3 * l + 2]
             K, N = src.shape[1], W.shape[0]
-            slots = STAT_SLOTS if P >= 16384 else 1
-            stats = torch.zeros(slots * 2 * N, dtype=torch.float64, device=dev) if cfg.training else None
+            stats = stat_arena[stat_off[l]:stat_off[l + 1]] if cfg.training else None
             Y = torch.empty((P, N), dtype=torch.float32, device=dev)
             _call("gb_gemm_fwd", dev, _lib.ptr(src), _lib.ptr(W), _lib.ptr(aff), _lib.ptr(Y), _lib.ptr(stats), slots,
-                  P, K, N, _s(X0), meta={"flop": 2.0 * P * K * N})
-            ab = torch.empty(4 * N, dtype=torch.float32, device=dev)
+                  P, K, N, _s(X0), meta={"flop": 2.0 * P * K * N, "pkn": (P, K, N)})
+            ab = ab_arena[ab_off:ab_off + 4 * N]
+            ab_off += 4 * N
             _call("gb_bn_finalize", dev, _lib.ptr(stats), slots, P, N, _lib.ptr(gamma), _lib.ptr(beta), cfg.eps,
                   cfg.momentum, _lib.ptr(cfg.running_mean), _lib.ptr(cfg.running_var), _lib.ptr(ab),
                   int(cfg.training), _s(X0))
             Ws.append(W); Ys.append(Y); abs_.append(ab)
             src, aff = Y, ab  # ab[:2N] = [a, b] is exactly the next GEMM's prologue table
-        N = Ws[-1].shape[0]
+        N = widths[-1]
         ctx.cfg = (L, P, int(pool_ns), bool(relu_last), [c.training for c in layers], residual is not None)
         if pool_ns:
             R = P // pool_ns
@@ -240,26 +248,58 @@ class MLPStack(Function):
             arg = torch.empty((R, N), dtype=torch.int32, device=dev)
             _call("gb_affine_relu_maxpool", dev, _lib.ptr(Ys[-1]), _lib.ptr(abs_[-1]), _lib.ptr(out), _lib.ptr(arg), R,
                   pool_ns, N, _s(X0))
-            ctx.save_for_backward(X0, out, arg, *Ws, *Ys, *abs_)
+            ctx.save_for_backward(X0, out, arg, ab_arena, *Ws, *Ys)
             return out
         if residual is not None:
             residual = residual.contiguous()
         out = torch.empty((P, N), dtype=torch.float32, device=dev)
         _call("gb_affine_act", dev, _lib.ptr(Ys[-1]), _lib.ptr(abs_[-1]), _lib.ptr(residual), _lib.ptr(out), P, N,
               int(relu_last), _s(X0))
-        ctx.save_for_backward(X0, residual if residual is not None else X0.new_empty(0), X0.new_empty(0), *Ws, *Ys, *abs_)
+        ctx.save_for_backward(X0, residual if residual is not None else X0.new_empty(0), X0.new_empty(0), ab_arena,
+                              *Ws, *Ys)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         L, P, pool_ns, relu_last, training, has_res = ctx.cfg
         saved = ctx.saved_tensors
-        X0, s1, s2 = saved[0], saved[1], saved[2]
-        Ws, Ys, abs_ = saved[3:3 + L], saved[3 + L:3 + 2 * L], saved[3 + 2 * L:3 + 3 * L]
+        X0, s1, s2, ab_arena = saved[0], saved[1], saved[2], saved[3]
+        Ws, Ys = saved[4:4 + L], saved[4 + L:4 + 2 * L]
+        widths = [W.shape[0] for W in Ws]
+        abs_, off = [], 0
+        for n in widths:
+            abs_.append(ab_arena[off:off + 4 * n])
+            off += 4 * n
         dev = dout.device
         dout = dout.contiguous()
-        N = Ws[-1].shape[0]
-        dstats = torch.zeros(2 * N, dtype=torch.float64, device=dev)
+        slots = STAT_SLOTS if P >= 16384 else 1
+        # zero-filled arenas: fp64 BatchNorm-backward sums ([2N] last layer, then per layer l<L-1 the slot rows
+        # the dgrad epilogue adds into + their total), fp32 weight gradients (wgrad accumulates with atomics)
+        fused = [widths[l] * P <= _DGRAD_BN_MAX for l in range(L - 1)]
+        d_off = [2 * widths[-1]]
+        for l in range(L - 1):
+            d_off.append(d_off[-1] + ((slots + 1) * 2 * widths[l] if fused[l] and slots > 1 else 2 * widths[l]))
+        d_arena = torch.zeros(d_off[-1], dtype=torch.float64, device=dev)
+        need_w = [ctx.needs_input_grad[5 + 3 * l] for l in range(L)]
+        kin = [X0.shape[1]] + widths[:-1]
+        w_off = [0]
+        for l in range(L):
+            w_off.append(w_off[-1] + (widths[l] * kin[l] if need_w[l] else 0))
+        w_arena = torch.zeros(w_off[-1], dtype=torch.float32, device=dev) if w_off[-1] else None
+        gb_arena = torch.empty(2 * sum(widths), dtype=torch.float32, device=dev)  # [dbeta, dgamma] per layer
+        gb_off = [0]
+        for n in widths:
+            gb_off.append(gb_off[-1] + 2 * n)
+
+        def param_grads(l, partial, nslots, total):
+            n = widths[l]
+            dbeta, dgamma = gb_arena[gb_off[l]:gb_off[l] + n], gb_arena[gb_off[l] + n:gb_off[l + 1]]
+            _call("gb_bn_bwd_reduce", dev, _lib.ptr(partial), nslots, n, _lib.ptr(total), _lib.ptr(dbeta),
+                  _lib.ptr(dgamma), _s(dout))
+            return dgamma, dbeta
+
+        N = widths[-1]
+        dstats = d_arena[:2 * N]
         dres = None
         dY = torch.empty((P, N), dtype=torch.float32, device=dev)
         if pool_ns:
@@ -278,44 +318,75 @@ class MLPStack(Function):
             _call("gb_bn_bwd_apply", dev, _lib.ptr(dout), _lib.ptr(Ys[-1]), _lib.ptr(abs_[-1]), _lib.ptr(residual),
                   _lib.ptr(dstats), P, N, int(relu_last), int(training[-1]), _lib.ptr(dY), _lib.ptr(dres), _s(dout))
         grads = [None] * (3 * L)
+        grads[3 * L - 2], grads[3 * L - 1] = param_grads(L - 1, dstats, 1, None)
         dX0 = None
         for l in range(L - 1, -1, -1):
             W = Ws[l]
             N, K = W.shape
             src, aff = (X0, None) if l == 0 else (Ys[l - 1], abs_[l - 1])
-            if ctx.needs_input_grad[5 + 3 * l]:
-                dW = torch.zeros((N, K), dtype=torch.float32, device=dev)
+            if need_w[l]:
+                dW = w_arena[w_off[l]:w_off[l + 1]]
                 _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(src), _lib.ptr(aff), _lib.ptr(dW), P, K, N, _s(dout),
-                      meta={"flop": 2.0 * P * K * N})
-                grads[3 * l] = dW.view_as(W)
-            grads[3 * l + 1] = dstats[N:].float()   # dgamma = sum dA*xhat
-            grads[3 * l + 2] = dstats[:N].float()   # dbeta  = sum dA
+                      meta={"flop": 2.0 * P * K * N, "pkn": (P, K, N)})
+                grads[3 * l] = dW.view(N, K)
             if l == 0:
                 if ctx.needs_input_grad[0]:
                     dX0 = torch.empty((P, K), dtype=torch.float32, device=dev)
-                    _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W.t().contiguous()), _lib.ptr(dX0), None, None,
-                          None, 0, P, K, N, _s(dout), meta={"flop": 2.0 * P * K * N})
+                    _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dX0), None, None, None, 0, P, K, N,
+                          _s(dout), meta={"flop": 2.0 * P * K * N, "pkn": (P, K, N)})
                 break
             # gradient of layer l-1's post-ReLU output + that layer's BatchNorm-backward sums in one launch
             dZ = torch.empty((P, K), dtype=torch.float32, device=dev)
-            if K * P <= _DGRAD_BN_MAX:
-                slots = STAT_SLOTS if P >= 16384 else 1
-                dst = torch.zeros(slots * 2 * K, dtype=torch.float64, device=dev)
-                _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W.t().contiguous()), _lib.ptr(dZ),
-                      _lib.ptr(Ys[l - 1]), _lib.ptr(abs_[l - 1]), _lib.ptr(dst), slots, P, K, N, _s(dout),
-                      meta={"flop": 2.0 * P * K * N})
-                dstats = dst.view(slots, 2 * K).sum(0) if slots > 1 else dst
+            region = d_arena[d_off[l - 1]:d_off[l]]
+            if fused[l - 1]:
+                _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dZ), _lib.ptr(Ys[l - 1]),
+                      _lib.ptr(abs_[l - 1]), _lib.ptr(region), slots, P, K, N, _s(dout),
+                      meta={"flop": 2.0 * P * K * N, "pkn": (P, K, N)})
+                dstats = region[slots * 2 * K:] if slots > 1 else region
+                grads[3 * l - 2], grads[3 * l - 1] = param_grads(l - 1, region, slots, dstats if slots > 1 else None)
             else:
                 # wide + long outputs: the fused epilogue measured slower than a separate column pass
-                _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W.t().contiguous()), _lib.ptr(dZ), None, None,
-                      None, 0, P, K, N, _s(dout), meta={"flop": 2.0 * P * K * N})
-                dstats = torch.zeros(2 * K, dtype=torch.float64, device=dev)
+                _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dZ), None, None, None, 0, P, K, N,
+                      _s(dout), meta={"flop": 2.0 * P * K * N, "pkn": (P, K, N)})
+                dstats = region
                 _call("gb_bn_bwd_stats", dev, _lib.ptr(dZ), _lib.ptr(Ys[l - 1]), _lib.ptr(abs_[l - 1]), None, P, K, 1,
                       _lib.ptr(dstats), _s(dout))
+                grads[3 * l - 2], grads[3 * l - 1] = param_grads(l - 1, dstats, 1, None)
             dY = torch.empty((P, K), dtype=torch.float32, device=dev)
             _call("gb_bn_bwd_apply", dev, _lib.ptr(dZ), _lib.ptr(Ys[l - 1]), _lib.ptr(abs_[l - 1]), None,
                   _lib.ptr(dstats), P, K, 1, int(training[l - 1]), _lib.ptr(dY), None, _s(dout))
         return (dX0, dres, None, None, None, *grads)
+
+
+_pending_counters = None  # list of num_batches_tracked buffers while inside deferred_counters()
+
+
+class deferred_counters:
+    """Within this context the fused layers' ``num_batches_tracked += 1`` are collected and applied as one
+    multi-tensor add on exit (the model's forward wraps itself in it: ~80 one-element launches -> 1)."""
+
+    def __enter__(self):
+        global _pending_counters
+        self.outer = _pending_counters
+        if self.outer is None:
+            _pending_counters = []
+        return self
+
+    def __exit__(self, *exc):
+        global _pending_counters
+        if self.outer is None:
+            pending, _pending_counters = _pending_counters, None
+            if pending:
+                torch._foreach_add_(pending, 1)
+        return False
+
+
+def _count_batch(bn):
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        if _pending_counters is not None:
+            _pending_counters.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked.add_(1)
 
 
 def _stack(X, convs_bns, pool_ns=0, residual=None, relu_last=True):
@@ -323,8 +394,7 @@ def _stack(X, convs_bns, pool_ns=0, residual=None, relu_last=True):
     for conv, bn in convs_bns:
         if conv.bias is not None:
             raise NotImplementedError("fused path expects bias-free convs followed by BatchNorm")
-        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+        _count_batch(bn)
         params += [conv.weight.view(conv.weight.shape[0], -1), bn.weight, bn.bias]
         layers.append(_LayerCfg(bn))
     return MLPStack.apply(X, residual, layers, pool_ns, relu_last, *params)
@@ -338,8 +408,7 @@ def conv_bn_act(X, conv, bn, relu=True, pool_ns=0, residual=None):
     W = conv.weight.view(conv.weight.shape[0], -1)
     if conv.bias is not None:
         raise NotImplementedError("fused path expects bias-free convs followed by BatchNorm")
-    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    _count_batch(bn)
     momentum = 0.0 if bn.momentum is None else bn.momentum
     training = bn.training or not bn.track_running_stats
     return LinearBNAct.apply(X, W, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, momentum, bn.eps,

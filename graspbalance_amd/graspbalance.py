@@ -10,7 +10,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import fused_ops
+from . import fused_mlp, fused_ops
 from .drp import DRP
 from .label_generation import match_grasp_view_and_label, process_grasp_labels
 from .loss_utils import GRASP_MAX_TOLERANCE, GRASP_MAX_WIDTH, batch_viewpoint_params_to_matrix
@@ -124,10 +124,11 @@ class GraspBalance(nn.Module):
             num_angle, num_depth, cylinder_radius, hmin, hmax_list, is_training, fused_cylinder=fused_cylinder)
 
     def forward(self, end_points):
-        end_points = self.view_estimator(end_points)
-        if self.is_training:
-            end_points = process_grasp_labels(end_points)
-        return self.grasp_generator(end_points)
+        with fused_mlp.deferred_counters():  # one multi-tensor BN batch-counter update for the whole pass
+            end_points = self.view_estimator(end_points)
+            if self.is_training:
+                end_points = process_grasp_labels(end_points)
+            return self.grasp_generator(end_points)
 
 
 def pred_decode(end_points):

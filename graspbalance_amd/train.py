@@ -45,6 +45,6 @@ class Trainer:
         loss.backward()
         self.grads.reduce()
         self.optimizer.step()
-        self.grads.zero_grad()  # optimizer.zero_grad() would drop the flat-bucket views
+        self.grads.zero_grad()  # .grad = None: the next backward assigns instead of accumulating
         self.scheduler.step()
         return loss

@@ -188,6 +188,13 @@ int gb_bn_bwd_apply_pool(const float *dout, const float *out, const int32_t *arg
                          const float *ab, const double *dstats, long long R, int ns, int C, int training,
                          float *dy, void *stream);
 
+/* Sum the [slots][2C] fp64 partial BatchNorm-backward sums a GEMM epilogue (gb_gemm_dgrad) or
+ * gb_bn_bwd_stats left: dstats (optional, fp64 [2C]) = the totals in the form gb_bn_bwd_apply reads,
+ * dbeta / dgamma (fp32 [C]) = the BatchNorm parameter gradients (torch: batch_norm_backward's
+ * grad_bias / grad_weight, reached by the reference through nn.BatchNorm2d, pytorch_utils.py:74-78). */
+int gb_bn_bwd_reduce(const double *dst, int slots, int C, double *dstats, float *dbeta, float *dgamma,
+                     void *stream);
+
 /* ---- fp32 MFMA GEMMs of the channel-last SharedMLP (csrc/gemm_cl.hip) — replace the cuBLAS/cuDNN
  * 1x1 convolutions the reference reaches through torch (pytorch_utils.py:61-113) ------------------- */
 /* Y (P,N) = f(X (P,K)) W(N,K)^T.  aff (optional) = [a(K), b(K)]: f(x) = relu(a_k x + b_k), i.e. the
@@ -196,11 +203,11 @@ int gb_bn_bwd_apply_pool(const float *dout, const float *out, const int32_t *arg
  * slot rows to avoid same-address atomic contention; gb_bn_finalize sums the rows.                 */
 int gb_gemm_fwd(const float *x, const float *w, const float *aff, float *y, double *stats, int stat_slots,
                 long long P, int K, int N, void *stream);
-/* dX (P,K) = dY (P,N) W(N,K), given Wt = W^T stored (K,N) row-major.  Optional fused BatchNorm-backward
+/* dX (P,K) = dY (P,N) W(N,K), W in its natural (N,K) row-major layout.  Optional fused BatchNorm-backward
  * statistics of the previous layer (dX is the gradient of its post-ReLU output): y_prev (P,K) its pre-BN
  * output, ab_prev = [a,b,mean,rstd](K), dstats fp64 [stat_slots][2K] (caller-zeroed) += [sum dA,
  * sum dA*xhat] with dA = dX*[a*y+b > 0].  Pass NULLs / 0 to skip.                                  */
-int gb_gemm_dgrad(const float *dy, const float *wt, float *dx, const float *y_prev, const float *ab_prev,
+int gb_gemm_dgrad(const float *dy, const float *w, float *dx, const float *y_prev, const float *ab_prev,
                   double *dstats, int stat_slots, long long P, int K, int N, void *stream);
 /* dW (N,K) += dY (P,N)^T f(X (P,K)); accumulates (fp32 atomics, reduction over P split across
  * workgroups).  x_aff (optional) = [a(K), b(K)]: f(x) = relu(a_k x + b_k), as in gb_gemm_fwd.      */

@@ -43,7 +43,7 @@ def _worker(rank, world, port, out_dir):
     opt = torch.optim.Adam(net.parameters(), lr=1e-3)
     loss, _ = get_loss(net(mine))
     loss.backward()
-    local = [p.grad.clone() for p in net.parameters()]
+    local = [p.grad.clone() if p.grad is not None else torch.zeros_like(p) for p in net.parameters()]
     grads.reduce()
     reduced = [p.grad.clone() for p in net.parameters()]
     opt.step()

@@ -46,9 +46,8 @@ def test_gemm_dgrad_and_wgrad(P, K, N):
     X = torch.randn(P, K, device=DEV)
     W = torch.randn(N, K, device=DEV)
     dY = torch.randn(P, N, device=DEV)
-    Wt = W.t().contiguous()
     dX = torch.empty(P, K, device=DEV)
-    L.check(L.lib().gb_gemm_dgrad(L.ptr(dY), L.ptr(Wt), L.ptr(dX), None, None, None, 0, P, K, N, None), "dgrad")
+    L.check(L.lib().gb_gemm_dgrad(L.ptr(dY), L.ptr(W), L.ptr(dX), None, None, None, 0, P, K, N, None), "dgrad")
     dW = torch.zeros(N, K, device=DEV)
     L.check(L.lib().gb_gemm_wgrad(L.ptr(dY), L.ptr(X), None, L.ptr(dW), P, K, N, None), "wgrad")
     torch.cuda.synchronize()

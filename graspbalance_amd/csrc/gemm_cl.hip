@@ -17,6 +17,7 @@
 // buffered, filled through registers one step ahead of the MFMAs.  The contraction is compute-bound
 // (16 KB of operands per 4.2 MFLOP), so plain ds_read_b32 operand fetches are off the critical path.
 #include "gb_common.h"
+#include "gemm_rs.h"
 
 namespace gb {
 
@@ -307,6 +308,9 @@ extern "C" int gb_gemm_fwd(const float *x, const float *w, const float *aff, flo
   if (P < 0 || K < 1 || N < 1 || !x || !w || !y || (stats && stat_slots < 1)) return GB_EINVAL;
   if (P == 0) return GB_OK;
   if (P / 64 * ((N + 63) / 64) > 0x7fffffffLL) return GB_ERANGE;
+  if (rs_gemm_try(x, w, y, aff, stats, stat_slots, nullptr, nullptr, P, K, N, 1, stats ? RS_STATS : RS_STORE,
+                  as_stream(stream)))
+    return check_launch("gb_gemm_fwd");
   Operand a = {x, P, K, K, aff};
   Operand b = {w, N, K, K, nullptr};
   const bool v = (K % 4 == 0) && aligned16(x) && aligned16(w);
@@ -327,6 +331,9 @@ extern "C" int gb_gemm_dgrad(const float *dy, const float *w, float *dx, const f
   if (dstats && (!y_prev || !ab_prev || stat_slots < 1)) return GB_EINVAL;
   if (P == 0) return GB_OK;
   if (P / 64 * ((K + 63) / 64) > 0x7fffffffLL) return GB_ERANGE;
+  if (rs_gemm_try(dy, w, dx, nullptr, dstats, stat_slots, y_prev, ab_prev, P, N, K, 0, dstats ? RS_BNBWD : RS_STORE,
+                  as_stream(stream)))
+    return check_launch("gb_gemm_dgrad");
   Operand a = {dy, P, N, N, nullptr};
   Operand b = {w, K, N, K, nullptr};  // tile rows = k, reduction = n, element (k,n) at w[n*K + k]
   const bool va = (N % 4 == 0) && aligned16(dy);

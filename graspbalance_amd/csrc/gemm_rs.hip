@@ -1,0 +1,306 @@
+// Row-streaming fp32 MFMA GEMM for the tall-skinny products of the channel-last SharedMLP path
+// (gfx950, v_mfma_f32_32x32x2_f32).  D (P,C) = f(A (P,R)) B (R,C) with P ~ 10^5..10^6 rows and a
+// small weight matrix B (R*C*4 <= ~128 KB):
+//
+//   * the whole of B is staged ONCE per workgroup in LDS ([r][C32] image, zero padded) and stays
+//     there; workgroups are persistent (one or two per CU) and their 8 waves walk 32-row tiles of A;
+//   * A never touches LDS.  The MFMA A operand of lane l is A[row l&31][k-slot l>>5], and any
+//     permutation of the reduction index is legal as long as B uses the same one, so each lane takes
+//     16 CONTIGUOUS reduction indices of its row per chunk (half 0: k0..k0+15, half 1: k0+16..k0+31)
+//     straight from global memory as four 16-byte loads, one chunk ahead of the MFMAs that consume it
+//     (register double buffer; a chunk is 16*NT MFMAs = 1024*NT cycles of cover for the next loads);
+//   * every element of A is read from HBM exactly once and every element of D written once; the
+//     previous layer's BatchNorm affine + ReLU is applied to A in registers, the BatchNorm column
+//     statistics of D (forward) or the BatchNorm-backward sums (dgrad) accumulate in fp64 registers
+//     across all the tiles of a wave and leave as ONE atomic per column per workgroup.
+//
+// Used by gb_gemm_fwd / gb_gemm_dgrad (csrc/gemm_cl.hip) when the shape fits; the LDS-tiled kernel
+// there remains the general path.  Replaces the cuBLAS/cuDNN 1x1 convolutions the reference reaches
+// through torch (pytorch_utils.py:61-113).
+#include <stdlib.h>
+
+#include "gb_common.h"
+#include "gemm_rs.h"
+
+namespace gb {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int RS_TPB = 512, RS_WAVES = RS_TPB / 64;
+constexpr int RS_CH = 32;  // reduction indices per chunk: 16 contiguous per lane half
+
+struct RsArgs {
+  const float *a;       // (P,R), row pitch lda
+  const float *w;       // weights, see w_kc
+  float *d;             // (P,C), row pitch ldd
+  const float *aff;     // optional [a(R), b(R)]: A is used as relu(a_k x + b_k)
+  double *stats;        // fp64 [slots][2C]
+  const float *epi_y;   // RS_BNBWD: (P,C) pitch ldd, pre-BatchNorm output of the layer D is the gradient of
+  const float *epi_ab;  // RS_BNBWD: [a, b, mean, rstd](C)
+  long long P;
+  int R, C, lda, ldd;
+  int w_kc;             // 1: B[r][c] = w[c*R + r] (forward, W (C,R));  0: B[r][c] = w[r*C + c] (dgrad, W (R,C))
+  int slots, nch;       // statistics slot rows ; chunks = ceil(R / 32)
+};
+
+template <int NT, int EPI>
+__global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD) ? 4 : 2)) void gemm_rs_kernel(RsArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int C32 = NT * 32;
+  const int rpad = g.nch * RS_CH;
+  float *Bs = lds;                        // [rpad][C32]
+  float *s_aff = lds + (size_t)rpad * C32;  // [2][rpad]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int m = lane & 31, h = lane >> 5;
+
+  // ---- stage B (zero padded); consecutive threads write consecutive columns: conflict-free
+  if (g.w_kc) {
+    const int quads = rpad / 4;
+    for (int i = t; i < quads * C32; i += RS_TPB) {
+      const int c = i % C32, r = (i / C32) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < g.C && r < g.R) v = *reinterpret_cast<const float4 *>(g.w + (size_t)c * g.R + r);  // R % 4 == 0
+      Bs[(r + 0) * C32 + c] = v.x;
+      Bs[(r + 1) * C32 + c] = v.y;
+      Bs[(r + 2) * C32 + c] = v.z;
+      Bs[(r + 3) * C32 + c] = v.w;
+    }
+  } else {
+    for (int i = t; i < rpad * C32; i += RS_TPB) {
+      const int c = i % C32, r = i / C32;
+      Bs[i] = (r < g.R && c < g.C) ? g.w[(size_t)r * g.C + c] : 0.f;
+    }
+  }
+  if (g.aff)
+    for (int i = t; i < rpad; i += RS_TPB) {
+      s_aff[i] = i < g.R ? g.aff[i] : 0.f;
+      s_aff[rpad + i] = i < g.R ? g.aff[g.R + i] : 0.f;
+    }
+  __syncthreads();
+
+  const long long ntiles = (g.P + 31) / 32;
+  const long long nw = (long long)gridDim.x * RS_WAVES;
+  long long tile = (long long)blockIdx.x * RS_WAVES + wave;
+
+  double dsum[NT], dsq[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) { dsum[j] = 0.0; dsq[j] = 0.0; }
+  // BatchNorm coefficients of this lane's columns: resident in registers unless the accumulators need them
+  constexpr bool COEF_REGS = NT <= 5;
+  float ea[NT], eb[NT], em[NT], er[NT];
+  if constexpr (EPI == RS_BNBWD && COEF_REGS) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = j * 32 + m;
+      const bool ok = col < g.C;
+      ea[j] = ok ? g.epi_ab[col] : 0.f;
+      eb[j] = ok ? g.epi_ab[g.C + col] : 0.f;
+      em[j] = ok ? g.epi_ab[2 * g.C + col] : 0.f;
+      er[j] = ok ? g.epi_ab[3 * g.C + col] : 0.f;
+    }
+  }
+
+  auto load_chunk = [&](float4 (&dst)[4], long long tl, int kc) {
+    const long long row = tl * 32 + m;
+    const int k = kc * RS_CH + h * 16;
+    const float *p = g.a + row * g.lda + k;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      dst[i] = (row < g.P && k + 4 * i < g.R) ? *reinterpret_cast<const float4 *>(p + 4 * i)
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+
+  if (tile < ntiles) {
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    float4 cur[4], nxt[4];
+    load_chunk(cur, tile, 0);
+    int kc = 0;
+    while (true) {
+      int nkc = kc + 1;
+      long long ntile = tile;
+      if (nkc == g.nch) { nkc = 0; ntile = tile + nw; }
+      const bool more = ntile < ntiles;
+      if (more) load_chunk(nxt, ntile, nkc);
+
+      float av[16];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { av[4 * i] = cur[i].x; av[4 * i + 1] = cur[i].y; av[4 * i + 2] = cur[i].z; av[4 * i + 3] = cur[i].w; }
+      if (g.aff) {  // previous layer's BatchNorm + ReLU; channels >= R have a = b = 0 and stay zero
+        const float *ca = s_aff + kc * RS_CH + h * 16;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float z = ca[i] * av[i] + ca[rpad + i];
+          av[i] = z > 0.f ? z : 0.f;
+        }
+      }
+      // RS_BNBWD: the y values the epilogue needs are requested BEFORE the tile's last MFMA block, so their
+      // latency hides behind it (registers permitting; otherwise per column tile inside the epilogue)
+      constexpr bool YPRE = EPI == RS_BNBWD && NT <= 4;
+      float yv[YPRE ? NT : 1][16];
+      if constexpr (YPRE) {
+        if (kc == g.nch - 1) {
+#pragma unroll
+          for (int q = 0; q < NT; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const long long row = tile * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
+              const int col = q * 32 + m;
+              yv[q][r] = (col < g.C && row < g.P) ? g.epi_y[row * g.ldd + col] : 0.f;
+            }
+        }
+      }
+      const float *bp = Bs + (size_t)(kc * RS_CH + h * 16) * C32 + m;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        float bv[NT];
+#pragma unroll
+        for (int q = 0; q < NT; ++q) bv[q] = bp[j * C32 + q * 32];
+#pragma unroll
+        for (int q = 0; q < NT; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[q], acc[q], 0, 0, 0);
+      }
+
+      if (kc == g.nch - 1) {
+        // acc[q][r] = D[tile*32 + (r&3) + 8*(r>>2) + 4*h][q*32 + m]
+        const long long row0 = tile * 32 + 4 * h;
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+          const int col = q * 32 + m;
+          const bool colok = col < g.C;
+          float cs = 0.f, cq = 0.f;
+          if constexpr (EPI == RS_BNBWD && !COEF_REGS) {
+            ea[q] = colok ? g.epi_ab[col] : 0.f;
+            eb[q] = colok ? g.epi_ab[g.C + col] : 0.f;
+            em[q] = colok ? g.epi_ab[2 * g.C + col] : 0.f;
+            er[q] = colok ? g.epi_ab[3 * g.C + col] : 0.f;
+          }
+          float yq[16];
+          if constexpr (EPI == RS_BNBWD && !YPRE) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const long long row = row0 + (r & 3) + 8 * (r >> 2);
+              yq[r] = (colok && row < g.P) ? g.epi_y[row * g.ldd + col] : 0.f;
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const long long row = row0 + (r & 3) + 8 * (r >> 2);
+            const float v = acc[q][r];
+            if (colok && row < g.P) {
+              g.d[row * g.ldd + col] = v;
+              if constexpr (EPI == RS_STATS) { cs += v; cq += v * v; }
+              if constexpr (EPI == RS_BNBWD) {
+                const float y = YPRE ? yv[YPRE ? q : 0][r] : yq[r];
+                const float gg = (ea[q] * y + eb[q]) > 0.f ? v : 0.f;
+                cs += gg;
+                cq += gg * ((y - em[q]) * er[q]);
+              }
+            }
+            acc[q][r] = 0.f;
+          }
+          if constexpr (EPI != RS_STORE) { dsum[q] += (double)cs; dsq[q] += (double)cq; }
+        }
+      }
+      if (!more) break;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
+      kc = nkc;
+      tile = ntile;
+    }
+  }
+
+  if constexpr (EPI != RS_STORE) {
+    // per-column totals: lanes l / l+32 share a column, then the 8 waves through LDS (B is dead now)
+    __syncthreads();
+    double *sd = reinterpret_cast<double *>(lds);  // [wave][2][C32]
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+      const double s1 = dsum[q] + __shfl_xor(dsum[q], 32);
+      const double s2 = dsq[q] + __shfl_xor(dsq[q], 32);
+      if (h == 0) {
+        sd[(wave * 2 + 0) * C32 + q * 32 + m] = s1;
+        sd[(wave * 2 + 1) * C32 + q * 32 + m] = s2;
+      }
+    }
+    __syncthreads();
+    double *st = g.stats + (size_t)(blockIdx.x % g.slots) * 2 * g.C;
+    for (int i = t; i < 2 * C32; i += RS_TPB) {
+      const int which = i / C32, col = i % C32;
+      if (col < g.C) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; ++w) s += sd[(w * 2 + which) * C32 + col];
+        atomicAdd(st + which * g.C + col, s);
+      }
+    }
+  }
+}
+
+static int num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+  }
+  return n;
+}
+
+static bool rs_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char *e = getenv("GB_GEMM_RS");  // GB_GEMM_RS=0: A/B switch back to the LDS-tiled kernel
+    on = !(e && e[0] == '0');
+  }
+  return on != 0;
+}
+
+template <int NT, int EPI>
+static void rs_launch(const RsArgs &g, size_t lds_bytes, int blocks_per_cu, hipStream_t s) {
+  static bool attr_set = false;
+  auto kern = gemm_rs_kernel<NT, EPI>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const long long ntiles = (g.P + 31) / 32;
+  long long blocks = (ntiles + RS_WAVES - 1) / RS_WAVES;
+  const long long cap = (long long)num_cus() * blocks_per_cu;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(RS_TPB), lds_bytes, s, g);
+}
+
+bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, double *stats, int slots,
+                 const float *epi_y, const float *epi_ab, long long P, int R, int C, int w_kc, int epi,
+                 hipStream_t s) {
+  if (!rs_enabled()) return false;
+  if (P < 16384 || R % 4 != 0 || R < 16 || C < 33) return false;
+  if (reinterpret_cast<uintptr_t>(a) % 16 != 0 || (w_kc && reinterpret_cast<uintptr_t>(w) % 16 != 0)) return false;
+  const int nch = (R + RS_CH - 1) / RS_CH;
+  const int tiles_c = (C + 31) / 32;
+  const int nt = tiles_c <= 2 ? 2 : tiles_c <= 4 ? 4 : tiles_c == 5 ? 5 : tiles_c <= 8 ? 8 : 0;
+  if (!nt) return false;
+  if (epi == RS_BNBWD && nt == 8) return false;  // accumulators + y prefetch do not fit the register file
+  // MFMA work wasted on padding must stay small
+  if ((long long)nch * RS_CH * nt * 32 * 4 > (long long)R * C * 5) return false;
+  const size_t lds_bytes = ((size_t)nch * RS_CH * nt * 32 + (aff ? 2 * nch * RS_CH : 0)) * sizeof(float);
+  if (lds_bytes > 156 * 1024) return false;
+  RsArgs g = {a, w, d, aff, stats, epi_y, epi_ab, P, R, C, R, C, w_kc, slots < 1 ? 1 : slots, nch};
+  const int bpc = (nt <= 2 && epi != RS_BNBWD && lds_bytes <= 78 * 1024) ? 2 : 1;
+#define GB_RS(NT_)                                                         \
+  do {                                                                     \
+    if (epi == RS_STATS) rs_launch<NT_, RS_STATS>(g, lds_bytes, bpc, s);   \
+    else if (epi == RS_BNBWD) rs_launch<NT_, RS_BNBWD>(g, lds_bytes, bpc, s); \
+    else rs_launch<NT_, RS_STORE>(g, lds_bytes, bpc, s);                   \
+  } while (0)
+  if (nt == 2) GB_RS(2);
+  else if (nt == 4) GB_RS(4);
+  else if (nt == 5) GB_RS(5);
+  else GB_RS(8);
+#undef GB_RS
+  return true;
+}
+
+}  // namespace gb

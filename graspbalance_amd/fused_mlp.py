@@ -21,7 +21,7 @@ from . import _lib
 
 _ENABLED = True
 STAT_SLOTS = 32   # rows of the BN-statistics buffer the GEMM epilogue spreads its fp64 atomics over
-_DGRAD_BN_MAX = int(os.environ.get("GB_DGRAD_BN_MAX", 1 << 26))  # rows*cols above which dgrad's fused BN-backward sums lose to a separate pass
+_DGRAD_BN_MAX = int(os.environ.get("GB_DGRAD_BN_MAX", 1 << 40))  # rows*cols above which dgrad's BN-backward sums run as a separate pass (A/B switch)
 _OWN_GEMM = True  # hand-written MFMA GEMMs (csrc/gemm_cl.hip); False = torch.mm (rocBLAS) for A/B timing
 
 

@@ -7,7 +7,9 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 SHAPES = [(1000, 3, 64), (4096, 64, 64), (5000, 131, 128), (777, 259, 256), (2048, 128, 512), (130, 512, 128),
-          (8192, 16, 8), (1, 5, 3), (33000, 64, 128)]
+          (8192, 16, 8), (1, 5, 3), (33000, 64, 128),
+          # tall shapes that take the row-streaming kernel (csrc/gemm_rs.hip) in fwd and/or dgrad
+          (20011, 128, 256), (16400, 64, 131), (17000, 132, 40), (40000, 256, 96), (16384, 32, 256), (70000, 256, 128)]
 
 
 def _lib():
@@ -55,3 +57,41 @@ def test_gemm_dgrad_and_wgrad(P, K, N):
     rw = dY.double().t() @ X.double()
     assert float((dX.double() - rx).abs().max()) / (float(rx.abs().max()) + 1e-12) < 2e-6
     assert float((dW.double() - rw).abs().max()) / (float(rw.abs().max()) + 1e-12) < 1e-5
+
+
+@pytest.mark.parametrize("P,K,N", SHAPES)
+def test_gemm_fused_epilogues_slotted(P, K, N):
+    """forward: prologue affine + statistics spread over slot rows; dgrad: BatchNorm-backward sums."""
+    L = _lib()
+    torch.manual_seed(P * 7 + K + N)
+    slots = 4
+    X = torch.randn(P, K, device=DEV)
+    W = torch.randn(N, K, device=DEV) / K ** 0.5
+    aff = torch.cat([torch.randn(K, device=DEV), torch.randn(K, device=DEV)])
+    Y = torch.empty(P, N, device=DEV)
+    stats = torch.zeros(slots, 2 * N, dtype=torch.float64, device=DEV)
+    L.check(L.lib().gb_gemm_fwd(L.ptr(X), L.ptr(W), L.ptr(aff), L.ptr(Y), L.ptr(stats), slots, P, K, N, None), "fwd")
+    torch.cuda.synchronize()
+    ref = torch.relu(aff[:K] * X + aff[K:]).double() @ W.double().t()
+    assert float((Y.double() - ref).abs().max()) / (float(ref.abs().max()) + 1e-12) < 2e-6
+    st = stats.sum(0)
+    assert torch.allclose(st[:N], Y.double().sum(0), rtol=1e-6, atol=1e-6 * P ** 0.5)
+    assert torch.allclose(st[N:], (Y.double() ** 2).sum(0), rtol=1e-6, atol=1e-9)
+
+    dY = torch.randn(P, N, device=DEV)
+    yprev = torch.randn(P, K, device=DEV)
+    ab = torch.cat([torch.randn(K, device=DEV), torch.randn(K, device=DEV), torch.randn(K, device=DEV),
+                    torch.rand(K, device=DEV) + 0.5])
+    dX = torch.empty(P, K, device=DEV)
+    dst = torch.zeros(slots, 2 * K, dtype=torch.float64, device=DEV)
+    L.check(L.lib().gb_gemm_dgrad(L.ptr(dY), L.ptr(W), L.ptr(dX), L.ptr(yprev), L.ptr(ab), L.ptr(dst), slots, P, K, N,
+                                  None), "dgrad bn")
+    torch.cuda.synchronize()
+    rx = dY.double() @ W.double()
+    assert float((dX.double() - rx).abs().max()) / (float(rx.abs().max()) + 1e-12) < 2e-6
+    a, b, mean, rstd = ab[:K], ab[K:2 * K], ab[2 * K:3 * K], ab[3 * K:]
+    g = torch.where(a * yprev + b > 0, dX, torch.zeros_like(dX)).double()
+    xhat = ((yprev - mean) * rstd).double()
+    d = dst.sum(0)
+    assert torch.allclose(d[:K], g.sum(0), rtol=1e-5, atol=1e-5 * P ** 0.5)
+    assert torch.allclose(d[K:], (g * xhat).sum(0), rtol=1e-5, atol=1e-5 * P ** 0.5)

@@ -46,6 +46,8 @@ def _s(t):
 def _call(name, dev, *args, meta=None):
     with torch.cuda.device(dev):
         fn = getattr(_lib.lib(), name)
+        if meta is None and _lib.KernelTimer.active is not None:
+            meta = {"ints": tuple(a for a in args if isinstance(a, int))}  # sizes, for tools/kernel_breakdown.py
         _lib.check(_lib.timed(name, dev, meta, lambda: fn(*args)), name)
 
 

@@ -53,6 +53,7 @@ SIGNATURES = {
     "gb_gemm_fwd": [_P, _P, _P, _P, _P, _I, _L, _I, _I, _P],
     "gb_gemm_dgrad": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P],
     "gb_gemm_wgrad": [_P, _P, _P, _P, _L, _I, _I, _P],
+    "gb_gemm_uses_rs": [_L, _I, _I, _I, _I, _I],
 }
 
 

@@ -272,12 +272,10 @@ static void rs_launch(const RsArgs &g, size_t lds_bytes, int blocks_per_cu, hipS
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(RS_TPB), lds_bytes, s, g);
 }
 
-bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, double *stats, int slots,
-                 const float *epi_y, const float *epi_ab, long long P, int R, int C, int w_kc, int epi,
-                 hipStream_t s) {
+// shape part of the dispatch rule (pointer alignment aside); nt_out = column tiles of the instantiation
+static bool rs_shape_ok(long long P, int R, int C, int epi, bool has_aff, int *nt_out, size_t *lds_out) {
   if (!rs_enabled()) return false;
   if (P < 16384 || R % 4 != 0 || R < 16 || C < 33) return false;
-  if (reinterpret_cast<uintptr_t>(a) % 16 != 0 || (w_kc && reinterpret_cast<uintptr_t>(w) % 16 != 0)) return false;
   const int nch = (R + RS_CH - 1) / RS_CH;
   const int tiles_c = (C + 31) / 32;
   const int nt = tiles_c <= 2 ? 2 : tiles_c <= 4 ? 4 : tiles_c == 5 ? 5 : tiles_c <= 8 ? 8 : 0;
@@ -285,8 +283,21 @@ bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, dou
   if (epi == RS_BNBWD && nt == 8) return false;  // accumulators + y prefetch do not fit the register file
   // MFMA work wasted on padding must stay small
   if ((long long)nch * RS_CH * nt * 32 * 4 > (long long)R * C * 5) return false;
-  const size_t lds_bytes = ((size_t)nch * RS_CH * nt * 32 + (aff ? 2 * nch * RS_CH : 0)) * sizeof(float);
+  const size_t lds_bytes = ((size_t)nch * RS_CH * nt * 32 + (has_aff ? 2 * nch * RS_CH : 0)) * sizeof(float);
   if (lds_bytes > 156 * 1024) return false;
+  if (nt_out) *nt_out = nt;
+  if (lds_out) *lds_out = lds_bytes;
+  return true;
+}
+
+bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, double *stats, int slots,
+                 const float *epi_y, const float *epi_ab, long long P, int R, int C, int w_kc, int epi,
+                 hipStream_t s) {
+  int nt = 0;
+  size_t lds_bytes = 0;
+  if (!rs_shape_ok(P, R, C, epi, aff != nullptr, &nt, &lds_bytes)) return false;
+  if (reinterpret_cast<uintptr_t>(a) % 16 != 0 || (w_kc && reinterpret_cast<uintptr_t>(w) % 16 != 0)) return false;
+  const int nch = (R + RS_CH - 1) / RS_CH;
   RsArgs g = {a, w, d, aff, stats, epi_y, epi_ab, P, R, C, R, C, w_kc, slots < 1 ? 1 : slots, nch};
   const int bpc = (nt <= 2 && epi != RS_BNBWD && lds_bytes <= 78 * 1024) ? 2 : 1;
 #define GB_RS(NT_)                                                         \
@@ -304,3 +315,11 @@ bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, dou
 }
 
 }  // namespace gb
+
+// which kernel gb_gemm_fwd (dgrad = 0) / gb_gemm_dgrad (dgrad = 1) launches for 16-byte aligned operands:
+// 1 = gemm_rs_kernel, 0 = gemm_cl_kernel.  Introspection for bench.py's per-kernel roofline accounting.
+extern "C" int gb_gemm_uses_rs(long long P, int K, int N, int dgrad, int fused_stats, int has_aff) {
+  const int R = dgrad ? N : K, C = dgrad ? K : N;
+  const int epi = fused_stats ? (dgrad ? gb::RS_BNBWD : gb::RS_STATS) : gb::RS_STORE;
+  return gb::rs_shape_ok(P, R, C, epi, has_aff != 0, nullptr, nullptr) ? 1 : 0;
+}

@@ -51,6 +51,15 @@ def _call(name, dev, *args, meta=None):
         _lib.check(_lib.timed(name, dev, meta, lambda: fn(*args)), name)
 
 
+def _gemm_meta(kind, P, K, N, fused=False, aff=False):
+    """Timing metadata of a GEMM launch (only built while a KernelTimer is active): FLOP, shape and which
+    kernel the C entry dispatches to (gemm_rs_kernel / gemm_cl_kernel)."""
+    if _lib.KernelTimer.active is None:
+        return None
+    rs = kind != "wgrad" and _lib.lib().gb_gemm_uses_rs(P, K, N, int(kind == "dgrad"), int(fused), int(aff))
+    return {"flop": 2.0 * P * K * N, "pkn": (P, K, N), "kernel": "gemm_rs_kernel" if rs else "gemm_cl_kernel"}
+
+
 def _wgrad(dY, X):
     """dW (Cout,Cin) = dY^T X with the reduction over P rows split into S batched slices: a plain
     (Cout x P) x (P x Cin) GEMM has only Cout*Cin/tile^2 output tiles (4 for 64x64), i.e. 4 busy CUs."""
@@ -118,7 +127,7 @@ class LinearBNAct(Function):
             Wc = W.contiguous()
             Y = torch.empty((P, Cout), dtype=torch.float32, device=dev)
             _call("gb_gemm_fwd", dev, _lib.ptr(X), _lib.ptr(Wc), None, _lib.ptr(Y), _lib.ptr(stats), slots, P, X.shape[1],
-                  Cout, _s(X), meta={"flop": 2.0 * P * X.shape[1] * Cout, "pkn": (P, X.shape[1], Cout)})
+                  Cout, _s(X), meta=_gemm_meta("fwd", P, X.shape[1], Cout, stats is not None))
         else:
             Y = torch.mm(X, W.t())
             if training:
@@ -175,12 +184,12 @@ class LinearBNAct(Function):
             if ctx.needs_input_grad[1]:
                 dW = torch.zeros((Cout, Cin), dtype=torch.float32, device=dev)
                 _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(X), None, _lib.ptr(dW), P, Cin, Cout, _s(dY),
-                      meta={"flop": 2.0 * P * Cin * Cout, "pkn": (P, Cin, Cout)})
+                      meta=_gemm_meta("wgrad", P, Cin, Cout))
             if ctx.needs_input_grad[0]:
                 dX = torch.empty((P, Cin), dtype=torch.float32, device=dev)
                 W = W.contiguous()
                 _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dX), None, None, None, 0, P, Cin, Cout, _s(dY),
-                      meta={"flop": 2.0 * P * Cin * Cout, "pkn": (P, Cin, Cout)})
+                      meta=_gemm_meta("dgrad", P, Cin, Cout))
         else:
             dW = _wgrad(dY, X) if ctx.needs_input_grad[1] else None
             dX = torch.mm(dY, W) if ctx.needs_input_grad[0] else None
@@ -234,7 +243,7 @@ class MLPStack(Function):
             stats = stat_arena[stat_off[l]:stat_off[l + 1]] if cfg.training else None
             Y = torch.empty((P, N), dtype=torch.float32, device=dev)
             _call("gb_gemm_fwd", dev, _lib.ptr(src), _lib.ptr(W), _lib.ptr(aff), _lib.ptr(Y), _lib.ptr(stats), slots,
-                  P, K, N, _s(X0), meta={"flop": 2.0 * P * K * N, "pkn": (P, K, N)})
+                  P, K, N, _s(X0), meta=_gemm_meta("fwd", P, K, N, stats is not None, aff is not None))
             ab = ab_arena[ab_off:ab_off + 4 * N]
             ab_off += 4 * N
             _call("gb_bn_finalize", dev, _lib.ptr(stats), slots, P, N, _lib.ptr(gamma), _lib.ptr(beta), cfg.eps,
@@ -329,13 +338,13 @@ class MLPStack(Function):
             if need_w[l]:
                 dW = w_arena[w_off[l]:w_off[l + 1]]
                 _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(src), _lib.ptr(aff), _lib.ptr(dW), P, K, N, _s(dout),
-                      meta={"flop": 2.0 * P * K * N, "pkn": (P, K, N)})
+                      meta=_gemm_meta("wgrad", P, K, N))
                 grads[3 * l] = dW.view(N, K)
             if l == 0:
                 if ctx.needs_input_grad[0]:
                     dX0 = torch.empty((P, K), dtype=torch.float32, device=dev)
                     _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dX0), None, None, None, 0, P, K, N,
-                          _s(dout), meta={"flop": 2.0 * P * K * N, "pkn": (P, K, N)})
+                          _s(dout), meta=_gemm_meta("dgrad", P, K, N))
                 break
             # gradient of layer l-1's post-ReLU output + that layer's BatchNorm-backward sums in one launch
             dZ = torch.empty((P, K), dtype=torch.float32, device=dev)
@@ -343,13 +352,13 @@ class MLPStack(Function):
             if fused[l - 1]:
                 _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dZ), _lib.ptr(Ys[l - 1]),
                       _lib.ptr(abs_[l - 1]), _lib.ptr(region), slots, P, K, N, _s(dout),
-                      meta={"flop": 2.0 * P * K * N, "pkn": (P, K, N)})
+                      meta=_gemm_meta("dgrad", P, K, N, fused=True))
                 dstats = region[slots * 2 * K:] if slots > 1 else region
                 grads[3 * l - 2], grads[3 * l - 1] = param_grads(l - 1, region, slots, dstats if slots > 1 else None)
             else:
                 # wide + long outputs: the fused epilogue measured slower than a separate column pass
                 _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dZ), None, None, None, 0, P, K, N,
-                      _s(dout), meta={"flop": 2.0 * P * K * N, "pkn": (P, K, N)})
+                      _s(dout), meta=_gemm_meta("dgrad", P, K, N))
                 dstats = region
                 _call("gb_bn_bwd_stats", dev, _lib.ptr(dZ), _lib.ptr(Ys[l - 1]), _lib.ptr(abs_[l - 1]), None, P, K, 1,
                       _lib.ptr(dstats), _s(dout))

@@ -213,6 +213,10 @@ int gb_gemm_dgrad(const float *dy, const float *w, float *dx, const float *y_pre
  * workgroups).  x_aff (optional) = [a(K), b(K)]: f(x) = relu(a_k x + b_k), as in gb_gemm_fwd.      */
 int gb_gemm_wgrad(const float *dy, const float *x, const float *x_aff, float *dw, long long P, int K, int N,
                   void *stream);
+/* Which kernel gb_gemm_fwd (dgrad = 0) / gb_gemm_dgrad (dgrad = 1) launches for 16-byte aligned operands of
+ * this shape: 1 = the row-streaming kernel (csrc/gemm_rs.hip), 0 = the LDS-tiled one (csrc/gemm_cl.hip).
+ * Pure host-side introspection (no launch), used by bench.py to attribute timings per kernel.      */
+int gb_gemm_uses_rs(long long P, int K, int N, int dgrad, int fused_stats, int has_aff);
 
 #ifdef __cplusplus
 }

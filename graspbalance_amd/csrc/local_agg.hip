@@ -1,0 +1,345 @@
+// LocalAggregation (reference drp.py:32-67: ball-query group -> [dp, fj] -> 1x1 conv -> BN -> ReLU -> max over
+// the ns neighbours), evaluated WITHOUT the grouped (B*m*ns, 3+C) tensor.
+//
+// The 1x1 convolution is linear and the grouping is a gather, so they commute:
+//     y[p, c] = sum_k W[c, k] [dp_p, f_idx(p)]_k  =  G[idx(p), c] + dp_p . Wx[c]        G = f Wf^T  (B*n rows)
+// with Wx = W[:, :3], Wf = W[:, 3:].  G is ns times smaller than the grouped tensor (4 MB: L2 resident), and
+// everything BatchNorm and the backward pass need from the P = B*m*ns rows reduces to per-POINT sums
+// (cnt_i = references of point i, D_i = sum of their dp) and 12 moments of dp:
+//     sum_p y      = sum_i cnt_i G_i + S.Wx                       sum_p y^2 = sum_i (cnt_i G_i^2 + 2 G_i D_i.Wx) + Wx^T M Wx
+//     dG[i, c]     = a_c (Sg[i, c] - cnt_i m1_c - m2_c rstd_c (cnt_i (G[i, c] - mean_c) + D_i.Wx[c]))
+//     dWx[c, j]    = a_c (T[c, j] - m1_c S_j - m2_c rstd_c (U[c, j] - mean_c S_j + sum_j' Wx[c, j'] M[j', j]))
+// where Sg / T are the max-pool-routed output gradients scattered to the arg-max rows only (R*C values, not P*C),
+// m1 = dbeta/P, m2 = dgamma/P, U[c, j] = sum_i G[i, c] D_i[j].  The only pass over P*C values left is the
+// max-pool itself, a gather from L2.  Same function as conv -> BN -> ReLU -> max on the grouped tensor, in a
+// different (fp32-rounding-level) summation order.
+#include "gb_common.h"
+
+namespace gb {
+
+constexpr int LA_TPB = 256;
+constexpr int LA_MAX_NS = 64;
+
+// dp of one grouped row: (xyz[b, id] - centre[b, j]) (* scale when mode == 1), as gb_group_concat_cl forms it
+__device__ __forceinline__ void la_dp(const float *__restrict__ xyz, const float *__restrict__ centres, int bi, int n,
+                                      long long grp, int id, int mode, float scale, float d[3]) {
+  const float *p = xyz + ((size_t)bi * n + id) * 3;
+  const float *q = centres + grp * 3;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    d[t] = p[t] - q[t];
+    if (mode == 1) d[t] = d[t] * scale;
+  }
+}
+
+// per-point reference counts and dp sums, and the 12 dp moments  mom = [S(3), M(3x3)]  (fp64)
+__global__ __launch_bounds__(LA_TPB) void la_point_stats_kernel(const float *__restrict__ xyz,
+                                                                 const float *__restrict__ centres,
+                                                                 const int32_t *__restrict__ idx, int n, int m, int ns,
+                                                                 int mode, float scale, long long total_rows,
+                                                                 float *__restrict__ cnt, float *__restrict__ dsum,
+                                                                 double *__restrict__ mom) {
+  float s[3] = {0.f, 0.f, 0.f}, mm[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const long long p = ((long long)blockIdx.x * 8 + u) * LA_TPB + threadIdx.x;
+    if (p < total_rows) {
+      const long long grp = p / ns;
+      const int bi = (int)(grp / m);
+      const int id = idx[p];
+      float d[3];
+      la_dp(xyz, centres, bi, n, grp, id, mode, scale, d);
+      const size_t pt = (size_t)bi * n + id;
+      atomicAdd(cnt + pt, 1.f);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        atomicAdd(dsum + pt * 3 + t, d[t]);
+        s[t] += d[t];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) mm[3 * t + q] += d[t] * d[q];
+      }
+    }
+  }
+  double v[12];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) v[i] = (double)s[i];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) v[3 + i] = (double)mm[i];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v[i] += __shfl_xor(v[i], off);
+  }
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) atomicAdd(mom + i, v[i]);
+}
+
+// column sums over the B*n points:  stats = [sum_p y, sum_p y^2](C),  u = [U_0, U_1, U_2](C)
+constexpr int LA_RB = 32;
+__global__ __launch_bounds__(LA_TPB) void la_col_stats_kernel(const float *__restrict__ G, const float *__restrict__ cnt,
+                                                               const float *__restrict__ dsum,
+                                                               const float *__restrict__ wx,
+                                                               const double *__restrict__ mom, long long rows, int C,
+                                                               double *__restrict__ stats, double *__restrict__ u) {
+  const long long r0 = (long long)blockIdx.x * LA_RB;
+  long long r1 = r0 + LA_RB;
+  if (r1 > rows) r1 = rows;
+  for (int c = threadIdx.x; c < C; c += LA_TPB) {
+    const double w0 = wx[c * 3], w1 = wx[c * 3 + 1], w2 = wx[c * 3 + 2];
+    double a1 = 0.0, a2 = 0.0, u0 = 0.0, u1 = 0.0, u2 = 0.0;
+    for (long long r = r0; r < r1; ++r) {
+      const double g = G[r * C + c], cn = cnt[r];
+      const double d0 = dsum[r * 3], d1 = dsum[r * 3 + 1], d2 = dsum[r * 3 + 2];
+      a1 += cn * g;
+      a2 += cn * g * g + 2.0 * g * (d0 * w0 + d1 * w1 + d2 * w2);
+      u0 += g * d0;
+      u1 += g * d1;
+      u2 += g * d2;
+    }
+    if (blockIdx.x == 0) {  // the terms that do not depend on G
+      const double w[3] = {w0, w1, w2};
+      double q = 0.0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        a1 += mom[i] * w[i];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) q += w[i] * mom[3 + 3 * i + j] * w[j];
+      }
+      a2 += q;
+    }
+    atomicAdd(stats + c, a1);
+    atomicAdd(stats + C + c, a2);
+    atomicAdd(u + c, u0);
+    atomicAdd(u + C + c, u1);
+    atomicAdd(u + 2 * C + c, u2);
+  }
+}
+
+// out[r, c] = max_k relu(a_c y + b_c), y = G[idx(r,k), c] + dp(r,k).Wx[c];  arg = first k attaining it.
+// A workgroup stages (id, dp) of its groups' samples in LDS once; a thread owns 4 columns of one group and
+// streams that group's ns rows of G (16-byte gathers that hit L2), 8 in flight.
+__global__ __launch_bounds__(LA_TPB) void la_pool_kernel(const float *__restrict__ G, const float *__restrict__ xyz,
+                                                          const float *__restrict__ centres,
+                                                          const int32_t *__restrict__ idx, const float *__restrict__ wx,
+                                                          const float *__restrict__ ab, float *__restrict__ out,
+                                                          int32_t *__restrict__ arg, int n, int m, int ns, int C,
+                                                          int mode, float scale, long long R) {
+  extern __shared__ float4 nb[];  // [groups per block][ns] = (id bits, dp0, dp1, dp2)
+  const int tpg = C / 4, gpb = LA_TPB / tpg;
+  const long long g0 = (long long)blockIdx.x * gpb;
+  for (int i = threadIdx.x; i < gpb * ns; i += LA_TPB) {
+    const long long r = g0 + i / ns;
+    if (r < R) {
+      const int bi = (int)(r / m);
+      const int id = idx[r * ns + i % ns];
+      float d[3];
+      la_dp(xyz, centres, bi, n, r, id, mode, scale, d);
+      nb[i] = make_float4(__int_as_float(id), d[0], d[1], d[2]);
+    }
+  }
+  __syncthreads();
+  const int gl = threadIdx.x / tpg;
+  const long long r = g0 + gl;
+  if (gl >= gpb || r >= R) return;
+  const int c = (threadIdx.x % tpg) * 4;
+  const float *Gb = G + (size_t)(r / m) * n * C + c;
+  float a[4], b[4], w[4][3], best[4];
+  int bk[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    a[t] = ab[c + t];
+    b[t] = ab[C + c + t];
+    w[t][0] = wx[(c + t) * 3];
+    w[t][1] = wx[(c + t) * 3 + 1];
+    w[t][2] = wx[(c + t) * 3 + 2];
+    best[t] = -INFINITY;
+    bk[t] = 0;
+  }
+  const float4 *mine = nb + gl * ns;
+  for (int k0 = 0; k0 < ns; k0 += 8) {
+    float4 gv[8], q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (k0 + u < ns) {
+        q[u] = mine[k0 + u];
+        gv[u] = *reinterpret_cast<const float4 *>(Gb + (size_t)__float_as_int(q[u].x) * C);
+      }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (k0 + u < ns) {
+        const float g4[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float y = ((g4[t] + q[u].y * w[t][0]) + q[u].z * w[t][1]) + q[u].w * w[t][2];
+          float o = a[t] * y + b[t];
+          o = o > 0.f ? o : 0.f;
+          if (o > best[t]) { best[t] = o; bk[t] = k0 + u; }
+        }
+      }
+  }
+  *reinterpret_cast<float4 *>(out + r * C + c) = make_float4(best[0], best[1], best[2], best[3]);
+  *reinterpret_cast<int4 *>(arg + r * C + c) = make_int4(bk[0], bk[1], bk[2], bk[3]);
+}
+
+// backward of the pool + ReLU: routes dout to the arg-max rows.  sg[idx, c] += g (float atomics, R*C of them),
+// red = fp64 [5][C] += column sums of g, g*xhat, g*dp0, g*dp1, g*dp2
+constexpr int LA_GB = 16;
+__global__ __launch_bounds__(LA_TPB) void la_pool_bwd_kernel(const float *__restrict__ dout, const float *__restrict__ out,
+                                                              const int32_t *__restrict__ arg,
+                                                              const float *__restrict__ G, const float *__restrict__ xyz,
+                                                              const float *__restrict__ centres,
+                                                              const int32_t *__restrict__ idx,
+                                                              const float *__restrict__ wx, const float *__restrict__ ab,
+                                                              float *__restrict__ sg, double *__restrict__ red, int n,
+                                                              int m, int ns, int C, int mode, float scale, long long R) {
+  const long long r0 = (long long)blockIdx.x * LA_GB;
+  long long r1 = r0 + LA_GB;
+  if (r1 > R) r1 = R;
+  for (int c = threadIdx.x; c < C; c += LA_TPB) {
+    const float w0 = wx[c * 3], w1 = wx[c * 3 + 1], w2 = wx[c * 3 + 2];
+    const float mean = ab[2 * C + c], rstd = ab[3 * C + c];
+    double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (long long r = r0; r < r1; ++r) {
+      const float o = out[r * C + c];
+      const float g = o > 0.f ? dout[r * C + c] : 0.f;
+      if (g != 0.f) {
+        const int bi = (int)(r / m);
+        const int id = idx[r * ns + arg[r * C + c]];
+        float d[3];
+        la_dp(xyz, centres, bi, n, r, id, mode, scale, d);
+        const size_t pt = (size_t)bi * n + id;
+        const float y = ((G[pt * C + c] + d[0] * w0) + d[1] * w1) + d[2] * w2;
+        const float xhat = (y - mean) * rstd;
+        atomicAdd(sg + pt * C + c, g);
+        acc[0] += g;
+        acc[1] += g * xhat;
+        acc[2] += g * d[0];
+        acc[3] += g * d[1];
+        acc[4] += g * d[2];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) atomicAdd(red + (size_t)i * C + c, acc[i]);
+  }
+}
+
+// dG[i, c] = a (sg - cnt m1 - m2 rstd (cnt (G - mean) + D.Wx))      (training: m1 = dbeta/P, m2 = dgamma/P; eval: 0)
+__global__ __launch_bounds__(LA_TPB) void la_point_grad_kernel(const float *__restrict__ sg, const float *__restrict__ G,
+                                                                const float *__restrict__ cnt,
+                                                                const float *__restrict__ dsum,
+                                                                const float *__restrict__ wx, const float *__restrict__ ab,
+                                                                const double *__restrict__ red, double invP,
+                                                                long long rows, int C, int training,
+                                                                float *__restrict__ dG) {
+  const long long e = (long long)blockIdx.x * LA_TPB + threadIdx.x;
+  if (e >= rows * C) return;
+  const long long i = e / C;
+  const int c = (int)(e % C);
+  const float a = ab[c];
+  float v = sg[e];
+  if (training) {
+    const float m1 = (float)(red[c] * invP), m2 = (float)(red[C + c] * invP);
+    const float cn = cnt[i];
+    const float dw = (dsum[i * 3] * wx[c * 3] + dsum[i * 3 + 1] * wx[c * 3 + 1]) + dsum[i * 3 + 2] * wx[c * 3 + 2];
+    v = v - cn * m1 - (m2 * ab[3 * C + c]) * (cn * (G[e] - ab[2 * C + c]) + dw);
+  }
+  dG[e] = a * v;
+}
+
+// dWx[c, j] = a (T_j - m1 S_j - m2 rstd (U_j - mean S_j + sum_j' Wx[c, j'] M[j', j]))
+__global__ void la_wx_grad_kernel(const double *__restrict__ red, const double *__restrict__ u,
+                                  const double *__restrict__ mom, const float *__restrict__ wx,
+                                  const float *__restrict__ ab, double invP, int C, int training,
+                                  float *__restrict__ dwx) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double a = ab[c], mean = ab[2 * C + c], rstd = ab[3 * C + c];
+  const double m1 = training ? red[c] * invP : 0.0, m2 = training ? red[C + c] * invP : 0.0;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    double wm = 0.0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) wm += (double)wx[c * 3 + q] * mom[3 + 3 * q + j];
+    const double v = red[(size_t)(2 + j) * C + c] - m1 * mom[j] - m2 * rstd * (u[(size_t)j * C + c] - mean * mom[j] + wm);
+    dwx[c * 3 + j] = (float)(a * v);
+  }
+}
+
+}  // namespace gb
+
+using namespace gb;
+
+static bool la_geom_ok(int b, int n, int m, int ns) { return b >= 0 && n >= 1 && m >= 0 && ns >= 1; }
+
+extern "C" int gb_la_point_stats(const float *xyz, const float *centres, const int32_t *idx, int b, int n, int m,
+                                 int ns, int mode, float scale, float *cnt, float *dsum, double *mom, void *stream) {
+  if (!la_geom_ok(b, n, m, ns) || !xyz || !centres || !idx || !cnt || !dsum || !mom || (mode != 0 && mode != 1))
+    return GB_EINVAL;
+  const long long rows = (long long)b * m * ns;
+  if (rows == 0) return GB_OK;
+  const long long blocks = (rows + 8 * LA_TPB - 1) / (8 * LA_TPB);
+  if (blocks > 0x7fffffffLL) return GB_ERANGE;
+  hipLaunchKernelGGL(la_point_stats_kernel, dim3((unsigned)blocks), dim3(LA_TPB), 0, as_stream(stream), xyz, centres,
+                     idx, n, m, ns, mode, scale, rows, cnt, dsum, mom);
+  return check_launch("gb_la_point_stats");
+}
+
+extern "C" int gb_la_col_stats(const float *G, const float *cnt, const float *dsum, const float *wx,
+                               const double *mom, long long rows, int C, double *stats, double *u, void *stream) {
+  if (rows < 0 || C < 1 || !G || !cnt || !dsum || !wx || !mom || !stats || !u) return GB_EINVAL;
+  if (rows == 0) return GB_OK;
+  hipLaunchKernelGGL(la_col_stats_kernel, dim3((unsigned)((rows + LA_RB - 1) / LA_RB)), dim3(LA_TPB), 0,
+                     as_stream(stream), G, cnt, dsum, wx, mom, rows, C, stats, u);
+  return check_launch("gb_la_col_stats");
+}
+
+extern "C" int gb_la_pool(const float *G, const float *xyz, const float *centres, const int32_t *idx, const float *wx,
+                          const float *ab, float *out, int32_t *arg, int b, int n, int m, int ns, int C, int mode,
+                          float scale, void *stream) {
+  if (!la_geom_ok(b, n, m, ns) || !G || !xyz || !centres || !idx || !wx || !ab || !out || !arg) return GB_EINVAL;
+  if (C < 16 || C % 4 != 0 || C / 4 > LA_TPB || ns > LA_MAX_NS || (mode != 0 && mode != 1)) return GB_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(arg)) % 16 != 0)
+    return GB_EINVAL;
+  const long long R = (long long)b * m;
+  if (R == 0) return GB_OK;
+  const int gpb = LA_TPB / (C / 4);
+  hipLaunchKernelGGL(la_pool_kernel, dim3((unsigned)((R + gpb - 1) / gpb)), dim3(LA_TPB),
+                     (size_t)gpb * ns * sizeof(float4), as_stream(stream), G, xyz, centres, idx, wx, ab, out, arg, n, m,
+                     ns, C, mode, scale, R);
+  return check_launch("gb_la_pool");
+}
+
+extern "C" int gb_la_pool_bwd(const float *dout, const float *out, const int32_t *arg, const float *G,
+                              const float *xyz, const float *centres, const int32_t *idx, const float *wx,
+                              const float *ab, float *sg, double *red, int b, int n, int m, int ns, int C, int mode,
+                              float scale, void *stream) {
+  if (!la_geom_ok(b, n, m, ns) || !dout || !out || !arg || !G || !xyz || !centres || !idx || !wx || !ab || !sg || !red)
+    return GB_EINVAL;
+  if (C < 1 || (mode != 0 && mode != 1)) return GB_EINVAL;
+  const long long R = (long long)b * m;
+  if (R == 0) return GB_OK;
+  hipLaunchKernelGGL(la_pool_bwd_kernel, dim3((unsigned)((R + LA_GB - 1) / LA_GB)), dim3(LA_TPB), 0, as_stream(stream),
+                     dout, out, arg, G, xyz, centres, idx, wx, ab, sg, red, n, m, ns, C, mode, scale, R);
+  return check_launch("gb_la_pool_bwd");
+}
+
+extern "C" int gb_la_point_grad(const float *sg, const float *G, const float *cnt, const float *dsum, const float *wx,
+                                const float *ab, const double *red, long long P, long long rows, int C, int training,
+                                float *dG, void *stream) {
+  if (rows < 0 || C < 1 || P < 1 || !sg || !G || !cnt || !dsum || !wx || !ab || !red || !dG) return GB_EINVAL;
+  if (rows == 0) return GB_OK;
+  const long long blocks = (rows * C + LA_TPB - 1) / LA_TPB;
+  if (blocks > 0x7fffffffLL) return GB_ERANGE;
+  hipLaunchKernelGGL(la_point_grad_kernel, dim3((unsigned)blocks), dim3(LA_TPB), 0, as_stream(stream), sg, G, cnt, dsum,
+                     wx, ab, red, 1.0 / (double)P, rows, C, training, dG);
+  return check_launch("gb_la_point_grad");
+}
+
+extern "C" int gb_la_wx_grad(const double *red, const double *u, const double *mom, const float *wx, const float *ab,
+                             long long P, int C, int training, float *dwx, void *stream) {
+  if (C < 1 || P < 1 || !red || !u || !mom || !wx || !ab || !dwx) return GB_EINVAL;
+  hipLaunchKernelGGL(la_wx_grad_kernel, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), red, u, mom, wx, ab,
+                     1.0 / (double)P, C, training, dwx);
+  return check_launch("gb_la_wx_grad");
+}

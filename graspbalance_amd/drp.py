@@ -99,16 +99,22 @@ class InvResMLP(nn.Module):
                 and is_block(self.pwconv[0], True) and is_block(self.pwconv[1], False) and self.use_res
                 and isinstance(self.act, nn.ReLU))
 
-    def forward_cl(self, p, f_cl, idx=None):
-        """Channel-last execution: f_cl (B,N,C) -> (B,N,C).  `idx` (B,N,ns) may be shared by all blocks
-        of a stage (same points, same radius)."""
+    def forward_cl(self, p, f_cl, idx=None, geo=None):
+        """Channel-last execution: f_cl (B,N,C) -> (B,N,C).  `idx` (B,N,ns) and the grouping summary `geo`
+        (fused_mlp.LocalGeometry) may be shared by all blocks of a stage (same points, same radius)."""
         B, N, C = f_cl.shape
         g = self.convs.grouper
         if idx is None:
             idx = ball_query(g.radius, g.nsample, p, p)
-        x0 = fused_mlp.group_concat_cl(p, p, idx, f_cl, mode=0)               # [dp, fj] rows
         agg_conv, agg_bn = self.convs.convs[0][0], self.convs.convs[0][1]
-        agg = fused_mlp.conv_bn_act(x0, agg_conv, agg_bn, relu=True, pool_ns=g.nsample)   # (B*N, C)
+        if fused_mlp.local_agg_supported(agg_conv.weight.shape[0], g.nsample) and fused_mlp.local_agg_enabled():
+            # the 1x1 conv commutes with the gather: no grouped (B*N*ns, 3+C) tensor at all
+            if geo is None:
+                geo = fused_mlp.LocalGeometry(p, p, idx, mode=0)
+            agg = fused_mlp.local_agg_pool(f_cl.reshape(B * N, C), agg_conv, agg_bn, geo)            # (B*N, C)
+        else:
+            x0 = fused_mlp.group_concat_cl(p, p, idx, f_cl, mode=0)               # [dp, fj] rows
+            agg = fused_mlp.conv_bn_act(x0, agg_conv, agg_bn, relu=True, pool_ns=g.nsample)   # (B*N, C)
         # C -> 4C -> C pointwise pair as one fused stack; act(bn(.) + identity) at the end
         out = fused_mlp.conv_bn_act_chain(agg, [(self.pwconv[0][0], self.pwconv[0][1]),
                                                 (self.pwconv[1][0], self.pwconv[1][1])],
@@ -138,9 +144,13 @@ def run_stage(blocks, p, f):
     g0 = blocks[0].convs.grouper
     same = all(b.convs.grouper.radius == g0.radius and b.convs.grouper.nsample == g0.nsample for b in blocks)
     idx = ball_query(g0.radius, g0.nsample, p, p) if same else None
+    geo = None
+    if same and fused_mlp.local_agg_enabled() and all(
+            fused_mlp.local_agg_supported(b.convs.convs[0][0].weight.shape[0], g0.nsample) for b in blocks):
+        geo = fused_mlp.LocalGeometry(p, p, idx, mode=0)
     f_cl = f.transpose(1, 2).contiguous()
     for blk in blocks:
-        f_cl = blk.forward_cl(p, f_cl, idx)
+        f_cl = blk.forward_cl(p, f_cl, idx, geo)
     return p, f_cl.transpose(1, 2).contiguous()
 
 

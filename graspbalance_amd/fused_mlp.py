@@ -25,6 +25,18 @@ _DGRAD_BN_MAX = int(os.environ.get("GB_DGRAD_BN_MAX", 1 << 40))  # rows*cols abo
 _OWN_GEMM = True  # hand-written MFMA GEMMs (csrc/gemm_cl.hip); False = torch.mm (rocBLAS) for A/B timing
 
 
+_LOCAL_AGG = os.environ.get("GB_LOCAL_AGG", "1") != "0"  # A/B switch: 0 = grouped tensor + GEMM for LocalAggregation
+
+
+def local_agg_enabled():
+    return _LOCAL_AGG
+
+
+def set_local_agg(flag):
+    global _LOCAL_AGG
+    _LOCAL_AGG = bool(flag)
+
+
 def set_enabled(flag):
     global _ENABLED
     _ENABLED = bool(flag)
@@ -367,6 +379,109 @@ class MLPStack(Function):
             _call("gb_bn_bwd_apply", dev, _lib.ptr(dZ), _lib.ptr(Ys[l - 1]), _lib.ptr(abs_[l - 1]), None,
                   _lib.ptr(dstats), P, K, 1, int(training[l - 1]), _lib.ptr(dY), None, _s(dout))
         return (dX0, dres, None, None, None, *grads)
+
+
+class LocalGeometry:
+    """The per-point summary of one grouping (xyz, centres, idx) that LocalAggPool needs instead of the grouped
+    tensor: cnt (b*n) references per point, dsum (b*n,3) sum of their relative positions, mom fp64 [12] = [sum dp,
+    sum dp dp^T].  A stage of InvResMLP blocks over the same points and radius shares one."""
+
+    def __init__(self, xyz, centres, idx, mode=0, scale=1.0):
+        self.xyz, self.centres, self.idx = xyz.contiguous(), centres.contiguous(), idx.contiguous()
+        self.b, self.n = self.xyz.shape[0], self.xyz.shape[1]
+        self.m, self.ns = self.idx.shape[1], self.idx.shape[2]
+        self.mode, self.scale = int(mode), float(scale)
+        dev = xyz.device
+        pts = torch.zeros(self.b * self.n * 4, dtype=torch.float32, device=dev)
+        self.cnt, self.dsum = pts[:self.b * self.n], pts[self.b * self.n:]
+        self.mom = torch.zeros(12, dtype=torch.float64, device=dev)
+        _call("gb_la_point_stats", dev, _lib.ptr(self.xyz), _lib.ptr(self.centres), _lib.ptr(self.idx), self.b, self.n,
+              self.m, self.ns, self.mode, self.scale, _lib.ptr(self.cnt), _lib.ptr(self.dsum), _lib.ptr(self.mom),
+              _s(xyz))
+
+    @property
+    def rows(self):
+        return self.b * self.m * self.ns
+
+
+def local_agg_supported(C_out, ns):
+    return C_out % 4 == 0 and 16 <= C_out <= 1024 and ns <= 64
+
+
+class LocalAggPool(Function):
+    """LocalAggregation's  group -> [dp, fj] -> 1x1 conv -> BatchNorm -> ReLU -> max over neighbours  (reference
+    drp.py:32-67) on the point features f (b*n, C) directly: G = f Wf^T, y = G[idx] + dp.Wx is formed on the fly
+    and never stored (csrc/local_agg.hip).  forward(ctx, f, W (N,3+C), gamma, beta, geo, cfg) -> (b*m, N)."""
+
+    @staticmethod
+    def forward(ctx, f, W, gamma, beta, geo, cfg):
+        dev = f.device
+        f = f.contiguous()
+        N, C = W.shape[0], W.shape[1] - 3
+        Wx, Wf = W[:, :3].contiguous(), W[:, 3:].contiguous()
+        rows, P = geo.b * geo.n, geo.rows
+        G = torch.empty((rows, N), dtype=torch.float32, device=dev)
+        _call("gb_gemm_fwd", dev, _lib.ptr(f), _lib.ptr(Wf), None, _lib.ptr(G), None, 1, rows, C, N, _s(f),
+              meta=_gemm_meta("fwd", rows, C, N))
+        sums = torch.zeros(5 * N, dtype=torch.float64, device=dev)  # [sum y, sum y^2, U0, U1, U2]
+        stats, u = sums[:2 * N], sums[2 * N:]
+        if cfg.training:
+            _call("gb_la_col_stats", dev, _lib.ptr(G), _lib.ptr(geo.cnt), _lib.ptr(geo.dsum), _lib.ptr(Wx),
+                  _lib.ptr(geo.mom), rows, N, _lib.ptr(stats), _lib.ptr(u), _s(f))
+        ab = torch.empty(4 * N, dtype=torch.float32, device=dev)
+        _call("gb_bn_finalize", dev, _lib.ptr(stats), 1, P, N, _lib.ptr(gamma), _lib.ptr(beta), cfg.eps, cfg.momentum,
+              _lib.ptr(cfg.running_mean), _lib.ptr(cfg.running_var), _lib.ptr(ab), int(cfg.training), _s(f))
+        R = geo.b * geo.m
+        out = torch.empty((R, N), dtype=torch.float32, device=dev)
+        arg = torch.empty((R, N), dtype=torch.int32, device=dev)
+        _call("gb_la_pool", dev, _lib.ptr(G), _lib.ptr(geo.xyz), _lib.ptr(geo.centres), _lib.ptr(geo.idx), _lib.ptr(Wx),
+              _lib.ptr(ab), _lib.ptr(out), _lib.ptr(arg), geo.b, geo.n, geo.m, geo.ns, N, geo.mode, geo.scale, _s(f))
+        ctx.geo, ctx.training = geo, cfg.training
+        ctx.save_for_backward(f, Wx, Wf, G, ab, out, arg, u)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        f, Wx, Wf, G, ab, out, arg, u = ctx.saved_tensors
+        geo, training = ctx.geo, int(ctx.training)
+        dev = dout.device
+        dout = dout.contiguous()
+        N, C = Wf.shape
+        rows, P = geo.b * geo.n, geo.rows
+        sg = torch.zeros((rows, N), dtype=torch.float32, device=dev)
+        red = torch.zeros(5 * N, dtype=torch.float64, device=dev)  # [dbeta, dgamma, T0, T1, T2]
+        _call("gb_la_pool_bwd", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(G), _lib.ptr(geo.xyz),
+              _lib.ptr(geo.centres), _lib.ptr(geo.idx), _lib.ptr(Wx), _lib.ptr(ab), _lib.ptr(sg), _lib.ptr(red), geo.b,
+              geo.n, geo.m, geo.ns, N, geo.mode, geo.scale, _s(dout))
+        small = torch.empty(5 * N + N * C, dtype=torch.float32, device=dev)  # dbeta, dgamma, dWx (N,3), then dWf
+        dbeta, dgamma, dWx = small[:N], small[N:2 * N], small[2 * N:5 * N].view(N, 3)
+        _call("gb_bn_bwd_reduce", dev, _lib.ptr(red), 1, N, None, _lib.ptr(dbeta), _lib.ptr(dgamma), _s(dout))
+        dG = torch.empty((rows, N), dtype=torch.float32, device=dev)
+        _call("gb_la_point_grad", dev, _lib.ptr(sg), _lib.ptr(G), _lib.ptr(geo.cnt), _lib.ptr(geo.dsum), _lib.ptr(Wx),
+              _lib.ptr(ab), _lib.ptr(red), P, rows, N, training, _lib.ptr(dG), _s(dout))
+        dW = None
+        if ctx.needs_input_grad[1]:
+            _call("gb_la_wx_grad", dev, _lib.ptr(red), _lib.ptr(u), _lib.ptr(geo.mom), _lib.ptr(Wx), _lib.ptr(ab), P, N,
+                  training, _lib.ptr(dWx), _s(dout))
+            dWf = torch.zeros((N, C), dtype=torch.float32, device=dev)
+            _call("gb_gemm_wgrad", dev, _lib.ptr(dG), _lib.ptr(f), None, _lib.ptr(dWf), rows, C, N, _s(dout),
+                  meta=_gemm_meta("wgrad", rows, C, N))
+            dW = torch.cat([dWx, dWf], 1)
+        df = None
+        if ctx.needs_input_grad[0]:
+            df = torch.empty((rows, C), dtype=torch.float32, device=dev)
+            _call("gb_gemm_dgrad", dev, _lib.ptr(dG), _lib.ptr(Wf), _lib.ptr(df), None, None, None, 0, rows, C, N,
+                  _s(dout), meta=_gemm_meta("dgrad", rows, C, N))
+        return df, dW, dgamma, dbeta, None, None
+
+
+def local_agg_pool(f_cl, conv, bn, geo):
+    """conv (1x1, 3+C -> N, no bias) + bn + ReLU + max over the neighbours of `geo`, from point features (b*n, C)."""
+    if conv.bias is not None:
+        raise NotImplementedError("fused path expects bias-free convs followed by BatchNorm")
+    _count_batch(bn)
+    W = conv.weight.view(conv.weight.shape[0], -1)
+    return LocalAggPool.apply(f_cl, W, bn.weight, bn.bias, geo, _LayerCfg(bn))
 
 
 _pending_counters = None  # list of num_batches_tracked buffers while inside deferred_counters()

@@ -195,6 +195,41 @@ int gb_bn_bwd_apply_pool(const float *dout, const float *out, const int32_t *arg
 int gb_bn_bwd_reduce(const double *dst, int slots, int C, double *dstats, float *dbeta, float *dgamma,
                      void *stream);
 
+/* ---- LocalAggregation without the grouped tensor (csrc/local_agg.hip) ---------------------------------
+ * Reference: TrainModel/drp.py:32-67 (LocalAggregation.forward :62 = QueryAndGroup -> [dp, fj] ->
+ * create_convblock2d (1x1 conv, BatchNorm2d, ReLU) -> max over the ns neighbours), reached from
+ * InvResMLP.forward drp.py:109-117.  The 1x1 conv commutes with the gather:
+ *   y[p,c] = G[idx(p),c] + dp_p . Wx[c],   G = f Wf^T on the B*n points,  Wx = W[:, :3], Wf = W[:, 3:],
+ * so only per-point sums of the grouping are needed besides G (see the header of local_agg.hip).
+ * Geometry arguments as gb_group_concat_cl: xyz (b,n,3), centres (b,m,3), idx (b,m,ns) int32 into n,
+ * mode 0: dp = xyz[idx] - centre; mode 1: that times `scale`.                                          */
+/* cnt (b*n) += number of rows referencing each point, dsum (b*n,3) += sum of their dp,
+ * mom fp64 [12] += [S = sum_p dp (3), M = sum_p dp dp^T (3x3)]; all caller-zeroed.                      */
+int gb_la_point_stats(const float *xyz, const float *centres, const int32_t *idx, int b, int n, int m, int ns,
+                      int mode, float scale, float *cnt, float *dsum, double *mom, void *stream);
+/* stats fp64 [2C] += [sum_p y, sum_p y^2] (the BatchNorm batch sums over all P = b*m*ns rows, in the form
+ * gb_bn_finalize reads), u fp64 [3][C] += U[j][c] = sum_i G[i,c] D_i[j]; G (rows = b*n, C); caller-zeroed. */
+int gb_la_col_stats(const float *G, const float *cnt, const float *dsum, const float *wx, const double *mom,
+                    long long rows, int C, double *stats, double *u, void *stream);
+/* out (b*m, C) = max_k relu(a y + b), arg = first k attaining it; ab = [a, b, mean, rstd](C) from
+ * gb_bn_finalize.  C % 4 == 0, 16 <= C <= 1024, ns <= 64.                                               */
+int gb_la_pool(const float *G, const float *xyz, const float *centres, const int32_t *idx, const float *wx,
+               const float *ab, float *out, int32_t *arg, int b, int n, int m, int ns, int C, int mode,
+               float scale, void *stream);
+/* Backward of pool + ReLU: g = dout*[out > 0] goes to the arg-max row only.  sg (b*n, C) += g at that row's
+ * point (caller-zeroed), red fp64 [5][C] += column sums of [g, g*xhat, g*dp0, g*dp1, g*dp2] (caller-zeroed;
+ * red[0] = dbeta, red[1] = dgamma).                                                                     */
+int gb_la_pool_bwd(const float *dout, const float *out, const int32_t *arg, const float *G, const float *xyz,
+                   const float *centres, const int32_t *idx, const float *wx, const float *ab, float *sg,
+                   double *red, int b, int n, int m, int ns, int C, int mode, float scale, void *stream);
+/* dG (rows = b*n, C): gradient of G through BatchNorm (training: batch statistics over P rows; else a*sg). */
+int gb_la_point_grad(const float *sg, const float *G, const float *cnt, const float *dsum, const float *wx,
+                     const float *ab, const double *red, long long P, long long rows, int C, int training,
+                     float *dG, void *stream);
+/* dwx (C,3): gradient of Wx.                                                                            */
+int gb_la_wx_grad(const double *red, const double *u, const double *mom, const float *wx, const float *ab,
+                  long long P, int C, int training, float *dwx, void *stream);
+
 /* ---- fp32 MFMA GEMMs of the channel-last SharedMLP (csrc/gemm_cl.hip) — replace the cuBLAS/cuDNN
  * 1x1 convolutions the reference reaches through torch (pytorch_utils.py:61-113) ------------------- */
 /* Y (P,N) = f(X (P,K)) W(N,K)^T.  aff (optional) = [a(K), b(K)]: f(x) = relu(a_k x + b_k), i.e. the

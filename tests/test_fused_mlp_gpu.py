@@ -227,3 +227,45 @@ def test_drp_backbone_fused_equals_plain():
     fused_feat, fused_grad = gap(run(True), plain)
     assert fused_feat < 2.0 * base_feat + 1e-4, (fused_feat, base_feat)
     assert fused_grad < 1.5 * base_grad + 1e-3, (fused_grad, base_grad)
+
+
+@pytest.mark.parametrize("C,ns,train", [(32, 16, True), (64, 24, True), (32, 16, False)])
+def test_local_aggregation_without_grouped_tensor(C, ns, train):
+    """LocalAggPool (conv commuted with the gather, csrc/local_agg.hip) against the grouped-tensor execution of
+    the same block (group_concat_cl -> GEMM -> BN -> ReLU -> max), forward and every gradient."""
+    from graspbalance_amd import fused_mlp
+    from graspbalance_amd.drp import InvResMLP
+    from graspbalance_amd.scene import make_batch
+    torch.manual_seed(5)
+    blk = InvResMLP(in_channels=C, aggr_args={'feature_type': 'dp_fj', "reduction": 'max'},
+                    norm_args={'norm': 'bn'}, act_args={'act': 'relu'},
+                    group_args={'NAME': 'ballquery', 'radius': 0.12, 'nsample': ns},
+                    conv_args={'order': 'conv-norm-act'}, expansion=4, use_res=True).to(DEV)
+    with torch.no_grad():  # non-trivial running statistics for the eval case
+        for mod in blk.modules():
+            if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+                mod.running_mean.normal_(0, 0.1)
+                mod.running_var.uniform_(0.5, 1.5)
+    blk.train(train)
+    p = torch.from_numpy(make_batch([3, 4], 2048)).to(DEV)
+    f0 = torch.randn(2, 2048, C, device=DEV)
+    res = {}
+    for flag in (True, False):
+        fused_mlp.set_local_agg(flag)
+        try:
+            m = copy.deepcopy(blk)
+            f = f0.clone().requires_grad_(True)
+            out = m.forward_cl(p, f)
+            torch.manual_seed(7)
+            (out * torch.randn_like(out)).sum().backward()
+            res[flag] = (out.detach(), f.grad.clone(), {k: v.grad.clone() for k, v in m.named_parameters()},
+                         {k: v.clone() for k, v in m.named_buffers() if v.dtype.is_floating_point})
+        finally:
+            fused_mlp.set_local_agg(True)
+    a, b = res[True], res[False]
+    _close(a[0], b[0], 1e-5, "forward")
+    _close(a[1], b[1], 1e-4, "input grad", True)
+    for k in b[2]:
+        _close(a[2][k], b[2][k], 2e-4, "grad " + k, True, 1e-2 * max(float(v.norm()) for v in b[2].values()))
+    for k in b[3]:
+        _close(a[3][k], b[3][k], 1e-5, "buffer " + k)

@@ -21,7 +21,7 @@ torch.cuda.synchronize()
 acc = defaultdict(lambda: [0, 0.0])
 for n in names:
     for a, b, meta in kt.events[n]:
-        key = (n[8:],) + tuple(meta["pkn"])
+        key = (n[8:] + ("*" if meta["kernel"] == "gemm_rs_kernel" else ""),) + tuple(meta["pkn"])
         acc[key][0] += 1
         acc[key][1] += a.elapsed_time(b)
 tot = sum(v[1] for v in acc.values()) / 3

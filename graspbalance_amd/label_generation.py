@@ -8,7 +8,7 @@ import torch
 
 from .knn_modules import myknn
 from .loss_utils import (GRASP_MAX_WIDTH, batch_viewpoint_params_to_matrix, generate_grasp_views,
-                         transform_point_cloud)
+                         grasp_views_on, transform_point_cloud)
 
 
 def _nearest(ref_points, query_points):
@@ -22,7 +22,7 @@ def _assign_views(poses, V):
     """For every object pose (K,3,4): index of the transformed template view nearest to each template
     view, (K,V) — the reference's per-object 300x300 kNN (label_generation.py:56-58), as ONE batched
     launch over all objects of the batch."""
-    views = generate_grasp_views(V).to(poses.device)                     # (V,3)
+    views = grasp_views_on(poses.device, V)                              # (V,3)
     trans = torch.matmul(poses[:, :3, :3], views.T)                      # (K,3,V) == (R v)^T per object
     query = views.T.contiguous().unsqueeze(0).expand(poses.size(0), -1, -1).contiguous()
     return myknn(trans.contiguous(), query, k=1).view(poses.size(0), V) - 1
@@ -88,7 +88,7 @@ def _process_grasp_labels_fused(end_points):
     all_poses = torch.stack([p for poses in poses_l for p in poses], 0)          # (Kt,3,4)
     _, V, A, D = labels_l[0].shape
     view_inds = _assign_views(all_poses, V).contiguous()                         # (Kt,V) int64
-    views = generate_grasp_views(V).to(dev)
+    views = grasp_views_on(dev, V)
     rot_template = batch_viewpoint_params_to_matrix(-views, torch.zeros(V, dtype=views.dtype, device=dev))
     R = all_poses[:, :3, :3]
     views_trans = torch.matmul(R, views.T).transpose(1, 2)                       # (Kt,V,3)

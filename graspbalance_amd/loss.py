@@ -21,6 +21,7 @@ class ScalePrior:
         num = torch.as_tensor(np.asarray(num), dtype=torch.float32)
         self.intervals = [float(v) for v in np.asarray(interval).tolist()]
         self.weights = -(num / num.max()).log() + 1
+        self._dev = {}
 
     @classmethod
     def uniform(cls, bins=32, max_width=GRASP_MAX_WIDTH):
@@ -31,11 +32,21 @@ class ScalePrior:
         d = np.load(path, allow_pickle=True).item()
         return cls(d['num'], d['interval'])
 
+    def _on(self, device):
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = (self.weights.to(device), torch.tensor(self.intervals, dtype=torch.float32, device=device))
+        return self._dev[key]
+
     def lookup(self, widths):
-        idx = torch.zeros(widths.shape, dtype=torch.long, device=widths.device)
-        for b in range(len(self.intervals) - 1):
-            idx[(self.intervals[b] < widths) & (self.intervals[b + 1] > widths)] = b
-        return self.weights.to(widths.device)[idx]
+        """weights[b] for the bin with intervals[b] < width < intervals[b+1] (both strict, as the reference's
+        loop of masked assignments loss.py:32-36; a width on a boundary or outside keeps bin 0) — as one
+        bucketize instead of 32 x (two compares, and, masked store), and without the boolean-index host sync."""
+        weights, edges = self._on(widths.device)
+        nb = edges.numel() - 1
+        i = torch.bucketize(widths, edges)  # edges[i-1] < w <= edges[i]
+        inside = (i >= 1) & (i <= nb) & (widths != edges[i.clamp(max=nb)])
+        return weights[torch.where(inside, i - 1, torch.zeros_like(i))]
 
 
 _DEFAULT_PRIOR = ScalePrior.uniform()
@@ -48,6 +59,12 @@ def generate_reweight_mask(end_points, prior=None):
     widths = end_points['batch_grasp_offset_all'][:, :, :, :, :, 2].reshape(B, Ns, -1)
     best = torch.argmax(labels.reshape(B, Ns, -1), dim=2, keepdim=True)
     return prior.lookup(torch.gather(widths, 2, best).squeeze(2))
+
+
+def _masked_fraction(flags, mask):
+    """== flags[mask].float().mean() (NaN for an empty selection, like the mean of an empty tensor) without the
+    boolean-index gather, whose output size costs a device->host synchronisation."""
+    return (flags & mask).sum().float() / mask.sum().float()
 
 
 def _seed_objectness(end_points):
@@ -71,8 +88,8 @@ def compute_robust_graspable_loss(end_points):
     pred = torch.argmax(objectness_score, 1)
     correct = pred == graspable_label.long()
     end_points['stage1_graspable_acc'] = correct.float().mean()
-    end_points['stage1_graspable_prec'] = correct[pred == 1].float().mean()
-    end_points['stage1_graspable_recall'] = correct[graspable_label == 1].float().mean()
+    end_points['stage1_graspable_prec'] = _masked_fraction(correct, pred == 1)
+    end_points['stage1_graspable_recall'] = _masked_fraction(correct, graspable_label == 1)
     return loss, end_points
 
 
@@ -125,9 +142,9 @@ def compute_weighted_grasp_loss(end_points, weight_mask):
     angle_pred = torch.argmax(angle_scores, 1)
     diff = torch.abs(angle_pred - target_angles_cls)
     sel = loss_mask.bool()
-    end_points['stage2_grasp_angle_class_acc/0_degree'] = (angle_pred == target_angles_cls)[sel].float().mean()
-    end_points['stage2_grasp_angle_class_acc/15_degree'] = ((diff <= 1) | (diff >= A - 1))[sel].float().mean()
-    end_points['stage2_grasp_angle_class_acc/30_degree'] = ((diff <= 2) | (diff >= A - 2))[sel].float().mean()
+    end_points['stage2_grasp_angle_class_acc/0_degree'] = _masked_fraction(angle_pred == target_angles_cls, sel)
+    end_points['stage2_grasp_angle_class_acc/15_degree'] = _masked_fraction((diff <= 1) | (diff >= A - 1), sel)
+    end_points['stage2_grasp_angle_class_acc/30_degree'] = _masked_fraction((diff <= 2) | (diff >= A - 2), sel)
     # 3. width, 4. tolerance
     width_pred = torch.gather(end_points['grasp_width_pred'], 1, pick).squeeze(1)
     width_loss = masked_mean(huber_loss((width_pred - target_widths) / GRASP_MAX_WIDTH, delta=1), loss_mask)

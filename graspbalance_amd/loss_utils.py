@@ -36,6 +36,18 @@ def generate_grasp_views(N=300, phi=(np.sqrt(5) - 1) / 2, center=np.zeros(3), r=
     return _VIEW_CACHE[key].clone()
 
 
+_VIEW_DEVICE_CACHE = {}
+
+
+def grasp_views_on(device, N=300):
+    """generate_grasp_views(N) resident on `device`, uploaded once (a per-step ``.to(device)`` of the host
+    tensor is a synchronous copy that stalls the launch queue).  Read-only: do not modify in place."""
+    key = (N, str(device))
+    if key not in _VIEW_DEVICE_CACHE:
+        _VIEW_DEVICE_CACHE[key] = generate_grasp_views(N).to(device)
+    return _VIEW_DEVICE_CACHE[key]
+
+
 def batch_viewpoint_params_to_matrix(batch_towards, batch_angle):
     """Approach vectors (N,3) + in-plane angles (N,) -> rotation matrices (N,3,3) whose first column
     is the normalised approach direction."""

@@ -7,7 +7,7 @@ import torch.nn.functional as F
 
 from . import fused_mlp
 from . import pytorch_utils as pt_utils
-from .loss_utils import batch_viewpoint_params_to_matrix, generate_grasp_views
+from .loss_utils import batch_viewpoint_params_to_matrix, generate_grasp_views, grasp_views_on
 from .pointnet2_utils import CylinderQueryAndGroup, furthest_point_sample
 
 
@@ -75,7 +75,7 @@ class GraspableDetection(nn.Module):
         end_points['objectness_score'] = features[:, :2, :]
         end_points['view_score'] = view_score
         top_view_scores, top_view_inds = torch.max(view_score, dim=2)
-        template_views = generate_grasp_views(self.num_view).to(features.device)  # (V,3)
+        template_views = grasp_views_on(features.device, self.num_view)  # (V,3)
         vp_xyz = template_views[top_view_inds]  # (B,num_seed,3) == gather of the expanded templates
         batch_angle = torch.zeros(B * num_seed, dtype=vp_xyz.dtype, device=vp_xyz.device)
         vp_rot = batch_viewpoint_params_to_matrix(-vp_xyz.view(-1, 3), batch_angle).view(B, num_seed, 3, 3)

@@ -263,6 +263,61 @@ __global__ __launch_bounds__(GTPB) void gemm_cl_kernel(Operand a, Operand b, flo
   }
 }
 
+// wgrad for a handful of input channels (K <= 4: the xyz-only first layer of a grouped SharedMLP): dW[n, j] =
+// sum_p dY[p, n] x[p, j] is a weighted column reduction of dY, HBM-bound on reading dY once - the MFMA tiling
+// above would waste 60/64 of its reduction lanes on it.  A thread owns 4 columns n and all K inputs, 4 rows in
+// flight; row lanes of a workgroup are combined through LDS, one fp32 atomic per (n, j) per workgroup.
+constexpr int WSK_ROWS = 2048;  // rows per workgroup: few workgroups, so few same-address atomics per dW element
+template <int K>
+__global__ __launch_bounds__(GTPB) void wgrad_smallk_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                            float *__restrict__ dw, long long P, int N) {
+  __shared__ float part[GTPB * 4 * K];
+  const int tpr = N / 4, rpp = GTPB / tpr;
+  const int cg = threadIdx.x % tpr, rl = threadIdx.x / tpr;
+  const long long r0 = (long long)blockIdx.x * WSK_ROWS;
+  long long r1 = r0 + WSK_ROWS;
+  if (r1 > P) r1 = P;
+  float acc[4][K];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int j = 0; j < K; ++j) acc[t][j] = 0.f;
+  if (rl < rpp)
+    for (long long r = r0 + rl; r < r1; r += 4 * rpp) {
+      float4 g[4];
+      float xv[4][K];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long rr = r + (long long)u * rpp;
+        if (rr < r1) {
+          g[u] = *reinterpret_cast<const float4 *>(dy + rr * N + 4 * cg);
+#pragma unroll
+          for (int j = 0; j < K; ++j) xv[u][j] = x[rr * K + j];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (r + (long long)u * rpp < r1) {
+          const float gv[4] = {g[u].x, g[u].y, g[u].z, g[u].w};
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < K; ++j) acc[t][j] += gv[t] * xv[u][j];
+        }
+    }
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int j = 0; j < K; ++j) part[(threadIdx.x * 4 + t) * K + j] = acc[t][j];
+  __syncthreads();
+  // element o = (cg*4 + t)*K + j  of row lane l lives at part[(l*tpr*4)*K + o]
+  for (int o = threadIdx.x; o < N * K; o += GTPB) {
+    float s = 0.f;
+    for (int l = 0; l < rpp; ++l) s += part[l * tpr * 4 * K + o];
+    atomicAdd(dw + o, s);  // dw is (N, K) row-major: o = n*K + j
+  }
+}
+
 static inline bool aligned16(const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
 
 template <int KA, int KB, int EPI, int BM, int BN>
@@ -354,6 +409,14 @@ extern "C" int gb_gemm_wgrad(const float *dy, const float *x, const float *x_aff
                              int N, void *stream) {
   if (P < 0 || K < 1 || N < 1 || !dy || !x || !dw) return GB_EINVAL;
   if (P == 0) return GB_OK;
+  if (K <= 4 && !x_aff && N % 4 == 0 && N / 4 <= GTPB && P >= 4096 && reinterpret_cast<uintptr_t>(dy) % 16 == 0) {
+    const dim3 grid((unsigned)((P + WSK_ROWS - 1) / WSK_ROWS));
+    if (K == 1) hipLaunchKernelGGL(wgrad_smallk_kernel<1>, grid, dim3(GTPB), 0, as_stream(stream), dy, x, dw, P, N);
+    else if (K == 2) hipLaunchKernelGGL(wgrad_smallk_kernel<2>, grid, dim3(GTPB), 0, as_stream(stream), dy, x, dw, P, N);
+    else if (K == 3) hipLaunchKernelGGL(wgrad_smallk_kernel<3>, grid, dim3(GTPB), 0, as_stream(stream), dy, x, dw, P, N);
+    else hipLaunchKernelGGL(wgrad_smallk_kernel<4>, grid, dim3(GTPB), 0, as_stream(stream), dy, x, dw, P, N);
+    return check_launch("gb_gemm_wgrad");
+  }
   Operand a = {dy, N, P, N, nullptr};  // tile rows = n, reduction = p, element (n,p) at dy[p*N + n]
   Operand b = {x, K, P, K, x_aff};     // tile rows = k, reduction = p, element (k,p) at x[p*K + k]
   const long long tiles = (long long)((N + (N <= 64 ? 63 : 127)) / (N <= 64 ? 64 : 128)) *

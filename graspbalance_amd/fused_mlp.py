@@ -68,8 +68,13 @@ def _gemm_meta(kind, P, K, N, fused=False, aff=False):
     kernel the C entry dispatches to (gemm_rs_kernel / gemm_cl_kernel)."""
     if _lib.KernelTimer.active is None:
         return None
-    rs = kind != "wgrad" and _lib.lib().gb_gemm_uses_rs(P, K, N, int(kind == "dgrad"), int(fused), int(aff))
-    return {"flop": 2.0 * P * K * N, "pkn": (P, K, N), "kernel": "gemm_rs_kernel" if rs else "gemm_cl_kernel"}
+    if kind == "wgrad":
+        smallk = K <= 4 and not aff and N % 4 == 0 and N <= 1024 and P >= 4096  # gb_gemm_wgrad's dispatch rule
+        kernel = "wgrad_smallk_kernel" if smallk else "gemm_cl_kernel"
+    else:
+        rs = _lib.lib().gb_gemm_uses_rs(P, K, N, int(kind == "dgrad"), int(fused), int(aff))
+        kernel = "gemm_rs_kernel" if rs else "gemm_cl_kernel"
+    return {"flop": 2.0 * P * K * N, "pkn": (P, K, N), "kernel": kernel}
 
 
 def _wgrad(dY, X):
@@ -350,7 +355,7 @@ class MLPStack(Function):
             if need_w[l]:
                 dW = w_arena[w_off[l]:w_off[l + 1]]
                 _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(src), _lib.ptr(aff), _lib.ptr(dW), P, K, N, _s(dout),
-                      meta=_gemm_meta("wgrad", P, K, N))
+                      meta=_gemm_meta("wgrad", P, K, N, aff=aff is not None))
                 grads[3 * l] = dW.view(N, K)
             if l == 0:
                 if ctx.needs_input_grad[0]:

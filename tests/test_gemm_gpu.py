@@ -9,7 +9,9 @@ DEV = "cuda:0"
 SHAPES = [(1000, 3, 64), (4096, 64, 64), (5000, 131, 128), (777, 259, 256), (2048, 128, 512), (130, 512, 128),
           (8192, 16, 8), (1, 5, 3), (33000, 64, 128),
           # tall shapes that take the row-streaming kernel (csrc/gemm_rs.hip) in fwd and/or dgrad
-          (20011, 128, 256), (16400, 64, 131), (17000, 132, 40), (40000, 256, 96), (16384, 32, 256), (70000, 256, 128)]
+          (20011, 128, 256), (16400, 64, 131), (17000, 132, 40), (40000, 256, 96), (16384, 32, 256), (70000, 256, 128),
+          # few input channels: the column-reduction wgrad (wgrad_smallk_kernel)
+          (9001, 3, 64), (5000, 4, 40), (66000, 1, 128)]
 
 
 def _lib():

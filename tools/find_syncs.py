@@ -13,7 +13,9 @@ seen = []
 def showwarning(message, category, filename, lineno, file=None, line=None):
     st = [f for f in traceback.extract_stack() if "/root/repo/" in f.filename or "graspbalance_amd" in f.filename]
     st = [f for f in st if "find_syncs" not in f.filename]
-    seen.append(" <- ".join("%s:%d" % (os.path.basename(f.filename), f.lineno) for f in st[-3:][::-1]))
+    if not st:
+        st = [f for f in traceback.extract_stack() if "find_syncs" not in f.filename and "warnings" not in f.filename][-6:]
+    seen.append(" <- ".join("%s:%d" % (os.path.basename(f.filename), f.lineno) for f in st[-4:][::-1]))
 warnings.showwarning = showwarning
 warnings.simplefilter("always")
 torch.cuda.set_sync_debug_mode("warn")

@@ -397,9 +397,74 @@ __global__ __launch_bounds__(TPB) void label_gather_kernel(const float *const *_
   }
 }
 
+// Score transform + per-view maximum of the gathered grasp labels (reference label_generation.py:112-116:
+//   mask = (label > 0) & (width <= max_width); label[mask] = log(u_max / label[mask]); label[~mask] = 0;
+//   view_score = max over the A*D grasps of a view)  as one pass instead of eight element-wise launches over
+// the (B,Ns,V,A,D) tensor.  A thread owns 4 consecutive grasps (one 16-byte label load, their 12 offset
+// floats as three 16-byte loads); the AD/4 threads of a view combine their maxima through LDS.
+constexpr int LF_ROWS = 16;  // views per workgroup
+__global__ void label_finish_kernel(const float *__restrict__ labels, const float *__restrict__ offsets,
+                                    const float *__restrict__ u_max, float max_width, float *__restrict__ out,
+                                    float *__restrict__ view_scores, long long rows, int ad4) {
+  extern __shared__ float s_max[];  // [LF_ROWS][ad4]
+  const int rl = threadIdx.x / ad4, q = threadIdx.x % ad4;
+  const long long row = (long long)blockIdx.x * LF_ROWS + rl;
+  const float um = *u_max;
+  float best = -INFINITY;
+  if (row < rows) {
+    const long long e4 = row * ad4 + q;  // index of this thread's group of 4 grasps
+    const float4 l = reinterpret_cast<const float4 *>(labels)[e4];
+    const float4 o0 = reinterpret_cast<const float4 *>(offsets)[3 * e4];
+    const float4 o1 = reinterpret_cast<const float4 *>(offsets)[3 * e4 + 1];
+    const float4 o2 = reinterpret_cast<const float4 *>(offsets)[3 * e4 + 2];
+    const float lv[4] = {l.x, l.y, l.z, l.w};
+    const float wv[4] = {o0.z, o1.y, o2.x, o2.w};  // offsets[..., 2] of the 4 grasps
+    float r[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bool m = lv[t] > 0.f && wv[t] <= max_width;
+      const float c = lv[t] < 1e-30f ? 1e-30f : lv[t];  // clamp_min(1e-30) (NaN passes through, as in torch)
+      r[t] = m ? logf(um / c) : 0.f;
+      best = fmaxf(best, r[t]);
+      if (r[t] != r[t]) best = r[t];  // torch.max propagates NaN
+    }
+    reinterpret_cast<float4 *>(out)[e4] = make_float4(r[0], r[1], r[2], r[3]);
+  }
+  s_max[threadIdx.x] = best;
+  __syncthreads();
+  if (threadIdx.x < LF_ROWS) {
+    const long long vr = (long long)blockIdx.x * LF_ROWS + threadIdx.x;
+    if (vr < rows) {
+      float b = -INFINITY;
+      bool nan = false;
+      for (int i = 0; i < ad4; ++i) {
+        const float v = s_max[threadIdx.x * ad4 + i];
+        nan |= v != v;
+        b = fmaxf(b, v);
+      }
+      view_scores[vr] = nan ? NAN : b;
+    }
+  }
+}
+
 }  // namespace gb
 
 using namespace gb;
+
+extern "C" int gb_label_finish(const float *labels, const float *offsets, const float *u_max, float max_width,
+                               float *out, float *view_scores, long long rows, int ad, void *stream) {
+  if (rows < 0 || ad < 4 || ad % 4 != 0 || ad / 4 * LF_ROWS > 1024 || !labels || !offsets || !u_max || !out ||
+      !view_scores)
+    return GB_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(labels) | reinterpret_cast<uintptr_t>(offsets) | reinterpret_cast<uintptr_t>(out)) % 16)
+    return GB_EINVAL;
+  if (rows == 0) return GB_OK;
+  const int ad4 = ad / 4, threads = LF_ROWS * ad4;
+  hipLaunchKernelGGL(label_finish_kernel, dim3((unsigned)((rows + LF_ROWS - 1) / LF_ROWS)), dim3(threads),
+                     threads * sizeof(float), as_stream(stream), labels, offsets, u_max, max_width, out, view_scores, rows,
+                     ad4);
+  return check_launch("gb_label_finish");
+}
 
 extern "C" int gb_label_gather(const float *const *srcs, const int32_t *obj, const int32_t *pt,
                                const int64_t *view_inds, float *out, int R, int V, int W, void *stream) {

@@ -59,12 +59,26 @@ def _label_gather(tensors, obj, pt, view_inds, V, W):
 def _finish_labels(end_points, batch, batch_size, num_samples):
     labels = batch['label']  # (B,Ns,V,A,D)
     V, A, D = labels.shape[2:]
-    widths = batch['offset'][:, :, :, :, :, 2]
-    label_mask = (labels > 0) & (widths <= GRASP_MAX_WIDTH)
+    offsets = batch['offset']
     u_max = labels.max()
-    # == labels[mask] = log(u_max / labels[mask]); labels[~mask] = 0   (no boolean-index host sync)
-    labels = torch.where(label_mask, torch.log(u_max / labels.clamp_min(1e-30)), torch.zeros_like(labels))
-    view_scores, _ = labels.view(batch_size, num_samples, V, A * D).max(dim=-1)
+    if (labels.is_cuda and (A * D) % 4 == 0 and A * D <= 256 and labels.is_contiguous() and offsets.is_contiguous()
+            and labels.dtype == torch.float32 and offsets.dtype == torch.float32):
+        # one pass (gb_label_finish) instead of compare / and / clamp / div / log / where / max over (B,Ns,V,A,D)
+        from . import _lib
+        out = torch.empty_like(labels)
+        view_scores = torch.empty((batch_size, num_samples, V), dtype=torch.float32, device=labels.device)
+        with torch.cuda.device(labels.device):
+            _lib.check(_lib.lib().gb_label_finish(_lib.ptr(labels), _lib.ptr(offsets), _lib.ptr(u_max),
+                                                  float(GRASP_MAX_WIDTH), _lib.ptr(out), _lib.ptr(view_scores),
+                                                  batch_size * num_samples * V, A * D,
+                                                  _lib.current_stream(labels.device)), "gb_label_finish")
+        labels = out
+    else:
+        widths = offsets[:, :, :, :, :, 2]
+        label_mask = (labels > 0) & (widths <= GRASP_MAX_WIDTH)
+        # == labels[mask] = log(u_max / labels[mask]); labels[~mask] = 0   (no boolean-index host sync)
+        labels = torch.where(label_mask, torch.log(u_max / labels.clamp_min(1e-30)), torch.zeros_like(labels))
+        view_scores, _ = labels.view(batch_size, num_samples, V, A * D).max(dim=-1)
     end_points['batch_grasp_point'] = batch['point']
     end_points['batch_grasp_view'] = batch['view']
     end_points['batch_grasp_view_rot'] = batch['view_rot']
@@ -72,6 +86,7 @@ def _finish_labels(end_points, batch, batch_size, num_samples):
     end_points['batch_grasp_offset'] = batch['offset']
     end_points['batch_grasp_tolerance'] = batch['tolerance']
     end_points['batch_grasp_view_label'] = view_scores.float()
+    end_points['_view_label_source'] = labels  # lets the loss reuse the per-view maximum (same tensor object)
     return end_points
 
 

@@ -56,9 +56,10 @@ def generate_reweight_mask(end_points, prior=None):
     prior = prior or _DEFAULT_PRIOR
     labels = end_points['batch_grasp_label_all']
     B, Ns = labels.shape[:2]
-    widths = end_points['batch_grasp_offset_all'][:, :, :, :, :, 2].reshape(B, Ns, -1)
     best = torch.argmax(labels.reshape(B, Ns, -1), dim=2, keepdim=True)
-    return prior.lookup(torch.gather(widths, 2, best).squeeze(2))
+    # == gather(offsets[..., 2].reshape(B,Ns,-1), 2, best) without materialising the strided width slice
+    offsets = end_points['batch_grasp_offset_all'].reshape(B, Ns, -1)
+    return prior.lookup(torch.gather(offsets, 2, best * 3 + 2).squeeze(2))
 
 
 def _masked_fraction(flags, mask):
@@ -74,7 +75,9 @@ def _seed_objectness(end_points):
 def _graspable_label(end_points, objectness_label):
     labels = end_points['batch_grasp_label_all']
     B, Ns, V = labels.shape[:3]
-    per_view = labels.view(B, Ns, V, -1).max(3)[0]
+    per_view = end_points.get('batch_grasp_view_label')  # process_grasp_labels already took this max of `labels`
+    if per_view is None or end_points.get('_view_label_source') is not labels:
+        per_view = labels.view(B, Ns, V, -1).max(3)[0]
     graspable_cnt = torch.sum((per_view > THRESH_BAD).long(), dim=2)
     return (graspable_cnt > 10) * objectness_label
 

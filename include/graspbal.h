@@ -141,6 +141,12 @@ int gb_knn1(const float *ref, const float *query, int64_t *idx, int b, int dim, 
  * then seeds) so only the kept rows are copied.                                                   */
 int gb_label_gather(const float *const *srcs, const int32_t *obj, const int32_t *pt,
                     const int64_t *view_inds, float *out, int R, int V, int W, void *stream);
+/* Score transform + per-view maximum of the gathered labels (reference label_generation.py:112-116):
+ * out = log(*u_max / label) where label > 0 and offsets[..., 2] (width) <= max_width, else 0;
+ * view_scores[row] = max over the ad = A*D grasps of the row.  labels/out (rows, ad), offsets (rows, ad, 3),
+ * u_max: device scalar (the maximum of `labels`); ad % 4 == 0; 16-byte aligned tensors.                */
+int gb_label_finish(const float *labels, const float *offsets, const float *u_max, float max_width, float *out,
+                    float *view_scores, long long rows, int ad, void *stream);
 
 /* ---- channel-last fused pieces of the SharedMLP (1x1 conv + BatchNorm + ReLU + max over nsample) ----
  * No reference launcher corresponds one-to-one: these replace the torch passes the reference runs

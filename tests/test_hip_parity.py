@@ -280,3 +280,29 @@ def test_error_contract(ext):
         ext.gather_points(torch.rand(1, 3, 8, device=DEV), torch.zeros(1, 2, dtype=torch.int64, device=DEV))
     with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
         ext.gather_points(torch.rand(1, 3, 8, device=DEV), torch.zeros(1, 2, dtype=torch.int32))
+
+
+def test_label_finish_matches_torch_composition():
+    """gb_label_finish against the reference's element-wise formulation (label_generation.py:112-116)."""
+    import torch
+    from graspbalance_amd import _lib
+    from graspbalance_amd.loss_utils import GRASP_MAX_WIDTH
+    torch.manual_seed(0)
+    B, Ns, V, A, D = 2, 37, 30, 12, 4
+    labels = torch.rand(B, Ns, V, A, D, device="cuda:0") * 1.2 - 0.2
+    labels[torch.rand_like(labels) < 0.3] = -1.0
+    labels[torch.rand_like(labels) < 0.05] = 0.0
+    offsets = torch.rand(B, Ns, V, A, D, 3, device="cuda:0") * 0.15
+    u_max = labels.max()
+    out = torch.empty_like(labels)
+    vs = torch.empty(B, Ns, V, device="cuda:0")
+    _lib.check(_lib.lib().gb_label_finish(_lib.ptr(labels), _lib.ptr(offsets), _lib.ptr(u_max), float(GRASP_MAX_WIDTH),
+                                          _lib.ptr(out), _lib.ptr(vs), B * Ns * V, A * D, None), "label_finish")
+    torch.cuda.synchronize()
+    mask = (labels > 0) & (offsets[..., 2] <= GRASP_MAX_WIDTH)
+    ref = labels.clone()
+    ref[mask] = torch.log(u_max / ref[mask])
+    ref[~mask] = 0
+    ref_vs = ref.view(B, Ns, V, A * D).max(dim=-1)[0]
+    assert torch.equal(out, ref)
+    assert torch.equal(vs, ref_vs)

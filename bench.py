@@ -136,8 +136,10 @@ def main():
         # path (gemm_cl_kernel: LDS-tiled; gemm_rs_kernel: row-streaming).  "roofline" is whichever has the
         # larger share, the other goes to "roofline_gemm2".  Per launch: algorithmic FLOP = 2*P*K*N;
         # achieved = sum FLOP / sum launch durations (HIP events on the launch stream, in the timed region).
+        ev_bias = _lib.event_pair_overhead_ms(device)  # what an empty event bracket reads; removed from every launch
+
         def gemm_roofline(kernel, what):
-            ev = [(a.elapsed_time(b), m["flop"]) for n in ("gb_gemm_fwd", "gb_gemm_dgrad", "gb_gemm_wgrad")
+            ev = [(max(a.elapsed_time(b) - ev_bias, 1e-4), m["flop"]) for n in ("gb_gemm_fwd", "gb_gemm_dgrad", "gb_gemm_wgrad")
                   for a, b, m in kt.events[n] if m["kernel"] == kernel]
             if not ev:
                 return None
@@ -157,7 +159,7 @@ def main():
         roofline_second = both[1] if len(both) > 1 else None
         # largest single launch of the step: the first-level FPS (HBM class, streaming-model bytes)
         roofline_fps = None
-        big = [(a.elapsed_time(b), m) for a, b, m in kt.events["gb_fps"] if m["n"] == NUM_POINT]
+        big = [(a.elapsed_time(b) - ev_bias, m) for a, b, m in kt.events["gb_fps"] if m["n"] == NUM_POINT]
         if big:
             mean_ms = sum(x for x, _ in big) / len(big)
             meta = big[0][1]
@@ -177,6 +179,7 @@ def main():
                        "global_batch": world * BATCH_PER_GPU, "parallelism": "dp%d" % world},
             "roofline": roofline,
             "roofline_gemm2": roofline_second,
+            "event_bias_us": round(ev_bias * 1e3, 2),
             "roofline_fps": roofline_fps,
         }
         if world == 1 and not args.no_cpu_baseline:

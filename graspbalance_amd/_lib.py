@@ -140,6 +140,22 @@ def timed(name, device, meta, launch):
     return rc
 
 
+def event_pair_overhead_ms(device, pairs=64):
+    """Median elapsed time of an EMPTY start/stop event pair on `device`'s current stream: the bias a HIP-event
+    bracket adds to a kernel's duration (a few microseconds - visible on 50 us kernels).  bench.py subtracts it."""
+    import torch
+    s = torch.cuda.current_stream(device)
+    evs = []
+    for _ in range(pairs):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(s)
+        b.record(s)
+        evs.append((a, b))
+    torch.cuda.synchronize(device)
+    ms = sorted(a.elapsed_time(b) for a, b in evs)
+    return ms[len(ms) // 2]
+
+
 def check(rc, what):
     if rc != GB_OK:
         msg = lib().gb_last_error().decode() if rc == -2 else ""

@@ -20,18 +20,40 @@ def load(dirpath, counter):
     return tot, cnt
 
 
-def main(fetch_dir, write_dir, pattern):
+def main(fetch_dir, write_dir, pattern, as_json=False):
     ft, fc = load(fetch_dir, "FETCH_SIZE")
     wt, wc = load(write_dir, "WRITE_SIZE")
+    out = {}
     for name in sorted(ft, key=lambda k: -ft[k]):
         if pattern not in name:
             continue
         n = fc[name]
         fetch = ft[name] * 1024 * 2 / n
         write = wt.get(name, 0.0) * 1024 / max(wc.get(name, 1), 1)
-        print("%-70s launches %5d  fetch %10.3f MB (x2 corrected)  write %10.3f MB  total %10.3f MB per launch"
-              % (name, n, fetch / 1e6, write / 1e6, (fetch + write) / 1e6))
+        if as_json:
+            # key = the kernel's short name as bench.py's pmc_traffic() looks it up
+            key = name.replace("gb::", "")
+            key = key if key.startswith("fps_reg_kernel<1024, 20>") else key.split("<")[0]
+            ent = out.setdefault(key, {"launches_profiled": 0, "fetch": 0.0, "write": 0.0})
+            ent["launches_profiled"] += n
+            ent["fetch"] += fetch * n
+            ent["write"] += write * n
+        else:
+            print("%-70s launches %5d  fetch %10.3f MB (x2 corrected)  write %10.3f MB  total %10.3f MB per launch"
+                  % (name, n, fetch / 1e6, write / 1e6, (fetch + write) / 1e6))
+    if as_json:
+        import json
+        res = {}
+        for k, e in out.items():
+            n = e["launches_profiled"]
+            res[k] = {"launches_profiled": n, "fetch_bytes_per_launch_x2_corrected": e["fetch"] / n,
+                      "write_bytes_per_launch": e["write"] / n, "hbm_bytes_per_launch": (e["fetch"] + e["write"]) / n}
+        res["_how"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 "
+                       "--warmup 1 --no-cpu-baseline; counters in KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md "
+                       "(128-B requests tallied at 64 B); mean over all launches of the kernel (all template variants)")
+        print(json.dumps(res, indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "gb::")
+    args = [a for a in sys.argv[1:] if a != "--json"]
+    main(args[0], args[1], args[2] if len(args) > 2 else "gb::", "--json" in sys.argv)

@@ -27,6 +27,8 @@ _P, _I, _F, _U, _L = _c.c_void_p, _c.c_int, _c.c_float, _c.c_uint, _c.c_longlong
 # shared object exports exactly what include/graspbal.h declares.
 SIGNATURES = {
     "gb_fps": [_P, _P, _P, _I, _I, _I, _U, _P],
+    "gb_fps_pruned": [_P, _P, _P, _P, _I, _I, _I, _U, _P],
+    "gb_fps_morton_keys": [_P, _P, _I, _I, _P],
     "gb_gather": [_P, _P, _P, _I, _I, _I, _I, _P],
     "gb_gather_grad": [_P, _P, _P, _I, _I, _I, _I, _P],
     "gb_ball_query": [_P, _P, _P, _P, _I, _I, _I, _F, _I, _P],
@@ -154,6 +156,23 @@ def event_pair_overhead_ms(device, pairs=64):
     torch.cuda.synchronize(device)
     ms = sorted(a.elapsed_time(b) for a, b in evs)
     return ms[len(ms) // 2]
+
+
+FPS_PRUNE_MIN_N, FPS_PRUNE_MAX_N, FPS_PRUNE_MIN_M = 8192, 20480, 128
+_fps_prune = os.environ.get("GB_FPS_PRUNE", "1") != "0"  # A/B switch
+
+
+def fps(points, temp, output, b, n, m, flags, stream):
+    """gb_fps, or for large clouds its pruned form on a Morton-sorted visiting order (identical outputs)."""
+    import torch
+    if _fps_prune and FPS_PRUNE_MIN_N <= n <= FPS_PRUNE_MAX_N and m >= FPS_PRUNE_MIN_M:
+        keys = torch.empty((b, n), dtype=torch.int32, device=points.device)
+        rc = lib().gb_fps_morton_keys(ptr(points), ptr(keys), b, n, stream)
+        if rc != GB_OK:
+            return rc
+        perm = torch.argsort(keys, dim=1).to(torch.int32)
+        return lib().gb_fps_pruned(ptr(points), ptr(perm), ptr(temp), ptr(output), b, n, m, flags, stream)
+    return lib().gb_fps(ptr(points), ptr(temp), ptr(output), b, n, m, flags, stream)
 
 
 def check(rc, what):

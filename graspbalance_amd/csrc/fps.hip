@@ -146,6 +146,171 @@ __global__ __launch_bounds__(BLOCK) void fps_reg_kernel(const float *__restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pruned variant for large clouds.  The update temp[k] = min(temp[k], d(k, new sample)) changes nothing for a
+// point that is farther from the new sample than its current temp.  With the points visited in a spatially
+// coherent order (`perm`: Morton order, gb_fps_morton_keys + a sort), thread t owns P CONSECUTIVE sorted
+// points, keeps their bounding box in 6 VGPRs, and compares the box's distance to the new sample with the
+// largest temp it holds (its running arg-max value): if every lane of a wave passes that test the wave skips
+// the update — after a few dozen samples that is most waves (16 waves x 1280 sorted points each).
+// The result is the SAME sequence of samples as the full update, bit for bit: the bound is formed with the
+// same un-fused operations as the distances, and IEEE rounding is monotonic, so box-distance <= every
+// point's computed distance.  Tie keys follow the ORIGINAL indices (LDS table), so all three tie rules hold.
+template <int BLOCK, int P>
+__global__ __launch_bounds__(BLOCK) void fps_pruned_kernel(const float *__restrict__ xyz,
+                                                            const int32_t *__restrict__ perm,
+                                                            float *__restrict__ temp_io,
+                                                            int32_t *__restrict__ idx, int n, int m, int skip,
+                                                            int bs_log2) {
+  extern __shared__ unsigned s_tie[];  // [BLOCK * P] tie key of each sorted position
+  __shared__ float s_d[32];
+  __shared__ unsigned s_key[32];
+  const int tid = threadIdx.x;
+  const float *pts = xyz + (size_t)blockIdx.x * n * 3;
+  const int32_t *pm = perm + (size_t)blockIdx.x * n;
+  int32_t *out = idx + (size_t)blockIdx.x * m;
+  float *tio = temp_io ? temp_io + (size_t)blockIdx.x * n : nullptr;
+
+  float px[P], py[P], pz[P], pt[P];
+  float lox = INFINITY, loy = INFINITY, loz = INFINITY, hix = -INFINITY, hiy = -INFINITY, hiz = -INFINITY;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int k = tid * P + p;
+    float x = 0.f, y = 0.f, z = 0.f, t = -INFINITY;  // -inf: never a candidate, never equal to a running best
+    unsigned key = 0xFFFFFFFFu;
+    if (k < n) {
+      const int o = pm[k];
+      const f3 v = reinterpret_cast<const f3 *>(pts)[o];
+      x = v.x; y = v.y; z = v.z;
+      t = tio ? tio[o] : 1e10f;
+      key = fps_key(o, bs_log2);
+      if (skip) {
+        const float mag = ((x * x) + (y * y)) + (z * z);
+        if (mag < 1e-3f) t = -INFINITY;
+      }
+      if (t >= 0.f) {
+        lox = fminf(lox, x); loy = fminf(loy, y); loz = fminf(loz, z);
+        hix = fmaxf(hix, x); hiy = fmaxf(hiy, y); hiz = fmaxf(hiz, z);
+      }
+    }
+    px[p] = x; py[p] = y; pz[p] = z; pt[p] = t;
+    s_tie[k] = key;
+  }
+  __syncthreads();
+
+  // > any squared distance: forces the first update; afterwards the largest temp I hold.  A thread without
+  // candidates (padding, all points skipped) never needs an update and never wins.
+  float best = lox <= hix ? 3.0e38f : -1.0f;
+  unsigned key = fps_key(0, bs_log2);
+  int old = 0;
+  if (tid == 0) out[0] = 0;
+  for (int j = 1; j < m; ++j) {
+    const float x1 = pts[old * 3 + 0], y1 = pts[old * 3 + 1], z1 = pts[old * 3 + 2];
+    // squared distance from the new sample to my box, in the same operation order as a point distance
+    const float bx = fmaxf(fmaxf(lox - x1, x1 - hix), 0.f);
+    const float by = fmaxf(fmaxf(loy - y1, y1 - hiy), 0.f);
+    const float bz = fmaxf(fmaxf(loz - z1, z1 - hiz), 0.f);
+    const float lb = ((bx * bx) + (by * by)) + (bz * bz);
+    if (__builtin_amdgcn_ballot_w64(lb < best) != 0ull) {  // wave-uniform
+      constexpr int NACC = P >= 4 ? 4 : 1;
+      float bq[NACC];
+      int bpq[NACC];
+      bool tie = false;
+#pragma unroll
+      for (int q = 0; q < NACC; ++q) { bq[q] = -1.0f; bpq[q] = q; }
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const float dx = px[p] - x1, dy = py[p] - y1, dz = pz[p] - z1;
+        const float d = ((dx * dx) + (dy * dy)) + (dz * dz);
+        const float d2 = __builtin_fminf(d, pt[p]);
+        pt[p] = d2;
+        const bool gt = d2 > bq[p % NACC];
+        tie |= d2 == bq[p % NACC];
+        bq[p % NACC] = gt ? d2 : bq[p % NACC];
+        bpq[p % NACC] = gt ? p : bpq[p % NACC];
+      }
+      float b = bq[0];
+      int bp = bpq[0];
+#pragma unroll
+      for (int q = 1; q < NACC; ++q) {
+        tie |= bq[q] == b;
+        const bool take = bq[q] > b;
+        b = take ? bq[q] : b;
+        bp = take ? bpq[q] : bp;
+      }
+      unsigned kk = s_tie[tid * P + bp];
+      if (__builtin_amdgcn_ballot_w64(tie && b >= 0.f) != 0ull) {
+        // an equal value somewhere in my slab (duplicate points, exact distance ties): the winner among equals is
+        // the smallest tie key; rare, so resolved out of line
+        kk = 0xFFFFFFFFu;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const unsigned kp = s_tie[tid * P + p];
+          if (pt[p] == b && kp < kk) kk = kp;
+        }
+      }
+      best = b;
+      key = b < 0.f ? fps_key(0, bs_log2) : kk;
+    }
+    old = block_argmax<BLOCK>(best, key, bs_log2, s_d, s_key, j & 1);
+    if (tid == 0) out[j] = old;
+  }
+  if (tio) {
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int k = tid * P + p;
+      if (k < n && pt[p] >= 0.0f) tio[pm[k]] = pt[p];
+    }
+  }
+}
+
+// 30-bit Morton keys of each cloud's points over the cloud's bounding box (10 bits per axis); one workgroup per
+// cloud.  Any permutation gives the same FPS result; this one makes consecutive points spatially close.
+__device__ __forceinline__ unsigned spread10(unsigned v) {
+  v &= 0x3FFu;
+  v = (v | (v << 16)) & 0x030000FFu;
+  v = (v | (v << 8)) & 0x0300F00Fu;
+  v = (v | (v << 4)) & 0x030C30C3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+__global__ __launch_bounds__(1024) void fps_morton_kernel(const float *__restrict__ xyz, int32_t *__restrict__ keys,
+                                                           int n) {
+  __shared__ float s_lo[3][16], s_hi[3][16];
+  const float *pts = xyz + (size_t)blockIdx.x * n * 3;
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int k = threadIdx.x; k < n; k += 1024)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float v = pts[k * 3 + a];
+      lo[a] = fminf(lo[a], v);
+      hi[a] = fmaxf(hi[a], v);
+    }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float h = wave_max_f32(hi[a]), l = -wave_max_f32(-lo[a]);
+    if ((threadIdx.x & 63) == 0) { s_hi[a][threadIdx.x >> 6] = h; s_lo[a][threadIdx.x >> 6] = l; }
+  }
+  __syncthreads();
+  float scale[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float h = s_hi[a][0], l = s_lo[a][0];
+    for (int w = 1; w < 16; ++w) { h = fmaxf(h, s_hi[a][w]); l = fminf(l, s_lo[a][w]); }
+    lo[a] = l;
+    scale[a] = h > l ? 1023.0f / (h - l) : 0.f;
+  }
+  for (int k = threadIdx.x; k < n; k += 1024) {
+    unsigned q[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float f = (pts[k * 3 + a] - lo[a]) * scale[a];
+      q[a] = f >= 1023.f ? 1023u : (f > 0.f ? (unsigned)f : 0u);  // NaN -> 0
+    }
+    keys[(size_t)blockIdx.x * n + k] = (int32_t)(spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2));
+  }
+}
+
 // Fallback for clouds larger than one CU's register file: min-distances stay in `temp` (global).
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void fps_stream_kernel(const float *__restrict__ xyz,
@@ -244,4 +409,47 @@ extern "C" int gb_fps(const float *xyz, float *temp, int32_t *idx, int b, int n,
                        skip, bs_log2);
   }
   return check_launch("gb_fps");
+}
+
+extern "C" int gb_fps_morton_keys(const float *xyz, int32_t *keys, int b, int n, void *stream) {
+  using namespace gb;
+  if (b < 0 || n < 1 || !xyz || !keys) return GB_EINVAL;
+  if ((long long)n * 3 > 0x7fffffffLL) return GB_ERANGE;
+  if (b == 0) return GB_OK;
+  hipLaunchKernelGGL(fps_morton_kernel, dim3(b), dim3(1024), 0, as_stream(stream), xyz, keys, n);
+  return check_launch("gb_fps_morton_keys");
+}
+
+extern "C" int gb_fps_pruned(const float *xyz, const int32_t *perm, float *temp, int32_t *idx, int b, int n, int m,
+                             unsigned flags, void *stream) {
+  using namespace gb;
+  if (b < 0 || n < 1 || m < 0 || !xyz || !perm || !idx) return GB_EINVAL;
+  if (n > 1024 * 20) return GB_ERANGE;  // register-resident only (20 points per thread); larger clouds: gb_fps
+  if (b == 0 || m == 0) return GB_OK;
+  const unsigned tie = flags & GB_FPS_TIE_MASK;
+  if (tie != GB_FPS_TIE_LOWEST && tie != GB_FPS_TIE_TREE512 && tie != GB_FPS_TIE_TREE1024) return GB_EINVAL;
+  const int skip = (flags & GB_FPS_SKIP_NEAR_ORIGIN) ? 1 : 0;
+  int bs_log2 = -1;
+  if (tie != GB_FPS_TIE_LOWEST) {
+    const int cap = tie == GB_FPS_TIE_TREE512 ? 9 : 10;
+    bs_log2 = floor_log2(n) < cap ? floor_log2(n) : cap;
+    if ((n >> bs_log2) >= (1 << GB_FPS_KEY_SHIFT)) return GB_ERANGE;
+  }
+  hipStream_t s = as_stream(stream);
+  const int p_need = ceil_div(n, 1024);
+#define GB_PR(PV)                                                                                              \
+  if (p_need <= PV) {                                                                                          \
+    static bool attr = false;                                                                                  \
+    if (!attr) {                                                                                               \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fps_pruned_kernel<1024, PV>),                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * PV * 4);                    \
+      attr = true;                                                                                             \
+    }                                                                                                          \
+    hipLaunchKernelGGL((fps_pruned_kernel<1024, PV>), dim3(b), dim3(1024), 1024 * PV * sizeof(unsigned), s, xyz, perm, \
+                       temp, idx, n, m, skip, bs_log2);                                                        \
+    return check_launch("gb_fps_pruned");                                                                      \
+  }
+  GB_PR(4) GB_PR(8) GB_PR(12) GB_PR(16) GB_PR(20)
+#undef GB_PR
+  return GB_ERANGE;
 }

@@ -51,8 +51,7 @@ def furthest_point_sampling(points, nsamples):
     with torch.cuda.device(points.device):
         stream = _lib.current_stream(points.device)
         _lib.check(_lib.timed("gb_fps", points.device, {"b": B, "n": N, "m": nsamples},
-                              lambda: _lib.lib().gb_fps(_lib.ptr(points), _lib.ptr(tmp), _lib.ptr(output), B, N,
-                                                        nsamples, FPS_FLAGS, stream)),
+                              lambda: _lib.fps(points, tmp, output, B, N, nsamples, FPS_FLAGS, stream)),
                    "furthest_point_sampling")
     return output
 

@@ -70,8 +70,7 @@ def gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points):
 def furthest_point_sampling_wrapper(b, n, m, points, temp, idx):
     _gpu(points, temp, idx)
     with torch.cuda.device(points.device):
-        _lib.check(_lib.lib().gb_fps(_lib.ptr(points), _lib.ptr(temp), _lib.ptr(idx), b, n, m, FPS_FLAGS,
-                                     _stream(points)), "furthest_point_sampling_wrapper")
+        _lib.check(_lib.fps(points, temp, idx, b, n, m, FPS_FLAGS, _stream(points)), "furthest_point_sampling_wrapper")
     return 1
 
 

@@ -68,6 +68,15 @@ const char *gb_last_error(void);
  * back (PB-ext caller-allocated contract, subsample.py:76-79).                                   */
 int gb_fps(const float *xyz, float *temp, int32_t *idx, int b, int n, int m, unsigned flags,
            void *stream);
+/* Pruned FPS for large clouds: same outputs as gb_fps, bit for bit (same samples, same order, same tie rules),
+ * with the per-iteration min-distance update skipped for the wavefronts whose points are all farther from the
+ * new sample than their current min-distance.  `perm` (b,n) int32 is any permutation of each cloud's indices;
+ * a spatially coherent one (sort by gb_fps_morton_keys) is what makes the skipping effective.  n <= 20480.
+ * temp (optional) as in gb_fps.                                                                          */
+int gb_fps_pruned(const float *xyz, const int32_t *perm, float *temp, int32_t *idx, int b, int n, int m,
+                  unsigned flags, void *stream);
+/* keys (b,n) int32: 30-bit Morton code of each point within its cloud's bounding box.                   */
+int gb_fps_morton_keys(const float *xyz, int32_t *keys, int b, int n, void *stream);
 
 /* out[b,c,j] = points[b,c,idx[b,j]]  — gather_points_kernel_wrapper (PN sampling_gpu.cu:27-35),
  * gather_points_kernel_launcher_fast (PB sampling_gpu.cu:21-33). points (b,c,n), idx (b,m).      */

@@ -306,3 +306,39 @@ def test_label_finish_matches_torch_composition():
     ref_vs = ref.view(B, Ns, V, A * D).max(dim=-1)[0]
     assert torch.equal(out, ref)
     assert torch.equal(vs, ref_vs)
+
+
+@pytest.mark.parametrize("tie", ["lowest", "tree512", "tree1024"])
+@pytest.mark.parametrize("skip", [0, 1])
+def test_fps_pruned_is_the_same_sequence(orc, tie, skip):
+    """gb_fps_pruned (wave-level skipping on a sorted visiting order) against the oracle: heavy exact ties
+    (integer lattice + duplicated points), near-origin points, every tie rule, Morton / identity / random
+    visiting orders, and the running min-distance state."""
+    import torch
+    from graspbalance_amd import _lib
+    g = torch.Generator().manual_seed(11)
+    flags = {"lowest": _lib.FPS_TIE_LOWEST, "tree512": _lib.FPS_TIE_TREE512, "tree1024": _lib.FPS_TIE_TREE1024}[tie] | skip
+    cases = []
+    for (B, N, m) in [(2, 9000, 300), (1, 20000, 256), (2, 4100, 128), (1, 70, 70)]:
+        xyz = torch.randint(0, 9, (B, N, 3), generator=g).float() * 0.125
+        xyz[:, N - N // 3:] = xyz[:, :N // 3]  # exact duplicates
+        cases.append((xyz, m))
+    cases.append((torch.from_numpy(make_batch([5, 6], 20000)), 512))  # the bench's kind of cloud
+    for xyz, m in cases:
+        B, N = xyz.shape[:2]
+        dev = xyz.to(DEV)
+        keys = torch.empty(B, N, dtype=torch.int32, device=DEV)
+        _lib.check(_lib.lib().gb_fps_morton_keys(_lib.ptr(dev), _lib.ptr(keys), B, N, None), "morton")
+        perms = {"morton": torch.argsort(keys, dim=1).int(),
+                 "identity": torch.arange(N, device=DEV, dtype=torch.int32).repeat(B, 1),
+                 "random": torch.stack([torch.randperm(N, generator=g) for _ in range(B)]).int().to(DEV)}
+        temp_o = torch.full((B, N), 1e10)
+        want = orc.furthest_point_sampling(xyz, m, flags, temp=temp_o)
+        for name, perm in perms.items():
+            idx = torch.zeros(B, m, dtype=torch.int32, device=DEV)
+            temp = torch.full((B, N), 1e10, device=DEV)
+            _lib.check(_lib.lib().gb_fps_pruned(_lib.ptr(dev), _lib.ptr(perm.contiguous()), _lib.ptr(temp), _lib.ptr(idx),
+                                                B, N, m, flags, None), "gb_fps_pruned")
+            torch.cuda.synchronize()
+            assert torch.equal(idx.cpu(), want), (tie, skip, name, B, N, m)
+            assert torch.equal(temp.cpu(), temp_o), ("running min-distance state differs", name)

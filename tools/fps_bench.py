@@ -1,22 +1,29 @@
-import os, sys
+"""FPS 20000 -> 2048 on 4 clouds: gb_fps vs Morton keys + sort + gb_fps_pruned, timed separately."""
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from graspbalance_amd import _lib as L
+from graspbalance_amd import _lib
 from graspbalance_amd.scene import make_batch
-dev = "cuda:0"
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-xyz = torch.from_numpy(make_batch(range(B), 20000)).to(dev)
-lib = L.lib()
-def timeit(fn, iters=10, warm=2):
-    for _ in range(warm): fn()
-    torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+B, N, m = 4, 20000, 2048
+xyz = torch.from_numpy(make_batch(range(B), N)).cuda()
+idx = torch.zeros(B, m, dtype=torch.int32, device="cuda")
+keys = torch.empty(B, N, dtype=torch.int32, device="cuda")
+L = _lib.lib()
+def timeit(fn, n=10):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
     a.record()
-    for _ in range(iters): fn()
+    for _ in range(n): fn()
     b.record(); torch.cuda.synchronize()
-    return a.elapsed_time(b) / iters * 1e3
-for (n, m) in [(20000, 2048), (2048, 1024), (1024, 512), (512, 256)]:
-    x = xyz[:, :n].contiguous()
-    idx = torch.zeros(B, m, dtype=torch.int32, device=dev)
-    t = timeit(lambda: lib.gb_fps(L.ptr(x), None, L.ptr(idx), B, n, m, 0x11, None))
-    print("fps n=%d m=%d: %.1f us (%.3f us/iter)" % (n, m, t, t / (m - 1)))
+    return a.elapsed_time(b) / n * 1e3
+flags = _lib.FPS_SKIP_NEAR_ORIGIN | _lib.FPS_TIE_TREE512
+print("gb_fps                 %8.1f us" % timeit(lambda: L.gb_fps(_lib.ptr(xyz), None, _lib.ptr(idx), B, N, m, flags, None)))
+ref = idx.clone()
+print("morton keys            %8.1f us" % timeit(lambda: L.gb_fps_morton_keys(_lib.ptr(xyz), _lib.ptr(keys), B, N, None)))
+print("argsort + int32        %8.1f us" % timeit(lambda: torch.argsort(keys, dim=1).to(torch.int32)))
+perm = torch.argsort(keys, dim=1).to(torch.int32)
+print("gb_fps_pruned (morton) %8.1f us" % timeit(lambda: L.gb_fps_pruned(_lib.ptr(xyz), _lib.ptr(perm), None, _lib.ptr(idx), B, N, m, flags, None)))
+assert torch.equal(idx, ref)
+ident = torch.arange(N, device="cuda", dtype=torch.int32).repeat(B, 1).contiguous()
+print("gb_fps_pruned (ident.) %8.1f us" % timeit(lambda: L.gb_fps_pruned(_lib.ptr(xyz), _lib.ptr(ident), None, _lib.ptr(idx), B, N, m, flags, None)))
+assert torch.equal(idx, ref)

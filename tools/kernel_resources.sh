@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/kernel_resources.sh graspbalance_amd/csrc/<file>.hip  -> table of VGPR/AGPR/spill/occupancy per kernel
 f=$1
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -munsafe-fp-atomics -fno-fast-math \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -munsafe-fp-atomics -fno-fast-math $EXTRA \
   -I$(dirname $f) -c $f -o /tmp/kr.o -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c '
 import re,sys
 cur=None

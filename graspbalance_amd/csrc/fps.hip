@@ -149,34 +149,42 @@ __global__ __launch_bounds__(BLOCK) void fps_reg_kernel(const float *__restrict_
 // ------------------------------------------------------------------------------------------------
 // Pruned variant for large clouds.  The update temp[k] = min(temp[k], d(k, new sample)) changes nothing for a
 // point that is farther from the new sample than its current temp.  With the points visited in a spatially
-// coherent order (`perm`: Morton order, gb_fps_morton_keys + a sort), thread t owns P CONSECUTIVE sorted
-// points, keeps their bounding box in 6 VGPRs, and compares the box's distance to the new sample with the
-// largest temp it holds (its running arg-max value): if every lane of a wave passes that test the wave skips
-// the update — after a few dozen samples that is most waves (16 waves x 1280 sorted points each).
-// The result is the SAME sequence of samples as the full update, bit for bit: the bound is formed with the
-// same un-fused operations as the distances, and IEEE rounding is monotonic, so box-distance <= every
-// point's computed distance.  Tie keys follow the ORIGINAL indices (LDS table), so all three tie rules hold.
+// coherent order (`perm`: Morton order, gb_fps_morton_keys + a sort), the cloud is cut into "rows" of 64
+// CONSECUTIVE sorted points; row r lives in register slot r / W of wave r % W (one point per lane), so the
+// handful of adjacent rows a new sample touches fall into DIFFERENT waves and are processed in parallel.  Lane p
+// of a wave keeps the record of the wave's p-th row: bounding box, largest temp, tie key of the point holding
+// it.  Per iteration a wave forms, in lanes 0..P-1, the squared distance from the new sample to each of its
+// rows' boxes (same un-fused operations as a point distance: IEEE rounding is monotonic, so box distance <=
+// every point's computed distance) and updates only the rows where that bound is below the row's largest temp -
+// after a few dozen samples ~10 of the 320 rows.  An updated row re-derives its maximum and tie key with two
+// DPP wave reductions, and the block arg-max only looks at the row records.  The result is the SAME sample
+// sequence as the full update, bit for bit, for every tie rule (keys follow the ORIGINAL indices, LDS table).
 template <int BLOCK, int P>
 __global__ __launch_bounds__(BLOCK) void fps_pruned_kernel(const float *__restrict__ xyz,
                                                             const int32_t *__restrict__ perm,
                                                             float *__restrict__ temp_io,
                                                             int32_t *__restrict__ idx, int n, int m, int skip,
                                                             int bs_log2) {
+  static_assert(P <= 32, "row records live in lanes 0..P-1");
+  constexpr int W = BLOCK / 64;
   extern __shared__ unsigned s_tie[];  // [BLOCK * P] tie key of each sorted position
   __shared__ float s_d[32];
   __shared__ unsigned s_key[32];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float *pts = xyz + (size_t)blockIdx.x * n * 3;
   const int32_t *pm = perm + (size_t)blockIdx.x * n;
   int32_t *out = idx + (size_t)blockIdx.x * m;
   float *tio = temp_io ? temp_io + (size_t)blockIdx.x * n : nullptr;
 
   float px[P], py[P], pz[P], pt[P];
+  // row records, valid in lane p < P; other lanes: empty box, never a candidate
   float lox = INFINITY, loy = INFINITY, loz = INFINITY, hix = -INFINITY, hiy = -INFINITY, hiz = -INFINITY;
+  float rmax = -2.0f;
+  unsigned rkey = 0xFFFFFFFFu;
 #pragma unroll
   for (int p = 0; p < P; ++p) {
-    const int k = tid * P + p;
-    float x = 0.f, y = 0.f, z = 0.f, t = -INFINITY;  // -inf: never a candidate, never equal to a running best
+    const int k = (p * W + wave) * 64 + lane;
+    float x = 0.f, y = 0.f, z = 0.f, t = -INFINITY;  // -inf: never a candidate
     unsigned key = 0xFFFFFFFFu;
     if (k < n) {
       const int o = pm[k];
@@ -188,77 +196,60 @@ __global__ __launch_bounds__(BLOCK) void fps_pruned_kernel(const float *__restri
         const float mag = ((x * x) + (y * y)) + (z * z);
         if (mag < 1e-3f) t = -INFINITY;
       }
-      if (t >= 0.f) {
-        lox = fminf(lox, x); loy = fminf(loy, y); loz = fminf(loz, z);
-        hix = fmaxf(hix, x); hiy = fmaxf(hiy, y); hiz = fmaxf(hiz, z);
-      }
     }
     px[p] = x; py[p] = y; pz[p] = z; pt[p] = t;
     s_tie[k] = key;
+    const bool cand = t >= 0.f;
+    const float bhx = wave_max_f32(cand ? x : -INFINITY), blx = -wave_max_f32(cand ? -x : -INFINITY);
+    const float bhy = wave_max_f32(cand ? y : -INFINITY), bly = -wave_max_f32(cand ? -y : -INFINITY);
+    const float bhz = wave_max_f32(cand ? z : -INFINITY), blz = -wave_max_f32(cand ? -z : -INFINITY);
+    const bool any = __builtin_amdgcn_ballot_w64(cand) != 0ull;
+    if (lane == p) {
+      lox = blx; loy = bly; loz = blz; hix = bhx; hiy = bhy; hiz = bhz;
+      rmax = any ? 3.0e38f : -1.0f;  // > any squared distance: forces the row's first update
+      rkey = fps_key(0, bs_log2);
+    }
   }
   __syncthreads();
 
-  // > any squared distance: forces the first update; afterwards the largest temp I hold.  A thread without
-  // candidates (padding, all points skipped) never needs an update and never wins.
-  float best = lox <= hix ? 3.0e38f : -1.0f;
-  unsigned key = fps_key(0, bs_log2);
   int old = 0;
   if (tid == 0) out[0] = 0;
   for (int j = 1; j < m; ++j) {
     const float x1 = pts[old * 3 + 0], y1 = pts[old * 3 + 1], z1 = pts[old * 3 + 2];
-    // squared distance from the new sample to my box, in the same operation order as a point distance
-    const float bx = fmaxf(fmaxf(lox - x1, x1 - hix), 0.f);
-    const float by = fmaxf(fmaxf(loy - y1, y1 - hiy), 0.f);
-    const float bz = fmaxf(fmaxf(loz - z1, z1 - hiz), 0.f);
-    const float lb = ((bx * bx) + (by * by)) + (bz * bz);
-    if (__builtin_amdgcn_ballot_w64(lb < best) != 0ull) {  // wave-uniform
-      constexpr int NACC = P >= 4 ? 4 : 1;
-      float bq[NACC];
-      int bpq[NACC];
-      bool tie = false;
-#pragma unroll
-      for (int q = 0; q < NACC; ++q) { bq[q] = -1.0f; bpq[q] = q; }
+    const float ex = fmaxf(fmaxf(lox - x1, x1 - hix), 0.f);
+    const float ey = fmaxf(fmaxf(loy - y1, y1 - hiy), 0.f);
+    const float ez = fmaxf(fmaxf(loz - z1, z1 - hiz), 0.f);
+    const float lb = ((ex * ex) + (ey * ey)) + (ez * ez);
+    const unsigned long long need = __builtin_amdgcn_ballot_w64(lb < rmax);  // bit p: my p-th row must be updated
+    if (need != 0ull) {
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        const float dx = px[p] - x1, dy = py[p] - y1, dz = pz[p] - z1;
-        const float d = ((dx * dx) + (dy * dy)) + (dz * dz);
-        const float d2 = __builtin_fminf(d, pt[p]);
-        pt[p] = d2;
-        const bool gt = d2 > bq[p % NACC];
-        tie |= d2 == bq[p % NACC];
-        bq[p % NACC] = gt ? d2 : bq[p % NACC];
-        bpq[p % NACC] = gt ? p : bpq[p % NACC];
-      }
-      float b = bq[0];
-      int bp = bpq[0];
-#pragma unroll
-      for (int q = 1; q < NACC; ++q) {
-        tie |= bq[q] == b;
-        const bool take = bq[q] > b;
-        b = take ? bq[q] : b;
-        bp = take ? bpq[q] : bp;
-      }
-      unsigned kk = s_tie[tid * P + bp];
-      if (__builtin_amdgcn_ballot_w64(tie && b >= 0.f) != 0ull) {
-        // an equal value somewhere in my slab (duplicate points, exact distance ties): the winner among equals is
-        // the smallest tie key; rare, so resolved out of line
-        kk = 0xFFFFFFFFu;
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-          const unsigned kp = s_tie[tid * P + p];
-          if (pt[p] == b && kp < kk) kk = kp;
+        if (need & (1ull << p)) {  // wave-uniform
+          const unsigned kk = s_tie[(p * W + wave) * 64 + lane];
+          const float dx = px[p] - x1, dy = py[p] - y1, dz = pz[p] - z1;
+          const float d = ((dx * dx) + (dy * dy)) + (dz * dz);
+          const float d2 = __builtin_fminf(d, pt[p]);
+          pt[p] = d2;
+          const float mx = wave_max_f32(d2);
+          // the row's arg-max key: almost always a single lane holds the maximum -> read its key directly;
+          // exact ties (duplicate points, lattice data) take the min-key reduction
+          const unsigned long long eq = __builtin_amdgcn_ballot_w64(d2 == mx);
+          unsigned kmin;
+          if (__builtin_popcountll(eq) == 1)
+            kmin = (unsigned)__builtin_amdgcn_readlane((int)kk, __builtin_ctzll(eq));
+          else
+            kmin = wave_min_u32(d2 == mx ? kk : 0xFFFFFFFFu);
+          if (lane == p) { rmax = mx; rkey = kmin; }
         }
       }
-      best = b;
-      key = b < 0.f ? fps_key(0, bs_log2) : kk;
     }
-    old = block_argmax<BLOCK>(best, key, bs_log2, s_d, s_key, j & 1);
+    old = block_argmax<BLOCK>(rmax, rkey, bs_log2, s_d, s_key, j & 1);
     if (tid == 0) out[j] = old;
   }
   if (tio) {
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-      const int k = tid * P + p;
+      const int k = (p * W + wave) * 64 + lane;
       if (k < n && pt[p] >= 0.0f) tio[pm[k]] = pt[p];
     }
   }

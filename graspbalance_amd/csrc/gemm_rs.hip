@@ -40,6 +40,7 @@ struct RsArgs {
   int R, C, lda, ldd;
   int w_kc;             // 1: B[r][c] = w[c*R + r] (forward, W (C,R));  0: B[r][c] = w[r*C + c] (dgrad, W (R,C))
   int slots, nch;       // statistics slot rows ; chunks = ceil(R / 32)
+  int stagger;          // delay waves 4-7 by half a tile
 };
 
 template <int NT, int EPI>
@@ -109,6 +110,13 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD) ? 4 : 2)) voi
                                               : make_float4(0.f, 0.f, 0.f, 0.f);
   };
 
+  // The two waves that share a SIMD (w and w+4) run the same program from the same start and would reach their
+  // MFMA phases and their epilogues together; delaying the upper four by half a tile's worth of MFMA time lets one
+  // partner's epilogue (stores, statistics) run under the other's MFMAs (+2-4 % on the 1 M-row layers).
+  if (g.stagger && wave >= RS_WAVES / 2) {
+    int units = g.nch * NT * 8;  // half a tile = nch*16*NT MFMAs * 64 cycles / 2, in s_sleep units of 64 cycles
+    for (; units > 0; units -= 100) __builtin_amdgcn_s_sleep(100);
+  }
   if (tile < ntiles) {
     f32x16 acc[NT];
 #pragma unroll
@@ -298,7 +306,12 @@ bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, dou
   if (!rs_shape_ok(P, R, C, epi, aff != nullptr, &nt, &lds_bytes)) return false;
   if (reinterpret_cast<uintptr_t>(a) % 16 != 0 || (w_kc && reinterpret_cast<uintptr_t>(w) % 16 != 0)) return false;
   const int nch = (R + RS_CH - 1) / RS_CH;
-  RsArgs g = {a, w, d, aff, stats, epi_y, epi_ab, P, R, C, R, C, w_kc, slots < 1 ? 1 : slots, nch};
+  static int stagger = -1;
+  if (stagger < 0) {
+    const char *e = getenv("GB_RS_STAGGER");  // A/B switch
+    stagger = e ? atoi(e) : 1;
+  }
+  RsArgs g = {a, w, d, aff, stats, epi_y, epi_ab, P, R, C, R, C, w_kc, slots < 1 ? 1 : slots, nch, stagger};
   const int bpc = (nt <= 2 && epi != RS_BNBWD && lds_bytes <= 78 * 1024) ? 2 : 1;
 #define GB_RS(NT_)                                                         \
   do {                                                                     \

@@ -352,6 +352,23 @@ static void launch_gemm(const Operand &a, const Operand &b, bool va, bool vb, fl
   else launch_tile<KA, KB, EPI, 128, 128>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots, epi_y, epi_ab);
 }
 
+// Reduction split for forward / dgrad products with few output tiles and a long reduction (the C -> 4C -> C
+// pointwise pairs on a few thousand rows: 32-128 tiles of 64 steps each leave most CUs idle and each busy one
+// latency-bound).  Returns the number of reduction chunks (1 = no split) and the chunk length.
+static int split_reduction(long long rows, long long cols, long long red, long long *kchunk) {
+  const long long tiles = ((rows + 63) / 64) * ((cols + 127) / 128);
+  long long chunks = 1;
+  if ((red >= 1024 && tiles <= 160) || (red >= 512 && tiles <= 64)) {  // measured break-even (memset + column pass)
+    chunks = 320 / tiles;
+    if (chunks > red / 128) chunks = red / 128;
+    if (chunks < 1) chunks = 1;
+  }
+  long long kc = (red + chunks - 1) / chunks;
+  kc = (kc + GK - 1) / GK * GK;
+  *kchunk = kc;
+  return (int)((red + kc - 1) / kc);
+}
+
 }  // namespace gb
 
 using namespace gb;
@@ -369,7 +386,17 @@ extern "C" int gb_gemm_fwd(const float *x, const float *w, const float *aff, flo
   Operand a = {x, P, K, K, aff};
   Operand b = {w, N, K, K, nullptr};
   const bool v = (K % 4 == 0) && aligned16(x) && aligned16(w);
-  const long long kchunk = (K + GK - 1) / GK * GK;
+  long long kchunk = 0;
+  const int chunks = split_reduction(P, N, K, &kchunk);
+  if (chunks > 1) {
+    // split reduction: partial products accumulate into a zeroed Y with fp32 atomics; the BatchNorm sums then
+    // need the finished Y, i.e. a (small) column pass
+    if (hipMemsetAsync(y, 0, (size_t)P * N * sizeof(float), as_stream(stream)) != hipSuccess) return GB_ELAUNCH;
+    launch_gemm<OP_KC, OP_KC, EPI_ATOMIC>(a, b, v, v, y, N, nullptr, kchunk, (unsigned)chunks, as_stream(stream));
+    const int rc = check_launch("gb_gemm_fwd");
+    if (rc != GB_OK || !stats) return rc;
+    return gb_col_stats(y, P, N, stats, stream);
+  }
   if (stats) launch_gemm<OP_KC, OP_KC, EPI_STORE_STATS>(a, b, v, v, y, N, stats, kchunk, 1, as_stream(stream), stat_slots);
   else launch_gemm<OP_KC, OP_KC, EPI_STORE>(a, b, v, v, y, N, stats, kchunk, 1, as_stream(stream));
   return check_launch("gb_gemm_fwd");
@@ -393,7 +420,15 @@ extern "C" int gb_gemm_dgrad(const float *dy, const float *w, float *dx, const f
   Operand b = {w, K, N, K, nullptr};  // tile rows = k, reduction = n, element (k,n) at w[n*K + k]
   const bool va = (N % 4 == 0) && aligned16(dy);
   const bool vb = (K % 4 == 0) && aligned16(w);
-  const long long kchunk = (N + GK - 1) / GK * GK;
+  long long kchunk = 0;
+  const int chunks = split_reduction(P, K, N, &kchunk);
+  if (chunks > 1) {
+    if (hipMemsetAsync(dx, 0, (size_t)P * K * sizeof(float), as_stream(stream)) != hipSuccess) return GB_ELAUNCH;
+    launch_gemm<OP_KC, OP_RC, EPI_ATOMIC>(a, b, va, vb, dx, K, nullptr, kchunk, (unsigned)chunks, as_stream(stream));
+    const int rc = check_launch("gb_gemm_dgrad");
+    if (rc != GB_OK || !dstats) return rc;
+    return gb_bn_bwd_stats(dx, y_prev, ab_prev, nullptr, P, K, 1, dstats, stream);
+  }
   if (dstats)
     launch_gemm<OP_KC, OP_RC, EPI_STORE_BNBWD>(a, b, va, vb, dx, K, dstats, kchunk, 1, as_stream(stream), stat_slots,
                                                y_prev, ab_prev);

@@ -19,6 +19,10 @@ SHAPES = [("sa1.l0", 524288, 3, 64), ("sa1.l1", 524288, 64, 64), ("sa1.l2", 5242
           ("inv1.pw0", 8192, 128, 512), ("inv1.pw1", 8192, 512, 128), ("sa2.l0", 131072, 131, 128), ("sa2.l2", 131072, 128, 256),
           ("inv2.agg", 131072, 259, 256), ("inv2.pw0", 4096, 256, 1024), ("wg.l0", 1048576, 3, 64), ("wg.l1", 1048576, 64, 128),
           ("wg.l2", 1048576, 128, 256)]
+if os.environ.get("SMALL"):
+    SHAPES = [("inv2.pw0", 4096, 256, 1024), ("inv2.pw1", 4096, 1024, 256), ("inv3.pw0", 2048, 256, 1024),
+              ("inv3.pw1", 2048, 1024, 256), ("inv4.pw0", 1024, 256, 1024), ("inv4.pw1", 1024, 1024, 256),
+              ("inv1.pw0", 8192, 128, 512), ("inv1.pw1", 8192, 512, 128), ("la2.G", 4096, 256, 256), ("la1.G", 8192, 128, 128)]
 lib = L.lib()
 tot = {"own": 0.0, "blas": 0.0}
 for name, P, K, N in SHAPES:

@@ -1,6 +1,6 @@
 """Steady-state per-step kernel breakdown from a rocprofv3 kernel_trace.csv of bench.py.
 
-The first-level FPS kernel (fps_reg_kernel<1024, 20>) is launched exactly once per train step, so
+The first-level FPS kernel (fps_pruned_kernel<1024, 20> / fps_reg_kernel<1024, 20>) is launched exactly once per train step, so
 its launches mark step boundaries; only the last `nsteps` whole steps are summarised (drops the
 one-time MIOpen find / lazy-init kernels of the first steps).
 """
@@ -15,7 +15,8 @@ from prof_summary import category, short
 def main(path, nsteps=3, top=30):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    marks = [i for i, r in enumerate(rows) if "fps_reg_kernel<1024, 20>" in r["Kernel_Name"]]
+    marks = [i for i, r in enumerate(rows) if "fps_reg_kernel<1024, 20>" in r["Kernel_Name"]
+             or "fps_pruned_kernel<1024, 20>" in r["Kernel_Name"]]
     if len(marks) < nsteps + 1:
         raise SystemExit("not enough steps in trace (%d markers)" % len(marks))
     lo, hi = marks[-nsteps - 1], marks[-1]

@@ -63,6 +63,8 @@ SIGNATURES = {
     "gb_gemm_dgrad": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P],
     "gb_gemm_wgrad": [_P, _P, _P, _P, _L, _I, _I, _P],
     "gb_gemm_uses_rs": [_L, _I, _I, _I, _I, _I],
+    "gb_gemm_dgrad_first": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P],
+    "gb_moments3": [_P, _L, _P, _P],
 }
 
 

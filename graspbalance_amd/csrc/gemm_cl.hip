@@ -469,3 +469,60 @@ extern "C" int gb_gemm_wgrad(const float *dy, const float *x, const float *x_aff
   launch_gemm<OP_RC, OP_RC, EPI_ATOMIC>(a, b, va, vb, dw, K, nullptr, kchunk, (unsigned)chunks, as_stream(stream));
   return check_launch("gb_gemm_wgrad");
 }
+
+// dgrad into the FIRST layer of a stack whose input x has 3 channels (xyz-only grouped rows): dZ = dY W is formed
+// tile by tile but never stored - all that is needed downstream are five column sums,
+//   sums[slot][0:K] += g, [K:2K] += g*xhat, [2K+jK : ...] += g*x_j (j < 3),   g = dZ*[a*y+b > 0], xhat = (y-mean)*rstd,
+// from which the layer's BatchNorm gradients and its weight gradient follow in closed form (gb_la_wx_grad with
+// u = 0 and the 12 moments of x).  Saves the dZ write, the bn_bwd_apply pass and the K=3 wgrad.
+// Only the row-streaming kernel implements it: GB_EINVAL when the shape is not eligible (gb_gemm_uses_rs(.., 2, 0)).
+extern "C" int gb_gemm_dgrad_first(const float *dy, const float *w, const float *y_prev, const float *ab_prev,
+                                   const float *x_in, double *sums, int slots, long long P, int K, int N, void *stream) {
+  if (P < 0 || K < 1 || N < 1 || !dy || !w || !y_prev || !ab_prev || !x_in || !sums || slots < 1) return GB_EINVAL;
+  if (P == 0) return GB_OK;
+  if (!rs_gemm_try(dy, w, nullptr, nullptr, sums, slots, y_prev, ab_prev, P, N, K, 0, RS_BNBWD_X, as_stream(stream),
+                   x_in))
+    return GB_EINVAL;
+  return check_launch("gb_gemm_dgrad_first");
+}
+
+// mom fp64 [12] += [sum_p x (3), sum_p x x^T (3x3)] of x (P,3); caller-zeroed
+namespace gb {
+__global__ __launch_bounds__(GTPB) void moments3_kernel(const float *__restrict__ x, long long P, double *__restrict__ mom) {
+  float s[3] = {0.f, 0.f, 0.f}, mm[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const long long p = ((long long)blockIdx.x * 8 + u) * GTPB + threadIdx.x;
+    if (p < P) {
+      const float d[3] = {x[p * 3], x[p * 3 + 1], x[p * 3 + 2]};
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        s[t] += d[t];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) mm[3 * t + q] += d[t] * d[q];
+      }
+    }
+  }
+  double v[12];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) v[i] = (double)s[i];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) v[3 + i] = (double)mm[i];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v[i] += __shfl_xor(v[i], off);
+  }
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) atomicAdd(mom + i, v[i]);
+}
+}  // namespace gb
+
+extern "C" int gb_moments3(const float *x, long long P, double *mom, void *stream) {
+  if (P < 0 || !x || !mom) return GB_EINVAL;
+  if (P == 0) return GB_OK;
+  hipLaunchKernelGGL(moments3_kernel, dim3((unsigned)((P + 8 * GTPB - 1) / (8 * GTPB))), dim3(GTPB), 0, as_stream(stream), x,
+                     P, mom);
+  return check_launch("gb_moments3");
+}

@@ -6,13 +6,14 @@ namespace gb {
 
 enum { RS_STORE = 0,   // D only
        RS_STATS = 1,   // + column sums of D and D^2                       (BatchNorm batch statistics)
-       RS_BNBWD = 2 }; // + column sums of g and g*xhat, g = D*[a*y+b > 0]  (BatchNorm-backward sums)
+       RS_BNBWD = 2,   // + column sums of g and g*xhat, g = D*[a*y+b > 0]  (BatchNorm-backward sums)
+       RS_BNBWD_X = 3 }; // those two + sum g*x_j (j < 3) for the layer's 3-channel input x; D is NOT stored
 
 // D (P,C) = f(A (P,R)) B (R,C);  w_kc = 1: B[r][c] = w[c*R + r], 0: B[r][c] = w[r*C + c].
 // Returns false (nothing launched) when the shape does not suit the kernel; the caller then uses the
 // LDS-tiled kernel.
 bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, double *stats, int slots,
                  const float *epi_y, const float *epi_ab, long long P, int R, int C, int w_kc, int epi,
-                 hipStream_t s);
+                 hipStream_t s, const float *epi_x = nullptr);
 
 }  // namespace gb

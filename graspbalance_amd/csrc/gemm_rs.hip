@@ -36,6 +36,7 @@ struct RsArgs {
   double *stats;        // fp64 [slots][2C]
   const float *epi_y;   // RS_BNBWD: (P,C) pitch ldd, pre-BatchNorm output of the layer D is the gradient of
   const float *epi_ab;  // RS_BNBWD: [a, b, mean, rstd](C)
+  const float *epi_x;   // RS_BNBWD_X: (P,3) the 3-channel input of the layer D is the gradient of
   long long P;
   int R, C, lda, ldd;
   int w_kc;             // 1: B[r][c] = w[c*R + r] (forward, W (C,R));  0: B[r][c] = w[r*C + c] (dgrad, W (R,C))
@@ -44,7 +45,7 @@ struct RsArgs {
 };
 
 template <int NT, int EPI>
-__global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD) ? 4 : 2)) void gemm_rs_kernel(RsArgs g) {
+__global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_BNBWD_X) ? 4 : 2)) void gemm_rs_kernel(RsArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int C32 = NT * 32;
   const int rpad = g.nch * RS_CH;
@@ -82,13 +83,17 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD) ? 4 : 2)) voi
   const long long nw = (long long)gridDim.x * RS_WAVES;
   long long tile = (long long)blockIdx.x * RS_WAVES + wave;
 
-  double dsum[NT], dsq[NT];
+  constexpr bool BNB = EPI == RS_BNBWD || EPI == RS_BNBWD_X;
+  constexpr int NS = EPI == RS_BNBWD_X ? 5 : 2;  // column sums per column: [g, g*xhat (, g*x0, g*x1, g*x2)] / [y, y^2]
+  double dsum[NT], dsq[NT], dtx[EPI == RS_BNBWD_X ? NT : 1][3];
 #pragma unroll
   for (int j = 0; j < NT; ++j) { dsum[j] = 0.0; dsq[j] = 0.0; }
+#pragma unroll
+  for (int j = 0; j < (EPI == RS_BNBWD_X ? NT : 1); ++j) { dtx[j][0] = 0.0; dtx[j][1] = 0.0; dtx[j][2] = 0.0; }
   // BatchNorm coefficients of this lane's columns: resident in registers unless the accumulators need them
   constexpr bool COEF_REGS = NT <= 5;
   float ea[NT], eb[NT], em[NT], er[NT];
-  if constexpr (EPI == RS_BNBWD && COEF_REGS) {
+  if constexpr (BNB && COEF_REGS) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int col = j * 32 + m;
@@ -146,8 +151,19 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD) ? 4 : 2)) voi
       }
       // RS_BNBWD: the y values the epilogue needs are requested BEFORE the tile's last MFMA block, so their
       // latency hides behind it (registers permitting; otherwise per column tile inside the epilogue)
-      constexpr bool YPRE = EPI == RS_BNBWD && NT <= 4;
+      constexpr bool YPRE = BNB && NT <= 4;
       float yv[YPRE ? NT : 1][16];
+      float xr[EPI == RS_BNBWD_X ? 16 : 1][3];  // RS_BNBWD_X: the 3-channel input rows of this tile, same early request
+      if constexpr (EPI == RS_BNBWD_X) {
+        if (kc == g.nch - 1) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const long long row = tile * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) xr[r][j] = row < g.P ? g.epi_x[row * 3 + j] : 0.f;
+          }
+        }
+      }
       if constexpr (YPRE) {
         if (kc == g.nch - 1) {
 #pragma unroll
@@ -177,15 +193,15 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD) ? 4 : 2)) voi
         for (int q = 0; q < NT; ++q) {
           const int col = q * 32 + m;
           const bool colok = col < g.C;
-          float cs = 0.f, cq = 0.f;
-          if constexpr (EPI == RS_BNBWD && !COEF_REGS) {
+          float cs = 0.f, cq = 0.f, ct[3] = {0.f, 0.f, 0.f};
+          if constexpr (BNB && !COEF_REGS) {
             ea[q] = colok ? g.epi_ab[col] : 0.f;
             eb[q] = colok ? g.epi_ab[g.C + col] : 0.f;
             em[q] = colok ? g.epi_ab[2 * g.C + col] : 0.f;
             er[q] = colok ? g.epi_ab[3 * g.C + col] : 0.f;
           }
           float yq[16];
-          if constexpr (EPI == RS_BNBWD && !YPRE) {
+          if constexpr (BNB && !YPRE) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const long long row = row0 + (r & 3) + 8 * (r >> 2);
@@ -197,18 +213,26 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD) ? 4 : 2)) voi
             const long long row = row0 + (r & 3) + 8 * (r >> 2);
             const float v = acc[q][r];
             if (colok && row < g.P) {
-              g.d[row * g.ldd + col] = v;
+              if constexpr (EPI != RS_BNBWD_X) g.d[row * g.ldd + col] = v;  // _X: D itself is not needed
               if constexpr (EPI == RS_STATS) { cs += v; cq += v * v; }
-              if constexpr (EPI == RS_BNBWD) {
+              if constexpr (BNB) {
                 const float y = YPRE ? yv[YPRE ? q : 0][r] : yq[r];
                 const float gg = (ea[q] * y + eb[q]) > 0.f ? v : 0.f;
                 cs += gg;
                 cq += gg * ((y - em[q]) * er[q]);
+                if constexpr (EPI == RS_BNBWD_X) {
+#pragma unroll
+                  for (int j = 0; j < 3; ++j) ct[j] += gg * xr[r][j];
+                }
               }
             }
             acc[q][r] = 0.f;
           }
           if constexpr (EPI != RS_STORE) { dsum[q] += (double)cs; dsq[q] += (double)cq; }
+          if constexpr (EPI == RS_BNBWD_X) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) dtx[q][j] += (double)ct[j];
+          }
         }
       }
       if (!more) break;
@@ -222,25 +246,28 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD) ? 4 : 2)) voi
   if constexpr (EPI != RS_STORE) {
     // per-column totals: lanes l / l+32 share a column, then the 8 waves through LDS (B is dead now)
     __syncthreads();
-    double *sd = reinterpret_cast<double *>(lds);  // [wave][2][C32]
+    double *sd = reinterpret_cast<double *>(lds);  // [wave][NS][C32]
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
-      const double s1 = dsum[q] + __shfl_xor(dsum[q], 32);
-      const double s2 = dsq[q] + __shfl_xor(dsq[q], 32);
-      if (h == 0) {
-        sd[(wave * 2 + 0) * C32 + q * 32 + m] = s1;
-        sd[(wave * 2 + 1) * C32 + q * 32 + m] = s2;
+      double v[NS];
+      v[0] = dsum[q];
+      v[1] = dsq[q];
+      if constexpr (EPI == RS_BNBWD_X) { v[2] = dtx[q][0]; v[3] = dtx[q][1]; v[4] = dtx[q][2]; }
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        const double t2 = v[i] + __shfl_xor(v[i], 32);
+        if (h == 0) sd[(wave * NS + i) * C32 + q * 32 + m] = t2;
       }
     }
     __syncthreads();
-    double *st = g.stats + (size_t)(blockIdx.x % g.slots) * 2 * g.C;
-    for (int i = t; i < 2 * C32; i += RS_TPB) {
+    double *st = g.stats + (size_t)(blockIdx.x % g.slots) * NS * g.C;
+    for (int i = t; i < NS * C32; i += RS_TPB) {
       const int which = i / C32, col = i % C32;
       if (col < g.C) {
-        double s = 0.0;
+        double sum = 0.0;
 #pragma unroll
-        for (int w = 0; w < RS_WAVES; ++w) s += sd[(w * 2 + which) * C32 + col];
-        atomicAdd(st + which * g.C + col, s);
+        for (int w = 0; w < RS_WAVES; ++w) sum += sd[(w * NS + which) * C32 + col];
+        atomicAdd(st + which * g.C + col, sum);
       }
     }
   }
@@ -289,6 +316,7 @@ static bool rs_shape_ok(long long P, int R, int C, int epi, bool has_aff, int *n
   const int nt = tiles_c <= 2 ? 2 : tiles_c <= 4 ? 4 : tiles_c == 5 ? 5 : tiles_c <= 8 ? 8 : 0;
   if (!nt) return false;
   if (epi == RS_BNBWD && nt == 8) return false;  // accumulators + y prefetch do not fit the register file
+  if (epi == RS_BNBWD_X && nt > 2) return false;  // 64-wide first layers only (registers)
   // MFMA work wasted on padding must stay small
   if ((long long)nch * RS_CH * nt * 32 * 4 > (long long)R * C * 5) return false;
   const size_t lds_bytes = ((size_t)nch * RS_CH * nt * 32 + (has_aff ? 2 * nch * RS_CH : 0)) * sizeof(float);
@@ -300,7 +328,7 @@ static bool rs_shape_ok(long long P, int R, int C, int epi, bool has_aff, int *n
 
 bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, double *stats, int slots,
                  const float *epi_y, const float *epi_ab, long long P, int R, int C, int w_kc, int epi,
-                 hipStream_t s) {
+                 hipStream_t s, const float *epi_x) {
   int nt = 0;
   size_t lds_bytes = 0;
   if (!rs_shape_ok(P, R, C, epi, aff != nullptr, &nt, &lds_bytes)) return false;
@@ -311,8 +339,12 @@ bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, dou
     const char *e = getenv("GB_RS_STAGGER");  // A/B switch
     stagger = e ? atoi(e) : 1;
   }
-  RsArgs g = {a, w, d, aff, stats, epi_y, epi_ab, P, R, C, R, C, w_kc, slots < 1 ? 1 : slots, nch, stagger};
-  const int bpc = (nt <= 2 && epi != RS_BNBWD && lds_bytes <= 78 * 1024) ? 2 : 1;
+  RsArgs g = {a, w, d, aff, stats, epi_y, epi_ab, epi_x, P, R, C, R, C, w_kc, slots < 1 ? 1 : slots, nch, stagger};
+  const int bpc = (nt <= 2 && epi != RS_BNBWD && epi != RS_BNBWD_X && lds_bytes <= 78 * 1024) ? 2 : 1;
+  if (epi == RS_BNBWD_X) {
+    rs_launch<2, RS_BNBWD_X>(g, lds_bytes, bpc, s);
+    return true;
+  }
 #define GB_RS(NT_)                                                         \
   do {                                                                     \
     if (epi == RS_STATS) rs_launch<NT_, RS_STATS>(g, lds_bytes, bpc, s);   \
@@ -333,6 +365,7 @@ bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, dou
 // 1 = gemm_rs_kernel, 0 = gemm_cl_kernel.  Introspection for bench.py's per-kernel roofline accounting.
 extern "C" int gb_gemm_uses_rs(long long P, int K, int N, int dgrad, int fused_stats, int has_aff) {
   const int R = dgrad ? N : K, C = dgrad ? K : N;
-  const int epi = fused_stats ? (dgrad ? gb::RS_BNBWD : gb::RS_STATS) : gb::RS_STORE;
+  // fused_stats = 2 (dgrad only): the first-layer form gb_gemm_dgrad_first
+  const int epi = fused_stats ? (dgrad ? (fused_stats == 2 ? gb::RS_BNBWD_X : gb::RS_BNBWD) : gb::RS_STATS) : gb::RS_STORE;
   return gb::rs_shape_ok(P, R, C, epi, has_aff != 0, nullptr, nullptr) ? 1 : 0;
 }

@@ -25,6 +25,7 @@ _DGRAD_BN_MAX = int(os.environ.get("GB_DGRAD_BN_MAX", 1 << 40))  # rows*cols abo
 _OWN_GEMM = True  # hand-written MFMA GEMMs (csrc/gemm_cl.hip); False = torch.mm (rocBLAS) for A/B timing
 
 
+_FIRST_FUSE = os.environ.get("GB_FIRST_FUSE", "1") != "0"  # A/B switch: closed-form backward of xyz-only first layers
 _LOCAL_AGG = os.environ.get("GB_LOCAL_AGG", "1") != "0"  # A/B switch: 0 = grouped tensor + GEMM for LocalAggregation
 
 
@@ -362,6 +363,23 @@ class MLPStack(Function):
                     dX0 = torch.empty((P, K), dtype=torch.float32, device=dev)
                     _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dX0), None, None, None, 0, P, K, N,
                           _s(dout), meta=_gemm_meta("dgrad", P, K, N))
+                break
+            if (l == 1 and _FIRST_FUSE and X0.shape[1] == 3 and not ctx.needs_input_grad[0] and need_w[0]
+                    and _lib.lib().gb_gemm_uses_rs(P, K, N, 1, 2, 0)):
+                # xyz-only first layer: its dZ is never written - five column sums out of the dgrad epilogue give its
+                # BatchNorm gradients and, with the 12 moments of the input rows, its weight gradient in closed form
+                z = torch.zeros(slots * 5 * K + 3 * K + 12, dtype=torch.float64, device=dev)
+                sums, u0, mom = z[:slots * 5 * K], z[slots * 5 * K:slots * 5 * K + 3 * K], z[slots * 5 * K + 3 * K:]
+                _call("gb_gemm_dgrad_first", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(Ys[0]), _lib.ptr(abs_[0]),
+                      _lib.ptr(X0), _lib.ptr(sums), slots, P, K, N, _s(dout),
+                      meta={"flop": 2.0 * P * K * N, "pkn": (P, K, N), "kernel": "gemm_rs_kernel"})
+                _call("gb_moments3", dev, _lib.ptr(X0), P, _lib.ptr(mom), _s(dout))
+                red = sums.view(slots, 5 * K).sum(0) if slots > 1 else sums
+                grads[1], grads[2] = param_grads(0, red, 1, None)
+                dW0 = torch.empty((K, 3), dtype=torch.float32, device=dev)
+                _call("gb_la_wx_grad", dev, _lib.ptr(red), _lib.ptr(u0), _lib.ptr(mom), _lib.ptr(Ws[0]), _lib.ptr(abs_[0]),
+                      P, K, int(training[0]), _lib.ptr(dW0), _s(dout))
+                grads[0] = dW0
                 break
             # gradient of layer l-1's post-ReLU output + that layer's BatchNorm-backward sums in one launch
             dZ = torch.empty((P, K), dtype=torch.float32, device=dev)

@@ -267,6 +267,16 @@ int gb_gemm_wgrad(const float *dy, const float *x, const float *x_aff, float *dw
  * this shape: 1 = the row-streaming kernel (csrc/gemm_rs.hip), 0 = the LDS-tiled one (csrc/gemm_cl.hip).
  * Pure host-side introspection (no launch), used by bench.py to attribute timings per kernel.      */
 int gb_gemm_uses_rs(long long P, int K, int N, int dgrad, int fused_stats, int has_aff);
+/* dgrad into the first layer of a stack whose input x_in (P,3) has 3 channels: dZ = dY (P,N) W (N,K) is formed
+ * but not stored; sums fp64 [slots][5K] (caller-zeroed) += column sums of [g, g*xhat, g*x_0, g*x_1, g*x_2] with
+ * g = dZ*[a*y+b > 0], xhat = (y - mean)*rstd, y = y_prev (P,K) the layer's pre-BatchNorm output, ab_prev =
+ * [a,b,mean,rstd](K).  The layer's dgamma/dbeta are the first two sums; its weight gradient follows from the sums
+ * and the moments of x_in (gb_moments3) by gb_la_wx_grad with u = 0.  GB_EINVAL when the shape is not eligible:
+ * ask gb_gemm_uses_rs(P, K, N, 1, 2, 0) first.                                                          */
+int gb_gemm_dgrad_first(const float *dy, const float *w, const float *y_prev, const float *ab_prev, const float *x_in,
+                        double *sums, int slots, long long P, int K, int N, void *stream);
+/* mom fp64 [12] (caller-zeroed) += [sum_p x (3), sum_p x x^T (3x3)] of x (P,3).                          */
+int gb_moments3(const float *x, long long P, double *mom, void *stream);
 
 #ifdef __cplusplus
 }

@@ -269,3 +269,40 @@ def test_local_aggregation_without_grouped_tensor(C, ns, train):
         _close(a[2][k], b[2][k], 2e-4, "grad " + k, True, 1e-2 * max(float(v.norm()) for v in b[2].values()))
     for k in b[3]:
         _close(a[3][k], b[3][k], 1e-5, "buffer " + k)
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_first_layer_closed_form_backward(train):
+    """xyz-only stacks (3 -> 64 -> 128 [-> max]): the backward that never writes the first layer's dZ
+    (gb_gemm_dgrad_first + moments + closed-form dW) against the layer-by-layer backward."""
+    import torch.nn as nn
+    from graspbalance_amd import fused_mlp
+    torch.manual_seed(3)
+    P, ns = 32768 + 64, 64
+    convs = [nn.Conv2d(3, 64, 1, bias=False), nn.Conv2d(64, 128, 1, bias=False)]
+    bns = [nn.BatchNorm2d(64), nn.BatchNorm2d(128)]
+    mods = nn.ModuleList(convs + bns).to(DEV)
+    with torch.no_grad():
+        for bn in bns:
+            bn.weight.uniform_(-1.0, 1.5)
+            bn.bias.normal_(0, 0.3)
+            bn.running_mean.normal_(0, 0.1)
+            bn.running_var.uniform_(0.5, 1.5)
+    mods.train(train)
+    X0 = (torch.randn(P, 3, device=DEV) * torch.tensor([0.05, 0.02, 0.03], device=DEV) + 0.01).contiguous()
+    res = {}
+    for flag in (True, False):
+        fused_mlp._FIRST_FUSE = flag
+        try:
+            m = copy.deepcopy(mods)
+            out = fused_mlp.conv_bn_act_chain(X0, [(m[0], m[2]), (m[1], m[3])], pool_ns=ns)
+            torch.manual_seed(8)
+            (out * torch.randn_like(out)).sum().backward()
+            res[flag] = (out.detach(), {k: v.grad.clone() for k, v in m.named_parameters()})
+        finally:
+            fused_mlp._FIRST_FUSE = True
+    a, b = res[True], res[False]
+    assert torch.equal(a[0], b[0])
+    floor = 1e-2 * max(float(v.norm()) for v in b[1].values())
+    for k in b[1]:
+        _close(a[1][k], b[1][k], 2e-4, "grad " + k, True, floor)

@@ -489,25 +489,32 @@ extern "C" int gb_gemm_dgrad_first(const float *dy, const float *w, const float 
 // mom fp64 [12] += [sum_p x (3), sum_p x x^T (3x3)] of x (P,3); caller-zeroed
 namespace gb {
 __global__ __launch_bounds__(GTPB) void moments3_kernel(const float *__restrict__ x, long long P, double *__restrict__ mom) {
-  float s[3] = {0.f, 0.f, 0.f}, mm[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const long long p = ((long long)blockIdx.x * 8 + u) * GTPB + threadIdx.x;
-    if (p < P) {
-      const float d[3] = {x[p * 3], x[p * 3 + 1], x[p * 3 + 2]};
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        s[t] += d[t];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) mm[3 * t + q] += d[t] * d[q];
-      }
-    }
-  }
+  // few workgroups, each striding over the rows: the 12 results are same-address fp64 atomics, which serialise
+  // (one per wave of a 512-block grid cost 190 us; one per workgroup of a 64-block grid is free)
+  __shared__ double part[GTPB / 64][12];
   double v[12];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) v[i] = (double)s[i];
+  for (int i = 0; i < 12; ++i) v[i] = 0.0;
+  for (long long p0 = (long long)blockIdx.x * GTPB * 8; p0 < P; p0 += (long long)gridDim.x * GTPB * 8) {
+    float s[3] = {0.f, 0.f, 0.f}, mm[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < 9; ++i) v[3 + i] = (double)mm[i];
+    for (int u = 0; u < 8; ++u) {
+      const long long p = p0 + (long long)u * GTPB + threadIdx.x;
+      if (p < P) {
+        const float d[3] = {x[p * 3], x[p * 3 + 1], x[p * 3 + 2]};
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          s[t] += d[t];
+#pragma unroll
+          for (int q = 0; q < 3; ++q) mm[3 * t + q] += d[t] * d[q];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) v[i] += (double)s[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) v[3 + i] += (double)mm[i];
+  }
 #pragma unroll
   for (int i = 0; i < 12; ++i) {
 #pragma unroll
@@ -515,14 +522,21 @@ __global__ __launch_bounds__(GTPB) void moments3_kernel(const float *__restrict_
   }
   if ((threadIdx.x & 63) == 0)
 #pragma unroll
-    for (int i = 0; i < 12; ++i) atomicAdd(mom + i, v[i]);
+    for (int i = 0; i < 12; ++i) part[threadIdx.x >> 6][i] = v[i];
+  __syncthreads();
+  if (threadIdx.x < 12) {
+    double t = 0.0;
+    for (int w = 0; w < GTPB / 64; ++w) t += part[w][threadIdx.x];
+    atomicAdd(mom + threadIdx.x, t);
+  }
 }
 }  // namespace gb
 
 extern "C" int gb_moments3(const float *x, long long P, double *mom, void *stream) {
   if (P < 0 || !x || !mom) return GB_EINVAL;
   if (P == 0) return GB_OK;
-  hipLaunchKernelGGL(moments3_kernel, dim3((unsigned)((P + 8 * GTPB - 1) / (8 * GTPB))), dim3(GTPB), 0, as_stream(stream), x,
-                     P, mom);
+  long long blocks = (P + 8 * GTPB - 1) / (8 * GTPB);
+  if (blocks > 128) blocks = 128;
+  hipLaunchKernelGGL(moments3_kernel, dim3((unsigned)blocks), dim3(GTPB), 0, as_stream(stream), x, P, mom);
   return check_launch("gb_moments3");
 }

@@ -60,6 +60,8 @@ __global__ __launch_bounds__(LA_TPB) void la_point_stats_kernel(const float *__r
       }
     }
   }
+  // the 12 moments are same-address fp64 atomics (they serialise): combine the workgroup's waves in LDS first
+  __shared__ double part[LA_TPB / 64][12];
   double v[12];
 #pragma unroll
   for (int i = 0; i < 3; ++i) v[i] = (double)s[i];
@@ -72,7 +74,13 @@ __global__ __launch_bounds__(LA_TPB) void la_point_stats_kernel(const float *__r
   }
   if ((threadIdx.x & 63) == 0)
 #pragma unroll
-    for (int i = 0; i < 12; ++i) atomicAdd(mom + i, v[i]);
+    for (int i = 0; i < 12; ++i) part[threadIdx.x >> 6][i] = v[i];
+  __syncthreads();
+  if (threadIdx.x < 12) {
+    double t = 0.0;
+    for (int w = 0; w < LA_TPB / 64; ++w) t += part[w][threadIdx.x];
+    atomicAdd(mom + threadIdx.x, t);
+  }
 }
 
 // column sums over the B*n points:  stats = [sum_p y, sum_p y^2](C),  u = [U_0, U_1, U_2](C)

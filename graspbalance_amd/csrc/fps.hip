@@ -70,17 +70,13 @@ __device__ __forceinline__ int block_argmax(float d, unsigned key, int bs_log2, 
   return wmax < 0.0f ? 0 : fps_unkey(wkey, bs_log2);
 }
 
-// LDSXYZ: the cloud's coordinates are also kept in LDS (n <= 4096 points = 48 KB) so the new sample's xyz comes from
-// a broadcast ds_read (~100 cycles) instead of a scalar load from L2 (~500): the small levels are bound by exactly
-// that serial chain.
-template <int BLOCK, int P, bool LDSXYZ>
+template <int BLOCK, int P>
 __global__ __launch_bounds__(BLOCK) void fps_reg_kernel(const float *__restrict__ xyz,
                                                          float *__restrict__ temp_io,
                                                          int32_t *__restrict__ idx, int n, int m,
                                                          int skip, int bs_log2) {
   __shared__ float s_d[32];
   __shared__ unsigned s_key[32];
-  __shared__ float s_xyz[LDSXYZ ? 4096 * 3 : 1];
   const int tid = threadIdx.x;
   const float *pts = xyz + (size_t)blockIdx.x * n * 3;
   int32_t *out = idx + (size_t)blockIdx.x * m;
@@ -101,11 +97,7 @@ __global__ __launch_bounds__(BLOCK) void fps_reg_kernel(const float *__restrict_
       }
     }
     px[p] = x; py[p] = y; pz[p] = z; pt[p] = t;
-    if constexpr (LDSXYZ) {
-      if (k < n) { s_xyz[k * 3] = x; s_xyz[k * 3 + 1] = y; s_xyz[k * 3 + 2] = z; }
-    }
   }
-  if constexpr (LDSXYZ) __syncthreads();
   // my tie key for p = 0; p only adds to the low (k div BS) field / to k itself
   const unsigned key0 = fps_key(tid, bs_log2);
   const unsigned keystep = bs_log2 < 0 ? (unsigned)BLOCK : ((unsigned)BLOCK >> bs_log2);
@@ -113,9 +105,8 @@ __global__ __launch_bounds__(BLOCK) void fps_reg_kernel(const float *__restrict_
   int old = 0;
   if (tid == 0) out[0] = 0;
   for (int j = 1; j < m; ++j) {
-    // wave-uniform address -> scalar loads (or broadcast LDS reads)
-    const float *src = LDSXYZ ? s_xyz : pts;
-    const float x1 = src[old * 3 + 0], y1 = src[old * 3 + 1], z1 = src[old * 3 + 2];
+    // wave-uniform address -> scalar loads
+    const float x1 = pts[old * 3 + 0], y1 = pts[old * 3 + 1], z1 = pts[old * 3 + 2];
     // NACC independent (best, argbest) chains over p mod NACC: the compare/select recurrence of a
     // single chain is 3 dependent VALU ops per point, which 4 waves per SIMD cannot fully hide
     constexpr int NACC = P >= 4 ? 4 : 1;
@@ -356,12 +347,8 @@ static int floor_log2(int v) {
 template <int BLOCK, int P>
 static void launch_reg(const float *xyz, float *temp, int32_t *idx, int b, int n, int m, int skip,
                        int bs_log2, hipStream_t s) {
-  if (BLOCK * P <= 4096)
-    hipLaunchKernelGGL((fps_reg_kernel<BLOCK, P, BLOCK * P <= 4096>), dim3(b), dim3(BLOCK), 0, s, xyz, temp, idx, n, m,
-                       skip, bs_log2);
-  else
-    hipLaunchKernelGGL((fps_reg_kernel<BLOCK, P, false>), dim3(b), dim3(BLOCK), 0, s, xyz, temp, idx, n, m, skip,
-                       bs_log2);
+  hipLaunchKernelGGL((fps_reg_kernel<BLOCK, P>), dim3(b), dim3(BLOCK), 0, s, xyz, temp, idx, n, m,
+                     skip, bs_log2);
 }
 
 template <int BLOCK>

@@ -18,6 +18,34 @@ def _nearest(ref_points, query_points):
     return myknn(ref, query, k=1).view(-1) - 1
 
 
+_ROW_ID_CACHE = {}
+_ONES_CACHE = {}
+
+
+def _row_ids(sizes, first_obj, device):
+    key = (sizes, first_obj, str(device))
+    if key not in _ROW_ID_CACHE:
+        if len(_ROW_ID_CACHE) > 256:
+            _ROW_ID_CACHE.clear()
+        oid = torch.cat([torch.full((n,), first_obj + k, dtype=torch.int32) for k, n in enumerate(sizes)])
+        loc = torch.cat([torch.arange(n, dtype=torch.int32) for n in sizes])
+        _ROW_ID_CACHE[key] = (oid.to(device), loc.to(device))
+    return _ROW_ID_CACHE[key]
+
+
+def _transform_3x4(cloud, pose):
+    """transform_point_cloud(cloud, pose, '3x4') with the column of ones taken from a per-size cache (same matmul,
+    same values; saves the ones() launch per object)."""
+    key = (int(cloud.size(0)), cloud.dtype, str(cloud.device))
+    ones = _ONES_CACHE.get(key)
+    if ones is None:
+        if len(_ONES_CACHE) > 256:
+            _ONES_CACHE.clear()
+        ones = _ONES_CACHE[key] = cloud.new_ones(cloud.size(0), 1)
+    homo = torch.cat([cloud, ones], dim=1)
+    return torch.matmul(pose, homo.T).T[:, :3]
+
+
 def _assign_views(poses, V):
     """For every object pose (K,3,4): index of the transformed template view nearest to each template
     view, (K,V) — the reference's per-object 300x300 kNN (label_generation.py:56-58), as ONE batched
@@ -113,14 +141,12 @@ def _process_grasp_labels_fused(end_points):
     obj_of_seed, pt_of_seed, points = [], [], []
     k0 = 0
     for i in range(B):
-        pts, oid, loc = [], [], []
-        for k, pose in enumerate(poses_l[i]):
-            gp = end_points['grasp_points_list'][i][k]
-            pts.append(transform_point_cloud(gp, pose, '3x4'))
-            oid.append(torch.full((gp.size(0),), k0 + k, dtype=torch.int32, device=dev))
-            loc.append(torch.arange(gp.size(0), dtype=torch.int32, device=dev))
+        gps = end_points['grasp_points_list'][i]
+        pts = torch.cat([_transform_3x4(gp, pose) for gp, pose in zip(gps, poses_l[i])], 0)
+        # (object id, point id within the object) of every row of pts: depends on the sizes only - built once per
+        # size pattern instead of a full_() + arange() pair per object per step
+        oid, loc = _row_ids(tuple(int(gp.size(0)) for gp in gps), k0, dev)
         k0 += len(poses_l[i])
-        pts, oid, loc = torch.cat(pts, 0), torch.cat(oid, 0), torch.cat(loc, 0)
         nn_inds = _nearest(pts, seed_xyzs[i])
         points.append(torch.index_select(pts, 0, nn_inds))
         obj_of_seed.append(torch.index_select(oid, 0, nn_inds))

@@ -64,7 +64,13 @@ SIGNATURES = {
     "gb_gemm_wgrad": [_P, _P, _P, _P, _L, _I, _I, _P],
     "gb_gemm_uses_rs": [_L, _I, _I, _I, _I, _I],
     "gb_gemm_dgrad_first": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P],
-    "gb_moments3": [_P, _L, _P, _P],
+    "gb_moments3": [_P, _P, _L, _P, _P],
+    "gb_cyl_unique": [_P, _I, _L, _I, _P, _P, _P, _P],
+    "gb_cyl_rows": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "gb_gemm_fwd_w": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P],
+    "gb_affine_relu_maxpool_members": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "gb_bn_bwd_apply_members": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _L, _I, _P, _P],
+    "gb_bn_bwd_apply_w": [_P, _P, _P, _P, _P, _L, _L, _I, _I, _P, _P],
 }
 
 

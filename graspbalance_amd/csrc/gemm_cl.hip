@@ -140,7 +140,8 @@ __global__ __launch_bounds__(GTPB) void gemm_cl_kernel(Operand a, Operand b, flo
                                                         double *__restrict__ stats, long long kchunk,
                                                         int tiles_n, int stat_slots,
                                                         const float *__restrict__ epi_y,
-                                                        const float *__restrict__ epi_ab) {
+                                                        const float *__restrict__ epi_ab,
+                                                        const uint16_t *__restrict__ epi_w16) {
   // LDS image per operand kind: OP_KC [row][17] (element (r,k) at r*17 + k), OP_RC [k][rows+4]
   constexpr int A_RS = KA == OP_KC ? GPITCH : 1, A_KS = KA == OP_KC ? 1 : GM + 4;  // row / k strides
   constexpr int B_RS = KB == OP_KC ? GPITCH : 1, B_KS = KB == OP_KC ? 1 : GN + 4;
@@ -234,7 +235,16 @@ __global__ __launch_bounds__(GTPB) void gemm_cl_kernel(Operand a, Operand b, flo
             csq[nt] += g * ((y - emean) * erstd);
           }
         }
-        if constexpr (EPI == EPI_STORE_STATS) { csum[nt] += v; csq[nt] += v * v; }  // padded rows/cols are exact zeros
+        if constexpr (EPI == EPI_STORE_STATS) {  // padded rows/cols are exact zeros
+          if (epi_w16) {  // row multiplicities (de-duplicated rows): sums over the original batch
+            const float wv = (row < a.rows ? (float)epi_w16[row] : 0.f) * v;
+            csum[nt] += wv;
+            csq[nt] += wv * v;
+          } else {
+            csum[nt] += v;
+            csq[nt] += v * v;
+          }
+        }
       }
     }
   if constexpr (EPI == EPI_STORE_STATS || EPI == EPI_STORE_BNBWD) {
@@ -323,13 +333,13 @@ static inline bool aligned16(const void *p) { return reinterpret_cast<uintptr_t>
 template <int KA, int KB, int EPI, int BM, int BN>
 static void launch_tile(const Operand &a, const Operand &b, bool va, bool vb, float *d, long long ldd, double *stats,
                         long long kchunk, unsigned chunks, hipStream_t s, int stat_slots, const float *epi_y,
-                        const float *epi_ab) {
+                        const float *epi_ab, const uint16_t *epi_w16) {
   const int tiles_n = (int)((b.rows + BN - 1) / BN);
   const long long tiles_m = (a.rows + BM - 1) / BM;
   const dim3 grid((unsigned)(tiles_m * tiles_n), chunks);
 #define GB_L(VA_, VB_)                                                                                          \
   hipLaunchKernelGGL((gemm_cl_kernel<KA, KB, VA_, VB_, EPI, BM, BN>), grid, dim3(GTPB), 0, s, a, b, d, ldd, stats, \
-                     kchunk, tiles_n, stat_slots, epi_y, epi_ab)
+                     kchunk, tiles_n, stat_slots, epi_y, epi_ab, epi_w16)
   if (va && vb) GB_L(true, true);
   else if (va) GB_L(true, false);
   else if (vb) GB_L(false, true);
@@ -342,14 +352,14 @@ static void launch_tile(const Operand &a, const Operand &b, bool va, bool vb, fl
 template <int KA, int KB, int EPI>
 static void launch_gemm(const Operand &a, const Operand &b, bool va, bool vb, float *d, long long ldd, double *stats,
                         long long kchunk, unsigned chunks, hipStream_t s, int stat_slots = 1,
-                        const float *epi_y = nullptr, const float *epi_ab = nullptr) {
+                        const float *epi_y = nullptr, const float *epi_ab = nullptr, const uint16_t *epi_w16 = nullptr) {
   const bool bn64 = b.rows <= 64;
   const long long blocks128 = ((a.rows + 127) / 128) * ((b.rows + (bn64 ? 63 : 127)) / (bn64 ? 64 : 128)) * chunks;
   const bool bm64 = a.rows <= 64 || blocks128 < 512;
-  if (bm64 && bn64) launch_tile<KA, KB, EPI, 64, 64>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots, epi_y, epi_ab);
-  else if (bm64) launch_tile<KA, KB, EPI, 64, 128>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots, epi_y, epi_ab);
-  else if (bn64) launch_tile<KA, KB, EPI, 128, 64>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots, epi_y, epi_ab);
-  else launch_tile<KA, KB, EPI, 128, 128>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots, epi_y, epi_ab);
+  if (bm64 && bn64) launch_tile<KA, KB, EPI, 64, 64>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots, epi_y, epi_ab, epi_w16);
+  else if (bm64) launch_tile<KA, KB, EPI, 64, 128>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots, epi_y, epi_ab, epi_w16);
+  else if (bn64) launch_tile<KA, KB, EPI, 128, 64>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots, epi_y, epi_ab, epi_w16);
+  else launch_tile<KA, KB, EPI, 128, 128>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots, epi_y, epi_ab, epi_w16);
 }
 
 // Reduction split for forward / dgrad products with few output tiles and a long reduction (the C -> 4C -> C
@@ -375,19 +385,23 @@ using namespace gb;
 
 // Y (P,N) = f(X (P,K)) W(N,K)^T ; aff (optional) = [a(K), b(K)] -> f = relu(a*x+b); stats (optional,
 // fp64 [stat_slots][2N], caller-zeroed) += column sums / sums of squares of Y (summed over slots by gb_bn_finalize)
-extern "C" int gb_gemm_fwd(const float *x, const float *w, const float *aff, float *y, double *stats,
-                           int stat_slots, long long P, int K, int N, void *stream) {
+static int gemm_fwd_impl(const float *x, const float *w, const float *aff, const uint16_t *row_w16, float *y,
+                         double *stats, int stat_slots, long long P, int K, int N, void *stream) {
   if (P < 0 || K < 1 || N < 1 || !x || !w || !y || (stats && stat_slots < 1)) return GB_EINVAL;
   if (P == 0) return GB_OK;
   if (P / 64 * ((N + 63) / 64) > 0x7fffffffLL) return GB_ERANGE;
   if (rs_gemm_try(x, w, y, aff, stats, stat_slots, nullptr, nullptr, P, K, N, 1, stats ? RS_STATS : RS_STORE,
-                  as_stream(stream)))
+                  as_stream(stream), nullptr, stats ? row_w16 : nullptr))
     return check_launch("gb_gemm_fwd");
   Operand a = {x, P, K, K, aff};
   Operand b = {w, N, K, K, nullptr};
   const bool v = (K % 4 == 0) && aligned16(x) && aligned16(w);
   long long kchunk = 0;
-  const int chunks = split_reduction(P, N, K, &kchunk);
+  int chunks = split_reduction(P, N, K, &kchunk);
+  if (row_w16 && stats && chunks > 1) {  // the column pass of the split path does not know row weights
+    chunks = 1;
+    kchunk = (K + GK - 1) / GK * GK;
+  }
   if (chunks > 1) {
     // split reduction: partial products accumulate into a zeroed Y with fp32 atomics; the BatchNorm sums then
     // need the finished Y, i.e. a (small) column pass
@@ -397,9 +411,24 @@ extern "C" int gb_gemm_fwd(const float *x, const float *w, const float *aff, flo
     if (rc != GB_OK || !stats) return rc;
     return gb_col_stats(y, P, N, stats, stream);
   }
-  if (stats) launch_gemm<OP_KC, OP_KC, EPI_STORE_STATS>(a, b, v, v, y, N, stats, kchunk, 1, as_stream(stream), stat_slots);
+  if (stats)
+    launch_gemm<OP_KC, OP_KC, EPI_STORE_STATS>(a, b, v, v, y, N, stats, kchunk, 1, as_stream(stream), stat_slots, nullptr,
+                                               nullptr, row_w16);
   else launch_gemm<OP_KC, OP_KC, EPI_STORE>(a, b, v, v, y, N, stats, kchunk, 1, as_stream(stream));
   return check_launch("gb_gemm_fwd");
+}
+
+extern "C" int gb_gemm_fwd(const float *x, const float *w, const float *aff, float *y, double *stats,
+                           int stat_slots, long long P, int K, int N, void *stream) {
+  return gemm_fwd_impl(x, w, aff, nullptr, y, stats, stat_slots, P, K, N, stream);
+}
+
+// gb_gemm_fwd whose BatchNorm sums weight row p by row_w16[p] (uint16; the array must extend, zero-filled, to the
+// next multiple of 32 rows): the rows are the DISTINCT rows of a batch with duplicates (csrc/cyl_rows.hip), the
+// sums are those of the full batch.
+extern "C" int gb_gemm_fwd_w(const float *x, const float *w, const float *aff, const uint16_t *row_w16, float *y,
+                             double *stats, int stat_slots, long long P, int K, int N, void *stream) {
+  return gemm_fwd_impl(x, w, aff, row_w16, y, stats, stat_slots, P, K, N, stream);
 }
 
 // dX (P,K) = dY (P,N) W(N,K)   with W in its natural (N,K) row-major layout (no transposed copy).
@@ -486,9 +515,10 @@ extern "C" int gb_gemm_dgrad_first(const float *dy, const float *w, const float 
   return check_launch("gb_gemm_dgrad_first");
 }
 
-// mom fp64 [12] += [sum_p x (3), sum_p x x^T (3x3)] of x (P,3); caller-zeroed
+// mom fp64 [12] += [sum_p w_p x (3), sum_p w_p x x^T (3x3)] of x (P,3), w = row_w or 1; caller-zeroed
 namespace gb {
-__global__ __launch_bounds__(GTPB) void moments3_kernel(const float *__restrict__ x, long long P, double *__restrict__ mom) {
+__global__ __launch_bounds__(GTPB) void moments3_kernel(const float *__restrict__ x, const float *__restrict__ rw,
+                                                        long long P, double *__restrict__ mom) {
   // few workgroups, each striding over the rows: the 12 results are same-address fp64 atomics, which serialise
   // (one per wave of a 512-block grid cost 190 us; one per workgroup of a 64-block grid is free)
   __shared__ double part[GTPB / 64][12];
@@ -502,11 +532,12 @@ __global__ __launch_bounds__(GTPB) void moments3_kernel(const float *__restrict_
       const long long p = p0 + (long long)u * GTPB + threadIdx.x;
       if (p < P) {
         const float d[3] = {x[p * 3], x[p * 3 + 1], x[p * 3 + 2]};
+        const float wt = rw ? rw[p] : 1.f;
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-          s[t] += d[t];
+          s[t] += wt * d[t];
 #pragma unroll
-          for (int q = 0; q < 3; ++q) mm[3 * t + q] += d[t] * d[q];
+          for (int q = 0; q < 3; ++q) mm[3 * t + q] += (wt * d[t]) * d[q];
         }
       }
     }
@@ -532,11 +563,11 @@ __global__ __launch_bounds__(GTPB) void moments3_kernel(const float *__restrict_
 }
 }  // namespace gb
 
-extern "C" int gb_moments3(const float *x, long long P, double *mom, void *stream) {
+extern "C" int gb_moments3(const float *x, const float *row_w, long long P, double *mom, void *stream) {
   if (P < 0 || !x || !mom) return GB_EINVAL;
   if (P == 0) return GB_OK;
   long long blocks = (P + 8 * GTPB - 1) / (8 * GTPB);
   if (blocks > 128) blocks = 128;
-  hipLaunchKernelGGL(moments3_kernel, dim3((unsigned)blocks), dim3(GTPB), 0, as_stream(stream), x, P, mom);
+  hipLaunchKernelGGL(moments3_kernel, dim3((unsigned)blocks), dim3(GTPB), 0, as_stream(stream), x, row_w, P, mom);
   return check_launch("gb_moments3");
 }

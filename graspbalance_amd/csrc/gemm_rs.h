@@ -1,6 +1,7 @@
 // Row-streaming GEMM (csrc/gemm_rs.hip): internal interface used by the C entry points in gemm_cl.hip.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 
 namespace gb {
 
@@ -14,6 +15,6 @@ enum { RS_STORE = 0,   // D only
 // LDS-tiled kernel.
 bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, double *stats, int slots,
                  const float *epi_y, const float *epi_ab, long long P, int R, int C, int w_kc, int epi,
-                 hipStream_t s, const float *epi_x = nullptr);
+                 hipStream_t s, const float *epi_x = nullptr, const uint16_t *epi_w16 = nullptr);
 
 }  // namespace gb

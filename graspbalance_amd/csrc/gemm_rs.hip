@@ -37,6 +37,7 @@ struct RsArgs {
   const float *epi_y;   // RS_BNBWD: (P,C) pitch ldd, pre-BatchNorm output of the layer D is the gradient of
   const float *epi_ab;  // RS_BNBWD: [a, b, mean, rstd](C)
   const float *epi_x;   // RS_BNBWD_X: (P,3) the 3-channel input of the layer D is the gradient of
+  const uint16_t *epi_w16;  // RS_STATS (optional): per-row multiplicity, padded with zeros to a multiple of 32 rows
   long long P;
   int R, C, lda, ldd;
   int w_kc;             // 1: B[r][c] = w[c*R + r] (forward, W (C,R));  0: B[r][c] = w[r*C + c] (dgrad, W (R,C))
@@ -164,6 +165,14 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
           }
         }
       }
+      uint2 wq[EPI == RS_STATS ? 4 : 1];  // RS_STATS with row weights: 16 uint16 multiplicities of this lane's rows
+      if constexpr (EPI == RS_STATS) {
+        if (g.epi_w16 && kc == g.nch - 1) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            wq[i] = *reinterpret_cast<const uint2 *>(g.epi_w16 + tile * 32 + 4 * h + 8 * i);
+        }
+      }
       if constexpr (YPRE) {
         if (kc == g.nch - 1) {
 #pragma unroll
@@ -214,7 +223,17 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
             const float v = acc[q][r];
             if (colok && row < g.P) {
               if constexpr (EPI != RS_BNBWD_X) g.d[row * g.ldd + col] = v;  // _X: D itself is not needed
-              if constexpr (EPI == RS_STATS) { cs += v; cq += v * v; }
+              if constexpr (EPI == RS_STATS) {
+                if (g.epi_w16) {  // the row stands for `mult` identical rows of the original batch
+                  const unsigned pk = (r & 2) ? wq[r >> 2].y : wq[r >> 2].x;
+                  const float wv = (float)((r & 1) ? (pk >> 16) : (pk & 0xFFFFu)) * v;
+                  cs += wv;
+                  cq += wv * v;
+                } else {
+                  cs += v;
+                  cq += v * v;
+                }
+              }
               if constexpr (BNB) {
                 const float y = YPRE ? yv[YPRE ? q : 0][r] : yq[r];
                 const float gg = (ea[q] * y + eb[q]) > 0.f ? v : 0.f;
@@ -328,7 +347,7 @@ static bool rs_shape_ok(long long P, int R, int C, int epi, bool has_aff, int *n
 
 bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, double *stats, int slots,
                  const float *epi_y, const float *epi_ab, long long P, int R, int C, int w_kc, int epi,
-                 hipStream_t s, const float *epi_x) {
+                 hipStream_t s, const float *epi_x, const uint16_t *epi_w16) {
   int nt = 0;
   size_t lds_bytes = 0;
   if (!rs_shape_ok(P, R, C, epi, aff != nullptr, &nt, &lds_bytes)) return false;
@@ -339,7 +358,7 @@ bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, dou
     const char *e = getenv("GB_RS_STAGGER");  // A/B switch
     stagger = e ? atoi(e) : 1;
   }
-  RsArgs g = {a, w, d, aff, stats, epi_y, epi_ab, epi_x, P, R, C, R, C, w_kc, slots < 1 ? 1 : slots, nch, stagger};
+  RsArgs g = {a, w, d, aff, stats, epi_y, epi_ab, epi_x, epi_w16, P, R, C, R, C, w_kc, slots < 1 ? 1 : slots, nch, stagger};
   const int bpc = (nt <= 2 && epi != RS_BNBWD && epi != RS_BNBWD_X && lds_bytes <= 78 * 1024) ? 2 : 1;
   if (epi == RS_BNBWD_X) {
     rs_launch<2, RS_BNBWD_X>(g, lds_bytes, bpc, s);

@@ -441,6 +441,172 @@ __global__ __launch_bounds__(CL_TPB) void bn_bwd_apply_rows_kernel(const float *
   }
 }
 
+// ---- rows with multiplicities and cylinder membership (csrc/cyl_rows.hip) ------------------------------------
+// Seed r owns the distinct rows [off[r], off[r] + cnt[r]); row_mem has bit d set when the row's point lies in the
+// seed's d-th cylinder; row_w is how many slots of the original (D x ns) grouping hold it.
+
+// out[(r*D + d), c] = max over the rows of seed r with bit d of relu(a*y + b); arg = that row's absolute index.
+// A thread owns 4 columns of one seed and streams the seed's rows (4 in flight).
+template <int D>
+__global__ __launch_bounds__(CL_TPB) void affine_relu_maxpool_members_kernel(
+    const float *__restrict__ y, const float *__restrict__ ab, const int32_t *__restrict__ row_mem,
+    const int64_t *__restrict__ off, const int32_t *__restrict__ cnt, float *__restrict__ out,
+    int32_t *__restrict__ arg, long long R, int C) {
+  const int tpg = C / 4, gpb = CL_TPB / tpg;
+  const long long r = (long long)blockIdx.x * gpb + threadIdx.x / tpg;
+  if (threadIdx.x / tpg >= gpb || r >= R) return;
+  const int c = (threadIdx.x % tpg) * 4;
+  float a[4], b[4], best[D][4];
+  int bk[D][4];
+  load_vec<4>(ab + c, a);
+  load_vec<4>(ab + C + c, b);
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { best[d][t] = -INFINITY; bk[d][t] = 0; }
+  const long long u0 = off[r], u1 = u0 + cnt[r];
+  for (long long u = u0; u < u1; u += 4) {
+    float v[4][4];
+    int mem[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (u + q < u1) { load_vec<4>(y + (u + q) * C + c, v[q]); mem[q] = row_mem[u + q]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (u + q < u1) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          float o = a[t] * v[q][t] + b[t];
+          o = o > 0.f ? o : 0.f;
+#pragma unroll
+          for (int d = 0; d < D; ++d)
+            if (((mem[q] >> d) & 1) && o > best[d][t]) { best[d][t] = o; bk[d][t] = (int)(u + q); }
+        }
+      }
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    *reinterpret_cast<float4 *>(out + (r * D + d) * C + c) = make_float4(best[d][0], best[d][1], best[d][2], best[d][3]);
+    *reinterpret_cast<int4 *>(arg + (r * D + d) * C + c) = make_int4(bk[d][0], bk[d][1], bk[d][2], bk[d][3]);
+  }
+}
+
+// BatchNorm + ReLU + member-max-pool backward for the distinct rows: the gradient of row u sums, over the cylinders
+// d whose arg-max it is, dout*[out > 0]; every COPY of the row also receives the -(dbeta/P + xhat*dgamma/P) terms, so
+// with multiplicity w:  dy[u] = a*(g - w*(dbeta/P) - xhat*(w*dgamma/P)),  P = rows of the original batch.
+template <int D>
+__global__ __launch_bounds__(CL_TPB) void bn_bwd_apply_members_kernel(
+    const float *__restrict__ dout, const float *__restrict__ out, const int32_t *__restrict__ arg,
+    const float *__restrict__ y, const float *__restrict__ ab, const double *__restrict__ dstats,
+    const float *__restrict__ row_w, const int64_t *__restrict__ off, const int32_t *__restrict__ cnt, long long R,
+    int C, double invP, int training, float *__restrict__ dy) {
+  const int tpg = C / 4, gpb = CL_TPB / tpg;
+  const long long r = (long long)blockIdx.x * gpb + threadIdx.x / tpg;
+  if (threadIdx.x / tpg >= gpb || r >= R) return;
+  const int c = (threadIdx.x % tpg) * 4;
+  float ka[4], km[4], kr[4], k1[4], k2[4], g[D][4];
+  int ar[D][4];
+  load_vec<4>(ab + c, ka);
+  load_vec<4>(ab + 2 * C + c, km);
+  load_vec<4>(ab + 3 * C + c, kr);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    k1[t] = training ? (float)(dstats[c + t] * invP) : 0.f;
+    k2[t] = training ? (float)(dstats[C + c + t] * invP) : 0.f;
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    float o[4];
+    load_vec<4>(out + (r * D + d) * C + c, o);
+    load_vec<4>(dout + (r * D + d) * C + c, g[d]);
+    const int4 q = *reinterpret_cast<const int4 *>(arg + (r * D + d) * C + c);
+    ar[d][0] = q.x; ar[d][1] = q.y; ar[d][2] = q.z; ar[d][3] = q.w;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (!(o[t] > 0.f)) g[d][t] = 0.f;
+  }
+  const long long u0 = off[r], u1 = u0 + cnt[r];
+  for (long long u = u0; u < u1; u += 4) {
+    float v[4][4], w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (u + q < u1) { load_vec<4>(y + (u + q) * C + c, v[q]); w[q] = row_w[u + q]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (u + q < u1) {
+        float dd[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          float gs = 0.f;
+#pragma unroll
+          for (int d = 0; d < D; ++d) gs += (ar[d][t] == (int)(u + q)) ? g[d][t] : 0.f;
+          if (training) {
+            const float xhat = (v[q][t] - km[t]) * kr[t];
+            gs = gs - w[q] * k1[t] - xhat * (w[q] * k2[t]);
+          }
+          dd[t] = ka[t] * gs;
+        }
+        *reinterpret_cast<float4 *>(dy + (u + q) * C + c) = make_float4(dd[0], dd[1], dd[2], dd[3]);
+      }
+  }
+}
+
+// dense weighted form of bn_bwd_apply_rows_kernel (ReLU, no residual): dy = a*(dA*[z>0] - w*dbeta/P - xhat*w*dgamma/P)
+__global__ __launch_bounds__(CL_TPB) void bn_bwd_apply_w_kernel(const float *__restrict__ dout, const float *__restrict__ y,
+                                                                 const float *__restrict__ ab,
+                                                                 const double *__restrict__ dstats,
+                                                                 const float *__restrict__ row_w, long long rows, int C,
+                                                                 double invP, int training, float *__restrict__ dy,
+                                                                 int rows_per_block) {
+  const int tpr = C / 4, rpp = CL_TPB / tpr;
+  const int cg = threadIdx.x % tpr, rl = threadIdx.x / tpr;
+  if (rl >= rpp) return;
+  const int c = cg * 4;
+  float ka[4], kb[4], km[4], kr[4], k1[4], k2[4];
+  load_vec<4>(ab + c, ka);
+  load_vec<4>(ab + C + c, kb);
+  load_vec<4>(ab + 2 * C + c, km);
+  load_vec<4>(ab + 3 * C + c, kr);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    k1[t] = training ? (float)(dstats[c + t] * invP) : 0.f;
+    k2[t] = training ? (float)(dstats[C + c + t] * invP) : 0.f;
+  }
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  long long r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  for (long long r = r0 + rl; r < r1; r += 4 * rpp) {
+    float yy[4][4], g[4][4], w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long rr = r + (long long)u * rpp;
+      if (rr < r1) {
+        load_vec<4>(y + rr * C + c, yy[u]);
+        load_vec<4>(dout + rr * C + c, g[u]);
+        w[u] = row_w[rr];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long rr = r + (long long)u * rpp;
+      if (rr < r1) {
+        float d[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float z = ka[t] * yy[u][t] + kb[t];
+          float dd = z > 0.f ? g[u][t] : 0.f;
+          if (training) {
+            const float xhat = (yy[u][t] - km[t]) * kr[t];
+            dd = dd - w[u] * k1[t] - xhat * (w[u] * k2[t]);
+          }
+          d[t] = ka[t] * dd;
+        }
+        *reinterpret_cast<float4 *>(dy + rr * C + c) = make_float4(d[0], d[1], d[2], d[3]);
+      }
+    }
+  }
+}
+
 // pooled variants: dOut is (R,C); the gradient reaches only the arg-max sample and only if out > 0
 template <int VEC>
 __global__ __launch_bounds__(CL_TPB) void bn_bwd_stats_pool_kernel(const float *__restrict__ dout,
@@ -656,10 +822,65 @@ extern "C" int gb_bn_bwd_apply(const float *dout, const float *y, const float *a
   return check_launch("gb_bn_bwd_apply");
 }
 
+static bool members_ok(long long R, int D, int C, const void *a, const void *b, const void *c, const void *d) {
+  return R >= 0 && (D == 1 || D == 2 || D == 4) && C >= 16 && C % 4 == 0 && C / 4 <= CL_TPB &&
+         (reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
+          reinterpret_cast<uintptr_t>(d)) % 16 == 0;
+}
+
+extern "C" int gb_affine_relu_maxpool_members(const float *y, const float *ab, const int32_t *row_mem, const int64_t *off,
+                                              const int32_t *cnt, float *out, int32_t *arg, long long R, int D, int C,
+                                              void *stream) {
+  if (!y || !ab || !row_mem || !off || !cnt || !out || !arg || !members_ok(R, D, C, y, ab, out, arg)) return GB_EINVAL;
+  if (R == 0) return GB_OK;
+  const int gpb = CL_TPB / (C / 4);
+  const dim3 grid((unsigned)((R + gpb - 1) / gpb));
+#define GB_MP(D_) hipLaunchKernelGGL((affine_relu_maxpool_members_kernel<D_>), grid, dim3(CL_TPB), 0, as_stream(stream), y, \
+                                     ab, row_mem, off, cnt, out, arg, R, C)
+  if (D == 1) GB_MP(1); else if (D == 2) GB_MP(2); else GB_MP(4);
+#undef GB_MP
+  return check_launch("gb_affine_relu_maxpool_members");
+}
+
+extern "C" int gb_bn_bwd_apply_members(const float *dout, const float *out, const int32_t *arg, const float *y,
+                                       const float *ab, const double *dstats, const float *row_w, const int64_t *off,
+                                       const int32_t *cnt, long long R, int D, int C, long long P_total, int training,
+                                       float *dy, void *stream) {
+  if (!dout || !out || !arg || !y || !ab || !row_w || !off || !cnt || !dy || (training && !dstats) || P_total < 1 ||
+      !members_ok(R, D, C, dout, out, arg, y) || (reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(ab)) % 16)
+    return GB_EINVAL;
+  if (R == 0) return GB_OK;
+  const int gpb = CL_TPB / (C / 4);
+  const dim3 grid((unsigned)((R + gpb - 1) / gpb));
+#define GB_MB(D_) hipLaunchKernelGGL((bn_bwd_apply_members_kernel<D_>), grid, dim3(CL_TPB), 0, as_stream(stream), dout, out, \
+                                     arg, y, ab, dstats, row_w, off, cnt, R, C, 1.0 / (double)P_total, training, dy)
+  if (D == 1) GB_MB(1); else if (D == 2) GB_MB(2); else GB_MB(4);
+#undef GB_MB
+  return check_launch("gb_bn_bwd_apply_members");
+}
+
+extern "C" int gb_bn_bwd_apply_w(const float *dout, const float *y, const float *ab, const double *dstats,
+                                 const float *row_w, long long rows, long long P_total, int C, int training, float *dy,
+                                 void *stream) {
+  if (rows < 0 || P_total < 1 || C < 4 || C % 4 != 0 || C / 4 > CL_TPB || !dout || !y || !ab || !row_w || !dy ||
+      (training && !dstats))
+    return GB_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(ab) |
+       reinterpret_cast<uintptr_t>(dy)) % 16)
+    return GB_EINVAL;
+  if (rows == 0) return GB_OK;
+  const int rpp = CL_TPB / (C / 4);
+  long long rpb = (rows + 4095) / 4096;
+  rpb = (rpb + 4 * rpp - 1) / (4 * rpp) * (4 * rpp);
+  hipLaunchKernelGGL(bn_bwd_apply_w_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(CL_TPB), 0, as_stream(stream),
+                     dout, y, ab, dstats, row_w, rows, C, 1.0 / (double)P_total, training, dy, (int)rpb);
+  return check_launch("gb_bn_bwd_apply_w");
+}
+
 extern "C" int gb_bn_bwd_stats_pool(const float *dout, const float *out, const int32_t *arg, const float *y,
                                     const float *ab, long long R, int ns, int C, double *dstats, void *stream) {
-  if (R < 0 || ns < 1 || C < 1 || !dout || !out || !arg || !y || !ab || !dstats) return GB_EINVAL;
-  if (R == 0) return GB_OK;
+  if (R < 0 || ns < 0 || C < 1 || !dout || !out || !arg || !y || !ab || !dstats) return GB_EINVAL;  // ns = 0: arg is an
+  if (R == 0) return GB_OK;                                                                        // absolute row index
   const int rpb = rows_per_block(R);
   const dim3 grid((unsigned)((R + rpb - 1) / rpb));
   const bool vec = C % 4 == 0 && (reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(dout)) % 16 == 0;

@@ -235,13 +235,16 @@ class MLPStack(Function):
       BatchNorm-backward sums (dbeta, dgamma) of layer l-1 while it writes that layer's dZ, so the only
       element-wise pass per layer is dy = a*(dA - dbeta/P - xhat*dgamma/P).
 
-    forward(ctx, X0, residual|None, layers: list[_LayerCfg], pool_ns, relu_last, W0, g0, b0, W1, g1, b1, ...)
+    forward(ctx, X0, residual|None, layers: list[_LayerCfg], pool_ns, relu_last, rows: RowSet|None, W0, g0, b0, ...)
+    `rows`: X0's rows are the distinct rows of a batch with duplicates (RowSet: multiplicities, cylinder membership);
+    statistics / gradients are those of the full batch and the final max runs per cylinder over its members.
     """
 
     @staticmethod
-    def forward(ctx, X0, residual, layers, pool_ns, relu_last, *params):
+    def forward(ctx, X0, residual, layers, pool_ns, relu_last, rows, *params):
         dev = X0.device
         L = len(layers)
+        P_stat = rows.P_total if rows is not None else X0.shape[0]  # rows of the batch the BatchNorm sums stand for
         X0 = X0.contiguous()
         P = X0.shape[0]
         slots = STAT_SLOTS if P >= 16384 else 1
@@ -260,17 +263,31 @@ class MLPStack(Function):
             K, N = src.shape[1], W.shape[0]
             stats = stat_arena[stat_off[l]:stat_off[l + 1]] if cfg.training else None
             Y = torch.empty((P, N), dtype=torch.float32, device=dev)
-            _call("gb_gemm_fwd", dev, _lib.ptr(src), _lib.ptr(W), _lib.ptr(aff), _lib.ptr(Y), _lib.ptr(stats), slots,
-                  P, K, N, _s(X0), meta=_gemm_meta("fwd", P, K, N, stats is not None, aff is not None))
+            if rows is not None and stats is not None:
+                _call("gb_gemm_fwd_w", dev, _lib.ptr(src), _lib.ptr(W), _lib.ptr(aff), _lib.ptr(rows.w16), _lib.ptr(Y),
+                      _lib.ptr(stats), slots, P, K, N, _s(X0),
+                      meta=_gemm_meta("fwd", P, K, N, True, aff is not None))
+            else:
+                _call("gb_gemm_fwd", dev, _lib.ptr(src), _lib.ptr(W), _lib.ptr(aff), _lib.ptr(Y), _lib.ptr(stats), slots,
+                      P, K, N, _s(X0), meta=_gemm_meta("fwd", P, K, N, stats is not None, aff is not None))
             ab = ab_arena[ab_off:ab_off + 4 * N]
             ab_off += 4 * N
-            _call("gb_bn_finalize", dev, _lib.ptr(stats), slots, P, N, _lib.ptr(gamma), _lib.ptr(beta), cfg.eps,
+            _call("gb_bn_finalize", dev, _lib.ptr(stats), slots, P_stat, N, _lib.ptr(gamma), _lib.ptr(beta), cfg.eps,
                   cfg.momentum, _lib.ptr(cfg.running_mean), _lib.ptr(cfg.running_var), _lib.ptr(ab),
                   int(cfg.training), _s(X0))
             Ws.append(W); Ys.append(Y); abs_.append(ab)
             src, aff = Y, ab  # ab[:2N] = [a, b] is exactly the next GEMM's prologue table
         N = widths[-1]
         ctx.cfg = (L, P, int(pool_ns), bool(relu_last), [c.training for c in layers], residual is not None)
+        ctx.rows = rows
+        if rows is not None:
+            RD = rows.R * rows.D
+            out = torch.empty((RD, N), dtype=torch.float32, device=dev)
+            arg = torch.empty((RD, N), dtype=torch.int32, device=dev)
+            _call("gb_affine_relu_maxpool_members", dev, _lib.ptr(Ys[-1]), _lib.ptr(abs_[-1]), _lib.ptr(rows.mem),
+                  _lib.ptr(rows.off), _lib.ptr(rows.cnt), _lib.ptr(out), _lib.ptr(arg), rows.R, rows.D, N, _s(X0))
+            ctx.save_for_backward(X0, out, arg, ab_arena, *Ws, *Ys)
+            return out
         if pool_ns:
             R = P // pool_ns
             out = torch.empty((R, N), dtype=torch.float32, device=dev)
@@ -291,6 +308,8 @@ class MLPStack(Function):
     @staticmethod
     def backward(ctx, dout):
         L, P, pool_ns, relu_last, training, has_res = ctx.cfg
+        rows = ctx.rows
+        P_stat = rows.P_total if rows is not None else P
         saved = ctx.saved_tensors
         X0, s1, s2, ab_arena = saved[0], saved[1], saved[2], saved[3]
         Ws, Ys = saved[4:4 + L], saved[4 + L:4 + 2 * L]
@@ -309,7 +328,7 @@ class MLPStack(Function):
         for l in range(L - 1):
             d_off.append(d_off[-1] + ((slots + 1) * 2 * widths[l] if fused[l] and slots > 1 else 2 * widths[l]))
         d_arena = torch.zeros(d_off[-1], dtype=torch.float64, device=dev)
-        need_w = [ctx.needs_input_grad[5 + 3 * l] for l in range(L)]
+        need_w = [ctx.needs_input_grad[6 + 3 * l] for l in range(L)]
         kin = [X0.shape[1]] + widths[:-1]
         w_off = [0]
         for l in range(L):
@@ -331,7 +350,14 @@ class MLPStack(Function):
         dstats = d_arena[:2 * N]
         dres = None
         dY = torch.empty((P, N), dtype=torch.float32, device=dev)
-        if pool_ns:
+        if rows is not None:
+            out, arg = s1, s2
+            _call("gb_bn_bwd_stats_pool", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(Ys[-1]),
+                  _lib.ptr(abs_[-1]), rows.R * rows.D, 0, N, _lib.ptr(dstats), _s(dout))  # ns = 0: absolute arg rows
+            _call("gb_bn_bwd_apply_members", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(Ys[-1]),
+                  _lib.ptr(abs_[-1]), _lib.ptr(dstats), _lib.ptr(rows.w), _lib.ptr(rows.off), _lib.ptr(rows.cnt), rows.R,
+                  rows.D, N, P_stat, int(training[-1]), _lib.ptr(dY), _s(dout))
+        elif pool_ns:
             out, arg = s1, s2
             R = P // pool_ns
             _call("gb_bn_bwd_stats_pool", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(Ys[-1]),
@@ -373,12 +399,13 @@ class MLPStack(Function):
                 _call("gb_gemm_dgrad_first", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(Ys[0]), _lib.ptr(abs_[0]),
                       _lib.ptr(X0), _lib.ptr(sums), slots, P, K, N, _s(dout),
                       meta={"flop": 2.0 * P * K * N, "pkn": (P, K, N), "kernel": "gemm_rs_kernel"})
-                _call("gb_moments3", dev, _lib.ptr(X0), P, _lib.ptr(mom), _s(dout))
+                _call("gb_moments3", dev, _lib.ptr(X0), _lib.ptr(rows.w if rows is not None else None), P, _lib.ptr(mom),
+                      _s(dout))
                 red = sums.view(slots, 5 * K).sum(0) if slots > 1 else sums
                 grads[1], grads[2] = param_grads(0, red, 1, None)
                 dW0 = torch.empty((K, 3), dtype=torch.float32, device=dev)
                 _call("gb_la_wx_grad", dev, _lib.ptr(red), _lib.ptr(u0), _lib.ptr(mom), _lib.ptr(Ws[0]), _lib.ptr(abs_[0]),
-                      P, K, int(training[0]), _lib.ptr(dW0), _s(dout))
+                      P_stat, K, int(training[0]), _lib.ptr(dW0), _s(dout))
                 grads[0] = dW0
                 break
             # gradient of layer l-1's post-ReLU output + that layer's BatchNorm-backward sums in one launch
@@ -399,9 +426,13 @@ class MLPStack(Function):
                       _lib.ptr(dstats), _s(dout))
                 grads[3 * l - 2], grads[3 * l - 1] = param_grads(l - 1, dstats, 1, None)
             dY = torch.empty((P, K), dtype=torch.float32, device=dev)
-            _call("gb_bn_bwd_apply", dev, _lib.ptr(dZ), _lib.ptr(Ys[l - 1]), _lib.ptr(abs_[l - 1]), None,
-                  _lib.ptr(dstats), P, K, 1, int(training[l - 1]), _lib.ptr(dY), None, _s(dout))
-        return (dX0, dres, None, None, None, *grads)
+            if rows is not None:
+                _call("gb_bn_bwd_apply_w", dev, _lib.ptr(dZ), _lib.ptr(Ys[l - 1]), _lib.ptr(abs_[l - 1]), _lib.ptr(dstats),
+                      _lib.ptr(rows.w), P, P_stat, K, int(training[l - 1]), _lib.ptr(dY), _s(dout))
+            else:
+                _call("gb_bn_bwd_apply", dev, _lib.ptr(dZ), _lib.ptr(Ys[l - 1]), _lib.ptr(abs_[l - 1]), None,
+                      _lib.ptr(dstats), P, K, 1, int(training[l - 1]), _lib.ptr(dY), None, _s(dout))
+        return (dX0, dres, None, None, None, None, *grads)
 
 
 class LocalGeometry:
@@ -538,7 +569,18 @@ def _count_batch(bn):
             bn.num_batches_tracked.add_(1)
 
 
-def _stack(X, convs_bns, pool_ns=0, residual=None, relu_last=True):
+class RowSet:
+    """Distinct rows of a batch with duplicates (the D nested cylinder crops of a seed, csrc/cyl_rows.hip): w / w16
+    multiplicities (float / uint16 padded to a multiple of 32 rows), mem member bits, off / cnt the rows of each of
+    the R seeds, D crops per seed, P_total rows of the full batch."""
+    __slots__ = ("w", "w16", "mem", "off", "cnt", "R", "D", "P_total")
+
+    def __init__(self, w, w16, mem, off, cnt, R, D, P_total):
+        self.w, self.w16, self.mem, self.off, self.cnt = w, w16, mem, off, cnt
+        self.R, self.D, self.P_total = int(R), int(D), int(P_total)
+
+
+def _stack(X, convs_bns, pool_ns=0, residual=None, relu_last=True, rows=None):
     params, layers = [], []
     for conv, bn in convs_bns:
         if conv.bias is not None:
@@ -546,7 +588,7 @@ def _stack(X, convs_bns, pool_ns=0, residual=None, relu_last=True):
         _count_batch(bn)
         params += [conv.weight.view(conv.weight.shape[0], -1), bn.weight, bn.bias]
         layers.append(_LayerCfg(bn))
-    return MLPStack.apply(X, residual, layers, pool_ns, relu_last, *params)
+    return MLPStack.apply(X, residual, layers, pool_ns, relu_last, rows, *params)
 
 
 def conv_bn_act(X, conv, bn, relu=True, pool_ns=0, residual=None):
@@ -564,10 +606,10 @@ def conv_bn_act(X, conv, bn, relu=True, pool_ns=0, residual=None):
                              training, relu, pool_ns)
 
 
-def conv_bn_act_chain(X, convs_bns, residual=None, relu_last=True, pool_ns=0):
+def conv_bn_act_chain(X, convs_bns, residual=None, relu_last=True, pool_ns=0, rows=None):
     """Consecutive conv+BN(+ReLU) layers (ReLU after every layer but optionally the last) as one fused stack."""
-    if _OWN_GEMM:
-        return _stack(X, convs_bns, pool_ns=pool_ns, residual=residual, relu_last=relu_last)
+    if _OWN_GEMM or rows is not None:
+        return _stack(X, convs_bns, pool_ns=pool_ns, residual=residual, relu_last=relu_last, rows=rows)
     n = len(convs_bns)
     for i, (conv, bn) in enumerate(convs_bns):
         last = i == n - 1
@@ -576,11 +618,56 @@ def conv_bn_act_chain(X, convs_bns, residual=None, relu_last=True, pool_ns=0):
     return X
 
 
-def shared_mlp_cl(X, shared_mlp, pool_ns=0):
+def shared_mlp_cl(X, shared_mlp, pool_ns=0, rows=None):
     """Run a ``pytorch_utils.SharedMLP`` (layer0..layerK of conv+bn+ReLU) on channel-last rows; the
-    last layer is fused with the max over `pool_ns` consecutive rows when pool_ns > 0."""
+    last layer is fused with the max over `pool_ns` consecutive rows when pool_ns > 0, or - with `rows`
+    (RowSet: X holds the distinct rows of a batch with duplicates) - with the per-crop max over the members."""
     layers = [(layer.conv, layer.bn.bn) for layer in shared_mlp.children()]
-    return conv_bn_act_chain(X, layers, pool_ns=pool_ns)
+    return conv_bn_act_chain(X, layers, pool_ns=pool_ns, rows=rows)
+
+
+_CYL_DEDUP = os.environ.get("GB_CYL_DEDUP", "1") != "0"  # A/B switch: distinct rows for the nested cylinder crops
+
+
+def cyl_dedup_enabled():
+    return _CYL_DEDUP
+
+
+def set_cyl_dedup(flag):
+    global _CYL_DEDUP
+    _CYL_DEDUP = bool(flag)
+
+
+def cylinder_rows(idx, xyz, centres, rot):
+    """idx (nr, D, B, m, ns) int32 from fused_ops.cylinder_query_multi -> per radius (x0 (P_u,3), RowSet): the DISTINCT
+    (seed, point) rows of the D nested crops of every seed, rotated into the seed's frame (csrc/cyl_rows.hip).  One
+    device->host read of the nr row counts (the allocation sizes) is the only synchronisation."""
+    nr, D, B, m, ns = idx.shape
+    R, W, dev = B * m, D * ns, idx.device
+    idx = idx.contiguous()
+    xyz, centres, rot9 = xyz.contiguous(), centres.contiguous(), rot.reshape(B, m, 9).contiguous()
+    scratch = torch.empty((2, nr, R, W), dtype=torch.int32, device=dev)
+    count = torch.empty((nr, R), dtype=torch.int32, device=dev)
+    st = _s(idx)
+    for i in range(nr):
+        _call("gb_cyl_unique", dev, _lib.ptr(idx[i]), D, R, ns, _lib.ptr(scratch[0, i]), _lib.ptr(scratch[1, i]),
+              _lib.ptr(count[i]), st)
+    ends = torch.cumsum(count, dim=1, dtype=torch.int64)
+    off = (ends - count).contiguous()
+    totals = ends[:, -1].tolist()  # the one host synchronisation: row counts size the activations
+    out = []
+    for i in range(nr):
+        Pu = int(totals[i])
+        pad = (Pu + 31) // 32 * 32
+        x0 = torch.empty((Pu, 3), dtype=torch.float32, device=dev)
+        w = torch.empty(Pu, dtype=torch.float32, device=dev)
+        w16 = torch.zeros(pad, dtype=torch.int16, device=dev)  # uint16 bits; zero tail for the GEMM epilogue
+        mem = torch.empty(Pu, dtype=torch.int32, device=dev)
+        _call("gb_cyl_rows", dev, _lib.ptr(xyz), _lib.ptr(centres), _lib.ptr(rot9), _lib.ptr(scratch[0, i]),
+              _lib.ptr(scratch[1, i]), _lib.ptr(count[i]), _lib.ptr(off[i]), B, xyz.shape[1], m, W, _lib.ptr(x0),
+              _lib.ptr(w), _lib.ptr(w16), _lib.ptr(mem), st)
+        out.append((x0, RowSet(w, w16, mem, off[i], count[i], R, D, R * W)))
+    return out
 
 
 def supports(shared_mlp):

@@ -100,7 +100,13 @@ class GraspPoseStage2_seed_features_multi_scale(nn.Module):
             g0 = groups[0]
             idx = fused_ops.cylinder_query_multi(pointcloud, seed_xyz, rot, [g.cylinder_radius for g in groups],
                                                  g0.hmin, g0.hmax_list, g0.nsample)
-            scales = [g(seed_xyz, pointcloud, rot, idx=idx[i]) for i, g in enumerate(groups)]
+            if (fused_mlp.cyl_dedup_enabled() and all(g._cl_ok(pointcloud) for g in groups)
+                    and len(g0.hmax_list) in (1, 2, 4) and len(g0.hmax_list) * g0.nsample <= 256):
+                # the crops of a seed are nested: run each MLP on the distinct (seed, point) rows only
+                rows = fused_mlp.cylinder_rows(idx, pointcloud, seed_xyz, rot)
+                scales = [g(seed_xyz, pointcloud, rot, rows=rows[i]) for i, g in enumerate(groups)]
+            else:
+                scales = [g(seed_xyz, pointcloud, rot, idx=idx[i]) for i, g in enumerate(groups)]
         else:
             scales = [g(seed_xyz, pointcloud, rot) for g in groups]
         B, _, num_seed, num_depth = scales[0].size()

@@ -102,13 +102,21 @@ class GraspWidthGrouping(nn.Module):
                          for hmax in hmax_list]
         self.mlps = pt_utils.SharedMLP([self.in_dim, 64, 128, 256], bn=True)
 
-    def forward(self, seed_xyz, pointcloud, vp_rot, idx=None):
+    def _cl_ok(self, pointcloud):
+        return fused_mlp.enabled(pointcloud) and fused_mlp.supports(self.mlps) \
+            and all(g.use_xyz and g.rotate_xyz and not g.normalize_xyz for g in self.groupers)
+
+    def forward(self, seed_xyz, pointcloud, vp_rot, idx=None, rows=None):
         """idx: optional precomputed neighbour indices (num_depth,B,num_seed,nsample) from the fused
-        multi-query kernel; None runs one cylinder query per depth like the reference."""
+        multi-query kernel; None runs one cylinder query per depth like the reference.
+        rows: optional (x0, RowSet) from fused_mlp.cylinder_rows - the distinct (seed, point) rows of the crops."""
         B, num_seed, _, _ = vp_rot.size()
         num_depth = len(self.groupers)
-        if idx is not None and fused_mlp.enabled(pointcloud) and fused_mlp.supports(self.mlps) \
-                and all(g.use_xyz and g.rotate_xyz and not g.normalize_xyz for g in self.groupers):
+        if rows is not None and self._cl_ok(pointcloud):
+            x0, rowset = rows
+            out = fused_mlp.shared_mlp_cl(x0, self.mlps, rows=rowset)  # (B*seed*depth, 256), rows (b, seed, depth)
+            return out.view(B, num_seed, num_depth, -1).permute(0, 3, 1, 2).contiguous()
+        if idx is not None and self._cl_ok(pointcloud):
             # channel-last: rows ordered (b, seed, depth, sample) exactly like the reference's stacked view
             rows = [fused_mlp.group_concat_cl(pointcloud, seed_xyz, idx[d], None, mode=2, rot=vp_rot)
                     .view(B, num_seed, self.nsample, 3) for d in range(num_depth)]

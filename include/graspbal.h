@@ -210,6 +210,40 @@ int gb_bn_bwd_apply_pool(const float *dout, const float *out, const int32_t *arg
 int gb_bn_bwd_reduce(const double *dst, int slots, int C, double *dstats, float *dbeta, float *dgamma,
                      void *stream);
 
+/* ---- distinct rows of the nested cylinder crops (csrc/cyl_rows.hip, *_members kernels in csrc/mlp_cl.hip) -----
+ * Reference: TrainModel/modules.py:99-124 (CloudCrop / GraspWidthGrouping: D CylinderQueryAndGroup crops per seed,
+ * hmax = 0.01..0.04, stacked and sent through ONE SharedMLP, then max_pool2d over the samples of each crop).  A point
+ * lying in several of a seed's cylinders gives identical rows; the MLP runs on the distinct rows, weighted by their
+ * multiplicity in the BatchNorm sums, and each crop's max runs over its members.                              */
+/* idx (D, R, ns) int32 (R = b*m seeds).  Per seed: sorted (R, D*ns) = its distinct point ids, ascending, compacted
+ * to the front; meta (R, D*ns) = (multiplicity << 8) | member bits (bit d: in crop d); count (R).  D*ns <= 256.  */
+int gb_cyl_unique(const int32_t *idx, int D, long long R, int ns, int32_t *sorted, int32_t *meta, int32_t *count,
+                  void *stream);
+/* Rows off[r] .. off[r]+count[r]-1 of seed r (off = exclusive prefix sum of count, int64):
+* x0 (P_u,3) = (xyz[b,id] - centre[r]) rotated by rot[r] (3x3) as gb_group_concat_cl mode 2, row_w = multiplicity
+ * (row_w16: the same as uint16, for gb_gemm_fwd_w), row_mem = member bits.  W = D*ns is the row pitch of sorted / meta.                                         */
+int gb_cyl_rows(const float *xyz, const float *centres, const float *rot, const int32_t *sorted, const int32_t *meta,
+                const int32_t *count, const int64_t *off, int b, int n, int m, int W, float *x0, float *row_w,
+                uint16_t *row_w16, int32_t *row_mem, void *stream);
+/* gb_gemm_fwd whose BatchNorm sums weight row p by row_w16[p] (uint16 multiplicities; the array must extend,
+ * zero-filled, to the next multiple of 32 rows).                                                              */
+int gb_gemm_fwd_w(const float *x, const float *w, const float *aff, const uint16_t *row_w16, float *y, double *stats,
+                  int stat_slots, long long P, int K, int N, void *stream);
+/* out ((R*D), C) [row r*D + d] = max over the rows of seed r with member bit d of relu(a*y + b); arg = absolute
+ * row index of the maximum.  D in {1,2,4}; C % 4 == 0.                                                         */
+int gb_affine_relu_maxpool_members(const float *y, const float *ab, const int32_t *row_mem, const int64_t *off,
+                                   const int32_t *cnt, float *out, int32_t *arg, long long R, int D, int C,
+                                   void *stream);
+/* Backward of BatchNorm + ReLU + member max-pool onto the distinct rows: dy[u] = a*(g_u - w_u*dbeta/P - xhat_u*
+ * w_u*dgamma/P), g_u = sum over the crops whose arg-max is u of dout*[out > 0]; dstats = [dbeta, dgamma] sums from
+ * gb_bn_bwd_stats_pool(..., ns = 0: arg is an absolute row index); P_total = rows of the original batch.        */
+int gb_bn_bwd_apply_members(const float *dout, const float *out, const int32_t *arg, const float *y, const float *ab,
+                            const double *dstats, const float *row_w, const int64_t *off, const int32_t *cnt,
+                            long long R, int D, int C, long long P_total, int training, float *dy, void *stream);
+/* gb_bn_bwd_apply (ReLU, no residual) for rows with multiplicities: dy = a*(dA*[z>0] - w*dbeta/P - xhat*w*dgamma/P). */
+int gb_bn_bwd_apply_w(const float *dout, const float *y, const float *ab, const double *dstats, const float *row_w,
+                      long long rows, long long P_total, int C, int training, float *dy, void *stream);
+
 /* ---- LocalAggregation without the grouped tensor (csrc/local_agg.hip) ---------------------------------
  * Reference: TrainModel/drp.py:32-67 (LocalAggregation.forward :62 = QueryAndGroup -> [dp, fj] ->
  * create_convblock2d (1x1 conv, BatchNorm2d, ReLU) -> max over the ns neighbours), reached from
@@ -275,8 +309,8 @@ int gb_gemm_uses_rs(long long P, int K, int N, int dgrad, int fused_stats, int h
  * ask gb_gemm_uses_rs(P, K, N, 1, 2, 0) first.                                                          */
 int gb_gemm_dgrad_first(const float *dy, const float *w, const float *y_prev, const float *ab_prev, const float *x_in,
                         double *sums, int slots, long long P, int K, int N, void *stream);
-/* mom fp64 [12] (caller-zeroed) += [sum_p x (3), sum_p x x^T (3x3)] of x (P,3).                          */
-int gb_moments3(const float *x, long long P, double *mom, void *stream);
+/* mom fp64 [12] (caller-zeroed) += [sum_p w_p x (3), sum_p w_p x x^T (3x3)] of x (P,3); w = row_w (P) or 1.   */
+int gb_moments3(const float *x, const float *row_w, long long P, double *mom, void *stream);
 
 #ifdef __cplusplus
 }

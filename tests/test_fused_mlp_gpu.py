@@ -306,3 +306,78 @@ def test_first_layer_closed_form_backward(train):
     floor = 1e-2 * max(float(v.norm()) for v in b[1].values())
     for k in b[1]:
         _close(a[1][k], b[1][k], 2e-4, "grad " + k, True, floor)
+
+
+def test_cylinder_distinct_rows_against_torch_unique():
+    """gb_cyl_unique / gb_cyl_rows: per seed the distinct point ids of its D crops (ascending), multiplicities, member
+    bits, offsets - against torch.unique / a dense membership count; rows against gb_group_concat_cl (mode 2)."""
+    from graspbalance_amd import fused_mlp, fused_ops
+    from graspbalance_amd.scene import make_batch
+    import numpy as np
+    cloud = torch.from_numpy(make_batch([2, 3], 6000)).to(DEV)
+    seeds = cloud[:, :96].contiguous()
+    torch.manual_seed(1)
+    q = torch.linalg.qr(torch.randn(2, 96, 3, 3))[0].to(DEV).contiguous()
+    idx = fused_ops.cylinder_query_multi(cloud, seeds, q, [0.05, 0.11], -0.02, [0.01, 0.02, 0.03, 0.04], 48)
+    idx[0, :, 0, 5] = 7  # a seed whose every slot holds the same point (multiplicity D*ns)
+    res = fused_mlp.cylinder_rows(idx, cloud, seeds, q)
+    torch.cuda.synchronize()
+    for i, (x0, rs) in enumerate(res):
+        ids = idx[i].permute(1, 2, 0, 3).reshape(2 * 96, 4, 48).cpu().numpy()  # (R, D, ns)
+        off, cnt = rs.off.cpu().numpy(), rs.cnt.cpu().numpy()
+        w, mem = rs.w.cpu().numpy(), rs.mem.cpu().numpy()
+        w16 = rs.w16.cpu().numpy()
+        assert rs.P_total == ids.size and rs.R == 192 and rs.D == 4
+        assert off[0] == 0 and np.array_equal(off[1:], np.cumsum(cnt)[:-1]) and x0.shape[0] == off[-1] + cnt[-1]
+        assert np.all(w16[x0.shape[0]:] == 0) and w16.size % 32 == 0
+        for r in range(192):
+            u, c = np.unique(ids[r], return_counts=True)
+            sl = slice(off[r], off[r] + cnt[r])
+            assert cnt[r] == u.size and np.array_equal(w[sl], c.astype(np.float32)) and np.array_equal(w16[sl], c)
+            bits = np.array([sum(int(p in ids[r, d]) << d for d in range(4)) for p in u])
+            assert np.array_equal(mem[sl], bits)
+            # rotated offsets of the distinct points == the rows gb_group_concat_cl would emit for them
+            b, j = divmod(r, 96)
+            dp = (cloud[b, torch.from_numpy(u).long().to(DEV)] - seeds[b, j])
+            ref = ((dp[:, 0:1] * q[b, j, 0]) + (dp[:, 1:2] * q[b, j, 1])) + (dp[:, 2:3] * q[b, j, 2])
+            assert torch.equal(x0[off[r]:off[r] + cnt[r]], ref)
+        assert float(w.sum()) == ids.size
+
+
+def test_grasp_width_grouping_distinct_rows_equals_plain(golden):
+    """The de-duplicated execution of the nested cylinder crops (multiplicity-weighted BatchNorm, per-crop member
+    max): tight against the same stack run on all D*ns rows per seed (forward, every gradient, running statistics),
+    and within the usual bounds against the reference composition."""
+    from graspbalance_amd import fused_mlp, fused_ops
+    from graspbalance_amd.modules import GraspWidthGrouping
+    from graspbalance_amd.scene import make_batch
+    torch.manual_seed(5)
+    plain = GraspWidthGrouping(64, 3, 0.06, -0.02, [0.01, 0.02, 0.03, 0.04]).to(DEV).train()
+    cloud = torch.from_numpy(make_batch([0, 1], 20000)).to(DEV)
+    seeds = cloud[:, :256].contiguous()
+    rot = torch.from_numpy(golden.load("g9_views")["rot"])[:256].unsqueeze(0).repeat(2, 1, 1, 1).contiguous().to(DEV)
+    idx = fused_ops.cylinder_query_multi(cloud, seeds, rot, [0.06], -0.02, [0.01, 0.02, 0.03, 0.04], 64)
+    rows = fused_mlp.cylinder_rows(idx, cloud, seeds, rot)[0]
+    assert rows[0].shape[0] < 0.6 * idx[0].numel()  # the crops really overlap on this cloud
+    res = {}
+    for name in ("dedup", "all_rows"):
+        m = copy.deepcopy(plain)
+        out = m(seeds, cloud, rot, rows=rows) if name == "dedup" else m(seeds, cloud, rot, idx=idx[0])
+        torch.manual_seed(99)
+        (out * torch.randn_like(out)).sum().backward()
+        res[name] = (out.detach(), {k: v.grad.clone() for k, v in m.named_parameters()},
+                     {k: v.clone() for k, v in m.named_buffers() if v.dtype.is_floating_point})
+    a, b = res["dedup"], res["all_rows"]
+    _close(a[0], b[0], 1e-5, "forward")
+    floor = 1e-2 * max(float(v.norm()) for v in b[1].values())
+    for k in b[1]:
+        _close(a[1][k], b[1][k], 5e-5, "grad " + k, True, floor)
+    for k in b[2]:
+        _close(a[2][k], b[2][k], 1e-5, "buffer " + k)
+    fused = copy.deepcopy(plain)
+
+    def call(mod):
+        if mod is fused:
+            return mod(seeds, cloud, rot, rows=rows), []
+        return mod(seeds, cloud, rot, idx=idx[0]), []
+    _run(fused, plain, call, tol_grad=2e-3, l2=True)  # torch's own fp32 BatchNorm backward over 131072 rows is the noise here

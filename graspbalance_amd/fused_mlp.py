@@ -262,7 +262,7 @@ class MLPStack(Function):
             gamma, beta = params[3 * l + 1], params[3 * l + 2]
             K, N = src.shape[1], W.shape[0]
             stats = stat_arena[stat_off[l]:stat_off[l + 1]] if cfg.training else None
-            Y = torch.empty((P, N), dtype=torch.float32, device=dev)
+            Y = _empty_rows(P, N, dev, rows is not None)
             if rows is not None and stats is not None:
                 _call("gb_gemm_fwd_w", dev, _lib.ptr(src), _lib.ptr(W), _lib.ptr(aff), _lib.ptr(rows.w16), _lib.ptr(Y),
                       _lib.ptr(stats), slots, P, K, N, _s(X0),
@@ -349,7 +349,7 @@ class MLPStack(Function):
         N = widths[-1]
         dstats = d_arena[:2 * N]
         dres = None
-        dY = torch.empty((P, N), dtype=torch.float32, device=dev)
+        dY = _empty_rows(P, N, dev, rows is not None)
         if rows is not None:
             out, arg = s1, s2
             _call("gb_bn_bwd_stats_pool", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(Ys[-1]),
@@ -409,7 +409,7 @@ class MLPStack(Function):
                 grads[0] = dW0
                 break
             # gradient of layer l-1's post-ReLU output + that layer's BatchNorm-backward sums in one launch
-            dZ = torch.empty((P, K), dtype=torch.float32, device=dev)
+            dZ = _empty_rows(P, K, dev, rows is not None)
             region = d_arena[d_off[l - 1]:d_off[l]]
             if fused[l - 1]:
                 _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dZ), _lib.ptr(Ys[l - 1]),
@@ -425,7 +425,7 @@ class MLPStack(Function):
                 _call("gb_bn_bwd_stats", dev, _lib.ptr(dZ), _lib.ptr(Ys[l - 1]), _lib.ptr(abs_[l - 1]), None, P, K, 1,
                       _lib.ptr(dstats), _s(dout))
                 grads[3 * l - 2], grads[3 * l - 1] = param_grads(l - 1, dstats, 1, None)
-            dY = torch.empty((P, K), dtype=torch.float32, device=dev)
+            dY = _empty_rows(P, K, dev, rows is not None)
             if rows is not None:
                 _call("gb_bn_bwd_apply_w", dev, _lib.ptr(dZ), _lib.ptr(Ys[l - 1]), _lib.ptr(abs_[l - 1]), _lib.ptr(dstats),
                       _lib.ptr(rows.w), P, P_stat, K, int(training[l - 1]), _lib.ptr(dY), _s(dout))
@@ -569,6 +569,19 @@ def _count_batch(bn):
             bn.num_batches_tracked.add_(1)
 
 
+_ROW_QUANTUM = 32768
+
+
+def _empty_rows(P, C, dev, quantised):
+    """(P, C) fp32 activation buffer.  With `quantised` (row counts that change from step to step: the distinct rows
+    of the cylinder crops) the allocation is rounded up to a multiple of 32768 rows, so the caching allocator sees
+    the same few sizes every step instead of a new one (a new size means a fresh hipMalloc - a device sync)."""
+    if not quantised:
+        return torch.empty((P, C), dtype=torch.float32, device=dev)
+    cap = (P + _ROW_QUANTUM - 1) // _ROW_QUANTUM * _ROW_QUANTUM
+    return torch.empty((cap, C), dtype=torch.float32, device=dev)[:P]
+
+
 class RowSet:
     """Distinct rows of a batch with duplicates (the D nested cylinder crops of a seed, csrc/cyl_rows.hip): w / w16
     multiplicities (float / uint16 padded to a multiple of 32 rows), mem member bits, off / cnt the rows of each of
@@ -659,10 +672,11 @@ def cylinder_rows(idx, xyz, centres, rot):
     for i in range(nr):
         Pu = int(totals[i])
         pad = (Pu + 31) // 32 * 32
-        x0 = torch.empty((Pu, 3), dtype=torch.float32, device=dev)
-        w = torch.empty(Pu, dtype=torch.float32, device=dev)
-        w16 = torch.zeros(pad, dtype=torch.int16, device=dev)  # uint16 bits; zero tail for the GEMM epilogue
-        mem = torch.empty(Pu, dtype=torch.int32, device=dev)
+        cap = (Pu + _ROW_QUANTUM - 1) // _ROW_QUANTUM * _ROW_QUANTUM  # allocation sizes that repeat from step to step
+        x0 = torch.empty((cap, 3), dtype=torch.float32, device=dev)[:Pu]
+        w = torch.empty(cap, dtype=torch.float32, device=dev)[:Pu]
+        w16 = torch.zeros(cap, dtype=torch.int16, device=dev)[:pad]  # uint16 bits; zero tail for the GEMM epilogue
+        mem = torch.empty(cap, dtype=torch.int32, device=dev)[:Pu]
         _call("gb_cyl_rows", dev, _lib.ptr(xyz), _lib.ptr(centres), _lib.ptr(rot9), _lib.ptr(scratch[0, i]),
               _lib.ptr(scratch[1, i]), _lib.ptr(count[i]), _lib.ptr(off[i]), B, xyz.shape[1], m, W, _lib.ptr(x0),
               _lib.ptr(w), _lib.ptr(w16), _lib.ptr(mem), st)

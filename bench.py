@@ -118,7 +118,7 @@ def main():
     for _ in range(args.warmup):
         trainer.train_step(batch)
     barrier()
-    with _lib.KernelTimer(["gb_fps", "gb_gemm_fwd", "gb_gemm_dgrad", "gb_gemm_dgrad_first", "gb_gemm_wgrad"]) as kt:
+    with _lib.KernelTimer(["gb_fps", "gb_gemm_fwd", "gb_gemm_fwd_w", "gb_gemm_dgrad", "gb_gemm_dgrad_first", "gb_gemm_wgrad"]) as kt:
         t0 = time.perf_counter()
         for _ in range(args.steps):
             loss = trainer.train_step(batch)
@@ -139,7 +139,7 @@ def main():
         ev_bias = _lib.event_pair_overhead_ms(device)  # what an empty event bracket reads; removed from every launch
 
         def gemm_roofline(kernel, what):
-            ev = [(max(a.elapsed_time(b) - ev_bias, 1e-4), m["flop"]) for n in ("gb_gemm_fwd", "gb_gemm_dgrad", "gb_gemm_dgrad_first", "gb_gemm_wgrad")
+            ev = [(max(a.elapsed_time(b) - ev_bias, 1e-4), m["flop"]) for n in ("gb_gemm_fwd", "gb_gemm_fwd_w", "gb_gemm_dgrad", "gb_gemm_dgrad_first", "gb_gemm_wgrad")
                   for a, b, m in kt.events[n] if m["kernel"] == kernel]
             if not ev:
                 return None

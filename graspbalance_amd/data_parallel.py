@@ -24,14 +24,18 @@ def shard_batch(batch, rank, world_size):
 
 class FlatGradAllReduce:
     """All-reduces the whole gradient as a handful of contiguous fp32 buckets (sum, then divide by world
-    size).  Buckets follow reverse registration order (the order backward produces gradients in).
+    size), overlapped with backward.  Buckets follow reverse registration order (the order backward produces
+    gradients in), so bucket 0 is complete first.
 
-    Gradients are NOT accumulated into the buckets during backward: ``zero_grad()`` sets every ``.grad`` to
-    None so autograd just hands each parameter its freshly computed gradient (no per-parameter add kernel),
-    and ``reduce()`` packs them with one multi-tensor copy per bucket, points ``.grad`` at the bucket views,
-    and launches the collectives.  Single process: ``reduce()`` is a no-op."""
+    Gradients are NOT accumulated into the buckets: ``zero_grad()`` sets every ``.grad`` to None so autograd just
+    hands each parameter its freshly computed gradient (no per-parameter add kernel).  A post-accumulate hook per
+    parameter counts arrivals; as soon as a bucket is complete (and every earlier bucket has been issued - all
+    ranks must issue collectives in the same order) its gradients are packed with one multi-tensor copy and its
+    all-reduce is launched asynchronously, so it runs on RCCL's stream under the rest of backward.  ``reduce()``
+    after backward issues whatever is left (buckets holding parameters the graph did not reach), waits, divides and
+    points ``.grad`` at the bucket views.  Single process: everything is a no-op."""
 
-    def __init__(self, module, bucket_mb=16.0, process_group=None):
+    def __init__(self, module, bucket_mb=16.0, process_group=None, overlap=True):
         self.group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         params = [p for p in module.parameters() if p.requires_grad]
@@ -49,6 +53,9 @@ class FlatGradAllReduce:
         if cur:
             self.buckets.append(cur)
         self.flat, self.views = [], []
+        self._works = [None] * len(self.buckets)
+        self._arrived = [0] * len(self.buckets)
+        self._next = 0
         if not dist.is_initialized():
             return
         for bucket in self.buckets:
@@ -60,28 +67,49 @@ class FlatGradAllReduce:
                 off += p.numel()
             self.flat.append(flat)
             self.views.append(views)
+        if overlap:
+            self._bucket_of = {}
+            for b, bucket in enumerate(self.buckets):
+                for p in bucket:
+                    self._bucket_of[id(p)] = b
+                    p.register_post_accumulate_grad_hook(self._on_grad)
 
     def zero_grad(self):
         for p in self.params:
             p.grad = None
+        self._works = [None] * len(self.buckets)
+        self._arrived = [0] * len(self.buckets)
+        self._next = 0
+
+    def _issue(self, b):
+        bucket, views, flat = self.buckets[b], self.views[b], self.flat[b]
+        have = [(v, p.grad) for v, p in zip(views, bucket) if p.grad is not None and p.grad is not v]
+        for v, p in zip(views, bucket):
+            if p.grad is None:
+                v.zero_()  # a parameter this rank's graph did not reach still takes part in the sum
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        self._works[b] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _on_grad(self, p):
+        b = self._bucket_of[id(p)]
+        self._arrived[b] += 1
+        # issue in bucket order only: every rank must launch the same sequence of collectives
+        while self._next < len(self.buckets) and self._arrived[self._next] == len(self.buckets[self._next]):
+            self._issue(self._next)
+            self._next += 1
 
     def reduce(self):
         if not dist.is_initialized():
             return
-        works = []
-        for bucket, views, flat in zip(self.buckets, self.views, self.flat):
-            have = [(v, p.grad) for v, p in zip(views, bucket) if p.grad is not None]
-            for v, p in zip(views, bucket):
-                if p.grad is None:
-                    v.zero_()  # a parameter this rank's graph did not reach still takes part in the sum
-            if have:
-                torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
-            for v, p in zip(views, bucket):
-                p.grad = v
-            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        for w, flat in zip(works, self.flat):
+        while self._next < len(self.buckets):  # not completed by the hooks (unreached parameters) or no overlap
+            self._issue(self._next)
+            self._next += 1
+        for b, (w, flat) in enumerate(zip(self._works, self.flat)):
             w.wait()
             flat.div_(self.world_size)
+            for v, p in zip(self.views[b], self.buckets[b]):
+                p.grad = v
 
 
 def broadcast_module(module, src=0, process_group=None):

@@ -44,6 +44,7 @@ def _worker(rank, world, port, out_dir):
     loss, _ = get_loss(net(mine))
     loss.backward()
     local = [p.grad.clone() if p.grad is not None else torch.zeros_like(p) for p in net.parameters()]
+    assert grads._next >= 1, "no bucket was all-reduced during backward (overlap hooks did not fire)"
     grads.reduce()
     reduced = [p.grad.clone() for p in net.parameters()]
     opt.step()

@@ -56,9 +56,21 @@ def _s(t):
     return _lib.current_stream(t.device)
 
 
+_FN = {}
+
+
 def _call(name, dev, *args, meta=None):
+    """One C-ABI launch.  Fast path (no timer, tensor on the current device): a cached ctypes function and nothing
+    else - this runs ~600 times per train step, and the host has to stay ahead of the GPU."""
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(_lib.lib(), name)
+    if _lib.KernelTimer.active is None and (dev.index is None or dev.index == torch.cuda.current_device()):
+        rc = fn(*args)
+        if rc:
+            _lib.check(rc, name)
+        return
     with torch.cuda.device(dev):
-        fn = getattr(_lib.lib(), name)
         if meta is None and _lib.KernelTimer.active is not None:
             meta = {"ints": tuple(a for a in args if isinstance(a, int))}  # sizes, for tools/kernel_breakdown.py
         _lib.check(_lib.timed(name, dev, meta, lambda: fn(*args)), name)
@@ -243,6 +255,7 @@ class MLPStack(Function):
     @staticmethod
     def forward(ctx, X0, residual, layers, pool_ns, relu_last, rows, *params):
         dev = X0.device
+        st = _s(X0)  # one stream lookup per call, not one per launch
         L = len(layers)
         P_stat = rows.P_total if rows is not None else X0.shape[0]  # rows of the batch the BatchNorm sums stand for
         X0 = X0.contiguous()
@@ -265,16 +278,16 @@ class MLPStack(Function):
             Y = _empty_rows(P, N, dev, rows is not None)
             if rows is not None and stats is not None:
                 _call("gb_gemm_fwd_w", dev, _lib.ptr(src), _lib.ptr(W), _lib.ptr(aff), _lib.ptr(rows.w16), _lib.ptr(Y),
-                      _lib.ptr(stats), slots, P, K, N, _s(X0),
+                      _lib.ptr(stats), slots, P, K, N, st,
                       meta=_gemm_meta("fwd", P, K, N, True, aff is not None))
             else:
                 _call("gb_gemm_fwd", dev, _lib.ptr(src), _lib.ptr(W), _lib.ptr(aff), _lib.ptr(Y), _lib.ptr(stats), slots,
-                      P, K, N, _s(X0), meta=_gemm_meta("fwd", P, K, N, stats is not None, aff is not None))
+                      P, K, N, st, meta=_gemm_meta("fwd", P, K, N, stats is not None, aff is not None))
             ab = ab_arena[ab_off:ab_off + 4 * N]
             ab_off += 4 * N
             _call("gb_bn_finalize", dev, _lib.ptr(stats), slots, P_stat, N, _lib.ptr(gamma), _lib.ptr(beta), cfg.eps,
                   cfg.momentum, _lib.ptr(cfg.running_mean), _lib.ptr(cfg.running_var), _lib.ptr(ab),
-                  int(cfg.training), _s(X0))
+                  int(cfg.training), st)
             Ws.append(W); Ys.append(Y); abs_.append(ab)
             src, aff = Y, ab  # ab[:2N] = [a, b] is exactly the next GEMM's prologue table
         N = widths[-1]
@@ -285,7 +298,7 @@ class MLPStack(Function):
             out = torch.empty((RD, N), dtype=torch.float32, device=dev)
             arg = torch.empty((RD, N), dtype=torch.int32, device=dev)
             _call("gb_affine_relu_maxpool_members", dev, _lib.ptr(Ys[-1]), _lib.ptr(abs_[-1]), _lib.ptr(rows.mem),
-                  _lib.ptr(rows.off), _lib.ptr(rows.cnt), _lib.ptr(out), _lib.ptr(arg), rows.R, rows.D, N, _s(X0))
+                  _lib.ptr(rows.off), _lib.ptr(rows.cnt), _lib.ptr(out), _lib.ptr(arg), rows.R, rows.D, N, st)
             ctx.save_for_backward(X0, out, arg, ab_arena, *Ws, *Ys)
             return out
         if pool_ns:
@@ -293,14 +306,14 @@ class MLPStack(Function):
             out = torch.empty((R, N), dtype=torch.float32, device=dev)
             arg = torch.empty((R, N), dtype=torch.int32, device=dev)
             _call("gb_affine_relu_maxpool", dev, _lib.ptr(Ys[-1]), _lib.ptr(abs_[-1]), _lib.ptr(out), _lib.ptr(arg), R,
-                  pool_ns, N, _s(X0))
+                  pool_ns, N, st)
             ctx.save_for_backward(X0, out, arg, ab_arena, *Ws, *Ys)
             return out
         if residual is not None:
             residual = residual.contiguous()
         out = torch.empty((P, N), dtype=torch.float32, device=dev)
         _call("gb_affine_act", dev, _lib.ptr(Ys[-1]), _lib.ptr(abs_[-1]), _lib.ptr(residual), _lib.ptr(out), P, N,
-              int(relu_last), _s(X0))
+              int(relu_last), st)
         ctx.save_for_backward(X0, residual if residual is not None else X0.new_empty(0), X0.new_empty(0), ab_arena,
                               *Ws, *Ys)
         return out
@@ -319,6 +332,7 @@ class MLPStack(Function):
             abs_.append(ab_arena[off:off + 4 * n])
             off += 4 * n
         dev = dout.device
+        st = _s(dout)  # one stream lookup per call, not one per launch
         dout = dout.contiguous()
         slots = STAT_SLOTS if P >= 16384 else 1
         # zero-filled arenas: fp64 BatchNorm-backward sums ([2N] last layer, then per layer l<L-1 the slot rows
@@ -343,7 +357,7 @@ class MLPStack(Function):
             n = widths[l]
             dbeta, dgamma = gb_arena[gb_off[l]:gb_off[l] + n], gb_arena[gb_off[l] + n:gb_off[l + 1]]
             _call("gb_bn_bwd_reduce", dev, _lib.ptr(partial), nslots, n, _lib.ptr(total), _lib.ptr(dbeta),
-                  _lib.ptr(dgamma), _s(dout))
+                  _lib.ptr(dgamma), st)
             return dgamma, dbeta
 
         N = widths[-1]
@@ -353,25 +367,25 @@ class MLPStack(Function):
         if rows is not None:
             out, arg = s1, s2
             _call("gb_bn_bwd_stats_pool", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(Ys[-1]),
-                  _lib.ptr(abs_[-1]), rows.R * rows.D, 0, N, _lib.ptr(dstats), _s(dout))  # ns = 0: absolute arg rows
+                  _lib.ptr(abs_[-1]), rows.R * rows.D, 0, N, _lib.ptr(dstats), st)  # ns = 0: absolute arg rows
             _call("gb_bn_bwd_apply_members", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(Ys[-1]),
                   _lib.ptr(abs_[-1]), _lib.ptr(dstats), _lib.ptr(rows.w), _lib.ptr(rows.off), _lib.ptr(rows.cnt), rows.R,
-                  rows.D, N, P_stat, int(training[-1]), _lib.ptr(dY), _s(dout))
+                  rows.D, N, P_stat, int(training[-1]), _lib.ptr(dY), st)
         elif pool_ns:
             out, arg = s1, s2
             R = P // pool_ns
             _call("gb_bn_bwd_stats_pool", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(Ys[-1]),
-                  _lib.ptr(abs_[-1]), R, pool_ns, N, _lib.ptr(dstats), _s(dout))
+                  _lib.ptr(abs_[-1]), R, pool_ns, N, _lib.ptr(dstats), st)
             _call("gb_bn_bwd_apply_pool", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(Ys[-1]),
-                  _lib.ptr(abs_[-1]), _lib.ptr(dstats), R, pool_ns, N, int(training[-1]), _lib.ptr(dY), _s(dout))
+                  _lib.ptr(abs_[-1]), _lib.ptr(dstats), R, pool_ns, N, int(training[-1]), _lib.ptr(dY), st)
         else:
             residual = s1 if has_res else None
             if has_res and ctx.needs_input_grad[1]:
                 dres = torch.empty((P, N), dtype=torch.float32, device=dev)
             _call("gb_bn_bwd_stats", dev, _lib.ptr(dout), _lib.ptr(Ys[-1]), _lib.ptr(abs_[-1]), _lib.ptr(residual), P, N,
-                  int(relu_last), _lib.ptr(dstats), _s(dout))
+                  int(relu_last), _lib.ptr(dstats), st)
             _call("gb_bn_bwd_apply", dev, _lib.ptr(dout), _lib.ptr(Ys[-1]), _lib.ptr(abs_[-1]), _lib.ptr(residual),
-                  _lib.ptr(dstats), P, N, int(relu_last), int(training[-1]), _lib.ptr(dY), _lib.ptr(dres), _s(dout))
+                  _lib.ptr(dstats), P, N, int(relu_last), int(training[-1]), _lib.ptr(dY), _lib.ptr(dres), st)
         grads = [None] * (3 * L)
         grads[3 * L - 2], grads[3 * L - 1] = param_grads(L - 1, dstats, 1, None)
         dX0 = None
@@ -381,14 +395,14 @@ class MLPStack(Function):
             src, aff = (X0, None) if l == 0 else (Ys[l - 1], abs_[l - 1])
             if need_w[l]:
                 dW = w_arena[w_off[l]:w_off[l + 1]]
-                _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(src), _lib.ptr(aff), _lib.ptr(dW), P, K, N, _s(dout),
+                _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(src), _lib.ptr(aff), _lib.ptr(dW), P, K, N, st,
                       meta=_gemm_meta("wgrad", P, K, N, aff=aff is not None))
                 grads[3 * l] = dW.view(N, K)
             if l == 0:
                 if ctx.needs_input_grad[0]:
                     dX0 = torch.empty((P, K), dtype=torch.float32, device=dev)
                     _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dX0), None, None, None, 0, P, K, N,
-                          _s(dout), meta=_gemm_meta("dgrad", P, K, N))
+                          st, meta=_gemm_meta("dgrad", P, K, N))
                 break
             if (l == 1 and _FIRST_FUSE and X0.shape[1] == 3 and not ctx.needs_input_grad[0] and need_w[0]
                     and _lib.lib().gb_gemm_uses_rs(P, K, N, 1, 2, 0)):
@@ -397,15 +411,15 @@ class MLPStack(Function):
                 z = torch.zeros(slots * 5 * K + 3 * K + 12, dtype=torch.float64, device=dev)
                 sums, u0, mom = z[:slots * 5 * K], z[slots * 5 * K:slots * 5 * K + 3 * K], z[slots * 5 * K + 3 * K:]
                 _call("gb_gemm_dgrad_first", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(Ys[0]), _lib.ptr(abs_[0]),
-                      _lib.ptr(X0), _lib.ptr(sums), slots, P, K, N, _s(dout),
+                      _lib.ptr(X0), _lib.ptr(sums), slots, P, K, N, st,
                       meta={"flop": 2.0 * P * K * N, "pkn": (P, K, N), "kernel": "gemm_rs_kernel"})
                 _call("gb_moments3", dev, _lib.ptr(X0), _lib.ptr(rows.w if rows is not None else None), P, _lib.ptr(mom),
-                      _s(dout))
+                      st)
                 red = sums.view(slots, 5 * K).sum(0) if slots > 1 else sums
                 grads[1], grads[2] = param_grads(0, red, 1, None)
                 dW0 = torch.empty((K, 3), dtype=torch.float32, device=dev)
                 _call("gb_la_wx_grad", dev, _lib.ptr(red), _lib.ptr(u0), _lib.ptr(mom), _lib.ptr(Ws[0]), _lib.ptr(abs_[0]),
-                      P_stat, K, int(training[0]), _lib.ptr(dW0), _s(dout))
+                      P_stat, K, int(training[0]), _lib.ptr(dW0), st)
                 grads[0] = dW0
                 break
             # gradient of layer l-1's post-ReLU output + that layer's BatchNorm-backward sums in one launch
@@ -413,25 +427,25 @@ class MLPStack(Function):
             region = d_arena[d_off[l - 1]:d_off[l]]
             if fused[l - 1]:
                 _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dZ), _lib.ptr(Ys[l - 1]),
-                      _lib.ptr(abs_[l - 1]), _lib.ptr(region), slots, P, K, N, _s(dout),
+                      _lib.ptr(abs_[l - 1]), _lib.ptr(region), slots, P, K, N, st,
                       meta=_gemm_meta("dgrad", P, K, N, fused=True))
                 dstats = region[slots * 2 * K:] if slots > 1 else region
                 grads[3 * l - 2], grads[3 * l - 1] = param_grads(l - 1, region, slots, dstats if slots > 1 else None)
             else:
                 # wide + long outputs: the fused epilogue measured slower than a separate column pass
                 _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dZ), None, None, None, 0, P, K, N,
-                      _s(dout), meta=_gemm_meta("dgrad", P, K, N))
+                      st, meta=_gemm_meta("dgrad", P, K, N))
                 dstats = region
                 _call("gb_bn_bwd_stats", dev, _lib.ptr(dZ), _lib.ptr(Ys[l - 1]), _lib.ptr(abs_[l - 1]), None, P, K, 1,
-                      _lib.ptr(dstats), _s(dout))
+                      _lib.ptr(dstats), st)
                 grads[3 * l - 2], grads[3 * l - 1] = param_grads(l - 1, dstats, 1, None)
             dY = _empty_rows(P, K, dev, rows is not None)
             if rows is not None:
                 _call("gb_bn_bwd_apply_w", dev, _lib.ptr(dZ), _lib.ptr(Ys[l - 1]), _lib.ptr(abs_[l - 1]), _lib.ptr(dstats),
-                      _lib.ptr(rows.w), P, P_stat, K, int(training[l - 1]), _lib.ptr(dY), _s(dout))
+                      _lib.ptr(rows.w), P, P_stat, K, int(training[l - 1]), _lib.ptr(dY), st)
             else:
                 _call("gb_bn_bwd_apply", dev, _lib.ptr(dZ), _lib.ptr(Ys[l - 1]), _lib.ptr(abs_[l - 1]), None,
-                      _lib.ptr(dstats), P, K, 1, int(training[l - 1]), _lib.ptr(dY), None, _s(dout))
+                      _lib.ptr(dstats), P, K, 1, int(training[l - 1]), _lib.ptr(dY), None, st)
         return (dX0, dres, None, None, None, None, *grads)
 
 
@@ -470,26 +484,27 @@ class LocalAggPool(Function):
     @staticmethod
     def forward(ctx, f, W, gamma, beta, geo, cfg):
         dev = f.device
+        st = _s(f)  # one stream lookup per call, not one per launch
         f = f.contiguous()
         N, C = W.shape[0], W.shape[1] - 3
         Wx, Wf = W[:, :3].contiguous(), W[:, 3:].contiguous()
         rows, P = geo.b * geo.n, geo.rows
         G = torch.empty((rows, N), dtype=torch.float32, device=dev)
-        _call("gb_gemm_fwd", dev, _lib.ptr(f), _lib.ptr(Wf), None, _lib.ptr(G), None, 1, rows, C, N, _s(f),
+        _call("gb_gemm_fwd", dev, _lib.ptr(f), _lib.ptr(Wf), None, _lib.ptr(G), None, 1, rows, C, N, st,
               meta=_gemm_meta("fwd", rows, C, N))
         sums = torch.zeros(5 * N, dtype=torch.float64, device=dev)  # [sum y, sum y^2, U0, U1, U2]
         stats, u = sums[:2 * N], sums[2 * N:]
         if cfg.training:
             _call("gb_la_col_stats", dev, _lib.ptr(G), _lib.ptr(geo.cnt), _lib.ptr(geo.dsum), _lib.ptr(Wx),
-                  _lib.ptr(geo.mom), rows, N, _lib.ptr(stats), _lib.ptr(u), _s(f))
+                  _lib.ptr(geo.mom), rows, N, _lib.ptr(stats), _lib.ptr(u), st)
         ab = torch.empty(4 * N, dtype=torch.float32, device=dev)
         _call("gb_bn_finalize", dev, _lib.ptr(stats), 1, P, N, _lib.ptr(gamma), _lib.ptr(beta), cfg.eps, cfg.momentum,
-              _lib.ptr(cfg.running_mean), _lib.ptr(cfg.running_var), _lib.ptr(ab), int(cfg.training), _s(f))
+              _lib.ptr(cfg.running_mean), _lib.ptr(cfg.running_var), _lib.ptr(ab), int(cfg.training), st)
         R = geo.b * geo.m
         out = torch.empty((R, N), dtype=torch.float32, device=dev)
         arg = torch.empty((R, N), dtype=torch.int32, device=dev)
         _call("gb_la_pool", dev, _lib.ptr(G), _lib.ptr(geo.xyz), _lib.ptr(geo.centres), _lib.ptr(geo.idx), _lib.ptr(Wx),
-              _lib.ptr(ab), _lib.ptr(out), _lib.ptr(arg), geo.b, geo.n, geo.m, geo.ns, N, geo.mode, geo.scale, _s(f))
+              _lib.ptr(ab), _lib.ptr(out), _lib.ptr(arg), geo.b, geo.n, geo.m, geo.ns, N, geo.mode, geo.scale, st)
         ctx.geo, ctx.training = geo, cfg.training
         ctx.save_for_backward(f, Wx, Wf, G, ab, out, arg, u)
         return out
@@ -499,6 +514,7 @@ class LocalAggPool(Function):
         f, Wx, Wf, G, ab, out, arg, u = ctx.saved_tensors
         geo, training = ctx.geo, int(ctx.training)
         dev = dout.device
+        st = _s(dout)  # one stream lookup per call, not one per launch
         dout = dout.contiguous()
         N, C = Wf.shape
         rows, P = geo.b * geo.n, geo.rows
@@ -506,26 +522,26 @@ class LocalAggPool(Function):
         red = torch.zeros(5 * N, dtype=torch.float64, device=dev)  # [dbeta, dgamma, T0, T1, T2]
         _call("gb_la_pool_bwd", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(G), _lib.ptr(geo.xyz),
               _lib.ptr(geo.centres), _lib.ptr(geo.idx), _lib.ptr(Wx), _lib.ptr(ab), _lib.ptr(sg), _lib.ptr(red), geo.b,
-              geo.n, geo.m, geo.ns, N, geo.mode, geo.scale, _s(dout))
+              geo.n, geo.m, geo.ns, N, geo.mode, geo.scale, st)
         small = torch.empty(5 * N + N * C, dtype=torch.float32, device=dev)  # dbeta, dgamma, dWx (N,3), then dWf
         dbeta, dgamma, dWx = small[:N], small[N:2 * N], small[2 * N:5 * N].view(N, 3)
-        _call("gb_bn_bwd_reduce", dev, _lib.ptr(red), 1, N, None, _lib.ptr(dbeta), _lib.ptr(dgamma), _s(dout))
+        _call("gb_bn_bwd_reduce", dev, _lib.ptr(red), 1, N, None, _lib.ptr(dbeta), _lib.ptr(dgamma), st)
         dG = torch.empty((rows, N), dtype=torch.float32, device=dev)
         _call("gb_la_point_grad", dev, _lib.ptr(sg), _lib.ptr(G), _lib.ptr(geo.cnt), _lib.ptr(geo.dsum), _lib.ptr(Wx),
-              _lib.ptr(ab), _lib.ptr(red), P, rows, N, training, _lib.ptr(dG), _s(dout))
+              _lib.ptr(ab), _lib.ptr(red), P, rows, N, training, _lib.ptr(dG), st)
         dW = None
         if ctx.needs_input_grad[1]:
             _call("gb_la_wx_grad", dev, _lib.ptr(red), _lib.ptr(u), _lib.ptr(geo.mom), _lib.ptr(Wx), _lib.ptr(ab), P, N,
-                  training, _lib.ptr(dWx), _s(dout))
+                  training, _lib.ptr(dWx), st)
             dWf = torch.zeros((N, C), dtype=torch.float32, device=dev)
-            _call("gb_gemm_wgrad", dev, _lib.ptr(dG), _lib.ptr(f), None, _lib.ptr(dWf), rows, C, N, _s(dout),
+            _call("gb_gemm_wgrad", dev, _lib.ptr(dG), _lib.ptr(f), None, _lib.ptr(dWf), rows, C, N, st,
                   meta=_gemm_meta("wgrad", rows, C, N))
             dW = torch.cat([dWx, dWf], 1)
         df = None
         if ctx.needs_input_grad[0]:
             df = torch.empty((rows, C), dtype=torch.float32, device=dev)
             _call("gb_gemm_dgrad", dev, _lib.ptr(dG), _lib.ptr(Wf), _lib.ptr(df), None, None, None, 0, rows, C, N,
-                  _s(dout), meta=_gemm_meta("dgrad", rows, C, N))
+                  st, meta=_gemm_meta("dgrad", rows, C, N))
         return df, dW, dgamma, dbeta, None, None
 
 

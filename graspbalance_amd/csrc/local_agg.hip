@@ -83,6 +83,79 @@ __global__ __launch_bounds__(LA_TPB) void la_point_stats_kernel(const float *__r
   }
 }
 
+// LDS-accumulating form for n <= 4096 points per cloud: a workgroup owns a slice of one cloud's rows and adds into an
+// (n x 4) image of [cnt, dsum] in LDS (ds_add_f32), then flushes the touched entries with coalesced global atomics -
+// 4 scattered global atomics per row (2 M of them at the first level, 263 us) become ~n*4 per workgroup.
+__global__ __launch_bounds__(LA_TPB) void la_point_stats_lds_kernel(const float *__restrict__ xyz,
+                                                                     const float *__restrict__ centres,
+                                                                     const int32_t *__restrict__ idx, int n, int m,
+                                                                     int ns, int mode, float scale, int rows_per_block,
+                                                                     float *__restrict__ cnt, float *__restrict__ dsum,
+                                                                     double *__restrict__ mom) {
+  extern __shared__ float img[];  // [n][4] = cnt, dsum0..2
+  __shared__ double part[LA_TPB / 64][12];
+  const int bi = blockIdx.y;
+  for (int i = threadIdx.x; i < n * 4; i += LA_TPB) img[i] = 0.f;
+  __syncthreads();
+  const long long rows = (long long)m * ns;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  long long r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  float s[3] = {0.f, 0.f, 0.f}, mm[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  double v[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) v[i] = 0.0;
+  int since = 0;
+  for (long long p = r0 + threadIdx.x; p < r1; p += LA_TPB) {
+    const long long grp = (long long)bi * m + p / ns;
+    const int id = idx[(size_t)bi * rows + p];
+    float d[3];
+    la_dp(xyz, centres, bi, n, grp, id, mode, scale, d);
+    atomicAdd(&img[id * 4], 1.f);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      atomicAdd(&img[id * 4 + 1 + t], d[t]);
+      s[t] += d[t];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) mm[3 * t + q] += d[t] * d[q];
+    }
+    if (++since == 8) {  // fp32 partials of at most 8 rows, then fp64 (as the direct kernel)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { v[i] += (double)s[i]; s[i] = 0.f; }
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { v[3 + i] += (double)mm[i]; mm[i] = 0.f; }
+      since = 0;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) v[i] += (double)s[i];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) v[3 + i] += (double)mm[i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < n * 4; i += LA_TPB) {
+    const float a = img[i];
+    if (a != 0.f) {
+      const int pt = i >> 2, f = i & 3;
+      if (f == 0) atomicAdd(cnt + (size_t)bi * n + pt, a);
+      else atomicAdd(dsum + ((size_t)bi * n + pt) * 3 + (f - 1), a);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v[i] += __shfl_xor(v[i], off);
+  }
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) part[threadIdx.x >> 6][i] = v[i];
+  __syncthreads();
+  if (threadIdx.x < 12) {
+    double t = 0.0;
+    for (int w = 0; w < LA_TPB / 64; ++w) t += part[w][threadIdx.x];
+    atomicAdd(mom + threadIdx.x, t);
+  }
+}
+
 // column sums over the B*n points:  stats = [sum_p y, sum_p y^2](C),  u = [U_0, U_1, U_2](C)
 constexpr int LA_RB = 32;
 __global__ __launch_bounds__(LA_TPB) void la_col_stats_kernel(const float *__restrict__ G, const float *__restrict__ cnt,
@@ -286,6 +359,18 @@ extern "C" int gb_la_point_stats(const float *xyz, const float *centres, const i
     return GB_EINVAL;
   const long long rows = (long long)b * m * ns;
   if (rows == 0) return GB_OK;
+  if (n <= 4096 && b <= 65535 && rows / b >= 8192) {
+    const long long brows = (long long)m * ns;
+    long long slices = 64 / b;  // ~64 workgroups in all: every extra slice repeats the flush of the n x 4 image
+    if (slices < 1) slices = 1;
+    if (slices > brows / 2048) slices = brows / 2048;
+    const long long rpb = (brows + slices - 1) / slices;
+    slices = (brows + rpb - 1) / rpb;
+    hipLaunchKernelGGL(la_point_stats_lds_kernel, dim3((unsigned)slices, (unsigned)b), dim3(LA_TPB),
+                       (size_t)n * 4 * sizeof(float), as_stream(stream), xyz, centres, idx, n, m, ns, mode, scale, (int)rpb,
+                       cnt, dsum, mom);
+    return check_launch("gb_la_point_stats");
+  }
   const long long blocks = (rows + 8 * LA_TPB - 1) / (8 * LA_TPB);
   if (blocks > 0x7fffffffLL) return GB_ERANGE;
   hipLaunchKernelGGL(la_point_stats_kernel, dim3((unsigned)blocks), dim3(LA_TPB), 0, as_stream(stream), xyz, centres,

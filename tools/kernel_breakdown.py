@@ -16,6 +16,13 @@ BYTES = {
     "gb_affine_relu_maxpool": lambda a: 4 * a[0] * a[1] * a[2] + 8 * a[0] * a[2],       # R, ns, C
     "gb_bn_bwd_stats_pool": lambda a: 4 * a[0] * a[2] * 3 + 4 * a[0] * a[2],            # R, ns, C (argmax rows only)
     "gb_bn_bwd_apply_pool": lambda a: 2 * 4 * a[0] * a[1] * a[2] + 12 * a[0] * a[2],    # R, ns, C, training
+    "gb_bn_bwd_apply_members": lambda a: 0,   # R, D, C, P_total, training: row count unknown here -> time only
+    "gb_affine_relu_maxpool_members": lambda a: 0,
+    "gb_bn_bwd_apply_w": lambda a: 3 * 4 * a[0] * a[2],                 # rows, P_total, C, training
+    "gb_la_pool_bwd": lambda a: 0,
+    "gb_la_point_stats": lambda a: 0,
+    "gb_cyl_unique": lambda a: 0,
+    "gb_cyl_rows": lambda a: 0,
     "gb_group_concat_cl": lambda a: 4 * a[0] * a[2] * a[3] * (3 + a[4]) * 2,            # b, n, m, ns, c, mode
     "gb_group_concat_cl_grad": lambda a: 4 * a[0] * a[2] * a[3] * (3 + a[4]) + 4 * a[0] * a[1] * a[4],
 }

@@ -58,6 +58,43 @@ def _s(t):
 
 _FN = {}
 
+# ---- per-step zero arena for the small fp64 reduction buffers --------------------------------------------------
+# Every fused stack needs a few zero-initialised fp64 buffers (BatchNorm sums, their backward counterparts, moments):
+# ~85 of them per train step, each a separate fill launch.  A training loop that knows its own step boundaries
+# (train.Trainer) calls begin_step(): the buffers then come out of one arena that is re-zeroed once per step.  Nothing
+# taken from the arena may be kept across begin_step() - true for a forward -> backward -> optimizer step; code that
+# keeps several graphs alive simply does not call begin_step() and gets plain torch.zeros.
+_ARENA = {}
+
+
+def begin_step(device):
+    """Start a train step on `device`: re-zero what the previous step took from the fp64 arena and rewind it."""
+    ar = _ARENA.get(str(device))
+    if ar is None:
+        ar = _ARENA[str(device)] = {"buf": torch.zeros(1 << 20, dtype=torch.float64, device=device), "off": 0,
+                                     "live": True}
+    elif ar["off"]:
+        ar["buf"][:ar["off"]].zero_()
+    ar["off"], ar["live"] = 0, True
+
+
+def end_arena(device):
+    """Stop serving buffers from the arena (e.g. before code that keeps results across steps)."""
+    ar = _ARENA.get(str(device))
+    if ar is not None:
+        ar["live"] = False
+
+
+def _zeros64(n, dev):
+    ar = _ARENA.get(str(dev))
+    if ar is not None and ar["live"]:
+        off = ar["off"]
+        end = off + (n + 31) // 32 * 32
+        if end <= ar["buf"].numel():
+            ar["off"] = end
+            return ar["buf"][off:off + n]
+    return torch.zeros(n, dtype=torch.float64, device=dev)
+
 
 def _call(name, dev, *args, meta=None):
     """One C-ABI launch.  Fast path (no timer, tensor on the current device): a cached ctypes function and nothing
@@ -266,7 +303,7 @@ class MLPStack(Function):
         stat_off = [0]
         for l, cfg in enumerate(layers):
             stat_off.append(stat_off[-1] + (slots * 2 * widths[l] if cfg.training else 0))
-        stat_arena = torch.zeros(stat_off[-1], dtype=torch.float64, device=dev) if stat_off[-1] else None
+        stat_arena = _zeros64(stat_off[-1], dev) if stat_off[-1] else None
         ab_arena = torch.empty(4 * sum(widths), dtype=torch.float32, device=dev)
         Ws, Ys, abs_ = [], [], []
         src, aff, ab_off = X0, None, 0
@@ -341,7 +378,7 @@ class MLPStack(Function):
         d_off = [2 * widths[-1]]
         for l in range(L - 1):
             d_off.append(d_off[-1] + ((slots + 1) * 2 * widths[l] if fused[l] and slots > 1 else 2 * widths[l]))
-        d_arena = torch.zeros(d_off[-1], dtype=torch.float64, device=dev)
+        d_arena = _zeros64(d_off[-1], dev)
         need_w = [ctx.needs_input_grad[6 + 3 * l] for l in range(L)]
         kin = [X0.shape[1]] + widths[:-1]
         w_off = [0]
@@ -408,7 +445,7 @@ class MLPStack(Function):
                     and _lib.lib().gb_gemm_uses_rs(P, K, N, 1, 2, 0)):
                 # xyz-only first layer: its dZ is never written - five column sums out of the dgrad epilogue give its
                 # BatchNorm gradients and, with the 12 moments of the input rows, its weight gradient in closed form
-                z = torch.zeros(slots * 5 * K + 3 * K + 12, dtype=torch.float64, device=dev)
+                z = _zeros64(slots * 5 * K + 3 * K + 12, dev)
                 sums, u0, mom = z[:slots * 5 * K], z[slots * 5 * K:slots * 5 * K + 3 * K], z[slots * 5 * K + 3 * K:]
                 _call("gb_gemm_dgrad_first", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(Ys[0]), _lib.ptr(abs_[0]),
                       _lib.ptr(X0), _lib.ptr(sums), slots, P, K, N, st,
@@ -462,7 +499,7 @@ class LocalGeometry:
         dev = xyz.device
         pts = torch.zeros(self.b * self.n * 4, dtype=torch.float32, device=dev)
         self.cnt, self.dsum = pts[:self.b * self.n], pts[self.b * self.n:]
-        self.mom = torch.zeros(12, dtype=torch.float64, device=dev)
+        self.mom = _zeros64(12, dev)
         _call("gb_la_point_stats", dev, _lib.ptr(self.xyz), _lib.ptr(self.centres), _lib.ptr(self.idx), self.b, self.n,
               self.m, self.ns, self.mode, self.scale, _lib.ptr(self.cnt), _lib.ptr(self.dsum), _lib.ptr(self.mom),
               _s(xyz))
@@ -492,7 +529,7 @@ class LocalAggPool(Function):
         G = torch.empty((rows, N), dtype=torch.float32, device=dev)
         _call("gb_gemm_fwd", dev, _lib.ptr(f), _lib.ptr(Wf), None, _lib.ptr(G), None, 1, rows, C, N, st,
               meta=_gemm_meta("fwd", rows, C, N))
-        sums = torch.zeros(5 * N, dtype=torch.float64, device=dev)  # [sum y, sum y^2, U0, U1, U2]
+        sums = _zeros64(5 * N, dev)  # [sum y, sum y^2, U0, U1, U2]
         stats, u = sums[:2 * N], sums[2 * N:]
         if cfg.training:
             _call("gb_la_col_stats", dev, _lib.ptr(G), _lib.ptr(geo.cnt), _lib.ptr(geo.dsum), _lib.ptr(Wx),
@@ -519,7 +556,7 @@ class LocalAggPool(Function):
         N, C = Wf.shape
         rows, P = geo.b * geo.n, geo.rows
         sg = torch.zeros((rows, N), dtype=torch.float32, device=dev)
-        red = torch.zeros(5 * N, dtype=torch.float64, device=dev)  # [dbeta, dgamma, T0, T1, T2]
+        red = _zeros64(5 * N, dev)  # [dbeta, dgamma, T0, T1, T2]
         _call("gb_la_pool_bwd", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(G), _lib.ptr(geo.xyz),
               _lib.ptr(geo.centres), _lib.ptr(geo.idx), _lib.ptr(Wx), _lib.ptr(ab), _lib.ptr(sg), _lib.ptr(red), geo.b,
               geo.n, geo.m, geo.ns, N, geo.mode, geo.scale, st)

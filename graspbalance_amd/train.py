@@ -7,6 +7,7 @@ import torch
 import torch.optim as optim
 from torch.optim.lr_scheduler import OneCycleLR
 
+from . import fused_mlp
 from .data_parallel import FlatGradAllReduce, broadcast_module
 from .graspbalance import GraspBalance
 from .loss import get_loss
@@ -40,6 +41,8 @@ class Trainer:
     def train_step(self, batch):
         """forward -> loss -> backward -> gradient all-reduce -> Adam step -> LR step.  Returns the
         loss tensor (no host sync here; the reference's per-key .item() logging is the caller's)."""
+        if self.device.type == "cuda":
+            fused_mlp.begin_step(self.device)  # one re-zeroed arena for the step's small fp64 reduction buffers
         end_points = self.net(dict(batch))  # the network adds its outputs to the dict it is given
         loss, end_points = get_loss(end_points)
         loss.backward()

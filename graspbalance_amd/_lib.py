@@ -29,6 +29,7 @@ SIGNATURES = {
     "gb_fps": [_P, _P, _P, _I, _I, _I, _U, _P],
     "gb_fps_pruned": [_P, _P, _P, _P, _I, _I, _I, _U, _P],
     "gb_fps_morton_keys": [_P, _P, _I, _I, _P],
+    "gb_fps_guarded": [_P, _P, _P, _I, _I, _I, _U, _P, _P, _P, _P],
     "gb_gather": [_P, _P, _P, _I, _I, _I, _I, _P],
     "gb_gather_grad": [_P, _P, _P, _I, _I, _I, _I, _P],
     "gb_ball_query": [_P, _P, _P, _P, _I, _I, _I, _F, _I, _P],
@@ -168,6 +169,8 @@ def event_pair_overhead_ms(device, pairs=64):
 
 FPS_PRUNE_MIN_N, FPS_PRUNE_MAX_N, FPS_PRUNE_MIN_M = 8192, 20480, 128
 _fps_prune = os.environ.get("GB_FPS_PRUNE", "1") != "0"  # A/B switch
+FPS_PREFIX_MAX_N = 4096
+_fps_prefix = os.environ.get("GB_FPS_PREFIX", "1") != "0"  # A/B switch
 
 
 def fps(points, temp, output, b, n, m, flags, stream):
@@ -180,6 +183,13 @@ def fps(points, temp, output, b, n, m, flags, stream):
             return rc
         perm = torch.argsort(keys, dim=1).to(torch.int32)
         return lib().gb_fps_pruned(ptr(points), ptr(perm), ptr(temp), ptr(output), b, n, m, flags, stream)
+    if _fps_prefix and n <= FPS_PREFIX_MAX_N and 64 <= m <= n:
+        # small clouds are usually the centres of the previous level, i.e. already in farthest-point order: verify
+        # "samples = 0..m-1" in parallel and skip the sequential loop where it holds (identical outputs either way)
+        ws = torch.empty(b * (m + n), dtype=torch.float32, device=points.device)
+        ok = torch.empty(b, dtype=torch.int32, device=points.device)
+        return lib().gb_fps_guarded(ptr(points), ptr(temp), ptr(output), b, n, m, flags, ptr(ws),
+                                    _c.c_void_p(ws.data_ptr() + 4 * b * m), ptr(ok), stream)
     return lib().gb_fps(ptr(points), ptr(temp), ptr(output), b, n, m, flags, stream)
 
 

@@ -74,13 +74,21 @@ template <int BLOCK, int P>
 __global__ __launch_bounds__(BLOCK) void fps_reg_kernel(const float *__restrict__ xyz,
                                                          float *__restrict__ temp_io,
                                                          int32_t *__restrict__ idx, int n, int m,
-                                                         int skip, int bs_log2) {
+                                                         int skip, int bs_log2, const int32_t *__restrict__ guard,
+                                                         const float *__restrict__ guard_temp) {
   __shared__ float s_d[32];
   __shared__ unsigned s_key[32];
   const int tid = threadIdx.x;
   const float *pts = xyz + (size_t)blockIdx.x * n * 3;
   int32_t *out = idx + (size_t)blockIdx.x * m;
   float *tio = temp_io ? temp_io + (size_t)blockIdx.x * n : nullptr;
+  if (guard && guard[blockIdx.x]) {
+    // gb_fps_guarded: the prefix check proved that the samples are 0..m-1 (already written); only the running
+    // min-distances remain to be handed over
+    if (tio)
+      for (int k = tid; k < n; k += BLOCK) tio[k] = guard_temp[(size_t)blockIdx.x * n + k];
+    return;
+  }
 
   float px[P], py[P], pz[P], pt[P];
 #pragma unroll
@@ -346,17 +354,18 @@ static int floor_log2(int v) {
 
 template <int BLOCK, int P>
 static void launch_reg(const float *xyz, float *temp, int32_t *idx, int b, int n, int m, int skip,
-                       int bs_log2, hipStream_t s) {
+                       int bs_log2, hipStream_t s, const int32_t *guard, const float *guard_temp) {
   hipLaunchKernelGGL((fps_reg_kernel<BLOCK, P>), dim3(b), dim3(BLOCK), 0, s, xyz, temp, idx, n, m,
-                     skip, bs_log2);
+                     skip, bs_log2, guard, guard_temp);
 }
 
 template <int BLOCK>
 static bool dispatch_p(int p_need, const float *xyz, float *temp, int32_t *idx, int b, int n, int m,
-                       int skip, int bs_log2, hipStream_t s) {
+                       int skip, int bs_log2, hipStream_t s, const int32_t *guard = nullptr,
+                       const float *guard_temp = nullptr) {
 #define GB_CASE(PV)                                                            \
   if (p_need <= PV) {                                                          \
-    launch_reg<BLOCK, PV>(xyz, temp, idx, b, n, m, skip, bs_log2, s);          \
+    launch_reg<BLOCK, PV>(xyz, temp, idx, b, n, m, skip, bs_log2, s, guard, guard_temp); \
     return true;                                                               \
   }
   GB_CASE(1) GB_CASE(2) GB_CASE(4) GB_CASE(8)
@@ -368,8 +377,8 @@ static bool dispatch_p(int p_need, const float *xyz, float *temp, int32_t *idx, 
 
 }  // namespace gb
 
-extern "C" int gb_fps(const float *xyz, float *temp, int32_t *idx, int b, int n, int m,
-                      unsigned flags, void *stream) {
+static int fps_impl(const float *xyz, float *temp, int32_t *idx, int b, int n, int m, unsigned flags, void *stream,
+                    const int32_t *guard, const float *guard_temp) {
   using namespace gb;
   if (b < 0 || n < 1 || m < 0 || !xyz || !idx) return GB_EINVAL;
   if ((long long)n * 3 > 0x7fffffffLL) return GB_ERANGE;
@@ -391,15 +400,113 @@ extern "C" int gb_fps(const float *xyz, float *temp, int32_t *idx, int b, int n,
   if (bs_log2 >= 0 && (1 << bs_log2) > block) block = 1 << bs_log2;
   bool done = false;
   const int p_need = ceil_div(n, block);
-  if (block == 256) done = dispatch_p<256>(p_need, xyz, temp, idx, b, n, m, skip, bs_log2, s);
-  else if (block == 512) done = dispatch_p<512>(p_need, xyz, temp, idx, b, n, m, skip, bs_log2, s);
-  else done = dispatch_p<1024>(p_need, xyz, temp, idx, b, n, m, skip, bs_log2, s);
+  if (block == 256) done = dispatch_p<256>(p_need, xyz, temp, idx, b, n, m, skip, bs_log2, s, guard, guard_temp);
+  else if (block == 512) done = dispatch_p<512>(p_need, xyz, temp, idx, b, n, m, skip, bs_log2, s, guard, guard_temp);
+  else done = dispatch_p<1024>(p_need, xyz, temp, idx, b, n, m, skip, bs_log2, s, guard, guard_temp);
   if (!done) {
+    if (guard) return GB_ERANGE;  // guarded form: register-resident clouds only
     if (!temp) return GB_EINVAL;  // the streaming path needs the caller's (b,n) scratch
     hipLaunchKernelGGL((fps_stream_kernel<1024>), dim3(b), dim3(1024), 0, s, xyz, temp, idx, n, m,
                        skip, bs_log2);
   }
   return check_launch("gb_fps");
+}
+
+extern "C" int gb_fps(const float *xyz, float *temp, int32_t *idx, int b, int n, int m, unsigned flags, void *stream) {
+  return fps_impl(xyz, temp, idx, b, n, m, flags, stream, nullptr, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Prefix check.  FPS of an FPS: when the input points are themselves in farthest-point order (the centres of set
+// abstraction level l are the first 2048 samples of level l-1's sampling, in order), the m samples are 0..m-1 -
+// the j-th pick over the whole previous cloud was point j, which is in the subset, so it is also the pick within
+// it.  That holds unless an exact tie is broken differently (the tie key depends on the index within the set).
+// Instead of 1023 sequential iterations the hypothesis "the result is 0..m-1" is VERIFIED in parallel, exactly:
+//   T[j]  = min(temp0[j], min_{i<j} d(j, i))        the value point j must win with          (thread per j)
+//   every point k: its running min-distance t_k after samples 0..j-1 must not beat T[j]      (thread per k, no
+//   (t_k > T[j], or t_k == T[j] with a smaller tie key) for any j                             cross-thread step)
+// ok[cloud] = 1 only if no point objects; the FPS kernel launched next returns at once for such clouds (idx and the
+// final min-distances come from here) and runs normally otherwise.  Same outputs as gb_fps in every case.
+namespace gb {
+// Both kernels stage the m samples (x, y, z, T) in LDS first: their loops then read broadcast LDS words instead of
+// issuing a dependent global load per iteration (which would cost as much as the sequential FPS they replace).
+__global__ __launch_bounds__(256) void fps_prefix_T_kernel(const float *__restrict__ xyz, const float *__restrict__ temp0,
+                                                           int n, int m, int skip, float *__restrict__ T,
+                                                           int32_t *__restrict__ idx, int32_t *__restrict__ ok) {
+  extern __shared__ float4 smp[];  // [m] = (x, y, z, -)
+  const float *pts = xyz + (size_t)blockIdx.y * n * 3;
+  for (int i = threadIdx.x; i < m; i += 256) smp[i] = make_float4(pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2], 0.f);
+  __syncthreads();
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j == 0) ok[blockIdx.y] = 1;
+  if (j >= m) return;
+  idx[(size_t)blockIdx.y * m + j] = j;
+  const float x = smp[j].x, y = smp[j].y, z = smp[j].z;
+  float t = temp0 ? temp0[(size_t)blockIdx.y * n + j] : 1e10f;
+  if (skip && (((x * x) + (y * y)) + (z * z)) < 1e-3f) t = -1.0f;  // point j can never be picked (j >= 1)
+  else
+    for (int i = 0; i < j; ++i) {
+      const float4 q = smp[i];
+      const float dx = x - q.x, dy = y - q.y, dz = z - q.z;
+      t = __builtin_fminf(((dx * dx) + (dy * dy)) + (dz * dz), t);
+    }
+  T[(size_t)blockIdx.y * m + j] = t;
+}
+
+__global__ __launch_bounds__(256) void fps_prefix_verify_kernel(const float *__restrict__ xyz,
+                                                                const float *__restrict__ temp0, int n, int m,
+                                                                int skip, int bs_log2, const float *__restrict__ T,
+                                                                float *__restrict__ temp_out, int32_t *__restrict__ ok) {
+  extern __shared__ float4 smp[];  // [m] = (x, y, z, T)
+  const float *pts = xyz + (size_t)blockIdx.y * n * 3;
+  const float *Tc = T + (size_t)blockIdx.y * m;
+  for (int i = threadIdx.x; i < m; i += 256) smp[i] = make_float4(pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2], Tc[i]);
+  __syncthreads();
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const float x = pts[k * 3], y = pts[k * 3 + 1], z = pts[k * 3 + 2];
+  const float t0 = temp0 ? temp0[(size_t)blockIdx.y * n + k] : 1e10f;
+  const bool sk = skip && (((x * x) + (y * y)) + (z * z)) < 1e-3f;
+  const unsigned mykey = fps_key(k, bs_log2);
+  float t = t0;
+  bool bad = false;
+  float4 prev = smp[0];
+  for (int j = 1; j < m; ++j) {
+    const float4 cur = smp[j];  // sample j's coordinates (needed next iteration) and T[j]
+    const float dx = x - prev.x, dy = y - prev.y, dz = z - prev.z;
+    t = __builtin_fminf(((dx * dx) + (dy * dy)) + (dz * dz), t);
+    const float tj = cur.w;
+    if (k == j) bad |= sk || !(tj >= 0.f);                                          // j itself must be a candidate
+    else if (!sk) bad |= t > tj || (t == tj && mykey < fps_key(j, bs_log2));       // nobody may beat it
+    prev = cur;
+  }
+  temp_out[(size_t)blockIdx.y * n + k] = sk ? t0 : t;
+  if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicExch(ok + blockIdx.y, 0);
+}
+}  // namespace gb
+
+extern "C" int gb_fps_guarded(const float *xyz, float *temp, int32_t *idx, int b, int n, int m, unsigned flags,
+                              float *scratch_T, float *scratch_temp, int32_t *ok, void *stream) {
+  using namespace gb;
+  if (b < 0 || n < 1 || m < 1 || m > n || !xyz || !idx || !scratch_T || !scratch_temp || !ok) return GB_EINVAL;
+  if (b > 65535 || n > 24576 || m > 4096) return GB_ERANGE;  // the m samples are staged in 64 KB of LDS
+  if (b == 0) return GB_OK;
+  const unsigned tie = flags & GB_FPS_TIE_MASK;
+  if (tie != GB_FPS_TIE_LOWEST && tie != GB_FPS_TIE_TREE512 && tie != GB_FPS_TIE_TREE1024) return GB_EINVAL;
+  const int skip = (flags & GB_FPS_SKIP_NEAR_ORIGIN) ? 1 : 0;
+  int bs_log2 = -1;
+  if (tie != GB_FPS_TIE_LOWEST) {
+    const int cap = tie == GB_FPS_TIE_TREE512 ? 9 : 10;
+    bs_log2 = floor_log2(n) < cap ? floor_log2(n) : cap;
+  }
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(fps_prefix_T_kernel, dim3((m + 255) / 256, b), dim3(256), (size_t)m * sizeof(float4), s, xyz, temp, n,
+                     m, skip, scratch_T, idx, ok);
+  hipLaunchKernelGGL(fps_prefix_verify_kernel, dim3((n + 255) / 256, b), dim3(256), (size_t)m * sizeof(float4), s, xyz, temp,
+                     n, m, skip, bs_log2, scratch_T, scratch_temp, ok);
+  const int rc = check_launch("gb_fps_guarded");
+  if (rc != GB_OK) return rc;
+  return fps_impl(xyz, temp, idx, b, n, m, flags, stream, ok, scratch_temp);
 }
 
 extern "C" int gb_fps_morton_keys(const float *xyz, int32_t *keys, int b, int n, void *stream) {

@@ -77,6 +77,12 @@ int gb_fps_pruned(const float *xyz, const int32_t *perm, float *temp, int32_t *i
                   unsigned flags, void *stream);
 /* keys (b,n) int32: 30-bit Morton code of each point within its cloud's bounding box.                   */
 int gb_fps_morton_keys(const float *xyz, int32_t *keys, int b, int n, void *stream);
+/* gb_fps preceded by a parallel, exact check of the hypothesis "the samples are 0..m-1" (true when the input is
+ * itself in farthest-point order, e.g. the centres of the previous set-abstraction level, and no exact tie is broken
+ * differently): clouds that pass skip the m-1 sequential iterations, the others run them.  Same outputs as gb_fps
+ * in every case.  scratch_T (b,m), scratch_temp (b,n) floats, ok (b) int32: workspace.  n <= 24576, m <= n.        */
+int gb_fps_guarded(const float *xyz, float *temp, int32_t *idx, int b, int n, int m, unsigned flags, float *scratch_T,
+                   float *scratch_temp, int32_t *ok, void *stream);
 
 /* out[b,c,j] = points[b,c,idx[b,j]]  — gather_points_kernel_wrapper (PN sampling_gpu.cu:27-35),
  * gather_points_kernel_launcher_fast (PB sampling_gpu.cu:21-33). points (b,c,n), idx (b,m).      */

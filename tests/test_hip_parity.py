@@ -342,3 +342,46 @@ def test_fps_pruned_is_the_same_sequence(orc, tie, skip):
             torch.cuda.synchronize()
             assert torch.equal(idx.cpu(), want), (tie, skip, name, B, N, m)
             assert torch.equal(temp.cpu(), temp_o), ("running min-distance state differs", name)
+
+
+@pytest.mark.parametrize("tie", ["lowest", "tree512", "tree1024"])
+@pytest.mark.parametrize("skip", [0, 1])
+def test_fps_guarded_prefix_check(orc, tie, skip):
+    """gb_fps_guarded = gb_fps in every case: inputs already in farthest-point order (the check passes and the
+    sequential loop is skipped), the same with exact ties (lattice / duplicated points: the check may fail and the
+    loop runs), arbitrary clouds (fails at once), near-origin points; samples and running min-distances."""
+    import torch
+    from graspbalance_amd import _lib
+    g = torch.Generator().manual_seed(21)
+    flags = {"lowest": _lib.FPS_TIE_LOWEST, "tree512": _lib.FPS_TIE_TREE512, "tree1024": _lib.FPS_TIE_TREE1024}[tie] | skip
+
+    def fps_order(xyz, m0):  # reorder every cloud into its own farthest-point order (oracle)
+        idx = orc.furthest_point_sampling(xyz, m0, flags)
+        return torch.gather(xyz, 1, idx.long()[:, :, None].expand(-1, -1, 3)).contiguous()
+
+    scene = torch.from_numpy(make_batch([7, 8], 6000))
+    lattice = torch.randint(0, 7, (2, 3000, 3), generator=g).float() * 0.2
+    lattice[:, 2000:] = lattice[:, :1000]
+    cases = [(fps_order(scene, 2048), 1024, True), (fps_order(scene, 1024), 512, True), (fps_order(scene, 300), 300, True),
+             (fps_order(lattice, 1500), 700, False), (scene[:, :3000].contiguous(), 500, False),
+             (torch.rand(3, 100, 3, generator=g) * 0.02, 64, False)]
+    passed = 0
+    for xyz, m, expect_identity in cases:
+        B, N = xyz.shape[:2]
+        dev = xyz.to(DEV)
+        idx = torch.full((B, m), -7, dtype=torch.int32, device=DEV)
+        temp = torch.full((B, N), 1e10, device=DEV)
+        ws = torch.empty(B * (m + N), device=DEV)
+        ok = torch.full((B,), -1, dtype=torch.int32, device=DEV)
+        _lib.check(_lib.lib().gb_fps_guarded(_lib.ptr(dev), _lib.ptr(temp), _lib.ptr(idx), B, N, m, flags, _lib.ptr(ws),
+                                             _lib._c.c_void_p(ws.data_ptr() + 4 * B * m), _lib.ptr(ok), None), "guarded")
+        torch.cuda.synchronize()
+        temp_o = torch.full((B, N), 1e10)
+        want = orc.furthest_point_sampling(xyz, m, flags, temp=temp_o)
+        assert torch.equal(idx.cpu(), want), (tie, skip, N, m)
+        assert torch.equal(temp.cpu(), temp_o), "running min-distance state differs"
+        if expect_identity and not skip:
+            assert torch.equal(want, torch.arange(m, dtype=torch.int32).repeat(B, 1))
+            assert bool((ok == 1).all()), "prefix check should have passed on farthest-point-ordered input"
+        passed += int((ok == 1).sum())
+    assert passed > 0

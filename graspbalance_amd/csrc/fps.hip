@@ -445,10 +445,16 @@ __global__ __launch_bounds__(256) void fps_prefix_T_kernel(const float *__restri
   float t = temp0 ? temp0[(size_t)blockIdx.y * n + j] : 1e10f;
   if (skip && (((x * x) + (y * y)) + (z * z)) < 1e-3f) t = -1.0f;  // point j can never be picked (j >= 1)
   else
-    for (int i = 0; i < j; ++i) {
-      const float4 q = smp[i];
-      const float dx = x - q.x, dy = y - q.y, dz = z - q.z;
-      t = __builtin_fminf(((dx * dx) + (dy * dy)) + (dz * dz), t);
+    for (int i0 = 0; i0 < j; i0 += 8) {
+      float4 q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q[u] = smp[i0 + u < j ? i0 + u : j];  // clamp to j itself: d = 0... excluded below
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u < j) {
+          const float dx = x - q[u].x, dy = y - q[u].y, dz = z - q[u].z;
+          t = __builtin_fminf(((dx * dx) + (dy * dy)) + (dz * dz), t);
+        }
     }
   T[(size_t)blockIdx.y * m + j] = t;
 }
@@ -471,14 +477,25 @@ __global__ __launch_bounds__(256) void fps_prefix_verify_kernel(const float *__r
   float t = t0;
   bool bad = false;
   float4 prev = smp[0];
-  for (int j = 1; j < m; ++j) {
-    const float4 cur = smp[j];  // sample j's coordinates (needed next iteration) and T[j]
-    const float dx = x - prev.x, dy = y - prev.y, dz = z - prev.z;
-    t = __builtin_fminf(((dx * dx) + (dy * dy)) + (dz * dz), t);
-    const float tj = cur.w;
-    if (k == j) bad |= sk || !(tj >= 0.f);                                          // j itself must be a candidate
-    else if (!sk) bad |= t > tj || (t == tj && mykey < fps_key(j, bs_log2));       // nobody may beat it
-    prev = cur;
+  for (int j0 = 1; j0 < m; j0 += 8) {
+    float4 cur[8];  // samples j0..j0+7: coordinates (used one step later) and T; 8 LDS reads in flight
+#pragma unroll
+    for (int u = 0; u < 8; ++u) cur[u] = smp[j0 + u < m ? j0 + u : m - 1];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = j0 + u;
+      if (j < m) {
+        const float dx = x - prev.x, dy = y - prev.y, dz = z - prev.z;
+        t = __builtin_fminf(((dx * dx) + (dy * dy)) + (dz * dz), t);
+        const float tj = cur[u].w;
+        if (k == j) bad |= sk || !(tj >= 0.f);  // j itself must be a candidate
+        else if (!sk) {                          // nobody may beat it
+          bad |= t > tj;
+          if (t == tj) bad |= mykey < fps_key(j, bs_log2);
+        }
+        prev = cur[u];
+      }
+    }
   }
   temp_out[(size_t)blockIdx.y * n + k] = sk ? t0 : t;
   if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicExch(ok + blockIdx.y, 0);

@@ -437,28 +437,37 @@ __global__ __launch_bounds__(256) void fps_prefix_T_kernel(const float *__restri
   const float *pts = xyz + (size_t)blockIdx.y * n * 3;
   for (int i = threadIdx.x; i < m; i += 256) smp[i] = make_float4(pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2], 0.f);
   __syncthreads();
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j == 0) ok[blockIdx.y] = 1;
-  if (j >= m) return;
+  // eight lanes per sample j, lane e takes i = e, e+8, ... < j; min over the eight at the end
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int j = gid / 8, e = gid % 8;
+  if (gid == 0) ok[blockIdx.y] = 1;
+  const int jj = j < m ? j : m - 1;
+  const float x = smp[jj].x, y = smp[jj].y, z = smp[jj].z;
+  float t = 3.0e38f;
+  for (int i0 = e; i0 < jj; i0 += 64) {
+    float4 q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) q[u] = smp[i0 + 8 * u < jj ? i0 + 8 * u : jj];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + 8 * u < jj) {
+        const float dx = x - q[u].x, dy = y - q[u].y, dz = z - q[u].z;
+        t = __builtin_fminf(((dx * dx) + (dy * dy)) + (dz * dz), t);
+      }
+  }
+#pragma unroll
+  for (int off = 4; off >= 1; off >>= 1) t = __builtin_fminf(__shfl_xor(t, off, 8), t);
+  if (j >= m || e != 0) return;
   idx[(size_t)blockIdx.y * m + j] = j;
-  const float x = smp[j].x, y = smp[j].y, z = smp[j].z;
-  float t = temp0 ? temp0[(size_t)blockIdx.y * n + j] : 1e10f;
+  t = __builtin_fminf(temp0 ? temp0[(size_t)blockIdx.y * n + j] : 1e10f, t);
   if (skip && (((x * x) + (y * y)) + (z * z)) < 1e-3f) t = -1.0f;  // point j can never be picked (j >= 1)
-  else
-    for (int i0 = 0; i0 < j; i0 += 8) {
-      float4 q[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) q[u] = smp[i0 + u < j ? i0 + u : j];  // clamp to j itself: d = 0... excluded below
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (i0 + u < j) {
-          const float dx = x - q[u].x, dy = y - q[u].y, dz = z - q[u].z;
-          t = __builtin_fminf(((dx * dx) + (dy * dy)) + (dz * dz), t);
-        }
-    }
   T[(size_t)blockIdx.y * m + j] = t;
 }
 
+// Eight lanes per point k, each walking one eighth of the samples twice: first its segment's minimum distance to k
+// (so the running minimum at the START of every segment is a prefix over 8 lanes), then the segment again with the
+// true running value, checking it against T[j].  Twice the arithmetic, one eighth of the dependent iterations.
+constexpr int FPV_S = 8;
 __global__ __launch_bounds__(256) void fps_prefix_verify_kernel(const float *__restrict__ xyz,
                                                                 const float *__restrict__ temp0, int n, int m,
                                                                 int skip, int bs_log2, const float *__restrict__ T,
@@ -468,36 +477,64 @@ __global__ __launch_bounds__(256) void fps_prefix_verify_kernel(const float *__r
   const float *Tc = T + (size_t)blockIdx.y * m;
   for (int i = threadIdx.x; i < m; i += 256) smp[i] = make_float4(pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2], Tc[i]);
   __syncthreads();
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= n) return;
-  const float x = pts[k * 3], y = pts[k * 3 + 1], z = pts[k * 3 + 2];
-  const float t0 = temp0 ? temp0[(size_t)blockIdx.y * n + k] : 1e10f;
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int k = gid / FPV_S, sgm = gid % FPV_S;
+  const bool live = k < n;
+  const int kk = live ? k : n - 1;
+  const float x = pts[kk * 3], y = pts[kk * 3 + 1], z = pts[kk * 3 + 2];
+  const float t0 = temp0 ? temp0[(size_t)blockIdx.y * n + kk] : 1e10f;
   const bool sk = skip && (((x * x) + (y * y)) + (z * z)) < 1e-3f;
-  const unsigned mykey = fps_key(k, bs_log2);
-  float t = t0;
-  bool bad = false;
-  float4 prev = smp[0];
-  for (int j0 = 1; j0 < m; j0 += 8) {
-    float4 cur[8];  // samples j0..j0+7: coordinates (used one step later) and T; 8 LDS reads in flight
+  const unsigned mykey = fps_key(kk, bs_log2);
+  const int len = (m - 1 + FPV_S - 1) / FPV_S;        // iterations j = 1..m-1 split into FPV_S segments
+  const int j_lo = 1 + sgm * len, j_hi = (j_lo + len < m) ? j_lo + len : m;
+  // pass 1: minimum over my segment's samples (sample j-1 enters at iteration j)
+  float mseg = 3.0e38f;
+  for (int j0 = j_lo; j0 < j_hi; j0 += 8) {
+    float4 q[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) cur[u] = smp[j0 + u < m ? j0 + u : m - 1];
+    for (int u = 0; u < 8; ++u) q[u] = smp[(j0 + u < j_hi ? j0 + u : j_hi - 1) - 1];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (j0 + u < j_hi) {
+        const float dx = x - q[u].x, dy = y - q[u].y, dz = z - q[u].z;
+        mseg = __builtin_fminf(((dx * dx) + (dy * dy)) + (dz * dz), mseg);
+      }
+  }
+  // exclusive prefix-min over the FPV_S lanes of this point (lanes are consecutive: width-8 shuffles)
+  float t = t0;
+#pragma unroll
+  for (int e = 1; e < FPV_S; ++e) {
+    const float other = __shfl_up(mseg, e, FPV_S);
+    if (sgm >= e) t = __builtin_fminf(other, t);
+  }
+  // pass 2: the true running value through my segment, against T[j]
+  bool bad = false;
+  for (int j0 = j_lo; j0 < j_hi; j0 += 8) {
+    float4 q[8];
+    float tj[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = j0 + u < j_hi ? j0 + u : j_hi - 1;
+      q[u] = smp[j - 1];
+      tj[u] = smp[j].w;
+    }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int j = j0 + u;
-      if (j < m) {
-        const float dx = x - prev.x, dy = y - prev.y, dz = z - prev.z;
+      if (j < j_hi) {
+        const float dx = x - q[u].x, dy = y - q[u].y, dz = z - q[u].z;
         t = __builtin_fminf(((dx * dx) + (dy * dy)) + (dz * dz), t);
-        const float tj = cur[u].w;
-        if (k == j) bad |= sk || !(tj >= 0.f);  // j itself must be a candidate
-        else if (!sk) {                          // nobody may beat it
-          bad |= t > tj;
-          if (t == tj) bad |= mykey < fps_key(j, bs_log2);
+        if (kk == j) bad |= sk || !(tj[u] >= 0.f);  // j itself must be a candidate
+        else if (!sk) {                              // nobody may beat it
+          bad |= t > tj[u];
+          if (t == tj[u]) bad |= mykey < fps_key(j, bs_log2);
         }
-        prev = cur[u];
       }
     }
   }
-  temp_out[(size_t)blockIdx.y * n + k] = sk ? t0 : t;
+  bad = bad && live;
+  // the last non-empty segment ends with the final running value; empty trailing segments just carry the prefix
+  if (live && sgm == FPV_S - 1) temp_out[(size_t)blockIdx.y * n + k] = sk ? t0 : t;
   if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicExch(ok + blockIdx.y, 0);
 }
 }  // namespace gb
@@ -517,10 +554,10 @@ extern "C" int gb_fps_guarded(const float *xyz, float *temp, int32_t *idx, int b
     bs_log2 = floor_log2(n) < cap ? floor_log2(n) : cap;
   }
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(fps_prefix_T_kernel, dim3((m + 255) / 256, b), dim3(256), (size_t)m * sizeof(float4), s, xyz, temp, n,
+  hipLaunchKernelGGL(fps_prefix_T_kernel, dim3((m * 8 + 255) / 256, b), dim3(256), (size_t)m * sizeof(float4), s, xyz, temp, n,
                      m, skip, scratch_T, idx, ok);
-  hipLaunchKernelGGL(fps_prefix_verify_kernel, dim3((n + 255) / 256, b), dim3(256), (size_t)m * sizeof(float4), s, xyz, temp,
-                     n, m, skip, bs_log2, scratch_T, scratch_temp, ok);
+  hipLaunchKernelGGL(fps_prefix_verify_kernel, dim3((n * FPV_S + 255) / 256, b), dim3(256), (size_t)m * sizeof(float4), s, xyz,
+                     temp, n, m, skip, bs_log2, scratch_T, scratch_temp, ok);
   const int rc = check_launch("gb_fps_guarded");
   if (rc != GB_OK) return rc;
   return fps_impl(xyz, temp, idx, b, n, m, flags, stream, ok, scratch_temp);

@@ -27,7 +27,7 @@ _P, _I, _F, _U, _L = _c.c_void_p, _c.c_int, _c.c_float, _c.c_uint, _c.c_longlong
 # shared object exports exactly what include/graspbal.h declares.
 SIGNATURES = {
     "gb_fps": [_P, _P, _P, _I, _I, _I, _U, _P],
-    "gb_fps_pruned": [_P, _P, _P, _P, _I, _I, _I, _U, _P],
+    "gb_fps_pruned": [_P, _P, _P, _P, _I, _I, _I, _U, _P, _P],
     "gb_fps_morton_keys": [_P, _P, _I, _I, _P],
     "gb_fps_guarded": [_P, _P, _P, _I, _I, _I, _U, _P, _P, _P, _P],
     "gb_gather": [_P, _P, _P, _I, _I, _I, _I, _P],
@@ -167,7 +167,7 @@ def event_pair_overhead_ms(device, pairs=64):
     return ms[len(ms) // 2]
 
 
-FPS_PRUNE_MIN_N, FPS_PRUNE_MAX_N, FPS_PRUNE_MIN_M = 8192, 20480, 128
+FPS_PRUNE_MIN_N, FPS_PRUNE_MAX_N, FPS_PRUNE_MIN_M = 8192, 65536, 128
 _fps_prune = os.environ.get("GB_FPS_PRUNE", "1") != "0"  # A/B switch
 FPS_PREFIX_MAX_N = 4096
 _fps_prefix = os.environ.get("GB_FPS_PREFIX", "1") != "0"  # A/B switch
@@ -182,7 +182,8 @@ def fps(points, temp, output, b, n, m, flags, stream):
         if rc != GB_OK:
             return rc
         perm = torch.argsort(keys, dim=1).to(torch.int32)
-        return lib().gb_fps_pruned(ptr(points), ptr(perm), ptr(temp), ptr(output), b, n, m, flags, stream)
+        scratch = torch.empty((b, n, 4), dtype=torch.float32, device=points.device) if n > 20480 else None
+        return lib().gb_fps_pruned(ptr(points), ptr(perm), ptr(temp), ptr(output), b, n, m, flags, ptr(scratch), stream)
     if _fps_prefix and n <= FPS_PREFIX_MAX_N and 64 <= m <= n:
         # small clouds are usually the centres of the previous level, i.e. already in farthest-point order: verify
         # "samples = 0..m-1" in parallel and skip the sequential loop where it holds (identical outputs either way)

@@ -263,6 +263,108 @@ __global__ __launch_bounds__(BLOCK) void fps_pruned_kernel(const float *__restri
   }
 }
 
+// The same for clouds beyond one CU's register file (20 480 < n <= 65 536): only the running min-distances stay in
+// registers (P <= 64 per lane); a row's coordinates and tie keys are re-read from a sorted (x, y, z, key) copy in
+// global memory - one 16-byte coalesced load per lane - but only for the few rows a sample actually touches, so the
+// cloud is streamed once at the start instead of once per iteration (fps_stream_kernel: 16 us per iteration at
+// n = 50 000).
+template <int BLOCK, int P, int PR>  // rows p < PR keep their min-distances in registers, the rest in LDS
+__global__ __launch_bounds__(BLOCK) void fps_pruned_big_kernel(const float *__restrict__ xyz,
+                                                                const int32_t *__restrict__ perm,
+                                                                float4 *__restrict__ sorted, float *__restrict__ temp_io,
+                                                                int32_t *__restrict__ idx, int n, int m, int skip,
+                                                                int bs_log2) {
+  static_assert(P <= 64, "row records live in lanes 0..P-1");
+  constexpr int W = BLOCK / 64;
+  __shared__ float s_d[32];
+  __shared__ unsigned s_key[32];
+  __shared__ float s_t[(P > PR ? P - PR : 1) * BLOCK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float *pts = xyz + (size_t)blockIdx.x * n * 3;
+  const int32_t *pm = perm + (size_t)blockIdx.x * n;
+  float4 *srt = sorted + (size_t)blockIdx.x * n;
+  int32_t *out = idx + (size_t)blockIdx.x * m;
+  float *tio = temp_io ? temp_io + (size_t)blockIdx.x * n : nullptr;
+
+  float pt[PR];
+  float lox = INFINITY, loy = INFINITY, loz = INFINITY, hix = -INFINITY, hiy = -INFINITY, hiz = -INFINITY;
+  float rmax = -2.0f;
+  unsigned rkey = 0xFFFFFFFFu;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int k = (p * W + wave) * 64 + lane;
+    float x = 0.f, y = 0.f, z = 0.f, t = -INFINITY;
+    if (k < n) {
+      const int o = pm[k];
+      const f3 v = reinterpret_cast<const f3 *>(pts)[o];
+      x = v.x; y = v.y; z = v.z;
+      t = tio ? tio[o] : 1e10f;
+      if (skip) {
+        const float mag = ((x * x) + (y * y)) + (z * z);
+        if (mag < 1e-3f) t = -INFINITY;
+      }
+      srt[k] = make_float4(x, y, z, __uint_as_float(fps_key(o, bs_log2)));
+    }
+    if (p < PR) pt[p] = t; else s_t[(p - PR) * BLOCK + tid] = t;
+    const bool cand = t >= 0.f;
+    const float bhx = wave_max_f32(cand ? x : -INFINITY), blx = -wave_max_f32(cand ? -x : -INFINITY);
+    const float bhy = wave_max_f32(cand ? y : -INFINITY), bly = -wave_max_f32(cand ? -y : -INFINITY);
+    const float bhz = wave_max_f32(cand ? z : -INFINITY), blz = -wave_max_f32(cand ? -z : -INFINITY);
+    const bool any = __builtin_amdgcn_ballot_w64(cand) != 0ull;
+    if (lane == p) {
+      lox = blx; loy = bly; loz = blz; hix = bhx; hiy = bhy; hiz = bhz;
+      rmax = any ? 3.0e38f : -1.0f;
+      rkey = fps_key(0, bs_log2);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the unrolled rows from piling their loads up (register pressure)
+  }
+
+  int old = 0;
+  if (tid == 0) out[0] = 0;
+  for (int j = 1; j < m; ++j) {
+    const float x1 = pts[old * 3 + 0], y1 = pts[old * 3 + 1], z1 = pts[old * 3 + 2];
+    const float ex = fmaxf(fmaxf(lox - x1, x1 - hix), 0.f);
+    const float ey = fmaxf(fmaxf(loy - y1, y1 - hiy), 0.f);
+    const float ez = fmaxf(fmaxf(loz - z1, z1 - hiz), 0.f);
+    const float lb = ((ex * ex) + (ey * ey)) + (ez * ez);
+    const unsigned long long need = __builtin_amdgcn_ballot_w64(lb < rmax);
+    if (need != 0ull) {
+      int k0 = wave * 64 + lane;
+      asm volatile("" : "+v"(k0));  // keep the P row addresses from being hoisted out of the loop (2 VGPRs each)
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        if (need & (1ull << p)) {  // wave-uniform
+          const int k = p * W * 64 + k0;
+          const float4 q = k < n ? srt[k] : make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu));
+          const unsigned kk = __float_as_uint(q.w);
+          const float dx = q.x - x1, dy = q.y - y1, dz = q.z - z1;
+          const float d = ((dx * dx) + (dy * dy)) + (dz * dz);
+          const float d2 = __builtin_fminf(d, p < PR ? pt[p] : s_t[(p - PR) * BLOCK + tid]);
+          if (p < PR) pt[p] = d2; else s_t[(p - PR) * BLOCK + tid] = d2;
+          const float mx = wave_max_f32(d2);
+          const unsigned long long eq = __builtin_amdgcn_ballot_w64(d2 == mx);
+          unsigned kmin;
+          if (__builtin_popcountll(eq) == 1)
+            kmin = (unsigned)__builtin_amdgcn_readlane((int)kk, __builtin_ctzll(eq));
+          else
+            kmin = wave_min_u32(d2 == mx ? kk : 0xFFFFFFFFu);
+          if (lane == p) { rmax = mx; rkey = kmin; }
+        }
+      }
+    }
+    old = block_argmax<BLOCK>(rmax, rkey, bs_log2, s_d, s_key, j & 1);
+    if (tid == 0) out[j] = old;
+  }
+  if (tio) {
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int k = (p * W + wave) * 64 + lane;
+      const float t = p < PR ? pt[p] : s_t[(p - PR) * BLOCK + tid];
+      if (k < n && t >= 0.0f) tio[pm[k]] = t;
+    }
+  }
+}
+
 // 30-bit Morton keys of each cloud's points over the cloud's bounding box (10 bits per axis); one workgroup per
 // cloud.  Any permutation gives the same FPS result; this one makes consecutive points spatially close.
 __device__ __forceinline__ unsigned spread10(unsigned v) {
@@ -573,10 +675,11 @@ extern "C" int gb_fps_morton_keys(const float *xyz, int32_t *keys, int b, int n,
 }
 
 extern "C" int gb_fps_pruned(const float *xyz, const int32_t *perm, float *temp, int32_t *idx, int b, int n, int m,
-                             unsigned flags, void *stream) {
+                             unsigned flags, float *scratch, void *stream) {
   using namespace gb;
   if (b < 0 || n < 1 || m < 0 || !xyz || !perm || !idx) return GB_EINVAL;
-  if (n > 1024 * 20) return GB_ERANGE;  // register-resident only (20 points per thread); larger clouds: gb_fps
+  if (n > 1024 * 63) return GB_ERANGE;  // 24 rows in registers + 39 in LDS
+  if (n > 1024 * 20 && (!scratch || reinterpret_cast<uintptr_t>(scratch) % 16 != 0)) return GB_EINVAL;
   if (b == 0 || m == 0) return GB_OK;
   const unsigned tie = flags & GB_FPS_TIE_MASK;
   if (tie != GB_FPS_TIE_LOWEST && tie != GB_FPS_TIE_TREE512 && tie != GB_FPS_TIE_TREE1024) return GB_EINVAL;
@@ -603,5 +706,13 @@ extern "C" int gb_fps_pruned(const float *xyz, const int32_t *perm, float *temp,
   }
   GB_PR(4) GB_PR(8) GB_PR(12) GB_PR(16) GB_PR(20)
 #undef GB_PR
+#define GB_PB(PV)                                                                                               \
+  if (p_need <= PV) {                                                                                          \
+    hipLaunchKernelGGL((fps_pruned_big_kernel<1024, PV, 24>), dim3(b), dim3(1024), 0, s, xyz, perm,                 \
+                       reinterpret_cast<float4 *>(scratch), temp, idx, n, m, skip, bs_log2);                    \
+    return check_launch("gb_fps_pruned");                                                                      \
+  }
+  GB_PB(32) GB_PB(48) GB_PB(63)
+#undef GB_PB
   return GB_ERANGE;
 }

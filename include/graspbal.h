@@ -71,10 +71,11 @@ int gb_fps(const float *xyz, float *temp, int32_t *idx, int b, int n, int m, uns
 /* Pruned FPS for large clouds: same outputs as gb_fps, bit for bit (same samples, same order, same tie rules),
  * with the per-iteration min-distance update skipped for the wavefronts whose points are all farther from the
  * new sample than their current min-distance.  `perm` (b,n) int32 is any permutation of each cloud's indices;
- * a spatially coherent one (sort by gb_fps_morton_keys) is what makes the skipping effective.  n <= 20480.
- * temp (optional) as in gb_fps.                                                                          */
+ * a spatially coherent one (sort by gb_fps_morton_keys) is what makes the skipping effective.  n <= 65536; for
+ * n > 20480 the cloud no longer fits one CU's registers and `scratch` (b*n*4 floats, 16-byte aligned) receives a
+ * sorted (x,y,z,key) copy that the touched rows are re-read from; temp (optional) as in gb_fps.                                                                          */
 int gb_fps_pruned(const float *xyz, const int32_t *perm, float *temp, int32_t *idx, int b, int n, int m,
-                  unsigned flags, void *stream);
+                  unsigned flags, float *scratch, void *stream);
 /* keys (b,n) int32: 30-bit Morton code of each point within its cloud's bounding box.                   */
 int gb_fps_morton_keys(const float *xyz, int32_t *keys, int b, int n, void *stream);
 /* gb_fps preceded by a parallel, exact check of the hypothesis "the samples are 0..m-1" (true when the input is

@@ -324,9 +324,16 @@ def test_fps_pruned_is_the_same_sequence(orc, tie, skip):
         xyz[:, N - N // 3:] = xyz[:, :N // 3]  # exact duplicates
         cases.append((xyz, m))
     cases.append((torch.from_numpy(make_batch([5, 6], 20000)), 512))  # the bench's kind of cloud
+    # beyond one CU's registers: rows re-read from the sorted scratch copy (24 rows in registers, the rest in LDS)
+    big = torch.randint(0, 40, (1, 30000, 3), generator=g).float() * 0.03125
+    big[:, 20000:] = big[:, :10000]
+    cases.append((big, 200))
+    cases.append((torch.from_numpy(make_batch([9], 50000)), 384))    # BASELINE configs[4] cloud size
+    cases.append((torch.from_numpy(make_batch([10], 64512)), 130))   # the largest cloud the kernel takes
     for xyz, m in cases:
         B, N = xyz.shape[:2]
         dev = xyz.to(DEV)
+        scratch = torch.empty(B, N, 4, device=DEV) if N > 20480 else None
         keys = torch.empty(B, N, dtype=torch.int32, device=DEV)
         _lib.check(_lib.lib().gb_fps_morton_keys(_lib.ptr(dev), _lib.ptr(keys), B, N, None), "morton")
         perms = {"morton": torch.argsort(keys, dim=1).int(),
@@ -338,7 +345,7 @@ def test_fps_pruned_is_the_same_sequence(orc, tie, skip):
             idx = torch.zeros(B, m, dtype=torch.int32, device=DEV)
             temp = torch.full((B, N), 1e10, device=DEV)
             _lib.check(_lib.lib().gb_fps_pruned(_lib.ptr(dev), _lib.ptr(perm.contiguous()), _lib.ptr(temp), _lib.ptr(idx),
-                                                B, N, m, flags, None), "gb_fps_pruned")
+                                                B, N, m, flags, _lib.ptr(scratch), None), "gb_fps_pruned")
             torch.cuda.synchronize()
             assert torch.equal(idx.cpu(), want), (tie, skip, name, B, N, m)
             assert torch.equal(temp.cpu(), temp_o), ("running min-distance state differs", name)

@@ -4,11 +4,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from graspbalance_amd import _lib
 from graspbalance_amd.scene import make_batch
-B, N, m = 4, 20000, 2048
+B, N, m = int(os.environ.get('B', 4)), int(os.environ.get('N', 20000)), int(os.environ.get('M', 2048))
+scratch = torch.empty(B, N, 4, device='cuda') if N > 20480 else None
 xyz = torch.from_numpy(make_batch(range(B), N)).cuda()
 idx = torch.zeros(B, m, dtype=torch.int32, device="cuda")
 keys = torch.empty(B, N, dtype=torch.int32, device="cuda")
 L = _lib.lib()
+tmp = torch.empty(B, N, device='cuda')
 def timeit(fn, n=10):
     for _ in range(3): fn()
     torch.cuda.synchronize(); a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
@@ -17,13 +19,13 @@ def timeit(fn, n=10):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n * 1e3
 flags = _lib.FPS_SKIP_NEAR_ORIGIN | _lib.FPS_TIE_TREE512
-print("gb_fps                 %8.1f us" % timeit(lambda: L.gb_fps(_lib.ptr(xyz), None, _lib.ptr(idx), B, N, m, flags, None)))
+print("gb_fps                 %8.1f us" % timeit(lambda: _lib.check(L.gb_fps(_lib.ptr(xyz), _lib.ptr(tmp.fill_(1e10)), _lib.ptr(idx), B, N, m, flags, None), 'gb_fps')))
 ref = idx.clone()
 print("morton keys            %8.1f us" % timeit(lambda: L.gb_fps_morton_keys(_lib.ptr(xyz), _lib.ptr(keys), B, N, None)))
 print("argsort + int32        %8.1f us" % timeit(lambda: torch.argsort(keys, dim=1).to(torch.int32)))
 perm = torch.argsort(keys, dim=1).to(torch.int32)
-print("gb_fps_pruned (morton) %8.1f us" % timeit(lambda: L.gb_fps_pruned(_lib.ptr(xyz), _lib.ptr(perm), None, _lib.ptr(idx), B, N, m, flags, None)))
+print("gb_fps_pruned (morton) %8.1f us" % timeit(lambda: L.gb_fps_pruned(_lib.ptr(xyz), _lib.ptr(perm), None, _lib.ptr(idx), B, N, m, flags, _lib.ptr(scratch), None)))
 assert torch.equal(idx, ref)
 ident = torch.arange(N, device="cuda", dtype=torch.int32).repeat(B, 1).contiguous()
-print("gb_fps_pruned (ident.) %8.1f us" % timeit(lambda: L.gb_fps_pruned(_lib.ptr(xyz), _lib.ptr(ident), None, _lib.ptr(idx), B, N, m, flags, None)))
+print("gb_fps_pruned (ident.) %8.1f us" % timeit(lambda: L.gb_fps_pruned(_lib.ptr(xyz), _lib.ptr(ident), None, _lib.ptr(idx), B, N, m, flags, _lib.ptr(scratch), None)))
 assert torch.equal(idx, ref)

@@ -353,7 +353,9 @@ template <int KA, int KB, int EPI>
 static void launch_gemm(const Operand &a, const Operand &b, bool va, bool vb, float *d, long long ldd, double *stats,
                         long long kchunk, unsigned chunks, hipStream_t s, int stat_slots = 1,
                         const float *epi_y = nullptr, const float *epi_ab = nullptr, const uint16_t *epi_w16 = nullptr) {
-  const bool bn64 = b.rows <= 64;
+  // ... and 64 x 64 tiles while those number at most four per CU: the pointwise C -> 4C -> C pairs on a few thousand
+  // rows then run on 2-4x as many workgroups (measured: the ten such shapes of the step 735 -> 621 us in total)
+  const bool bn64 = b.rows <= 64 || (((a.rows + 63) / 64) * ((b.rows + 63) / 64) * chunks <= 1024);
   const long long blocks128 = ((a.rows + 127) / 128) * ((b.rows + (bn64 ? 63 : 127)) / (bn64 ? 64 : 128)) * chunks;
   const bool bm64 = a.rows <= 64 || blocks128 < 512;
   if (bm64 && bn64) launch_tile<KA, KB, EPI, 64, 64>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots, epi_y, epi_ab, epi_w16);

@@ -28,6 +28,7 @@ _P, _I, _F, _U, _L = _c.c_void_p, _c.c_int, _c.c_float, _c.c_uint, _c.c_longlong
 SIGNATURES = {
     "gb_fps": [_P, _P, _P, _I, _I, _I, _U, _P],
     "gb_fps_pruned": [_P, _P, _P, _P, _I, _I, _I, _U, _P, _P],
+    "gb_fps_segments": [_P, _P, _P, _P, _P, _I, _I, _U, _P],
     "gb_fps_morton_keys": [_P, _P, _I, _I, _P],
     "gb_fps_guarded": [_P, _P, _P, _I, _I, _I, _U, _P, _P, _P, _P],
     "gb_gather": [_P, _P, _P, _I, _I, _I, _I, _P],

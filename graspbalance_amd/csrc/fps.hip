@@ -448,6 +448,56 @@ __global__ __launch_bounds__(BLOCK) void fps_stream_kernel(const float *__restri
   }
 }
 
+// Segmented FPS: one workgroup per segment of a packed point list (the per-object sampling of the reference's
+// ObjectBalanceSampling, modules.py:178-221: `furthest_point_sample(points[seg == j], share_j)` for every object of
+// every cloud - dozens of one-workgroup launches there, one launch here).  Segment s = points
+// [seg_off[s], seg_off[s+1]), its samples go to idx[out_off[s] .. out_off[s+1]) as indices WITHIN the segment; the
+// tie rule is the one gb_fps applies to a cloud of that size.  Min-distances live in `temp` (L2-resident).
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void fps_segments_kernel(const float *__restrict__ xyz,
+                                                              const int32_t *__restrict__ seg_off,
+                                                              const int32_t *__restrict__ out_off,
+                                                              float *__restrict__ temp, int32_t *__restrict__ idx,
+                                                              int skip, int tie_cap) {
+  __shared__ float s_d[32];
+  __shared__ unsigned s_key[32];
+  const int tid = threadIdx.x, sgm = blockIdx.x;
+  const int p0 = seg_off[sgm], n = seg_off[sgm + 1] - p0;
+  const int o0 = out_off[sgm], m = out_off[sgm + 1] - o0;
+  if (n <= 0 || m <= 0) return;  // block-uniform
+  int bs_log2 = -1;
+  if (tie_cap >= 0) {
+    const int fl = 31 - __clz(n);
+    bs_log2 = fl < tie_cap ? fl : tie_cap;
+  }
+  const float *pts = xyz + (size_t)p0 * 3;
+  float *t = temp + p0;
+  int32_t *out = idx + o0;
+  for (int k = tid; k < n; k += BLOCK) t[k] = 1e10f;
+  int old = 0;
+  if (tid == 0) out[0] = 0;
+  for (int j = 1; j < m; ++j) {
+    const float x1 = pts[old * 3 + 0], y1 = pts[old * 3 + 1], z1 = pts[old * 3 + 2];
+    float best = -1.0f;
+    unsigned bestkey = 0xFFFFFFFFu;
+    for (int k = tid; k < n; k += BLOCK) {
+      const f3 v = reinterpret_cast<const f3 *>(pts)[k];
+      if (skip) {
+        const float mag = ((v.x * v.x) + (v.y * v.y)) + (v.z * v.z);
+        if (mag < 1e-3f) continue;
+      }
+      const float dx = v.x - x1, dy = v.y - y1, dz = v.z - z1;
+      const float d = ((dx * dx) + (dy * dy)) + (dz * dz);
+      const float d2 = __builtin_fminf(d, t[k]);
+      t[k] = d2;
+      const unsigned key = fps_key(k, bs_log2);  // BLOCK need not be a multiple of the reference block size here
+      if (d2 > best || (d2 == best && key < bestkey)) { best = d2; bestkey = key; }
+    }
+    old = block_argmax<BLOCK>(best, bestkey, bs_log2, s_d, s_key, j & 1);
+    if (tid == 0) out[j] = old;
+  }
+}
+
 static int floor_log2(int v) {
   int l = 0;
   while ((2 << l) <= v) ++l;
@@ -715,4 +765,24 @@ extern "C" int gb_fps_pruned(const float *xyz, const int32_t *perm, float *temp,
   GB_PB(32) GB_PB(48) GB_PB(63)
 #undef GB_PB
   return GB_ERANGE;
+}
+
+// Segmented FPS (see fps_segments_kernel).  xyz (T,3) packed points; seg_off / out_off (S+1) int32 device arrays
+// (non-decreasing); temp (T) float workspace; idx (out_off[S]) int32.  max_n = the largest segment (host-known
+// bound, for the tie-key range check only).
+extern "C" int gb_fps_segments(const float *xyz, const int32_t *seg_off, const int32_t *out_off, float *temp,
+                               int32_t *idx, int S, int max_n, unsigned flags, void *stream) {
+  using namespace gb;
+  if (S < 0 || max_n < 0 || !xyz || !seg_off || !out_off || !temp || !idx) return GB_EINVAL;
+  if (S == 0) return GB_OK;
+  const unsigned tie = flags & GB_FPS_TIE_MASK;
+  if (tie != GB_FPS_TIE_LOWEST && tie != GB_FPS_TIE_TREE512 && tie != GB_FPS_TIE_TREE1024) return GB_EINVAL;
+  const int tie_cap = tie == GB_FPS_TIE_LOWEST ? -1 : (tie == GB_FPS_TIE_TREE512 ? 9 : 10);
+  if (tie_cap >= 0 && max_n > 0) {
+    const int bl = floor_log2(max_n) < tie_cap ? floor_log2(max_n) : tie_cap;
+    if ((max_n >> bl) >= (1 << GB_FPS_KEY_SHIFT)) return GB_ERANGE;
+  }
+  hipLaunchKernelGGL((fps_segments_kernel<256>), dim3(S), dim3(256), 0, as_stream(stream), xyz, seg_off, out_off, temp,
+                     idx, (flags & GB_FPS_SKIP_NEAR_ORIGIN) ? 1 : 0, tie_cap);
+  return check_launch("gb_fps_segments");
 }

@@ -5,6 +5,7 @@ import torch
 
 from . import _lib
 from . import pointnet2_utils
+from .pointnet2 import _ext as _hip_ext
 
 
 def cylinder_query_multi(xyz, new_xyz, rot, radii, hmin, hmaxs, nsample):
@@ -34,3 +35,32 @@ def cylinder_query_multi(xyz, new_xyz, rot, radii, hmin, hmaxs, nsample):
             ctypes.cast(ra, ctypes.c_void_p), nr, float(hmin), ctypes.cast(ha, ctypes.c_void_p), nh,
             int(nsample), _lib.current_stream(xyz.device)), "cylinder_query_multi")
     return out
+
+
+def fps_segments(xyz_packed, seg_sizes, sample_counts):
+    """furthest_point_sample on every segment of a packed (T,3) point list in ONE launch (the per-object loop of
+    ObjectBalanceSampling, modules.py:178-221).  seg_sizes / sample_counts: python int lists; returns int64 (sum of
+    sample_counts,) indices INTO xyz_packed (segment offset already added), segment after segment."""
+    if not xyz_packed.is_cuda:
+        raise RuntimeError("fps_segments: CPU not supported")
+    if not xyz_packed.is_contiguous() or xyz_packed.dtype != torch.float32:
+        raise RuntimeError("xyz_packed must be a contiguous float tensor")
+    if any(m > 0 and n <= 0 for n, m in zip(seg_sizes, sample_counts)):
+        raise RuntimeError("fps_segments: cannot sample from an empty segment")
+    dev = xyz_packed.device
+    S = len(seg_sizes)
+    offs = [0] * (S + 1)
+    outs = [0] * (S + 1)
+    for i in range(S):
+        offs[i + 1] = offs[i] + int(seg_sizes[i])
+        outs[i + 1] = outs[i] + int(sample_counts[i])
+    assert offs[S] == xyz_packed.size(0)
+    table = torch.tensor([offs, outs], dtype=torch.int32).to(dev, non_blocking=True)
+    idx = torch.zeros(outs[S], dtype=torch.int32, device=dev)
+    temp = torch.empty(max(offs[S], 1), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().gb_fps_segments(_lib.ptr(xyz_packed), _lib.ptr(table[0]), _lib.ptr(table[1]), _lib.ptr(temp),
+                                              _lib.ptr(idx), S, max([int(n) for n in seg_sizes], default=0),
+                                              _hip_ext.FPS_FLAGS, _lib.current_stream(dev)), "fps_segments")
+    base = torch.repeat_interleave(table[0, :S].long(), torch.tensor(sample_counts, device=dev), output_size=outs[S])
+    return idx.long() + base

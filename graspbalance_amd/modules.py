@@ -38,16 +38,62 @@ def ForegroundSampling(end_points):
     return _resample_seeds(end_points, picks)
 
 
-def ObjectBalanceSampling(end_points):
-    """1024 seeds split evenly over the segmented objects (label 0 = background), FPS inside each."""
+def _object_shares(num_labels_with_background, num_objects):
+    """Seeds per object as the reference computes them (modules.py:190-192): 1024 // (number of distinct labels - 1),
+    remainder to the last - i.e. label 0 is assumed present; without it the reference runs out of shares."""
+    count = num_labels_with_background - 1
+    share = [1024 // count for _ in range(count)]  # ZeroDivisionError for a background-only cloud, like the reference
+    share[-1] += 1024 % count
+    if num_objects > count:
+        raise IndexError("list index out of range")  # the reference's points_per_object[t]
+    return share
+
+
+def _object_balance_sampling_loop(end_points):
+    """The reference's composition: one furthest_point_sample call per object per cloud."""
     seg = end_points["seed_cluster"]
     picks = []
     for i in range(seg.shape[0]):
-        labels = [j for j in torch.unique(seg[i]) if j != 0]
-        share = [1024 // len(labels)] * len(labels)
-        share[-1] += 1024 % len(labels)
+        uniq = torch.unique(seg[i])
+        labels = [j for j in uniq if j != 0]
+        share = _object_shares(len(uniq), len(labels))
         picks.append(torch.cat([_fps_within(end_points['point_clouds'][i], torch.where(seg[i] == j)[0], n)
                                 for j, n in zip(labels, share)], 0))
+    return _resample_seeds(end_points, picks)
+
+
+def ObjectBalanceSampling(end_points):
+    """1024 seeds split evenly over the segmented objects (label 0 = background), FPS inside each.  On the GPU the
+    per-object FPS calls of all clouds run as ONE segmented launch (fused_ops.fps_segments): a stable sort by label
+    lists every object's points in index order - what `torch.where(seg == j)` yields - and one host read of the
+    label counts replaces the unique / where synchronisations per object.  Same picks, bit for bit."""
+    seg = end_points["seed_cluster"]
+    points = end_points['point_clouds']
+    if not (points.is_cuda and points.dtype == torch.float32 and points.is_contiguous()):
+        return _object_balance_sampling_loop(end_points)
+    from . import fused_ops
+    B, N = seg.shape
+    sorted_labels, order = torch.sort(seg, dim=1, stable=True)
+    per_cloud = [torch.unique_consecutive(sorted_labels[i], return_counts=True) for i in range(B)]
+    host = [(lab.tolist(), cnt.tolist()) for lab, cnt in per_cloud]
+    member_parts, seg_sizes, sample_counts = [], [], []
+    for i, (labs, cnts) in enumerate(host):
+        objects = [k for k, lab in enumerate(labs) if lab != 0]
+        share = _object_shares(len(labs), len(objects))
+        start = 0
+        starts = []
+        for c in cnts:
+            starts.append(start)
+            start += c
+        for k, m in zip(objects, share):
+            member_parts.append(order[i, starts[k]:starts[k] + cnts[k]] + i * N)
+            seg_sizes.append(cnts[k])
+            sample_counts.append(m)
+    members = torch.cat(member_parts, 0)                                  # flat (cloud * N + point) ids
+    packed = torch.index_select(points.view(B * N, 3), 0, members)
+    picked = fused_ops.fps_segments(packed, seg_sizes, sample_counts)     # indices into `members`
+    flat = torch.index_select(members, 0, picked).view(B, 1024)
+    picks = [flat[i] - i * N for i in range(B)]
     return _resample_seeds(end_points, picks)
 
 

@@ -78,6 +78,14 @@ int gb_fps_pruned(const float *xyz, const int32_t *perm, float *temp, int32_t *i
                   unsigned flags, float *scratch, void *stream);
 /* keys (b,n) int32: 30-bit Morton code of each point within its cloud's bounding box.                   */
 int gb_fps_morton_keys(const float *xyz, int32_t *keys, int b, int n, void *stream);
+/* Segmented FPS - the per-object sampling loop of ObjectBalanceSampling (TrainModel/modules.py:178-221, one
+ * furthest_point_sample(points[seg == j], share_j) call per object per cloud) as ONE launch, a workgroup per
+ * segment.  xyz (T,3): the segments' points packed back to back; seg_off, out_off (S+1) int32 device arrays:
+ * segment s = points [seg_off[s], seg_off[s+1]), its out_off[s+1]-out_off[s] samples are written to
+ * idx[out_off[s]..) as indices WITHIN the segment, exactly what gb_fps returns for that segment as a cloud of its
+ * own (same flags, same tie rule for its size).  temp (T) floats: workspace.  max_n: largest segment size.       */
+int gb_fps_segments(const float *xyz, const int32_t *seg_off, const int32_t *out_off, float *temp, int32_t *idx,
+                    int S, int max_n, unsigned flags, void *stream);
 /* gb_fps preceded by a parallel, exact check of the hypothesis "the samples are 0..m-1" (true when the input is
  * itself in farthest-point order, e.g. the centres of the previous set-abstraction level, and no exact tie is broken
  * differently): clouds that pass skip the m-1 sequential iterations, the others run them.  Same outputs as gb_fps

@@ -392,3 +392,43 @@ def test_fps_guarded_prefix_check(orc, tie, skip):
             assert bool((ok == 1).all()), "prefix check should have passed on farthest-point-ordered input"
         passed += int((ok == 1).sum())
     assert passed > 0
+
+
+@pytest.mark.parametrize("tie", ["lowest", "tree512", "tree1024"])
+def test_fps_segments_equals_per_segment_fps(orc, tie):
+    """gb_fps_segments (one workgroup per segment of a packed list) == the oracle's FPS of every segment as a cloud
+    of its own: segment sizes 1 .. 5000 (different reference block sizes, hence tie rules), exact ties (lattice +
+    duplicates), near-origin points, more samples than points, empty sample counts."""
+    import torch
+    from graspbalance_amd import _lib
+    g = torch.Generator().manual_seed(31)
+    flags = {"lowest": _lib.FPS_TIE_LOWEST, "tree512": _lib.FPS_TIE_TREE512, "tree1024": _lib.FPS_TIE_TREE1024}[tie] | 1
+    sizes = [1, 7, 64, 300, 513, 1024, 1500, 5000, 90]
+    counts = [1, 7, 20, 128, 128, 0, 300, 146, 120]
+    segs = []
+    for n in sizes:
+        pts = torch.randint(0, 6, (n, 3), generator=g).float() * 0.25 + 0.5
+        if n >= 64:
+            pts[n // 2:n // 2 + n // 4] = pts[:n // 4]     # duplicates
+            pts[-3:] = 0.001                               # near the origin: skipped
+        segs.append(pts)
+    packed = torch.cat(segs, 0).contiguous()
+    offs = [0]
+    outs = [0]
+    for n, m in zip(sizes, counts):
+        offs.append(offs[-1] + n)
+        outs.append(outs[-1] + m)
+    dev = packed.to(DEV)
+    seg_off = torch.tensor(offs, dtype=torch.int32, device=DEV)
+    out_off = torch.tensor(outs, dtype=torch.int32, device=DEV)
+    temp = torch.empty(offs[-1], device=DEV)
+    idx = torch.full((outs[-1],), -5, dtype=torch.int32, device=DEV)
+    _lib.check(_lib.lib().gb_fps_segments(_lib.ptr(dev), _lib.ptr(seg_off), _lib.ptr(out_off), _lib.ptr(temp), _lib.ptr(idx),
+                                          len(sizes), max(sizes), flags, None), "gb_fps_segments")
+    torch.cuda.synchronize()
+    got = idx.cpu()
+    for s, (pts, m) in enumerate(zip(segs, counts)):
+        if m == 0:
+            continue
+        want = orc.furthest_point_sampling(pts.unsqueeze(0).contiguous(), m, flags)[0]
+        assert torch.equal(got[outs[s]:outs[s + 1]], want), (tie, s, sizes[s], m)

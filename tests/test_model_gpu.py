@@ -100,3 +100,62 @@ def test_fused_label_matching_equals_per_object_composition(monkeypatch):
         assert torch.equal(fused[k], plain[k]), k
     for k in ('batch_grasp_view', 'batch_grasp_view_rot'):
         assert torch.allclose(fused[k], plain[k], rtol=0, atol=1e-6), k
+
+
+def _segmented_clouds(B, N, objects, seed):
+    import numpy as np
+    from graspbalance_amd.scene import make_batch
+    clouds = torch.from_numpy(make_batch(list(range(seed, seed + B)), N))
+    rng = np.random.default_rng(seed)
+    seg = torch.from_numpy(rng.integers(0, objects + 1, size=(B, N))).long()
+    seg[0, :40] = 0
+    seg[0][seg[0] == objects] = 0          # cloud 0 has one object fewer
+    seg[-1][seg[-1] == 1] = 0
+    seg[-1, 5:25] = 1                      # ... and the last one an object smaller than its share of seeds
+    return clouds, seg
+
+
+def test_object_balance_sampling_batched_equals_per_object_loop():
+    """ObjectBalanceSampling (TrainModel/modules.py:178-221) as one segmented FPS launch == the reference's
+    per-object composition: same seed indices, coordinates and features."""
+    from graspbalance_amd import modules
+    clouds, seg = _segmented_clouds(3, 6000, 7, seed=40)
+    feats = torch.randn(3, 256, 6000)
+    def ep():
+        return {'point_clouds': clouds.to(DEV), 'seed_cluster': seg.to(DEV), 'up_sample_features': feats.to(DEV),
+                'fp2_inds': torch.zeros(3, 1024, dtype=torch.int32, device=DEV)}
+    a = modules.ObjectBalanceSampling(ep())
+    b = modules._object_balance_sampling_loop(ep())
+    for k in ('fp2_inds', 'fp2_xyz', 'fp2_features'):
+        assert torch.equal(a[k], b[k]), k
+    assert a['fp2_inds'].dtype == torch.int32 and a['fp2_inds'].shape == (3, 1024)
+    # every seed lies on an object, objects get 1024 // K seeds each (remainder to the last)
+    picked = torch.gather(seg.to(DEV), 1, a['fp2_inds'].long())
+    assert bool((picked != 0).all())
+    labels, counts = torch.unique(picked[1], return_counts=True)
+    assert counts.tolist() == [1024 // 7] * 6 + [1024 // 7 + 1024 % 7]
+    # label 0 absent: the reference runs out of per-object shares (IndexError); so does the build
+    e = ep()
+    e['seed_cluster'] = torch.ones_like(e['seed_cluster'])
+    with pytest.raises((IndexError, ZeroDivisionError)):
+        modules.ObjectBalanceSampling(e)
+
+
+def test_obs_eval_forward():
+    """Inference with object-balanced seeds (GraspPoseStage1 obs branch, graspbalance.py:35-42): runs end to end,
+    seeds are the sampled object points, features are the 3-NN up-sampled backbone features at those points."""
+    from tests.test_model_cpu import _tiny_net
+    from graspbalance_amd.graspbalance import pred_decode
+    net = _tiny_net(training=False)
+    net.view_estimator.obs = True
+    net = net.to(DEV).eval()
+    clouds, seg = _segmented_clouds(2, 3000, 4, seed=50)
+    with torch.no_grad():
+        out = net({'point_clouds': clouds.to(DEV), 'seed_cluster': seg.to(DEV)})
+    inds = out['fp2_inds'].long()
+    assert torch.equal(out['fp2_xyz'], torch.gather(clouds.to(DEV), 1, inds[:, :, None].expand(-1, -1, 3)))
+    up = out['up_sample_features']  # (B,256,N)
+    assert torch.equal(out['fp2_features'], torch.gather(up, 2, inds[:, None, :].expand(-1, up.size(1), -1)))
+    assert bool((torch.gather(seg.to(DEV), 1, inds) != 0).all())
+    assert out['grasp_score_pred'].shape[0] == 2 and bool(torch.isfinite(out['grasp_score_pred']).all())
+    assert len(pred_decode(out)) == 2

@@ -19,6 +19,8 @@
 // through torch (pytorch_utils.py:61-113).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "gb_common.h"
 #include "gemm_rs.h"
 
@@ -43,6 +45,7 @@ struct RsArgs {
   int w_kc;             // 1: B[r][c] = w[c*R + r] (forward, W (C,R));  0: B[r][c] = w[r*C + c] (dgrad, W (R,C))
   int slots, nch;       // statistics slot rows ; chunks = ceil(R / 32)
   int stagger;          // delay waves 4-7 by half a tile
+  int tail_split;       // cut the tiles of a short last round into column groups
 };
 
 template <int NT, int EPI>
@@ -55,17 +58,51 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int m = lane & 31, h = lane >> 5;
 
-  // ---- stage B (zero padded); consecutive threads write consecutive columns: conflict-free
+  // ---- stage B (zero padded); consecutive threads write consecutive columns: conflict-free.  Four 16-byte loads per
+  // thread are issued back to back from clamped (always valid) addresses before anything uses them - with a load
+  // per loop trip the 128 KB image took 16-64 dependent round trips (50 us of a 73 us launch at P = 16 384).
   if (g.w_kc) {
-    const int quads = rpad / 4;
-    for (int i = t; i < quads * C32; i += RS_TPB) {
-      const int c = i % C32, r = (i / C32) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c < g.C && r < g.R) v = *reinterpret_cast<const float4 *>(g.w + (size_t)c * g.R + r);  // R % 4 == 0
-      Bs[(r + 0) * C32 + c] = v.x;
-      Bs[(r + 1) * C32 + c] = v.y;
-      Bs[(r + 2) * C32 + c] = v.z;
-      Bs[(r + 3) * C32 + c] = v.w;
+    const int total = (rpad / 4) * C32;
+    for (int i0 = t; i0 < total; i0 += 4 * RS_TPB) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * RS_TPB;
+        const int c = i % C32, r = (i / C32) * 4;
+        const bool ok = i < total && c < g.C && r < g.R;  // R % 4 == 0
+        v[u] = *reinterpret_cast<const float4 *>(g.w + (ok ? (size_t)c * g.R + r : 0));
+        if (!ok) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * RS_TPB;
+        if (i < total) {
+          const int c = i % C32, r = (i / C32) * 4;
+          Bs[(r + 0) * C32 + c] = v[u].x;
+          Bs[(r + 1) * C32 + c] = v[u].y;
+          Bs[(r + 2) * C32 + c] = v[u].z;
+          Bs[(r + 3) * C32 + c] = v[u].w;
+        }
+      }
+    }
+  } else if (g.C % 4 == 0 && reinterpret_cast<uintptr_t>(g.w) % 16 == 0) {
+    constexpr int Q = C32 / 4;  // float4 per LDS row
+    const int total = rpad * Q;
+    for (int i0 = t; i0 < total; i0 += 4 * RS_TPB) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * RS_TPB;
+        const int r = i / Q, c = (i % Q) * 4;
+        const bool ok = i < total && r < g.R && c < g.C;
+        v[u] = *reinterpret_cast<const float4 *>(g.w + (ok ? (size_t)r * g.C + c : 0));
+        if (!ok) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * RS_TPB;
+        if (i < total) *reinterpret_cast<float4 *>(Bs + (size_t)(i / Q) * C32 + (i % Q) * 4) = v[u];
+      }
     }
   } else {
     for (int i = t; i < rpad * C32; i += RS_TPB) {
@@ -82,7 +119,9 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
 
   const long long ntiles = (g.P + 31) / 32;
   const long long nw = (long long)gridDim.x * RS_WAVES;
-  long long tile = (long long)blockIdx.x * RS_WAVES + wave;
+  // wave w of every workgroup before wave w+1 of any: with fewer tiles than waves the work spreads over all CUs
+  // (and over the four SIMDs of each) instead of filling the 8 waves of the first workgroups
+  long long tile = (long long)wave * gridDim.x + blockIdx.x;
 
   constexpr bool BNB = EPI == RS_BNBWD || EPI == RS_BNBWD_X;
   constexpr int NS = EPI == RS_BNBWD_X ? 5 : 2;  // column sums per column: [g, g*xhat (, g*x0, g*x1, g*x2)] / [y, y^2]
@@ -123,7 +162,26 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
     int units = g.nch * NT * 8;  // half a tile = nch*16*NT MFMAs * 64 cycles / 2, in s_sleep units of 64 cycles
     for (; units > 0; units -= 100) __builtin_amdgcn_s_sleep(100);
   }
-  if (tile < ntiles) {
+  // Tail balance: ntiles is rarely a multiple of the nw waves, and a last round with a few tiles costs a whole tile
+  // time (6.06 rounds run as 7).  When the remainder is small, its tiles are cut into G column groups handled by G
+  // different waves (each re-reads the 32 rows of A - L2 hits - and owns NT/G column tiles: stores, statistics and
+  // fp64 sums are per column, so nothing else changes): the last round then costs 1/G of a tile time.
+  long long main_end = ntiles;
+  int G = 1;
+  {
+    const long long rem = ntiles % nw;
+    if (g.tail_split && rem > 0) {
+      const long long gmax = nw / rem;
+      while (G * 2 <= gmax && G * 2 <= NT && NT % (G * 2) == 0) G *= 2;
+      if (G >= 2) main_end = ntiles - rem;
+      else G = 1;
+    }
+  }
+
+  auto walk = [&](auto part, long long tile, const long long tend, const int qlo, const int qhi) {
+    constexpr bool PART = decltype(part)::value;  // true: only column tiles [qlo, qhi) of the tile
+    auto in = [&](int q) { return !PART || (q >= qlo && q < qhi); };
+  if (tile < tend) {
     f32x16 acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -136,7 +194,7 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
       int nkc = kc + 1;
       long long ntile = tile;
       if (nkc == g.nch) { nkc = 0; ntile = tile + nw; }
-      const bool more = ntile < ntiles;
+      const bool more = ntile < tend;
       if (more) load_chunk(nxt, ntile, nkc);
 
       float av[16];
@@ -177,11 +235,13 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
         if (kc == g.nch - 1) {
 #pragma unroll
           for (int q = 0; q < NT; ++q)
+            if (in(q)) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const long long row = tile * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
-              const int col = q * 32 + m;
-              yv[q][r] = (col < g.C && row < g.P) ? g.epi_y[row * g.ldd + col] : 0.f;
+              for (int r = 0; r < 16; ++r) {
+                const long long row = tile * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
+                const int col = q * 32 + m;
+                yv[q][r] = (col < g.C && row < g.P) ? g.epi_y[row * g.ldd + col] : 0.f;
+              }
             }
         }
       }
@@ -190,9 +250,11 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
       for (int j = 0; j < 16; ++j) {
         float bv[NT];
 #pragma unroll
-        for (int q = 0; q < NT; ++q) bv[q] = bp[j * C32 + q * 32];
+        for (int q = 0; q < NT; ++q)
+          if (in(q)) bv[q] = bp[j * C32 + q * 32];
 #pragma unroll
-        for (int q = 0; q < NT; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[q], acc[q], 0, 0, 0);
+        for (int q = 0; q < NT; ++q)
+          if (in(q)) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[q], acc[q], 0, 0, 0);
       }
 
       if (kc == g.nch - 1) {
@@ -200,6 +262,7 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
         const long long row0 = tile * 32 + 4 * h;
 #pragma unroll
         for (int q = 0; q < NT; ++q) {
+          if (!in(q)) continue;
           const int col = q * 32 + m;
           const bool colok = col < g.C;
           float cs = 0.f, cq = 0.f, ct[3] = {0.f, 0.f, 0.f};
@@ -261,6 +324,13 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
       tile = ntile;
     }
   }
+  };
+  walk(std::false_type{}, tile, main_end, 0, NT);
+  if (G >= 2) {
+    const long long u = (long long)wave * gridDim.x + blockIdx.x;
+    const int cg = (int)(u % G), per = NT / G;
+    walk(std::true_type{}, main_end + u / G, (u / G) < (ntiles - main_end) ? main_end + u / G + 1 : 0, cg * per, (cg + 1) * per);
+  }
 
   if constexpr (EPI != RS_STORE) {
     // per-column totals: lanes l / l+32 share a column, then the 8 waves through LDS (B is dead now)
@@ -320,7 +390,7 @@ static void rs_launch(const RsArgs &g, size_t lds_bytes, int blocks_per_cu, hipS
     attr_set = true;
   }
   const long long ntiles = (g.P + 31) / 32;
-  long long blocks = (ntiles + RS_WAVES - 1) / RS_WAVES;
+  long long blocks = ntiles;  // at least one tile per workgroup; all 512 threads stage B either way
   const long long cap = (long long)num_cus() * blocks_per_cu;
   if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(RS_TPB), lds_bytes, s, g);
@@ -358,7 +428,13 @@ bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, dou
     const char *e = getenv("GB_RS_STAGGER");  // A/B switch
     stagger = e ? atoi(e) : 1;
   }
-  RsArgs g = {a, w, d, aff, stats, epi_y, epi_ab, epi_x, epi_w16, P, R, C, R, C, w_kc, slots < 1 ? 1 : slots, nch, stagger};
+  static int tail_split = -1;
+  if (tail_split < 0) {
+    const char *e = getenv("GB_RS_TAIL");  // A/B switch
+    tail_split = e ? atoi(e) : 1;
+  }
+  RsArgs g = {a, w, d, aff, stats, epi_y, epi_ab, epi_x, epi_w16, P, R, C, R, C, w_kc, slots < 1 ? 1 : slots, nch, stagger,
+              tail_split};
   const int bpc = (nt <= 2 && epi != RS_BNBWD && epi != RS_BNBWD_X && lds_bytes <= 78 * 1024) ? 2 : 1;
   if (epi == RS_BNBWD_X) {
     rs_launch<2, RS_BNBWD_X>(g, lds_bytes, bpc, s);

@@ -10,6 +10,8 @@ SHAPES = [(1000, 3, 64), (4096, 64, 64), (5000, 131, 128), (777, 259, 256), (204
           (8192, 16, 8), (1, 5, 3), (33000, 64, 128),
           # tall shapes that take the row-streaming kernel (csrc/gemm_rs.hip) in fwd and/or dgrad
           (20011, 128, 256), (16400, 64, 131), (17000, 132, 40), (40000, 256, 96), (16384, 32, 256), (70000, 256, 128),
+          # ... with a short last round of tiles, which the kernel cuts into column groups (8, 4 and 2 of them)
+          (67601, 128, 256), (133003, 64, 64),
           # few input channels: the column-reduction wgrad (wgrad_smallk_kernel)
           (9001, 3, 64), (5000, 4, 40), (66000, 1, 128)]
 

@@ -432,3 +432,55 @@ def test_fps_segments_equals_per_segment_fps(orc, tie):
             continue
         want = orc.furthest_point_sampling(pts.unsqueeze(0).contiguous(), m, flags)[0]
         assert torch.equal(got[outs[s]:outs[s + 1]], want), (tie, s, sizes[s], m)
+
+
+def test_known_answers_and_degenerate_shapes(ext, pb, orc):
+    """The hand-derived known answers of tests/test_oracle_golden.py (G10: d2 == r2 boundary, empty ball -> zeros,
+    first-hit padding, nsample = 1 early exit, FPS tie rules and the near-origin skip) on the HIP path itself, a
+    lattice cloud where most pair distances hit r2 exactly, and the degenerate shapes (no centres, no samples, one
+    point) through the raw C-ABI."""
+    import torch
+    from graspbalance_amd import _lib
+    xyz = torch.tensor([[[0.0, 0, 1], [0.5, 0, 1], [0.25, 0, 1], [0.1, 0, 1], [3.0, 0, 1]]])
+    new_xyz = torch.tensor([[[0.0, 0, 1], [10.0, 0, 1], [0.25, 0, 1]]])
+    idx = ext.ball_query(new_xyz.to(DEV), xyz.to(DEV), 0.25, 4).cpu()
+    assert idx[0].tolist() == [[0, 3, 0, 0], [0, 0, 0, 0], [2, 3, 2, 2]]
+    assert ext.ball_query(new_xyz.to(DEV), xyz.to(DEV), 0.25, 1).cpu()[0, :, 0].tolist() == [0, 0, 2]
+    # lattice: every coordinate a multiple of 1/8, r = 0.25 -> many pairs with d2 == r2 exactly (excluded: strict <)
+    g = torch.Generator().manual_seed(5)
+    lat = torch.randint(0, 6, (2, 700, 3), generator=g).float() * 0.125 + 1.0
+    cen = lat[:, :90].contiguous()
+    for r, ns in ((0.25, 16), (0.125, 8), (0.2165063509461097, 32)):   # the last one: r2 = 3/64 up to rounding
+        want = orc.ball_query(cen, lat, r, ns)
+        assert torch.equal(ext.ball_query(cen.to(DEV), lat.to(DEV), r, ns).cpu(), want), (r, ns)
+    rot = torch.eye(3).repeat(2, 90, 1, 1).view(2, 90, 9).contiguous()
+    for radius, hmax in ((0.25, 0.125), (0.125, 0.25)):
+        want = orc.cylinder_query(cen, lat, rot, radius, -0.125, hmax, 16)
+        got = ext.cylinder_query(cen.to(DEV), lat.to(DEV), rot.to(DEV), radius, -0.125, hmax, 16).cpu()
+        assert torch.equal(got, want), (radius, hmax)
+    # FPS: square corners + duplicate; tie rules; near-origin skip
+    sq = torch.tensor([[[1.0, 1, 1], [2.0, 1, 1], [1.0, 2, 1], [2.0, 2, 1], [2.0, 2, 1]]]).to(DEV)
+    out = torch.zeros(1, 3, dtype=torch.int32, device=DEV)
+    for flags, first_two in ((_lib.FPS_TIE_LOWEST, [0, 3]), (_lib.FPS_TIE_TREE512, [0, 4])):
+        _lib.check(_lib.lib().gb_fps(_lib.ptr(sq), None, _lib.ptr(out), 1, 5, 3, flags, None), "gb_fps")
+        torch.cuda.synchronize()
+        assert out[0].tolist()[:2] == first_two
+    og = torch.tensor([[[1.0, 0, 0], [0.0, 0, 0], [1.1, 0, 0], [0.01, 0.01, 0.01]]]).to(DEV)
+    out2 = torch.zeros(1, 2, dtype=torch.int32, device=DEV)
+    for flags, want2 in ((_lib.FPS_TIE_LOWEST, [0, 1]), (_lib.FPS_TIE_LOWEST | _lib.FPS_SKIP_NEAR_ORIGIN, [0, 2])):
+        _lib.check(_lib.lib().gb_fps(_lib.ptr(og), None, _lib.ptr(out2), 1, 4, 2, flags, None), "gb_fps")
+        torch.cuda.synchronize()
+        assert out2[0].tolist() == want2
+    # degenerate shapes: nothing to do is not an error and writes nothing
+    L = _lib.lib()
+    guard = torch.full((8,), -3, dtype=torch.int32, device=DEV)
+    one = torch.tensor([[[0.5, 0.5, 0.5]]], device=DEV)
+    assert L.gb_fps(_lib.ptr(one), None, _lib.ptr(guard), 0, 1, 4, _lib.FPS_TIE_LOWEST, None) == 0      # b = 0
+    assert L.gb_fps(_lib.ptr(one), None, _lib.ptr(guard), 1, 1, 0, _lib.FPS_TIE_LOWEST, None) == 0      # m = 0
+    assert L.gb_ball_query(_lib.ptr(one), _lib.ptr(one), _lib.ptr(guard), None, 1, 1, 0, 0.1, 4, None) == 0  # no centres
+    torch.cuda.synchronize()
+    assert bool((guard == -3).all())
+    # one point, several samples: index 0 every time (m > n is legal in the reference's loop)
+    assert L.gb_fps(_lib.ptr(one), None, _lib.ptr(guard), 1, 1, 4, _lib.FPS_TIE_TREE512, None) == 0
+    torch.cuda.synchronize()
+    assert guard[:4].tolist() == [0, 0, 0, 0]

@@ -376,24 +376,69 @@ __global__ __launch_bounds__(TPB) void knn1_dim3_kernel(const float *__restrict_
 // The reference first permutes EVERY object tensor along the view axis (index_select, 52 MB per
 // object) and then selects the seeds' rows; this composes the two index maps and touches only the
 // rows that are kept.  One workgroup per seed, 16-byte copies.
+// *addr = max(*addr, v) with torch.max's NaN rule (a NaN wins and stays)
+__device__ __forceinline__ void atomic_max_nan(float *addr, float v) {
+  int *ia = reinterpret_cast<int *>(addr);
+  int old = *ia;
+  while (true) {
+    const float f = __int_as_float(old);
+    if (f != f) return;
+    if (v == v && !(v > f)) return;
+    const int assumed = old;
+    old = atomicCAS(ia, assumed, __float_as_int(v));
+    if (old == assumed) return;
+  }
+}
+
+// out_max (optional, caller-initialised to -inf): the maximum of everything gathered - the reference's
+// `batch_grasp_label.max()` (label_generation.py:113) without another pass over the (B,Ns,V,A,D) tensor
 __global__ __launch_bounds__(TPB) void label_gather_kernel(const float *const *__restrict__ srcs,
                                                             const int32_t *__restrict__ obj,
                                                             const int32_t *__restrict__ pt,
                                                             const int64_t *__restrict__ view_inds,
-                                                            float *__restrict__ out, int V, int W) {
+                                                            float *__restrict__ out, float *__restrict__ out_max, int V,
+                                                            int W) {
+  __shared__ float s_m[TPB / 64];
   const int r = blockIdx.x;
   const int o = obj[r];
   const float *src = srcs[o] + (size_t)pt[r] * V * W;
   const int64_t *vi = view_inds + (size_t)o * V;
   float *dst = out + (size_t)r * V * W;
+  float mx = -INFINITY;
+  bool nan = false;
   if ((W & 3) == 0) {
     const int w4 = W >> 2;
     for (int e = threadIdx.x; e < V * w4; e += TPB) {
       const int v = e / w4, q = e % w4;
-      reinterpret_cast<float4 *>(dst)[e] = reinterpret_cast<const float4 *>(src + (size_t)vi[v] * W)[q];
+      const float4 x = reinterpret_cast<const float4 *>(src + (size_t)vi[v] * W)[q];
+      reinterpret_cast<float4 *>(dst)[e] = x;
+      if (out_max) {
+        mx = fmaxf(fmaxf(mx, x.x), fmaxf(fmaxf(x.y, x.z), x.w));
+        nan |= (x.x != x.x) | (x.y != x.y) | (x.z != x.z) | (x.w != x.w);
+      }
     }
   } else {
-    for (int e = threadIdx.x; e < V * W; e += TPB) dst[e] = src[(size_t)vi[e / W] * W + e % W];
+    for (int e = threadIdx.x; e < V * W; e += TPB) {
+      const float x = src[(size_t)vi[e / W] * W + e % W];
+      dst[e] = x;
+      if (out_max) { mx = fmaxf(mx, x); nan |= x != x; }
+    }
+  }
+  if (out_max) {  // block-uniform
+    if (nan) mx = NAN;
+    // wave: NaN-aware maximum through shuffles, then the waves through LDS
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const float other = __shfl_xor(mx, off);
+      mx = (mx != mx || other != other) ? NAN : fmaxf(mx, other);
+    }
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float b = s_m[0];
+      for (int w = 1; w < TPB / 64; ++w) b = (b != b || s_m[w] != s_m[w]) ? NAN : fmaxf(b, s_m[w]);
+      atomic_max_nan(out_max, b);
+    }
   }
 }
 
@@ -467,11 +512,12 @@ extern "C" int gb_label_finish(const float *labels, const float *offsets, const 
 }
 
 extern "C" int gb_label_gather(const float *const *srcs, const int32_t *obj, const int32_t *pt,
-                               const int64_t *view_inds, float *out, int R, int V, int W, void *stream) {
+                               const int64_t *view_inds, float *out, float *out_max, int R, int V, int W,
+                               void *stream) {
   if (R < 0 || V < 1 || W < 1 || !srcs || !obj || !pt || !view_inds || !out) return GB_EINVAL;
   if (R == 0) return GB_OK;
   hipLaunchKernelGGL(label_gather_kernel, dim3(R), dim3(TPB), 0, as_stream(stream), srcs, obj, pt, view_inds, out,
-                     V, W);
+                     out_max, V, W);
   return check_launch("gb_label_gather");
 }
 

@@ -100,18 +100,28 @@ class GraspPoseStage2_seed_features_multi_scale(nn.Module):
             g0 = groups[0]
             idx = fused_ops.cylinder_query_multi(pointcloud, seed_xyz, rot, [g.cylinder_radius for g in groups],
                                                  g0.hmin, g0.hmax_list, g0.nsample)
-            if (fused_mlp.cyl_dedup_enabled() and all(g._cl_ok(pointcloud) for g in groups)
+            cl = all(g._cl_ok(pointcloud) for g in groups)  # every scale returns channel-last pooled rows
+            if (fused_mlp.cyl_dedup_enabled() and cl
                     and len(g0.hmax_list) in (1, 2, 4) and len(g0.hmax_list) * g0.nsample <= 256):
                 # the crops of a seed are nested: run each MLP on the distinct (seed, point) rows only
                 rows = fused_mlp.cylinder_rows(idx, pointcloud, seed_xyz, rot)
-                scales = [g(seed_xyz, pointcloud, rot, rows=rows[i]) for i, g in enumerate(groups)]
+                scales = [g(seed_xyz, pointcloud, rot, rows=rows[i], channel_last=True) for i, g in enumerate(groups)]
             else:
-                scales = [g(seed_xyz, pointcloud, rot, idx=idx[i]) for i, g in enumerate(groups)]
+                scales = [g(seed_xyz, pointcloud, rot, idx=idx[i], channel_last=cl) for i, g in enumerate(groups)]
         else:
+            cl = False
             scales = [g(seed_xyz, pointcloud, rot) for g in groups]
-        B, _, num_seed, num_depth = scales[0].size()
-        fused = self.fuse_multi_scale(torch.cat(scales, dim=1).view(B, -1, num_seed * num_depth))
-        fused = fused.view(B, -1, num_seed, num_depth)
+        if cl:
+            # the 1x1 fuse convolution on the channel-last rows (b, seed, depth): cat along the channels + one linear,
+            # then ONE transpose to the reference layout instead of four (one per scale) before the cat
+            B, num_seed, num_depth = seed_xyz.size(0), seed_xyz.size(1), len(g0.hmax_list)
+            w = self.fuse_multi_scale.weight
+            fused = nn.functional.linear(torch.cat(scales, dim=1), w.view(w.size(0), w.size(1)), self.fuse_multi_scale.bias)
+            fused = fused.view(B, num_seed, num_depth, -1).permute(0, 3, 1, 2).contiguous()
+        else:
+            B, _, num_seed, num_depth = scales[0].size()
+            fused = self.fuse_multi_scale(torch.cat(scales, dim=1).view(B, -1, num_seed * num_depth))
+            fused = fused.view(B, -1, num_seed, num_depth)
         seed_features = end_points['fp2_features']
         gated = self.gate_fusion(seed_features) * seed_features
         vp_features = fused + gated.unsqueeze(3).repeat(1, 1, 1, 4)

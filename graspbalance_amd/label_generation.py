@@ -71,24 +71,28 @@ def _pointer_table(tensors, device):
     return tab
 
 
-def _label_gather(tensors, obj, pt, view_inds, V, W):
-    """out[r,v,:] = tensors[obj[r]][pt[r], view_inds[obj[r], v], :] through the fused HIP gather."""
+def _label_gather(tensors, obj, pt, view_inds, V, W, want_max=False):
+    """out[r,v,:] = tensors[obj[r]][pt[r], view_inds[obj[r], v], :] through the fused HIP gather; with want_max also
+    the maximum of the gathered values (a 0-d tensor, == out.max()) from the same pass."""
     from . import _lib
     dev = obj.device
     out = torch.empty((obj.numel(), V, W), dtype=torch.float32, device=dev)
+    out_max = torch.full((), float("-inf"), dtype=torch.float32, device=dev) if want_max else None
     tab = _pointer_table(tensors, dev)
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().gb_label_gather(_lib.ptr(tab), _lib.ptr(obj), _lib.ptr(pt), _lib.ptr(view_inds),
-                                              _lib.ptr(out), obj.numel(), V, W, _lib.current_stream(dev)),
-                   "label_gather")
-    return out
+                                              _lib.ptr(out), _lib.ptr(out_max), obj.numel(), V, W,
+                                              _lib.current_stream(dev)), "label_gather")
+    return (out, out_max) if want_max else out
 
 
 def _finish_labels(end_points, batch, batch_size, num_samples):
     labels = batch['label']  # (B,Ns,V,A,D)
     V, A, D = labels.shape[2:]
     offsets = batch['offset']
-    u_max = labels.max()
+    u_max = batch.get('label_max')  # from the gather pass (fused path); else one more pass over the tensor
+    if u_max is None:
+        u_max = labels.max()
     if (labels.is_cuda and (A * D) % 4 == 0 and A * D <= 256 and labels.is_contiguous() and offsets.is_contiguous()
             and labels.dtype == torch.float32 and offsets.dtype == torch.float32):
         # one pass (gb_label_finish) instead of compare / and / clamp / div / log / where / max over (B,Ns,V,A,D)
@@ -154,11 +158,13 @@ def _process_grasp_labels_fused(end_points):
     obj = torch.cat(obj_of_seed, 0).contiguous()
     pt = torch.cat(pt_of_seed, 0).contiguous()
     objl = obj.long()
+    label, label_max = _label_gather(labels_l, obj, pt, view_inds, V, A * D, want_max=True)
     batch = {
         'point': torch.stack(points, 0),
         'view': torch.index_select(views_sel, 0, objl).view(B, Ns, V, 3),
         'view_rot': torch.index_select(rot_sel, 0, objl).view(B, Ns, V, 3, 3),
-        'label': _label_gather(labels_l, obj, pt, view_inds, V, A * D).view(B, Ns, V, A, D),
+        'label': label.view(B, Ns, V, A, D),
+        'label_max': label_max,
         'offset': _label_gather(offsets_l, obj, pt, view_inds, V, A * D * 3).view(B, Ns, V, A, D, 3),
         'tolerance': _label_gather(tol_l, obj, pt, view_inds, V, A * D).view(B, Ns, V, A, D),
     }

@@ -152,15 +152,19 @@ class GraspWidthGrouping(nn.Module):
         return fused_mlp.enabled(pointcloud) and fused_mlp.supports(self.mlps) \
             and all(g.use_xyz and g.rotate_xyz and not g.normalize_xyz for g in self.groupers)
 
-    def forward(self, seed_xyz, pointcloud, vp_rot, idx=None, rows=None):
+    def forward(self, seed_xyz, pointcloud, vp_rot, idx=None, rows=None, channel_last=False):
         """idx: optional precomputed neighbour indices (num_depth,B,num_seed,nsample) from the fused
         multi-query kernel; None runs one cylinder query per depth like the reference.
-        rows: optional (x0, RowSet) from fused_mlp.cylinder_rows - the distinct (seed, point) rows of the crops."""
+        rows: optional (x0, RowSet) from fused_mlp.cylinder_rows - the distinct (seed, point) rows of the crops.
+        channel_last (fused paths only): return the pooled rows (B*num_seed*num_depth, C) as they are instead of the
+        reference's (B, C, num_seed, num_depth) layout."""
         B, num_seed, _, _ = vp_rot.size()
         num_depth = len(self.groupers)
         if rows is not None and self._cl_ok(pointcloud):
             x0, rowset = rows
             out = fused_mlp.shared_mlp_cl(x0, self.mlps, rows=rowset)  # (B*seed*depth, 256), rows (b, seed, depth)
+            if channel_last:
+                return out
             return out.view(B, num_seed, num_depth, -1).permute(0, 3, 1, 2).contiguous()
         if idx is not None and self._cl_ok(pointcloud):
             # channel-last: rows ordered (b, seed, depth, sample) exactly like the reference's stacked view
@@ -168,6 +172,8 @@ class GraspWidthGrouping(nn.Module):
                     .view(B, num_seed, self.nsample, 3) for d in range(num_depth)]
             x0 = torch.stack(rows, dim=2).view(-1, 3)
             out = fused_mlp.shared_mlp_cl(x0, self.mlps, pool_ns=self.nsample)  # (B*seed*depth, 256)
+            if channel_last:
+                return out
             return out.view(B, num_seed, num_depth, -1).permute(0, 3, 1, 2).contiguous()
         if idx is None:
             grouped = [g(pointcloud, seed_xyz, vp_rot) for g in self.groupers]

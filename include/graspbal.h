@@ -162,9 +162,10 @@ int gb_knn1(const float *ref, const float *query, int64_t *idx, int b, int dim, 
  *   out[r, v, :] = srcs[obj[r]][pt[r], view_inds[obj[r], v], :]     (W floats per (point, view))
  * srcs: DEVICE array of device pointers, one (Np_o, V, W) tensor per object; obj/pt (R) int32;
  * view_inds (n_objects, V) int64; out (R, V, W).  Composes the reference's two index_selects (views
- * then seeds) so only the kept rows are copied.                                                   */
+ * then seeds) so only the kept rows are copied.  out_max (optional; one float, caller-initialised to
+ * -inf) receives the maximum of everything gathered, NaN if any (the `.max()` of label_generation.py:113). */
 int gb_label_gather(const float *const *srcs, const int32_t *obj, const int32_t *pt,
-                    const int64_t *view_inds, float *out, int R, int V, int W, void *stream);
+                    const int64_t *view_inds, float *out, float *out_max, int R, int V, int W, void *stream);
 /* Score transform + per-view maximum of the gathered labels (reference label_generation.py:112-116):
  * out = log(*u_max / label) where label > 0 and offsets[..., 2] (width) <= max_width, else 0;
  * view_scores[row] = max over the ad = A*D grasps of the row.  labels/out (rows, ad), offsets (rows, ad, 3),

@@ -7,6 +7,9 @@ The reference loads its object-scale prior from ScaleDistribution/objects_scales
 and ``.cuda()``s it (loss.py:18-26); that data file is not part of this repo, so the prior is an
 argument: ``ScalePrior.uniform()`` (all weights 1, used with synthetic data) or ``ScalePrior.from_npy``.
 """
+import ctypes
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -158,7 +161,101 @@ def compute_weighted_grasp_loss(end_points, weight_mask):
     return grasp_score_loss + angle_loss + width_loss + tol_loss, end_points
 
 
+_FUSED_LOSS = os.environ.get("GB_FUSED_LOSS", "1") != "0"  # A/B switch: the loss terms as three HIP launches
+
+
+def _dense_inner(t):
+    """(B,C,...) tensor whose dimensions after the batch are dense (a channel slice of a contiguous tensor is)."""
+    return t.dim() >= 2 and t[0].is_contiguous() and t.dtype == torch.float32 and t.is_cuda
+
+
+class _FusedGraspLoss(torch.autograd.Function):
+    """Every term of get_loss (csrc/loss.hip).  forward -> (out (14,), graspable_mask (B,Ns) int64)."""
+
+    @staticmethod
+    def forward(ctx, obj_score, view_score, score_pred, angle_pred, width_pred, tol_pred, view_label, obj_label, weight,
+                labels, offsets, tolerance):
+        from . import _lib
+        dev = view_score.device
+        B, Ns, V = view_score.shape
+        A, D = labels.shape[2], labels.shape[3]
+        S = B * Ns
+        strides = (ctypes.c_longlong * 5)(obj_score.stride(0), score_pred.stride(0), angle_pred.stride(0),
+                                          width_pred.stride(0), tol_pred.stride(0))
+        work = torch.empty(S * 40 + 3, dtype=torch.float32, device=dev)
+        partial, aux, den = work[:S * 20], work[S * 20:S * 40], work[S * 40:]
+        graspable = torch.empty((B, Ns), dtype=torch.int64, device=dev)
+        out = torch.empty(14, dtype=torch.float32, device=dev)
+        ins = (obj_score, view_score, view_label, obj_label, weight, labels, offsets, tolerance, score_pred, angle_pred,
+               width_pred, tol_pred)
+        ctx.dims = (B, Ns, V, A, D)
+        ctx.strides = strides
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().gb_grasp_loss_fwd(*[_lib.ptr(t) for t in ins], ctypes.cast(strides, ctypes.c_void_p),
+                                                    B, Ns, V, A, D, THRESH_BAD, THRESH_GOOD, GRASP_MAX_WIDTH,
+                                                    GRASP_MAX_TOLERANCE, _lib.ptr(partial), _lib.ptr(aux),
+                                                    _lib.ptr(graspable), _lib.ptr(out), _lib.ptr(den),
+                                                    _lib.current_stream(dev)), "gb_grasp_loss_fwd")
+        ctx.save_for_backward(*ins, aux, graspable, den)
+        ctx.mark_non_differentiable(graspable)
+        return out, graspable
+
+    @staticmethod
+    def backward(ctx, g_out, _g_mask):
+        from . import _lib
+        *ins, aux, graspable, den = ctx.saved_tensors
+        B, Ns, V, A, D = ctx.dims
+        dev = g_out.device
+        g_out = g_out.contiguous().float()
+        d_obj = torch.empty((B, 2, Ns), dtype=torch.float32, device=dev)
+        d_view = torch.empty((B, Ns, V), dtype=torch.float32, device=dev)
+        d_preds = torch.empty((4, B, A, Ns, D), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().gb_grasp_loss_bwd(*[_lib.ptr(t) for t in ins], ctypes.cast(ctx.strides, ctypes.c_void_p),
+                                                    B, Ns, V, A, D, THRESH_BAD, THRESH_GOOD, GRASP_MAX_WIDTH,
+                                                    GRASP_MAX_TOLERANCE, _lib.ptr(aux), _lib.ptr(graspable), _lib.ptr(den),
+                                                    _lib.ptr(g_out), _lib.ptr(d_obj), _lib.ptr(d_view), _lib.ptr(d_preds[0]),
+                                                    _lib.ptr(d_preds[1]), _lib.ptr(d_preds[2]), _lib.ptr(d_preds[3]),
+                                                    _lib.current_stream(dev)), "gb_grasp_loss_bwd")
+        return (d_obj, d_view, d_preds[0], d_preds[1], d_preds[2], d_preds[3], None, None, None, None, None, None)
+
+
+def _fused_loss_ok(end_points):
+    keys = ('objectness_score', 'view_score', 'grasp_score_pred', 'grasp_angle_cls_pred', 'grasp_width_pred',
+            'grasp_tolerance_pred')
+    if not _FUSED_LOSS or not all(_dense_inner(end_points[k]) for k in keys):
+        return False
+    labels = end_points['batch_grasp_label']
+    return (labels.dim() == 4 and labels.size(3) <= 8 and end_points['objectness_score'].size(1) == 2
+            and end_points['grasp_score_pred'].shape[1:] == (labels.size(2), labels.size(1), labels.size(3)))
+
+
+def _get_loss_fused(end_points, prior):
+    """get_loss through _FusedGraspLoss: same keys, same values (masked means accumulated in fp64)."""
+    weight = generate_reweight_mask(end_points, prior)
+    f = lambda t: t.contiguous().float()
+    out, graspable = _FusedGraspLoss.apply(
+        end_points['objectness_score'], f(end_points['view_score']), end_points['grasp_score_pred'],
+        end_points['grasp_angle_cls_pred'], end_points['grasp_width_pred'], end_points['grasp_tolerance_pred'],
+        f(end_points['batch_grasp_view_label']), _seed_objectness(end_points).contiguous(), f(weight),
+        f(end_points['batch_grasp_label']), f(end_points['batch_grasp_offset']), f(end_points['batch_grasp_tolerance']))
+    vals = out.unbind(0)
+    end_points['graspable_mask'] = graspable
+    for k, name in enumerate(('loss/overall_loss', 'loss/stage1_graspable_loss', 'loss/stage1_view_loss',
+                              'loss/stage2_grasp_score_loss', 'loss/stage2_grasp_angle_class_loss',
+                              'loss/stage2_grasp_width_loss', 'loss/stage2_grasp_tolerance_loss', 'stage1_graspable_acc',
+                              'stage1_graspable_prec', 'stage1_graspable_recall', None,
+                              'stage2_grasp_angle_class_acc/0_degree', 'stage2_grasp_angle_class_acc/15_degree',
+                              'stage2_grasp_angle_class_acc/30_degree')):
+        if name:
+            end_points[name] = vals[k]
+    end_points['stage1_pos_view_pred_count'] = vals[10].long()
+    return vals[0], end_points
+
+
 def get_loss(end_points, prior=None):
+    if _fused_loss_ok(end_points):
+        return _get_loss_fused(end_points, prior)
     reweight_mask = generate_reweight_mask(end_points, prior)
     objectness_loss, end_points = compute_robust_graspable_loss(end_points)
     view_loss, end_points = compute_weighted_view_loss(end_points, reweight_mask.clone())

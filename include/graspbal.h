@@ -328,6 +328,32 @@ int gb_gemm_dgrad_first(const float *dy, const float *w, const float *y_prev, co
 /* mom fp64 [12] (caller-zeroed) += [sum_p w_p x (3), sum_p w_p x x^T (3x3)] of x (P,3); w = row_w (P) or 1.   */
 int gb_moments3(const float *x, const float *row_w, long long P, double *mom, void *stream);
 
+/* ---- the training loss (TrainModel/loss.py:44-179) ------------------------------------------------------------
+ * gb_grasp_loss_fwd: every term of get_loss in three launches.  Tensors as the reference holds them: obj_score
+ * (B,2,Ns), view_score / view_label (B,Ns,V), obj_label (B,Ns) int64 = objectness label of each seed, weight (B,Ns)
+ * = generate_reweight_mask (:29-42), labels / offsets / tolerance = the top-view labels (B,Ns,A,D[,3]), the four
+ * predictions (B,A,Ns,D).  obj_score and the predictions may be channel slices of wider tensors: batch_strides (HOST
+ * array of 5: obj_score, score, angle, width, tolerance) gives their batch strides in elements, the inner dimensions
+ * are dense.  D <= 8.  Workspace / results: partial (B*Ns*20), aux (B*Ns*20), den (3) floats; graspable (B,Ns) int64 =
+ * `graspable_mask`; out (14) = [overall, objectness, view, score, angle, width, tolerance losses, graspable acc /
+ * prec / recall, positive-view count, angle accuracy at 0 / 15 / 30 degrees].
+ * gb_grasp_loss_bwd: grad_out (7) = gradients of out[0..6]; writes the dense gradients d_obj (B,2,Ns), d_view
+ * (B,Ns,V), d_score / d_angle / d_width / d_tol (B,A,Ns,D) in full.                                                 */
+int gb_grasp_loss_fwd(const float *obj_score, const float *view_score, const float *view_label,
+                      const int64_t *obj_label, const float *weight, const float *labels, const float *offsets,
+                      const float *tolerance, const float *score_pred, const float *angle_pred,
+                      const float *width_pred, const float *tol_pred, const long long *batch_strides, int B, int Ns,
+                      int V, int A, int D, float thresh_bad, float thresh_good, float max_width, float max_tol,
+                      float *partial, float *aux, int64_t *graspable, float *out, float *den, void *stream);
+int gb_grasp_loss_bwd(const float *obj_score, const float *view_score, const float *view_label,
+                      const int64_t *obj_label, const float *weight, const float *labels, const float *offsets,
+                      const float *tolerance, const float *score_pred, const float *angle_pred,
+                      const float *width_pred, const float *tol_pred, const long long *batch_strides, int B, int Ns,
+                      int V, int A, int D, float thresh_bad, float thresh_good, float max_width, float max_tol,
+                      const float *aux, const int64_t *graspable, const float *den, const float *grad_out,
+                      float *d_obj, float *d_view, float *d_score, float *d_angle, float *d_width, float *d_tol,
+                      void *stream);
+
 #ifdef __cplusplus
 }
 #endif

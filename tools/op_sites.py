@@ -55,5 +55,5 @@ for name, ev in report.items():
     n = sum(e.count for e in ev)
     us = sum(e.self_device_time_total for e in ev)
     print("== %-16s %4d launches %8.1f us" % (name, n, us))
-    for e in sorted(ev, key=lambda e: -e.self_device_time_total)[:14]:
+    for e in sorted(ev, key=lambda e: -e.self_device_time_total)[:40]:
         print("      %-26s n=%3d %7.1f us  %s" % (e.key[:26], e.count, e.self_device_time_total, str(e.input_shapes)[:90]))

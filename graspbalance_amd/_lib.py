@@ -60,9 +60,9 @@ SIGNATURES = {
     "gb_la_point_grad": [_P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _P, _P],
     "gb_la_wx_grad": [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P],
     "gb_label_gather": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
-    "gb_grasp_loss_fwd": [_P] * 13 + [_I] * 5 + [_F] * 4 + [_P] * 6,
-    "gb_grasp_loss_bwd": [_P] * 13 + [_I] * 5 + [_F] * 4 + [_P] * 11,
-    "gb_label_finish": [_P, _P, _P, _F, _P, _P, _L, _I, _P],
+    "gb_grasp_loss_fwd": [_P] * 17 + [_I] * 6 + [_F] * 4 + [_P] * 6,
+    "gb_grasp_loss_bwd": [_P] * 17 + [_I] * 6 + [_F] * 4 + [_P] * 11,
+    "gb_label_finish": [_P, _P, _P, _F, _P, _P, _P, _L, _I, _P],
     "gb_gemm_fwd": [_P, _P, _P, _P, _P, _I, _L, _I, _I, _P],
     "gb_gemm_dgrad": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P],
     "gb_gemm_wgrad": [_P, _P, _P, _P, _L, _I, _I, _P],

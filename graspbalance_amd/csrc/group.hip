@@ -450,12 +450,15 @@ __global__ __launch_bounds__(TPB) void label_gather_kernel(const float *const *_
 constexpr int LF_ROWS = 16;  // views per workgroup
 __global__ void label_finish_kernel(const float *__restrict__ labels, const float *__restrict__ offsets,
                                     const float *__restrict__ u_max, float max_width, float *__restrict__ out,
-                                    float *__restrict__ view_scores, long long rows, int ad4) {
-  extern __shared__ float s_max[];  // [LF_ROWS][ad4]
+                                    float *__restrict__ view_scores, int32_t *__restrict__ view_arg, long long rows,
+                                    int ad4) {
+  extern __shared__ float s_max[];  // [LF_ROWS][ad4] maxima, then [LF_ROWS][ad4] their positions (as int)
+  int *s_pos = reinterpret_cast<int *>(s_max + LF_ROWS * ad4);
   const int rl = threadIdx.x / ad4, q = threadIdx.x % ad4;
   const long long row = (long long)blockIdx.x * LF_ROWS + rl;
   const float um = *u_max;
   float best = -INFINITY;
+  int bpos = 4 * q;  // first position of `best` among this thread's 4 grasps
   if (row < rows) {
     const long long e4 = row * ad4 + q;  // index of this thread's group of 4 grasps
     const float4 l = reinterpret_cast<const float4 *>(labels)[e4];
@@ -470,24 +473,29 @@ __global__ void label_finish_kernel(const float *__restrict__ labels, const floa
       const bool m = lv[t] > 0.f && wv[t] <= max_width;
       const float c = lv[t] < 1e-30f ? 1e-30f : lv[t];  // clamp_min(1e-30) (NaN passes through, as in torch)
       r[t] = m ? logf(um / c) : 0.f;
+      if (r[t] > best) bpos = 4 * q + t;
       best = fmaxf(best, r[t]);
       if (r[t] != r[t]) best = r[t];  // torch.max propagates NaN
     }
     reinterpret_cast<float4 *>(out)[e4] = make_float4(r[0], r[1], r[2], r[3]);
   }
   s_max[threadIdx.x] = best;
+  s_pos[threadIdx.x] = bpos;
   __syncthreads();
   if (threadIdx.x < LF_ROWS) {
     const long long vr = (long long)blockIdx.x * LF_ROWS + threadIdx.x;
     if (vr < rows) {
       float b = -INFINITY;
+      int bp = 0;
       bool nan = false;
       for (int i = 0; i < ad4; ++i) {
         const float v = s_max[threadIdx.x * ad4 + i];
         nan |= v != v;
+        if (v > b) bp = s_pos[threadIdx.x * ad4 + i];  // first position of the maximum (torch.argmax order)
         b = fmaxf(b, v);
       }
       view_scores[vr] = nan ? NAN : b;
+      if (view_arg) view_arg[vr] = bp;
     }
   }
 }
@@ -497,7 +505,7 @@ __global__ void label_finish_kernel(const float *__restrict__ labels, const floa
 using namespace gb;
 
 extern "C" int gb_label_finish(const float *labels, const float *offsets, const float *u_max, float max_width,
-                               float *out, float *view_scores, long long rows, int ad, void *stream) {
+                               float *out, float *view_scores, int32_t *view_arg, long long rows, int ad, void *stream) {
   if (rows < 0 || ad < 4 || ad % 4 != 0 || ad / 4 * LF_ROWS > 1024 || !labels || !offsets || !u_max || !out ||
       !view_scores)
     return GB_EINVAL;
@@ -506,8 +514,8 @@ extern "C" int gb_label_finish(const float *labels, const float *offsets, const 
   if (rows == 0) return GB_OK;
   const int ad4 = ad / 4, threads = LF_ROWS * ad4;
   hipLaunchKernelGGL(label_finish_kernel, dim3((unsigned)((rows + LF_ROWS - 1) / LF_ROWS)), dim3(threads),
-                     threads * sizeof(float), as_stream(stream), labels, offsets, u_max, max_width, out, view_scores, rows,
-                     ad4);
+                     2 * threads * sizeof(float), as_stream(stream), labels, offsets, u_max, max_width, out, view_scores,
+                     view_arg, rows, ad4);
   return check_launch("gb_label_finish");
 }
 

@@ -34,6 +34,13 @@ struct LossArgs {
   const float *offsets;     // (B,Ns,A,D,3) top-view (angle, depth, width)
   const float *tolerance;   // (B,Ns,A,D)
   const float *score_pred, *angle_pred, *width_pred, *tol_pred;  // (B,A,Ns,D)
+  // optional (view_arg != nullptr): the seed weight is formed here instead of read from `weight` - the reference's
+  // generate_reweight_mask (loss.py:29-42): width of the best grasp over ALL views of the seed, binned by the prior
+  const int32_t *view_arg;   // (B,Ns,V)  position in [0, A*D) of each view's best label (gb_label_finish)
+  const float *offsets_all;  // (B,Ns,V,A,D,3)
+  const float *edges;        // (nb+1) bin edges, ascending
+  const float *prior_w;      // (nb) bin weights
+  int nb;
   int B, Ns, V, A, D;
   long long bs_obj, bs_score, bs_angle, bs_width, bs_tol;  // batch strides (elements) of obj_score and the four predictions
   float thresh_bad, thresh_good, max_width, max_tol;
@@ -71,8 +78,11 @@ __global__ __launch_bounds__(256) void loss_seed_kernel(LossArgs g, float *__res
   // ---- views
   const float *vs = g.view_score + s * g.V, *vl = g.view_label + s * g.V;
   float cnt = 0.f, sq = 0.f, pos = 0.f;
+  float bestv = -INFINITY;
+  int besti = 0x7fffffff;
   for (int v = lane; v < g.V; v += 64) {
     const float a = vs[v], l = vl[v];
+    if (l > bestv) { bestv = l; besti = v; }  // first maximum among this lane's views
     cnt += l > g.thresh_bad ? 1.f : 0.f;
     const float df = a - l;
     sq += df * df;
@@ -83,7 +93,23 @@ __global__ __launch_bounds__(256) void loss_seed_kernel(LossArgs g, float *__res
   pos = wave_sum(pos);
   const long long ol = g.obj_label[s];
   const long long glabel = cnt > 10.f ? ol : 0;
-  const float w = g.weight[s];
+  float w;
+  if (g.view_arg) {  // wave-uniform
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {  // arg-max over the views: largest value, then the lowest view index
+      const float ov = __shfl_xor(bestv, off);
+      const int oi = __shfl_xor(besti, off);
+      if (ov > bestv || (ov == bestv && oi < besti)) { bestv = ov; besti = oi; }
+    }
+    const long long vrow = s * g.V + besti;
+    const float width = g.offsets_all[(vrow * g.A * g.D + g.view_arg[vrow]) * 3 + 2];
+    int nlt = 0;  // torch.bucketize(width, edges): the number of edges below it
+    for (int k = 0; k <= g.nb; ++k) nlt += g.edges[k] < width ? 1 : 0;
+    const bool inside = nlt >= 1 && nlt <= g.nb && width != g.edges[nlt < g.nb ? nlt : g.nb];
+    w = g.prior_w[inside ? nlt - 1 : 0];
+  } else {
+    w = g.weight[s];
+  }
   const bool vmask = glabel * ol > 0;
   const float mw = vmask ? w : 0.f;
   // ---- objectness cross entropy (2 classes)
@@ -279,9 +305,10 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(LossArgs g, const float *
 
 using namespace gb;
 
-static bool loss_args_ok(const LossArgs &g) {
+static bool loss_args_ok(const LossArgs &g, bool forward) {
+  if (forward && (g.view_arg ? (!g.offsets_all || !g.edges || !g.prior_w || g.nb < 1) : !g.weight)) return false;
   return g.B >= 1 && g.Ns >= 1 && g.V >= 1 && g.A >= 1 && g.D >= 1 && g.D <= LS_MAXD && g.obj_score && g.view_score &&
-         g.view_label && g.obj_label && g.weight && g.labels && g.offsets && g.tolerance && g.score_pred && g.angle_pred &&
+         g.view_label && g.obj_label && g.labels && g.offsets && g.tolerance && g.score_pred && g.angle_pred &&
          g.width_pred && g.tol_pred;
 }
 
@@ -289,14 +316,15 @@ extern "C" int gb_grasp_loss_fwd(const float *obj_score, const float *view_score
                                  const int64_t *obj_label, const float *weight, const float *labels,
                                  const float *offsets, const float *tolerance, const float *score_pred,
                                  const float *angle_pred, const float *width_pred, const float *tol_pred,
-                                 const long long *batch_strides, int B, int Ns, int V, int A, int D, float thresh_bad, float thresh_good, float max_width, float max_tol,
+                                 const long long *batch_strides, const int32_t *view_arg, const float *offsets_all,
+                                 const float *edges, const float *prior_w, int nb, int B, int Ns, int V, int A, int D, float thresh_bad, float thresh_good, float max_width, float max_tol,
                                  float *partial, float *aux, int64_t *graspable, float *out, float *den, void *stream) {
   if (!batch_strides) return GB_EINVAL;
   const long long *bsv = batch_strides;  // HOST array [obj_score, score, angle, width, tol]
   const LossArgs g = {obj_score, view_score, view_label, obj_label, weight, labels, offsets, tolerance, score_pred,
-                      angle_pred, width_pred, tol_pred, B, Ns, V, A, D, bsv[0], bsv[1], bsv[2], bsv[3], bsv[4], thresh_bad, thresh_good,
+                      angle_pred, width_pred, tol_pred, view_arg, offsets_all, edges, prior_w, nb, B, Ns, V, A, D, bsv[0], bsv[1], bsv[2], bsv[3], bsv[4], thresh_bad, thresh_good,
                       max_width, max_tol};
-  if (!loss_args_ok(g) || !partial || !aux || !graspable || !out || !den) return GB_EINVAL;
+  if (!loss_args_ok(g, true) || !partial || !aux || !graspable || !out || !den) return GB_EINVAL;
   const long long S = (long long)B * Ns;
   hipLaunchKernelGGL(loss_seed_kernel, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, as_stream(stream), g, partial, aux,
                      graspable);
@@ -308,16 +336,17 @@ extern "C" int gb_grasp_loss_bwd(const float *obj_score, const float *view_score
                                  const int64_t *obj_label, const float *weight, const float *labels,
                                  const float *offsets, const float *tolerance, const float *score_pred,
                                  const float *angle_pred, const float *width_pred, const float *tol_pred,
-                                 const long long *batch_strides, int B, int Ns, int V, int A, int D, float thresh_bad, float thresh_good, float max_width, float max_tol,
+                                 const long long *batch_strides, const int32_t *view_arg, const float *offsets_all,
+                                 const float *edges, const float *prior_w, int nb, int B, int Ns, int V, int A, int D, float thresh_bad, float thresh_good, float max_width, float max_tol,
                                  const float *aux, const int64_t *graspable, const float *den, const float *grad_out,
                                  float *d_obj, float *d_view, float *d_score, float *d_angle, float *d_width,
                                  float *d_tol, void *stream) {
   if (!batch_strides) return GB_EINVAL;
   const long long *bsv = batch_strides;  // HOST array [obj_score, score, angle, width, tol]
   const LossArgs g = {obj_score, view_score, view_label, obj_label, weight, labels, offsets, tolerance, score_pred,
-                      angle_pred, width_pred, tol_pred, B, Ns, V, A, D, bsv[0], bsv[1], bsv[2], bsv[3], bsv[4], thresh_bad, thresh_good,
+                      angle_pred, width_pred, tol_pred, view_arg, offsets_all, edges, prior_w, nb, B, Ns, V, A, D, bsv[0], bsv[1], bsv[2], bsv[3], bsv[4], thresh_bad, thresh_good,
                       max_width, max_tol};
-  if (!loss_args_ok(g) || !aux || !graspable || !den || !grad_out || !d_obj || !d_view || !d_score || !d_angle ||
+  if (!loss_args_ok(g, false) || !aux || !graspable || !den || !grad_out || !d_obj || !d_view || !d_score || !d_angle ||
       !d_width || !d_tol)
     return GB_EINVAL;
   const long long S = (long long)B * Ns;

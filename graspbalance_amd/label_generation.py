@@ -99,9 +99,12 @@ def _finish_labels(end_points, batch, batch_size, num_samples):
         from . import _lib
         out = torch.empty_like(labels)
         view_scores = torch.empty((batch_size, num_samples, V), dtype=torch.float32, device=labels.device)
+        view_arg = torch.empty((batch_size, num_samples, V), dtype=torch.int32, device=labels.device)
+        end_points['_view_label_arg'] = view_arg  # where in (A,D) each view's maximum sits (first one)
         with torch.cuda.device(labels.device):
             _lib.check(_lib.lib().gb_label_finish(_lib.ptr(labels), _lib.ptr(offsets), _lib.ptr(u_max),
                                                   float(GRASP_MAX_WIDTH), _lib.ptr(out), _lib.ptr(view_scores),
+                                                  _lib.ptr(view_arg),
                                                   batch_size * num_samples * V, A * D,
                                                   _lib.current_stream(labels.device)), "gb_label_finish")
         labels = out

@@ -174,7 +174,7 @@ class _FusedGraspLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, obj_score, view_score, score_pred, angle_pred, width_pred, tol_pred, view_label, obj_label, weight,
-                labels, offsets, tolerance):
+                labels, offsets, tolerance, view_arg=None, offsets_all=None, edges=None, prior_w=None):
         from . import _lib
         dev = view_score.device
         B, Ns, V = view_score.shape
@@ -190,13 +190,15 @@ class _FusedGraspLoss(torch.autograd.Function):
                width_pred, tol_pred)
         ctx.dims = (B, Ns, V, A, D)
         ctx.strides = strides
+        extra = (view_arg, offsets_all, edges, prior_w)
+        ctx.nb = int(prior_w.numel()) if prior_w is not None else 0
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().gb_grasp_loss_fwd(*[_lib.ptr(t) for t in ins], ctypes.cast(strides, ctypes.c_void_p),
-                                                    B, Ns, V, A, D, THRESH_BAD, THRESH_GOOD, GRASP_MAX_WIDTH,
+                                                    *[_lib.ptr(t) for t in extra], ctx.nb, B, Ns, V, A, D, THRESH_BAD, THRESH_GOOD, GRASP_MAX_WIDTH,
                                                     GRASP_MAX_TOLERANCE, _lib.ptr(partial), _lib.ptr(aux),
                                                     _lib.ptr(graspable), _lib.ptr(out), _lib.ptr(den),
                                                     _lib.current_stream(dev)), "gb_grasp_loss_fwd")
-        ctx.save_for_backward(*ins, aux, graspable, den)
+        ctx.save_for_backward(*ins, aux, graspable, den)  # backward reads the masks from aux, not the weights
         ctx.mark_non_differentiable(graspable)
         return out, graspable
 
@@ -212,12 +214,12 @@ class _FusedGraspLoss(torch.autograd.Function):
         d_preds = torch.empty((4, B, A, Ns, D), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().gb_grasp_loss_bwd(*[_lib.ptr(t) for t in ins], ctypes.cast(ctx.strides, ctypes.c_void_p),
-                                                    B, Ns, V, A, D, THRESH_BAD, THRESH_GOOD, GRASP_MAX_WIDTH,
+                                                    None, None, None, None, 0, B, Ns, V, A, D, THRESH_BAD, THRESH_GOOD, GRASP_MAX_WIDTH,
                                                     GRASP_MAX_TOLERANCE, _lib.ptr(aux), _lib.ptr(graspable), _lib.ptr(den),
                                                     _lib.ptr(g_out), _lib.ptr(d_obj), _lib.ptr(d_view), _lib.ptr(d_preds[0]),
                                                     _lib.ptr(d_preds[1]), _lib.ptr(d_preds[2]), _lib.ptr(d_preds[3]),
                                                     _lib.current_stream(dev)), "gb_grasp_loss_bwd")
-        return (d_obj, d_view, d_preds[0], d_preds[1], d_preds[2], d_preds[3], None, None, None, None, None, None)
+        return (d_obj, d_view, d_preds[0], d_preds[1], d_preds[2], d_preds[3]) + (None,) * 10
 
 
 def _fused_loss_ok(end_points):
@@ -232,13 +234,26 @@ def _fused_loss_ok(end_points):
 
 def _get_loss_fused(end_points, prior):
     """get_loss through _FusedGraspLoss: same keys, same values (masked means accumulated in fp64)."""
-    weight = generate_reweight_mask(end_points, prior)
     f = lambda t: t.contiguous().float()
+    view_label = f(end_points['batch_grasp_view_label'])
+    labels_all, view_arg = end_points['batch_grasp_label_all'], end_points.get('_view_label_arg')
+    offsets_all = end_points['batch_grasp_offset_all']
+    extra = ()
+    weight = None
+    if (view_arg is not None and end_points.get('_view_label_source') is labels_all and offsets_all.is_contiguous()
+            and offsets_all.dtype == torch.float32 and view_arg.shape == view_label.shape):
+        # per-view maxima and their positions came out of gb_label_finish: the arg-max over all views of a seed, the
+        # width gather and the prior lookup of generate_reweight_mask happen inside the loss kernel
+        prior_w, edges = (prior or _DEFAULT_PRIOR)._on(view_label.device)
+        extra = (view_arg, offsets_all, edges, prior_w)
+    else:
+        weight = f(generate_reweight_mask(end_points, prior))
     out, graspable = _FusedGraspLoss.apply(
         end_points['objectness_score'], f(end_points['view_score']), end_points['grasp_score_pred'],
         end_points['grasp_angle_cls_pred'], end_points['grasp_width_pred'], end_points['grasp_tolerance_pred'],
-        f(end_points['batch_grasp_view_label']), _seed_objectness(end_points).contiguous(), f(weight),
-        f(end_points['batch_grasp_label']), f(end_points['batch_grasp_offset']), f(end_points['batch_grasp_tolerance']))
+        view_label, _seed_objectness(end_points).contiguous(), weight,
+        f(end_points['batch_grasp_label']), f(end_points['batch_grasp_offset']), f(end_points['batch_grasp_tolerance']),
+        *extra)
     vals = out.unbind(0)
     end_points['graspable_mask'] = graspable
     for k, name in enumerate(('loss/overall_loss', 'loss/stage1_graspable_loss', 'loss/stage1_view_loss',

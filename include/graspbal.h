@@ -169,9 +169,11 @@ int gb_label_gather(const float *const *srcs, const int32_t *obj, const int32_t 
 /* Score transform + per-view maximum of the gathered labels (reference label_generation.py:112-116):
  * out = log(*u_max / label) where label > 0 and offsets[..., 2] (width) <= max_width, else 0;
  * view_scores[row] = max over the ad = A*D grasps of the row.  labels/out (rows, ad), offsets (rows, ad, 3),
- * u_max: device scalar (the maximum of `labels`); ad % 4 == 0; 16-byte aligned tensors.                */
+ * u_max: device scalar (the maximum of `labels`); ad % 4 == 0; 16-byte aligned tensors.  view_arg (optional,
+ * (rows) int32): the position in [0, ad) of that maximum, the first one - with view_scores it gives the arg-max
+ * over all views of a seed that loss.py:31 takes, without another pass over the tensor.                  */
 int gb_label_finish(const float *labels, const float *offsets, const float *u_max, float max_width, float *out,
-                    float *view_scores, long long rows, int ad, void *stream);
+                    float *view_scores, int32_t *view_arg, long long rows, int ad, void *stream);
 
 /* ---- channel-last fused pieces of the SharedMLP (1x1 conv + BatchNorm + ReLU + max over nsample) ----
  * No reference launcher corresponds one-to-one: these replace the torch passes the reference runs
@@ -334,7 +336,9 @@ int gb_moments3(const float *x, const float *row_w, long long P, double *mom, vo
  * = generate_reweight_mask (:29-42), labels / offsets / tolerance = the top-view labels (B,Ns,A,D[,3]), the four
  * predictions (B,A,Ns,D).  obj_score and the predictions may be channel slices of wider tensors: batch_strides (HOST
  * array of 5: obj_score, score, angle, width, tolerance) gives their batch strides in elements, the inner dimensions
- * are dense.  D <= 8.  Workspace / results: partial (B*Ns*20), aux (B*Ns*20), den (3) floats; graspable (B,Ns) int64 =
+ * are dense.  D <= 8.  With view_arg != NULL the seed weights are formed in the kernel instead of read from `weight`:
+ * view_arg (B,Ns,V) int32 from gb_label_finish, offsets_all (B,Ns,V,A,D,3), the prior's nb+1 ascending bin edges and nb
+ * bin weights (ScalePrior of loss.py:18-42).  Workspace / results: partial (B*Ns*20), aux (B*Ns*20), den (3) floats; graspable (B,Ns) int64 =
  * `graspable_mask`; out (14) = [overall, objectness, view, score, angle, width, tolerance losses, graspable acc /
  * prec / recall, positive-view count, angle accuracy at 0 / 15 / 30 degrees].
  * gb_grasp_loss_bwd: grad_out (7) = gradients of out[0..6]; writes the dense gradients d_obj (B,2,Ns), d_view
@@ -342,14 +346,16 @@ int gb_moments3(const float *x, const float *row_w, long long P, double *mom, vo
 int gb_grasp_loss_fwd(const float *obj_score, const float *view_score, const float *view_label,
                       const int64_t *obj_label, const float *weight, const float *labels, const float *offsets,
                       const float *tolerance, const float *score_pred, const float *angle_pred,
-                      const float *width_pred, const float *tol_pred, const long long *batch_strides, int B, int Ns,
-                      int V, int A, int D, float thresh_bad, float thresh_good, float max_width, float max_tol,
+                      const float *width_pred, const float *tol_pred, const long long *batch_strides,
+                      const int32_t *view_arg, const float *offsets_all, const float *edges, const float *prior_w, int nb,
+                      int B, int Ns, int V, int A, int D, float thresh_bad, float thresh_good, float max_width, float max_tol,
                       float *partial, float *aux, int64_t *graspable, float *out, float *den, void *stream);
 int gb_grasp_loss_bwd(const float *obj_score, const float *view_score, const float *view_label,
                       const int64_t *obj_label, const float *weight, const float *labels, const float *offsets,
                       const float *tolerance, const float *score_pred, const float *angle_pred,
-                      const float *width_pred, const float *tol_pred, const long long *batch_strides, int B, int Ns,
-                      int V, int A, int D, float thresh_bad, float thresh_good, float max_width, float max_tol,
+                      const float *width_pred, const float *tol_pred, const long long *batch_strides,
+                      const int32_t *view_arg, const float *offsets_all, const float *edges, const float *prior_w, int nb,
+                      int B, int Ns, int V, int A, int D, float thresh_bad, float thresh_good, float max_width, float max_tol,
                       const float *aux, const int64_t *graspable, const float *den, const float *grad_out,
                       float *d_obj, float *d_view, float *d_score, float *d_angle, float *d_width, float *d_tol,
                       void *stream);

@@ -296,8 +296,10 @@ def test_label_finish_matches_torch_composition():
     u_max = labels.max()
     out = torch.empty_like(labels)
     vs = torch.empty(B, Ns, V, device="cuda:0")
+    va = torch.empty(B, Ns, V, dtype=torch.int32, device="cuda:0")
     _lib.check(_lib.lib().gb_label_finish(_lib.ptr(labels), _lib.ptr(offsets), _lib.ptr(u_max), float(GRASP_MAX_WIDTH),
-                                          _lib.ptr(out), _lib.ptr(vs), B * Ns * V, A * D, None), "label_finish")
+                                          _lib.ptr(out), _lib.ptr(vs), _lib.ptr(va), B * Ns * V, A * D, None),
+               "label_finish")
     torch.cuda.synchronize()
     mask = (labels > 0) & (offsets[..., 2] <= GRASP_MAX_WIDTH)
     ref = labels.clone()
@@ -306,6 +308,11 @@ def test_label_finish_matches_torch_composition():
     ref_vs = ref.view(B, Ns, V, A * D).max(dim=-1)[0]
     assert torch.equal(out, ref)
     assert torch.equal(vs, ref_vs)
+    assert torch.equal(va.long(), ref.view(B, Ns, V, A * D).argmax(dim=-1))  # first maximum, many exact ties (zeros)
+    # ... which composes to the arg-max over all views of a seed (loss.py:31)
+    top_view = vs.argmax(dim=2, keepdim=True)
+    flat = top_view * (A * D) + torch.gather(va.long(), 2, top_view)
+    assert torch.equal(flat.squeeze(2), ref.view(B, Ns, -1).argmax(dim=2))
 
 
 @pytest.mark.parametrize("tie", ["lowest", "tree512", "tree1024"])

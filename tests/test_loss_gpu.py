@@ -14,7 +14,7 @@ LOSS_KEYS = ['loss/overall_loss', 'loss/stage1_graspable_loss', 'loss/stage1_vie
              'stage2_grasp_angle_class_acc/30_degree']
 
 
-def _inputs(seed, B=3, Ns=70, V=40, A=12, D=4, N=500, empty=False):
+def _inputs(seed, B=3, Ns=70, V=40, A=12, D=4, N=500, empty=False, with_view_arg=False):
     g = torch.Generator().manual_seed(seed)
     r = lambda *s: torch.rand(*s, generator=g)
     feats = (torch.randn(B, 2 + V, Ns, generator=g)).to(DEV).requires_grad_(True)
@@ -36,17 +36,21 @@ def _inputs(seed, B=3, Ns=70, V=40, A=12, D=4, N=500, empty=False):
         'batch_grasp_offset': take(offsets_all).to(DEV), 'batch_grasp_tolerance': take(tol_all).to(DEV),
         'objectness_label': obj.to(DEV), 'fp2_inds': torch.randint(0, N, (B, Ns), generator=g).int().to(DEV),
     }
+    if with_view_arg:  # what gb_label_finish leaves behind: the loss kernel then forms the seed weights itself
+        ep['_view_label_arg'] = labels_all.view(B, Ns, V, -1).argmax(3).int().to(DEV)
+        ep['_view_label_source'] = ep['batch_grasp_label_all']
     return ep, (feats, head, tol)
 
 
+@pytest.mark.parametrize("with_view_arg", [False, True])
 @pytest.mark.parametrize("seed,empty", [(0, False), (1, False), (2, True)])
-def test_fused_loss_equals_torch_formulation(monkeypatch, seed, empty):
+def test_fused_loss_equals_torch_formulation(monkeypatch, seed, empty, with_view_arg):
     from graspbalance_amd import loss as L
     prior = L.ScalePrior(np.arange(1, 33)[::-1].copy(), np.linspace(0.1 / 33, 0.1, 33))
     res = {}
     for fused in (True, False):
         monkeypatch.setattr(L, "_FUSED_LOSS", fused)
-        ep, leaves = _inputs(seed, empty=empty)
+        ep, leaves = _inputs(seed, empty=empty, with_view_arg=with_view_arg)
         assert L._fused_loss_ok(ep) == fused
         loss, ep = L.get_loss(ep, prior)
         grads = torch.autograd.grad(loss, leaves)

@@ -1,0 +1,98 @@
+"""Adam (the reference's optimizer, train.py:94: torch.optim.Adam defaults) on ONE flat parameter buffer.
+
+GraspBalance has 253 parameter tensors, most of them tiny (BatchNorm scales, biases): torch's multi-tensor Adam spends
+~1 ms of host time per step building its tensor lists and 0.33 ms of GPU time in 12 chunked launches that move 250 MB
+at 0.8 TB/s.  Here every ``p.data`` is a view into one flat fp32 buffer, the moments are flat too, the gradients are
+packed with one multi-tensor copy and the update is ONE fused launch over 9 M elements - the same per-element
+arithmetic (torch's own fused Adam kernel on CUDA), so parameters follow torch.optim.Adam's trajectory.
+
+``state_dict()`` has torch.optim.Adam's layout (per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq``; the tensors
+are views of the flat buffers) and ``load_state_dict`` copies into them.  A parameter whose ``.grad`` is None takes
+part with a zero gradient (torch skips it); every GraspBalance parameter receives a gradient in every step.
+"""
+import math
+
+import torch
+from torch.optim import Optimizer
+
+
+class FlatAdam(Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        if len(self.param_groups) != 1:
+            raise ValueError("FlatAdam takes one parameter group")
+        ps = [p for p in self.param_groups[0]['params'] if p.requires_grad]
+        if not ps or any(p.dtype != torch.float32 or p.device != ps[0].device for p in ps):
+            raise ValueError("FlatAdam needs float32 parameters on one device")
+        self._params = ps
+        dev = ps[0].device
+        total = sum(p.numel() for p in ps)
+        self._flat_p = torch.empty(total, dtype=torch.float32, device=dev)
+        self._flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._step_t = torch.zeros((), dtype=torch.float32, device=dev)
+        self._steps = 0
+        self._grad_views = []
+        off = 0
+        for p in ps:
+            n = p.numel()
+            view = self._flat_p[off:off + n].view_as(p)
+            view.copy_(p.data)
+            p.data = view  # the parameter now lives in the flat buffer
+            self._grad_views.append(self._flat_g[off:off + n].view_as(p))
+            self.state[p] = {'step': self._step_t, 'exp_avg': self._exp_avg[off:off + n].view_as(p),
+                             'exp_avg_sq': self._exp_avg_sq[off:off + n].view_as(p)}
+            off += n
+        self._fused = dev.type == "cuda" and hasattr(torch, "_fused_adam_")
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        group = self.param_groups[0]
+        lr, (beta1, beta2), eps, wd = group['lr'], group['betas'], group['eps'], group['weight_decay']
+        have_v, have_g = [], []
+        for v, p in zip(self._grad_views, self._params):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad is not v:
+                have_v.append(v)
+                have_g.append(p.grad)
+        if have_v:
+            torch._foreach_copy_(have_v, have_g)
+        self._steps += 1
+        self._step_t += 1
+        if self._fused:
+            torch._fused_adam_([self._flat_p], [self._flat_g], [self._exp_avg], [self._exp_avg_sq], [], [self._step_t],
+                               lr=float(lr), beta1=beta1, beta2=beta2, weight_decay=wd, eps=eps, amsgrad=False,
+                               maximize=False, grad_scale=None, found_inf=None)
+        else:  # torch.optim.Adam's single-tensor arithmetic
+            g = self._flat_g
+            if wd != 0:
+                g = g.add(self._flat_p, alpha=wd)
+            self._exp_avg.lerp_(g, 1 - beta1)
+            self._exp_avg_sq.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+            bc1 = 1 - beta1 ** self._steps
+            bc2 = 1 - beta2 ** self._steps
+            denom = (self._exp_avg_sq.sqrt() / math.sqrt(bc2)).add_(eps)
+            self._flat_p.addcdiv_(self._exp_avg, denom, value=-lr / bc1)
+        return loss
+
+    def load_state_dict(self, state_dict):
+        """torch.optim.Adam's layout in; the moments are copied INTO the flat buffers (the views stay views)."""
+        ids = state_dict['param_groups'][0]['params']
+        for pid, p in zip(ids, self.param_groups[0]['params']):
+            st = state_dict['state'].get(pid)
+            if st is None or p not in self.state:
+                continue
+            self.state[p]['exp_avg'].copy_(st['exp_avg'])
+            self.state[p]['exp_avg_sq'].copy_(st['exp_avg_sq'])
+            self._steps = int(st['step'])
+        self._step_t.fill_(float(self._steps))
+        for k, v in state_dict['param_groups'][0].items():
+            if k != 'params':
+                self.param_groups[0][k] = v

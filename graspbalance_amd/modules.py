@@ -7,7 +7,7 @@ import torch.nn.functional as F
 
 from . import fused_mlp
 from . import pytorch_utils as pt_utils
-from .loss_utils import batch_viewpoint_params_to_matrix, generate_grasp_views, grasp_views_on
+from .loss_utils import batch_viewpoint_params_to_matrix, grasp_views_on
 from .pointnet2_utils import CylinderQueryAndGroup, furthest_point_sample
 
 

@@ -118,7 +118,11 @@ def main():
     for _ in range(args.warmup):
         trainer.train_step(batch)
     barrier()
-    with _lib.KernelTimer(["gb_fps", "gb_gemm_fwd", "gb_gemm_fwd_w", "gb_gemm_dgrad", "gb_gemm_dgrad_first", "gb_gemm_wgrad"]) as kt:
+    # ~240 timed launches per step, two events each: created before the timed region, recorded inside it
+    timer = _lib.KernelTimer(["gb_fps", "gb_gemm_fwd", "gb_gemm_fwd_w", "gb_gemm_dgrad", "gb_gemm_dgrad_first",
+                              "gb_gemm_wgrad"], reserve=min(2 * 260 * args.steps, 20000))
+    barrier()
+    with timer as kt:
         t0 = time.perf_counter()
         for _ in range(args.steps):
             loss = trainer.train_step(batch)

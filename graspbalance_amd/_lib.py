@@ -118,9 +118,20 @@ class KernelTimer:
 
     active = None
 
-    def __init__(self, names):
+    def __init__(self, names, reserve=0):
+        """reserve: events created up front (creating them inside the timed region is host time the step pays)."""
         self.names = set(names)
         self.events = {n: [] for n in names}
+        self._pool = []
+        if reserve:
+            import torch
+            self._pool = [torch.cuda.Event(enable_timing=True) for _ in range(reserve)]
+
+    def _event(self):
+        if self._pool:
+            return self._pool.pop()
+        import torch
+        return torch.cuda.Event(enable_timing=True)
 
     def __enter__(self):
         KernelTimer.active = self
@@ -146,7 +157,7 @@ def timed(name, device, meta, launch):
         return launch()
     import torch
     s = torch.cuda.current_stream(device)
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a, b = t._event(), t._event()
     a.record(s)
     rc = launch()
     b.record(s)

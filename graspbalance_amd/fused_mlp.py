@@ -102,14 +102,21 @@ def _call(name, dev, *args, meta=None):
     fn = _FN.get(name)
     if fn is None:
         fn = _FN[name] = getattr(_lib.lib(), name)
-    if _lib.KernelTimer.active is None and (dev.index is None or dev.index == torch.cuda.current_device()):
-        rc = fn(*args)
-        if rc:
-            _lib.check(rc, name)
+    timer = _lib.KernelTimer.active
+    wanted = timer is not None and name in timer.names  # a timer only costs the launches it asked for
+    if dev.index is None or dev.index == torch.cuda.current_device():
+        if not wanted:
+            rc = fn(*args)
+            if rc:
+                _lib.check(rc, name)
+            return
+        if meta is None:
+            meta = {"ints": tuple(a for a in args if isinstance(a, int))}  # sizes, for tools/kernel_breakdown.py
+        _lib.check(_lib.timed(name, dev, meta, lambda: fn(*args)), name)
         return
     with torch.cuda.device(dev):
-        if meta is None and _lib.KernelTimer.active is not None:
-            meta = {"ints": tuple(a for a in args if isinstance(a, int))}  # sizes, for tools/kernel_breakdown.py
+        if meta is None and wanted:
+            meta = {"ints": tuple(a for a in args if isinstance(a, int))}
         _lib.check(_lib.timed(name, dev, meta, lambda: fn(*args)), name)
 
 

@@ -218,6 +218,25 @@ def ptr(t):
     return _c.c_void_p(t.data_ptr()) if t is not None else _c.c_void_p(0)
 
 
+class _NoContext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_CONTEXT = _NoContext()
+
+
+def device_ctx(device):
+    """``torch.cuda.device(device)`` only when `device` is not already current (the guard costs ~4 us per launch)."""
+    import torch
+    if device.index is None or device.index == torch.cuda.current_device():
+        return _NO_CONTEXT
+    return torch.cuda.device(device)
+
+
 def current_stream(device):
     import torch
     return _c.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -29,7 +29,7 @@ def cylinder_query_multi(xyz, new_xyz, rot, radii, hmin, hmaxs, nsample):
     out = torch.empty((nr, nh, B, npoint, nsample), dtype=torch.int32, device=xyz.device)
     ra = (ctypes.c_float * nr)(*[float(r) for r in radii])
     ha = (ctypes.c_float * nh)(*[float(h) for h in hmaxs])
-    with torch.cuda.device(xyz.device):
+    with _lib.device_ctx(xyz.device):
         _lib.check(_lib.lib().gb_cylinder_query_multi(
             _lib.ptr(new_xyz), _lib.ptr(xyz), _lib.ptr(rot9), _lib.ptr(out), B, xyz.size(1), npoint,
             ctypes.cast(ra, ctypes.c_void_p), nr, float(hmin), ctypes.cast(ha, ctypes.c_void_p), nh,
@@ -58,7 +58,7 @@ def fps_segments(xyz_packed, seg_sizes, sample_counts):
     table = torch.tensor([offs, outs], dtype=torch.int32).to(dev, non_blocking=True)
     idx = torch.zeros(outs[S], dtype=torch.int32, device=dev)
     temp = torch.empty(max(offs[S], 1), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.device_ctx(dev):
         _lib.check(_lib.lib().gb_fps_segments(_lib.ptr(xyz_packed), _lib.ptr(table[0]), _lib.ptr(table[1]), _lib.ptr(temp),
                                               _lib.ptr(idx), S, max([int(n) for n in seg_sizes], default=0),
                                               _hip_ext.FPS_FLAGS, _lib.current_stream(dev)), "fps_segments")

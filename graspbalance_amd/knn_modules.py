@@ -16,7 +16,7 @@ def knn(ref, query, idx):
             raise RuntimeError("knn: tensors must be contiguous")
     B, dim, nref = ref.shape
     nq = query.size(2)
-    with torch.cuda.device(ref.device):
+    with _lib.device_ctx(ref.device):
         _lib.check(_lib.lib().gb_knn1(_lib.ptr(ref), _lib.ptr(query), _lib.ptr(idx), B, dim, nref, nq,
                                       _lib.current_stream(ref.device)), "knn")
     return 1

@@ -79,7 +79,7 @@ def _label_gather(tensors, obj, pt, view_inds, V, W, want_max=False):
     out = torch.empty((obj.numel(), V, W), dtype=torch.float32, device=dev)
     out_max = torch.full((), float("-inf"), dtype=torch.float32, device=dev) if want_max else None
     tab = _pointer_table(tensors, dev)
-    with torch.cuda.device(dev):
+    with _lib.device_ctx(dev):
         _lib.check(_lib.lib().gb_label_gather(_lib.ptr(tab), _lib.ptr(obj), _lib.ptr(pt), _lib.ptr(view_inds),
                                               _lib.ptr(out), _lib.ptr(out_max), obj.numel(), V, W,
                                               _lib.current_stream(dev)), "label_gather")
@@ -101,7 +101,7 @@ def _finish_labels(end_points, batch, batch_size, num_samples):
         view_scores = torch.empty((batch_size, num_samples, V), dtype=torch.float32, device=labels.device)
         view_arg = torch.empty((batch_size, num_samples, V), dtype=torch.int32, device=labels.device)
         end_points['_view_label_arg'] = view_arg  # where in (A,D) each view's maximum sits (first one)
-        with torch.cuda.device(labels.device):
+        with _lib.device_ctx(labels.device):
             _lib.check(_lib.lib().gb_label_finish(_lib.ptr(labels), _lib.ptr(offsets), _lib.ptr(u_max),
                                                   float(GRASP_MAX_WIDTH), _lib.ptr(out), _lib.ptr(view_scores),
                                                   _lib.ptr(view_arg),

@@ -192,7 +192,7 @@ class _FusedGraspLoss(torch.autograd.Function):
         ctx.strides = strides
         extra = (view_arg, offsets_all, edges, prior_w)
         ctx.nb = int(prior_w.numel()) if prior_w is not None else 0
-        with torch.cuda.device(dev):
+        with _lib.device_ctx(dev):
             _lib.check(_lib.lib().gb_grasp_loss_fwd(*[_lib.ptr(t) for t in ins], ctypes.cast(strides, ctypes.c_void_p),
                                                     *[_lib.ptr(t) for t in extra], ctx.nb, B, Ns, V, A, D, THRESH_BAD, THRESH_GOOD, GRASP_MAX_WIDTH,
                                                     GRASP_MAX_TOLERANCE, _lib.ptr(partial), _lib.ptr(aux),
@@ -212,7 +212,7 @@ class _FusedGraspLoss(torch.autograd.Function):
         d_obj = torch.empty((B, 2, Ns), dtype=torch.float32, device=dev)
         d_view = torch.empty((B, Ns, V), dtype=torch.float32, device=dev)
         d_preds = torch.empty((4, B, A, Ns, D), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.device_ctx(dev):
             _lib.check(_lib.lib().gb_grasp_loss_bwd(*[_lib.ptr(t) for t in ins], ctypes.cast(ctx.strides, ctypes.c_void_p),
                                                     None, None, None, None, 0, B, Ns, V, A, D, THRESH_BAD, THRESH_GOOD, GRASP_MAX_WIDTH,
                                                     GRASP_MAX_TOLERANCE, _lib.ptr(aux), _lib.ptr(graspable), _lib.ptr(den),

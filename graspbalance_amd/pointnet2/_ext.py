@@ -48,7 +48,7 @@ def furthest_point_sampling(points, nsamples):
     B, N = points.size(0), points.size(1)
     output = torch.zeros((B, nsamples), dtype=torch.int32, device=points.device)
     tmp = torch.full((B, N), 1e10, dtype=torch.float32, device=points.device)
-    with torch.cuda.device(points.device):
+    with _lib.device_ctx(points.device):
         stream = _lib.current_stream(points.device)
         _lib.check(_lib.timed("gb_fps", points.device, {"b": B, "n": N, "m": nsamples},
                               lambda: _lib.fps(points, tmp, output, B, N, nsamples, FPS_FLAGS, stream)),
@@ -68,7 +68,7 @@ def gather_points(points, idx):
     B, C, N = points.shape
     M = idx.size(1)
     output = torch.zeros((B, C, M), dtype=torch.float32, device=points.device)
-    with torch.cuda.device(points.device):
+    with _lib.device_ctx(points.device):
         _lib.check(_lib.lib().gb_gather(_lib.ptr(points), _lib.ptr(idx), _lib.ptr(output), B, C, N, M,
                                         _lib.current_stream(points.device)), "gather_points")
     return output
@@ -85,7 +85,7 @@ def gather_points_grad(grad_out, idx, n):
     _require_gpu(grad_out)
     B, C, M = grad_out.shape
     output = torch.zeros((B, C, n), dtype=torch.float32, device=grad_out.device)
-    with torch.cuda.device(grad_out.device):
+    with _lib.device_ctx(grad_out.device):
         _lib.check(_lib.lib().gb_gather_grad(_lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(output), B, C, n, M,
                                              _lib.current_stream(grad_out.device)), "gather_points_grad")
     return output
@@ -103,7 +103,7 @@ def ball_query(new_xyz, xyz, radius, nsample):
     B, M = new_xyz.size(0), new_xyz.size(1)
     N = xyz.size(1)
     idx = torch.zeros((B, M, nsample), dtype=torch.int32, device=new_xyz.device)
-    with torch.cuda.device(new_xyz.device):
+    with _lib.device_ctx(new_xyz.device):
         _lib.check(_lib.lib().gb_ball_query(_lib.ptr(new_xyz), _lib.ptr(xyz), _lib.ptr(idx), None, B, N, M,
                                             float(radius), int(nsample),
                                             _lib.current_stream(new_xyz.device)), "ball_query")
@@ -125,7 +125,7 @@ def cylinder_query(new_xyz, xyz, rot, radius, hmin, hmax, nsample):
     B, M = new_xyz.size(0), new_xyz.size(1)
     N = xyz.size(1)
     idx = torch.zeros((B, M, nsample), dtype=torch.int32, device=new_xyz.device)
-    with torch.cuda.device(new_xyz.device):
+    with _lib.device_ctx(new_xyz.device):
         _lib.check(_lib.lib().gb_cylinder_query(_lib.ptr(new_xyz), _lib.ptr(xyz), _lib.ptr(rot), _lib.ptr(idx),
                                                 None, B, N, M, float(radius), float(hmin), float(hmax),
                                                 int(nsample), _lib.current_stream(new_xyz.device)),
@@ -145,7 +145,7 @@ def group_points(points, idx):
     B, C, N = points.shape
     M, S = idx.size(1), idx.size(2)
     output = torch.zeros((B, C, M, S), dtype=torch.float32, device=points.device)
-    with torch.cuda.device(points.device):
+    with _lib.device_ctx(points.device):
         _lib.check(_lib.lib().gb_group(_lib.ptr(points), _lib.ptr(idx), _lib.ptr(output), B, C, N, M, S,
                                        _lib.current_stream(points.device)), "group_points")
     return output
@@ -163,7 +163,7 @@ def group_points_grad(grad_out, idx, n):
     B, C = grad_out.size(0), grad_out.size(1)
     M, S = idx.size(1), idx.size(2)
     output = torch.zeros((B, C, n), dtype=torch.float32, device=grad_out.device)
-    with torch.cuda.device(grad_out.device):
+    with _lib.device_ctx(grad_out.device):
         _lib.check(_lib.lib().gb_group_grad(_lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(output), B, C, n, M, S,
                                             _lib.current_stream(grad_out.device)), "group_points_grad")
     return output
@@ -182,7 +182,7 @@ def three_nn(unknowns, knows):
     m = knows.size(1)
     idx = torch.zeros((B, n, 3), dtype=torch.int32, device=unknowns.device)
     dist2 = torch.zeros((B, n, 3), dtype=torch.float32, device=unknowns.device)
-    with torch.cuda.device(unknowns.device):
+    with _lib.device_ctx(unknowns.device):
         _lib.check(_lib.lib().gb_three_nn(_lib.ptr(unknowns), _lib.ptr(knows), _lib.ptr(dist2), _lib.ptr(idx),
                                           B, n, m, _lib.current_stream(unknowns.device)), "three_nn")
     return [dist2, idx]
@@ -203,7 +203,7 @@ def three_interpolate(points, idx, weight):
     B, C, m = points.shape
     n = idx.size(1)
     output = torch.zeros((B, C, n), dtype=torch.float32, device=points.device)
-    with torch.cuda.device(points.device):
+    with _lib.device_ctx(points.device):
         _lib.check(_lib.lib().gb_three_interpolate(_lib.ptr(points), _lib.ptr(idx), _lib.ptr(weight),
                                                    _lib.ptr(output), B, C, m, n,
                                                    _lib.current_stream(points.device)), "three_interpolate")
@@ -224,7 +224,7 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     _require_gpu(grad_out)
     B, C, n = grad_out.shape
     output = torch.zeros((B, C, m), dtype=torch.float32, device=grad_out.device)
-    with torch.cuda.device(grad_out.device):
+    with _lib.device_ctx(grad_out.device):
         _lib.check(_lib.lib().gb_three_interpolate_grad(_lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(weight),
                                                         _lib.ptr(output), B, C, n, m,
                                                         _lib.current_stream(grad_out.device)),

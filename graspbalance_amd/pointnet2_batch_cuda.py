@@ -29,7 +29,7 @@ def _stream(t):
 
 def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
     _gpu(new_xyz, xyz, idx)
-    with torch.cuda.device(xyz.device):
+    with _lib.device_ctx(xyz.device):
         _lib.check(_lib.lib().gb_ball_query(_lib.ptr(new_xyz), _lib.ptr(xyz), _lib.ptr(idx), None, b, n, m,
                                             float(radius), int(nsample), _stream(xyz)), "ball_query_wrapper")
     return 1
@@ -37,7 +37,7 @@ def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
 
 def group_points_wrapper(b, c, n, npoints, nsample, points, idx, out):
     _gpu(points, idx, out)
-    with torch.cuda.device(points.device):
+    with _lib.device_ctx(points.device):
         _lib.check(_lib.lib().gb_group(_lib.ptr(points), _lib.ptr(idx), _lib.ptr(out), b, c, n, npoints, nsample,
                                        _stream(points)), "group_points_wrapper")
     return 1
@@ -45,7 +45,7 @@ def group_points_wrapper(b, c, n, npoints, nsample, points, idx, out):
 
 def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_points):
     _gpu(grad_out, idx, grad_points)
-    with torch.cuda.device(grad_out.device):
+    with _lib.device_ctx(grad_out.device):
         _lib.check(_lib.lib().gb_group_grad(_lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(grad_points), b, c, n,
                                             npoints, nsample, _stream(grad_out)), "group_points_grad_wrapper")
     return 1
@@ -53,7 +53,7 @@ def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_poi
 
 def gather_points_wrapper(b, c, n, npoints, points, idx, out):
     _gpu(points, idx, out)
-    with torch.cuda.device(points.device):
+    with _lib.device_ctx(points.device):
         _lib.check(_lib.lib().gb_gather(_lib.ptr(points), _lib.ptr(idx), _lib.ptr(out), b, c, n, npoints,
                                         _stream(points)), "gather_points_wrapper")
     return 1
@@ -61,7 +61,7 @@ def gather_points_wrapper(b, c, n, npoints, points, idx, out):
 
 def gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points):
     _gpu(grad_out, idx, grad_points)
-    with torch.cuda.device(grad_out.device):
+    with _lib.device_ctx(grad_out.device):
         _lib.check(_lib.lib().gb_gather_grad(_lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(grad_points), b, c, n,
                                              npoints, _stream(grad_out)), "gather_points_grad_wrapper")
     return 1
@@ -69,28 +69,28 @@ def gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points):
 
 def furthest_point_sampling_wrapper(b, n, m, points, temp, idx):
     _gpu(points, temp, idx)
-    with torch.cuda.device(points.device):
+    with _lib.device_ctx(points.device):
         _lib.check(_lib.fps(points, temp, idx, b, n, m, FPS_FLAGS, _stream(points)), "furthest_point_sampling_wrapper")
     return 1
 
 
 def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
     _gpu(unknown, known, dist2, idx)
-    with torch.cuda.device(unknown.device):
+    with _lib.device_ctx(unknown.device):
         _lib.check(_lib.lib().gb_three_nn(_lib.ptr(unknown), _lib.ptr(known), _lib.ptr(dist2), _lib.ptr(idx), b, n, m,
                                           _stream(unknown)), "three_nn_wrapper")
 
 
 def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):
     _gpu(points, idx, weight, out)
-    with torch.cuda.device(points.device):
+    with _lib.device_ctx(points.device):
         _lib.check(_lib.lib().gb_three_interpolate(_lib.ptr(points), _lib.ptr(idx), _lib.ptr(weight), _lib.ptr(out),
                                                    b, c, m, n, _stream(points)), "three_interpolate_wrapper")
 
 
 def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_points):
     _gpu(grad_out, idx, weight, grad_points)
-    with torch.cuda.device(grad_out.device):
+    with _lib.device_ctx(grad_out.device):
         _lib.check(_lib.lib().gb_three_interpolate_grad(_lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(weight),
                                                         _lib.ptr(grad_points), b, c, n, m, _stream(grad_out)),
                    "three_interpolate_grad_wrapper")

@@ -44,7 +44,7 @@ SIGNATURES = {
     "gb_knn1": [_P, _P, _P, _I, _I, _I, _I, _P],
     "gb_group_concat_cl": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
     "gb_group_concat_cl_grad": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "gb_col_stats": [_P, _L, _I, _P, _P],
+    "gb_col_stats": [_P, _L, _I, _P, _P, _P],
     "gb_bn_finalize": [_P, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _I, _P],
     "gb_affine_act": [_P, _P, _P, _P, _L, _I, _I, _P],
     "gb_affine_relu_maxpool": [_P, _P, _P, _P, _L, _I, _I, _P],
@@ -54,7 +54,7 @@ SIGNATURES = {
     "gb_bn_bwd_apply_pool": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P],
     "gb_bn_bwd_reduce": [_P, _I, _I, _P, _P, _P, _P],
     "gb_la_point_stats": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P],
-    "gb_la_col_stats": [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P],
+    "gb_la_col_stats": [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P],
     "gb_la_pool": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
     "gb_la_pool_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
     "gb_la_point_grad": [_P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _P, _P],
@@ -63,7 +63,7 @@ SIGNATURES = {
     "gb_grasp_loss_fwd": [_P] * 17 + [_I] * 6 + [_F] * 4 + [_P] * 6,
     "gb_grasp_loss_bwd": [_P] * 17 + [_I] * 6 + [_F] * 4 + [_P] * 11,
     "gb_label_finish": [_P, _P, _P, _F, _P, _P, _P, _L, _I, _P],
-    "gb_gemm_fwd": [_P, _P, _P, _P, _P, _I, _L, _I, _I, _P],
+    "gb_gemm_fwd": [_P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P],
     "gb_gemm_dgrad": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P],
     "gb_gemm_wgrad": [_P, _P, _P, _P, _L, _I, _I, _P],
     "gb_gemm_uses_rs": [_L, _I, _I, _I, _I, _I],
@@ -71,7 +71,7 @@ SIGNATURES = {
     "gb_moments3": [_P, _P, _L, _P, _P],
     "gb_cyl_unique": [_P, _I, _L, _I, _P, _P, _P, _P],
     "gb_cyl_rows": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
-    "gb_gemm_fwd_w": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P],
+    "gb_gemm_fwd_w": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P],
     "gb_affine_relu_maxpool_members": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "gb_bn_bwd_apply_members": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _L, _I, _P, _P],
     "gb_bn_bwd_apply_w": [_P, _P, _P, _P, _P, _L, _L, _I, _I, _P, _P],
@@ -110,6 +110,13 @@ def lib():
             fn.restype = _I
         _lib = handle
     return _lib
+
+
+class BnFinalize(_c.Structure):
+    """GbBnFinalize of include/graspbal.h: lets a statistics-producing entry point finish the BatchNorm layer."""
+    _fields_ = [("gamma", _c.c_void_p), ("beta", _c.c_void_p), ("running_mean", _c.c_void_p),
+                ("running_var", _c.c_void_p), ("ab", _c.c_void_p), ("P", _c.c_longlong), ("eps", _c.c_float),
+                ("momentum", _c.c_float), ("training", _c.c_int)]
 
 
 class KernelTimer:

@@ -387,14 +387,24 @@ using namespace gb;
 
 // Y (P,N) = f(X (P,K)) W(N,K)^T ; aff (optional) = [a(K), b(K)] -> f = relu(a*x+b); stats (optional,
 // fp64 [stat_slots][2N], caller-zeroed) += column sums / sums of squares of Y (summed over slots by gb_bn_finalize)
+// the layer's gb_bn_finalize as a second launch of the same call (kernels that cannot finish the layer themselves)
+static int finalize_after(int rc, const GbBnFinalize *fin, const double *stats, int slots, int N, void *stream) {
+  if (rc != GB_OK || !fin) return rc;
+  return gb_bn_finalize(stats, slots, fin->P, N, fin->gamma, fin->beta, fin->eps, fin->momentum, fin->running_mean,
+                        fin->running_var, fin->ab, 1, stream);
+}
+
 static int gemm_fwd_impl(const float *x, const float *w, const float *aff, const uint16_t *row_w16, float *y,
-                         double *stats, int stat_slots, long long P, int K, int N, void *stream) {
+                         double *stats, int stat_slots, long long P, int K, int N, const GbBnFinalize *fin,
+                         void *stream) {
   if (P < 0 || K < 1 || N < 1 || !x || !w || !y || (stats && stat_slots < 1)) return GB_EINVAL;
-  if (P == 0) return GB_OK;
+  if (fin && (!stats || !fin->gamma || !fin->beta || !fin->ab || fin->P < 1 || fin->training != 1))
+    return GB_EINVAL;
+  if (P == 0) return fin ? GB_EINVAL : GB_OK;
   if (P / 64 * ((N + 63) / 64) > 0x7fffffffLL) return GB_ERANGE;
   if (rs_gemm_try(x, w, y, aff, stats, stat_slots, nullptr, nullptr, P, K, N, 1, stats ? RS_STATS : RS_STORE,
                   as_stream(stream), nullptr, stats ? row_w16 : nullptr))
-    return check_launch("gb_gemm_fwd");
+    return finalize_after(check_launch("gb_gemm_fwd"), fin, stats, stat_slots, N, stream);
   Operand a = {x, P, K, K, aff};
   Operand b = {w, N, K, K, nullptr};
   const bool v = (K % 4 == 0) && aligned16(x) && aligned16(w);
@@ -411,26 +421,27 @@ static int gemm_fwd_impl(const float *x, const float *w, const float *aff, const
     launch_gemm<OP_KC, OP_KC, EPI_ATOMIC>(a, b, v, v, y, N, nullptr, kchunk, (unsigned)chunks, as_stream(stream));
     const int rc = check_launch("gb_gemm_fwd");
     if (rc != GB_OK || !stats) return rc;
-    return gb_col_stats(y, P, N, stats, stream);
+    return gb_col_stats(y, P, N, stats, fin, stream);
   }
   if (stats)
     launch_gemm<OP_KC, OP_KC, EPI_STORE_STATS>(a, b, v, v, y, N, stats, kchunk, 1, as_stream(stream), stat_slots, nullptr,
                                                nullptr, row_w16);
   else launch_gemm<OP_KC, OP_KC, EPI_STORE>(a, b, v, v, y, N, stats, kchunk, 1, as_stream(stream));
-  return check_launch("gb_gemm_fwd");
+  return finalize_after(check_launch("gb_gemm_fwd"), fin, stats, stat_slots, N, stream);
 }
 
 extern "C" int gb_gemm_fwd(const float *x, const float *w, const float *aff, float *y, double *stats,
-                           int stat_slots, long long P, int K, int N, void *stream) {
-  return gemm_fwd_impl(x, w, aff, nullptr, y, stats, stat_slots, P, K, N, stream);
+                           int stat_slots, long long P, int K, int N, const GbBnFinalize *fin, void *stream) {
+  return gemm_fwd_impl(x, w, aff, nullptr, y, stats, stat_slots, P, K, N, fin, stream);
 }
 
 // gb_gemm_fwd whose BatchNorm sums weight row p by row_w16[p] (uint16; the array must extend, zero-filled, to the
 // next multiple of 32 rows): the rows are the DISTINCT rows of a batch with duplicates (csrc/cyl_rows.hip), the
 // sums are those of the full batch.
 extern "C" int gb_gemm_fwd_w(const float *x, const float *w, const float *aff, const uint16_t *row_w16, float *y,
-                             double *stats, int stat_slots, long long P, int K, int N, void *stream) {
-  return gemm_fwd_impl(x, w, aff, row_w16, y, stats, stat_slots, P, K, N, stream);
+                             double *stats, int stat_slots, long long P, int K, int N, const GbBnFinalize *fin,
+                             void *stream) {
+  return gemm_fwd_impl(x, w, aff, row_w16, y, stats, stat_slots, P, K, N, fin, stream);
 }
 
 // dX (P,K) = dY (P,N) W(N,K)   with W in its natural (N,K) row-major layout (no transposed copy).

@@ -13,6 +13,7 @@
 // m1 = dbeta/P, m2 = dgamma/P, U[c, j] = sum_i G[i, c] D_i[j].  The only pass over P*C values left is the
 // max-pool itself, a gather from L2.  Same function as conv -> BN -> ReLU -> max on the grouped tensor, in a
 // different (fp32-rounding-level) summation order.
+
 #include "gb_common.h"
 
 namespace gb {
@@ -379,12 +380,17 @@ extern "C" int gb_la_point_stats(const float *xyz, const float *centres, const i
 }
 
 extern "C" int gb_la_col_stats(const float *G, const float *cnt, const float *dsum, const float *wx,
-                               const double *mom, long long rows, int C, double *stats, double *u, void *stream) {
+                               const double *mom, long long rows, int C, double *stats, double *u,
+                               const GbBnFinalize *fin, void *stream) {
   if (rows < 0 || C < 1 || !G || !cnt || !dsum || !wx || !mom || !stats || !u) return GB_EINVAL;
-  if (rows == 0) return GB_OK;
+  if (fin && (!fin->gamma || !fin->beta || !fin->ab || fin->P < 1 || fin->training != 1)) return GB_EINVAL;
+  if (rows == 0) return fin ? GB_EINVAL : GB_OK;
   hipLaunchKernelGGL(la_col_stats_kernel, dim3((unsigned)((rows + LA_RB - 1) / LA_RB)), dim3(LA_TPB), 0,
                      as_stream(stream), G, cnt, dsum, wx, mom, rows, C, stats, u);
-  return check_launch("gb_la_col_stats");
+  const int rc = check_launch("gb_la_col_stats");
+  if (rc != GB_OK || !fin) return rc;
+  return gb_bn_finalize(stats, 1, fin->P, C, fin->gamma, fin->beta, fin->eps, fin->momentum, fin->running_mean,
+                        fin->running_var, fin->ab, 1, stream);
 }
 
 extern "C" int gb_la_pool(const float *G, const float *xyz, const float *centres, const int32_t *idx, const float *wx,

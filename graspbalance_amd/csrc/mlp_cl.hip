@@ -16,6 +16,8 @@
 //   gb_affine_relu_maxpool  out[r,c] = max_k relu(a*y[r*ns+k,c] + b), argmax k
 //   gb_bn_bwd_stats(_pool)  dbeta = sum dA, dgamma = sum dA*xhat
 //   gb_bn_bwd_apply(_pool)  dy = a*(dA - dbeta/P - xhat*dgamma/P)
+#include <string.h>
+
 #include "gb_common.h"
 
 namespace gb {
@@ -169,27 +171,17 @@ __global__ void bn_finalize_kernel(const double *__restrict__ stats, int slots, 
                                    float *__restrict__ running_var, float *__restrict__ ab, int training) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  float mean, var;
   if (training) {
     double s1 = 0.0, s2 = 0.0;
     for (int sl = 0; sl < slots; ++sl) {  // partial sums of the GEMM epilogue's slot rows
       s1 += stats[(size_t)sl * 2 * C + c];
       s2 += stats[(size_t)sl * 2 * C + C + c];
     }
-    const double m = s1 / (double)P;
-    double v = s2 / (double)P - m * m;  // biased variance (normalisation)
-    if (v < 0.0) v = 0.0;
-    mean = (float)m;
-    var = (float)v;
-    if (running_mean) {
-      const double unbiased = P > 1 ? v * (double)P / (double)(P - 1) : v;
-      running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean;
-      running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
-    }
-  } else {
-    mean = running_mean[c];
-    var = running_var[c];
+    const BnFinalize f = {gamma, beta, running_mean, running_var, ab, P, eps, momentum, 1};
+    bn_finalize_column(f, s1, s2, c, C);
+    return;
   }
+  const float mean = running_mean[c], var = running_var[c];
   const float rstd = 1.0f / sqrtf(var + eps);
   const float a = gamma[c] * rstd;
   ab[c] = a;
@@ -727,16 +719,25 @@ extern "C" int gb_group_concat_cl_grad(const float *dx0, const int32_t *idx, flo
   return check_launch("gb_group_concat_cl_grad");
 }
 
-extern "C" int gb_col_stats(const float *y, long long P, int C, double *stats, void *stream) {
-  if (P < 0 || C < 1 || !y || !stats) return GB_EINVAL;
-  if (P == 0) return GB_OK;
+static bool fin_ok(const GbBnFinalize *fin) {
+  return !fin || (fin->gamma && fin->beta && fin->ab && fin->P >= 1 && fin->training == 1 &&
+                  (!fin->running_mean == !fin->running_var));
+}
+
+extern "C" int gb_col_stats(const float *y, long long P, int C, double *stats, const GbBnFinalize *fin, void *stream) {
+  if (P < 0 || C < 1 || !y || !stats || !fin_ok(fin)) return GB_EINVAL;
+  if (P == 0) return fin ? GB_EINVAL : GB_OK;
+  static_assert(sizeof(BnFinalize) == sizeof(GbBnFinalize), "device view of GbBnFinalize");
   const int rpb = rows_per_block(P);
   const dim3 grid((unsigned)((P + rpb - 1) / rpb));
   if (C % 4 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0)
     hipLaunchKernelGGL((col_stats_kernel<4>), grid, dim3(CL_TPB), 0, as_stream(stream), y, P, C, rpb, stats, stats + C);
   else
     hipLaunchKernelGGL((col_stats_kernel<1>), grid, dim3(CL_TPB), 0, as_stream(stream), y, P, C, rpb, stats, stats + C);
-  return check_launch("gb_col_stats");
+  const int rc = check_launch("gb_col_stats");
+  if (rc != GB_OK || !fin) return rc;
+  return gb_bn_finalize(stats, 1, fin->P, C, fin->gamma, fin->beta, fin->eps, fin->momentum, fin->running_mean,
+                        fin->running_var, fin->ab, 1, stream);
 }
 
 extern "C" int gb_bn_finalize(const double *stats, int slots, long long P, int C, const float *gamma, const float *beta,

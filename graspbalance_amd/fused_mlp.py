@@ -12,6 +12,7 @@ statistics), so state_dicts are unchanged; results equal the unfused path to fp3
 ``enabled()`` is False on CPU tensors: the python layers then run their plain torch composition
 (which only works with an extension bound for CPU, i.e. in the tests).
 """
+import ctypes
 import os
 
 import torch
@@ -120,6 +121,15 @@ def _call(name, dev, *args, meta=None):
         _lib.check(_lib.timed(name, dev, meta, lambda: fn(*args)), name)
 
 
+def _bn_fin(cfg, gamma, beta, ab, P_stat):
+    """ctypes GbBnFinalize of a layer, by reference."""
+    f = _lib.BnFinalize(gamma.data_ptr(), beta.data_ptr(),
+                        cfg.running_mean.data_ptr() if cfg.running_mean is not None else None,
+                        cfg.running_var.data_ptr() if cfg.running_var is not None else None, ab.data_ptr(), P_stat,
+                        cfg.eps, cfg.momentum, 1)
+    return ctypes.byref(f)
+
+
 def _gemm_meta(kind, P, K, N, fused=False, aff=False):
     """Timing metadata of a GEMM launch (only built while a KernelTimer is active): FLOP, shape and which
     kernel the C entry dispatches to (gemm_rs_kernel / gemm_cl_kernel)."""
@@ -201,11 +211,11 @@ class LinearBNAct(Function):
             Wc = W.contiguous()
             Y = torch.empty((P, Cout), dtype=torch.float32, device=dev)
             _call("gb_gemm_fwd", dev, _lib.ptr(X), _lib.ptr(Wc), None, _lib.ptr(Y), _lib.ptr(stats), slots, P, X.shape[1],
-                  Cout, _s(X), meta=_gemm_meta("fwd", P, X.shape[1], Cout, stats is not None))
+                  Cout, None, _s(X), meta=_gemm_meta("fwd", P, X.shape[1], Cout, stats is not None))
         else:
             Y = torch.mm(X, W.t())
             if training:
-                _call("gb_col_stats", dev, _lib.ptr(Y), P, Cout, _lib.ptr(stats), _s(Y))
+                _call("gb_col_stats", dev, _lib.ptr(Y), P, Cout, _lib.ptr(stats), None, _s(Y))
         _call("gb_bn_finalize", dev, _lib.ptr(stats), slots, P, Cout, _lib.ptr(gamma), _lib.ptr(beta), float(eps),
               float(momentum), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(ab), int(training), _s(Y))
         ctx.cfg = (P, Cout, bool(training), bool(relu), int(pool_ns))
@@ -320,18 +330,22 @@ class MLPStack(Function):
             K, N = src.shape[1], W.shape[0]
             stats = stat_arena[stat_off[l]:stat_off[l + 1]] if cfg.training else None
             Y = _empty_rows(P, N, dev, rows is not None)
+            ab = ab_arena[ab_off:ab_off + 4 * N]
+            ab_off += 4 * N
+            # training: the GEMM call finishes the layer's BatchNorm itself (a second launch from the same C call):
+            # one Python -> C transition per layer instead of two
+            fin = _bn_fin(cfg, gamma, beta, ab, P_stat) if cfg.training else None
             if rows is not None and stats is not None:
                 _call("gb_gemm_fwd_w", dev, _lib.ptr(src), _lib.ptr(W), _lib.ptr(aff), _lib.ptr(rows.w16), _lib.ptr(Y),
-                      _lib.ptr(stats), slots, P, K, N, st,
+                      _lib.ptr(stats), slots, P, K, N, fin, st,
                       meta=_gemm_meta("fwd", P, K, N, True, aff is not None))
             else:
                 _call("gb_gemm_fwd", dev, _lib.ptr(src), _lib.ptr(W), _lib.ptr(aff), _lib.ptr(Y), _lib.ptr(stats), slots,
-                      P, K, N, st, meta=_gemm_meta("fwd", P, K, N, stats is not None, aff is not None))
-            ab = ab_arena[ab_off:ab_off + 4 * N]
-            ab_off += 4 * N
-            _call("gb_bn_finalize", dev, _lib.ptr(stats), slots, P_stat, N, _lib.ptr(gamma), _lib.ptr(beta), cfg.eps,
-                  cfg.momentum, _lib.ptr(cfg.running_mean), _lib.ptr(cfg.running_var), _lib.ptr(ab),
-                  int(cfg.training), st)
+                      P, K, N, fin, st, meta=_gemm_meta("fwd", P, K, N, stats is not None, aff is not None))
+            if fin is None:
+                _call("gb_bn_finalize", dev, _lib.ptr(stats), slots, P_stat, N, _lib.ptr(gamma), _lib.ptr(beta), cfg.eps,
+                      cfg.momentum, _lib.ptr(cfg.running_mean), _lib.ptr(cfg.running_var), _lib.ptr(ab),
+                      int(cfg.training), st)
             Ws.append(W); Ys.append(Y); abs_.append(ab)
             src, aff = Y, ab  # ab[:2N] = [a, b] is exactly the next GEMM's prologue table
         N = widths[-1]
@@ -534,16 +548,18 @@ class LocalAggPool(Function):
         Wx, Wf = W[:, :3].contiguous(), W[:, 3:].contiguous()
         rows, P = geo.b * geo.n, geo.rows
         G = torch.empty((rows, N), dtype=torch.float32, device=dev)
-        _call("gb_gemm_fwd", dev, _lib.ptr(f), _lib.ptr(Wf), None, _lib.ptr(G), None, 1, rows, C, N, st,
+        _call("gb_gemm_fwd", dev, _lib.ptr(f), _lib.ptr(Wf), None, _lib.ptr(G), None, 1, rows, C, N, None, st,
               meta=_gemm_meta("fwd", rows, C, N))
         sums = _zeros64(5 * N, dev)  # [sum y, sum y^2, U0, U1, U2]
         stats, u = sums[:2 * N], sums[2 * N:]
-        if cfg.training:
-            _call("gb_la_col_stats", dev, _lib.ptr(G), _lib.ptr(geo.cnt), _lib.ptr(geo.dsum), _lib.ptr(Wx),
-                  _lib.ptr(geo.mom), rows, N, _lib.ptr(stats), _lib.ptr(u), st)
         ab = torch.empty(4 * N, dtype=torch.float32, device=dev)
-        _call("gb_bn_finalize", dev, _lib.ptr(stats), 1, P, N, _lib.ptr(gamma), _lib.ptr(beta), cfg.eps, cfg.momentum,
-              _lib.ptr(cfg.running_mean), _lib.ptr(cfg.running_var), _lib.ptr(ab), int(cfg.training), st)
+        if cfg.training:  # the same C call also finishes the BatchNorm (ab table, running statistics)
+            _call("gb_la_col_stats", dev, _lib.ptr(G), _lib.ptr(geo.cnt), _lib.ptr(geo.dsum), _lib.ptr(Wx),
+                  _lib.ptr(geo.mom), rows, N, _lib.ptr(stats), _lib.ptr(u),
+                  _bn_fin(cfg, gamma, beta, ab, P), st)
+        else:
+            _call("gb_bn_finalize", dev, _lib.ptr(stats), 1, P, N, _lib.ptr(gamma), _lib.ptr(beta), cfg.eps,
+                  cfg.momentum, _lib.ptr(cfg.running_mean), _lib.ptr(cfg.running_var), _lib.ptr(ab), 0, st)
         R = geo.b * geo.m
         out = torch.empty((R, N), dtype=torch.float32, device=dev)
         arg = torch.empty((R, N), dtype=torch.int32, device=dev)

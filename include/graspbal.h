@@ -191,8 +191,21 @@ int gb_group_concat_cl(const float *xyz, const float *new_xyz, const int32_t *id
 /* dfeat[b, idx[p], :] += dx0[p, 3:]   (accumulates into dfeat (b,n,c)) */
 int gb_group_concat_cl_grad(const float *dx0, const int32_t *idx, float *dfeat, int b, int n, int m,
                             int ns, int c, void *stream);
-/* stats[0:C] += column sums of y (P,C), stats[C:2C] += column sums of y*y; fp64, caller zeroes */
-int gb_col_stats(const float *y, long long P, int C, double *stats, void *stream);
+/* The arguments of gb_bn_finalize as a struct: entry points that produce BatchNorm sums take an optional pointer to
+ * one and then finish the layer themselves (ab table, running statistics) with a gb_bn_finalize launch from the same
+ * call - one host transition per layer instead of two.  training must be 1 (the evaluation-mode table does not depend
+ * on a kernel's sums: call gb_bn_finalize).                                                                         */
+typedef struct GbBnFinalize {
+  const float *gamma, *beta;
+  float *running_mean, *running_var; /* may be NULL */
+  float *ab;                         /* [a, b, mean, rstd](C) */
+  long long P;                       /* rows the sums stand for */
+  float eps, momentum;
+  int training;
+} GbBnFinalize;
+
+/* stats[0:C] += column sums of y (P,C), stats[C:2C] += column sums of y*y; fp64, caller zeroes.  fin: optional */
+int gb_col_stats(const float *y, long long P, int C, double *stats, const GbBnFinalize *fin, void *stream);
 /* ab[0:C] = a = gamma*rstd, ab[C:2C] = b = beta - mean*a, ab[2C:3C] = mean, ab[3C:4C] = rstd.
  * `stats` is [slots][2C] (slot rows are summed; gb_col_stats fills one row, gb_gemm_fwd spreads its
  * epilogue atomics over `stat_slots` rows).
@@ -246,7 +259,7 @@ int gb_cyl_rows(const float *xyz, const float *centres, const float *rot, const 
 /* gb_gemm_fwd whose BatchNorm sums weight row p by row_w16[p] (uint16 multiplicities; the array must extend,
  * zero-filled, to the next multiple of 32 rows).                                                              */
 int gb_gemm_fwd_w(const float *x, const float *w, const float *aff, const uint16_t *row_w16, float *y, double *stats,
-                  int stat_slots, long long P, int K, int N, void *stream);
+                  int stat_slots, long long P, int K, int N, const GbBnFinalize *fin, void *stream);
 /* out ((R*D), C) [row r*D + d] = max over the rows of seed r with member bit d of relu(a*y + b); arg = absolute
  * row index of the maximum.  D in {1,2,4}; C % 4 == 0.                                                         */
 int gb_affine_relu_maxpool_members(const float *y, const float *ab, const int32_t *row_mem, const int64_t *off,
@@ -277,7 +290,8 @@ int gb_la_point_stats(const float *xyz, const float *centres, const int32_t *idx
 /* stats fp64 [2C] += [sum_p y, sum_p y^2] (the BatchNorm batch sums over all P = b*m*ns rows, in the form
  * gb_bn_finalize reads), u fp64 [3][C] += U[j][c] = sum_i G[i,c] D_i[j]; G (rows = b*n, C); caller-zeroed. */
 int gb_la_col_stats(const float *G, const float *cnt, const float *dsum, const float *wx, const double *mom,
-                    long long rows, int C, double *stats, double *u, void *stream);
+                    long long rows, int C, double *stats, double *u, const GbBnFinalize *fin,
+                    void *stream);
 /* out (b*m, C) = max_k relu(a y + b), arg = first k attaining it; ab = [a, b, mean, rstd](C) from
  * gb_bn_finalize.  C % 4 == 0, 16 <= C <= 1024, ns <= 64.                                               */
 int gb_la_pool(const float *G, const float *xyz, const float *centres, const int32_t *idx, const float *wx,
@@ -304,7 +318,7 @@ int gb_la_wx_grad(const double *red, const double *u, const double *mom, const f
  * caller-zeroed) += column sums and sums of squares of Y (BatchNorm batch statistics), spread over the
  * slot rows to avoid same-address atomic contention; gb_bn_finalize sums the rows.                 */
 int gb_gemm_fwd(const float *x, const float *w, const float *aff, float *y, double *stats, int stat_slots,
-                long long P, int K, int N, void *stream);
+                long long P, int K, int N, const GbBnFinalize *fin, void *stream);
 /* dX (P,K) = dY (P,N) W(N,K), W in its natural (N,K) row-major layout.  Optional fused BatchNorm-backward
  * statistics of the previous layer (dX is the gradient of its post-ReLU output): y_prev (P,K) its pre-BN
  * output, ab_prev = [a,b,mean,rstd](K), dstats fp64 [stat_slots][2K] (caller-zeroed) += [sum dA,

@@ -29,7 +29,7 @@ def test_gemm_fwd_stats_and_affine(P, K, N):
     W = torch.randn(N, K, device=DEV) / K ** 0.5
     Y = torch.empty(P, N, device=DEV)
     stats = torch.zeros(2 * N, dtype=torch.float64, device=DEV)
-    L.check(L.lib().gb_gemm_fwd(L.ptr(X), L.ptr(W), None, L.ptr(Y), L.ptr(stats), 1, P, K, N, None), "fwd")
+    L.check(L.lib().gb_gemm_fwd(L.ptr(X), L.ptr(W), None, L.ptr(Y), L.ptr(stats), 1, P, K, N, None, None), "fwd")
     torch.cuda.synchronize()
     ref = X.double() @ W.double().t()
     scale = float(ref.abs().max()) + 1e-12
@@ -39,7 +39,7 @@ def test_gemm_fwd_stats_and_affine(P, K, N):
     # fused BatchNorm+ReLU prologue of the next layer
     aff = torch.cat([torch.randn(K, device=DEV), torch.randn(K, device=DEV)])
     Y2 = torch.empty(P, N, device=DEV)
-    L.check(L.lib().gb_gemm_fwd(L.ptr(X), L.ptr(W), L.ptr(aff), L.ptr(Y2), None, 1, P, K, N, None), "fwd aff")
+    L.check(L.lib().gb_gemm_fwd(L.ptr(X), L.ptr(W), L.ptr(aff), L.ptr(Y2), None, 1, P, K, N, None, None), "fwd aff")
     torch.cuda.synchronize()
     ref2 = torch.relu(aff[:K] * X + aff[K:]).double() @ W.double().t()
     assert float((Y2.double() - ref2).abs().max()) / (float(ref2.abs().max()) + 1e-12) < 2e-6
@@ -74,7 +74,7 @@ def test_gemm_fused_epilogues_slotted(P, K, N):
     aff = torch.cat([torch.randn(K, device=DEV), torch.randn(K, device=DEV)])
     Y = torch.empty(P, N, device=DEV)
     stats = torch.zeros(slots, 2 * N, dtype=torch.float64, device=DEV)
-    L.check(L.lib().gb_gemm_fwd(L.ptr(X), L.ptr(W), L.ptr(aff), L.ptr(Y), L.ptr(stats), slots, P, K, N, None), "fwd")
+    L.check(L.lib().gb_gemm_fwd(L.ptr(X), L.ptr(W), L.ptr(aff), L.ptr(Y), L.ptr(stats), slots, P, K, N, None, None), "fwd")
     torch.cuda.synchronize()
     ref = torch.relu(aff[:K] * X + aff[K:]).double() @ W.double().t()
     assert float((Y.double() - ref).abs().max()) / (float(ref.abs().max()) + 1e-12) < 2e-6

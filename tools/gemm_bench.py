@@ -31,7 +31,7 @@ for name, P, K, N in SHAPES:
     Wt = W.t().contiguous(); st = torch.zeros(SLOTS * 2 * N, dtype=torch.float64, device=DEV)
     fl = 2.0 * P * K * N
     r = {}
-    r["fwd own"] = timeit(lambda: lib.gb_gemm_fwd(L.ptr(X), L.ptr(W), None, L.ptr(Y), L.ptr(st), SLOTS, P, K, N, None))
+    r["fwd own"] = timeit(lambda: lib.gb_gemm_fwd(L.ptr(X), L.ptr(W), None, L.ptr(Y), L.ptr(st), SLOTS, P, K, N, None, None))
     r["fwd blas"] = timeit(lambda: torch.mm(X, W.t(), out=Y))
     r["dgrad own"] = timeit(lambda: lib.gb_gemm_dgrad(L.ptr(dY), L.ptr(W), L.ptr(dX), None, None, None, 0, P, K, N, None))
     r["dgrad blas"] = timeit(lambda: torch.mm(dY, W, out=dX))

@@ -20,8 +20,8 @@ for name, P, K, N in [("sa1.l1", 524288, 64, 64), ("sa1.l2", 524288, 64, 128), (
     Wt = W.t().contiguous(); st = torch.zeros(32 * 2 * N, dtype=torch.float64, device=DEV)
     affK = torch.randn(4 * K, device=DEV); dst = torch.zeros(32 * 2 * K, dtype=torch.float64, device=DEV)
     t = {}
-    t["fwd"] = timeit(lambda: lib.gb_gemm_fwd(L.ptr(X), L.ptr(W), None, L.ptr(Y), L.ptr(st), 32, P, K, N, None))
-    t["fwd+aff"] = timeit(lambda: lib.gb_gemm_fwd(L.ptr(X), L.ptr(W), L.ptr(affK), L.ptr(Y), L.ptr(st), 32, P, K, N, None))
+    t["fwd"] = timeit(lambda: lib.gb_gemm_fwd(L.ptr(X), L.ptr(W), None, L.ptr(Y), L.ptr(st), 32, P, K, N, None, None))
+    t["fwd+aff"] = timeit(lambda: lib.gb_gemm_fwd(L.ptr(X), L.ptr(W), L.ptr(affK), L.ptr(Y), L.ptr(st), 32, P, K, N, None, None))
     t["affine_act(K)"] = timeit(lambda: lib.gb_affine_act(L.ptr(X), L.ptr(affK), None, L.ptr(Z), P, K, 1, None))
     t["dgrad"] = timeit(lambda: lib.gb_gemm_dgrad(L.ptr(dY), L.ptr(W), L.ptr(dX), None, None, None, 0, P, K, N, None))
     t["dgrad+bn"] = timeit(lambda: lib.gb_gemm_dgrad(L.ptr(dY), L.ptr(W), L.ptr(dX), L.ptr(X), L.ptr(affK), L.ptr(dst), 32, P, K, N, None))

@@ -48,9 +48,9 @@ SIGNATURES = {
     "gb_bn_finalize": [_P, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _I, _P],
     "gb_affine_act": [_P, _P, _P, _P, _L, _I, _I, _P],
     "gb_affine_relu_maxpool": [_P, _P, _P, _P, _L, _I, _I, _P],
-    "gb_bn_bwd_stats": [_P, _P, _P, _P, _L, _I, _I, _P, _P],
+    "gb_bn_bwd_stats": [_P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P],
     "gb_bn_bwd_apply": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P],
-    "gb_bn_bwd_stats_pool": [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P],
+    "gb_bn_bwd_stats_pool": [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P],
     "gb_bn_bwd_apply_pool": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P],
     "gb_bn_bwd_reduce": [_P, _I, _I, _P, _P, _P, _P],
     "gb_la_point_stats": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P],
@@ -64,7 +64,7 @@ SIGNATURES = {
     "gb_grasp_loss_bwd": [_P] * 17 + [_I] * 6 + [_F] * 4 + [_P] * 11,
     "gb_label_finish": [_P, _P, _P, _F, _P, _P, _P, _L, _I, _P],
     "gb_gemm_fwd": [_P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P],
-    "gb_gemm_dgrad": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P],
+    "gb_gemm_dgrad": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P, _P, _P],
     "gb_gemm_wgrad": [_P, _P, _P, _P, _L, _I, _I, _P],
     "gb_gemm_uses_rs": [_L, _I, _I, _I, _I, _I],
     "gb_gemm_dgrad_first": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P],

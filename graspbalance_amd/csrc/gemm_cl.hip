@@ -450,14 +450,21 @@ extern "C" int gb_gemm_fwd_w(const float *x, const float *w, const float *aff, c
 // dstats fp64 [stat_slots][2K] (caller-zeroed) += [sum dA, sum dA*xhat],  dA = dX * [a*y+b > 0].
 extern "C" int gb_gemm_dgrad(const float *dy, const float *w, float *dx, const float *y_prev,
                              const float *ab_prev, double *dstats, int stat_slots, long long P, int K, int N,
-                             void *stream) {
+                             double *dstats_total, float *dbeta, float *dgamma, void *stream) {
   if (P < 0 || K < 1 || N < 1 || !dy || !w || !dx) return GB_EINVAL;
   if (dstats && (!y_prev || !ab_prev || stat_slots < 1)) return GB_EINVAL;
+  if ((!dbeta != !dgamma) || (dbeta && !dstats)) return GB_EINVAL;
+  // dbeta / dgamma (optional): the previous layer's gb_bn_bwd_reduce runs from this call (dstats_total: where the
+  // slot rows' total goes when stat_slots > 1)
+  auto done = [&](int rc) {
+    if (rc != GB_OK || !dbeta) return rc;
+    return gb_bn_bwd_reduce(dstats, stat_slots, K, stat_slots > 1 ? dstats_total : nullptr, dbeta, dgamma, stream);
+  };
   if (P == 0) return GB_OK;
   if (P / 64 * ((K + 63) / 64) > 0x7fffffffLL) return GB_ERANGE;
   if (rs_gemm_try(dy, w, dx, nullptr, dstats, stat_slots, y_prev, ab_prev, P, N, K, 0, dstats ? RS_BNBWD : RS_STORE,
                   as_stream(stream)))
-    return check_launch("gb_gemm_dgrad");
+    return done(check_launch("gb_gemm_dgrad"));
   Operand a = {dy, P, N, N, nullptr};
   Operand b = {w, K, N, K, nullptr};  // tile rows = k, reduction = n, element (k,n) at w[n*K + k]
   const bool va = (N % 4 == 0) && aligned16(dy);
@@ -469,14 +476,14 @@ extern "C" int gb_gemm_dgrad(const float *dy, const float *w, float *dx, const f
     launch_gemm<OP_KC, OP_RC, EPI_ATOMIC>(a, b, va, vb, dx, K, nullptr, kchunk, (unsigned)chunks, as_stream(stream));
     const int rc = check_launch("gb_gemm_dgrad");
     if (rc != GB_OK || !dstats) return rc;
-    return gb_bn_bwd_stats(dx, y_prev, ab_prev, nullptr, P, K, 1, dstats, stream);
+    return done(gb_bn_bwd_stats(dx, y_prev, ab_prev, nullptr, P, K, 1, dstats, nullptr, nullptr, stream));
   }
   if (dstats)
     launch_gemm<OP_KC, OP_RC, EPI_STORE_BNBWD>(a, b, va, vb, dx, K, dstats, kchunk, 1, as_stream(stream), stat_slots,
                                                y_prev, ab_prev);
   else
     launch_gemm<OP_KC, OP_RC, EPI_STORE>(a, b, va, vb, dx, K, nullptr, kchunk, 1, as_stream(stream));
-  return check_launch("gb_gemm_dgrad");
+  return done(check_launch("gb_gemm_dgrad"));
 }
 
 // dW (N,K) += dY (P,N)^T X (P,K) ; dW must be zeroed by the caller (accumulates with fp32 atomics)

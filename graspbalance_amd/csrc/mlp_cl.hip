@@ -790,10 +790,18 @@ extern "C" int gb_affine_relu_maxpool(const float *y, const float *ab, float *ou
   return check_launch("gb_affine_relu_maxpool");
 }
 
+// the layer's gb_bn_bwd_reduce as a second launch of the same call (dbeta != NULL)
+static int reduce_after(int rc, const double *dst, int slots, int C, double *total, float *dbeta, float *dgamma,
+                        void *stream) {
+  if (rc != GB_OK || !dbeta) return rc;
+  return gb_bn_bwd_reduce(dst, slots, C, total, dbeta, dgamma, stream);
+}
+
 extern "C" int gb_bn_bwd_stats(const float *dout, const float *y, const float *ab, const float *residual,
-                               long long P, int C, int relu, double *dstats, void *stream) {
-  if (P < 0 || C < 1 || !dout || !y || !ab || !dstats) return GB_EINVAL;
-  if (P == 0) return GB_OK;
+                               long long P, int C, int relu, double *dstats, float *dbeta, float *dgamma,
+                               void *stream) {
+  if (P < 0 || C < 1 || !dout || !y || !ab || !dstats || (!dbeta != !dgamma)) return GB_EINVAL;
+  if (P == 0) return reduce_after(GB_OK, dstats, 1, C, nullptr, dbeta, dgamma, stream);
   const int rpb = rows_per_block(P);
   const dim3 grid((unsigned)((P + rpb - 1) / rpb));
   const bool vec = C % 4 == 0 && (reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dout) |
@@ -804,7 +812,7 @@ extern "C" int gb_bn_bwd_stats(const float *dout, const float *y, const float *a
   else
     hipLaunchKernelGGL((bn_bwd_stats_kernel<1>), grid, dim3(CL_TPB), 0, as_stream(stream), dout, y, ab, residual, P,
                        C, rpb, relu, dstats, dstats + C);
-  return check_launch("gb_bn_bwd_stats");
+  return reduce_after(check_launch("gb_bn_bwd_stats"), dstats, 1, C, nullptr, dbeta, dgamma, stream);
 }
 
 extern "C" int gb_bn_bwd_apply(const float *dout, const float *y, const float *ab, const float *residual,
@@ -886,9 +894,11 @@ extern "C" int gb_bn_bwd_apply_w(const float *dout, const float *y, const float 
 }
 
 extern "C" int gb_bn_bwd_stats_pool(const float *dout, const float *out, const int32_t *arg, const float *y,
-                                    const float *ab, long long R, int ns, int C, double *dstats, void *stream) {
-  if (R < 0 || ns < 0 || C < 1 || !dout || !out || !arg || !y || !ab || !dstats) return GB_EINVAL;  // ns = 0: arg is an
-  if (R == 0) return GB_OK;                                                                        // absolute row index
+                                    const float *ab, long long R, int ns, int C, double *dstats, float *dbeta,
+                                    float *dgamma, void *stream) {
+  if (R < 0 || ns < 0 || C < 1 || !dout || !out || !arg || !y || !ab || !dstats || (!dbeta != !dgamma))
+    return GB_EINVAL;  // ns = 0: arg is an absolute row index
+  if (R == 0) return reduce_after(GB_OK, dstats, 1, C, nullptr, dbeta, dgamma, stream);
   const int rpb = rows_per_block(R);
   const dim3 grid((unsigned)((R + rpb - 1) / rpb));
   const bool vec = C % 4 == 0 && (reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(dout)) % 16 == 0;
@@ -898,7 +908,7 @@ extern "C" int gb_bn_bwd_stats_pool(const float *dout, const float *out, const i
   else
     hipLaunchKernelGGL((bn_bwd_stats_pool_kernel<1>), grid, dim3(CL_TPB), 0, as_stream(stream), dout, out, arg, y, ab,
                        R, ns, C, rpb, dstats, dstats + C);
-  return check_launch("gb_bn_bwd_stats_pool");
+  return reduce_after(check_launch("gb_bn_bwd_stats_pool"), dstats, 1, C, nullptr, dbeta, dgamma, stream);
 }
 
 extern "C" int gb_bn_bwd_apply_pool(const float *dout, const float *out, const int32_t *arg, const float *y,

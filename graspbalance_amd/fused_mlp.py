@@ -245,7 +245,7 @@ class LinearBNAct(Function):
             R = P // pool_ns
             dY = torch.empty_like(Y)
             _call("gb_bn_bwd_stats_pool", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(Y),
-                  _lib.ptr(ab), R, pool_ns, Cout, _lib.ptr(dstats), _s(Y))
+                  _lib.ptr(ab), R, pool_ns, Cout, _lib.ptr(dstats), None, None, _s(Y))
             _call("gb_bn_bwd_apply_pool", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(Y),
                   _lib.ptr(ab), _lib.ptr(dstats), R, pool_ns, Cout, int(training), _lib.ptr(dY), _s(Y))
         else:
@@ -254,7 +254,7 @@ class LinearBNAct(Function):
             if residual is not None and ctx.needs_input_grad[4]:
                 dres = torch.empty_like(Y)
             _call("gb_bn_bwd_stats", dev, _lib.ptr(dout), _lib.ptr(Y), _lib.ptr(ab), _lib.ptr(residual), P, Cout,
-                  int(relu), _lib.ptr(dstats), _s(Y))
+                  int(relu), _lib.ptr(dstats), None, None, _s(Y))
             _call("gb_bn_bwd_apply", dev, _lib.ptr(dout), _lib.ptr(Y), _lib.ptr(ab), _lib.ptr(residual),
                   _lib.ptr(dstats), P, Cout, int(relu), int(training), _lib.ptr(dY), _lib.ptr(dres), _s(Y))
         dgamma = dbeta = None
@@ -272,7 +272,8 @@ class LinearBNAct(Function):
             if ctx.needs_input_grad[0]:
                 dX = torch.empty((P, Cin), dtype=torch.float32, device=dev)
                 W = W.contiguous()
-                _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dX), None, None, None, 0, P, Cin, Cout, _s(dY),
+                _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dX), None, None, None, 0, P, Cin, Cout, None,
+                      None, None, _s(dY),
                       meta=_gemm_meta("dgrad", P, Cin, Cout))
         else:
             dW = _wgrad(dY, X) if ctx.needs_input_grad[1] else None
@@ -411,10 +412,13 @@ class MLPStack(Function):
         for n in widths:
             gb_off.append(gb_off[-1] + 2 * n)
 
-        def param_grads(l, partial, nslots, total):
+        def bn_grads(l):  # (dbeta, dgamma) of layer l: filled by gb_bn_bwd_reduce, launched from the producer's C call
             n = widths[l]
-            dbeta, dgamma = gb_arena[gb_off[l]:gb_off[l] + n], gb_arena[gb_off[l] + n:gb_off[l + 1]]
-            _call("gb_bn_bwd_reduce", dev, _lib.ptr(partial), nslots, n, _lib.ptr(total), _lib.ptr(dbeta),
+            return gb_arena[gb_off[l]:gb_off[l] + n], gb_arena[gb_off[l] + n:gb_off[l + 1]]
+
+        def param_grads(l, partial, nslots, total):
+            dbeta, dgamma = bn_grads(l)
+            _call("gb_bn_bwd_reduce", dev, _lib.ptr(partial), nslots, widths[l], _lib.ptr(total), _lib.ptr(dbeta),
                   _lib.ptr(dgamma), st)
             return dgamma, dbeta
 
@@ -422,10 +426,12 @@ class MLPStack(Function):
         dstats = d_arena[:2 * N]
         dres = None
         dY = _empty_rows(P, N, dev, rows is not None)
+        dbeta, dgamma = bn_grads(L - 1)
+        pb, pg = _lib.ptr(dbeta), _lib.ptr(dgamma)
         if rows is not None:
             out, arg = s1, s2
             _call("gb_bn_bwd_stats_pool", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(Ys[-1]),
-                  _lib.ptr(abs_[-1]), rows.R * rows.D, 0, N, _lib.ptr(dstats), st)  # ns = 0: absolute arg rows
+                  _lib.ptr(abs_[-1]), rows.R * rows.D, 0, N, _lib.ptr(dstats), pb, pg, st)  # ns = 0: absolute arg rows
             _call("gb_bn_bwd_apply_members", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(Ys[-1]),
                   _lib.ptr(abs_[-1]), _lib.ptr(dstats), _lib.ptr(rows.w), _lib.ptr(rows.off), _lib.ptr(rows.cnt), rows.R,
                   rows.D, N, P_stat, int(training[-1]), _lib.ptr(dY), st)
@@ -433,7 +439,7 @@ class MLPStack(Function):
             out, arg = s1, s2
             R = P // pool_ns
             _call("gb_bn_bwd_stats_pool", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(Ys[-1]),
-                  _lib.ptr(abs_[-1]), R, pool_ns, N, _lib.ptr(dstats), st)
+                  _lib.ptr(abs_[-1]), R, pool_ns, N, _lib.ptr(dstats), pb, pg, st)
             _call("gb_bn_bwd_apply_pool", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(Ys[-1]),
                   _lib.ptr(abs_[-1]), _lib.ptr(dstats), R, pool_ns, N, int(training[-1]), _lib.ptr(dY), st)
         else:
@@ -441,11 +447,11 @@ class MLPStack(Function):
             if has_res and ctx.needs_input_grad[1]:
                 dres = torch.empty((P, N), dtype=torch.float32, device=dev)
             _call("gb_bn_bwd_stats", dev, _lib.ptr(dout), _lib.ptr(Ys[-1]), _lib.ptr(abs_[-1]), _lib.ptr(residual), P, N,
-                  int(relu_last), _lib.ptr(dstats), st)
+                  int(relu_last), _lib.ptr(dstats), pb, pg, st)
             _call("gb_bn_bwd_apply", dev, _lib.ptr(dout), _lib.ptr(Ys[-1]), _lib.ptr(abs_[-1]), _lib.ptr(residual),
                   _lib.ptr(dstats), P, N, int(relu_last), int(training[-1]), _lib.ptr(dY), _lib.ptr(dres), st)
         grads = [None] * (3 * L)
-        grads[3 * L - 2], grads[3 * L - 1] = param_grads(L - 1, dstats, 1, None)
+        grads[3 * L - 2], grads[3 * L - 1] = dgamma, dbeta
         dX0 = None
         for l in range(L - 1, -1, -1):
             W = Ws[l]
@@ -460,7 +466,7 @@ class MLPStack(Function):
                 if ctx.needs_input_grad[0]:
                     dX0 = torch.empty((P, K), dtype=torch.float32, device=dev)
                     _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dX0), None, None, None, 0, P, K, N,
-                          st, meta=_gemm_meta("dgrad", P, K, N))
+                          None, None, None, st, meta=_gemm_meta("dgrad", P, K, N))
                 break
             if (l == 1 and _FIRST_FUSE and X0.shape[1] == 3 and not ctx.needs_input_grad[0] and need_w[0]
                     and _lib.lib().gb_gemm_uses_rs(P, K, N, 1, 2, 0)):
@@ -483,20 +489,20 @@ class MLPStack(Function):
             # gradient of layer l-1's post-ReLU output + that layer's BatchNorm-backward sums in one launch
             dZ = _empty_rows(P, K, dev, rows is not None)
             region = d_arena[d_off[l - 1]:d_off[l]]
+            dbeta, dgamma = bn_grads(l - 1)
+            grads[3 * l - 2], grads[3 * l - 1] = dgamma, dbeta
             if fused[l - 1]:
+                dstats = region[slots * 2 * K:] if slots > 1 else region  # the slot rows' total
                 _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dZ), _lib.ptr(Ys[l - 1]),
-                      _lib.ptr(abs_[l - 1]), _lib.ptr(region), slots, P, K, N, st,
-                      meta=_gemm_meta("dgrad", P, K, N, fused=True))
-                dstats = region[slots * 2 * K:] if slots > 1 else region
-                grads[3 * l - 2], grads[3 * l - 1] = param_grads(l - 1, region, slots, dstats if slots > 1 else None)
+                      _lib.ptr(abs_[l - 1]), _lib.ptr(region), slots, P, K, N, _lib.ptr(dstats), _lib.ptr(dbeta),
+                      _lib.ptr(dgamma), st, meta=_gemm_meta("dgrad", P, K, N, fused=True))
             else:
                 # wide + long outputs: the fused epilogue measured slower than a separate column pass
                 _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dZ), None, None, None, 0, P, K, N,
-                      st, meta=_gemm_meta("dgrad", P, K, N))
+                      None, None, None, st, meta=_gemm_meta("dgrad", P, K, N))
                 dstats = region
                 _call("gb_bn_bwd_stats", dev, _lib.ptr(dZ), _lib.ptr(Ys[l - 1]), _lib.ptr(abs_[l - 1]), None, P, K, 1,
-                      _lib.ptr(dstats), st)
-                grads[3 * l - 2], grads[3 * l - 1] = param_grads(l - 1, dstats, 1, None)
+                      _lib.ptr(dstats), _lib.ptr(dbeta), _lib.ptr(dgamma), st)
             dY = _empty_rows(P, K, dev, rows is not None)
             if rows is not None:
                 _call("gb_bn_bwd_apply_w", dev, _lib.ptr(dZ), _lib.ptr(Ys[l - 1]), _lib.ptr(abs_[l - 1]), _lib.ptr(dstats),
@@ -601,7 +607,7 @@ class LocalAggPool(Function):
         if ctx.needs_input_grad[0]:
             df = torch.empty((rows, C), dtype=torch.float32, device=dev)
             _call("gb_gemm_dgrad", dev, _lib.ptr(dG), _lib.ptr(Wf), _lib.ptr(df), None, None, None, 0, rows, C, N,
-                  st, meta=_gemm_meta("dgrad", rows, C, N))
+                  None, None, None, st, meta=_gemm_meta("dgrad", rows, C, N))
         return df, dW, dgamma, dbeta, None, None
 
 

@@ -222,14 +222,16 @@ int gb_affine_relu_maxpool(const float *y, const float *ab, float *out, int32_t 
                            int C, void *stream);
 /* BatchNorm(+ReLU)(+residual) backward. dstats[0:C] += dbeta, dstats[C:2C] += dgamma (fp64, zeroed by
  * the caller); then dy = a*(dA - dbeta/P - xhat*dgamma/P) (training) or a*dA (eval); dres (optional)
- * receives dA = dout*[z>0].  The *_pool forms take the (R,C) gradient of the max-pooled output.     */
+ * receives dA = dout*[z>0].  The *_pool forms take the (R,C) gradient of the max-pooled output.
+ * dbeta / dgamma (optional, both or none): gb_bn_bwd_reduce runs from the same call (one host transition less). */
 int gb_bn_bwd_stats(const float *dout, const float *y, const float *ab, const float *residual, long long P,
-                    int C, int relu, double *dstats, void *stream);
+                    int C, int relu, double *dstats, float *dbeta, float *dgamma, void *stream);
 int gb_bn_bwd_apply(const float *dout, const float *y, const float *ab, const float *residual,
                     const double *dstats, long long P, int C, int relu, int training, float *dy, float *dres,
                     void *stream);
 int gb_bn_bwd_stats_pool(const float *dout, const float *out, const int32_t *arg, const float *y,
-                         const float *ab, long long R, int ns, int C, double *dstats, void *stream);
+                         const float *ab, long long R, int ns, int C, double *dstats, float *dbeta, float *dgamma,
+                         void *stream);
 int gb_bn_bwd_apply_pool(const float *dout, const float *out, const int32_t *arg, const float *y,
                          const float *ab, const double *dstats, long long R, int ns, int C, int training,
                          float *dy, void *stream);
@@ -322,9 +324,11 @@ int gb_gemm_fwd(const float *x, const float *w, const float *aff, float *y, doub
 /* dX (P,K) = dY (P,N) W(N,K), W in its natural (N,K) row-major layout.  Optional fused BatchNorm-backward
  * statistics of the previous layer (dX is the gradient of its post-ReLU output): y_prev (P,K) its pre-BN
  * output, ab_prev = [a,b,mean,rstd](K), dstats fp64 [stat_slots][2K] (caller-zeroed) += [sum dA,
- * sum dA*xhat] with dA = dX*[a*y+b > 0].  Pass NULLs / 0 to skip.                                  */
+ * sum dA*xhat] with dA = dX*[a*y+b > 0].  Pass NULLs / 0 to skip.  dbeta / dgamma (optional): the
+ * previous layer's gb_bn_bwd_reduce runs from the same call, the slot rows' total going to dstats_total. */
 int gb_gemm_dgrad(const float *dy, const float *w, float *dx, const float *y_prev, const float *ab_prev,
-                  double *dstats, int stat_slots, long long P, int K, int N, void *stream);
+                  double *dstats, int stat_slots, long long P, int K, int N, double *dstats_total, float *dbeta,
+                  float *dgamma, void *stream);
 /* dW (N,K) += dY (P,N)^T f(X (P,K)); accumulates (fp32 atomics, reduction over P split across
  * workgroups).  x_aff (optional) = [a(K), b(K)]: f(x) = relu(a_k x + b_k), as in gb_gemm_fwd.      */
 int gb_gemm_wgrad(const float *dy, const float *x, const float *x_aff, float *dw, long long P, int K, int N,

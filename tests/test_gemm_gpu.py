@@ -53,7 +53,7 @@ def test_gemm_dgrad_and_wgrad(P, K, N):
     W = torch.randn(N, K, device=DEV)
     dY = torch.randn(P, N, device=DEV)
     dX = torch.empty(P, K, device=DEV)
-    L.check(L.lib().gb_gemm_dgrad(L.ptr(dY), L.ptr(W), L.ptr(dX), None, None, None, 0, P, K, N, None), "dgrad")
+    L.check(L.lib().gb_gemm_dgrad(L.ptr(dY), L.ptr(W), L.ptr(dX), None, None, None, 0, P, K, N, None, None, None, None), "dgrad")
     dW = torch.zeros(N, K, device=DEV)
     L.check(L.lib().gb_gemm_wgrad(L.ptr(dY), L.ptr(X), None, L.ptr(dW), P, K, N, None), "wgrad")
     torch.cuda.synchronize()
@@ -89,7 +89,7 @@ def test_gemm_fused_epilogues_slotted(P, K, N):
     dX = torch.empty(P, K, device=DEV)
     dst = torch.zeros(slots, 2 * K, dtype=torch.float64, device=DEV)
     L.check(L.lib().gb_gemm_dgrad(L.ptr(dY), L.ptr(W), L.ptr(dX), L.ptr(yprev), L.ptr(ab), L.ptr(dst), slots, P, K, N,
-                                  None), "dgrad bn")
+                                  None, None, None, None), "dgrad bn")
     torch.cuda.synchronize()
     rx = dY.double() @ W.double()
     assert float((dX.double() - rx).abs().max()) / (float(rx.abs().max()) + 1e-12) < 2e-6

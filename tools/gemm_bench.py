@@ -33,7 +33,7 @@ for name, P, K, N in SHAPES:
     r = {}
     r["fwd own"] = timeit(lambda: lib.gb_gemm_fwd(L.ptr(X), L.ptr(W), None, L.ptr(Y), L.ptr(st), SLOTS, P, K, N, None, None))
     r["fwd blas"] = timeit(lambda: torch.mm(X, W.t(), out=Y))
-    r["dgrad own"] = timeit(lambda: lib.gb_gemm_dgrad(L.ptr(dY), L.ptr(W), L.ptr(dX), None, None, None, 0, P, K, N, None))
+    r["dgrad own"] = timeit(lambda: lib.gb_gemm_dgrad(L.ptr(dY), L.ptr(W), L.ptr(dX), None, None, None, 0, P, K, N, None, None, None, None))
     r["dgrad blas"] = timeit(lambda: torch.mm(dY, W, out=dX))
     r["wgrad own"] = timeit(lambda: lib.gb_gemm_wgrad(L.ptr(dY), L.ptr(X), None, L.ptr(dW), P, K, N, None))
     from graspbalance_amd.fused_mlp import _wgrad

@@ -23,9 +23,9 @@ for name, P, K, N in [("sa1.l1", 524288, 64, 64), ("sa1.l2", 524288, 64, 128), (
     t["fwd"] = timeit(lambda: lib.gb_gemm_fwd(L.ptr(X), L.ptr(W), None, L.ptr(Y), L.ptr(st), 32, P, K, N, None, None))
     t["fwd+aff"] = timeit(lambda: lib.gb_gemm_fwd(L.ptr(X), L.ptr(W), L.ptr(affK), L.ptr(Y), L.ptr(st), 32, P, K, N, None, None))
     t["affine_act(K)"] = timeit(lambda: lib.gb_affine_act(L.ptr(X), L.ptr(affK), None, L.ptr(Z), P, K, 1, None))
-    t["dgrad"] = timeit(lambda: lib.gb_gemm_dgrad(L.ptr(dY), L.ptr(W), L.ptr(dX), None, None, None, 0, P, K, N, None))
-    t["dgrad+bn"] = timeit(lambda: lib.gb_gemm_dgrad(L.ptr(dY), L.ptr(W), L.ptr(dX), L.ptr(X), L.ptr(affK), L.ptr(dst), 32, P, K, N, None))
-    t["bn_bwd_stats(K)"] = timeit(lambda: lib.gb_bn_bwd_stats(L.ptr(dX), L.ptr(X), L.ptr(affK), None, P, K, 1, L.ptr(dst), None))
+    t["dgrad"] = timeit(lambda: lib.gb_gemm_dgrad(L.ptr(dY), L.ptr(W), L.ptr(dX), None, None, None, 0, P, K, N, None, None, None, None))
+    t["dgrad+bn"] = timeit(lambda: lib.gb_gemm_dgrad(L.ptr(dY), L.ptr(W), L.ptr(dX), L.ptr(X), L.ptr(affK), L.ptr(dst), 32, P, K, N, None, None, None, None))
+    t["bn_bwd_stats(K)"] = timeit(lambda: lib.gb_bn_bwd_stats(L.ptr(dX), L.ptr(X), L.ptr(affK), None, P, K, 1, L.ptr(dst), None, None, None))
     t["wgrad"] = timeit(lambda: lib.gb_gemm_wgrad(L.ptr(dY), L.ptr(X), None, L.ptr(dW), P, K, N, None))
     t["wgrad+aff"] = timeit(lambda: lib.gb_gemm_wgrad(L.ptr(dY), L.ptr(X), L.ptr(affK), L.ptr(dW), P, K, N, None))
     print("%-8s " % name + " | ".join("%s %.0f" % kv for kv in t.items()))

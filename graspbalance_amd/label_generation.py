@@ -46,6 +46,34 @@ def _transform_3x4(cloud, pose):
     return torch.matmul(pose, homo.T).T[:, :3]
 
 
+_PAD_CACHE = {}
+
+
+def _transform_all(gps_all, all_poses):
+    """``transform_point_cloud(gp, pose, '3x4')`` of EVERY object of the batch as one batched matmul instead of a
+    cat + matmul + slice per object: the clouds are packed (one cat), scattered into a cached (K, nmax, 4) homogeneous
+    buffer through a cached index (it depends on the sizes only), multiplied by their poses in one bmm, and gathered
+    back.  rocBLAS forms each of the four-term dot products the same way in both shapes, so the result is the
+    per-object matmul's bit for bit (asserted on the full batch in tests/test_model_gpu.py, with unequal sizes).
+    Returns (T,3), objects one after another."""
+    dev = all_poses.device
+    sizes = tuple(int(gp.size(0)) for gp in gps_all)
+    key = (sizes, str(dev), all_poses.dtype)
+    ent = _PAD_CACHE.get(key)
+    if ent is None:
+        if len(_PAD_CACHE) > 64:
+            _PAD_CACHE.clear()
+        nmax = max(sizes)
+        flat = torch.cat([torch.arange(n, dtype=torch.int64) + k * nmax for k, n in enumerate(sizes)]).to(dev)
+        buf = torch.ones((len(sizes) * nmax, 4), dtype=all_poses.dtype, device=dev)  # column 3 stays 1
+        ent = _PAD_CACHE[key] = (flat, buf, nmax)
+    flat, buf, nmax = ent
+    K = len(sizes)
+    buf[:, :3].index_copy_(0, flat, torch.cat(gps_all, 0))  # padding rows keep stale values: never read back
+    out = torch.bmm(all_poses, buf.view(K, nmax, 4).transpose(1, 2))  # (K,3,nmax) == matmul(pose, homo.T) per object
+    return out.transpose(1, 2).reshape(K * nmax, 3).index_select(0, flat)
+
+
 def _assign_views(poses, V):
     """For every object pose (K,3,4): index of the transformed template view nearest to each template
     view, (K,V) — the reference's per-object 300x300 kNN (label_generation.py:56-58), as ONE batched
@@ -147,9 +175,14 @@ def _process_grasp_labels_fused(end_points):
     rot_sel = torch.gather(rot_trans, 1, view_inds.view(-1, V, 1, 1).expand(-1, -1, 3, 3))
     obj_of_seed, pt_of_seed, points = [], [], []
     k0 = 0
+    gps_l = end_points['grasp_points_list']
+    pts_all = _transform_all([gp for gps in gps_l for gp in gps], all_poses)  # every object's grasp points, camera frame
+    p0 = 0
     for i in range(B):
-        gps = end_points['grasp_points_list'][i]
-        pts = torch.cat([_transform_3x4(gp, pose) for gp, pose in zip(gps, poses_l[i])], 0)
+        gps = gps_l[i]
+        n_i = sum(int(gp.size(0)) for gp in gps)
+        pts = pts_all[p0:p0 + n_i]  # == cat([transform_point_cloud(gp, pose, '3x4') for the cloud's objects])
+        p0 += n_i
         # (object id, point id within the object) of every row of pts: depends on the sizes only - built once per
         # size pattern instead of a full_() + arange() pair per object per step
         oid, loc = _row_ids(tuple(int(gp.size(0)) for gp in gps), k0, dev)

@@ -82,12 +82,19 @@ def test_full_size_forward_properties():
     assert len(preds) == 2 and preds[0].shape[1] == 17
 
 
-def test_fused_label_matching_equals_per_object_composition(monkeypatch):
-    """gb_label_gather path of process_grasp_labels == the reference-style two-stage index_select."""
+@pytest.mark.parametrize("ragged", [False, True])
+def test_fused_label_matching_equals_per_object_composition(monkeypatch, ragged):
+    """gb_label_gather path of process_grasp_labels (all objects' pose transforms as one batched matmul, composed
+    index maps, fused score transform) == the reference-style per-object composition, bit for bit - also with a
+    different number of grasp points per object."""
     from graspbalance_amd import label_generation as lg
     from graspbalance_amd.synthetic import make_training_batch
     batch = make_training_batch(range(2), num_point=6000, num_objects=3, grasp_points_per_object=40, num_view=60,
                                 device=DEV)
+    if ragged:
+        keep = {(0, 1): 23, (1, 0): 31, (1, 1): 1}
+        for key in ('grasp_points_list', 'grasp_labels_list', 'grasp_offsets_list', 'grasp_tolerance_list'):
+            batch[key] = [[t[:keep.get((i, k), t.size(0))] for k, t in enumerate(per)] for i, per in enumerate(batch[key])]
     ep = dict(batch)
     ep['input_xyz'] = batch['point_clouds']
     ep['fp2_xyz'] = batch['point_clouds'][:, :256].contiguous()

@@ -170,7 +170,11 @@ def _process_grasp_labels_fused(end_points):
     rot_template = batch_viewpoint_params_to_matrix(-views, torch.zeros(V, dtype=views.dtype, device=dev))
     R = all_poses[:, :3, :3]
     views_trans = torch.matmul(R, views.T).transpose(1, 2)                       # (Kt,V,3)
-    rot_trans = torch.matmul(R.unsqueeze(1), rot_template.unsqueeze(0))          # (Kt,V,3,3)
+    # R_k @ T_v for every (object, view) as ONE (3 Kt x 3) @ (3 x 3 V) product instead of a 3x3 bmm with Kt*V batches
+    # (94 us): the same three-term dot products - bit-identical, tests/test_model_gpu.py compares the rotations exactly
+    Kt = R.size(0)
+    rot_trans = torch.mm(R.reshape(Kt * 3, 3), rot_template.permute(1, 0, 2).reshape(3, V * 3)) \
+        .view(Kt, 3, V, 3).permute(0, 2, 1, 3)                                   # (Kt,V,3,3), strided
     views_sel = torch.gather(views_trans, 1, view_inds.unsqueeze(-1).expand(-1, -1, 3))
     rot_sel = torch.gather(rot_trans, 1, view_inds.view(-1, V, 1, 1).expand(-1, -1, 3, 3))
     obj_of_seed, pt_of_seed, points = [], [], []

@@ -106,7 +106,7 @@ def test_fused_label_matching_equals_per_object_composition(monkeypatch, ragged)
               'batch_grasp_view_label'):
         assert torch.equal(fused[k], plain[k]), k
     for k in ('batch_grasp_view', 'batch_grasp_view_rot'):
-        assert torch.allclose(fused[k], plain[k], rtol=0, atol=1e-6), k
+        assert torch.equal(fused[k], plain[k]), k
 
 
 def _segmented_clouds(B, N, objects, seed):

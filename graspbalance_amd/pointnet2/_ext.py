@@ -4,8 +4,9 @@
 Same contract as the reference wrappers (sampling.cpp, ball_query.cpp, group_points.cpp,
 interpolate.cpp, cylinder_query.cpp): inputs must be contiguous float32 / int32 tensors
 (``RuntimeError`` otherwise, the TORCH_CHECK texts of _ext_src/include/utils.h:10-30), outputs are
-allocated here and zero-filled (``torch::zeros``), CPU tensors raise ``RuntimeError("CPU not
-supported")``, launches go to the current stream and never synchronise.
+allocated here (the reference zero-fills them with ``torch::zeros``; the kernels here write every element -
+empty ball rows as zeros - so only the scatter-add targets of the *_grad ops still need the fill), CPU tensors
+raise ``RuntimeError("CPU not supported")``, launches go to the current stream and never synchronise.
 """
 import torch
 
@@ -46,7 +47,7 @@ def furthest_point_sampling(points, nsamples):
     _check_float(points, "points")
     _require_gpu(points)
     B, N = points.size(0), points.size(1)
-    output = torch.zeros((B, nsamples), dtype=torch.int32, device=points.device)
+    output = torch.empty((B, nsamples), dtype=torch.int32, device=points.device)  # every element is written by the kernel
     tmp = torch.full((B, N), 1e10, dtype=torch.float32, device=points.device)
     with _lib.device_ctx(points.device):
         stream = _lib.current_stream(points.device)
@@ -67,7 +68,7 @@ def gather_points(points, idx):
     _require_gpu(points)
     B, C, N = points.shape
     M = idx.size(1)
-    output = torch.zeros((B, C, M), dtype=torch.float32, device=points.device)
+    output = torch.empty((B, C, M), dtype=torch.float32, device=points.device)  # every element is written by the kernel
     with _lib.device_ctx(points.device):
         _lib.check(_lib.lib().gb_gather(_lib.ptr(points), _lib.ptr(idx), _lib.ptr(output), B, C, N, M,
                                         _lib.current_stream(points.device)), "gather_points")
@@ -102,7 +103,7 @@ def ball_query(new_xyz, xyz, radius, nsample):
     _require_gpu(new_xyz)
     B, M = new_xyz.size(0), new_xyz.size(1)
     N = xyz.size(1)
-    idx = torch.zeros((B, M, nsample), dtype=torch.int32, device=new_xyz.device)
+    idx = torch.empty((B, M, nsample), dtype=torch.int32, device=new_xyz.device)  # every element is written by the kernel
     with _lib.device_ctx(new_xyz.device):
         _lib.check(_lib.lib().gb_ball_query(_lib.ptr(new_xyz), _lib.ptr(xyz), _lib.ptr(idx), None, B, N, M,
                                             float(radius), int(nsample),
@@ -124,7 +125,7 @@ def cylinder_query(new_xyz, xyz, rot, radius, hmin, hmax, nsample):
     _require_gpu(new_xyz)
     B, M = new_xyz.size(0), new_xyz.size(1)
     N = xyz.size(1)
-    idx = torch.zeros((B, M, nsample), dtype=torch.int32, device=new_xyz.device)
+    idx = torch.empty((B, M, nsample), dtype=torch.int32, device=new_xyz.device)  # every element is written by the kernel
     with _lib.device_ctx(new_xyz.device):
         _lib.check(_lib.lib().gb_cylinder_query(_lib.ptr(new_xyz), _lib.ptr(xyz), _lib.ptr(rot), _lib.ptr(idx),
                                                 None, B, N, M, float(radius), float(hmin), float(hmax),
@@ -144,7 +145,7 @@ def group_points(points, idx):
     _require_gpu(points)
     B, C, N = points.shape
     M, S = idx.size(1), idx.size(2)
-    output = torch.zeros((B, C, M, S), dtype=torch.float32, device=points.device)
+    output = torch.empty((B, C, M, S), dtype=torch.float32, device=points.device)  # every element is written by the kernel
     with _lib.device_ctx(points.device):
         _lib.check(_lib.lib().gb_group(_lib.ptr(points), _lib.ptr(idx), _lib.ptr(output), B, C, N, M, S,
                                        _lib.current_stream(points.device)), "group_points")
@@ -202,7 +203,7 @@ def three_interpolate(points, idx, weight):
     _require_gpu(points)
     B, C, m = points.shape
     n = idx.size(1)
-    output = torch.zeros((B, C, n), dtype=torch.float32, device=points.device)
+    output = torch.empty((B, C, n), dtype=torch.float32, device=points.device)  # every element is written by the kernel
     with _lib.device_ctx(points.device):
         _lib.check(_lib.lib().gb_three_interpolate(_lib.ptr(points), _lib.ptr(idx), _lib.ptr(weight),
                                                    _lib.ptr(output), B, C, m, n,

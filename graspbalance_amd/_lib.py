@@ -54,6 +54,8 @@ SIGNATURES = {
     "gb_bn_bwd_apply_pool": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P],
     "gb_bn_bwd_reduce": [_P, _I, _I, _P, _P, _P, _P],
     "gb_la_point_stats": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P],
+    "gb_la_split_w": [_P, _P, _P, _I, _I, _P],
+    "gb_la_join_w": [_P, _P, _P, _I, _I, _P],
     "gb_la_col_stats": [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P],
     "gb_la_pool": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
     "gb_la_pool_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],

@@ -379,6 +379,34 @@ extern "C" int gb_la_point_stats(const float *xyz, const float *centres, const i
   return check_launch("gb_la_point_stats");
 }
 
+// W (N, 3 + C) <-> [Wx (N,3), Wf (N,C)]: the two column blocks of the LocalAggregation convolution weight as separate
+// dense matrices (what the kernels above and the GEMMs take) in one launch, and their gradients back into one.
+__global__ __launch_bounds__(LA_TPB) void la_split_join_kernel(float *__restrict__ w, float *__restrict__ wx,
+                                                                float *__restrict__ wf, int N, int C, int join) {
+  const long long e = (long long)blockIdx.x * LA_TPB + threadIdx.x;
+  if (e >= (long long)N * (3 + C)) return;
+  const int n = (int)(e / (3 + C)), c = (int)(e % (3 + C));
+  float *part = c < 3 ? wx + n * 3 + c : wf + (size_t)n * C + (c - 3);
+  if (join) w[e] = *part;
+  else *part = w[e];
+}
+
+extern "C" int gb_la_split_w(const float *w, float *wx, float *wf, int N, int C, void *stream) {
+  if (N < 1 || C < 1 || !w || !wx || !wf) return GB_EINVAL;
+  const long long total = (long long)N * (3 + C);
+  hipLaunchKernelGGL(la_split_join_kernel, dim3((unsigned)((total + LA_TPB - 1) / LA_TPB)), dim3(LA_TPB), 0,
+                     as_stream(stream), const_cast<float *>(w), wx, wf, N, C, 0);
+  return check_launch("gb_la_split_w");
+}
+
+extern "C" int gb_la_join_w(const float *wx, const float *wf, float *w, int N, int C, void *stream) {
+  if (N < 1 || C < 1 || !w || !wx || !wf) return GB_EINVAL;
+  const long long total = (long long)N * (3 + C);
+  hipLaunchKernelGGL(la_split_join_kernel, dim3((unsigned)((total + LA_TPB - 1) / LA_TPB)), dim3(LA_TPB), 0,
+                     as_stream(stream), w, const_cast<float *>(wx), const_cast<float *>(wf), N, C, 1);
+  return check_launch("gb_la_join_w");
+}
+
 extern "C" int gb_la_col_stats(const float *G, const float *cnt, const float *dsum, const float *wx,
                                const double *mom, long long rows, int C, double *stats, double *u,
                                const GbBnFinalize *fin, void *stream) {

@@ -551,7 +551,10 @@ class LocalAggPool(Function):
         st = _s(f)  # one stream lookup per call, not one per launch
         f = f.contiguous()
         N, C = W.shape[0], W.shape[1] - 3
-        Wx, Wf = W[:, :3].contiguous(), W[:, 3:].contiguous()
+        W = W.contiguous()
+        wbuf = torch.empty(N * (3 + C), dtype=torch.float32, device=dev)
+        Wx, Wf = wbuf[:N * 3].view(N, 3), wbuf[N * 3:].view(N, C)  # N*3*4 bytes is a multiple of 16 for N % 4 == 0
+        _call("gb_la_split_w", dev, _lib.ptr(W), _lib.ptr(Wx), _lib.ptr(Wf), N, C, st)
         rows, P = geo.b * geo.n, geo.rows
         G = torch.empty((rows, N), dtype=torch.float32, device=dev)
         _call("gb_gemm_fwd", dev, _lib.ptr(f), _lib.ptr(Wf), None, _lib.ptr(G), None, 1, rows, C, N, None, st,
@@ -602,7 +605,8 @@ class LocalAggPool(Function):
             dWf = torch.zeros((N, C), dtype=torch.float32, device=dev)
             _call("gb_gemm_wgrad", dev, _lib.ptr(dG), _lib.ptr(f), None, _lib.ptr(dWf), rows, C, N, st,
                   meta=_gemm_meta("wgrad", rows, C, N))
-            dW = torch.cat([dWx, dWf], 1)
+            dW = torch.empty((N, 3 + C), dtype=torch.float32, device=dev)
+            _call("gb_la_join_w", dev, _lib.ptr(dWx), _lib.ptr(dWf), _lib.ptr(dW), N, C, st)
         df = None
         if ctx.needs_input_grad[0]:
             df = torch.empty((rows, C), dtype=torch.float32, device=dev)

@@ -291,6 +291,10 @@ int gb_la_point_stats(const float *xyz, const float *centres, const int32_t *idx
                       int mode, float scale, float *cnt, float *dsum, double *mom, void *stream);
 /* stats fp64 [2C] += [sum_p y, sum_p y^2] (the BatchNorm batch sums over all P = b*m*ns rows, in the form
  * gb_bn_finalize reads), u fp64 [3][C] += U[j][c] = sum_i G[i,c] D_i[j]; G (rows = b*n, C); caller-zeroed. */
+/* W (N, 3+C) -> Wx (N,3), Wf (N,C) (dense copies of the two column blocks of the LocalAggregation conv weight,
+ * drp.py:32-67: the xyz part and the feature part) in one launch; gb_la_join_w is the inverse (for the gradients). */
+int gb_la_split_w(const float *w, float *wx, float *wf, int N, int C, void *stream);
+int gb_la_join_w(const float *wx, const float *wf, float *w, int N, int C, void *stream);
 int gb_la_col_stats(const float *G, const float *cnt, const float *dsum, const float *wx, const double *mom,
                     long long rows, int C, double *stats, double *u, const GbBnFinalize *fin,
                     void *stream);

@@ -587,7 +587,9 @@ class LocalAggPool(Function):
         dout = dout.contiguous()
         N, C = Wf.shape
         rows, P = geo.b * geo.n, geo.rows
-        sg = torch.zeros((rows, N), dtype=torch.float32, device=dev)
+        # one zero fill for the two atomic-add targets: sg (rows, N) and, when the weight gradient is wanted, dWf (N, C)
+        zbuf = torch.zeros(rows * N + (N * C if ctx.needs_input_grad[1] else 0), dtype=torch.float32, device=dev)
+        sg = zbuf[:rows * N].view(rows, N)
         red = _zeros64(5 * N, dev)  # [dbeta, dgamma, T0, T1, T2]
         _call("gb_la_pool_bwd", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(G), _lib.ptr(geo.xyz),
               _lib.ptr(geo.centres), _lib.ptr(geo.idx), _lib.ptr(Wx), _lib.ptr(ab), _lib.ptr(sg), _lib.ptr(red), geo.b,
@@ -602,7 +604,7 @@ class LocalAggPool(Function):
         if ctx.needs_input_grad[1]:
             _call("gb_la_wx_grad", dev, _lib.ptr(red), _lib.ptr(u), _lib.ptr(geo.mom), _lib.ptr(Wx), _lib.ptr(ab), P, N,
                   training, _lib.ptr(dWx), st)
-            dWf = torch.zeros((N, C), dtype=torch.float32, device=dev)
+            dWf = zbuf[rows * N:].view(N, C)
             _call("gb_gemm_wgrad", dev, _lib.ptr(dG), _lib.ptr(f), None, _lib.ptr(dWf), rows, C, N, st,
                   meta=_gemm_meta("wgrad", rows, C, N))
             dW = torch.empty((N, 3 + C), dtype=torch.float32, device=dev)

@@ -170,7 +170,8 @@ def main():
             achieved = fps_algorithmic_bytes(meta["b"], meta["n"], meta["m"]) / (mean_ms * 1e-3) / 1e9
             pruned = _lib._fps_prune and _lib.FPS_PRUNE_MIN_N <= meta["n"] <= _lib.FPS_PRUNE_MAX_N
             kname = "fps_pruned_kernel" if pruned else "fps_reg_kernel<1024, 20>"
-            what = "Morton keys + sort + fps_pruned_kernel<1024,20>" if pruned else "fps_reg_kernel<1024,20>"
+            order = "cell-order counting sort" if _lib._fps_cell_order else "Morton keys + sort"
+            what = order + " + fps_pruned_kernel<1024,20>" if pruned else "fps_reg_kernel<1024,20>"
             roofline_fps = {"kernel": "%s (furthest_point_sampling %d->%d, b=%d)" % (what, meta["n"], meta["m"], meta["b"]),
                             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(kname),

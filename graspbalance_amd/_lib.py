@@ -29,6 +29,7 @@ SIGNATURES = {
     "gb_fps": [_P, _P, _P, _I, _I, _I, _U, _P],
     "gb_fps_pruned": [_P, _P, _P, _P, _I, _I, _I, _U, _P, _P],
     "gb_fps_segments": [_P, _P, _P, _P, _P, _I, _I, _U, _P],
+    "gb_fps_cell_order": [_P, _P, _I, _I, _P],
     "gb_fps_morton_keys": [_P, _P, _I, _I, _P],
     "gb_fps_guarded": [_P, _P, _P, _I, _I, _I, _U, _P, _P, _P, _P],
     "gb_gather": [_P, _P, _P, _I, _I, _I, _I, _P],
@@ -192,19 +193,26 @@ def event_pair_overhead_ms(device, pairs=64):
 
 FPS_PRUNE_MIN_N, FPS_PRUNE_MAX_N, FPS_PRUNE_MIN_M = 8192, 65536, 128
 _fps_prune = os.environ.get("GB_FPS_PRUNE", "1") != "0"  # A/B switch
+_fps_cell_order = os.environ.get("GB_FPS_CELL_ORDER", "1") != "0"  # A/B switch: visiting order by counting sort
 FPS_PREFIX_MAX_N = 4096
 _fps_prefix = os.environ.get("GB_FPS_PREFIX", "1") != "0"  # A/B switch
 
 
 def fps(points, temp, output, b, n, m, flags, stream):
-    """gb_fps, or for large clouds its pruned form on a Morton-sorted visiting order (identical outputs)."""
+    """gb_fps, or for large clouds its pruned form on a spatially coherent visiting order (identical outputs)."""
     import torch
     if _fps_prune and FPS_PRUNE_MIN_N <= n <= FPS_PRUNE_MAX_N and m >= FPS_PRUNE_MIN_M:
-        keys = torch.empty((b, n), dtype=torch.int32, device=points.device)
-        rc = lib().gb_fps_morton_keys(ptr(points), ptr(keys), b, n, stream)
-        if rc != GB_OK:
-            return rc
-        perm = torch.argsort(keys, dim=1).to(torch.int32)
+        perm = torch.empty((b, n), dtype=torch.int32, device=points.device)
+        if _fps_cell_order:  # counting sort by grid cell: one launch
+            rc = lib().gb_fps_cell_order(ptr(points), ptr(perm), b, n, stream)
+            if rc != GB_OK:
+                return rc
+        else:                # full 30-bit Morton sort (keys kernel + torch sort)
+            keys = torch.empty((b, n), dtype=torch.int32, device=points.device)
+            rc = lib().gb_fps_morton_keys(ptr(points), ptr(keys), b, n, stream)
+            if rc != GB_OK:
+                return rc
+            perm = torch.argsort(keys, dim=1).to(torch.int32)
         scratch = torch.empty((b, n, 4), dtype=torch.float32, device=points.device) if n > 20480 else None
         return lib().gb_fps_pruned(ptr(points), ptr(perm), ptr(temp), ptr(output), b, n, m, flags, ptr(scratch), stream)
     if _fps_prefix and n <= FPS_PREFIX_MAX_N and 64 <= m <= n:

@@ -76,6 +76,10 @@ int gb_fps(const float *xyz, float *temp, int32_t *idx, int b, int n, int m, uns
  * sorted (x,y,z,key) copy that the touched rows are re-read from; temp (optional) as in gb_fps.                                                                          */
 int gb_fps_pruned(const float *xyz, const int32_t *perm, float *temp, int32_t *idx, int b, int n, int m,
                   unsigned flags, float *scratch, void *stream);
+/* perm (b,n) int32: a spatially coherent permutation of each cloud's indices for gb_fps_pruned - counting sort by the
+ * Morton code of a 32^3 grid cell, one launch; the order inside a cell is not deterministic (gb_fps_pruned's output
+ * does not depend on the permutation).                                                                  */
+int gb_fps_cell_order(const float *xyz, int32_t *perm, int b, int n, void *stream);
 /* keys (b,n) int32: 30-bit Morton code of each point within its cloud's bounding box.                   */
 int gb_fps_morton_keys(const float *xyz, int32_t *keys, int b, int n, void *stream);
 /* Segmented FPS - the per-object sampling loop of ObjectBalanceSampling (TrainModel/modules.py:178-221, one

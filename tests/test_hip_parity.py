@@ -491,3 +491,34 @@ def test_known_answers_and_degenerate_shapes(ext, pb, orc):
     assert L.gb_fps(_lib.ptr(one), None, _lib.ptr(guard), 1, 1, 4, _lib.FPS_TIE_TREE512, None) == 0
     torch.cuda.synchronize()
     assert guard[:4].tolist() == [0, 0, 0, 0]
+
+
+def test_fps_cell_order_is_a_coherent_permutation(orc):
+    """gb_fps_cell_order: every cloud's output is a permutation of its indices, grouped by grid cell (points of one
+    32^3 cell are contiguous), and gb_fps_pruned on it returns the oracle's samples."""
+    import torch
+    from graspbalance_amd import _lib
+    for (B, N, m) in [(3, 20000, 300), (1, 777, 128), (2, 50000, 150)]:
+        xyz = torch.from_numpy(make_batch(list(range(20, 20 + B)), N))
+        xyz[0, : N // 10] = xyz[0, 0]  # many points in one cell
+        dev = xyz.to(DEV)
+        perm = torch.full((B, N), -1, dtype=torch.int32, device=DEV)
+        _lib.check(_lib.lib().gb_fps_cell_order(_lib.ptr(dev), _lib.ptr(perm), B, N, None), "cell_order")
+        torch.cuda.synchronize()
+        p = perm.cpu().long()
+        assert torch.equal(torch.sort(p, dim=1)[0], torch.arange(N).repeat(B, 1))
+        lo, hi = xyz.min(1, keepdim=True)[0], xyz.max(1, keepdim=True)[0]
+        q = ((xyz - lo) * (31.0 / (hi - lo))).clamp(0, 31).floor().long()
+        cell = q[..., 0] * 1024 + q[..., 1] * 32 + q[..., 2]           # any injective cell id
+        walked = torch.gather(cell, 1, p)
+        changes = (walked[:, 1:] != walked[:, :-1]).sum(1) + 1
+        distinct = torch.tensor([len(torch.unique(c)) for c in cell])
+        # (a point on a cell boundary may round differently here and in the kernel: allow a few extra runs)
+        assert bool(((changes >= distinct) & (changes <= distinct + 3)).all()), (changes, distinct)
+        flags = _lib.FPS_TIE_TREE512 | _lib.FPS_SKIP_NEAR_ORIGIN
+        idx = torch.zeros(B, m, dtype=torch.int32, device=DEV)
+        scratch = torch.empty(B, N, 4, device=DEV) if N > 20480 else None
+        _lib.check(_lib.lib().gb_fps_pruned(_lib.ptr(dev), _lib.ptr(perm), None, _lib.ptr(idx), B, N, m, flags,
+                                            _lib.ptr(scratch), None), "gb_fps_pruned")
+        torch.cuda.synchronize()
+        assert torch.equal(idx.cpu(), orc.furthest_point_sampling(xyz, m, flags))

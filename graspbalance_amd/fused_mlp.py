@@ -97,6 +97,11 @@ def _zeros64(n, dev):
     return torch.zeros(n, dtype=torch.float64, device=dev)
 
 
+def _size_args(args):
+    """The integer SIZE arguments of a launch (tensor addresses are plain ints too: they are far above 2^40)."""
+    return tuple(a for a in args if isinstance(a, int) and not isinstance(a, bool) and -(1 << 40) < a < (1 << 40))
+
+
 def _call(name, dev, *args, meta=None):
     """One C-ABI launch.  Fast path (no timer, tensor on the current device): a cached ctypes function and nothing
     else - this runs ~600 times per train step, and the host has to stay ahead of the GPU."""
@@ -112,12 +117,12 @@ def _call(name, dev, *args, meta=None):
                 _lib.check(rc, name)
             return
         if meta is None:
-            meta = {"ints": tuple(a for a in args if isinstance(a, int))}  # sizes, for tools/kernel_breakdown.py
+            meta = {"ints": _size_args(args)}  # sizes, for tools/kernel_breakdown.py
         _lib.check(_lib.timed(name, dev, meta, lambda: fn(*args)), name)
         return
     with torch.cuda.device(dev):
         if meta is None and wanted:
-            meta = {"ints": tuple(a for a in args if isinstance(a, int))}
+            meta = {"ints": _size_args(args)}
         _lib.check(_lib.timed(name, dev, meta, lambda: fn(*args)), name)
 
 

@@ -166,3 +166,31 @@ def test_obs_eval_forward():
     assert bool((torch.gather(seg.to(DEV), 1, inds) != 0).all())
     assert out['grasp_score_pred'].shape[0] == 2 and bool(torch.isfinite(out['grasp_score_pred']).all())
     assert len(pred_decode(out)) == 2
+
+
+def test_flat_adam_gpu_follows_torch_fused_adam():
+    """FlatAdam's CUDA path (torch's fused Adam kernel on one flat buffer) == torch.optim.Adam(fused=True) per tensor,
+    under the OneCycleLR schedule (lr and beta1 change every step)."""
+    from torch.optim.lr_scheduler import OneCycleLR
+    from graspbalance_amd.flat_adam import FlatAdam
+    from tests.test_flat_adam_cpu import _net
+
+    def run(make_opt):
+        net = _net(0).to(DEV)
+        opt = make_opt(net.parameters())
+        sched = OneCycleLR(opt, max_lr=1e-2, steps_per_epoch=4, epochs=3)
+        torch.manual_seed(1)
+        for _ in range(9):
+            x = torch.randn(9, 7, device=DEV)
+            for p in net.parameters():
+                p.grad = None
+            net(x).square().mean().backward()
+            opt.step()
+            sched.step()
+        return net, opt
+
+    a, _ = run(lambda ps: torch.optim.Adam(ps, lr=1e-2, fused=True))
+    b, opt = run(lambda ps: FlatAdam(ps, lr=1e-2))
+    assert opt._fused
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.allclose(pa, pb, rtol=1e-6, atol=1e-8)

@@ -1,4 +1,4 @@
-"""configs[4]-style smoke: B clouds of 50 000 points through one full train step (FPS falls to the streaming kernel,
+"""configs[4]-style smoke: B clouds of 50 000 points through one full train step (the first-level FPS takes fps_pruned_big_kernel,
 everything else as in the bench); prints the step time.  Not a bench line."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,4 +14,4 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(3):
     loss = tr.train_step(batch)
 torch.cuda.synchronize()
-print("B=%d N=%d: %.1f ms/step, loss %.4f, finite=%s, peak mem %.1f GB" % (B, N, (time.perf_counter() - t0) / 3 * 1e3, float(loss), bool(torch.isfinite(loss)), torch.cuda.max_memory_allocated() / 1e9))
+print("B=%d N=%d: %.1f ms/step, loss %.4f, finite=%s, peak mem %.1f GB" % (B, N, (time.perf_counter() - t0) / 3 * 1e3, float(loss.detach()), bool(torch.isfinite(loss)), torch.cuda.max_memory_allocated() / 1e9))

@@ -191,7 +191,7 @@ def event_pair_overhead_ms(device, pairs=64):
     return ms[len(ms) // 2]
 
 
-FPS_PRUNE_MIN_N, FPS_PRUNE_MAX_N, FPS_PRUNE_MIN_M = 8192, 65536, 128
+FPS_PRUNE_MIN_N, FPS_PRUNE_MAX_N, FPS_PRUNE_MIN_M = 8192, 64512, 128  # gb_fps_pruned: n <= 1024 * 63 rows of 64
 _fps_prune = os.environ.get("GB_FPS_PRUNE", "1") != "0"  # A/B switch
 _fps_cell_order = os.environ.get("GB_FPS_CELL_ORDER", "1") != "0"  # A/B switch: visiting order by counting sort
 FPS_PREFIX_MAX_N = 4096

@@ -31,24 +31,34 @@ _ALIASES = {
 }
 
 
+def _knn_package():
+    """``from KNN import _C`` (KNN/knn_modules.py:6) and ``import KNN._C``: ``_C.knn(ref, query, idx)``."""
+    import types
+    from . import knn_modules
+    pkg = types.ModuleType("KNN")
+    pkg.__path__ = []  # a package, so that ``import KNN._C`` resolves through sys.modules
+    ext = types.ModuleType("KNN._C")
+    ext.knn = lambda ref, query, idx: knn_modules.knn(ref, query, idx)  # late-bound: follows knn_modules.knn
+    pkg._C = ext
+    return {"KNN": pkg, "KNN._C": ext}
+
+
 def install(names=None, override=False):
     """Register the aliases (all, or the given subset).  Existing entries are kept unless ``override``."""
     done = []
-    for alias, target in _ALIASES.items():
+    targets = {alias: (lambda t=target: importlib.import_module(t)) for alias, target in _ALIASES.items()}
+    knn = None
+    for alias in ("KNN", "KNN._C"):
+        targets[alias] = None
+    for alias, load in targets.items():
         if names is not None and alias not in names:
             continue
         if alias in sys.modules and not override:
             continue
-        sys.modules[alias] = importlib.import_module(target)
+        if load is None:
+            knn = knn or _knn_package()
+            sys.modules[alias] = knn[alias]
+        else:
+            sys.modules[alias] = load()
         done.append(alias)
     return done
-
-
-class _KNNPackage:
-    """``from KNN import _C`` (KNN/knn_modules.py:6): ``_C.knn(ref, query, idx)``."""
-
-    class _C:
-        @staticmethod
-        def knn(ref, query, idx):
-            from . import knn_modules
-            return knn_modules.knn(ref, query, idx)

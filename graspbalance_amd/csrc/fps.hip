@@ -804,12 +804,8 @@ extern "C" int gb_fps_cell_order(const float *xyz, int32_t *perm, int b, int n, 
   if (b < 0 || n < 1 || !xyz || !perm) return GB_EINVAL;
   if ((long long)n * 3 > 0x7fffffffLL) return GB_ERANGE;
   if (b == 0) return GB_OK;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fps_cell_order_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, CO_BINS * (int)sizeof(int));
-    attr = true;
-  }
+  static std::atomic<unsigned long long> attr{0};
+  allow_dynamic_lds(fps_cell_order_kernel, CO_BINS * (int)sizeof(int), attr);
   hipLaunchKernelGGL(fps_cell_order_kernel, dim3(b), dim3(1024), CO_BINS * sizeof(int), as_stream(stream), xyz, perm, n);
   return check_launch("gb_fps_cell_order");
 }
@@ -834,12 +830,8 @@ extern "C" int gb_fps_pruned(const float *xyz, const int32_t *perm, float *temp,
   const int p_need = ceil_div(n, 1024);
 #define GB_PR(PV)                                                                                              \
   if (p_need <= PV) {                                                                                          \
-    static bool attr = false;                                                                                  \
-    if (!attr) {                                                                                               \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fps_pruned_kernel<1024, PV>),                   \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * PV * 4);                    \
-      attr = true;                                                                                             \
-    }                                                                                                          \
+    static std::atomic<unsigned long long> attr{0};                                                            \
+    allow_dynamic_lds(fps_pruned_kernel<1024, PV>, 1024 * PV * 4, attr);                                       \
     hipLaunchKernelGGL((fps_pruned_kernel<1024, PV>), dim3(b), dim3(1024), 1024 * PV * sizeof(unsigned), s, xyz, perm, \
                        temp, idx, n, m, skip, bs_log2);                                                        \
     return check_launch("gb_fps_pruned");                                                                      \

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/graspbal.h"
 
 namespace gb {
@@ -21,6 +23,19 @@ inline int check_launch(const char *what) {
 }
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: set it once on every device a kernel is
+// launched on (`done` = one bit per device ordinal, a function-local static of the caller).  Two threads racing on
+// the first launch both set it - harmless, the call is idempotent - and the bit is published after the attribute.
+template <typename K>
+inline void allow_dynamic_lds(K kern, int bytes, std::atomic<unsigned long long> &done) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  done.fetch_or(bit, std::memory_order_release);
+}
 
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 

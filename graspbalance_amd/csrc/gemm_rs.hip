@@ -383,12 +383,9 @@ static bool rs_enabled() {
 
 template <int NT, int EPI>
 static void rs_launch(const RsArgs &g, size_t lds_bytes, int blocks_per_cu, hipStream_t s) {
-  static bool attr_set = false;
+  static std::atomic<unsigned long long> attr_set{0};
   auto kern = gemm_rs_kernel<NT, EPI>;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  allow_dynamic_lds(kern, 160 * 1024, attr_set);
   const long long ntiles = (g.P + 31) / 32;
   long long blocks = ntiles;  // at least one tile per workgroup; all 512 threads stage B either way
   const long long cap = (long long)num_cus() * blocks_per_cu;
@@ -437,7 +434,11 @@ bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, dou
               tail_split};
   const int bpc = (nt <= 2 && epi != RS_BNBWD && epi != RS_BNBWD_X && lds_bytes <= 78 * 1024) ? 2 : 1;
   if (epi == RS_BNBWD_X) {
-    rs_launch<2, RS_BNBWD_X>(g, lds_bytes, bpc, s);
+    // the closing per-column reduction reuses the LDS of B as [waves][5][64] doubles = 20 KB: more than the B image of
+    // a reduction of <= 64 (16 KB).  (Round 1 launched with the B size only: for a 64 -> 64 second layer - SA1's
+    // 3 -> 64 -> 64 -> 128 stack - the tail of that array lay outside the allocation and the five sums were wrong.)
+    const size_t red_bytes = (size_t)RS_WAVES * 5 * 2 * 32 * sizeof(double);
+    rs_launch<2, RS_BNBWD_X>(g, lds_bytes > red_bytes ? lds_bytes : red_bytes, bpc, s);
     return true;
   }
 #define GB_RS(NT_)                                                         \

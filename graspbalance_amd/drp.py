@@ -92,6 +92,7 @@ class InvResMLP(nn.Module):
             want = 3 if with_act else 2
             return (len(mods) == want and isinstance(mods[0], (nn.Conv1d, nn.Conv2d)) and mods[0].bias is None
                     and isinstance(mods[1], (nn.BatchNorm1d, nn.BatchNorm2d))
+                    and not (mods[1].momentum is None and mods[1].track_running_stats)
                     and (not with_act or isinstance(mods[2], nn.ReLU)))
         return (la.feature_type == 'dp_fj' and la.reduction == 'max' and isinstance(g, QueryAndGroup)
                 and g.relative_xyz and not g.normalize_dp and not g.return_only_idx

@@ -291,6 +291,10 @@ class _LayerCfg:
 
     def __init__(self, bn):
         self.running_mean, self.running_var = bn.running_mean, bn.running_var
+        if bn.momentum is None and bn.track_running_stats:
+            # torch's cumulative moving average (factor 1 / num_batches_tracked) is not built into gb_bn_finalize;
+            # supports() / InvResMLP.fusable() route such layers to the plain composition instead
+            raise NotImplementedError("fused BatchNorm path needs a numeric momentum (momentum=None = cumulative average)")
         self.momentum = 0.0 if bn.momentum is None else float(bn.momentum)
         self.eps = float(bn.eps)
         self.training = bool(bn.training or not bn.track_running_stats)
@@ -785,4 +789,7 @@ def supports(shared_mlp):
             return False
         if not isinstance(layer.activation, torch.nn.ReLU):
             return False
+        bn = getattr(layer.bn, "bn", layer.bn)
+        if bn.momentum is None and bn.track_running_stats:
+            return False  # cumulative-average running statistics: plain composition
     return True

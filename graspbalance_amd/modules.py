@@ -110,6 +110,11 @@ class GraspableDetection(nn.Module):
         self.bn1 = nn.BatchNorm1d(self.in_dim)
         self.bn2 = nn.BatchNorm1d(2 + self.num_view)
 
+    @staticmethod
+    def _top_view(view_score):
+        """(scores, indices) of every seed's best approach view (modules.py:74: torch.max over the views)."""
+        return torch.max(view_score, dim=2)
+
     def forward(self, seed_xyz, seed_features, end_points, record=True):
         B, num_seed, _ = seed_xyz.size()
         features = F.relu(self.bn1(self.conv1(seed_features)), inplace=True)
@@ -120,7 +125,7 @@ class GraspableDetection(nn.Module):
         view_score = features[:, 2:2 + self.num_view, :].transpose(1, 2).contiguous()
         end_points['objectness_score'] = features[:, :2, :]
         end_points['view_score'] = view_score
-        top_view_scores, top_view_inds = torch.max(view_score, dim=2)
+        top_view_scores, top_view_inds = self._top_view(view_score)
         template_views = grasp_views_on(features.device, self.num_view)  # (V,3)
         vp_xyz = template_views[top_view_inds]  # (B,num_seed,3) == gather of the expanded templates
         batch_angle = torch.zeros(B * num_seed, dtype=vp_xyz.dtype, device=vp_xyz.device)

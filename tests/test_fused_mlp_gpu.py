@@ -3,7 +3,9 @@ composition the reference uses (grouping -> cat -> Conv2d -> BatchNorm2d -> ReLU
 parameters, same inputs: forward values, running statistics and every gradient.
 
 Tolerance: 1e-5 of the tensor's scale for forward values (fp32, different summation order in the BN
-statistics), 1e-4 for gradients.
+statistics), 1e-4 for gradients.  Stacked blocks and whole networks (where ReLU / max-pool routing flips make a
+fused-vs-plain comparison meaningless beyond a few layers) are judged against an fp64 run of the plain composition in
+tests/test_parity_f64_gpu.py.
 """
 import copy
 
@@ -94,27 +96,6 @@ def test_grouped_xyz_bits_match_torch_division():
         assert torch.equal(got.view(1, 256, 16, 8).permute(0, 3, 1, 2), want)
 
 
-def test_invresmlp_stage_fused_equals_plain():
-    from graspbalance_amd.drp import InvResMLP, run_stage
-    from graspbalance_amd.scene import make_batch
-    import torch.nn as nn
-    torch.manual_seed(4)
-    blocks = nn.Sequential(*[InvResMLP(in_channels=32, aggr_args={'feature_type': 'dp_fj', "reduction": 'max'},
-                                       norm_args={'norm': 'bn'}, act_args={'act': 'relu'},
-                                       group_args={'NAME': 'ballquery', 'radius': 0.1, 'nsample': 16},
-                                       conv_args={'order': 'conv-norm-act'}, expansion=4, use_res=True)
-                             for _ in range(2)]).to(DEV).train()
-    fused = copy.deepcopy(blocks)
-    p = torch.from_numpy(make_batch([0, 1], 1024)).to(DEV)
-    f0 = torch.randn(2, 32, 1024, device=DEV)
-
-    def call(mod):
-        f = f0.clone().requires_grad_(True)
-        _, out = run_stage(mod, p, f)
-        return out, [f]
-    _run(fused, blocks, call, tol_grad=2e-2, l2=True)  # two stacked blocks: see _close
-
-
 def test_grasp_width_grouping_fused_equals_plain(golden):
     from graspbalance_amd import fused_ops
     from graspbalance_amd.modules import GraspWidthGrouping
@@ -154,79 +135,6 @@ def test_eval_mode_uses_running_statistics():
     _close(a, b, 1e-5, "eval forward")
     for k, v in sa.named_buffers():
         assert torch.equal(v, before[k]), "eval must not touch " + k
-
-
-def test_whole_network_train_step_fused_equals_plain():
-    from tests.test_model_cpu import _tiny_net
-    from graspbalance_amd import fused_mlp
-    from graspbalance_amd.loss import get_loss
-    from graspbalance_amd.synthetic import make_training_batch
-    batch = make_training_batch(range(2), num_point=3000, num_objects=2, grasp_points_per_object=20, num_view=30,
-                                device=DEV)
-    results = {}
-    for flag in (True, False):
-        net = _tiny_net().to(DEV).train()
-        fused_mlp.set_enabled(flag)
-        try:
-            loss, ep = get_loss(net(dict(batch)))
-            loss.backward()
-        finally:
-            fused_mlp.set_enabled(True)
-        results[flag] = (float(loss), {k: v.grad.clone() for k, v in net.named_parameters()},
-                         ep['grasp_score_pred'].detach().clone(), ep['fp2_features'].detach().clone())
-    # the top-view arg-max (which picks labels and cylinder rotations) can flip on 1e-6 score differences
-    assert abs(results[True][0] - results[False][0]) < 1e-3 * max(1.0, abs(results[False][0]))
-    # 19 stacked BN/max-pool blocks: a different (equally exact) GEMM summation order flips a few
-    # max/ReLU routes, so whole-network tensors are compared in the L2 sense; the per-module tests
-    # above hold 1e-5 / 1e-4 element-wise
-    _close(results[True][3], results[False][3], 2e-2, "fp2_features", l2=True)
-    # seeds whose top-view arg-max flips get a different cylinder rotation and label, i.e. an unrelated
-    # score row: a sanity bound only (the loss above is the tight end-to-end check)
-    _close(results[True][2], results[False][2], 0.25, "grasp_score_pred", l2=True)
-    num = sum(float((results[True][1][k] - results[False][1][k]).norm()) ** 2 for k in results[False][1]) ** 0.5
-    den = sum(float(results[False][1][k].norm()) ** 2 for k in results[False][1]) ** 0.5
-    # the per-module tests above hold 1e-4 on every gradient; here a flipped top-view arg-max swaps a
-    # seed's label rows (an unrelated loss term), so only gross breakage is caught
-    assert num / den < 0.6, num / den
-
-
-def test_drp_backbone_fused_equals_plain():
-    """Whole DRP backbone (4 SA levels, 15 InvResMLP blocks at toy sizes, 2 FP levels), fixed random
-    projection as loss: no label arg-max in the loop, so fused and plain gradients must agree closely."""
-    from tests.test_model_cpu import _tiny_net
-    from graspbalance_amd import fused_mlp
-    from graspbalance_amd.scene import make_batch
-    clouds = torch.from_numpy(make_batch([0, 1], 3000)).to(DEV)
-
-    def run(flag, perturb=0.0):
-        drp = _tiny_net().view_estimator.FeatureExtraction.to(DEV).train()
-        if perturb:
-            torch.manual_seed(123)
-            with torch.no_grad():
-                for p in drp.parameters():
-                    p.mul_(1.0 + perturb * torch.randn_like(p))
-        fused_mlp.set_enabled(flag)
-        try:
-            feats, _, _ = drp(clouds)
-            torch.manual_seed(7)
-            (feats * torch.randn_like(feats)).sum().backward()
-        finally:
-            fused_mlp.set_enabled(True)
-        return feats.detach().clone(), {k: v.grad.clone() for k, v in drp.named_parameters()}
-
-    def gap(a, b):
-        num = sum(float((a[1][k] - b[1][k]).norm()) ** 2 for k in b[1]) ** 0.5
-        den = sum(float(b[1][k].norm()) ** 2 for k in b[1]) ** 0.5
-        return float((a[0] - b[0]).norm() / b[0].norm()), num / den
-
-    plain = run(False)
-    # 19 stacked train-mode BatchNorm + max/ReLU blocks on a toy batch are chaotic: ONE ULP (1e-7) on the
-    # weights of the plain path already moves features by ~1e-2 and gradients by tens of percent
-    # (tools/chaos_check.py).  The fused path must sit inside that one-ulp baseline.
-    base_feat, base_grad = gap(run(False, 1e-7), plain)
-    fused_feat, fused_grad = gap(run(True), plain)
-    assert fused_feat < 2.0 * base_feat + 1e-4, (fused_feat, base_feat)
-    assert fused_grad < 1.5 * base_grad + 1e-3, (fused_grad, base_grad)
 
 
 @pytest.mark.parametrize("C,ns,train", [(32, 16, True), (64, 24, True), (32, 16, False)])
@@ -271,16 +179,20 @@ def test_local_aggregation_without_grouped_tensor(C, ns, train):
         _close(a[3][k], b[3][k], 1e-5, "buffer " + k)
 
 
+@pytest.mark.parametrize("widths", [(64, 128), (64, 64, 128), (64, 128, 256)])
 @pytest.mark.parametrize("train", [True, False])
-def test_first_layer_closed_form_backward(train):
-    """xyz-only stacks (3 -> 64 -> 128 [-> max]): the backward that never writes the first layer's dZ
-    (gb_gemm_dgrad_first + moments + closed-form dW) against the layer-by-layer backward."""
+def test_first_layer_closed_form_backward(train, widths):
+    """xyz-only stacks (3 -> 64 -> ... [-> max]): the backward that never writes the first layer's dZ
+    (gb_gemm_dgrad_first + moments + closed-form dW) against the layer-by-layer backward.  (64, 64, 128) is SA1's
+    stack: its 64 -> 64 second layer is the shape whose closing LDS reduction once overran the allocation.)"""
     import torch.nn as nn
     from graspbalance_amd import fused_mlp
     torch.manual_seed(3)
     P, ns = 32768 + 64, 64
-    convs = [nn.Conv2d(3, 64, 1, bias=False), nn.Conv2d(64, 128, 1, bias=False)]
-    bns = [nn.BatchNorm2d(64), nn.BatchNorm2d(128)]
+    chans = (3,) + tuple(widths)
+    L = len(widths)
+    convs = [nn.Conv2d(a, b, 1, bias=False) for a, b in zip(chans[:-1], chans[1:])]
+    bns = [nn.BatchNorm2d(b) for b in widths]
     mods = nn.ModuleList(convs + bns).to(DEV)
     with torch.no_grad():
         for bn in bns:
@@ -295,7 +207,7 @@ def test_first_layer_closed_form_backward(train):
         fused_mlp._FIRST_FUSE = flag
         try:
             m = copy.deepcopy(mods)
-            out = fused_mlp.conv_bn_act_chain(X0, [(m[0], m[2]), (m[1], m[3])], pool_ns=ns)
+            out = fused_mlp.conv_bn_act_chain(X0, [(m[i], m[L + i]) for i in range(L)], pool_ns=ns)
             torch.manual_seed(8)
             (out * torch.randn_like(out)).sum().backward()
             res[flag] = (out.detach(), {k: v.grad.clone() for k, v in m.named_parameters()})

@@ -1,5 +1,5 @@
 """GPU: the whole network on the HIP path against the same network on the CPU oracle path (same
-weights, same inputs): indices bit-exact, head outputs within 1e-4 (fp32 conv/BN on different BLAS
+weights, same inputs): indices bit-exact, head outputs within 1e-5 (fp32 conv/BN on different BLAS
 back ends; the geometry feeding them is bit-identical)."""
 import pytest
 import torch
@@ -9,27 +9,36 @@ DEV = "cuda:0"
 
 
 def _nets():
+    from tests.seeded import fill_by_key
     from tests.test_model_cpu import _tiny_net
-    cpu_net = _tiny_net(training=False)
+    cpu_net = fill_by_key(_tiny_net(training=False), seed=2)  # by-key weights incl. non-trivial running statistics
     gpu_net = _tiny_net(training=False)
     gpu_net.load_state_dict(cpu_net.state_dict())
     return cpu_net.eval(), gpu_net.to(DEV).eval()
 
 
 def test_eval_forward_matches_cpu_oracle_path(monkeypatch):
+    """Toy-size eval forward, HIP path vs CPU oracle path: indices identical, every output within 1e-5 with the
+    top-view arg-max frozen to the CPU path's picks (the free arg-max may differ only at near-ties).  The full-size
+    version with an fp64 truth is tests/test_parity_f64_gpu.py."""
     from tests.test_model_cpu import _tiny_batch
     from tests import cpu_backend
     cpu_net, gpu_net = _nets()
     clouds = _tiny_batch(B=2, N=3000)['point_clouds']
-    with torch.no_grad():
-        got = gpu_net({'point_clouds': clouds.to(DEV)})
-        got_sep = None
-        gpu_net.grasp_generator.fused_cylinder = False
-        got_sep = gpu_net({'point_clouds': clouds.to(DEV)})
     with monkeypatch.context() as mp:
         cpu_backend.install(mp)
         with torch.no_grad():
             want = cpu_net({'point_clouds': clouds})
+    views = want['grasp_top_view_inds']
+    with torch.no_grad():
+        free = gpu_net({'point_clouds': clouds.to(DEV)})
+    assert int((free['grasp_top_view_inds'].cpu() != views).sum()) <= 2
+    gpu_net.view_estimator.GraspableClasification._top_view = \
+        lambda vs: (torch.gather(vs, 2, views.to(DEV).unsqueeze(-1)).squeeze(-1), views.to(DEV))
+    with torch.no_grad():
+        got = gpu_net({'point_clouds': clouds.to(DEV)})
+        gpu_net.grasp_generator.fused_cylinder = False
+        got_sep = gpu_net({'point_clouds': clouds.to(DEV)})
     for k in ('sa1_inds', 'sa2_inds', 'fp2_inds', 'grasp_top_view_inds'):
         assert torch.equal(got[k].cpu(), want[k]), k
     for k in ('sa1_xyz', 'sa4_xyz', 'fp2_xyz'):
@@ -37,11 +46,11 @@ def test_eval_forward_matches_cpu_oracle_path(monkeypatch):
     for k in ('fp2_features', 'objectness_score', 'view_score', 'grasp_score_pred', 'grasp_angle_cls_pred',
               'grasp_width_pred', 'grasp_tolerance_pred'):
         err = float((got[k].cpu() - want[k]).norm() / (want[k].norm() + 1e-12))
-        assert err < 1e-3, (k, err)
+        assert err < 1e-5, (k, err)
         # 16 separate cylinder queries (unfused head) vs the fused query + channel-last MLP: same indices
         # (test_cylinder_query_multi_equals_16_single_queries), values equal to fp32 rounding
         err = float((got[k] - got_sep[k]).norm() / (got_sep[k].norm() + 1e-12))
-        assert err < 1e-3, (k, err)
+        assert err < 1e-5, (k, err)
 
 
 def test_train_step_runs_and_updates(monkeypatch):

@@ -3,7 +3,7 @@
 20 000-point GraspNet-like scenes, B = 4 clouds per GPU — BASELINE.json configs[3] (the configuration
 the metric "fwd+bwd ... 1/2/4/8 MI355X" is quoted on; it fits one GPU).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1: spawns its own N ranks (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -13,42 +13,85 @@ loss -> backward -> flat-bucket RCCL all-reduce -> Adam -> LR step, on a batch a
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # before anything initialises HIP: dmabuf IPC for RCCL
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch
-import torch.distributed as dist
-
 BATCH_PER_GPU = 4
 NUM_POINT = 20000
 HBM_PEAK_GBS = 8000.0
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+# vector ALU: 256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz = 78.6e12 lane-instructions/s (the 157.3 TFLOP/s vector
+# figure counts an FMA as two; the geometry kernels are built -ffp-contract=off, one rounding per operation)
+VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+# lane-instructions per scanned (centre, candidate) pair, from the kernels' arithmetic:
+BALL_OPS_PER_PAIR = 9        # 3 sub, 3 mul, 2 add, 1 compare
+CYL16_OPS_PER_PAIR = 30      # 3 sub, 9 mul + 6 add (rotate), 2 mul + 1 add (radial), 4 + 4 + 1 compares (4 radii x 4 hmax, hmin)
+
+
+def _spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh worker processes (one per GPU) through
+    torch.distributed.run BEFORE this process touches the GPU, relay rank 0's JSON line, exit with the job's code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    return subprocess.call(cmd, env=env)
 
 
 def fps_algorithmic_bytes(b, n, m):
-    """SURVEY.md §8d streaming model: 12 B xyz + 4 B read + 4 B write of the running min-distance per
+    """SURVEY.md section 8d streaming model: 12 B xyz + 4 B read + 4 B write of the running min-distance per
     point per iteration, plus the index output."""
     return b * (20.0 * n * (m - 1) + 4.0 * m)
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json: separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 corrections applied);
-    None when the file is absent.  Counters cannot be collected from inside this process."""
+    """HBM bytes per launch from the committed PMC passes (profiles/*_pmc_traffic.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 corrections applied; the newest
+    round that has the kernel wins); None when absent.  Counters cannot be collected from inside this process."""
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return round(json.load(f)[kernel]["hbm_bytes_per_launch"], 1)
+        except Exception:
+            continue
+    return None
+
+
+def _cpu_model():
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            return round(json.load(f)[kernel]["hbm_bytes_per_launch"], 1)
-    except Exception:
-        return None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
-def cpu_baseline(num_threads):
-    """The same train step on the host cores, with the CPU oracle (oracle/graspbal_oracle.c) standing
-    in for the HIP extension and torch-CPU for the MLPs: a bounded sample of ONE step on ONE cloud."""
+def _median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
+
+
+def cpu_baseline(num_threads, device, repeats=5):
+    """SURVEY.md section 8d leg (ii), the graded ``cpu_baseline``: the SAME train step (forward incl. label matching,
+    loss, backward, Adam) on the host cores, with the C oracle (oracle/graspbal_oracle.c, OpenMP) standing in for the
+    HIP extension and torch-CPU for the MLPs.  Bounded sample: ONE cloud per step; 1 warm-up + median of `repeats`
+    steps (time.perf_counter).  Before the number counts, the first step's loss is cross-checked against the HIP
+    path's first step from the same seed on the same cloud."""
+    import torch
     from tests import cpu_backend
     from graspbalance_amd.synthetic import make_training_batch
     from graspbalance_amd.train import Trainer
@@ -58,21 +101,90 @@ def cpu_baseline(num_threads):
              (subsample, "pointnet2_cuda", subsample.pointnet2_cuda),
              (upsampling, "pointnet2_cuda", upsampling.pointnet2_cuda), (knn_modules, "knn", knn_modules.knn)]
     torch.set_num_threads(num_threads)
+    gpu_loss = float(Trainer(device).train_step(make_training_batch([0], NUM_POINT, device=device)))
     try:
         cpu_backend.install()
         trainer = Trainer("cpu")
         trainer.net.grasp_generator.fused_cylinder = False  # the reference issues 16 separate queries
-        batch = make_training_batch([0], NUM_POINT, device="cpu")
-        t0 = time.time()
-        loss = trainer.train_step(batch)
-        dt = time.time() - t0
-        assert bool(torch.isfinite(loss))
+        # the label generator is device-specific: build on the GPU's generator, move to the host
+        batch = {k: ([[t.cpu() for t in per] for per in v] if isinstance(v, list) else v.cpu())
+                 for k, v in make_training_batch([0], NUM_POINT, device=device).items()}
+        times, first = [], None
+        for i in range(repeats + 1):
+            t0 = time.perf_counter()
+            loss = trainer.train_step(batch)
+            dt = time.perf_counter() - t0
+            if first is None:
+                first = float(loss)
+            if i:
+                times.append(dt)
+            assert bool(torch.isfinite(loss))
     finally:
         for mod, name, val in saved:
             setattr(mod, name, val)
-    return {"value": 1.0 / dt, "unit": "point-clouds/s", "cores": num_threads, "kind": "port",
-            "sample": "1 train step (fwd+bwd+Adam) on 1 cloud of %d points, oracle C geometry (OpenMP) + torch CPU MLPs, %.1f s"
-                      % (NUM_POINT, dt)}
+    agree = abs(first - gpu_loss) / max(1.0, abs(gpu_loss))
+    assert agree < 5e-3, "CPU and HIP first-step losses disagree: %r vs %r" % (first, gpu_loss)
+    med = _median(times)
+    return {"value": round(1.0 / med, 4), "unit": "point-clouds/s", "cores": num_threads, "kind": "port",
+            "sample": "train step (fwd+bwd+Adam) on 1 cloud of %d points: 1 warm-up + median of %d steps (%.2f s each), "
+                      "oracle C geometry (OpenMP) + torch CPU MLPs" % (NUM_POINT, repeats, med),
+            "cpu_model": _cpu_model(), "os_cpu_count": os.cpu_count(), "torch_threads": torch.get_num_threads(),
+            "first_step_loss": {"cpu": round(first, 6), "hip": round(gpu_loss, 6)}}
+
+
+def cpu_baseline_dense(num_threads, device, repeats=5):
+    """SURVEY.md section 8d leg (i): the dense-torch restatement of the reference's CPU fallback algorithm
+    (oracle/dense_torch.py: distance matrix + sort, whole-tensor FPS) on BASELINE configs[1] - one SA layer
+    (npoint 1024, r 0.04, ns 32, MLP [3,64,128]) forward on a 20 000-point cloud - next to the HIP path on the same
+    cloud.  Outputs are cross-checked (FPS and ball-query indices identical, features to 1e-4) before timing:
+    1 warm-up + median of `repeats`."""
+    import torch
+    from graspbalance_amd import pointnet2_modules as pm
+    from graspbalance_amd.scene import make_batch
+    from oracle import dense_torch as dt
+    torch.set_num_threads(num_threads)
+    torch.manual_seed(11)
+    sa = pm.PointnetSAModuleVotes(npoint=1024, radius=0.04, nsample=32, mlp=[0, 64, 128], use_xyz=True,
+                                  normalize_xyz=True).train()
+    weights = [(l.conv.weight.detach().view(l.conv.weight.shape[0], -1).clone(), l.bn.bn.weight.detach().clone(),
+                l.bn.bn.bias.detach().clone()) for l in sa.mlp_module.children()]
+    cloud = torch.from_numpy(make_batch([0], NUM_POINT))
+    sa = sa.to(device)
+    xyz = cloud.to(device)
+    cpu_t, gpu_t = [], []
+    for i in range(repeats + 1):
+        t0 = time.perf_counter()
+        inds, idx, feats = dt.sa_layer_forward(cloud, 1024, 0.04, 32, weights)
+        if i:
+            cpu_t.append(time.perf_counter() - t0)
+    with torch.no_grad():
+        for i in range(repeats + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            new_xyz, got, got_inds = sa(xyz)
+            torch.cuda.synchronize()
+            if i:
+                gpu_t.append(time.perf_counter() - t0)
+    from graspbalance_amd import pointnet2_utils as pu
+    # the module samples with the CUDA kernel's tree tie-break, the fallback algorithm with the lowest index: they
+    # differ only between exact duplicates of a point, so the sampled COORDINATES must agree - and the HIP kernel in
+    # lowest-index mode must reproduce the dense indices themselves
+    want_xyz = torch.gather(cloud, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3))
+    assert torch.equal(new_xyz.cpu(), want_xyz), "FPS samples differ between the HIP path and the dense restatement"
+    from graspbalance_amd import _lib
+    low = torch.empty((1, 1024), dtype=torch.int32, device=device)
+    tmp = torch.full((1, NUM_POINT), 1e10, dtype=torch.float32, device=device)
+    _lib.check(_lib.fps(xyz, tmp, low, 1, NUM_POINT, 1024, _lib.FPS_SKIP_NEAR_ORIGIN | _lib.FPS_TIE_LOWEST,
+                        _lib.current_stream(device)), "fps")
+    assert torch.equal(low.cpu(), inds), "FPS indices (lowest-index ties) differ from the dense restatement"
+    assert torch.equal(pu.ball_query(0.04, 32, xyz, new_xyz).cpu(), idx), "ball-query indices differ"
+    err = float((got.cpu() - feats).norm() / feats.norm())
+    assert err < 1e-4, err
+    c, g = _median(cpu_t), _median(gpu_t)
+    return {"workload": "configs[1]: one SA layer (npoint 1024, r 0.04, ns 32, MLP [3,64,128]) forward, 1 cloud of %d points"
+                        % NUM_POINT, "cpu_value": round(1.0 / c, 3), "hip_value": round(1.0 / g, 1),
+            "unit": "point-clouds/s", "ratio": round(c / g, 1), "cores": num_threads, "kind": "port (dense torch)",
+            "feature_rel_err": err, "sample": "1 warm-up + median of %d (CPU %.3f s, HIP %.2f ms per cloud)" % (repeats, c, g * 1e3)}
 
 
 def main():
@@ -83,11 +195,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(_spawn_ranks(args.gpus, sys.argv[1:]))  # nothing has touched the GPU in this process
+
+    import torch
+    import torch.distributed as dist
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("bench.py --gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, args.gpus))
+        raise SystemExit("bench.py --gpus %d was launched with WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible)")
     torch.cuda.set_device(local_rank)
@@ -95,7 +213,6 @@ def main():
     # GB_FORCE_DIST=1 runs the RCCL path (broadcast, flat-bucket all-reduce, barriers) even with one rank
     use_dist = world > 1 or os.environ.get("GB_FORCE_DIST") == "1"
     if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -105,7 +222,7 @@ def main():
     from graspbalance_amd.train import Trainer
     _lib.lib()  # fail loudly if the HIP library is missing
 
-    trainer = Trainer(device, distributed=use_dist)
+    trainer = Trainer(device, distributed=use_dist, time_collectives=use_dist)
     seeds = [1000 * rank + i for i in range(BATCH_PER_GPU)]
     batch = make_training_batch(seeds, NUM_POINT, device=device)
 
@@ -118,9 +235,12 @@ def main():
     for _ in range(args.warmup):
         trainer.train_step(batch)
     barrier()
-    # ~240 timed launches per step, two events each: created before the timed region, recorded inside it
-    timer = _lib.KernelTimer(["gb_fps", "gb_gemm_fwd", "gb_gemm_fwd_w", "gb_gemm_dgrad", "gb_gemm_dgrad_first",
-                              "gb_gemm_wgrad"], reserve=min(2 * 260 * args.steps, 20000))
+    if use_dist:
+        trainer.grads.exposed_ms()  # drop the warm-up samples
+    # ~250 timed launches per step, two events each: created before the timed region, recorded inside it
+    gemm_names = ["gb_gemm_fwd", "gb_gemm_fwd_w", "gb_gemm_dgrad", "gb_gemm_dgrad_first", "gb_gemm_wgrad"]
+    timer = _lib.KernelTimer(gemm_names + ["gb_fps", "gb_ball_query", "gb_cylinder_query_multi"],
+                             reserve=min(2 * 270 * args.steps, 20000))
     barrier()
     with timer as kt:
         t0 = time.perf_counter()
@@ -129,10 +249,18 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
     assert bool(torch.isfinite(loss)), "training diverged"
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed, 1.0], dtype=torch.float64, device=device)
+    ranks_seen = 1
+    allreduce = None
     if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
+        dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
+        ranks_seen = int(t[1].item())
+        # exposed: what the compute stream waited for inside the timed steps; standalone: the same collectives with
+        # nothing to hide under (after the timed region)
+        allreduce = {"exposed_ms": trainer.grads.exposed_ms(), "standalone_ms": trainer.grads.standalone_ms(),
+                     "buckets": len(trainer.grads.flat), "bytes": 4 * int(trainer.grads.flat_all.numel())}
+    elapsed = float(t[0].item())
 
     if rank == 0:
         clouds = world * BATCH_PER_GPU * args.steps
@@ -143,7 +271,7 @@ def main():
         ev_bias = _lib.event_pair_overhead_ms(device)  # what an empty event bracket reads; removed from every launch
 
         def gemm_roofline(kernel, what):
-            ev = [(max(a.elapsed_time(b) - ev_bias, 1e-4), m["flop"]) for n in ("gb_gemm_fwd", "gb_gemm_fwd_w", "gb_gemm_dgrad", "gb_gemm_dgrad_first", "gb_gemm_wgrad")
+            ev = [(max(a.elapsed_time(b) - ev_bias, 1e-4), m["flop"]) for n in gemm_names
                   for a, b, m in kt.events[n] if m["kernel"] == kernel]
             if not ev:
                 return None
@@ -163,11 +291,13 @@ def main():
         roofline_second = both[1] if len(both) > 1 else None
         # largest single launch of the step: the first-level FPS (HBM class, streaming-model bytes)
         roofline_fps = None
+        fps_ms = 0.0
         big = [(a.elapsed_time(b) - ev_bias, m) for a, b, m in kt.events["gb_fps"] if m["n"] == NUM_POINT]
         if big:
-            mean_ms = sum(x for x, _ in big) / len(big)
+            fps_ms = sum(x for x, _ in big) / len(big)
             meta = big[0][1]
-            achieved = fps_algorithmic_bytes(meta["b"], meta["n"], meta["m"]) / (mean_ms * 1e-3) / 1e9
+            fps_bytes = fps_algorithmic_bytes(meta["b"], meta["n"], meta["m"])
+            achieved = fps_bytes / (fps_ms * 1e-3) / 1e9
             pruned = _lib._fps_prune and _lib.FPS_PRUNE_MIN_N <= meta["n"] <= _lib.FPS_PRUNE_MAX_N
             kname = "fps_pruned_kernel" if pruned else "fps_reg_kernel<1024, 20>"
             order = "cell-order counting sort" if _lib._fps_cell_order else "Morton keys + sort"
@@ -175,7 +305,61 @@ def main():
             roofline_fps = {"kernel": "%s (furthest_point_sampling %d->%d, b=%d)" % (what, meta["n"], meta["m"], meta["b"]),
                             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(kname),
-                            "launch_ms": round(mean_ms, 4), "launches": len(big)}
+                            "launch_ms": round(fps_ms, 4), "launches": len(big)}
+        # first-level ball query and the fused 16-fold cylinder query: neighbour scans over an L2-resident cloud, so the
+        # streaming-byte model says nothing (it exceeds HBM peak); they are priced against the vector ALU instead -
+        # lane-instructions per scanned pair x the scanned pairs the kernels report, over the launch time
+        roofline_ball = roofline_cyl = roofline_fps_ball = None
+        ball = [(a.elapsed_time(b) - ev_bias, m) for a, b, m in kt.events["gb_ball_query"] if m["n"] == NUM_POINT]
+        if ball:
+            ball_ms = sum(x for x, _ in ball) / len(ball)
+            m = ball[-1][1]
+            new_xyz, xyz = m["args"]
+            idx = torch.empty((m["b"], m["m"], m["ns"]), dtype=torch.int32, device=device)
+            scanned = torch.empty((m["b"], m["m"]), dtype=torch.int32, device=device)
+            _lib.check(_lib.lib().gb_ball_query(_lib.ptr(new_xyz), _lib.ptr(xyz), _lib.ptr(idx), _lib.ptr(scanned), m["b"],
+                                                m["n"], m["m"], m["radius"], m["ns"], _lib.current_stream(device)), "ball")
+            pairs = float(scanned.double().sum())
+            ach = pairs * BALL_OPS_PER_PAIR / (ball_ms * 1e-3) / 1e12
+            ball_bytes = 12.0 * pairs + 12.0 * m["b"] * m["m"] + 4.0 * m["b"] * m["m"] * m["ns"]
+            roofline_ball = {"kernel": "ball_query_kernel (first level: %d centres x %d points, ns=%d, b=%d)"
+                                       % (m["m"], m["n"], m["ns"], m["b"]), "bound": "valu",
+                             "achieved": round(ach, 2), "peak": round(VALU_PEAK_TLANEOPS, 1), "unit": "T lane-ops/s",
+                             "frac": round(ach / VALU_PEAK_TLANEOPS, 4), "scanned_pairs": pairs,
+                             "scanned_frac_of_full": round(pairs / (m["b"] * m["m"] * float(m["n"])), 4),
+                             "gpairs_per_s": round(pairs / (ball_ms * 1e-3) / 1e9, 1), "launch_ms": round(ball_ms, 4),
+                             "launches": len(ball), "streaming_model_gbs": round(ball_bytes / (ball_ms * 1e-3) / 1e9, 1)}
+            if roofline_fps:
+                # north_star's "FPS + ball-query" figure: both first-level launches together, streaming-model bytes
+                tot_ms = fps_ms + ball_ms
+                ach = (fps_bytes + ball_bytes) / (tot_ms * 1e-3) / 1e9
+                roofline_fps_ball = {"kernel": "first-level FPS + ball query together", "bound": "hbm",
+                                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": round(ach / HBM_PEAK_GBS, 4), "launch_ms": round(tot_ms, 4)}
+        cyl = [(a.elapsed_time(b) - ev_bias, m) for a, b, m in kt.events["gb_cylinder_query_multi"]]
+        if cyl:
+            cyl_ms = sum(x for x, _ in cyl) / len(cyl)
+            m = cyl[-1][1]
+            new_xyz, xyz, rot9 = m["args"]
+            # the fused kernel scans a centre until the slowest of its 16 lists is full: max of the 16 single counts
+            worst = torch.zeros((m["b"], m["m"]), dtype=torch.int32, device=device)
+            idx = torch.empty((m["b"], m["m"], m["ns"]), dtype=torch.int32, device=device)
+            scanned = torch.empty((m["b"], m["m"]), dtype=torch.int32, device=device)
+            for r in m["radii"]:
+                for h in m["hmaxs"]:
+                    _lib.check(_lib.lib().gb_cylinder_query(_lib.ptr(new_xyz), _lib.ptr(xyz), _lib.ptr(rot9), _lib.ptr(idx),
+                                                            _lib.ptr(scanned), m["b"], m["n"], m["m"], r, m["hmin"], h,
+                                                            m["ns"], _lib.current_stream(device)), "cyl")
+                    worst = torch.maximum(worst, scanned)
+            pairs = float(worst.double().sum())
+            ach = pairs * CYL16_OPS_PER_PAIR / (cyl_ms * 1e-3) / 1e12
+            roofline_cyl = {"kernel": "cylinder_query_kernel<4,4> (16 queries fused: %d seeds x %d points, ns=%d, b=%d)"
+                                      % (m["m"], m["n"], m["ns"], m["b"]), "bound": "valu", "achieved": round(ach, 2),
+                            "peak": round(VALU_PEAK_TLANEOPS, 1), "unit": "T lane-ops/s",
+                            "frac": round(ach / VALU_PEAK_TLANEOPS, 4), "scanned_pairs": pairs,
+                            "scanned_frac_of_full": round(pairs / (m["b"] * m["m"] * float(m["n"])), 4),
+                            "gpairs_per_s": round(pairs / (cyl_ms * 1e-3) / 1e9, 1), "launch_ms": round(cyl_ms, 4),
+                            "launches": len(cyl)}
         out = {
             "metric": "point-clouds/sec fwd+bwd, 20k-pt GraspNet scene",
             "value": round(clouds / elapsed, 3), "unit": "point-clouds/s", "n_gpus": world,
@@ -189,9 +373,22 @@ def main():
             "roofline_gemm2": roofline_second,
             "event_bias_us": round(ev_bias * 1e3, 2),
             "roofline_fps": roofline_fps,
+            "roofline_ball": roofline_ball,
+            "roofline_fps_ball": roofline_fps_ball,
+            "roofline_cyl": roofline_cyl,
+            "ranks_seen": ranks_seen,
         }
+        if allreduce:
+            out["allreduce_ms"] = round(allreduce["standalone_ms"], 4)
+            out["allreduce_exposed_ms"] = round(allreduce["exposed_ms"], 4)
+            out["allreduce"] = {"buckets": allreduce["buckets"], "bytes": allreduce["bytes"],
+                                "note": "allreduce_ms = the step's bucket all-reduces back to back with nothing to hide "
+                                        "under (median of 5 after the timed region); allreduce_exposed_ms = mean time per "
+                                        "timed step the compute stream waited for them (HIP events around the waits)"}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 32))
+            threads = min(os.cpu_count() or 1, 32)
+            out["cpu_baseline"] = cpu_baseline(threads, device)
+            out["cpu_baseline_dense"] = cpu_baseline_dense(threads, device)
         print(json.dumps(out))
     if use_dist:
         dist.barrier()

@@ -23,50 +23,67 @@ def shard_batch(batch, rank, world_size):
 
 
 class FlatGradAllReduce:
-    """All-reduces the whole gradient as a handful of contiguous fp32 buckets (sum, then divide by world
-    size), overlapped with backward.  Buckets follow reverse registration order (the order backward produces
-    gradients in), so bucket 0 is complete first.
+    """All-reduces the whole gradient as a handful of contiguous slices of ONE flat fp32 buffer (mean over the
+    ranks), overlapped with backward.
 
-    Gradients are NOT accumulated into the buckets: ``zero_grad()`` sets every ``.grad`` to None so autograd just
+    The flat buffer holds the parameters' gradients in registration order - it is the optimizer's own gradient
+    buffer when ``flat`` is given (flat_adam.FlatAdam: the reduced gradient is then already where the update reads
+    it, no second copy).  A bucket is a contiguous run of parameters taken from the END of that order (backward
+    produces gradients roughly in reverse registration order), so bucket 0 is complete first.
+
+    Gradients are NOT accumulated into the buffer: ``zero_grad()`` sets every ``.grad`` to None so autograd just
     hands each parameter its freshly computed gradient (no per-parameter add kernel).  A post-accumulate hook per
     parameter counts arrivals; as soon as a bucket is complete (and every earlier bucket has been issued - all
     ranks must issue collectives in the same order) its gradients are packed with one multi-tensor copy and its
     all-reduce is launched asynchronously, so it runs on RCCL's stream under the rest of backward.  ``reduce()``
-    after backward issues whatever is left (buckets holding parameters the graph did not reach), waits, divides and
-    points ``.grad`` at the bucket views.  Single process: everything is a no-op."""
+    after backward issues whatever is left (a bucket holding a parameter the graph did not reach - and every bucket
+    after it - waits until here: every GraspBalance parameter is reached in every step), waits, averages and points
+    ``.grad`` at the buffer views.  Single process: everything is a no-op.
 
-    def __init__(self, module, bucket_mb=16.0, process_group=None, overlap=True):
+    ``timing=True`` (bench.py): ``reduce()`` brackets its waits with events on the compute stream; ``exposed_ms()``
+    returns the time that stream spent stalled on the collectives."""
+
+    def __init__(self, module, bucket_mb=16.0, process_group=None, overlap=True, flat=None, timing=False):
         self.group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        params = [p for p in module.parameters() if p.requires_grad]
-        self.params = list(params)
-        params.reverse()
+        self.params = [p for p in module.parameters() if p.requires_grad]
         cap = int(bucket_mb * 1024 * 1024 / 4)
-        self.buckets = []
-        cur, cur_n = [], 0
-        for p in params:
-            if cur and cur_n + p.numel() > cap:
-                self.buckets.append(cur)
-                cur, cur_n = [], 0
-            cur.append(p)
-            cur_n += p.numel()
-        if cur:
-            self.buckets.append(cur)
-        self.flat, self.views = [], []
+        # buckets: parameter index ranges [lo, hi) walking the registration order from the end
+        self.ranges = []
+        hi, n = len(self.params), 0
+        for i in range(len(self.params) - 1, -1, -1):
+            if n and n + self.params[i].numel() > cap:
+                self.ranges.append((i + 1, hi))
+                hi, n = i + 1, 0
+            n += self.params[i].numel()
+        if hi > 0:
+            self.ranges.append((0, hi))
+        self.buckets = [self.params[lo:hi] for lo, hi in self.ranges]
         self._works = [None] * len(self.buckets)
         self._arrived = [0] * len(self.buckets)
         self._next = 0
+        self.timing = timing
+        self._stall_events = []
+        self.flat_all, self.views, self.flat = None, [], []
         if not dist.is_initialized():
             return
-        for bucket in self.buckets:
-            total = sum(p.numel() for p in bucket)
-            flat = torch.zeros(total, dtype=torch.float32, device=bucket[0].device)
-            views, off = [], 0
-            for p in bucket:
-                views.append(flat[off:off + p.numel()].view_as(p))
+        self._avg = dist.get_backend(process_group) == "nccl"  # RCCL averages in the collective; gloo sums
+        if flat is not None:
+            self.flat_all, all_views, flat_params = flat
+            assert len(flat_params) == len(self.params) and all(a is b for a, b in zip(flat_params, self.params))
+        else:
+            total = sum(p.numel() for p in self.params)
+            self.flat_all = torch.zeros(total, dtype=torch.float32, device=self.params[0].device)
+            all_views, off = [], 0
+            for p in self.params:
+                all_views.append(self.flat_all[off:off + p.numel()].view_as(p))
                 off += p.numel()
-            self.flat.append(flat)
-            self.views.append(views)
+        offs = [0]
+        for p in self.params:
+            offs.append(offs[-1] + p.numel())
+        for lo, hi in self.ranges:
+            self.flat.append(self.flat_all[offs[lo]:offs[hi]])
+            self.views.append(all_views[lo:hi])
         if overlap:
             self._bucket_of = {}
             for b, bucket in enumerate(self.buckets):
@@ -86,10 +103,11 @@ class FlatGradAllReduce:
         have = [(v, p.grad) for v, p in zip(views, bucket) if p.grad is not None and p.grad is not v]
         for v, p in zip(views, bucket):
             if p.grad is None:
-                v.zero_()  # a parameter this rank's graph did not reach still takes part in the sum
+                v.zero_()  # a parameter this rank's graph did not reach still takes part in the mean
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
-        self._works[b] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        self._works[b] = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
 
     def _on_grad(self, p):
         b = self._bucket_of[id(p)]
@@ -105,11 +123,47 @@ class FlatGradAllReduce:
         while self._next < len(self.buckets):  # not completed by the hooks (unreached parameters) or no overlap
             self._issue(self._next)
             self._next += 1
-        for b, (w, flat) in enumerate(zip(self._works, self.flat)):
+        if self.timing:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        for w in self._works:
             w.wait()
-            flat.div_(self.world_size)
+        if self.timing:
+            ev[1].record()
+            self._stall_events.append(ev)
+        for b, flat in enumerate(self.flat):
+            if not self._avg:
+                flat.div_(self.world_size)
             for v, p in zip(self.views[b], self.buckets[b]):
                 p.grad = v
+
+    def exposed_ms(self):
+        """Mean time per step the compute stream waited for the collectives (timing=True; call after a device
+        synchronisation) and forget the samples."""
+        ms = [a.elapsed_time(b) for a, b in self._stall_events]
+        self._stall_events = []
+        return sum(ms) / len(ms) if ms else 0.0
+
+    def standalone_ms(self, repeats=5):
+        """Duration of one step's collectives run back to back with nothing else on the GPU (median of `repeats`):
+        what the all-reduce costs when none of it is hidden under backward."""
+        if not dist.is_initialized():
+            return 0.0
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        times = []
+        for _ in range(repeats + 1):
+            torch.cuda.synchronize()
+            dist.barrier(group=self.group)
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for flat in self.flat:
+                dist.all_reduce(flat, op=op, group=self.group)
+            b.record()
+            torch.cuda.synchronize()
+            times.append(a.elapsed_time(b))
+        times = sorted(times[1:])  # the first repeat warms the communicator up
+        return times[len(times) // 2]
 
 
 def broadcast_module(module, src=0, process_group=None):

@@ -30,10 +30,15 @@ def cylinder_query_multi(xyz, new_xyz, rot, radii, hmin, hmaxs, nsample):
     ra = (ctypes.c_float * nr)(*[float(r) for r in radii])
     ha = (ctypes.c_float * nh)(*[float(h) for h in hmaxs])
     with _lib.device_ctx(xyz.device):
-        _lib.check(_lib.lib().gb_cylinder_query_multi(
+        stream = _lib.current_stream(xyz.device)
+        meta = None
+        if _lib.KernelTimer.active is not None:  # bench.py re-runs the timed queries afterwards to count scanned pairs
+            meta = {"b": B, "n": xyz.size(1), "m": npoint, "ns": int(nsample), "radii": [float(r) for r in radii],
+                    "hmin": float(hmin), "hmaxs": [float(h) for h in hmaxs], "args": (new_xyz, xyz, rot9)}
+        _lib.check(_lib.timed("gb_cylinder_query_multi", xyz.device, meta, lambda: _lib.lib().gb_cylinder_query_multi(
             _lib.ptr(new_xyz), _lib.ptr(xyz), _lib.ptr(rot9), _lib.ptr(out), B, xyz.size(1), npoint,
             ctypes.cast(ra, ctypes.c_void_p), nr, float(hmin), ctypes.cast(ha, ctypes.c_void_p), nh,
-            int(nsample), _lib.current_stream(xyz.device)), "cylinder_query_multi")
+            int(nsample), stream)), "cylinder_query_multi")
     return out
 
 

@@ -105,9 +105,14 @@ def ball_query(new_xyz, xyz, radius, nsample):
     N = xyz.size(1)
     idx = torch.empty((B, M, nsample), dtype=torch.int32, device=new_xyz.device)  # every element is written by the kernel
     with _lib.device_ctx(new_xyz.device):
-        _lib.check(_lib.lib().gb_ball_query(_lib.ptr(new_xyz), _lib.ptr(xyz), _lib.ptr(idx), None, B, N, M,
-                                            float(radius), int(nsample),
-                                            _lib.current_stream(new_xyz.device)), "ball_query")
+        stream = _lib.current_stream(new_xyz.device)
+        meta = None
+        if _lib.KernelTimer.active is not None:  # bench.py re-runs the timed query afterwards to count scanned pairs
+            meta = {"b": B, "n": N, "m": M, "ns": int(nsample), "radius": float(radius), "args": (new_xyz, xyz)}
+        _lib.check(_lib.timed("gb_ball_query", new_xyz.device, meta,
+                              lambda: _lib.lib().gb_ball_query(_lib.ptr(new_xyz), _lib.ptr(xyz), _lib.ptr(idx), None,
+                                                               B, N, M, float(radius), int(nsample), stream)),
+                   "ball_query")
     return idx
 
 

@@ -20,7 +20,7 @@ BN_MOMENTUM_MAX = 0.001
 class Trainer:
     def __init__(self, device, learning_rate=0.001, weight_decay=0.0, bn_decay_step=2, bn_decay_rate=0.5,
                  steps_per_epoch=100, max_epoch=18, num_view=300, seed=1234, distributed=False,
-                 bucket_mb=16.0, model=None):
+                 bucket_mb=16.0, model=None, time_collectives=False):
         torch.manual_seed(seed)
         self.device = torch.device(device)
         self.net = model if model is not None else GraspBalance(
@@ -36,7 +36,10 @@ class Trainer:
                                     epochs=max_epoch)
         bn_lbmd = lambda it: max(BN_MOMENTUM_INIT * bn_decay_rate ** (int(it / bn_decay_step)), BN_MOMENTUM_MAX)
         self.bnm_scheduler = BNMomentumScheduler(self.net, bn_lambda=bn_lbmd, last_epoch=-1)
-        self.grads = FlatGradAllReduce(self.net, bucket_mb=bucket_mb)
+        # the buckets ARE slices of the optimizer's flat gradient buffer: the averaged gradient lands where the
+        # update reads it (no second 36 MB copy per step)
+        self.grads = FlatGradAllReduce(self.net, bucket_mb=bucket_mb, timing=time_collectives,
+                                       flat=(self.optimizer._flat_g, self.optimizer._grad_views, self.optimizer._params))
         self.bnm_scheduler.step()
         self.net.train()
 

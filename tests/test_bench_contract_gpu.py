@@ -29,3 +29,7 @@ def test_bench_line_contract(monkeypatch, capsys):
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    for k in ("roofline_fps", "roofline_ball", "roofline_fps_ball", "roofline_cyl"):
+        assert d[k] is not None and 0.0 < d[k]["frac"] < 1.0, (k, d[k])
+    assert d["roofline_ball"]["bound"] == "valu" and 0 < d["roofline_ball"]["scanned_frac_of_full"] <= 1
+    assert d["ranks_seen"] == 1

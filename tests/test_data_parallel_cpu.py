@@ -38,15 +38,20 @@ def _worker(rank, world, port, out_dir):
     full = _tiny_batch(B=2)
     mine = shard_batch(full, rank, world)
     assert mine['point_clouds'].shape[0] == 1 and len(mine['grasp_points_list']) == 1
-    grads = FlatGradAllReduce(net, bucket_mb=0.5)
+    # the pairing Trainer(distributed=True) builds: FlatAdam's gradient buffer IS the all-reduce buffer
+    from graspbalance_amd.flat_adam import FlatAdam
+    opt = FlatAdam(net.parameters(), lr=1e-3)
+    grads = FlatGradAllReduce(net, bucket_mb=0.5, flat=(opt._flat_g, opt._grad_views, opt._params))
     assert len(grads.buckets) > 1
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    assert sum(f.numel() for f in grads.flat) == opt._flat_g.numel()
     loss, _ = get_loss(net(mine))
     loss.backward()
     local = [p.grad.clone() if p.grad is not None else torch.zeros_like(p) for p in net.parameters()]
     assert grads._next >= 1, "no bucket was all-reduced during backward (overlap hooks did not fire)"
     grads.reduce()
     reduced = [p.grad.clone() for p in net.parameters()]
+    lo, hi = opt._flat_g.data_ptr(), opt._flat_g.data_ptr() + 4 * opt._flat_g.numel()
+    assert all(lo <= p.grad.data_ptr() < hi for p in net.parameters())  # .grad = views of the optimizer's buffer
     opt.step()
     torch.save({"local": local, "reduced": reduced, "params": [p.detach().clone() for p in net.parameters()],
                 "bn_mean": net.view_estimator.FeatureExtraction.sa1.mlp_module.layer0.bn.bn.running_mean.clone()},

@@ -1,0 +1,38 @@
+"""CPU: oracle/dense_torch.py (the dense-torch restatement timed as bench.py's cpu_baseline_dense leg) against the
+reference-generated golden vectors and the C oracle."""
+import numpy as np
+import torch
+
+from oracle import dense_torch as dt
+
+
+def test_dense_fps_and_ball_query_match_golden(golden):
+    torch.manual_seed(0)
+    xyz = torch.rand(2, 4096, 3)
+    fps = dt.farthest_point_sample(xyz, 1024, skip_near_origin=False)
+    assert np.array_equal(fps.numpy(), golden.load("g1_fps_c1")["fps"])
+    new_xyz = torch.gather(xyz, 1, fps[:, :512].long().unsqueeze(-1).expand(-1, -1, 3))
+    g2 = golden.load("g2_ball_c1")
+    for r, ns in [(0.1, 32), (0.04, 32), (0.2, 64)]:
+        want = g2["idx_r%g_ns%d" % (r, ns)].copy()
+        want[want == 4096] = 0  # the fallback marks an empty ball with N, the kernels with 0
+        assert np.array_equal(dt.query_ball_point(r, ns, xyz, new_xyz).numpy(), want)
+
+
+def test_dense_matches_c_oracle_on_a_scene(orc):
+    from graspbalance_amd.scene import make_batch
+    xyz = torch.from_numpy(make_batch([4], 6000))
+    inds = dt.farthest_point_sample(xyz, 256)
+    assert torch.equal(inds, orc.furthest_point_sampling(xyz, 256, orc.FPS_SKIP_NEAR_ORIGIN | orc.FPS_TIE_LOWEST))
+    new_xyz = torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    assert torch.equal(dt.query_ball_point(0.04, 32, xyz, new_xyz), orc.ball_query(new_xyz, xyz, 0.04, 32))
+
+
+def test_dense_sa_layer_shapes():
+    from graspbalance_amd.scene import make_batch
+    xyz = torch.from_numpy(make_batch([1], 3000))
+    torch.manual_seed(0)
+    w = [(torch.randn(16, 3), torch.ones(16), torch.zeros(16)), (torch.randn(32, 16), torch.ones(32), torch.zeros(32))]
+    inds, idx, feats = dt.sa_layer_forward(xyz, 128, 0.05, 16, w)
+    assert inds.shape == (1, 128) and idx.shape == (1, 128, 16) and feats.shape == (1, 32, 128)
+    assert bool(torch.isfinite(feats).all()) and float(feats.min()) >= 0.0

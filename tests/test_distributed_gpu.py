@@ -1,0 +1,76 @@
+"""GPU: the RCCL data-parallel path as shipped (Trainer(distributed=True): FlatAdam's gradient buffer sliced into the
+all-reduce buckets, post-accumulate hooks, broadcast) - with one rank on a one-GPU box (GB_FORCE_DIST-style), and with
+two ranks through bench.py's own launcher when two devices are visible."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_WORLD1 = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+import torch, torch.distributed as dist
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+from tests.test_model_cpu import _tiny_net
+from graspbalance_amd.loss import get_loss
+from graspbalance_amd.synthetic import make_training_batch
+from graspbalance_amd.train import Trainer
+batch = make_training_batch(range(2), num_point=3000, num_objects=2, grasp_points_per_object=20, num_view=30, device=dev)
+tr = Trainer(dev, num_view=30, model=_tiny_net(), steps_per_epoch=10, max_epoch=2, distributed=True, bucket_mb=0.5,
+             time_collectives=True)
+assert len(tr.grads.flat) > 1 and tr.grads.flat_all is tr.optimizer._flat_g
+loss, _ = get_loss(tr.net(dict(batch)))
+loss.backward()
+assert tr.grads._next >= 1, "no bucket was issued during backward"
+tr.grads.reduce()
+lo, hi = tr.optimizer._flat_g.data_ptr(), tr.optimizer._flat_g.data_ptr() + 4 * tr.optimizer._flat_g.numel()
+assert all(lo <= p.grad.data_ptr() < hi for p in tr.net.parameters())
+got = [p.grad.clone() for p in tr.net.parameters()]
+plain = _tiny_net().to(dev).train()
+loss2, _ = get_loss(plain(dict(batch)))
+loss2.backward()
+want = [p.grad for p in plain.parameters()]
+assert abs(float(loss) - float(loss2)) < 1e-3 * abs(float(loss2))
+num = sum(float((a - b).norm()) ** 2 for a, b in zip(got, want)) ** 0.5
+den = sum(float(b.norm()) ** 2 for b in want) ** 0.5
+assert num / den < 0.2, num / den   # two executions of a chaotic train-mode net (atomics order); a mis-sliced bucket gives ~1.4
+for a, b in zip(got, want):
+    assert a.shape == b.shape
+tr.grads.zero_grad()
+before = [p.detach().clone() for p in tr.net.parameters()]
+for _ in range(2):
+    l = tr.train_step(batch)
+torch.cuda.synchronize()
+assert bool(torch.isfinite(l)) and sum(int(not torch.equal(a, b)) for a, b in zip(before, tr.net.parameters())) > 200
+assert tr.grads.exposed_ms() >= 0.0 and tr.grads.standalone_ms(repeats=2) > 0.0
+dist.destroy_process_group()
+print("world1 ok")
+'''
+
+
+def test_trainer_distributed_with_one_rank_matches_local_gradients():
+    out = subprocess.run([sys.executable, "-c", _WORLD1 % {"root": ROOT}], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "world1 ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two visible GPUs")
+def test_bench_launches_two_ranks_itself():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["config"]["global_batch"] == 8
+    assert d["allreduce_ms"] > 0 and d["allreduce_exposed_ms"] >= 0

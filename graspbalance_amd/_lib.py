@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libgraspbal_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 GB_OK = 0
 _ERRNAMES = {-1: "GB_EINVAL", -2: "GB_ELAUNCH", -3: "GB_ERANGE"}
@@ -62,10 +62,10 @@ SIGNATURES = {
     "gb_la_pool_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
     "gb_la_point_grad": [_P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _P, _P],
     "gb_la_wx_grad": [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P],
-    "gb_label_gather": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "gb_label_gather": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gb_grasp_loss_fwd": [_P] * 17 + [_I] * 6 + [_F] * 4 + [_P] * 6,
     "gb_grasp_loss_bwd": [_P] * 17 + [_I] * 6 + [_F] * 4 + [_P] * 11,
-    "gb_label_finish": [_P, _P, _P, _F, _P, _P, _P, _L, _I, _P],
+    "gb_label_finish": [_P, _P, _P, _P, _F, _P, _P, _P, _L, _I, _P],
     "gb_gemm_fwd": [_P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P],
     "gb_gemm_dgrad": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P, _P, _P],
     "gb_gemm_wgrad": [_P, _P, _P, _P, _L, _I, _I, _P],

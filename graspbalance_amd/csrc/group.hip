@@ -392,18 +392,25 @@ __device__ __forceinline__ void atomic_max_nan(float *addr, float v) {
 
 // out_max (optional, caller-initialised to -inf): the maximum of everything gathered - the reference's
 // `batch_grasp_label.max()` (label_generation.py:113) without another pass over the (B,Ns,V,A,D) tensor
-__global__ __launch_bounds__(TPB) void label_gather_kernel(const float *const *__restrict__ srcs,
-                                                            const int32_t *__restrict__ obj,
+constexpr int LG_MAX_SRC = 128;
+struct LabelSrcTable {  // by value in the kernel arguments: no device-side pointer table to build or cache
+  const float *p[LG_MAX_SRC];
+};
+
+__global__ __launch_bounds__(TPB) void label_gather_kernel(const LabelSrcTable srcs, const int32_t *__restrict__ obj,
                                                             const int32_t *__restrict__ pt,
                                                             const int64_t *__restrict__ view_inds,
-                                                            float *__restrict__ out, float *__restrict__ out_max, int V,
-                                                            int W) {
+                                                            float *__restrict__ out, float *__restrict__ out_max,
+                                                            float *__restrict__ out_col, int col_stride, int col_off,
+                                                            int V, int W) {
   __shared__ float s_m[TPB / 64];
   const int r = blockIdx.x;
   const int o = obj[r];
-  const float *src = srcs[o] + (size_t)pt[r] * V * W;
+  const float *src = srcs.p[o] + (size_t)pt[r] * V * W;
   const int64_t *vi = view_inds + (size_t)o * V;
   float *dst = out + (size_t)r * V * W;
+  const int wc = out_col ? W / col_stride : 0;
+  float *dcol = out_col ? out_col + (size_t)r * V * wc : nullptr;
   float mx = -INFINITY;
   bool nan = false;
   if ((W & 3) == 0) {
@@ -412,6 +419,14 @@ __global__ __launch_bounds__(TPB) void label_gather_kernel(const float *const *_
       const int v = e / w4, q = e % w4;
       const float4 x = reinterpret_cast<const float4 *>(src + (size_t)vi[v] * W)[q];
       reinterpret_cast<float4 *>(dst)[e] = x;
+      if (dcol) {
+        const float xv[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int i = 4 * q + t;
+          if (i % col_stride == col_off) dcol[(size_t)v * wc + i / col_stride] = xv[t];
+        }
+      }
       if (out_max) {
         mx = fmaxf(fmaxf(mx, x.x), fmaxf(fmaxf(x.y, x.z), x.w));
         nan |= (x.x != x.x) | (x.y != x.y) | (x.z != x.z) | (x.w != x.w);
@@ -421,6 +436,7 @@ __global__ __launch_bounds__(TPB) void label_gather_kernel(const float *const *_
     for (int e = threadIdx.x; e < V * W; e += TPB) {
       const float x = src[(size_t)vi[e / W] * W + e % W];
       dst[e] = x;
+      if (dcol && (e % W) % col_stride == col_off) dcol[(size_t)(e / W) * wc + (e % W) / col_stride] = x;
       if (out_max) { mx = fmaxf(mx, x); nan |= x != x; }
     }
   }
@@ -449,7 +465,7 @@ __global__ __launch_bounds__(TPB) void label_gather_kernel(const float *const *_
 // floats as three 16-byte loads); the AD/4 threads of a view combine their maxima through LDS.
 constexpr int LF_ROWS = 16;  // views per workgroup
 __global__ void label_finish_kernel(const float *__restrict__ labels, const float *__restrict__ offsets,
-                                    const float *__restrict__ u_max, float max_width, float *__restrict__ out,
+                                    const float *__restrict__ widths, const float *__restrict__ u_max, float max_width, float *__restrict__ out,
                                     float *__restrict__ view_scores, int32_t *__restrict__ view_arg, long long rows,
                                     int ad4) {
   extern __shared__ float s_max[];  // [LF_ROWS][ad4] maxima, then [LF_ROWS][ad4] their positions (as int)
@@ -462,11 +478,17 @@ __global__ void label_finish_kernel(const float *__restrict__ labels, const floa
   if (row < rows) {
     const long long e4 = row * ad4 + q;  // index of this thread's group of 4 grasps
     const float4 l = reinterpret_cast<const float4 *>(labels)[e4];
-    const float4 o0 = reinterpret_cast<const float4 *>(offsets)[3 * e4];
-    const float4 o1 = reinterpret_cast<const float4 *>(offsets)[3 * e4 + 1];
-    const float4 o2 = reinterpret_cast<const float4 *>(offsets)[3 * e4 + 2];
+    float wv[4];  // offsets[..., 2] of the 4 grasps
+    if (widths) {
+      const float4 w4 = reinterpret_cast<const float4 *>(widths)[e4];
+      wv[0] = w4.x; wv[1] = w4.y; wv[2] = w4.z; wv[3] = w4.w;
+    } else {
+      const float4 o0 = reinterpret_cast<const float4 *>(offsets)[3 * e4];
+      const float4 o1 = reinterpret_cast<const float4 *>(offsets)[3 * e4 + 1];
+      const float4 o2 = reinterpret_cast<const float4 *>(offsets)[3 * e4 + 2];
+      wv[0] = o0.z; wv[1] = o1.y; wv[2] = o2.x; wv[3] = o2.w;
+    }
     const float lv[4] = {l.x, l.y, l.z, l.w};
-    const float wv[4] = {o0.z, o1.y, o2.x, o2.w};  // offsets[..., 2] of the 4 grasps
     float r[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -504,28 +526,34 @@ __global__ void label_finish_kernel(const float *__restrict__ labels, const floa
 
 using namespace gb;
 
-extern "C" int gb_label_finish(const float *labels, const float *offsets, const float *u_max, float max_width,
-                               float *out, float *view_scores, int32_t *view_arg, long long rows, int ad, void *stream) {
-  if (rows < 0 || ad < 4 || ad % 4 != 0 || ad / 4 * LF_ROWS > 1024 || !labels || !offsets || !u_max || !out ||
-      !view_scores)
+extern "C" int gb_label_finish(const float *labels, const float *offsets, const float *widths, const float *u_max,
+                               float max_width, float *out, float *view_scores, int32_t *view_arg, long long rows,
+                               int ad, void *stream) {
+  if (rows < 0 || ad < 4 || ad % 4 != 0 || ad / 4 * LF_ROWS > 1024 || !labels || (!offsets && !widths) || !u_max ||
+      !out || !view_scores)
     return GB_EINVAL;
-  if ((reinterpret_cast<uintptr_t>(labels) | reinterpret_cast<uintptr_t>(offsets) | reinterpret_cast<uintptr_t>(out)) % 16)
+  if ((reinterpret_cast<uintptr_t>(labels) | reinterpret_cast<uintptr_t>(offsets) | reinterpret_cast<uintptr_t>(widths) |
+       reinterpret_cast<uintptr_t>(out)) % 16)
     return GB_EINVAL;
   if (rows == 0) return GB_OK;
   const int ad4 = ad / 4, threads = LF_ROWS * ad4;
   hipLaunchKernelGGL(label_finish_kernel, dim3((unsigned)((rows + LF_ROWS - 1) / LF_ROWS)), dim3(threads),
-                     2 * threads * sizeof(float), as_stream(stream), labels, offsets, u_max, max_width, out, view_scores,
-                     view_arg, rows, ad4);
+                     2 * threads * sizeof(float), as_stream(stream), labels, offsets, widths, u_max, max_width, out,
+                     view_scores, view_arg, rows, ad4);
   return check_launch("gb_label_finish");
 }
 
-extern "C" int gb_label_gather(const float *const *srcs, const int32_t *obj, const int32_t *pt,
-                               const int64_t *view_inds, float *out, float *out_max, int R, int V, int W,
-                               void *stream) {
-  if (R < 0 || V < 1 || W < 1 || !srcs || !obj || !pt || !view_inds || !out) return GB_EINVAL;
+extern "C" int gb_label_gather(const float *const *srcs, int nsrc, const int32_t *obj, const int32_t *pt,
+                               const int64_t *view_inds, float *out, float *out_max, float *out_col, int col_stride,
+                               int col_off, int R, int V, int W, void *stream) {
+  if (R < 0 || V < 1 || W < 1 || nsrc < 1 || !srcs || !obj || !pt || !view_inds || !out) return GB_EINVAL;
+  if (nsrc > LG_MAX_SRC) return GB_ERANGE;
+  if (out_col && (col_stride < 1 || col_off < 0 || col_off >= col_stride || W % col_stride != 0)) return GB_EINVAL;
   if (R == 0) return GB_OK;
-  hipLaunchKernelGGL(label_gather_kernel, dim3(R), dim3(TPB), 0, as_stream(stream), srcs, obj, pt, view_inds, out,
-                     out_max, V, W);
+  LabelSrcTable tab;
+  for (int i = 0; i < LG_MAX_SRC; ++i) tab.p[i] = i < nsrc ? srcs[i] : nullptr;
+  hipLaunchKernelGGL(label_gather_kernel, dim3(R), dim3(TPB), 0, as_stream(stream), tab, obj, pt, view_inds, out,
+                     out_max, out_col, col_stride, col_off, V, W);
   return check_launch("gb_label_gather");
 }
 

@@ -84,34 +84,30 @@ def _assign_views(poses, V):
     return myknn(trans.contiguous(), query, k=1).view(poses.size(0), V) - 1
 
 
-_PTR_CACHE = {}
-
-
-def _pointer_table(tensors, device):
-    """Device array of the tensors' data pointers (cached while the same tensors are reused)."""
-    key = tuple(t.data_ptr() for t in tensors)
-    tab = _PTR_CACHE.get(key)
-    if tab is None:
-        if len(_PTR_CACHE) > 64:
-            _PTR_CACHE.clear()
-        tab = torch.tensor(key, dtype=torch.int64, device=device)
-        _PTR_CACHE[key] = tab
-    return tab
-
-
-def _label_gather(tensors, obj, pt, view_inds, V, W, want_max=False):
+def _label_gather(tensors, obj, pt, view_inds, V, W, want_max=False, col=None):
     """out[r,v,:] = tensors[obj[r]][pt[r], view_inds[obj[r], v], :] through the fused HIP gather; with want_max also
-    the maximum of the gathered values (a 0-d tensor, == out.max()) from the same pass."""
+    the maximum of the gathered values (a 0-d tensor, == out.max()) from the same pass; with col = (stride, offset)
+    also a contiguous copy of the columns w % stride == offset (the widths of the offsets tensor).
+    The objects' label tensors are new every step in training: their addresses travel in the kernel arguments (a host
+    array), not through a device-side table that would need a copy - or a cache that only a benchmark could hit."""
+    import ctypes
     from . import _lib
     dev = obj.device
     out = torch.empty((obj.numel(), V, W), dtype=torch.float32, device=dev)
     out_max = torch.full((), float("-inf"), dtype=torch.float32, device=dev) if want_max else None
-    tab = _pointer_table(tensors, dev)
+    out_col = torch.empty((obj.numel(), V, W // col[0]), dtype=torch.float32, device=dev) if col else None
+    table = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
     with _lib.device_ctx(dev):
-        _lib.check(_lib.lib().gb_label_gather(_lib.ptr(tab), _lib.ptr(obj), _lib.ptr(pt), _lib.ptr(view_inds),
-                                              _lib.ptr(out), _lib.ptr(out_max), obj.numel(), V, W,
-                                              _lib.current_stream(dev)), "label_gather")
-    return (out, out_max) if want_max else out
+        _lib.check(_lib.lib().gb_label_gather(ctypes.cast(table, ctypes.c_void_p), len(tensors), _lib.ptr(obj),
+                                              _lib.ptr(pt), _lib.ptr(view_inds), _lib.ptr(out), _lib.ptr(out_max),
+                                              _lib.ptr(out_col), col[0] if col else 1, col[1] if col else 0,
+                                              obj.numel(), V, W, _lib.current_stream(dev)), "label_gather")
+    res = (out,)
+    if want_max:
+        res += (out_max,)
+    if col:
+        res += (out_col,)
+    return res if len(res) > 1 else out
 
 
 def _finish_labels(end_points, batch, batch_size, num_samples):
@@ -130,8 +126,9 @@ def _finish_labels(end_points, batch, batch_size, num_samples):
         view_arg = torch.empty((batch_size, num_samples, V), dtype=torch.int32, device=labels.device)
         end_points['_view_label_arg'] = view_arg  # where in (A,D) each view's maximum sits (first one)
         with _lib.device_ctx(labels.device):
-            _lib.check(_lib.lib().gb_label_finish(_lib.ptr(labels), _lib.ptr(offsets), _lib.ptr(u_max),
-                                                  float(GRASP_MAX_WIDTH), _lib.ptr(out), _lib.ptr(view_scores),
+            _lib.check(_lib.lib().gb_label_finish(_lib.ptr(labels), _lib.ptr(offsets), _lib.ptr(batch.get('width')),
+                                                  _lib.ptr(u_max), float(GRASP_MAX_WIDTH), _lib.ptr(out),
+                                                  _lib.ptr(view_scores),
                                                   _lib.ptr(view_arg),
                                                   batch_size * num_samples * V, A * D,
                                                   _lib.current_stream(labels.device)), "gb_label_finish")
@@ -199,13 +196,15 @@ def _process_grasp_labels_fused(end_points):
     pt = torch.cat(pt_of_seed, 0).contiguous()
     objl = obj.long()
     label, label_max = _label_gather(labels_l, obj, pt, view_inds, V, A * D, want_max=True)
+    offset, width = _label_gather(offsets_l, obj, pt, view_inds, V, A * D * 3, col=(3, 2))
     batch = {
         'point': torch.stack(points, 0),
         'view': torch.index_select(views_sel, 0, objl).view(B, Ns, V, 3),
         'view_rot': torch.index_select(rot_sel, 0, objl).view(B, Ns, V, 3, 3),
         'label': label.view(B, Ns, V, A, D),
         'label_max': label_max,
-        'offset': _label_gather(offsets_l, obj, pt, view_inds, V, A * D * 3).view(B, Ns, V, A, D, 3),
+        'offset': offset.view(B, Ns, V, A, D, 3),
+        'width': width,  # offsets[..., 2], contiguous: what the score transform reads
         'tolerance': _label_gather(tol_l, obj, pt, view_inds, V, A * D).view(B, Ns, V, A, D),
     }
     return _finish_labels(end_points, batch, B, Ns)
@@ -217,8 +216,8 @@ def _fusable(end_points):
     ts = [t for key in ('grasp_labels_list', 'grasp_offsets_list', 'grasp_tolerance_list')
           for per in end_points[key] for t in per]
     shape = ts[0].shape[1:4]
-    return all(t.is_contiguous() and t.dtype == torch.float32 and t.data_ptr() % 16 == 0 for t in ts) \
-        and all(t.shape[1:4] == shape for t in ts)
+    return len(ts) <= 3 * 128 and all(t.is_contiguous() and t.dtype == torch.float32 and t.data_ptr() % 16 == 0
+                                        for t in ts) and all(t.shape[1:4] == shape for t in ts)  # <= 128 objects per batch
 
 
 def process_grasp_labels(end_points):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GB_ABI_VERSION 1
+#define GB_ABI_VERSION 2
 
 enum {
   GB_OK = 0,
@@ -164,20 +164,27 @@ int gb_knn1(const float *ref, const float *query, int64_t *idx, int b, int dim, 
 
 /* Grasp-label gather for the training-time label matching (label_generation.py:60-99):
  *   out[r, v, :] = srcs[obj[r]][pt[r], view_inds[obj[r], v], :]     (W floats per (point, view))
- * srcs: DEVICE array of device pointers, one (Np_o, V, W) tensor per object; obj/pt (R) int32;
- * view_inds (n_objects, V) int64; out (R, V, W).  Composes the reference's two index_selects (views
- * then seeds) so only the kept rows are copied.  out_max (optional; one float, caller-initialised to
- * -inf) receives the maximum of everything gathered, NaN if any (the `.max()` of label_generation.py:113). */
-int gb_label_gather(const float *const *srcs, const int32_t *obj, const int32_t *pt,
-                    const int64_t *view_inds, float *out, float *out_max, int R, int V, int W, void *stream);
+ * srcs: HOST array of nsrc (<= 128) device pointers, one (Np_o, V, W) tensor per object - the table travels in the
+ * kernel arguments, so fresh label tensors every step cost neither a host-to-device copy nor a lookup cache;
+ * obj/pt (R) int32; view_inds (n_objects, V) int64; out (R, V, W).  Composes the reference's two index_selects
+ * (views then seeds) so only the kept rows are copied.  out_max (optional; one float, caller-initialised to
+ * -inf) receives the maximum of everything gathered, NaN if any (the `.max()` of label_generation.py:113).
+ * out_col (optional, (R, V, W / col_stride)): a contiguous copy of the columns w with w % col_stride == col_off -
+ * the widths offsets[..., 2] that gb_label_finish needs, so it reads a third of the offsets tensor's bytes. */
+int gb_label_gather(const float *const *srcs, int nsrc, const int32_t *obj, const int32_t *pt,
+                    const int64_t *view_inds, float *out, float *out_max, float *out_col, int col_stride,
+                    int col_off, int R, int V, int W, void *stream);
 /* Score transform + per-view maximum of the gathered labels (reference label_generation.py:112-116):
  * out = log(*u_max / label) where label > 0 and offsets[..., 2] (width) <= max_width, else 0;
  * view_scores[row] = max over the ad = A*D grasps of the row.  labels/out (rows, ad), offsets (rows, ad, 3),
- * u_max: device scalar (the maximum of `labels`); ad % 4 == 0; 16-byte aligned tensors.  view_arg (optional,
- * (rows) int32): the position in [0, ad) of that maximum, the first one - with view_scores it gives the arg-max
- * over all views of a seed that loss.py:31 takes, without another pass over the tensor.                  */
-int gb_label_finish(const float *labels, const float *offsets, const float *u_max, float max_width, float *out,
-                    float *view_scores, int32_t *view_arg, long long rows, int ad, void *stream);
+ * u_max: device scalar (the maximum of `labels`); ad % 4 == 0; 16-byte aligned tensors.  widths (optional,
+ * (rows, ad)): offsets[..., 2] as its own contiguous tensor (gb_label_gather's out_col) - read instead of `offsets`,
+ * which may then be NULL.  view_arg (optional, (rows) int32): the position in [0, ad) of that maximum, the first
+ * one - with view_scores it gives the arg-max over all views of a seed that loss.py:31 takes, without another
+ * pass over the tensor.                                                                                    */
+int gb_label_finish(const float *labels, const float *offsets, const float *widths, const float *u_max,
+                    float max_width, float *out, float *view_scores, int32_t *view_arg, long long rows, int ad,
+                    void *stream);
 
 /* ---- channel-last fused pieces of the SharedMLP (1x1 conv + BatchNorm + ReLU + max over nsample) ----
  * No reference launcher corresponds one-to-one: these replace the torch passes the reference runs

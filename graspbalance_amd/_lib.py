@@ -62,6 +62,10 @@ SIGNATURES = {
     "gb_la_pool_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
     "gb_la_point_grad": [_P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _P, _P],
     "gb_la_wx_grad": [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P],
+    "gb_set_reserved_cus": [_I],
+    "gb_stream_create_cu_mask": [_P, _I, _P],
+    "gb_stream_destroy": [_P],
+    "gb_device_cu_count": [_P],
     "gb_label_gather": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gb_grasp_loss_fwd": [_P] * 17 + [_I] * 6 + [_F] * 4 + [_P] * 6,
     "gb_grasp_loss_bwd": [_P] * 17 + [_I] * 6 + [_F] * 4 + [_P] * 11,

@@ -362,6 +362,11 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
   }
 }
 
+// CUs the persistent grid is sized for.  gb_set_reserved_cus(r) takes r of them out: a caller that keeps a long
+// latency-bound kernel resident on a side stream (the next step's furthest-point sampling: one workgroup per cloud,
+// 80 KB of LDS each, for ~2 ms) tells the statically partitioned GEMM not to count on those CUs - otherwise the
+// workgroups that find no free CU start only when others finish and the launch takes two rounds.
+static std::atomic<int> g_reserved_cus{0};
 static int num_cus() {
   static int n = 0;
   if (!n) {
@@ -369,7 +374,8 @@ static int num_cus() {
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
   }
-  return n;
+  const int r = g_reserved_cus.load(std::memory_order_relaxed);
+  return n - r >= 16 ? n - r : n;
 }
 
 static bool rs_enabled() {
@@ -456,6 +462,12 @@ bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, dou
 }
 
 }  // namespace gb
+
+extern "C" int gb_set_reserved_cus(int count) {
+  if (count < 0 || count > 128) return GB_EINVAL;
+  gb::g_reserved_cus.store(count, std::memory_order_relaxed);
+  return GB_OK;
+}
 
 // which kernel gb_gemm_fwd (dgrad = 0) / gb_gemm_dgrad (dgrad = 1) launches for 16-byte aligned operands:
 // 1 = gemm_rs_kernel, 0 = gemm_cl_kernel.  Introspection for bench.py's per-kernel roofline accounting.

@@ -208,8 +208,14 @@ class DRP(nn.Module):
         xyz, features = break_up_pc(pointcloud)
         end_points['input_xyz'] = xyz
         end_points['input_features'] = features
+        pre = end_points.pop('_sa1_inds_prefetched', None)  # sampled one step ahead on a side stream (prefetch.py)
         for level in (1, 2, 3, 4):
-            xyz, features, fps_inds = getattr(self, 'sa%d' % level)(xyz, features)
+            inds = pre if (level == 1 and pre is not None and pre.shape == (xyz.shape[0], self.sa1.npoint)) else None
+            xyz, features, fps_inds = getattr(self, 'sa%d' % level)(xyz, features, inds)
+            if level == 1:
+                hook = end_points.pop('_after_sa1', None)
+                if hook is not None:
+                    hook()
             xyz, features = run_stage(getattr(self, 'InvResMLP_blocks%d' % level), xyz, features)
             if level <= 2:
                 end_points['sa%d_inds' % level] = fps_inds

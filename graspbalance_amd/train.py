@@ -13,6 +13,9 @@ from .graspbalance import GraspBalance
 from .loss import get_loss
 from .pytorch_utils import BNMomentumScheduler
 
+import os
+_PREFETCH_AT = os.environ.get("GB_PREFETCH_AT", "sa1")  # A/B switch: "start" | "sa1" | "off"
+
 BN_MOMENTUM_INIT = 0.5
 BN_MOMENTUM_MAX = 0.001
 
@@ -20,7 +23,7 @@ BN_MOMENTUM_MAX = 0.001
 class Trainer:
     def __init__(self, device, learning_rate=0.001, weight_decay=0.0, bn_decay_step=2, bn_decay_rate=0.5,
                  steps_per_epoch=100, max_epoch=18, num_view=300, seed=1234, distributed=False,
-                 bucket_mb=16.0, model=None, time_collectives=False):
+                 bucket_mb=16.0, model=None, time_collectives=False, prefetch_sampling=True):
         torch.manual_seed(seed)
         self.device = torch.device(device)
         self.net = model if model is not None else GraspBalance(
@@ -42,13 +45,48 @@ class Trainer:
                                        flat=(self.optimizer._flat_g, self.optimizer._grad_views, self.optimizer._params))
         self.bnm_scheduler.step()
         self.net.train()
+        # first-level FPS of the next batch on a side stream (prefetch.py); needs the caller to pass `next_batch`
+        self.prefetch = None
+        sa1 = getattr(getattr(getattr(self.net, "view_estimator", None), "FeatureExtraction", None), "sa1", None)
+        if prefetch_sampling and _PREFETCH_AT != "off" and self.device.type == "cuda" and sa1 is not None and sa1.npoint:
+            from .prefetch import SamplingPrefetch
+            self.prefetch = SamplingPrefetch(self.device, sa1.npoint)
 
-    def train_step(self, batch):
+    def train_step(self, batch, next_batch=None):
         """forward -> loss -> backward -> gradient all-reduce -> Adam step -> LR step.  Returns the
-        loss tensor (no host sync here; the reference's per-key .item() logging is the caller's)."""
+        loss tensor (no host sync here; the reference's per-key .item() logging is the caller's).
+        next_batch: the batch of the FOLLOWING call, if the loop already holds it - its first-level furthest-point
+        sampling then runs on a side stream under this step (prefetch.py)."""
+        main = self.prefetch.main if self.prefetch is not None else None
+        if main is None:
+            return self._train_step(batch, next_batch)
+        # the step runs on the CU-masked training stream, ordered after / before the caller's current stream
+        caller = torch.cuda.current_stream(self.device)
+        main.wait_stream(caller)
+        with torch.cuda.stream(main):
+            loss = self._train_step(batch, next_batch)
+        caller.wait_stream(main)
+        loss.record_stream(caller)
+        return loss
+
+    def _train_step(self, batch, next_batch=None):
         if self.device.type == "cuda":
             fused_mlp.begin_step(self.device)  # one re-zeroed arena for the step's small fp64 reduction buffers
-        end_points = self.net(dict(batch))  # the network adds its outputs to the dict it is given
+        inputs = dict(batch)  # the network adds its outputs to the dict it is given
+        if self.prefetch is not None:
+            from .prefetch import AFTER_SA1, KEY
+            inds = self.prefetch.take(batch['point_clouds'])
+            if inds is not None:
+                inputs[KEY] = inds
+            if next_batch is not None:
+                clouds = next_batch['point_clouds']
+                if _PREFETCH_AT == "start":
+                    self.prefetch.launch(clouds)
+                else:
+                    inputs[AFTER_SA1] = lambda: self.prefetch.launch(clouds)
+        end_points = self.net(inputs)
+        if self.prefetch is not None and next_batch is not None and self.prefetch.pending is None:
+            self.prefetch.launch(next_batch['point_clouds'])  # a backbone without the hook: start it now
         loss, end_points = get_loss(end_points)
         loss.backward()
         self.grads.reduce()

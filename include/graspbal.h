@@ -174,6 +174,18 @@ int gb_knn1(const float *ref, const float *query, int64_t *idx, int b, int dim, 
 int gb_label_gather(const float *const *srcs, int nsrc, const int32_t *obj, const int32_t *pt,
                     const int64_t *view_inds, float *out, float *out_max, float *out_col, int col_stride,
                     int col_off, int R, int V, int W, void *stream);
+/* A stream whose kernels may only run on the compute units set in cu_mask (`words` 32-bit words, bit i = CU i);
+ * gb_stream_destroy releases it; gb_device_cu_count reports the current device's CU count.  prefetch.py splits
+ * the chip with two such streams: B CUs for the next batch's furthest-point sampling, the rest for the step.   */
+int gb_stream_create_cu_mask(const uint32_t *cu_mask, int words, void **stream);
+int gb_stream_destroy(void *stream);
+int gb_device_cu_count(int *count);
+
+/* Size the persistent GEMM grids for (CUs - count) compute units (0 restores the full device): for callers that keep
+ * a long one-workgroup-per-cloud kernel (furthest-point sampling of the NEXT batch) running on a side stream.
+ * Process-wide; 0 <= count <= 128.                                                                              */
+int gb_set_reserved_cus(int count);
+
 /* Score transform + per-view maximum of the gathered labels (reference label_generation.py:112-116):
  * out = log(*u_max / label) where label > 0 and offsets[..., 2] (width) <= max_width, else 0;
  * view_scores[row] = max over the ad = A*D grasps of the row.  labels/out (rows, ad), offsets (rows, ad, 3),

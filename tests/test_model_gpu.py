@@ -203,3 +203,46 @@ def test_flat_adam_gpu_follows_torch_fused_adam():
     assert opt._fused
     for pa, pb in zip(a.parameters(), b.parameters()):
         assert torch.allclose(pa, pb, rtol=1e-6, atol=1e-8)
+
+
+def test_sampling_prefetch_on_side_stream_equals_inline_sampling():
+    """prefetch.SamplingPrefetch: the first-level FPS of an announced batch, run on a side stream, is consumed by the
+    next step and equals the inline sampling; an unannounced (or modified) batch is sampled inline."""
+    from tests.test_model_cpu import _tiny_net
+    from graspbalance_amd import pointnet2_utils as pu
+    from graspbalance_amd.prefetch import KEY, SamplingPrefetch
+    from graspbalance_amd.synthetic import make_training_batch
+    from graspbalance_amd.train import Trainer
+    a = make_training_batch(range(2), num_point=3000, num_objects=2, grasp_points_per_object=20, num_view=30, device=DEV)
+    b = make_training_batch(range(2, 4), num_point=3000, num_objects=2, grasp_points_per_object=20, num_view=30, device=DEV)
+    pf = SamplingPrefetch(torch.device(DEV), 256)
+    pf.launch(b['point_clouds'])
+    assert pf.take(a['point_clouds']) is None and pf.pending is None      # announced b, asked for a: nothing
+    pf.launch(b['point_clouds'])
+    inds = pf.take(b['point_clouds'])
+    torch.cuda.synchronize()
+    assert torch.equal(inds, pu.furthest_point_sample(b['point_clouds'], 256))
+    pf.launch(b['point_clouds'])
+    b['point_clouds'].add_(0.0)                                            # modified in place after the announcement
+    assert pf.take(b['point_clouds']) is None
+    # through the trainer: the announced batch's indices reach the network (and are the ones it would compute)
+    tr = Trainer(DEV, num_view=30, model=_tiny_net(), steps_per_epoch=10, max_epoch=2)
+    seen = {}
+    sa1 = tr.net.view_estimator.FeatureExtraction.sa1
+    inner = sa1.forward
+
+    def spy(xyz, features=None, inds=None):
+        seen['given'] = inds
+        out = inner(xyz, features, inds)
+        seen['used'] = out[2]
+        return out
+    sa1.forward = spy
+    tr.train_step(a, next_batch=b)
+    assert seen['given'] is None
+    tr.train_step(b, next_batch=a)
+    assert seen['given'] is not None and seen['given'] is seen['used']
+    torch.cuda.synchronize()
+    assert torch.equal(seen['used'], pu.furthest_point_sample(b['point_clouds'], 256))
+    loss = tr.train_step(a)
+    assert seen['given'] is not None and bool(torch.isfinite(loss))
+    _ = KEY

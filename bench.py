@@ -28,6 +28,7 @@ BATCH_PER_GPU = 4
 NUM_POINT = 20000
 HBM_PEAK_GBS = 8000.0
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (16x the fp32 rate)
 # vector ALU: 256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz = 78.6e12 lane-instructions/s (the 157.3 TFLOP/s vector
 # figure counts an FMA as two; the geometry kernels are built -ffp-contract=off, one rounding per operation)
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
@@ -193,7 +194,13 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", choices=["train", "stress"], default="train",
+                    help="train = BASELINE configs[3] (the headline line); stress = configs[4]: B=8/GPU, N=50000, bf16 MLP")
     args = ap.parse_args()
+    global BATCH_PER_GPU, NUM_POINT
+    stress = args.config == "stress"
+    if stress:
+        BATCH_PER_GPU, NUM_POINT = 8, 50000
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(_spawn_ranks(args.gpus, sys.argv[1:]))  # nothing has touched the GPU in this process
@@ -222,7 +229,7 @@ def main():
     from graspbalance_amd.train import Trainer
     _lib.lib()  # fail loudly if the HIP library is missing
 
-    trainer = Trainer(device, distributed=use_dist, time_collectives=use_dist)
+    trainer = Trainer(device, distributed=use_dist, time_collectives=use_dist, mlp_precision="bf16" if stress else "f32")
     seeds = [1000 * rank + i for i in range(BATCH_PER_GPU)]
     batch = make_training_batch(seeds, NUM_POINT, device=device)
 
@@ -280,12 +287,27 @@ def main():
             ms = sum(t for t, _ in ev)
             flop = sum(f for _, f in ev)
             achieved = flop / (ms * 1e-3) / 1e12
+            if stress:
+                # bf16 matrix cores (2.5 PFLOP/s dense) with fp32 tensors in memory: the contraction is bound by
+                # reading X once and writing Y once - algorithmic bytes 4 (P K + P N + K N) per launch
+                byt = sum(4.0 * (m["pkn"][0] * (m["pkn"][1] + m["pkn"][2]) + m["pkn"][1] * m["pkn"][2])
+                          for n in gemm_names for a, b, m in kt.events[n] if m["kernel"] == kernel)
+                gbs = byt / (ms * 1e-3) / 1e9
+                return {"kernel": "%s (v_mfma_f32_32x32x16_bf16, fp32 operands in HBM; %s)" % (kernel, what), "bound": "hbm",
+                        "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                        "traffic": None, "launch_ms": round(ms / len(ev), 4), "launches": len(ev),
+                        "ms_per_step": round(ms / args.steps, 3), "tflops": round(achieved, 1),
+                        "mfma_bf16_frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4)}
             return {"kernel": "%s (v_mfma_f32_32x32x2_f32; %s)" % (kernel, what), "bound": "mfma",
                     "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic(kernel),
                     "launch_ms": round(ms / len(ev), 4), "launches": len(ev),
                     "ms_per_step": round(ms / args.steps, 3), "gflop_per_launch": round(flop / len(ev) / 1e9, 3)}
 
+        if stress:
+            out_metric = "point-clouds/sec fwd+bwd, 50k-pt stress scene (BASELINE configs[4])"
+        else:
+            out_metric = "point-clouds/sec fwd+bwd, 20k-pt GraspNet scene"
         rl_cl = gemm_roofline("gemm_cl_kernel", "LDS-tiled: split-K wgrad, small / unaligned fwd and dgrad")
         rl_rs = gemm_roofline("gemm_rs_kernel", "row-streaming: tall fwd+BN-stats and dgrad+BN-backward sums")
         both = sorted([r for r in (rl_cl, rl_rs) if r], key=lambda r: -r["ms_per_step"])
@@ -303,7 +325,8 @@ def main():
             pruned = _lib._fps_prune and _lib.FPS_PRUNE_MIN_N <= meta["n"] <= _lib.FPS_PRUNE_MAX_N
             kname = "fps_pruned_kernel" if pruned else "fps_reg_kernel<1024, 20>"
             order = "cell-order counting sort" if _lib._fps_cell_order else "Morton keys + sort"
-            what = order + " + fps_pruned_kernel<1024,20>" if pruned else "fps_reg_kernel<1024,20>"
+            pk = "fps_pruned_kernel<1024,20>" if meta["n"] <= 20480 else "fps_pruned_big_kernel (rows streamed from a sorted copy)"
+            what = order + " + " + pk if pruned else "fps_reg_kernel<1024,20>"
             roofline_fps = {"kernel": "%s (furthest_point_sampling %d->%d, b=%d)" % (what, meta["n"], meta["m"], meta["b"]),
                             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(kname),
@@ -363,13 +386,15 @@ def main():
                             "gpairs_per_s": round(pairs / (cyl_ms * 1e-3) / 1e9, 1), "launch_ms": round(cyl_ms, 4),
                             "launches": len(cyl)}
         out = {
-            "metric": "point-clouds/sec fwd+bwd, 20k-pt GraspNet scene",
+            "metric": out_metric,
             "value": round(clouds / elapsed, 3), "unit": "point-clouds/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if stress else "f32",
             "data": "synthetic (make_scene clouds + seeded uniform grasp labels; no dataset available)",
-            "config": {"workload": "configs[3]: GraspBalance train step fwd+bwd+Adam, B=%d/GPU, N=%d points, "
-                                   "8 objects x 300 grasp points x 300 views labels" % (BATCH_PER_GPU, NUM_POINT),
+            "config": {"workload": "%s: GraspBalance train step fwd+bwd+Adam, B=%d/GPU, N=%d points, "
+                                   "8 objects x 300 grasp points x 300 views labels%s"
+                                   % ("configs[4] (stress)" if stress else "configs[3]", BATCH_PER_GPU, NUM_POINT,
+                                      ", bf16 MLP contractions / fp32 geometry, statistics and storage" if stress else ""),
                        "global_batch": world * BATCH_PER_GPU, "parallelism": "dp%d" % world},
             "roofline": roofline,
             "roofline_gemm2": roofline_second,
@@ -387,7 +412,7 @@ def main():
                                 "note": "allreduce_ms = the step's bucket all-reduces back to back with nothing to hide "
                                         "under (median of 5 after the timed region); allreduce_exposed_ms = mean time per "
                                         "timed step the compute stream waited for them (HIP events around the waits)"}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not stress:
             threads = min(os.cpu_count() or 1, 32)
             out["cpu_baseline"] = cpu_baseline(threads, device)
             out["cpu_baseline_dense"] = cpu_baseline_dense(threads, device)

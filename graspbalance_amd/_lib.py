@@ -63,6 +63,8 @@ SIGNATURES = {
     "gb_la_point_grad": [_P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _P, _P],
     "gb_la_wx_grad": [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P],
     "gb_set_reserved_cus": [_I],
+    "gb_set_mlp_precision": [_I],
+    "gb_get_mlp_precision": [],
     "gb_stream_create_cu_mask": [_P, _I, _P],
     "gb_stream_destroy": [_P],
     "gb_device_cu_count": [_P],

@@ -13,6 +13,17 @@ void set_last_error(const char *what, hipError_t err) {
 void clear_last_error() { g_err[0] = 0; }
 }  // namespace gb
 
+namespace gb {
+std::atomic<int> g_mlp_bf16{0};
+}
+
+extern "C" int gb_set_mlp_precision(int precision) {
+  if (precision != GB_PREC_F32 && precision != GB_PREC_BF16) return GB_EINVAL;
+  gb::g_mlp_bf16.store(precision == GB_PREC_BF16 ? 1 : 0, std::memory_order_relaxed);
+  return GB_OK;
+}
+extern "C" int gb_get_mlp_precision(void) { return gb::mlp_bf16() ? GB_PREC_BF16 : GB_PREC_F32; }
+
 extern "C" int gb_abi_version(void) { return GB_ABI_VERSION; }
 extern "C" const char *gb_last_error(void) { return gb::g_err; }
 

@@ -135,7 +135,7 @@ enum { EPI_STORE = 0,
                               //   of the layer whose pre-BN output y has D's shape: dgrad of the next layer)
 
 // D[i,j] = sum_k A[i,k] B[j,k] over k in [kbeg, kend);  D is (a.rows x b.rows) with leading dim ldd
-template <int KA, int KB, bool VA, bool VB, int EPI, int GM, int GN>
+template <int KA, int KB, bool VA, bool VB, int EPI, int GM, int GN, bool BF = false>
 __global__ __launch_bounds__(GTPB) void gemm_cl_kernel(Operand a, Operand b, float *__restrict__ d, long long ldd,
                                                         double *__restrict__ stats, long long kchunk,
                                                         int tiles_n, int stat_slots,
@@ -181,6 +181,26 @@ __global__ __launch_bounds__(GTPB) void gemm_cl_kernel(Operand a, Operand b, flo
       load_frag<KA, VA, GM>(a, m0, k0 + GK, fa);
       load_frag<KB, VB, GN>(b, n0, k0 + GK, fb);
     }
+    if constexpr (BF) {
+      // bf16 matrix cores: ONE v_mfma_f32_32x32x16_bf16 per 32x32 tile and step; a lane supplies the 8 reduction
+      // indices 8*(lane>>5) .. +7 of its row, read as fp32 from the same LDS image and rounded here
+      const float *pa8 = lds_a[buf] + (wm * (GM / 2) + (lane & 31)) * A_RS + 8 * (lane >> 5) * A_KS;
+      const float *pb8 = lds_b[buf] + (wn * (GN / 2) + (lane & 31)) * B_RS + 8 * (lane >> 5) * B_KS;
+      bf16x8 a8[MT], b8[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a8[i][e] = (__bf16)pa8[i * 32 * A_RS + e * A_KS];
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b8[j][e] = (__bf16)pb8[j * 32 * B_RS + e * B_KS];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8[j], acc[i][j], 0, 0, 0);
+    } else {
     const float *pa = lds_a[buf] + (wm * (GM / 2) + (lane & 31)) * A_RS + (lane >> 5) * A_KS;
     const float *pb = lds_b[buf] + (wn * (GN / 2) + (lane & 31)) * B_RS + (lane >> 5) * B_KS;
 #pragma unroll
@@ -195,6 +215,7 @@ __global__ __launch_bounds__(GTPB) void gemm_cl_kernel(Operand a, Operand b, flo
 #pragma unroll
         for (int j = 0; j < NT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
     }
     if (more) {
       if (a.aff) apply_aff<GM>(fa);
@@ -337,13 +358,21 @@ static void launch_tile(const Operand &a, const Operand &b, bool va, bool vb, fl
   const int tiles_n = (int)((b.rows + BN - 1) / BN);
   const long long tiles_m = (a.rows + BM - 1) / BM;
   const dim3 grid((unsigned)(tiles_m * tiles_n), chunks);
-#define GB_L(VA_, VB_)                                                                                          \
-  hipLaunchKernelGGL((gemm_cl_kernel<KA, KB, VA_, VB_, EPI, BM, BN>), grid, dim3(GTPB), 0, s, a, b, d, ldd, stats, \
-                     kchunk, tiles_n, stat_slots, epi_y, epi_ab, epi_w16)
-  if (va && vb) GB_L(true, true);
-  else if (va) GB_L(true, false);
-  else if (vb) GB_L(false, true);
-  else GB_L(false, false);
+  const bool bf = mlp_bf16() && a.red >= 16;  // GB_PREC_BF16; short reductions (xyz-only first layers) stay fp32
+#define GB_L(VA_, VB_, BF_)                                                                                       \
+  hipLaunchKernelGGL((gemm_cl_kernel<KA, KB, VA_, VB_, EPI, BM, BN, BF_>), grid, dim3(GTPB), 0, s, a, b, d, ldd,   \
+                     stats, kchunk, tiles_n, stat_slots, epi_y, epi_ab, epi_w16)
+  if (bf) {
+    if (va && vb) GB_L(true, true, true);
+    else if (va) GB_L(true, false, true);
+    else if (vb) GB_L(false, true, true);
+    else GB_L(false, false, true);
+  } else {
+    if (va && vb) GB_L(true, true, false);
+    else if (va) GB_L(true, false, false);
+    else if (vb) GB_L(false, true, false);
+    else GB_L(false, false, false);
+  }
 #undef GB_L
 }
 

@@ -48,15 +48,21 @@ struct RsArgs {
   int tail_split;       // cut the tiles of a short last round into column groups
 };
 
-template <int NT, int EPI>
+// BF (GB_PREC_BF16): B lives in LDS as bf16 in [k / 8][C32][8] order - the 8 reduction indices one lane feeds to a
+// v_mfma_f32_32x32x16_bf16 are 16 contiguous bytes - and a lane's 16 fp32 values of A become two bf16x8 operands.
+template <int NT, int EPI, bool BF = false>
 __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_BNBWD_X) ? 4 : 2)) void gemm_rs_kernel(RsArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int C32 = NT * 32;
   const int rpad = g.nch * RS_CH;
-  float *Bs = lds;                        // [rpad][C32]
-  float *s_aff = lds + (size_t)rpad * C32;  // [2][rpad]
+  float *Bs = lds;                        // fp32: [rpad][C32] ; bf16: [rpad / 8][C32][8] (half the bytes)
+  float *s_aff = lds + (size_t)rpad * C32 / (BF ? 2 : 1);  // [2][rpad]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int m = lane & 31, h = lane >> 5;
+  auto put_b = [&](int r, int c, float v) {
+    if constexpr (BF) reinterpret_cast<__bf16 *>(lds)[((size_t)(r >> 3) * C32 + c) * 8 + (r & 7)] = (__bf16)v;
+    else Bs[(size_t)r * C32 + c] = v;
+  };
 
   // ---- stage B (zero padded); consecutive threads write consecutive columns: conflict-free.  Four 16-byte loads per
   // thread are issued back to back from clamped (always valid) addresses before anything uses them - with a load
@@ -78,10 +84,10 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
         const int i = i0 + u * RS_TPB;
         if (i < total) {
           const int c = i % C32, r = (i / C32) * 4;
-          Bs[(r + 0) * C32 + c] = v[u].x;
-          Bs[(r + 1) * C32 + c] = v[u].y;
-          Bs[(r + 2) * C32 + c] = v[u].z;
-          Bs[(r + 3) * C32 + c] = v[u].w;
+          put_b(r + 0, c, v[u].x);
+          put_b(r + 1, c, v[u].y);
+          put_b(r + 2, c, v[u].z);
+          put_b(r + 3, c, v[u].w);
         }
       }
     }
@@ -101,13 +107,22 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int i = i0 + u * RS_TPB;
-        if (i < total) *reinterpret_cast<float4 *>(Bs + (size_t)(i / Q) * C32 + (i % Q) * 4) = v[u];
+        if (i < total) {
+          if constexpr (BF) {
+            put_b(i / Q, (i % Q) * 4 + 0, v[u].x);
+            put_b(i / Q, (i % Q) * 4 + 1, v[u].y);
+            put_b(i / Q, (i % Q) * 4 + 2, v[u].z);
+            put_b(i / Q, (i % Q) * 4 + 3, v[u].w);
+          } else {
+            *reinterpret_cast<float4 *>(Bs + (size_t)(i / Q) * C32 + (i % Q) * 4) = v[u];
+          }
+        }
       }
     }
   } else {
     for (int i = t; i < rpad * C32; i += RS_TPB) {
       const int c = i % C32, r = i / C32;
-      Bs[i] = (r < g.R && c < g.C) ? g.w[(size_t)r * g.C + c] : 0.f;
+      put_b(r, c, (r < g.R && c < g.C) ? g.w[(size_t)r * g.C + c] : 0.f);
     }
   }
   if (g.aff)
@@ -245,6 +260,25 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
             }
         }
       }
+      if constexpr (BF) {
+        // this lane's 16 reduction indices kc*32 + h*16 + (0..15) = the two k-groups kc*4 + 2h + {0, 1}
+        bf16x8 a8[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a8[u][e] = (__bf16)av[8 * u + e];
+        const bf16x8 *bp8 = reinterpret_cast<const bf16x8 *>(lds) + (size_t)(kc * 4 + 2 * h) * C32 + m;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          bf16x8 b8[NT];
+#pragma unroll
+          for (int q = 0; q < NT; ++q)
+            if (in(q)) b8[q] = bp8[u * C32 + q * 32];
+#pragma unroll
+          for (int q = 0; q < NT; ++q)
+            if (in(q)) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[u], b8[q], acc[q], 0, 0, 0);
+        }
+      } else {
       const float *bp = Bs + (size_t)(kc * RS_CH + h * 16) * C32 + m;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
@@ -255,6 +289,7 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
 #pragma unroll
         for (int q = 0; q < NT; ++q)
           if (in(q)) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[q], acc[q], 0, 0, 0);
+      }
       }
 
       if (kc == g.nch - 1) {
@@ -387,16 +422,31 @@ static bool rs_enabled() {
   return on != 0;
 }
 
-template <int NT, int EPI>
-static void rs_launch(const RsArgs &g, size_t lds_bytes, int blocks_per_cu, hipStream_t s) {
+template <int NT, int EPI, bool BF>
+static void rs_launch_p(const RsArgs &g, size_t lds_bytes, int blocks_per_cu, hipStream_t s) {
   static std::atomic<unsigned long long> attr_set{0};
-  auto kern = gemm_rs_kernel<NT, EPI>;
+  auto kern = gemm_rs_kernel<NT, EPI, BF>;
   allow_dynamic_lds(kern, 160 * 1024, attr_set);
   const long long ntiles = (g.P + 31) / 32;
   long long blocks = ntiles;  // at least one tile per workgroup; all 512 threads stage B either way
   const long long cap = (long long)num_cus() * blocks_per_cu;
   if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(RS_TPB), lds_bytes, s, g);
+}
+
+template <int NT, int EPI>
+static void rs_launch(const RsArgs &g, size_t lds_bytes, int blocks_per_cu, hipStream_t s) {
+  if (mlp_bf16()) {
+    // bf16 image of B = half the bytes (+ the affine table); never below what the closing column reduction
+    // ([waves][sums per column][C32] doubles in the same LDS) needs
+    const size_t b_fp32 = (size_t)g.nch * RS_CH * NT * 32 * sizeof(float);
+    size_t need = lds_bytes - b_fp32 / 2;
+    const size_t red = (size_t)RS_WAVES * (EPI == RS_BNBWD_X ? 5 : 2) * NT * 32 * sizeof(double);
+    if (EPI != RS_STORE && need < red) need = red;
+    rs_launch_p<NT, EPI, true>(g, need, blocks_per_cu, s);
+  } else {
+    rs_launch_p<NT, EPI, false>(g, lds_bytes, blocks_per_cu, s);
+  }
 }
 
 // shape part of the dispatch rule (pointer alignment aside); nt_out = column tiles of the instantiation

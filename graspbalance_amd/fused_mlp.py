@@ -44,6 +44,22 @@ def set_enabled(flag):
     _ENABLED = bool(flag)
 
 
+def set_precision(precision):
+    """'f32' (default: exact fp32 MFMA) or 'bf16' (BASELINE configs[4], "mixed bf16 MLP / fp32 geometry"): every GEMM
+    of the fused SharedMLP path rounds its operands to bf16 on the way into the matrix cores and accumulates in fp32;
+    BatchNorm statistics, element-wise passes, geometry and all tensors in HBM stay fp32 (gb_set_mlp_precision).
+    Process-wide; returns the previous setting."""
+    lib = _lib.lib()
+    prev = "bf16" if lib.gb_get_mlp_precision() == 1 else "f32"
+    code = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}[str(precision).replace("torch.", "")]
+    _lib.check(lib.gb_set_mlp_precision(code), "gb_set_mlp_precision")
+    return prev
+
+
+def get_precision():
+    return "bf16" if _lib.lib().gb_get_mlp_precision() == 1 else "f32"
+
+
 def set_own_gemm(flag):
     global _OWN_GEMM
     _OWN_GEMM = bool(flag)

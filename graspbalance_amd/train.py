@@ -23,9 +23,11 @@ BN_MOMENTUM_MAX = 0.001
 class Trainer:
     def __init__(self, device, learning_rate=0.001, weight_decay=0.0, bn_decay_step=2, bn_decay_rate=0.5,
                  steps_per_epoch=100, max_epoch=18, num_view=300, seed=1234, distributed=False,
-                 bucket_mb=16.0, model=None, time_collectives=False, prefetch_sampling=True):
+                 bucket_mb=16.0, model=None, time_collectives=False, prefetch_sampling=True, mlp_precision=None):
         torch.manual_seed(seed)
         self.device = torch.device(device)
+        if mlp_precision is not None and self.device.type == "cuda":
+            fused_mlp.set_precision(mlp_precision)  # 'bf16': BASELINE configs[4] (process-wide switch of the GEMMs)
         self.net = model if model is not None else GraspBalance(
             input_feature_dim=0, num_view=num_view, num_angle=12, num_depth=4, cylinder_radius=0.08,
             hmin=-0.02, hmax_list=[0.01, 0.02, 0.03, 0.04])

@@ -174,6 +174,16 @@ int gb_knn1(const float *ref, const float *query, int64_t *idx, int b, int dim, 
 int gb_label_gather(const float *const *srcs, int nsrc, const int32_t *obj, const int32_t *pt,
                     const int64_t *view_inds, float *out, float *out_max, float *out_col, int col_stride,
                     int col_off, int R, int V, int W, void *stream);
+/* Precision of the SharedMLP contractions (gb_gemm_*): GB_PREC_F32 (default; exact fp32 MFMA, the 1e-5-parity
+ * configurations) or GB_PREC_BF16 (BASELINE configs[4], "mixed bf16 MLP / fp32 geometry"): operands are rounded to
+ * bf16 on their way into the matrix cores, accumulation, BatchNorm statistics and all tensors in memory stay fp32;
+ * reductions shorter than 16 stay fp32.  Process-wide; replaces what the reference would get from torch autocast
+ * around pytorch_utils.py:61-113.                                                                               */
+#define GB_PREC_F32 0
+#define GB_PREC_BF16 1
+int gb_set_mlp_precision(int precision);
+int gb_get_mlp_precision(void);
+
 /* A stream whose kernels may only run on the compute units set in cu_mask (`words` 32-bit words, bit i = CU i);
  * gb_stream_destroy releases it; gb_device_cu_count reports the current device's CU count.  prefetch.py splits
  * the chip with two such streams: B CUs for the next batch's furthest-point sampling, the rest for the step.   */

@@ -706,15 +706,96 @@ class RowSet:
         self.R, self.D, self.P_total = int(R), int(D), int(P_total)
 
 
+class _ZeroGradFor(Function):
+    """Identity on x that also hands zero gradients to `params`: a convolution bias directly in front of a
+    batch-statistics BatchNorm has an exactly zero gradient (the normalisation removes it), but the parameter must
+    still RECEIVE one - optimizers and the gradient all-reduce count arrivals."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        ctx.shapes = [(p.shape, p.dtype, p.device) for p in params]
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g,) + tuple(torch.zeros(sh, dtype=dt, device=dev) for sh, dt, dev in ctx.shapes)
+
+
 def _stack(X, convs_bns, pool_ns=0, residual=None, relu_last=True, rows=None):
-    params, layers = [], []
+    """conv (1x1) + BatchNorm stacks on rows.  A conv WITH bias (the grasp heads, modules.py:49-175) is run without it:
+    in front of BatchNorm the bias only shifts the batch mean, i.e. training outputs are unchanged and the running mean
+    moves by momentum * bias (applied afterwards); in eval mode it is folded into the running mean handed to the
+    finalisation."""
+    params, layers, biased, shifts = [], [], [], []
     for conv, bn in convs_bns:
-        if conv.bias is not None:
-            raise NotImplementedError("fused path expects bias-free convs followed by BatchNorm")
         _count_batch(bn)
         params += [conv.weight.view(conv.weight.shape[0], -1), bn.weight, bn.bias]
-        layers.append(_LayerCfg(bn))
-    return MLPStack.apply(X, residual, layers, pool_ns, relu_last, rows, *params)
+        cfg = _LayerCfg(bn)
+        if conv.bias is not None:
+            biased.append(conv.bias)
+            if cfg.training:
+                if cfg.running_mean is not None:
+                    shifts.append((bn.running_mean, conv.bias.detach(), cfg.momentum))
+            else:
+                cfg.running_mean = bn.running_mean - conv.bias.detach()
+        layers.append(cfg)
+    out = MLPStack.apply(X, residual, layers, pool_ns, relu_last, rows, *params)
+    for running_mean, bias, momentum in shifts:
+        running_mean.add_(bias, alpha=momentum)
+    if biased and any(b.requires_grad for b in biased) and out.requires_grad:
+        out = _ZeroGradFor.apply(out, *biased)
+    return out
+
+
+class LinearBias(Function):
+    """Y = X W^T + b on rows (a 1x1 convolution with bias and no normalisation: the last layer of the grasp heads,
+    the scale-fusion and gate convolutions) on the hand-written GEMMs.  forward(ctx, X (P,K), W (N,K), b (N)|None)."""
+
+    @staticmethod
+    def forward(ctx, X, W, b):
+        dev = X.device
+        st = _s(X)
+        X, W = X.contiguous(), W.contiguous()
+        P, K = X.shape
+        N = W.shape[0]
+        Y = torch.empty((P, N), dtype=torch.float32, device=dev)
+        _call("gb_gemm_fwd", dev, _lib.ptr(X), _lib.ptr(W), None, _lib.ptr(Y), None, 1, P, K, N, None, st,
+              meta=_gemm_meta("fwd", P, K, N))
+        if b is not None:
+            ab = torch.cat([torch.ones_like(b), b.detach()])
+            _call("gb_affine_act", dev, _lib.ptr(Y), _lib.ptr(ab), None, _lib.ptr(Y), P, N, 0, st)  # in place: y += b
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(X, W)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        X, W = ctx.saved_tensors
+        dev = dY.device
+        st = _s(dY)
+        dY = dY.contiguous()
+        P, K = X.shape
+        N = W.shape[0]
+        dX = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dX = torch.empty((P, K), dtype=torch.float32, device=dev)
+            _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dX), None, None, None, 0, P, K, N, None, None,
+                  None, st, meta=_gemm_meta("dgrad", P, K, N))
+        if ctx.needs_input_grad[1]:
+            dW = torch.zeros((N, K), dtype=torch.float32, device=dev)
+            _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(X), None, _lib.ptr(dW), P, K, N, st,
+                  meta=_gemm_meta("wgrad", P, K, N))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            sums = _zeros64(2 * N, dev)
+            _call("gb_col_stats", dev, _lib.ptr(dY), P, N, _lib.ptr(sums), None, st)
+            db = sums[:N].float()
+        return dX, dW, db
+
+
+def linear_bias(X, conv):
+    """A 1x1 Conv1d / Conv2d (with or without bias) applied to rows X (P, Cin) -> (P, Cout)."""
+    W = conv.weight.view(conv.weight.shape[0], -1)
+    return LinearBias.apply(X, W, conv.bias)
 
 
 def conv_bn_act(X, conv, bn, relu=True, pool_ns=0, residual=None):
@@ -724,7 +805,7 @@ def conv_bn_act(X, conv, bn, relu=True, pool_ns=0, residual=None):
         return _stack(X, [(conv, bn)], pool_ns=pool_ns, residual=residual, relu_last=relu)
     W = conv.weight.view(conv.weight.shape[0], -1)
     if conv.bias is not None:
-        raise NotImplementedError("fused path expects bias-free convs followed by BatchNorm")
+        raise NotImplementedError("the torch.mm comparison path expects bias-free convs followed by BatchNorm")
     _count_batch(bn)
     momentum = 0.0 if bn.momentum is None else bn.momentum
     training = bn.training or not bn.track_running_stats

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import fused_mlp, fused_ops
+from . import fused_mlp, fused_ops, modules
 from .drp import DRP
 from .label_generation import match_grasp_view_and_label, process_grasp_labels
 from .loss_utils import GRASP_MAX_TOLERANCE, GRASP_MAX_WIDTH, batch_viewpoint_params_to_matrix
@@ -111,6 +111,19 @@ class GraspPoseStage2_seed_features_multi_scale(nn.Module):
         else:
             cl = False
             scales = [g(seed_xyz, pointcloud, rot) for g in groups]
+        seed_features = end_points['fp2_features']
+        if cl and modules._HEADS_FUSED and seed_features.dtype == torch.float32:
+            # the whole tail on channel-last rows and the hand-written GEMMs: fuse convolution over the concatenated
+            # scales, sigmoid gate of the seed features, broadcast add over the depths - the depth heads then take the
+            # rows as they are (modules.RowsView), nothing is laid out channel-major in between
+            B, num_seed, num_depth = seed_xyz.size(0), seed_xyz.size(1), len(g0.hmax_list)
+            fused = fused_mlp.linear_bias(torch.cat(scales, dim=1), self.fuse_multi_scale)          # (B*Ns*D, 256)
+            seed_rows = seed_features.transpose(1, 2).reshape(B * num_seed, -1)
+            gated = torch.sigmoid(fused_mlp.linear_bias(seed_rows, self.gate_fusion[0])) * seed_rows   # (B*Ns, 256)
+            rows = (fused.view(B * num_seed, num_depth, -1) + gated.unsqueeze(1)).view(B * num_seed * num_depth, -1)
+            vp_features = modules.RowsView(rows, B, num_seed, num_depth)
+            end_points = self.GraspParameters(vp_features, end_points)
+            return self.tolerance(vp_features, end_points)
         if cl:
             # the 1x1 fuse convolution on the channel-last rows (b, seed, depth): cat along the channels + one linear,
             # then ONE transpose to the reference layout instead of four (one per scale) before the cat
@@ -122,7 +135,6 @@ class GraspPoseStage2_seed_features_multi_scale(nn.Module):
             B, _, num_seed, num_depth = scales[0].size()
             fused = self.fuse_multi_scale(torch.cat(scales, dim=1).view(B, -1, num_seed * num_depth))
             fused = fused.view(B, -1, num_seed, num_depth)
-        seed_features = end_points['fp2_features']
         gated = self.gate_fusion(seed_features) * seed_features
         vp_features = fused + gated.unsqueeze(3).repeat(1, 1, 1, 4)
         end_points = self.GraspParameters(vp_features, end_points)

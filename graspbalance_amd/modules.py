@@ -1,6 +1,8 @@
 """Grasp heads and seed re-sampling with the names / parameters of the reference's
 TrainModel/modules.py (ForegroundSampling :19, GraspableDetection :49, GraspWidthGrouping :89,
 GraspPoseParametersDetection :127, ToleranceNet :155, ObjectBalanceSampling :178)."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -97,6 +99,33 @@ def ObjectBalanceSampling(end_points):
     return _resample_seeds(end_points, picks)
 
 
+# Which grasp heads run on the fused channel-last stack (own MFMA GEMMs) instead of Conv1d / BatchNorm1d through
+# torch: "0" = none (default), "gd" = GraspableDetection, "1" = also the stage-2 tail (scale fusion, gate, the two
+# depth heads).  Measured on one box (tools/ab_bench.sh, ms per step): none 22.6, gd 22.8-23.2, all 23.6-24.7 - the
+# 4 096 / 16 384-row products of the heads are too short for the row-streaming GEMM and too few for the tiled one
+# (MIOpen / rocBLAS are no faster per product, but their conv+BN+ReLU take fewer passes) - and the tail on own
+# kernels moves the grasp scores from 7e-6 to 9e-6..1.5e-5 of the fp64 truth.  The path stays available and tested
+# (tests/test_reference_fixtures_gpu.py) for hosts where launch count matters more than GPU time.
+_HEADS_MODE = os.environ.get("GB_HEADS_FUSED", "0")
+_HEADS_FUSED = _HEADS_MODE == "1"
+_GD_FUSED = _HEADS_MODE in ("1", "gd")
+
+
+def _bn_fusable(*bns):
+    return all(not (bn.momentum is None and bn.track_running_stats) for bn in bns)
+
+
+class RowsView:
+    """The (B, C, num_seed, num_depth) view-point features kept as channel-last rows (B*num_seed*num_depth, C): what the
+    fused stage-2 tail hands to the fused depth heads, so the tensor is never laid out channel-major in between."""
+
+    def __init__(self, rows, B, num_seed, num_depth):
+        self.rows, self._size = rows, (B, rows.shape[1], num_seed, num_depth)
+
+    def size(self):
+        return self._size
+
+
 class GraspableDetection(nn.Module):
     """Per-seed objectness (2) + approach-view scores (num_view); picks the top view's rotation."""
 
@@ -115,18 +144,34 @@ class GraspableDetection(nn.Module):
         """(scores, indices) of every seed's best approach view (modules.py:74: torch.max over the views)."""
         return torch.max(view_score, dim=2)
 
+    def _fused_ok(self, x):
+        return _GD_FUSED and fused_mlp.enabled(x) and x.dtype == torch.float32 and _bn_fusable(self.bn1, self.bn2)
+
     def forward(self, seed_xyz, seed_features, end_points, record=True):
         B, num_seed, _ = seed_xyz.size()
+        if self._fused_ok(seed_features):
+            # channel-last rows (b, seed): conv1+bn1+ReLU, conv2+bn2+ReLU as one fused stack, conv3 as GEMM + bias
+            rows = seed_features.transpose(1, 2).reshape(B * num_seed, -1)
+            rows = fused_mlp.conv_bn_act_chain(rows, [(self.conv1, self.bn1), (self.conv2, self.bn2)])
+            rows = fused_mlp.linear_bias(rows, self.conv3).view(B, num_seed, -1)
+            if record == False:  # noqa: E712
+                return rows.transpose(1, 2).contiguous()
+            view_score = rows[:, :, 2:2 + self.num_view].contiguous()       # == features[:, 2:].transpose(1, 2)
+            objectness = rows[:, :, :2].transpose(1, 2).contiguous()
+            return self._record(end_points, rows.device, B, num_seed, objectness, view_score)
         features = F.relu(self.bn1(self.conv1(seed_features)), inplace=True)
         features = F.relu(self.bn2(self.conv2(features)), inplace=True)
         features = self.conv3(features)
         if record == False:  # noqa: E712  (the reference tests equality with False)
             return features
         view_score = features[:, 2:2 + self.num_view, :].transpose(1, 2).contiguous()
-        end_points['objectness_score'] = features[:, :2, :]
+        return self._record(end_points, features.device, B, num_seed, features[:, :2, :], view_score)
+
+    def _record(self, end_points, device, B, num_seed, objectness, view_score):
+        end_points['objectness_score'] = objectness
         end_points['view_score'] = view_score
         top_view_scores, top_view_inds = self._top_view(view_score)
-        template_views = grasp_views_on(features.device, self.num_view)  # (V,3)
+        template_views = grasp_views_on(device, self.num_view)  # (V,3)
         vp_xyz = template_views[top_view_inds]  # (B,num_seed,3) == gather of the expanded templates
         batch_angle = torch.zeros(B * num_seed, dtype=vp_xyz.dtype, device=vp_xyz.device)
         vp_rot = batch_viewpoint_params_to_matrix(-vp_xyz.view(-1, 3), batch_angle).view(B, num_seed, 3, 3)
@@ -201,8 +246,20 @@ class _DepthHead(nn.Module):
         self.bn1 = nn.BatchNorm1d(128)
         self.bn2 = nn.BatchNorm1d(128)
 
+    def _run_rows(self, rows, B, num_seed, num_depth):
+        """rows (B*num_seed*num_depth, 256) channel-last -> (B, out, num_seed, num_depth) like _run."""
+        x = fused_mlp.conv_bn_act_chain(rows, [(self.conv1, self.bn1), (self.conv2, self.bn2)])
+        x = fused_mlp.linear_bias(x, self.conv3)
+        return x.view(B, num_seed, num_depth, -1).permute(0, 3, 1, 2).contiguous()
+
     def _run(self, vp_features):
         B, _, num_seed, num_depth = vp_features.size()
+        if isinstance(vp_features, RowsView):
+            return self._run_rows(vp_features.rows, B, num_seed, num_depth)
+        if (_HEADS_FUSED and fused_mlp.enabled(vp_features) and vp_features.dtype == torch.float32
+                and _bn_fusable(self.bn1, self.bn2)):
+            rows = vp_features.permute(0, 2, 3, 1).reshape(B * num_seed * num_depth, -1)
+            return self._run_rows(rows, B, num_seed, num_depth)
         x = vp_features.view(B, -1, num_seed * num_depth)
         x = F.relu(self.bn1(self.conv1(x)), inplace=True)
         x = F.relu(self.bn2(self.conv2(x)), inplace=True)

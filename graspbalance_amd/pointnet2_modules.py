@@ -14,9 +14,14 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import os
+
 from . import fused_mlp
 from . import pointnet2_utils
 from . import pytorch_utils as pt_utils
+
+
+_FP_FUSED = os.environ.get("GB_FP_FUSED", "1") != "0"  # A/B switch: feature-propagation MLPs on the fused stack
 
 
 def _sample_centres(xyz, npoint, inds=None):
@@ -264,6 +269,13 @@ class PointnetFPModule(nn.Module):
             new_features = torch.cat([interpolated_feats, unknow_feats], dim=1)  # (B, C2 + C1, n)
         else:
             new_features = interpolated_feats
+        if _FP_FUSED and fused_mlp.enabled(new_features) and fused_mlp.supports(self.mlp):
+            # the SharedMLP as one fused stack on channel-last rows (own MFMA GEMMs, BatchNorm statistics out of
+            # their epilogues) instead of Conv2d / BatchNorm2d / ReLU launches on (B,C,n,1)
+            B, C, n = new_features.shape
+            rows = new_features.transpose(1, 2).reshape(B * n, C)
+            out = fused_mlp.shared_mlp_cl(rows, self.mlp)
+            return out.view(B, n, -1).transpose(1, 2).contiguous()
         return self.mlp(new_features.unsqueeze(-1)).squeeze(-1)
 
 

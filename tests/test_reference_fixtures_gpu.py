@@ -103,6 +103,17 @@ def test_heads_match_reference_gpu(golden):
     assert_errors(errs, {}, 1e-5)
 
 
+def test_heads_on_the_fused_stack_match_reference_gpu(golden, monkeypatch):
+    """The optional own-kernel execution of the heads (GB_HEADS_FUSED=1: conv+bias in front of BatchNorm folded,
+    LinearBias for the last layers) against the same reference-run fixture."""
+    from graspbalance_amd import modules
+    monkeypatch.setattr(modules, "_HEADS_FUSED", True)
+    monkeypatch.setattr(modules, "_GD_FUSED", True)
+    errs = cases.run_heads_case(DEV, golden.load("g17_heads"))
+    _report("heads (fused stack)", errs)
+    assert_errors(errs, {}, 1e-5)
+
+
 # Bounds = about 3x what MI355X measures (printed by the test; DESIGN.md section 3 keeps the table): relative L2 of
 # the HIP path vs the reference's own CPU run.  Eval mode meets north_star's 1e-5 on every tensor.  Train mode
 # (batch statistics at B = 2) amplifies last-bit differences level by level - sa1 2.8e-6, sa2 5.6e-5, sa3 6e-4,

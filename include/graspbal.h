@@ -174,6 +174,27 @@ int gb_knn1(const float *ref, const float *query, int64_t *idx, int b, int dim, 
 int gb_label_gather(const float *const *srcs, int nsrc, const int32_t *obj, const int32_t *pt,
                     const int64_t *view_inds, float *out, float *out_max, float *out_col, int col_stride,
                     int col_off, int R, int V, int W, void *stream);
+/* ---- host data path on the GPU (reference data_utils.py:14-72, graspnet_dataset.py:110-136) ----
+ * A depth frame becomes the network's input cloud without leaving the device: three passes over the H*W pixels.
+ * depth: (H,W) uint16 (depth_is_u16 = 1) or float32; cam5 = HOST [fx, fy, cx, cy, scale] doubles (CameraInfo);
+ * trans12 = HOST 3x4 row-major transform (cam0_wrt_table . camera_pose, graspnet_dataset.py:121) or NULL.
+ * Arithmetic in float64 in numpy's operation order; the cloud is rounded to float32 on output (:136).
+ *   gb_frame_cloud : cloud (H*W,3) f32 (may be NULL) = create_point_cloud_from_depth_image (data_utils.py:14-25);
+ *                    box (6 x uint64, caller-initialised to {~0,~0,~0,0,0,0}; may be NULL) = order-preserving keys of
+ *                    the min / max of the TRANSFORMED points with seg > 0 (get_workspace_mask :61-63; seg (H,W) int32)
+ *   gb_frame_mask  : mask (H*W) u8 (may be NULL) = workspace mask (:64-67: strictly inside the box widened by
+ *                    `outlier`; box NULL: depth > 0), counts (one int32 per 256 pixels) = kept pixels per workgroup,
+ *                    kept = depth > 0 & workspace mask (graspnet_dataset.py:118-124)
+ *   gb_frame_compact: out_idx[offsets[wg] + rank] = pixel index of every kept pixel in pixel order
+ *                    (== np.nonzero(mask): `cloud[mask]` :125 is a gather with it); offsets = exclusive scan of counts */
+int gb_frame_cloud(const void *depth, int depth_is_u16, const int32_t *seg, const double *cam5,
+                   const double *trans12, int H, int W, float *cloud, unsigned long long *box, void *stream);
+int gb_frame_mask(const void *depth, int depth_is_u16, const double *cam5, const double *trans12, int H, int W,
+                  const unsigned long long *box, double outlier, uint8_t *mask, int32_t *counts, void *stream);
+int gb_frame_compact(const void *depth, int depth_is_u16, const double *cam5, const double *trans12, int H, int W,
+                     const unsigned long long *box, double outlier, const int64_t *offsets, int32_t *out_idx,
+                     void *stream);
+
 /* Precision of the SharedMLP contractions (gb_gemm_*): GB_PREC_F32 (default; exact fp32 MFMA, the 1e-5-parity
  * configurations) or GB_PREC_BF16 (BASELINE configs[4], "mixed bf16 MLP / fp32 geometry"): operands are rounded to
  * bf16 on their way into the matrix cores, accumulation, BatchNorm statistics and all tensors in memory stay fp32;

@@ -295,6 +295,74 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
       if (kc == g.nch - 1) {
         // acc[q][r] = D[tile*32 + (r&3) + 8*(r>>2) + 4*h][q*32 + m]
         const long long row0 = tile * 32 + 4 * h;
+        // Full tiles (all 32 rows and all NT*32 columns valid - every tile but the last of the usual shapes) skip the
+        // per-element bounds checks and 64-bit index arithmetic: one uniform row pointer per accumulator register plus a
+        // 32-bit lane offset.  (The generic path spent ~16 vector instructions per stored element on them: ~10 k cycles
+        // per tile beside 32 k cycles of MFMA.)
+        const bool full = tile * 32 + 32 <= g.P && g.C == C32;
+        if (full) {
+          const unsigned lane_off = (unsigned)(4 * h) * (unsigned)g.ldd + (unsigned)m;
+          // the tile index is the same in every lane, but derived from threadIdx: tell the compiler (scalar registers,
+          // scalar address arithmetic, stores of the form  scalar base + 32-bit lane offset)
+          const long long trow = (long long)__builtin_amdgcn_readfirstlane((int)tile) * 32;
+          bool weighted = false;
+          if constexpr (EPI == RS_STATS) weighted = g.epi_w16 != nullptr;
+#pragma unroll
+          for (int q = 0; q < NT; ++q) {
+            if (!in(q)) continue;
+            float cs = 0.f, cq = 0.f, ct[3] = {0.f, 0.f, 0.f};
+            if constexpr (BNB && !COEF_REGS) {
+              const int col = q * 32 + m;
+              ea[q] = g.epi_ab[col];
+              eb[q] = g.epi_ab[g.C + col];
+              em[q] = g.epi_ab[2 * g.C + col];
+              er[q] = g.epi_ab[3 * g.C + col];
+            }
+            float yq[16];
+            if constexpr (BNB && !YPRE) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const float *yp = g.epi_y + (trow + (r & 3) + 8 * (r >> 2)) * (long long)g.ldd + q * 32;
+                yq[r] = yp[lane_off];
+              }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float v = acc[q][r];
+              if constexpr (EPI != RS_BNBWD_X) {
+                float *dp = g.d + (trow + (r & 3) + 8 * (r >> 2)) * (long long)g.ldd + q * 32;  // wave-uniform
+                dp[lane_off] = v;
+              }
+              if constexpr (EPI == RS_STATS) {
+                if (weighted) {
+                  const unsigned pk = (r & 2) ? wq[r >> 2].y : wq[r >> 2].x;
+                  const float wv = (float)((r & 1) ? (pk >> 16) : (pk & 0xFFFFu)) * v;
+                  cs += wv;
+                  cq += wv * v;
+                } else {
+                  cs += v;
+                  cq += v * v;
+                }
+              }
+              if constexpr (BNB) {
+                const float y = YPRE ? yv[YPRE ? q : 0][r] : yq[r];
+                const float gg = (ea[q] * y + eb[q]) > 0.f ? v : 0.f;
+                cs += gg;
+                cq += gg * ((y - em[q]) * er[q]);
+                if constexpr (EPI == RS_BNBWD_X) {
+#pragma unroll
+                  for (int j = 0; j < 3; ++j) ct[j] += gg * xr[r][j];
+                }
+              }
+              acc[q][r] = 0.f;
+            }
+            if constexpr (EPI != RS_STORE) { dsum[q] += (double)cs; dsq[q] += (double)cq; }
+            if constexpr (EPI == RS_BNBWD_X) {
+#pragma unroll
+              for (int j = 0; j < 3; ++j) dtx[q][j] += (double)ct[j];
+            }
+          }
+        } else {
 #pragma unroll
         for (int q = 0; q < NT; ++q) {
           if (!in(q)) continue;
@@ -350,6 +418,7 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
 #pragma unroll
             for (int j = 0; j < 3; ++j) dtx[q][j] += (double)ct[j];
           }
+        }
         }
       }
       if (!more) break;

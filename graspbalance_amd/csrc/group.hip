@@ -421,10 +421,18 @@ __global__ __launch_bounds__(TPB) void label_gather_kernel(const LabelSrcTable s
       reinterpret_cast<float4 *>(dst)[e] = x;
       if (dcol) {
         const float xv[4] = {x.x, x.y, x.z, x.w};
+        if (col_stride == 3) {  // the offsets tensor (angle, depth, width): constant divisor, no integer division
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int i = 4 * q + t;
-          if (i % col_stride == col_off) dcol[(size_t)v * wc + i / col_stride] = xv[t];
+          for (int t = 0; t < 4; ++t) {
+            const unsigned i = 4u * (unsigned)q + t;
+            if (i % 3u == (unsigned)col_off) dcol[(size_t)v * wc + i / 3u] = xv[t];
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int i = 4 * q + t;
+            if (i % col_stride == col_off) dcol[(size_t)v * wc + i / col_stride] = xv[t];
+          }
         }
       }
       if (out_max) {

@@ -297,10 +297,17 @@ def test_label_finish_matches_torch_composition():
     out = torch.empty_like(labels)
     vs = torch.empty(B, Ns, V, device="cuda:0")
     va = torch.empty(B, Ns, V, dtype=torch.int32, device="cuda:0")
-    _lib.check(_lib.lib().gb_label_finish(_lib.ptr(labels), _lib.ptr(offsets), _lib.ptr(u_max), float(GRASP_MAX_WIDTH),
-                                          _lib.ptr(out), _lib.ptr(vs), _lib.ptr(va), B * Ns * V, A * D, None),
-               "label_finish")
+    _lib.check(_lib.lib().gb_label_finish(_lib.ptr(labels), _lib.ptr(offsets), None, _lib.ptr(u_max),
+                                          float(GRASP_MAX_WIDTH), _lib.ptr(out), _lib.ptr(vs), _lib.ptr(va), B * Ns * V,
+                                          A * D, None), "label_finish")
+    # the same from a contiguous width column (what gb_label_gather's out_col provides), offsets not read at all
+    widths = offsets[..., 2].contiguous()
+    out2, vs2, va2 = torch.empty_like(out), torch.empty_like(vs), torch.empty_like(va)
+    _lib.check(_lib.lib().gb_label_finish(_lib.ptr(labels), None, _lib.ptr(widths), _lib.ptr(u_max),
+                                          float(GRASP_MAX_WIDTH), _lib.ptr(out2), _lib.ptr(vs2), _lib.ptr(va2), B * Ns * V,
+                                          A * D, None), "label_finish")
     torch.cuda.synchronize()
+    assert torch.equal(out2, out) and torch.equal(vs2, vs) and torch.equal(va2, va)
     mask = (labels > 0) & (offsets[..., 2] <= GRASP_MAX_WIDTH)
     ref = labels.clone()
     ref[mask] = torch.log(u_max / ref[mask])

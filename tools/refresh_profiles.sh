@@ -8,7 +8,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles_new
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o bench -- python3 bench.py > $OUT/bench_line_under_rocprof.json 2> $OUT/kt.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o bench -- python3 bench.py --no-cpu-baseline > $OUT/bench_line_under_rocprof.json 2> $OUT/kt.log
 tail -1 $OUT/bench_line_under_rocprof.json > $OUT/line.tmp && mv $OUT/line.tmp $OUT/bench_line_under_rocprof.json
 cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 python3 tools/prof_summary.py $OUT/kernel_stats.csv 10 30 > $OUT/kernel_stats_summary.txt

@@ -16,6 +16,8 @@
 // 17 floats: the 32 lanes of a half-wave read one column of 32 rows -> 32 distinct banks), double
 // buffered, filled through registers one step ahead of the MFMAs.  The contraction is compute-bound
 // (16 KB of operands per 4.2 MFLOP), so plain ds_read_b32 operand fetches are off the critical path.
+#include <stdlib.h>
+
 #include "gb_common.h"
 #include "gemm_rs.h"
 
@@ -535,7 +537,13 @@ extern "C" int gb_gemm_wgrad(const float *dy, const float *x, const float *x_aff
   const long long tiles = (long long)((N + (N <= 64 ? 63 : 127)) / (N <= 64 ? 64 : 128)) *
                           ((K + (K <= 64 ? 63 : 127)) / (K <= 64 ? 64 : 128));
   // split the P reduction so that ~1024 workgroups exist, chunks a multiple of the reduction step
-  long long chunks = 1024 / tiles;
+  static int target_blocks = 0;
+  if (!target_blocks) {
+    const char *e = getenv("GB_WGRAD_BLOCKS");  // A/B switch
+    target_blocks = e ? atoi(e) : 1024;
+    if (target_blocks < 64) target_blocks = 1024;
+  }
+  long long chunks = target_blocks / tiles;
   if (chunks < 1) chunks = 1;
   long long kchunk = (P + chunks - 1) / chunks;
   kchunk = (kchunk + GK - 1) / GK * GK;

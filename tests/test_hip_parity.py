@@ -37,7 +37,8 @@ def _rot(golden, m, B):
 # ------------------------------------------- FPS ----------------------------------------------
 @pytest.mark.parametrize("B,N,m", [(2, 4096, 1024), (1, 20000, 1024), (3, 2048, 1024), (2, 1024, 512),
                                    (2, 512, 256), (2, 300, 100), (1, 77, 77), (2, 9, 4), (1, 1, 1),
-                                   (1, 5000, 64), (2, 24576, 33), (1, 30000, 40)])
+                                   (1, 5000, 64), (2, 24576, 33), (1, 30000, 40),
+                                   (1, 64512, 130), (1, 65000, 130), (1, 70000, 129)])  # around the pruned kernel's limit
 def test_fps_matches_oracle_pn(ext, orc, B, N, m):
     torch.manual_seed(N + m)
     xyz = torch.rand(B, N, 3) + 0.1

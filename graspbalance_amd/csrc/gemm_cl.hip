@@ -137,8 +137,10 @@ enum { EPI_STORE = 0,
                               //   of the layer whose pre-BN output y has D's shape: dgrad of the next layer)
 
 // D[i,j] = sum_k A[i,k] B[j,k] over k in [kbeg, kend);  D is (a.rows x b.rows) with leading dim ldd
+// 128 x 128 tiles of the store / atomic kernels need 132-136 VGPRs as written: asking for four waves per SIMD
+// (<= 128 registers) buys a fourth resident workgroup per CU
 template <int KA, int KB, bool VA, bool VB, int EPI, int GM, int GN, bool BF = false>
-__global__ __launch_bounds__(GTPB) void gemm_cl_kernel(Operand a, Operand b, float *__restrict__ d, long long ldd,
+__global__ __launch_bounds__(GTPB, ((GM == 128 && GN == 128 && (EPI == 0 || EPI == 2) && !BF) ? 4 : 1)) void gemm_cl_kernel(Operand a, Operand b, float *__restrict__ d, long long ldd,
                                                         double *__restrict__ stats, long long kchunk,
                                                         int tiles_n, int stat_slots,
                                                         const float *__restrict__ epi_y,

@@ -54,6 +54,9 @@ enum {
 #define GB_FPS_TIE_TREE512  0x10u
 #define GB_FPS_TIE_TREE1024 0x20u
 #define GB_FPS_TIE_MASK     0x30u
+/* gb_fps_pruned only, n <= 20480: pick up to four samples per block-wide selection (same outputs, fewer dependent
+ * rounds: see fps_multi_kernel in csrc/fps.hip) */
+#define GB_FPS_MULTI_PICK   0x100u
 
 int gb_abi_version(void);
 /* last launch error text of the calling thread ("" if none) */

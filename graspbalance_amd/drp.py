@@ -176,6 +176,9 @@ class ResBlock(nn.Module):
         return [p, self.act(f)]
 
 
+import os
+_PREFETCH_LEVEL = int(os.environ.get("GB_PREFETCH_LEVEL", "1"))  # A/B switch: after which SA level the sampling of the next batch starts
+
 # (channels, ball radius, nsample, number of InvResMLP blocks) after SA1..SA4 (drp.py:167-262)
 STAGE_SPECS = ((128, 0.08, 64, 3), (256, 0.2, 32, 6), (256, 0.4, 16, 3), (256, 0.6, 16, 3))
 
@@ -212,7 +215,7 @@ class DRP(nn.Module):
         for level in (1, 2, 3, 4):
             inds = pre if (level == 1 and pre is not None and pre.shape == (xyz.shape[0], self.sa1.npoint)) else None
             xyz, features, fps_inds = getattr(self, 'sa%d' % level)(xyz, features, inds)
-            if level == 1:
+            if level == _PREFETCH_LEVEL:
                 hook = end_points.pop('_after_sa1', None)
                 if hook is not None:
                     hook()

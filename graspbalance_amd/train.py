@@ -86,10 +86,14 @@ class Trainer:
                     self.prefetch.launch(clouds)
                 else:
                     inputs[AFTER_SA1] = lambda: self.prefetch.launch(clouds)
+        if _PREFETCH_AT == "bwd":
+            inputs.pop(AFTER_SA1, None) if self.prefetch is not None else None
         end_points = self.net(inputs)
-        if self.prefetch is not None and next_batch is not None and self.prefetch.pending is None:
+        if self.prefetch is not None and next_batch is not None and self.prefetch.pending is None and _PREFETCH_AT != "bwd":
             self.prefetch.launch(next_batch['point_clouds'])  # a backbone without the hook: start it now
         loss, end_points = get_loss(end_points)
+        if _PREFETCH_AT == "bwd" and self.prefetch is not None and next_batch is not None:
+            self.prefetch.launch(next_batch['point_clouds'])
         loss.backward()
         self.grads.reduce()
         self.optimizer.step()

@@ -421,7 +421,15 @@ __global__ __launch_bounds__(TPB) void label_gather_kernel(const LabelSrcTable s
       reinterpret_cast<float4 *>(dst)[e] = x;
       if (dcol) {
         const float xv[4] = {x.x, x.y, x.z, x.w};
-        if (col_stride == 3) {  // the offsets tensor (angle, depth, width): constant divisor, no integer division
+        if (col_stride == 3 && col_off == 2) {
+          // the offsets tensor (angle, depth, width): float4 q = 3a + r holds the widths of grasps 4a (r = 0: .z),
+          // 4a + 1 (r = 1: .y), 4a + 2 and 4a + 3 (r = 2: .x, .w) - one constant division per 16 bytes
+          const unsigned a = (unsigned)q / 3u, r = (unsigned)q - 3u * a;
+          float *dw = dcol + (size_t)v * wc + 4u * a;
+          if (r == 0) dw[0] = x.z;
+          else if (r == 1) dw[1] = x.y;
+          else { dw[2] = x.x; dw[3] = x.w; }
+        } else if (col_stride == 3) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const unsigned i = 4u * (unsigned)q + t;

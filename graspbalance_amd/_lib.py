@@ -65,6 +65,8 @@ SIGNATURES = {
     "gb_frame_cloud": [_P, _I, _P, _P, _P, _I, _I, _P, _P, _P],
     "gb_frame_mask": [_P, _I, _P, _P, _I, _I, _P, _c.c_double, _P, _P, _P],
     "gb_frame_compact": [_P, _I, _P, _P, _I, _I, _P, _c.c_double, _P, _P, _P],
+    "gb_voxel_mean": [_P, _P, _P, _L, _P],
+    "gb_collision_counts": [_P, _P, _P, _P, _P, _I, _L, _P],
     "gb_set_reserved_cus": [_I],
     "gb_set_mlp_precision": [_I],
     "gb_get_mlp_precision": [],

@@ -198,6 +198,18 @@ int gb_frame_compact(const void *depth, int depth_is_u16, const double *cam5, co
                      const unsigned long long *box, double outlier, const int64_t *offsets, int32_t *out_idx,
                      void *stream);
 
+/* Model-free collision check of grasp candidates (collision_detector.py:6-64; csrc/collision.hip), fp64 like the
+ * reference's numpy arithmetic.
+ *   gb_voxel_mean      : the averaging step of open3d's voxel_down_sample (:11-14): pts_sorted (N,3) grouped by voxel in
+ *                        original point order, seg_start (V+1) first row of every voxel -> out (V,3) = per-voxel mean
+ *   gb_collision_counts: scene (M,3); per grasp g: trans (G,3), rot (G,9 row-major), thr (G,9) =
+ *                        {h/2, d, d-fl, -(w/2+fw), -w/2, w/2+fw, w/2, d-fl-fw, d-fl-fw-approach}  (:26-35) ->
+ *                        counts (G,6) int32 = points in the {left, right, bottom, shifting, any of the four, inner}
+ *                        volumes of the gripper (:37-41, :50), i.e. the row sums the reference divides by the volumes */
+int gb_voxel_mean(const double *pts_sorted, const int64_t *seg_start, double *out, long long V, void *stream);
+int gb_collision_counts(const double *scene, const double *trans, const double *rot, const double *thr,
+                        int32_t *counts, int G, long long M, void *stream);
+
 /* Precision of the SharedMLP contractions (gb_gemm_*): GB_PREC_F32 (default; exact fp32 MFMA, the 1e-5-parity
  * configurations) or GB_PREC_BF16 (BASELINE configs[4], "mixed bf16 MLP / fp32 geometry"): operands are rounded to
  * bf16 on their way into the matrix cores, accumulation, BatchNorm statistics and all tensors in memory stay fp32;

@@ -54,3 +54,77 @@ def test_no_outlier_removal_and_sampling_rule():
     assert idx.shape == (m + 500,) and torch.equal(idx[:m].cpu(), torch.arange(m)) and int(idx.max()) < m
     with pytest.raises(RuntimeError, match="CPU not supported"):
         du.create_point_cloud_from_depth_image(torch.from_numpy(depth.astype(np.float32)), camera)
+
+
+def _dev_labels(grasp_labels, collision_labels):
+    gl = {k: tuple(torch.from_numpy(a).to(DEV) for a in v) for k, v in grasp_labels.items()}
+    return gl, {k: torch.from_numpy(v).to(DEV) for k, v in collision_labels.items()}
+
+
+@pytest.mark.parametrize("num_points,remove_outlier", [(20000, True), (400000, False)])
+def test_frame_to_sample_equals_dataset_getitem_restatement(num_points, remove_outlier):
+    """get_data_label (graspnet_dataset.py:143-237) with the device path's own random choices replayed in numpy:
+    fewer / more points than requested, invalid and absent objects, invisible grasp points, collision zeroing."""
+    from graspbalance_amd import data_utils as du
+    depth, seg, cam, trans = data_path.synthetic_frame(4)
+    h, w = depth.shape
+    color = np.random.default_rng(4).random((h, w, 3)).astype(np.float32)
+    obj_idxs, poses, grasp_labels, collision_labels, valid = data_path.synthetic_frame_labels(4, depth, seg, cam)
+    gl, cl = _dev_labels(grasp_labels, collision_labels)
+    g = torch.Generator(device=DEV).manual_seed(7)
+    got = du.frame_to_sample(torch.from_numpy(depth).to(DEV), torch.from_numpy(color).to(DEV), torch.from_numpy(seg).to(DEV),
+                             du.CameraInfo(w, h, *cam), num_points=num_points, trans=trans, remove_outlier=remove_outlier,
+                             obj_idxs=obj_idxs, poses=torch.from_numpy(poses).to(DEV), grasp_labels=gl, collision_labels=cl,
+                             valid_obj_idxs=valid, generator=g)
+    cloud_idxs = got["_cloud_idxs"].cpu().numpy()
+    want = data_path.sample_from_frame(depth, color, seg, cam, num_points, cloud_idxs, trans=trans,
+                                       remove_outlier=remove_outlier, obj_idxs=obj_idxs, poses=poses,
+                                       grasp_labels=grasp_labels, collision_labels=collision_labels, valid_obj_idxs=valid,
+                                       grasp_idxs=[p.cpu().numpy() for p in got["_grasp_idxs"]])
+    n_masked = int(((depth > 0) & (data_path.frame_to_cloud(depth, seg, *cam, trans=trans)["workspace_mask"] if remove_outlier else True)).sum())
+    if n_masked >= num_points:
+        assert len(np.unique(cloud_idxs)) == num_points
+    else:
+        assert np.array_equal(cloud_idxs[:n_masked], np.arange(n_masked)) and cloud_idxs.max() < n_masked
+    for k in ("point_clouds", "cloud_colors", "objectness_label"):
+        assert got[k].dtype == torch.from_numpy(want[k]).dtype and np.array_equal(got[k].cpu().numpy(), want[k]), k
+    assert 2 <= len(want["object_poses_list"]) <= 4       # object 3 invalid, 7 absent
+    for k in ("object_poses_list", "grasp_points_list", "grasp_offsets_list", "grasp_labels_list", "grasp_tolerance_list"):
+        assert len(got[k]) == len(want[k])
+        for a, b in zip(got[k], want[k]):
+            assert np.array_equal(a.cpu().numpy(), b), k
+    assert any((s == 0).any() for s in want["grasp_labels_list"])
+    batch = du.collate_fn([got, got])
+    assert batch["point_clouds"].shape == (2, num_points, 3) and len(batch["grasp_points_list"]) == 2
+    assert batch["grasp_points_list"][1][0] is got["grasp_points_list"][0]
+    plain = du.frame_to_sample(torch.from_numpy(depth).to(DEV), torch.from_numpy(color).to(DEV), torch.from_numpy(seg).to(DEV),
+                               du.CameraInfo(w, h, *cam), num_points=num_points)
+    assert set(plain) == {"point_clouds", "cloud_colors", "_cloud_idxs"}
+
+
+def test_augment_data_follows_the_reference_transforms():
+    from graspbalance_amd import data_utils as du
+    rng = np.random.default_rng(0)
+    cloud = rng.normal(size=(1000, 3))
+    poses = [rng.normal(size=(3, 4)).astype(np.float32) for _ in range(3)]
+    for flip, ang in ((True, 0.3), (False, -0.5)):
+        got_c, got_p = du.augment_data(torch.from_numpy(cloud).to(DEV), [torch.from_numpy(p).to(DEV) for p in poses],
+                                       flip=flip, rot_angle=ang)
+        c, p = cloud, [q for q in poses]
+        if flip:                                            # graspnet_dataset.py:71-77
+            m = np.array([[-1, 0, 0], [0, 1, 0], [0, 0, 1]])
+            c = np.dot(m, c.T).T
+            p = [np.dot(m, q).astype(np.float32) for q in p]
+        co, si = np.cos(ang), np.sin(ang)                   # :79-86
+        m = np.array([[1, 0, 0], [0, co, -si], [0, si, co]])
+        c = np.dot(m, c.T).T
+        p = [np.dot(m, q).astype(np.float32) for q in p]
+        assert np.allclose(got_c.cpu().numpy(), c, rtol=0, atol=1e-14)
+        for a, b in zip(got_p, p):
+            assert np.allclose(a.cpu().numpy(), b, rtol=0, atol=1e-6)
+    g = torch.Generator().manual_seed(0)
+    angles = []
+    for _ in range(50):
+        c2, _ = du.augment_data(torch.tensor([[0., 1., 0.]], dtype=torch.float64, device=DEV), [], generator=g)
+        angles.append(float(torch.atan2(c2[0, 2], c2[0, 1])))
+    assert max(abs(a) for a in angles) <= np.pi / 6 + 1e-9 and np.std(angles) > 0.1

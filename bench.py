@@ -215,6 +215,12 @@ def main():
         raise SystemExit("bench.py --gpus %d was launched with WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible)")
+    # GB_REHEARSE_ON_ONE_GPU=1 (not a measurement: the line says so): every rank uses device 0 and the collectives run
+    # on gloo, so that the N-rank code path - launcher, per-rank batches, bucket all-reduce, max over ranks, rank 0's
+    # line - can be exercised on a one-GPU box.  RCCL refuses two ranks on one device.
+    rehearsal = os.environ.get("GB_REHEARSE_ON_ONE_GPU") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # GB_FORCE_DIST=1 runs the RCCL path (broadcast, flat-bucket all-reduce, barriers) even with one rank
@@ -222,7 +228,10 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from graspbalance_amd import _lib
     from graspbalance_amd.synthetic import make_training_batch
@@ -390,7 +399,8 @@ def main():
             "value": round(clouds / elapsed, 3), "unit": "point-clouds/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if stress else "f32",
-            "data": "synthetic (make_scene clouds + seeded uniform grasp labels; no dataset available)",
+            "data": "synthetic (make_scene clouds + seeded uniform grasp labels; no dataset available)" +
+                    (" - REHEARSAL: all ranks on one GPU over gloo, not a measurement" if rehearsal else ""),
             "config": {"workload": "%s: GraspBalance train step fwd+bwd+Adam, B=%d/GPU, N=%d points, "
                                    "8 objects x 300 grasp points x 300 views labels%s"
                                    % ("configs[4] (stress)" if stress else "configs[3]", BATCH_PER_GPU, NUM_POINT,

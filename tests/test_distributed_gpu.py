@@ -70,3 +70,21 @@ def test_bench_launches_two_ranks_itself():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["config"]["global_batch"] == 8
     assert d["allreduce_ms"] > 0 and d["allreduce_exposed_ms"] >= 0
+
+
+def test_bench_two_rank_path_rehearsed_on_one_gpu():
+    """The N-rank code path of bench.py (own launcher, per-rank seeds, bucket all-reduce with its timing, max over
+    ranks, rank 0's line) with both ranks on device 0 over gloo: GB_REHEARSE_ON_ONE_GPU=1 (RCCL refuses two ranks on
+    one device; the line marks itself as a rehearsal)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["GB_REHEARSE_ON_ONE_GPU"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["config"]["global_batch"] == 8 and "REHEARSAL" in d["data"]
+    assert d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
+    assert abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+    assert d["allreduce_ms"] > 0 and d["allreduce_exposed_ms"] >= 0 and d["allreduce"]["bytes"] > 30e6

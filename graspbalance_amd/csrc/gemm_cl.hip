@@ -18,6 +18,9 @@
 // (16 KB of operands per 4.2 MFLOP), so plain ds_read_b32 operand fetches are off the critical path.
 #include <stdlib.h>
 
+#include <mutex>
+#include <vector>
+
 #include "gb_common.h"
 #include "gemm_rs.h"
 
@@ -145,7 +148,10 @@ __global__ __launch_bounds__(GTPB, ((GM == 128 && GN == 128 && (EPI == 0 || EPI 
                                                         int tiles_n, int stat_slots,
                                                         const float *__restrict__ epi_y,
                                                         const float *__restrict__ epi_ab,
-                                                        const uint16_t *__restrict__ epi_w16) {
+                                                        const uint16_t *__restrict__ epi_w16, long long dchunk) {
+  // dchunk != 0: reduction chunk blockIdx.y stores its partial product to its own copy of D (split_reduce_kernel sums
+  // the copies in chunk order: same bits on every run, which accumulating with atomics does not give)
+  d += (long long)blockIdx.y * dchunk;
   // LDS image per operand kind: OP_KC [row][17] (element (r,k) at r*17 + k), OP_RC [k][rows+4]
   constexpr int A_RS = KA == OP_KC ? GPITCH : 1, A_KS = KA == OP_KC ? 1 : GM + 4;  // row / k strides
   constexpr int B_RS = KB == OP_KC ? GPITCH : 1, B_KS = KB == OP_KC ? 1 : GN + 4;
@@ -358,14 +364,14 @@ static inline bool aligned16(const void *p) { return reinterpret_cast<uintptr_t>
 template <int KA, int KB, int EPI, int BM, int BN>
 static void launch_tile(const Operand &a, const Operand &b, bool va, bool vb, float *d, long long ldd, double *stats,
                         long long kchunk, unsigned chunks, hipStream_t s, int stat_slots, const float *epi_y,
-                        const float *epi_ab, const uint16_t *epi_w16) {
+                        const float *epi_ab, const uint16_t *epi_w16, long long dchunk) {
   const int tiles_n = (int)((b.rows + BN - 1) / BN);
   const long long tiles_m = (a.rows + BM - 1) / BM;
   const dim3 grid((unsigned)(tiles_m * tiles_n), chunks);
   const bool bf = mlp_bf16() && a.red >= 16;  // GB_PREC_BF16; short reductions (xyz-only first layers) stay fp32
 #define GB_L(VA_, VB_, BF_)                                                                                       \
   hipLaunchKernelGGL((gemm_cl_kernel<KA, KB, VA_, VB_, EPI, BM, BN, BF_>), grid, dim3(GTPB), 0, s, a, b, d, ldd,   \
-                     stats, kchunk, tiles_n, stat_slots, epi_y, epi_ab, epi_w16)
+                     stats, kchunk, tiles_n, stat_slots, epi_y, epi_ab, epi_w16, dchunk)
   if (bf) {
     if (va && vb) GB_L(true, true, true);
     else if (va) GB_L(true, false, true);
@@ -385,16 +391,69 @@ static void launch_tile(const Operand &a, const Operand &b, bool va, bool vb, fl
 template <int KA, int KB, int EPI>
 static void launch_gemm(const Operand &a, const Operand &b, bool va, bool vb, float *d, long long ldd, double *stats,
                         long long kchunk, unsigned chunks, hipStream_t s, int stat_slots = 1,
-                        const float *epi_y = nullptr, const float *epi_ab = nullptr, const uint16_t *epi_w16 = nullptr) {
+                        const float *epi_y = nullptr, const float *epi_ab = nullptr, const uint16_t *epi_w16 = nullptr,
+                        long long dchunk = 0) {
   // ... and 64 x 64 tiles while those number at most four per CU: the pointwise C -> 4C -> C pairs on a few thousand
   // rows then run on 2-4x as many workgroups (measured: the ten such shapes of the step 735 -> 621 us in total)
   const bool bn64 = b.rows <= 64 || (((a.rows + 63) / 64) * ((b.rows + 63) / 64) * chunks <= 1024);
   const long long blocks128 = ((a.rows + 127) / 128) * ((b.rows + (bn64 ? 63 : 127)) / (bn64 ? 64 : 128)) * chunks;
   const bool bm64 = a.rows <= 64 || blocks128 < 512;
-  if (bm64 && bn64) launch_tile<KA, KB, EPI, 64, 64>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots, epi_y, epi_ab, epi_w16);
-  else if (bm64) launch_tile<KA, KB, EPI, 64, 128>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots, epi_y, epi_ab, epi_w16);
-  else if (bn64) launch_tile<KA, KB, EPI, 128, 64>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots, epi_y, epi_ab, epi_w16);
-  else launch_tile<KA, KB, EPI, 128, 128>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots, epi_y, epi_ab, epi_w16);
+  if (bm64 && bn64) launch_tile<KA, KB, EPI, 64, 64>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots, epi_y, epi_ab, epi_w16, dchunk);
+  else if (bm64) launch_tile<KA, KB, EPI, 64, 128>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots, epi_y, epi_ab, epi_w16, dchunk);
+  else if (bn64) launch_tile<KA, KB, EPI, 128, 64>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots, epi_y, epi_ab, epi_w16, dchunk);
+  else launch_tile<KA, KB, EPI, 128, 128>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots, epi_y, epi_ab, epi_w16, dchunk);
+}
+
+// out[i] = ((part0[i] + part1[i]) + part2[i]) + ...   (chunks copies of `elems` floats, summed in chunk order)
+__global__ __launch_bounds__(GTPB) void split_reduce_kernel(const float *__restrict__ part, int chunks, long long elems,
+                                                            float *__restrict__ out) {
+  const long long i = ((long long)blockIdx.x * GTPB + threadIdx.x) * 4;
+  if (i >= elems) return;
+  if (i + 3 < elems) {
+    float4 acc = *reinterpret_cast<const float4 *>(part + i);
+    for (int c = 1; c < chunks; ++c) {
+      const float4 v = *reinterpret_cast<const float4 *>(part + (long long)c * elems + i);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4 *>(out + i) = acc;
+  } else {
+    for (long long e = i; e < elems; ++e) {
+      float acc = part[e];
+      for (int c = 1; c < chunks; ++c) acc += part[(long long)c * elems + e];
+      out[e] = acc;
+    }
+  }
+}
+
+// Per-(device, stream) scratch for the partial products of a split reduction: grow-only, reused by every later call
+// on that stream (calls on one stream are ordered, so one buffer per stream suffices).  elems*chunks floats.
+static float *split_scratch(hipStream_t s, size_t bytes) {
+  struct Entry { int dev; hipStream_t s; float *p; size_t bytes; };
+  static std::mutex mu;
+  static std::vector<Entry> table;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  for (auto &e : table)
+    if (e.dev == dev && e.s == s) {
+      if (e.bytes >= bytes) return e.p;
+      (void)hipFree(e.p);  // synchronises the device: nothing in flight still reads the old buffer
+      e.p = nullptr; e.bytes = 0;
+      if (hipMalloc(reinterpret_cast<void **>(&e.p), bytes) != hipSuccess) return nullptr;
+      e.bytes = bytes;
+      return e.p;
+    }
+  Entry e = {dev, s, nullptr, 0};
+  if (hipMalloc(reinterpret_cast<void **>(&e.p), bytes) != hipSuccess) return nullptr;
+  e.bytes = bytes;
+  table.push_back(e);
+  return e.p;
+}
+
+static int split_reduce(const float *part, int chunks, long long elems, float *out, hipStream_t s) {
+  const long long blocks = (elems / 4 + GTPB) / GTPB;
+  hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)blocks), dim3(GTPB), 0, s, part, chunks, elems, out);
+  return check_launch("gb_gemm split reduce");
 }
 
 // Reduction split for forward / dgrad products with few output tiles and a long reduction (the C -> 4C -> C
@@ -448,11 +507,15 @@ static int gemm_fwd_impl(const float *x, const float *w, const float *aff, const
     kchunk = (K + GK - 1) / GK * GK;
   }
   if (chunks > 1) {
-    // split reduction: partial products accumulate into a zeroed Y with fp32 atomics; the BatchNorm sums then
-    // need the finished Y, i.e. a (small) column pass
-    if (hipMemsetAsync(y, 0, (size_t)P * N * sizeof(float), as_stream(stream)) != hipSuccess) return GB_ELAUNCH;
-    launch_gemm<OP_KC, OP_KC, EPI_ATOMIC>(a, b, v, v, y, N, nullptr, kchunk, (unsigned)chunks, as_stream(stream));
-    const int rc = check_launch("gb_gemm_fwd");
+    // split reduction: every chunk stores its partial product, split_reduce_kernel adds them in chunk order
+    // (bit-reproducible, unlike fp32 atomics into a zeroed Y); the BatchNorm sums then need the finished Y, i.e. a
+    // (small) column pass
+    float *part = split_scratch(as_stream(stream), (size_t)chunks * P * N * sizeof(float));
+    if (!part) return GB_ELAUNCH;
+    launch_gemm<OP_KC, OP_KC, EPI_STORE>(a, b, v, v, part, N, nullptr, kchunk, (unsigned)chunks, as_stream(stream), 1,
+                                         nullptr, nullptr, nullptr, (long long)P * N);
+    int rc = check_launch("gb_gemm_fwd");
+    if (rc == GB_OK) rc = split_reduce(part, chunks, (long long)P * N, y, as_stream(stream));
     if (rc != GB_OK || !stats) return rc;
     return gb_col_stats(y, P, N, stats, fin, stream);
   }
@@ -505,9 +568,12 @@ extern "C" int gb_gemm_dgrad(const float *dy, const float *w, float *dx, const f
   long long kchunk = 0;
   const int chunks = split_reduction(P, K, N, &kchunk);
   if (chunks > 1) {
-    if (hipMemsetAsync(dx, 0, (size_t)P * K * sizeof(float), as_stream(stream)) != hipSuccess) return GB_ELAUNCH;
-    launch_gemm<OP_KC, OP_RC, EPI_ATOMIC>(a, b, va, vb, dx, K, nullptr, kchunk, (unsigned)chunks, as_stream(stream));
-    const int rc = check_launch("gb_gemm_dgrad");
+    float *part = split_scratch(as_stream(stream), (size_t)chunks * P * K * sizeof(float));
+    if (!part) return GB_ELAUNCH;
+    launch_gemm<OP_KC, OP_RC, EPI_STORE>(a, b, va, vb, part, K, nullptr, kchunk, (unsigned)chunks, as_stream(stream), 1,
+                                         nullptr, nullptr, nullptr, (long long)P * K);
+    int rc = check_launch("gb_gemm_dgrad");
+    if (rc == GB_OK) rc = split_reduce(part, chunks, (long long)P * K, dx, as_stream(stream));
     if (rc != GB_OK || !dstats) return rc;
     return done(gb_bn_bwd_stats(dx, y_prev, ab_prev, nullptr, P, K, 1, dstats, nullptr, nullptr, stream));
   }

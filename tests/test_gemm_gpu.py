@@ -99,3 +99,33 @@ def test_gemm_fused_epilogues_slotted(P, K, N):
     d = dst.sum(0)
     assert torch.allclose(d[:K], g.sum(0), rtol=1e-5, atol=1e-5 * P ** 0.5)
     assert torch.allclose(d[K:], (g * xhat).sum(0), rtol=1e-5, atol=1e-5 * P ** 0.5)
+
+
+@pytest.mark.parametrize("P,K,N", [(1024, 1024, 256), (1024, 256, 1024), (4096, 512, 128), (2048, 1024, 256)])
+def test_split_reduction_products_are_bit_reproducible(P, K, N):
+    """Few-tile / long-reduction forward and dgrad products split the reduction over workgroups; the partial products
+    are stored per chunk and added in chunk order, so repeated calls return identical bits (and stay within fp32
+    rounding of the fp64 product)."""
+    from graspbalance_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator(device=DEV).manual_seed(P + K)
+    X = torch.randn(P, K, device=DEV, generator=g)
+    W = torch.randn(N, K, device=DEV, generator=g)
+    dY = torch.randn(P, N, device=DEV, generator=g)
+
+    def fwd():
+        Y = torch.full((P, N), float("nan"), device=DEV)
+        L.check(lib.gb_gemm_fwd(L.ptr(X), L.ptr(W), None, L.ptr(Y), None, 1, P, K, N, None, None), "gb_gemm_fwd")
+        return Y
+
+    def dgrad():
+        dX = torch.full((P, K), float("nan"), device=DEV)
+        L.check(lib.gb_gemm_dgrad(L.ptr(dY), L.ptr(W), L.ptr(dX), None, None, None, 0, P, K, N, None, None, None, None),
+                "gb_gemm_dgrad")
+        return dX
+
+    for fn, want in ((fwd, X.double() @ W.double().t()), (dgrad, dY.double() @ W.double())):
+        first = fn()
+        for _ in range(4):
+            assert torch.equal(fn(), first)
+        assert float((first.double() - want).norm() / want.norm()) < 2e-6

@@ -2,8 +2,8 @@
 distance of an independent fp32 implementation of the same composition from that truth:
 
   * full size (BASELINE configs[2]: the real GraspBalance, 20 000-point clouds), eval mode: HIP fused path vs the CPU
-    oracle path vs the truth - indices identical, every stage within 1.2e-5 of the truth and no farther from it than
-    three times the CPU path (the K = 1024 products accumulate sequentially on the MFMA path: tools/gemm_accuracy.py);
+    oracle path vs the truth - indices identical, every stage within 1e-5 of the truth and no farther from it than
+    twice the CPU path, the same bits on every run;
   * the exact configs[1] module (one SA layer, npoint 1024, r 0.04, ns 32, MLP [3,64,128]) on 20 000-point clouds;
   * train mode (batch statistics, backward): fused HIP path vs plain torch composition on the GPU vs the truth, with
     the top-view arg-max frozen - the fused path may be at most twice as far from the truth as the plain path is;
@@ -62,7 +62,12 @@ def test_full_size_eval_forward_hip_vs_oracle_path_vs_f64_truth(monkeypatch):
     _force(gpu, views)
     with torch.no_grad():
         got = gpu({'point_clouds': clouds.to(DEV)})
+        again = gpu({'point_clouds': clouds.to(DEV)})
         _, truth = _truth_forward(gpu, {'point_clouds': clouds.double().to(DEV)}, views)
+    # the eval forward is bit-reproducible (split reductions add their partial products in a fixed order; before
+    # that, fp32 atomics made the grasp heads wander between 4e-6 and 2e-5 of the truth from run to run)
+    for k in VALUE_KEYS:
+        assert torch.equal(got[k], again[k]), k
     for k in ('sa1_inds', 'sa2_inds', 'fp2_inds'):
         assert torch.equal(got[k].cpu(), cpu[k]) and torch.equal(got[k], truth[k]), k
     for k in ('sa1_xyz', 'sa2_xyz', 'sa3_xyz', 'sa4_xyz', 'fp2_xyz'):
@@ -74,8 +79,8 @@ def test_full_size_eval_forward_hip_vs_oracle_path_vs_f64_truth(monkeypatch):
     print("full-size eval: top-view flips (free HIP vs CPU arg-max) %d of %d;" % (flips, views.numel()),
           {k: "hip %.1e cpu %.1e" % v for k, v in report.items()})
     for k, (e_hip, e_cpu) in report.items():
-        assert e_hip <= 1.2e-5, (k, e_hip)                  # north_star: features and grasp scores within 1e-5
-        assert e_hip <= 3.0 * e_cpu + 2e-7, (k, e_hip, e_cpu)
+        assert e_hip <= 1e-5, (k, e_hip)                    # north_star: features and grasp scores within 1e-5
+        assert e_hip <= 2.0 * e_cpu + 2e-7, (k, e_hip, e_cpu)  # measured: 3.4e-7 (sa1) ... 5.2e-6 (angle classes), <= 1.5x CPU
     assert flips <= 4, flips
 
 

@@ -74,3 +74,29 @@ def sa_layer_forward(xyz, npoint, radius, nsample, weights, normalize_xyz=True, 
         x = torch.relu((y - mean) / torch.sqrt(var + eps) * gamma + beta)
     feats = x.view(B, npoint, nsample, -1).max(2)[0]
     return inds, idx, feats.transpose(1, 2).contiguous()
+
+
+def cylinder_query(radius, hmin, hmax, nsample, xyz, new_xyz, rot):
+    """A second, independent restatement of cylinder_query_gpu.cu:20-78 as whole-tensor operations (the C oracle loops;
+    this one masks and sorts like the fallback's query_ball_point): a point belongs to centre j's cylinder when, in the
+    frame rot[j] (columns = gripper axes), its offset has x in (hmin, hmax) and y^2 + z^2 < radius^2; the first
+    `nsample` members in index order, padded with the first, zeros when there is none.  Products and sums are single
+    rounded operations in the kernel's left-to-right order.  rot (B,S,9) or (B,S,3,3) -> (B,S,nsample) int32."""
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    r = rot.reshape(B, S, 9)
+    d = xyz[:, None, :, :] - new_xyz[:, :, None, :]                       # (B,S,N,3)
+    x, y, z = d[..., 0], d[..., 1], d[..., 2]
+    c = lambda i: r[:, :, i].unsqueeze(-1)
+    x_rot = (c(0) * x + c(3) * y) + c(6) * z
+    y_rot = (c(1) * x + c(4) * y) + c(7) * z
+    z_rot = (c(2) * x + c(5) * y) + c(8) * z
+    inside = ((y_rot * y_rot + z_rot * z_rot) < radius * radius) & (x_rot > hmin) & (x_rot < hmax)
+    grid = torch.arange(N, dtype=torch.long).view(1, 1, N).repeat(B, S, 1)
+    grid[~inside] = N
+    grid = grid.sort(dim=-1)[0][:, :, :nsample]
+    if grid.shape[-1] < nsample:
+        grid = torch.cat([grid, grid.new_full((B, S, nsample - grid.shape[-1]), N)], dim=-1)
+    first = grid[:, :, :1].expand(-1, -1, nsample)
+    grid = torch.where(grid == N, first, grid)
+    return torch.where(grid == N, torch.zeros_like(grid), grid).to(torch.int32)

@@ -36,3 +36,27 @@ def test_dense_sa_layer_shapes():
     inds, idx, feats = dt.sa_layer_forward(xyz, 128, 0.05, 16, w)
     assert inds.shape == (1, 128) and idx.shape == (1, 128, 16) and feats.shape == (1, 32, 128)
     assert bool(torch.isfinite(feats).all()) and float(feats.min()) >= 0.0
+
+
+def test_dense_cylinder_query_matches_c_oracle(orc):
+    """Two independent restatements of cylinder_query_gpu.cu (a C loop, a whole-tensor mask + sort) agree index for
+    index: the grasp heads' four crops (hmin -0.02, hmax 0.01..0.04, r 0.05) on a scene with random seed rotations, a
+    crop no point falls into, and fewer members than nsample."""
+    from graspbalance_amd.scene import make_batch
+    xyz = torch.from_numpy(make_batch([2, 3], 5000))
+    g = torch.Generator().manual_seed(5)
+    seeds = xyz[:, torch.randperm(5000, generator=g)[:200]].contiguous()
+    q = torch.randn(2, 200, 4, generator=g)
+    q = q / q.norm(dim=-1, keepdim=True)
+    w, x, y, z = q.unbind(-1)
+    rot = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                       2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                       2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1).contiguous()
+    filled = 0
+    for radius, hmin, hmax, ns in [(0.05, -0.02, 0.01, 64), (0.05, -0.02, 0.04, 64), (0.05, -0.02, 0.02, 8),
+                                   (0.2, -0.1, 0.1, 16), (0.01, 5.0, 6.0, 16)]:
+        want = orc.cylinder_query(seeds, xyz, rot, radius, hmin, hmax, ns)
+        got = dt.cylinder_query(radius, hmin, hmax, ns, xyz, seeds, rot)
+        assert torch.equal(got, want), (radius, hmin, hmax, ns)
+        filled += int((want[:, :, -1] != want[:, :, 0]).sum())
+    assert filled > 100 and int(want.abs().sum()) == 0      # the last crop is empty everywhere: zeros

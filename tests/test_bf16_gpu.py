@@ -107,7 +107,7 @@ def test_sa_module_and_cylinder_head_bf16_vs_fp32(golden):
             _, o1, inds = m1(xyz, f)
             o2 = m2(seeds, xyz, rot, rows=rows)
             torch.manual_seed(5)
-            ((o1 * torch.randn_like(o1)).sum() + (o2 * torch.randn_like(o2)).sum()).backward()
+            ((o1 * torch.randn(o1.shape, device=o1.device)).sum() + (o2 * torch.randn(o2.shape, device=o2.device)).sum()).backward()
             res[mode] = (o1.detach(), o2.detach(), inds, f.grad.clone(),
                          [p.grad.clone() for p in list(m1.parameters()) + list(m2.parameters())])
         finally:

@@ -37,7 +37,7 @@ def _run(module_fused, module_plain, call, tol_fwd=1e-5, tol_grad=1e-4, l2=False
             mod.zero_grad(set_to_none=True)
             out, leaves = call(mod)
             torch.manual_seed(99)
-            w = torch.randn_like(out)
+            w = torch.randn(out.shape, device=out.device)
             (out * w).sum().backward()
             outs[name] = (out.detach(), [l.grad.detach().clone() for l in leaves],
                           {k: v.grad.detach().clone() for k, v in mod.named_parameters() if v.grad is not None},
@@ -165,7 +165,7 @@ def test_local_aggregation_without_grouped_tensor(C, ns, train):
             f = f0.clone().requires_grad_(True)
             out = m.forward_cl(p, f)
             torch.manual_seed(7)
-            (out * torch.randn_like(out)).sum().backward()
+            (out * torch.randn(out.shape, device=out.device)).sum().backward()
             res[flag] = (out.detach(), f.grad.clone(), {k: v.grad.clone() for k, v in m.named_parameters()},
                          {k: v.clone() for k, v in m.named_buffers() if v.dtype.is_floating_point})
         finally:
@@ -209,7 +209,7 @@ def test_first_layer_closed_form_backward(train, widths):
             m = copy.deepcopy(mods)
             out = fused_mlp.conv_bn_act_chain(X0, [(m[i], m[L + i]) for i in range(L)], pool_ns=ns)
             torch.manual_seed(8)
-            (out * torch.randn_like(out)).sum().backward()
+            (out * torch.randn(out.shape, device=out.device)).sum().backward()
             res[flag] = (out.detach(), {k: v.grad.clone() for k, v in m.named_parameters()})
         finally:
             fused_mlp._FIRST_FUSE = True
@@ -276,7 +276,7 @@ def test_grasp_width_grouping_distinct_rows_equals_plain(golden):
         m = copy.deepcopy(plain)
         out = m(seeds, cloud, rot, rows=rows) if name == "dedup" else m(seeds, cloud, rot, idx=idx[0])
         torch.manual_seed(99)
-        (out * torch.randn_like(out)).sum().backward()
+        (out * torch.randn(out.shape, device=out.device)).sum().backward()
         res[name] = (out.detach(), {k: v.grad.clone() for k, v in m.named_parameters()},
                      {k: v.clone() for k, v in m.named_buffers() if v.dtype.is_floating_point})
     a, b = res["dedup"], res["all_rows"]

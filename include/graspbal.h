@@ -391,7 +391,11 @@ int gb_la_wx_grad(const double *red, const double *u, const double *mom, const f
 /* Y (P,N) = f(X (P,K)) W(N,K)^T.  aff (optional) = [a(K), b(K)]: f(x) = relu(a_k x + b_k), i.e. the
  * previous layer's BatchNorm + ReLU applied while loading.  stats (optional, fp64 [stat_slots][2N],
  * caller-zeroed) += column sums and sums of squares of Y (BatchNorm batch statistics), spread over the
- * slot rows to avoid same-address atomic contention; gb_bn_finalize sums the rows.                 */
+ * slot rows to avoid same-address atomic contention; gb_bn_finalize sums the rows.
+ * Reproducibility: Y holds the same bits on every call (gb_gemm_dgrad's dX likewise).  Products with few output
+ * tiles and a long reduction split the reduction over workgroups; each chunk's partial product goes to a scratch
+ * buffer the library keeps per (device, stream) - hipMalloc on first use, a few MB, grow-only - and the chunks are
+ * added in order.  (gb_gemm_wgrad accumulates with fp32 atomics: last-bit differences between runs.)  */
 int gb_gemm_fwd(const float *x, const float *w, const float *aff, float *y, double *stats, int stat_slots,
                 long long P, int K, int N, const GbBnFinalize *fin, void *stream);
 /* dX (P,K) = dY (P,N) W(N,K), W in its natural (N,K) row-major layout.  Optional fused BatchNorm-backward

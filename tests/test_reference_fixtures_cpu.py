@@ -248,6 +248,58 @@ def _check_keys(g15, prefix, ep, errs):
         errs[prefix + k] = check_summary(g15, prefix + k, ep[k].float(), None)
 
 
+def run_obs_case(device, g20, net_too=True):
+    """f3: the object-balanced re-sampling against the reference's own run (g20).  Seed indices (fp2_inds, and the
+    FPS indices they replace) are asserted identical; -> {key: relative error} for the float tensors."""
+    from graspbalance_amd import modules
+    from graspbalance_amd.graspbalance import GraspBalance, pred_decode
+    from graspbalance_amd.pointnet2_utils import three_interpolate, three_nn
+    x = mk.g20_inputs(device)
+    B = x['point_clouds'].size(0)
+    ep = {'point_clouds': x['point_clouds'], 'seed_cluster': x['seed_cluster'],
+          'fp2_inds': torch.arange(1024, dtype=torch.int32, device=device).unsqueeze(0).repeat(B, 1)}
+    dist, idx = three_nn(x['point_clouds'], x['seed_xyz'])
+    dist_recip = 1.0 / (dist + 1e-8)
+    weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
+    ep['up_sample_features'] = three_interpolate(x['seed_features'], idx, weight)
+    ep = modules.ObjectBalanceSampling(ep)
+    assert ep['fp2_inds'].dtype == torch.int32
+    assert np.array_equal(ep['fp2_inds'].cpu().numpy(), g20["branch_fp2_inds"])
+    assert np.array_equal(ep['fp2_inds_fps'].cpu().numpy(), g20["branch_fp2_inds_fps"])
+    errs = {"branch/" + k: check_summary(g20, "branch/" + k, ep[k], None)
+            for k in ('up_sample_features', 'fp2_xyz', 'fp2_features')}
+    if not net_too:
+        return errs
+    net = fill_by_key(GraspBalance(is_training=False, obs=True), seed=15).to(device).eval()
+    want_views = _stored(g20, "net/grasp_top_view_inds").long()
+    feed = lambda: {'point_clouds': x['point_clouds'].clone(), 'seed_cluster': x['seed_cluster'].clone()}
+    with torch.no_grad():
+        free = net(feed())
+    errs["net/top_view_flips"], errs["net/top_view_gap"] = _top_view_flips(free, want_views)
+    _force_views(net, want_views)
+    with torch.no_grad():
+        ep = net(feed())
+    assert np.array_equal(ep['fp2_inds'].cpu().numpy(), g20["net_fp2_inds"])
+    assert np.array_equal(ep['fp2_inds_fps'].cpu().numpy(), g20["net_fp2_inds_fps"])
+    for k in ('up_sample_features', 'fp2_xyz', 'fp2_features', 'objectness_score', 'view_score', 'grasp_score_pred',
+              'grasp_angle_cls_pred', 'grasp_width_pred', 'grasp_tolerance_pred'):
+        errs["net/" + k] = check_summary(g20, "net/" + k, ep[k].float(), None)
+    for i, p in enumerate(pred_decode(ep)):
+        if tuple(p.shape) == tuple(int(v) for v in g20["net__pred_decode%d::shape" % i]):
+            errs["net/pred_decode%d" % i] = check_summary(g20, "net/pred_decode%d" % i, p, None)
+        else:
+            errs["net/pred_decode%d" % i] = float("inf")
+    return errs
+
+
+def test_object_balance_sampling_matches_reference(cpu, golden):
+    """f3: ObjectBalanceSampling (modules.py:178-221) + the obs branch of GraspPoseStage1 (graspbalance.py:35-46), alone
+    on seeded backbone outputs and inside the reference's whole inference network (obs=True), vs the reference run."""
+    errs = run_obs_case("cpu", golden.load("g20_obs"))
+    print({k: "%.2e" % v for k, v in errs.items()})
+    assert_errors(errs, {"net/top_view_flips": 0, "net/top_view_gap": 0.0, "branch/fp2_xyz": 0.0, "net/fp2_xyz": 0.0}, 1e-6)
+
+
 def test_whole_network_matches_reference(cpu, golden):
     """a15: the reference's GraspBalance (graspbalance.py:122-136, DRP backbone, heads, label matching, loss) run
     on CPU over the oracle vs this repo's GraspBalance on the same oracle path: eval forward + pred_decode, train

@@ -55,6 +55,17 @@ def test_pred_decode_matches_reference_gpu(golden):
         check_summary(g14, "cloud%d" % i, p, 1e-6)
 
 
+def test_object_balance_sampling_matches_reference_gpu(golden):
+    """f3 on the HIP path (gb_three_nn 4096 x 1024, gb_three_interpolate, ONE gb_fps_segments launch for all objects
+    of all clouds) vs the reference's ObjectBalanceSampling + obs branch run (g20): seed indices bit-exact (asserted
+    inside the case), re-sampled features 1e-6, the whole obs=True inference network 1e-5."""
+    errs = cases.run_obs_case(DEV, golden.load("g20_obs"))
+    _report("obs", errs)
+    assert_errors(errs, {"net/top_view_flips": 0, "net/top_view_gap": 0.0, "branch/fp2_xyz": 0.0, "net/fp2_xyz": 0.0,
+                         "branch/": 1e-6, "net/up_sample_features": 1e-5, "net/fp2_features": 1e-5,
+                         "net/pred_decode": 3e-5}, 1e-5)
+
+
 def _report(name, errs):
     print(name, {k: "%.2e" % v for k, v in errs.items()})
 

@@ -12,6 +12,7 @@ from .backbone import break_up_pc, make_sa
 from .modified_net_tools.activation import CHANNEL_MAP, create_act
 from .modified_net_tools.conv import create_convblock1d, create_convblock2d
 from . import fused_mlp
+from . import pytorch_utils as pt_utils
 from .modified_net_tools.group import QueryAndGroup, ball_query, create_grouper, get_aggregation_feautres
 from .pointnet2_modules import PointnetFPModule
 
@@ -20,7 +21,7 @@ def get_reduction_fn(reduction):
     reduction = 'mean' if reduction.lower() == 'avg' else reduction
     assert reduction in ['sum', 'max', 'mean']
     if reduction == 'max':
-        return lambda x: torch.max(x, dim=-1, keepdim=False)[0]
+        return lambda x: pt_utils.max_over_samples(x)
     if reduction == 'mean':
         return lambda x: torch.mean(x, dim=-1, keepdim=False)
     return lambda x: torch.sum(x, dim=-1, keepdim=False)

@@ -30,6 +30,12 @@ _FIRST_FUSE = os.environ.get("GB_FIRST_FUSE", "1") != "0"  # A/B switch: closed-
 _LOCAL_AGG = os.environ.get("GB_LOCAL_AGG", "1") != "0"  # A/B switch: 0 = grouped tensor + GEMM for LocalAggregation
 
 
+# Debug / test facility: a callable (kind, **tensors) that every fused node hands its discrete routing to right after its
+# forward - the pre-BatchNorm outputs and (a, b) tables that decide the ReLU masks, the arg-max rows of the pooling - so a
+# test can replay exactly those decisions in another implementation (tests/routing_tape.py).  None: no cost.
+routing_observer = None
+
+
 def local_agg_enabled():
     return _LOCAL_AGG
 
@@ -384,6 +390,8 @@ class MLPStack(Function):
             _call("gb_affine_relu_maxpool_members", dev, _lib.ptr(Ys[-1]), _lib.ptr(abs_[-1]), _lib.ptr(rows.mem),
                   _lib.ptr(rows.off), _lib.ptr(rows.cnt), _lib.ptr(out), _lib.ptr(arg), rows.R, rows.D, N, st)
             ctx.save_for_backward(X0, out, arg, ab_arena, *Ws, *Ys)
+            if routing_observer is not None:
+                routing_observer("stack", Ys=Ys, abs=abs_, out=out, arg=arg, pool_ns=0, relu_last=True, rows=rows)
             return out
         if pool_ns:
             R = P // pool_ns
@@ -392,6 +400,8 @@ class MLPStack(Function):
             _call("gb_affine_relu_maxpool", dev, _lib.ptr(Ys[-1]), _lib.ptr(abs_[-1]), _lib.ptr(out), _lib.ptr(arg), R,
                   pool_ns, N, st)
             ctx.save_for_backward(X0, out, arg, ab_arena, *Ws, *Ys)
+            if routing_observer is not None:
+                routing_observer("stack", Ys=Ys, abs=abs_, out=out, arg=arg, pool_ns=int(pool_ns), relu_last=True, rows=None)
             return out
         if residual is not None:
             residual = residual.contiguous()
@@ -400,6 +410,8 @@ class MLPStack(Function):
               int(relu_last), st)
         ctx.save_for_backward(X0, residual if residual is not None else X0.new_empty(0), X0.new_empty(0), ab_arena,
                               *Ws, *Ys)
+        if routing_observer is not None:
+            routing_observer("stack", Ys=Ys, abs=abs_, out=out, arg=None, pool_ns=0, relu_last=bool(relu_last), rows=None)
         return out
 
     @staticmethod
@@ -601,6 +613,8 @@ class LocalAggPool(Function):
               _lib.ptr(ab), _lib.ptr(out), _lib.ptr(arg), geo.b, geo.n, geo.m, geo.ns, N, geo.mode, geo.scale, st)
         ctx.geo, ctx.training = geo, cfg.training
         ctx.save_for_backward(f, Wx, Wf, G, ab, out, arg, u)
+        if routing_observer is not None:
+            routing_observer("local_agg", out=out, arg=arg, ns=geo.ns)
         return out
 
     @staticmethod
@@ -875,6 +889,8 @@ def cylinder_rows(idx, xyz, centres, rot):
               _lib.ptr(scratch[1, i]), _lib.ptr(count[i]), _lib.ptr(off[i]), B, xyz.shape[1], m, W, _lib.ptr(x0),
               _lib.ptr(w), _lib.ptr(w16), _lib.ptr(mem), st)
         out.append((x0, RowSet(w, w16, mem, off[i], count[i], R, D, R * W)))
+        if routing_observer is not None:
+            routing_observer("cyl_rows", rowset=out[-1][1], sorted=scratch[0, i], idx=idx[i])
     return out
 
 

@@ -231,7 +231,7 @@ class GraspWidthGrouping(nn.Module):
             grouped = [g.group(pointcloud, seed_xyz, vp_rot, idx[d])[1] for d, g in enumerate(self.groupers)]
         grouped_features = torch.stack(grouped, dim=3).view(B, -1, num_seed * num_depth, self.nsample)
         vp_features = self.mlps(grouped_features)
-        vp_features = torch.max(vp_features, dim=3, keepdim=True)[0]  # == max_pool2d([1,nsample])
+        vp_features = pt_utils.max_over_samples(vp_features, keepdim=True)  # == max_pool2d([1,nsample])
         return vp_features.view(B, -1, num_seed, num_depth)
 
 

@@ -36,9 +36,8 @@ def _sample_centres(xyz, npoint, inds=None):
 
 
 def _max_over_samples(x):
-    """(B,C,npoint,nsample) -> (B,C,npoint,1): F.max_pool2d(kernel=[1,nsample]) of the reference; the
-    dim-reduction kernel is ~10x faster than the NCHW pooling kernel on ROCm and gives the same values."""
-    return torch.max(x, dim=3, keepdim=True)[0]
+    """(B,C,npoint,nsample) -> (B,C,npoint,1): F.max_pool2d(kernel=[1,nsample]) of the reference."""
+    return pt_utils.max_over_samples(x, keepdim=True)
 
 
 def _pool(features, grouped_xyz, pooling, sigma, nsample):

@@ -20,21 +20,29 @@ def cpu_ext(monkeypatch, orc):
     return pointnet2_utils
 
 
-def test_g6_sharedmlp_matches_reference(golden):
+def run_g6_case(golden, device="cpu", atol=1e-6):
+    """SharedMLP([3,64,128]) (pytorch_utils.py:61-113) against the reference's own run: train and eval outputs, running
+    statistics.  Shared with tests/test_modules_gpu.py (the same module on the HIP path)."""
     from graspbalance_amd import pytorch_utils as pt
     g = golden.load("g6_sharedmlp")
     torch.manual_seed(6)
     mlp = pt.SharedMLP([3, 64, 128], bn=True)  # same construction order -> same seeded init
     assert list(mlp.state_dict().keys()) == golden.manifest["G6_state_dict_keys"]
     x = torch.randn(2, 3, 16, 8)
+    mlp = mlp.to(device)
+    x = x.to(device)
     mlp.train()
     y = mlp(x.clone())
-    np.testing.assert_allclose(y.detach().numpy(), g["y_train"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["y_train"], rtol=0, atol=atol)
     for k, v in mlp.state_dict().items():
         if "running" in k:
-            np.testing.assert_allclose(v.numpy(), g[k.replace(".", "__")], rtol=0, atol=1e-6)
+            np.testing.assert_allclose(v.cpu().numpy(), g[k.replace(".", "__")], rtol=0, atol=atol)
     mlp.eval()
-    np.testing.assert_allclose(mlp(x.clone()).detach().numpy(), g["y_eval"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(mlp(x.clone()).detach().cpu().numpy(), g["y_eval"], rtol=0, atol=atol)
+
+
+def test_g6_sharedmlp_matches_reference(golden):
+    run_g6_case(golden)
 
 
 def test_sharedmlp_variants_and_scheduler():
@@ -57,37 +65,49 @@ def test_sharedmlp_variants_and_scheduler():
         pt.BNMomentumScheduler(object(), bn_lambda=lambda it: 0.1)
 
 
-def test_g11_sa_fp_cylinder_match_reference_composition(cpu_ext, golden):
+def run_g11_case(pu, golden, device="cpu", exact_groups=True):
+    """PointnetSAModuleVotes / QueryAndGroup / PointnetFPModule / CylinderQueryAndGroup (pointnet2_modules.py:105-188,
+    402-435; pointnet2_utils.py:152-308) against the reference's own composition.  `pu` = the pointnet2_utils module
+    (CPU: oracle-backed; GPU: the product as shipped).  exact_groups: grouped tensors must have the fixture's hash
+    (pure copies / subtractions / one division or one 3x3 rotation per element)."""
     from graspbalance_amd import pointnet2_modules as pm
     g = golden.load("g11_modules")
     torch.manual_seed(11)
-    xyz = torch.rand(2, 2048, 3) * 0.5
-    feat = torch.randn(2, 8, 2048)
+    xyz = (torch.rand(2, 2048, 3) * 0.5).to(device)
+    feat = torch.randn(2, 8, 2048).to(device)
     mlp = [8, 16, 32]
     sa = pm.PointnetSAModuleVotes(npoint=256, radius=0.1, nsample=16, mlp=mlp, use_xyz=True, normalize_xyz=True)
     assert mlp[0] == 11  # the caller's list is mutated like in the reference
     assert list(sa.state_dict().keys()) == golden.manifest["G11_sa_state_dict_keys"]
     sa.load_state_dict({k[4:].replace("__", "."): torch.from_numpy(g[k]) for k in g.files if k.startswith("sa__")})
-    sa.train()
+    sa = sa.to(device).train()
     new_xyz, new_feat, inds = sa(xyz, feat)
-    assert torch.equal(inds, torch.from_numpy(g["inds"]))
-    assert torch.equal(new_xyz, torch.from_numpy(g["new_xyz"]))
-    np.testing.assert_allclose(new_feat.detach().numpy(), g["sa_out"], rtol=0, atol=1e-5)
-    qg = cpu_ext.QueryAndGroup(0.1, 16, use_xyz=True, ret_grouped_xyz=True, normalize_xyz=True)
+    assert torch.equal(inds.cpu(), torch.from_numpy(g["inds"]))
+    assert torch.equal(new_xyz.cpu(), torch.from_numpy(g["new_xyz"]))
+    np.testing.assert_allclose(new_feat.detach().cpu().numpy(), g["sa_out"], rtol=0, atol=1e-5)
+    qg = pu.QueryAndGroup(0.1, 16, use_xyz=True, ret_grouped_xyz=True, normalize_xyz=True)
     grouped_feat, grouped_xyz = qg(xyz, new_xyz, feat)
+    assert torch.equal(grouped_xyz[:, :, :8].cpu(), torch.from_numpy(g["grouped_xyz_head"]))
     assert sha(grouped_feat) == bytes(g["grouped_feat_sha256"]).hex()
-    assert torch.equal(grouped_xyz[:, :, :8], torch.from_numpy(g["grouped_xyz_head"]))
     fp = pm.PointnetFPModule(mlp=[32 + 8, 16])
     assert list(fp.state_dict().keys()) == golden.manifest["G11_fp_state_dict_keys"]
     fp.load_state_dict({k[4:].replace("__", "."): torch.from_numpy(g[k]) for k in g.files if k.startswith("fp__")})
-    fp.train()
-    out = fp(xyz, new_xyz, feat, torch.from_numpy(g["sa_out"]))
-    np.testing.assert_allclose(out.detach().numpy(), g["fp_out"], rtol=0, atol=1e-5)
+    fp = fp.to(device).train()
+    out = fp(xyz, new_xyz, feat, torch.from_numpy(g["sa_out"]).to(device))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["fp_out"], rtol=0, atol=1e-5)
     rot = torch.from_numpy(golden.load("g9_views")["rot"])[:256].view(1, 256, 3, 3).repeat(2, 1, 1, 1).contiguous()
-    cq = cpu_ext.CylinderQueryAndGroup(0.05, -0.02, 0.04, 16, use_xyz=True)
-    cyl = cq(xyz, new_xyz, rot)
-    assert torch.equal(cyl[:, :, :32], torch.from_numpy(g["cyl_head"]))
-    assert sha(cyl) == bytes(g["cyl_sha256"]).hex()
+    cq = pu.CylinderQueryAndGroup(0.05, -0.02, 0.04, 16, use_xyz=True)
+    cyl = cq(xyz, new_xyz, rot.to(device))
+    if exact_groups:
+        assert torch.equal(cyl[:, :, :32].cpu(), torch.from_numpy(g["cyl_head"]))
+        assert sha(cyl) == bytes(g["cyl_sha256"]).hex()
+    else:  # the rotation is a torch.matmul: rocBLAS / CPU BLAS may order the three products differently
+        np.testing.assert_allclose(cyl[:, :, :32].cpu().numpy(), g["cyl_head"], rtol=0, atol=1e-6)
+    return cyl
+
+
+def test_g11_sa_fp_cylinder_match_reference_composition(cpu_ext, golden):
+    run_g11_case(cpu_ext, golden)
 
 
 def test_sa_module_backward_and_variants(cpu_ext):

@@ -191,13 +191,15 @@ def _segment_module(net, name):
     return getattr(fe, name)
 
 
-def frozen_routing_train_step(base, batch, views, prior=None):
+def frozen_routing_train_step(base, batch, views, prior=None, tamper=None):
     """One train step of a copy of `base` (whatever path is active: fused HIP on the GPU, plain on CPU) with routing
     recorded and segments probed, then every segment's fp64 truth.  -> {segment: {"out/<key>" | "din/<key>" |
-    "dparam/<name>": relative error}}, number of routing entries."""
+    "dparam/<name>": relative error}}, number of routing entries, loss."""
     from graspbalance_amd import fused_mlp
     from graspbalance_amd.loss import get_loss
     net = copy.deepcopy(base)
+    if tamper is not None:
+        tamper(net)    # negative control: break the implementation under test on purpose
 
     def force(n):
         n.view_estimator.GraspableClasification._top_view = \

@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libgraspbal_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 GB_OK = 0
 _ERRNAMES = {-1: "GB_EINVAL", -2: "GB_ELAUNCH", -3: "GB_ERANGE"}
@@ -67,25 +67,19 @@ SIGNATURES = {
     "gb_frame_compact": [_P, _I, _P, _P, _I, _I, _P, _c.c_double, _P, _P, _P],
     "gb_voxel_mean": [_P, _P, _P, _L, _P],
     "gb_collision_counts": [_P, _P, _P, _P, _P, _I, _L, _P],
-    "gb_set_reserved_cus": [_I],
-    "gb_set_mlp_precision": [_I],
-    "gb_get_mlp_precision": [],
-    "gb_stream_create_cu_mask": [_P, _I, _P],
-    "gb_stream_destroy": [_P],
-    "gb_device_cu_count": [_P],
     "gb_label_gather": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gb_grasp_loss_fwd": [_P] * 17 + [_I] * 6 + [_F] * 4 + [_P] * 6,
     "gb_grasp_loss_bwd": [_P] * 17 + [_I] * 6 + [_F] * 4 + [_P] * 11,
     "gb_label_finish": [_P, _P, _P, _P, _F, _P, _P, _P, _L, _I, _P],
-    "gb_gemm_fwd": [_P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P],
-    "gb_gemm_dgrad": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P, _P, _P],
-    "gb_gemm_wgrad": [_P, _P, _P, _P, _L, _I, _I, _P],
+    "gb_gemm_fwd": [_P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P, _P],
+    "gb_gemm_dgrad": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P, _P, _P, _P],
+    "gb_gemm_wgrad": [_P, _P, _P, _P, _L, _I, _I, _P, _P],
     "gb_gemm_uses_rs": [_L, _I, _I, _I, _I, _I],
-    "gb_gemm_dgrad_first": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P],
+    "gb_gemm_dgrad_first": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P],
     "gb_moments3": [_P, _P, _L, _P, _P],
     "gb_cyl_unique": [_P, _I, _L, _I, _P, _P, _P, _P],
     "gb_cyl_rows": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
-    "gb_gemm_fwd_w": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P],
+    "gb_gemm_fwd_w": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P, _P],
     "gb_affine_relu_maxpool_members": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "gb_bn_bwd_apply_members": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _L, _I, _P, _P],
     "gb_bn_bwd_apply_w": [_P, _P, _P, _P, _P, _L, _L, _I, _I, _P, _P],
@@ -131,6 +125,17 @@ class BnFinalize(_c.Structure):
     _fields_ = [("gamma", _c.c_void_p), ("beta", _c.c_void_p), ("running_mean", _c.c_void_p),
                 ("running_var", _c.c_void_p), ("ab", _c.c_void_p), ("P", _c.c_longlong), ("eps", _c.c_float),
                 ("momentum", _c.c_float), ("training", _c.c_int)]
+
+
+class GemmOpts(_c.Structure):
+    """GbGemmOpts of include/graspbal.h: the per-call options of the gb_gemm_* entry points (precision, CUs left to a
+    side-stream kernel, caller-owned split-reduction workspace)."""
+    _fields_ = [("precision", _c.c_int), ("reserved_cus", _c.c_int), ("scratch", _c.c_void_p),
+                ("scratch_bytes", _c.c_ulonglong)]
+
+
+PREC_F32, PREC_BF16 = 0, 1
+GEMM_SCRATCH_BYTES = 320 * 64 * 128 * 4
 
 
 class KernelTimer:

@@ -116,13 +116,17 @@ __device__ __forceinline__ void bn_finalize_column(const BnFinalize &f, double s
 }
 
 // ---- precision of the SharedMLP contractions ------------------------------------------------------------------------
-// gb_set_mlp_precision(GB_PREC_BF16): every GEMM of the channel-last MLP path (forward, dgrad, wgrad) rounds both
+// GbGemmOpts.precision = GB_PREC_BF16: every GEMM of the channel-last MLP path (forward, dgrad, wgrad) rounds both
 // operands to bf16 as they enter the matrix cores (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA rate) and keeps
 // accumulating in fp32; BatchNorm statistics, element-wise passes, geometry and the tensors in HBM stay fp32.
-// Reductions shorter than 16 (the xyz-only first layers) stay on the fp32 instruction.  Process-wide.
+// Reductions shorter than 16 (the xyz-only first layers) stay on the fp32 instruction.  Per call.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-extern std::atomic<int> g_mlp_bf16;
-inline bool mlp_bf16() { return g_mlp_bf16.load(std::memory_order_relaxed) != 0; }
+inline bool opts_bf16(const GbGemmOpts *o) { return o && o->precision == GB_PREC_BF16; }
+inline int opts_reserved(const GbGemmOpts *o) { return o ? o->reserved_cus : 0; }
+inline bool opts_bad(const GbGemmOpts *o) {
+  return o && ((o->precision != GB_PREC_F32 && o->precision != GB_PREC_BF16) || o->reserved_cus < 0 ||
+               o->reserved_cus > 128 || (o->scratch && reinterpret_cast<uintptr_t>(o->scratch) % 16 != 0));
+}
 
 struct __attribute__((packed, aligned(4))) f3 {
   float x, y, z;

@@ -18,8 +18,6 @@
 // (16 KB of operands per 4.2 MFLOP), so plain ds_read_b32 operand fetches are off the critical path.
 #include <stdlib.h>
 
-#include <mutex>
-#include <vector>
 
 #include "gb_common.h"
 #include "gemm_rs.h"
@@ -363,12 +361,12 @@ static inline bool aligned16(const void *p) { return reinterpret_cast<uintptr_t>
 
 template <int KA, int KB, int EPI, int BM, int BN>
 static void launch_tile(const Operand &a, const Operand &b, bool va, bool vb, float *d, long long ldd, double *stats,
-                        long long kchunk, unsigned chunks, hipStream_t s, int stat_slots, const float *epi_y,
+                        long long kchunk, unsigned chunks, hipStream_t s, bool bf16, int stat_slots, const float *epi_y,
                         const float *epi_ab, const uint16_t *epi_w16, long long dchunk) {
   const int tiles_n = (int)((b.rows + BN - 1) / BN);
   const long long tiles_m = (a.rows + BM - 1) / BM;
   const dim3 grid((unsigned)(tiles_m * tiles_n), chunks);
-  const bool bf = mlp_bf16() && a.red >= 16;  // GB_PREC_BF16; short reductions (xyz-only first layers) stay fp32
+  const bool bf = bf16 && a.red >= 16;  // GB_PREC_BF16; short reductions (xyz-only first layers) stay fp32
 #define GB_L(VA_, VB_, BF_)                                                                                       \
   hipLaunchKernelGGL((gemm_cl_kernel<KA, KB, VA_, VB_, EPI, BM, BN, BF_>), grid, dim3(GTPB), 0, s, a, b, d, ldd,   \
                      stats, kchunk, tiles_n, stat_slots, epi_y, epi_ab, epi_w16, dchunk)
@@ -390,7 +388,7 @@ static void launch_tile(const Operand &a, const Operand &b, bool va, bool vb, fl
 // 64-tall when 128-tall tiles would leave most of the 256 CUs without a workgroup
 template <int KA, int KB, int EPI>
 static void launch_gemm(const Operand &a, const Operand &b, bool va, bool vb, float *d, long long ldd, double *stats,
-                        long long kchunk, unsigned chunks, hipStream_t s, int stat_slots = 1,
+                        long long kchunk, unsigned chunks, hipStream_t s, bool bf16, int stat_slots = 1,
                         const float *epi_y = nullptr, const float *epi_ab = nullptr, const uint16_t *epi_w16 = nullptr,
                         long long dchunk = 0) {
   // ... and 64 x 64 tiles while those number at most four per CU: the pointwise C -> 4C -> C pairs on a few thousand
@@ -398,18 +396,18 @@ static void launch_gemm(const Operand &a, const Operand &b, bool va, bool vb, fl
   const bool bn64 = b.rows <= 64 || (((a.rows + 63) / 64) * ((b.rows + 63) / 64) * chunks <= 1024);
   const long long blocks128 = ((a.rows + 127) / 128) * ((b.rows + (bn64 ? 63 : 127)) / (bn64 ? 64 : 128)) * chunks;
   const bool bm64 = a.rows <= 64 || blocks128 < 512;
-  if (bm64 && bn64) launch_tile<KA, KB, EPI, 64, 64>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots, epi_y, epi_ab, epi_w16, dchunk);
-  else if (bm64) launch_tile<KA, KB, EPI, 64, 128>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots, epi_y, epi_ab, epi_w16, dchunk);
-  else if (bn64) launch_tile<KA, KB, EPI, 128, 64>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots, epi_y, epi_ab, epi_w16, dchunk);
-  else launch_tile<KA, KB, EPI, 128, 128>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, stat_slots, epi_y, epi_ab, epi_w16, dchunk);
+  if (bm64 && bn64) launch_tile<KA, KB, EPI, 64, 64>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, bf16, stat_slots, epi_y, epi_ab, epi_w16, dchunk);
+  else if (bm64) launch_tile<KA, KB, EPI, 64, 128>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, bf16, stat_slots, epi_y, epi_ab, epi_w16, dchunk);
+  else if (bn64) launch_tile<KA, KB, EPI, 128, 64>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, bf16, stat_slots, epi_y, epi_ab, epi_w16, dchunk);
+  else launch_tile<KA, KB, EPI, 128, 128>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, bf16, stat_slots, epi_y, epi_ab, epi_w16, dchunk);
 }
 
 // out[i] = ((part0[i] + part1[i]) + part2[i]) + ...   (chunks copies of `elems` floats, summed in chunk order)
 __global__ __launch_bounds__(GTPB) void split_reduce_kernel(const float *__restrict__ part, int chunks, long long elems,
-                                                            float *__restrict__ out) {
+                                                            float *__restrict__ out, int vec) {
   const long long i = ((long long)blockIdx.x * GTPB + threadIdx.x) * 4;
   if (i >= elems) return;
-  if (i + 3 < elems) {
+  if (vec && i + 3 < elems) {  // vec: elems % 4 == 0 and both base pointers 16-byte aligned (checked by the host)
     float4 acc = *reinterpret_cast<const float4 *>(part + i);
     for (int c = 1; c < chunks; ++c) {
       const float4 v = *reinterpret_cast<const float4 *>(part + (long long)c * elems + i);
@@ -417,7 +415,7 @@ __global__ __launch_bounds__(GTPB) void split_reduce_kernel(const float *__restr
     }
     *reinterpret_cast<float4 *>(out + i) = acc;
   } else {
-    for (long long e = i; e < elems; ++e) {
+    for (long long e = i; e < elems && e < i + 4; ++e) {
       float acc = part[e];
       for (int c = 1; c < chunks; ++c) acc += part[(long long)c * elems + e];
       out[e] = acc;
@@ -425,34 +423,10 @@ __global__ __launch_bounds__(GTPB) void split_reduce_kernel(const float *__restr
   }
 }
 
-// Per-(device, stream) scratch for the partial products of a split reduction: grow-only, reused by every later call
-// on that stream (calls on one stream are ordered, so one buffer per stream suffices).  elems*chunks floats.
-static float *split_scratch(hipStream_t s, size_t bytes) {
-  struct Entry { int dev; hipStream_t s; float *p; size_t bytes; };
-  static std::mutex mu;
-  static std::vector<Entry> table;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  for (auto &e : table)
-    if (e.dev == dev && e.s == s) {
-      if (e.bytes >= bytes) return e.p;
-      (void)hipFree(e.p);  // synchronises the device: nothing in flight still reads the old buffer
-      e.p = nullptr; e.bytes = 0;
-      if (hipMalloc(reinterpret_cast<void **>(&e.p), bytes) != hipSuccess) return nullptr;
-      e.bytes = bytes;
-      return e.p;
-    }
-  Entry e = {dev, s, nullptr, 0};
-  if (hipMalloc(reinterpret_cast<void **>(&e.p), bytes) != hipSuccess) return nullptr;
-  e.bytes = bytes;
-  table.push_back(e);
-  return e.p;
-}
-
 static int split_reduce(const float *part, int chunks, long long elems, float *out, hipStream_t s) {
   const long long blocks = (elems / 4 + GTPB) / GTPB;
-  hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)blocks), dim3(GTPB), 0, s, part, chunks, elems, out);
+  const int vec = elems % 4 == 0 && aligned16(part) && aligned16(out);
+  hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)blocks), dim3(GTPB), 0, s, part, chunks, elems, out, vec);
   return check_launch("gb_gemm split reduce");
 }
 
@@ -473,6 +447,11 @@ static int split_reduction(long long rows, long long cols, long long red, long l
   return (int)((red + kc - 1) / kc);
 }
 
+// does the caller's workspace (GbGemmOpts.scratch) hold `chunks` partial products of `elems` floats?
+static bool split_fits(const GbGemmOpts *o, int chunks, long long elems) {
+  return o && o->scratch && (unsigned long long)chunks * (unsigned long long)elems * sizeof(float) <= o->scratch_bytes;
+}
+
 }  // namespace gb
 
 using namespace gb;
@@ -488,31 +467,32 @@ static int finalize_after(int rc, const GbBnFinalize *fin, const double *stats, 
 
 static int gemm_fwd_impl(const float *x, const float *w, const float *aff, const uint16_t *row_w16, float *y,
                          double *stats, int stat_slots, long long P, int K, int N, const GbBnFinalize *fin,
-                         void *stream) {
-  if (P < 0 || K < 1 || N < 1 || !x || !w || !y || (stats && stat_slots < 1)) return GB_EINVAL;
+                         const GbGemmOpts *opts, void *stream) {
+  if (P < 0 || K < 1 || N < 1 || !x || !w || !y || (stats && stat_slots < 1) || opts_bad(opts)) return GB_EINVAL;
+  const bool bf16 = opts_bf16(opts);
   if (fin && (!stats || !fin->gamma || !fin->beta || !fin->ab || fin->P < 1 || fin->training != 1))
     return GB_EINVAL;
   if (P == 0) return fin ? GB_EINVAL : GB_OK;
   if (P / 64 * ((N + 63) / 64) > 0x7fffffffLL) return GB_ERANGE;
   if (rs_gemm_try(x, w, y, aff, stats, stat_slots, nullptr, nullptr, P, K, N, 1, stats ? RS_STATS : RS_STORE,
-                  as_stream(stream), nullptr, stats ? row_w16 : nullptr))
+                  as_stream(stream), bf16, opts_reserved(opts), nullptr, stats ? row_w16 : nullptr))
     return finalize_after(check_launch("gb_gemm_fwd"), fin, stats, stat_slots, N, stream);
   Operand a = {x, P, K, K, aff};
   Operand b = {w, N, K, K, nullptr};
   const bool v = (K % 4 == 0) && aligned16(x) && aligned16(w);
   long long kchunk = 0;
   int chunks = split_reduction(P, N, K, &kchunk);
-  if (row_w16 && stats && chunks > 1) {  // the column pass of the split path does not know row weights
+  // the column pass of the split path does not know row weights; no (or too small a) caller workspace: no split
+  if (chunks > 1 && ((row_w16 && stats) || !split_fits(opts, chunks, (long long)P * N))) {
     chunks = 1;
     kchunk = (K + GK - 1) / GK * GK;
   }
   if (chunks > 1) {
-    // split reduction: every chunk stores its partial product, split_reduce_kernel adds them in chunk order
-    // (bit-reproducible, unlike fp32 atomics into a zeroed Y); the BatchNorm sums then need the finished Y, i.e. a
-    // (small) column pass
-    float *part = split_scratch(as_stream(stream), (size_t)chunks * P * N * sizeof(float));
-    if (!part) return GB_ELAUNCH;
-    launch_gemm<OP_KC, OP_KC, EPI_STORE>(a, b, v, v, part, N, nullptr, kchunk, (unsigned)chunks, as_stream(stream), 1,
+    // split reduction: every chunk stores its partial product in the caller's workspace, split_reduce_kernel adds
+    // them in chunk order (bit-reproducible, unlike fp32 atomics into a zeroed Y); the BatchNorm sums then need the
+    // finished Y, i.e. a (small) column pass
+    float *part = static_cast<float *>(opts->scratch);
+    launch_gemm<OP_KC, OP_KC, EPI_STORE>(a, b, v, v, part, N, nullptr, kchunk, (unsigned)chunks, as_stream(stream), bf16, 1,
                                          nullptr, nullptr, nullptr, (long long)P * N);
     int rc = check_launch("gb_gemm_fwd");
     if (rc == GB_OK) rc = split_reduce(part, chunks, (long long)P * N, y, as_stream(stream));
@@ -520,15 +500,16 @@ static int gemm_fwd_impl(const float *x, const float *w, const float *aff, const
     return gb_col_stats(y, P, N, stats, fin, stream);
   }
   if (stats)
-    launch_gemm<OP_KC, OP_KC, EPI_STORE_STATS>(a, b, v, v, y, N, stats, kchunk, 1, as_stream(stream), stat_slots, nullptr,
-                                               nullptr, row_w16);
-  else launch_gemm<OP_KC, OP_KC, EPI_STORE>(a, b, v, v, y, N, stats, kchunk, 1, as_stream(stream));
+    launch_gemm<OP_KC, OP_KC, EPI_STORE_STATS>(a, b, v, v, y, N, stats, kchunk, 1, as_stream(stream), bf16, stat_slots,
+                                               nullptr, nullptr, row_w16);
+  else launch_gemm<OP_KC, OP_KC, EPI_STORE>(a, b, v, v, y, N, stats, kchunk, 1, as_stream(stream), bf16);
   return finalize_after(check_launch("gb_gemm_fwd"), fin, stats, stat_slots, N, stream);
 }
 
 extern "C" int gb_gemm_fwd(const float *x, const float *w, const float *aff, float *y, double *stats,
-                           int stat_slots, long long P, int K, int N, const GbBnFinalize *fin, void *stream) {
-  return gemm_fwd_impl(x, w, aff, nullptr, y, stats, stat_slots, P, K, N, fin, stream);
+                           int stat_slots, long long P, int K, int N, const GbBnFinalize *fin, const GbGemmOpts *opts,
+                           void *stream) {
+  return gemm_fwd_impl(x, w, aff, nullptr, y, stats, stat_slots, P, K, N, fin, opts, stream);
 }
 
 // gb_gemm_fwd whose BatchNorm sums weight row p by row_w16[p] (uint16; the array must extend, zero-filled, to the
@@ -536,8 +517,8 @@ extern "C" int gb_gemm_fwd(const float *x, const float *w, const float *aff, flo
 // sums are those of the full batch.
 extern "C" int gb_gemm_fwd_w(const float *x, const float *w, const float *aff, const uint16_t *row_w16, float *y,
                              double *stats, int stat_slots, long long P, int K, int N, const GbBnFinalize *fin,
-                             void *stream) {
-  return gemm_fwd_impl(x, w, aff, row_w16, y, stats, stat_slots, P, K, N, fin, stream);
+                             const GbGemmOpts *opts, void *stream) {
+  return gemm_fwd_impl(x, w, aff, row_w16, y, stats, stat_slots, P, K, N, fin, opts, stream);
 }
 
 // dX (P,K) = dY (P,N) W(N,K)   with W in its natural (N,K) row-major layout (no transposed copy).
@@ -546,8 +527,10 @@ extern "C" int gb_gemm_fwd_w(const float *x, const float *w, const float *aff, c
 // dstats fp64 [stat_slots][2K] (caller-zeroed) += [sum dA, sum dA*xhat],  dA = dX * [a*y+b > 0].
 extern "C" int gb_gemm_dgrad(const float *dy, const float *w, float *dx, const float *y_prev,
                              const float *ab_prev, double *dstats, int stat_slots, long long P, int K, int N,
-                             double *dstats_total, float *dbeta, float *dgamma, void *stream) {
-  if (P < 0 || K < 1 || N < 1 || !dy || !w || !dx) return GB_EINVAL;
+                             double *dstats_total, float *dbeta, float *dgamma, const GbGemmOpts *opts,
+                             void *stream) {
+  if (P < 0 || K < 1 || N < 1 || !dy || !w || !dx || opts_bad(opts)) return GB_EINVAL;
+  const bool bf16 = opts_bf16(opts);
   if (dstats && (!y_prev || !ab_prev || stat_slots < 1)) return GB_EINVAL;
   if ((!dbeta != !dgamma) || (dbeta && !dstats)) return GB_EINVAL;
   // dbeta / dgamma (optional): the previous layer's gb_bn_bwd_reduce runs from this call (dstats_total: where the
@@ -559,18 +542,21 @@ extern "C" int gb_gemm_dgrad(const float *dy, const float *w, float *dx, const f
   if (P == 0) return GB_OK;
   if (P / 64 * ((K + 63) / 64) > 0x7fffffffLL) return GB_ERANGE;
   if (rs_gemm_try(dy, w, dx, nullptr, dstats, stat_slots, y_prev, ab_prev, P, N, K, 0, dstats ? RS_BNBWD : RS_STORE,
-                  as_stream(stream)))
+                  as_stream(stream), bf16, opts_reserved(opts)))
     return done(check_launch("gb_gemm_dgrad"));
   Operand a = {dy, P, N, N, nullptr};
   Operand b = {w, K, N, K, nullptr};  // tile rows = k, reduction = n, element (k,n) at w[n*K + k]
   const bool va = (N % 4 == 0) && aligned16(dy);
   const bool vb = (K % 4 == 0) && aligned16(w);
   long long kchunk = 0;
-  const int chunks = split_reduction(P, K, N, &kchunk);
+  int chunks = split_reduction(P, K, N, &kchunk);
+  if (chunks > 1 && !split_fits(opts, chunks, (long long)P * K)) {  // no (or too small a) caller workspace: no split
+    chunks = 1;
+    kchunk = (N + GK - 1) / GK * GK;
+  }
   if (chunks > 1) {
-    float *part = split_scratch(as_stream(stream), (size_t)chunks * P * K * sizeof(float));
-    if (!part) return GB_ELAUNCH;
-    launch_gemm<OP_KC, OP_RC, EPI_STORE>(a, b, va, vb, part, K, nullptr, kchunk, (unsigned)chunks, as_stream(stream), 1,
+    float *part = static_cast<float *>(opts->scratch);
+    launch_gemm<OP_KC, OP_RC, EPI_STORE>(a, b, va, vb, part, K, nullptr, kchunk, (unsigned)chunks, as_stream(stream), bf16, 1,
                                          nullptr, nullptr, nullptr, (long long)P * K);
     int rc = check_launch("gb_gemm_dgrad");
     if (rc == GB_OK) rc = split_reduce(part, chunks, (long long)P * K, dx, as_stream(stream));
@@ -578,10 +564,10 @@ extern "C" int gb_gemm_dgrad(const float *dy, const float *w, float *dx, const f
     return done(gb_bn_bwd_stats(dx, y_prev, ab_prev, nullptr, P, K, 1, dstats, nullptr, nullptr, stream));
   }
   if (dstats)
-    launch_gemm<OP_KC, OP_RC, EPI_STORE_BNBWD>(a, b, va, vb, dx, K, dstats, kchunk, 1, as_stream(stream), stat_slots,
+    launch_gemm<OP_KC, OP_RC, EPI_STORE_BNBWD>(a, b, va, vb, dx, K, dstats, kchunk, 1, as_stream(stream), bf16, stat_slots,
                                                y_prev, ab_prev);
   else
-    launch_gemm<OP_KC, OP_RC, EPI_STORE>(a, b, va, vb, dx, K, nullptr, kchunk, 1, as_stream(stream));
+    launch_gemm<OP_KC, OP_RC, EPI_STORE>(a, b, va, vb, dx, K, nullptr, kchunk, 1, as_stream(stream), bf16);
   return done(check_launch("gb_gemm_dgrad"));
 }
 
@@ -589,8 +575,8 @@ extern "C" int gb_gemm_dgrad(const float *dy, const float *w, float *dx, const f
 // x_aff (optional) = [a(K), b(K)]: X is used as relu(a_k x + b_k) (the materialisation-free form of the
 // previous layer's BatchNorm + ReLU, matching gb_gemm_fwd's prologue)
 extern "C" int gb_gemm_wgrad(const float *dy, const float *x, const float *x_aff, float *dw, long long P, int K,
-                             int N, void *stream) {
-  if (P < 0 || K < 1 || N < 1 || !dy || !x || !dw) return GB_EINVAL;
+                             int N, const GbGemmOpts *opts, void *stream) {
+  if (P < 0 || K < 1 || N < 1 || !dy || !x || !dw || opts_bad(opts)) return GB_EINVAL;
   if (P == 0) return GB_OK;
   if (K <= 4 && !x_aff && N % 4 == 0 && N / 4 <= GTPB && P >= 4096 && reinterpret_cast<uintptr_t>(dy) % 16 == 0) {
     const dim3 grid((unsigned)((P + WSK_ROWS - 1) / WSK_ROWS));
@@ -605,12 +591,7 @@ extern "C" int gb_gemm_wgrad(const float *dy, const float *x, const float *x_aff
   const long long tiles = (long long)((N + (N <= 64 ? 63 : 127)) / (N <= 64 ? 64 : 128)) *
                           ((K + (K <= 64 ? 63 : 127)) / (K <= 64 ? 64 : 128));
   // split the P reduction so that ~1024 workgroups exist, chunks a multiple of the reduction step
-  static int target_blocks = 0;
-  if (!target_blocks) {
-    const char *e = getenv("GB_WGRAD_BLOCKS");  // A/B switch
-    target_blocks = e ? atoi(e) : 1024;
-    if (target_blocks < 64) target_blocks = 1024;
-  }
+  const int target_blocks = 1024;
   long long chunks = target_blocks / tiles;
   if (chunks < 1) chunks = 1;
   long long kchunk = (P + chunks - 1) / chunks;
@@ -620,7 +601,8 @@ extern "C" int gb_gemm_wgrad(const float *dy, const float *x, const float *x_aff
   if (chunks > 65535) return GB_ERANGE;
   const bool va = (N % 4 == 0) && aligned16(dy);
   const bool vb = (K % 4 == 0) && aligned16(x);
-  launch_gemm<OP_RC, OP_RC, EPI_ATOMIC>(a, b, va, vb, dw, K, nullptr, kchunk, (unsigned)chunks, as_stream(stream));
+  launch_gemm<OP_RC, OP_RC, EPI_ATOMIC>(a, b, va, vb, dw, K, nullptr, kchunk, (unsigned)chunks, as_stream(stream),
+                                        opts_bf16(opts));
   return check_launch("gb_gemm_wgrad");
 }
 
@@ -631,11 +613,13 @@ extern "C" int gb_gemm_wgrad(const float *dy, const float *x, const float *x_aff
 // u = 0 and the 12 moments of x).  Saves the dZ write, the bn_bwd_apply pass and the K=3 wgrad.
 // Only the row-streaming kernel implements it: GB_EINVAL when the shape is not eligible (gb_gemm_uses_rs(.., 2, 0)).
 extern "C" int gb_gemm_dgrad_first(const float *dy, const float *w, const float *y_prev, const float *ab_prev,
-                                   const float *x_in, double *sums, int slots, long long P, int K, int N, void *stream) {
-  if (P < 0 || K < 1 || N < 1 || !dy || !w || !y_prev || !ab_prev || !x_in || !sums || slots < 1) return GB_EINVAL;
+                                   const float *x_in, double *sums, int slots, long long P, int K, int N,
+                                   const GbGemmOpts *opts, void *stream) {
+  if (P < 0 || K < 1 || N < 1 || !dy || !w || !y_prev || !ab_prev || !x_in || !sums || slots < 1 || opts_bad(opts))
+    return GB_EINVAL;
   if (P == 0) return GB_OK;
   if (!rs_gemm_try(dy, w, nullptr, nullptr, sums, slots, y_prev, ab_prev, P, N, K, 0, RS_BNBWD_X, as_stream(stream),
-                   x_in))
+                   opts_bf16(opts), opts_reserved(opts), x_in))
     return GB_EINVAL;
   return check_launch("gb_gemm_dgrad_first");
 }

@@ -12,9 +12,10 @@ enum { RS_STORE = 0,   // D only
 
 // D (P,C) = f(A (P,R)) B (R,C);  w_kc = 1: B[r][c] = w[c*R + r], 0: B[r][c] = w[r*C + c].
 // Returns false (nothing launched) when the shape does not suit the kernel; the caller then uses the
-// LDS-tiled kernel.
+// LDS-tiled kernel.  bf16 / reserved_cus: GbGemmOpts.precision / .reserved_cus of the call.
 bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, double *stats, int slots,
                  const float *epi_y, const float *epi_ab, long long P, int R, int C, int w_kc, int epi,
-                 hipStream_t s, const float *epi_x = nullptr, const uint16_t *epi_w16 = nullptr);
+                 hipStream_t s, bool bf16, int reserved_cus, const float *epi_x = nullptr,
+                 const uint16_t *epi_w16 = nullptr);
 
 }  // namespace gb

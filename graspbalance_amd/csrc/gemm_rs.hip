@@ -466,61 +466,51 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
   }
 }
 
-// CUs the persistent grid is sized for.  gb_set_reserved_cus(r) takes r of them out: a caller that keeps a long
+// CUs the persistent grid is sized for.  GbGemmOpts.reserved_cus takes r of them out: a caller that keeps a long
 // latency-bound kernel resident on a side stream (the next step's furthest-point sampling: one workgroup per cloud,
 // 80 KB of LDS each, for ~2 ms) tells the statically partitioned GEMM not to count on those CUs - otherwise the
 // workgroups that find no free CU start only when others finish and the launch takes two rounds.
-static std::atomic<int> g_reserved_cus{0};
-static int num_cus() {
-  static int n = 0;
+static int num_cus(int reserved) {
+  static std::atomic<int> cached{0};  // a device property, not state: every thread computes the same value
+  int n = cached.load(std::memory_order_relaxed);
   if (!n) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+    cached.store(n, std::memory_order_relaxed);
   }
-  const int r = g_reserved_cus.load(std::memory_order_relaxed);
-  return n - r >= 16 ? n - r : n;
-}
-
-static bool rs_enabled() {
-  static int on = -1;
-  if (on < 0) {
-    const char *e = getenv("GB_GEMM_RS");  // GB_GEMM_RS=0: A/B switch back to the LDS-tiled kernel
-    on = !(e && e[0] == '0');
-  }
-  return on != 0;
+  return (reserved > 0 && n - reserved >= 16) ? n - reserved : n;
 }
 
 template <int NT, int EPI, bool BF>
-static void rs_launch_p(const RsArgs &g, size_t lds_bytes, int blocks_per_cu, hipStream_t s) {
+static void rs_launch_p(const RsArgs &g, size_t lds_bytes, int blocks_per_cu, hipStream_t s, int reserved) {
   static std::atomic<unsigned long long> attr_set{0};
   auto kern = gemm_rs_kernel<NT, EPI, BF>;
   allow_dynamic_lds(kern, 160 * 1024, attr_set);
   const long long ntiles = (g.P + 31) / 32;
   long long blocks = ntiles;  // at least one tile per workgroup; all 512 threads stage B either way
-  const long long cap = (long long)num_cus() * blocks_per_cu;
+  const long long cap = (long long)num_cus(reserved) * blocks_per_cu;
   if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(RS_TPB), lds_bytes, s, g);
 }
 
 template <int NT, int EPI>
-static void rs_launch(const RsArgs &g, size_t lds_bytes, int blocks_per_cu, hipStream_t s) {
-  if (mlp_bf16()) {
+static void rs_launch(const RsArgs &g, size_t lds_bytes, int blocks_per_cu, hipStream_t s, bool bf16, int reserved) {
+  if (bf16) {
     // bf16 image of B = half the bytes (+ the affine table); never below what the closing column reduction
     // ([waves][sums per column][C32] doubles in the same LDS) needs
     const size_t b_fp32 = (size_t)g.nch * RS_CH * NT * 32 * sizeof(float);
     size_t need = lds_bytes - b_fp32 / 2;
     const size_t red = (size_t)RS_WAVES * (EPI == RS_BNBWD_X ? 5 : 2) * NT * 32 * sizeof(double);
     if (EPI != RS_STORE && need < red) need = red;
-    rs_launch_p<NT, EPI, true>(g, need, blocks_per_cu, s);
+    rs_launch_p<NT, EPI, true>(g, need, blocks_per_cu, s, reserved);
   } else {
-    rs_launch_p<NT, EPI, false>(g, lds_bytes, blocks_per_cu, s);
+    rs_launch_p<NT, EPI, false>(g, lds_bytes, blocks_per_cu, s, reserved);
   }
 }
 
 // shape part of the dispatch rule (pointer alignment aside); nt_out = column tiles of the instantiation
 static bool rs_shape_ok(long long P, int R, int C, int epi, bool has_aff, int *nt_out, size_t *lds_out) {
-  if (!rs_enabled()) return false;
   if (P < 16384 || R % 4 != 0 || R < 16 || C < 33) return false;
   const int nch = (R + RS_CH - 1) / RS_CH;
   const int tiles_c = (C + 31) / 32;
@@ -539,22 +529,13 @@ static bool rs_shape_ok(long long P, int R, int C, int epi, bool has_aff, int *n
 
 bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, double *stats, int slots,
                  const float *epi_y, const float *epi_ab, long long P, int R, int C, int w_kc, int epi,
-                 hipStream_t s, const float *epi_x, const uint16_t *epi_w16) {
+                 hipStream_t s, bool bf16, int reserved_cus, const float *epi_x, const uint16_t *epi_w16) {
   int nt = 0;
   size_t lds_bytes = 0;
   if (!rs_shape_ok(P, R, C, epi, aff != nullptr, &nt, &lds_bytes)) return false;
   if (reinterpret_cast<uintptr_t>(a) % 16 != 0 || (w_kc && reinterpret_cast<uintptr_t>(w) % 16 != 0)) return false;
   const int nch = (R + RS_CH - 1) / RS_CH;
-  static int stagger = -1;
-  if (stagger < 0) {
-    const char *e = getenv("GB_RS_STAGGER");  // A/B switch
-    stagger = e ? atoi(e) : 1;
-  }
-  static int tail_split = -1;
-  if (tail_split < 0) {
-    const char *e = getenv("GB_RS_TAIL");  // A/B switch
-    tail_split = e ? atoi(e) : 1;
-  }
+  const int stagger = 1, tail_split = 1;  // both measured to help
   RsArgs g = {a, w, d, aff, stats, epi_y, epi_ab, epi_x, epi_w16, P, R, C, R, C, w_kc, slots < 1 ? 1 : slots, nch, stagger,
               tail_split};
   const int bpc = (nt <= 2 && epi != RS_BNBWD && epi != RS_BNBWD_X && lds_bytes <= 78 * 1024) ? 2 : 1;
@@ -563,14 +544,14 @@ bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, dou
     // a reduction of <= 64 (16 KB).  (Round 1 launched with the B size only: for a 64 -> 64 second layer - SA1's
     // 3 -> 64 -> 64 -> 128 stack - the tail of that array lay outside the allocation and the five sums were wrong.)
     const size_t red_bytes = (size_t)RS_WAVES * 5 * 2 * 32 * sizeof(double);
-    rs_launch<2, RS_BNBWD_X>(g, lds_bytes > red_bytes ? lds_bytes : red_bytes, bpc, s);
+    rs_launch<2, RS_BNBWD_X>(g, lds_bytes > red_bytes ? lds_bytes : red_bytes, bpc, s, bf16, reserved_cus);
     return true;
   }
 #define GB_RS(NT_)                                                         \
   do {                                                                     \
-    if (epi == RS_STATS) rs_launch<NT_, RS_STATS>(g, lds_bytes, bpc, s);   \
-    else if (epi == RS_BNBWD) rs_launch<NT_, RS_BNBWD>(g, lds_bytes, bpc, s); \
-    else rs_launch<NT_, RS_STORE>(g, lds_bytes, bpc, s);                   \
+    if (epi == RS_STATS) rs_launch<NT_, RS_STATS>(g, lds_bytes, bpc, s, bf16, reserved_cus);   \
+    else if (epi == RS_BNBWD) rs_launch<NT_, RS_BNBWD>(g, lds_bytes, bpc, s, bf16, reserved_cus); \
+    else rs_launch<NT_, RS_STORE>(g, lds_bytes, bpc, s, bf16, reserved_cus);                   \
   } while (0)
   if (nt == 2) GB_RS(2);
   else if (nt == 4) GB_RS(4);
@@ -581,12 +562,6 @@ bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, dou
 }
 
 }  // namespace gb
-
-extern "C" int gb_set_reserved_cus(int count) {
-  if (count < 0 || count > 128) return GB_EINVAL;
-  gb::g_reserved_cus.store(count, std::memory_order_relaxed);
-  return GB_OK;
-}
 
 // which kernel gb_gemm_fwd (dgrad = 0) / gb_gemm_dgrad (dgrad = 1) launches for 16-byte aligned operands:
 // 1 = gemm_rs_kernel, 0 = gemm_cl_kernel.  Introspection for bench.py's per-kernel roofline accounting.

@@ -14,6 +14,7 @@ statistics), so state_dicts are unchanged; results equal the unfused path to fp3
 """
 import ctypes
 import os
+import threading
 
 import torch
 from torch.autograd import Function
@@ -50,20 +51,80 @@ def set_enabled(flag):
     _ENABLED = bool(flag)
 
 
+# ---- per-call GEMM options (include/graspbal.h GbGemmOpts) ------------------------------------------------------------
+# The library keeps no state: precision, the CUs left to a side-stream kernel and the split-reduction workspace travel
+# with every gb_gemm_* call.  The POLICY lives here, on the caller's side:
+#   * precision: a per-thread setting (`precision("bf16")` context / `set_precision`), read when a fused node runs its
+#     FORWARD and stored in the autograd context - backward runs on autograd's worker thread, which must use the
+#     forward's precision, not its own thread's default.  Two trainers / two threads can hold different settings.
+#   * reserved CUs: set by prefetch.SamplingPrefetch while a side-stream sampling is in flight, 0 otherwise.
+#   * workspace: one GEMM_SCRATCH_BYTES tensor per (device, stream) from torch's caching allocator, allocated on first
+#     use and never resized; only kernels on that stream touch it, so the calls of a stream share it.
+_PREC_CODE = {"f32": _lib.PREC_F32, "fp32": _lib.PREC_F32, "float32": _lib.PREC_F32, "bf16": _lib.PREC_BF16,
+              "bfloat16": _lib.PREC_BF16}
+_PREC_NAME = {_lib.PREC_F32: "f32", _lib.PREC_BF16: "bf16"}
+_tls = threading.local()
+_RESERVED_CUS = 0
+_WORKSPACES = {}
+_OPTS = {}
+
+
+def _prec_code(precision):
+    return _PREC_CODE[str(precision).replace("torch.", "")]
+
+
 def set_precision(precision):
     """'f32' (default: exact fp32 MFMA) or 'bf16' (BASELINE configs[4], "mixed bf16 MLP / fp32 geometry"): every GEMM
     of the fused SharedMLP path rounds its operands to bf16 on the way into the matrix cores and accumulates in fp32;
-    BatchNorm statistics, element-wise passes, geometry and all tensors in HBM stay fp32 (gb_set_mlp_precision).
-    Process-wide; returns the previous setting."""
-    lib = _lib.lib()
-    prev = "bf16" if lib.gb_get_mlp_precision() == 1 else "f32"
-    code = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}[str(precision).replace("torch.", "")]
-    _lib.check(lib.gb_set_mlp_precision(code), "gb_set_mlp_precision")
+    BatchNorm statistics, element-wise passes, geometry and all tensors in HBM stay fp32.  Applies to fused nodes whose
+    forward runs on THIS thread from now on (their backward follows the forward); returns the previous setting."""
+    prev = get_precision()
+    _tls.prec = _prec_code(precision)
     return prev
 
 
 def get_precision():
-    return "bf16" if _lib.lib().gb_get_mlp_precision() == 1 else "f32"
+    return _PREC_NAME[getattr(_tls, "prec", _lib.PREC_F32)]
+
+
+class precision:
+    """``with fused_mlp.precision("bf16"): ...`` - set_precision for the duration of a block."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.prev = set_precision(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        set_precision(self.prev)
+        return False
+
+
+def set_reserved_cus(count):
+    """Size the persistent GEMM grids for (CUs - count) compute units while a side-stream kernel holds `count` of them
+    (0 restores the full device).  Returns the previous value."""
+    global _RESERVED_CUS
+    prev, _RESERVED_CUS = _RESERVED_CUS, max(0, min(int(count), 128))
+    return prev
+
+
+def _prec():
+    return getattr(_tls, "prec", _lib.PREC_F32)
+
+
+def _opts(dev, st, prec):
+    """ctypes pointer to the GbGemmOpts of a launch on stream `st` (c_void_p) of `dev` at precision code `prec`."""
+    key = (dev.index, st.value, prec, _RESERVED_CUS)
+    o = _OPTS.get(key)
+    if o is None:
+        wkey = (dev.index, st.value)
+        ws = _WORKSPACES.get(wkey)
+        if ws is None:
+            ws = _WORKSPACES[wkey] = torch.empty(_lib.GEMM_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
+        o = _OPTS[key] = (ctypes.pointer(_lib.GemmOpts(prec, _RESERVED_CUS, ws.data_ptr(), ws.numel())), ws)
+    return o[0]
 
 
 def set_own_gemm(flag):
@@ -237,8 +298,9 @@ class LinearBNAct(Function):
             X = X.contiguous()
             Wc = W.contiguous()
             Y = torch.empty((P, Cout), dtype=torch.float32, device=dev)
+            st = _s(X)
             _call("gb_gemm_fwd", dev, _lib.ptr(X), _lib.ptr(Wc), None, _lib.ptr(Y), _lib.ptr(stats), slots, P, X.shape[1],
-                  Cout, None, _s(X), meta=_gemm_meta("fwd", P, X.shape[1], Cout, stats is not None))
+                  Cout, None, _opts(dev, st, _prec()), st, meta=_gemm_meta("fwd", P, X.shape[1], Cout, stats is not None))
         else:
             Y = torch.mm(X, W.t())
             if training:
@@ -246,6 +308,7 @@ class LinearBNAct(Function):
         _call("gb_bn_finalize", dev, _lib.ptr(stats), slots, P, Cout, _lib.ptr(gamma), _lib.ptr(beta), float(eps),
               float(momentum), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(ab), int(training), _s(Y))
         ctx.cfg = (P, Cout, bool(training), bool(relu), int(pool_ns))
+        ctx.prec = _prec()
         if pool_ns:
             R = P // pool_ns
             out = torch.empty((R, Cout), dtype=torch.float32, device=dev)
@@ -294,13 +357,13 @@ class LinearBNAct(Function):
             Cin = X.shape[1]
             if ctx.needs_input_grad[1]:
                 dW = torch.zeros((Cout, Cin), dtype=torch.float32, device=dev)
-                _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(X), None, _lib.ptr(dW), P, Cin, Cout, _s(dY),
-                      meta=_gemm_meta("wgrad", P, Cin, Cout))
+                _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(X), None, _lib.ptr(dW), P, Cin, Cout,
+                      _opts(dev, _s(dY), ctx.prec), _s(dY), meta=_gemm_meta("wgrad", P, Cin, Cout))
             if ctx.needs_input_grad[0]:
                 dX = torch.empty((P, Cin), dtype=torch.float32, device=dev)
                 W = W.contiguous()
                 _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dX), None, None, None, 0, P, Cin, Cout, None,
-                      None, None, _s(dY),
+                      None, None, _opts(dev, _s(dY), ctx.prec), _s(dY),
                       meta=_gemm_meta("dgrad", P, Cin, Cout))
         else:
             dW = _wgrad(dY, X) if ctx.needs_input_grad[1] else None
@@ -342,6 +405,8 @@ class MLPStack(Function):
     def forward(ctx, X0, residual, layers, pool_ns, relu_last, rows, *params):
         dev = X0.device
         st = _s(X0)  # one stream lookup per call, not one per launch
+        prec = _prec()
+        opts = _opts(dev, st, prec)
         L = len(layers)
         P_stat = rows.P_total if rows is not None else X0.shape[0]  # rows of the batch the BatchNorm sums stand for
         X0 = X0.contiguous()
@@ -369,11 +434,11 @@ class MLPStack(Function):
             fin = _bn_fin(cfg, gamma, beta, ab, P_stat) if cfg.training else None
             if rows is not None and stats is not None:
                 _call("gb_gemm_fwd_w", dev, _lib.ptr(src), _lib.ptr(W), _lib.ptr(aff), _lib.ptr(rows.w16), _lib.ptr(Y),
-                      _lib.ptr(stats), slots, P, K, N, fin, st,
+                      _lib.ptr(stats), slots, P, K, N, fin, opts, st,
                       meta=_gemm_meta("fwd", P, K, N, True, aff is not None))
             else:
                 _call("gb_gemm_fwd", dev, _lib.ptr(src), _lib.ptr(W), _lib.ptr(aff), _lib.ptr(Y), _lib.ptr(stats), slots,
-                      P, K, N, fin, st, meta=_gemm_meta("fwd", P, K, N, stats is not None, aff is not None))
+                      P, K, N, fin, opts, st, meta=_gemm_meta("fwd", P, K, N, stats is not None, aff is not None))
             if fin is None:
                 _call("gb_bn_finalize", dev, _lib.ptr(stats), slots, P_stat, N, _lib.ptr(gamma), _lib.ptr(beta), cfg.eps,
                       cfg.momentum, _lib.ptr(cfg.running_mean), _lib.ptr(cfg.running_var), _lib.ptr(ab),
@@ -383,6 +448,7 @@ class MLPStack(Function):
         N = widths[-1]
         ctx.cfg = (L, P, int(pool_ns), bool(relu_last), [c.training for c in layers], residual is not None)
         ctx.rows = rows
+        ctx.prec = prec
         if rows is not None:
             RD = rows.R * rows.D
             out = torch.empty((RD, N), dtype=torch.float32, device=dev)
@@ -429,6 +495,7 @@ class MLPStack(Function):
             off += 4 * n
         dev = dout.device
         st = _s(dout)  # one stream lookup per call, not one per launch
+        opts = _opts(dev, st, ctx.prec)  # the forward's precision (this is autograd's thread)
         dout = dout.contiguous()
         slots = STAT_SLOTS if P >= 16384 else 1
         # zero-filled arenas: fp64 BatchNorm-backward sums ([2N] last layer, then per layer l<L-1 the slot rows
@@ -496,14 +563,14 @@ class MLPStack(Function):
             src, aff = (X0, None) if l == 0 else (Ys[l - 1], abs_[l - 1])
             if need_w[l]:
                 dW = w_arena[w_off[l]:w_off[l + 1]]
-                _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(src), _lib.ptr(aff), _lib.ptr(dW), P, K, N, st,
+                _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(src), _lib.ptr(aff), _lib.ptr(dW), P, K, N, opts, st,
                       meta=_gemm_meta("wgrad", P, K, N, aff=aff is not None))
                 grads[3 * l] = dW.view(N, K)
             if l == 0:
                 if ctx.needs_input_grad[0]:
                     dX0 = torch.empty((P, K), dtype=torch.float32, device=dev)
                     _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dX0), None, None, None, 0, P, K, N,
-                          None, None, None, st, meta=_gemm_meta("dgrad", P, K, N))
+                          None, None, None, opts, st, meta=_gemm_meta("dgrad", P, K, N))
                 break
             if (l == 1 and _FIRST_FUSE and X0.shape[1] == 3 and not ctx.needs_input_grad[0] and need_w[0]
                     and _lib.lib().gb_gemm_uses_rs(P, K, N, 1, 2, 0)):
@@ -512,7 +579,7 @@ class MLPStack(Function):
                 z = _zeros64(slots * 5 * K + 3 * K + 12, dev)
                 sums, u0, mom = z[:slots * 5 * K], z[slots * 5 * K:slots * 5 * K + 3 * K], z[slots * 5 * K + 3 * K:]
                 _call("gb_gemm_dgrad_first", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(Ys[0]), _lib.ptr(abs_[0]),
-                      _lib.ptr(X0), _lib.ptr(sums), slots, P, K, N, st,
+                      _lib.ptr(X0), _lib.ptr(sums), slots, P, K, N, opts, st,
                       meta={"flop": 2.0 * P * K * N, "pkn": (P, K, N), "kernel": "gemm_rs_kernel"})
                 _call("gb_moments3", dev, _lib.ptr(X0), _lib.ptr(rows.w if rows is not None else None), P, _lib.ptr(mom),
                       st)
@@ -532,11 +599,11 @@ class MLPStack(Function):
                 dstats = region[slots * 2 * K:] if slots > 1 else region  # the slot rows' total
                 _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dZ), _lib.ptr(Ys[l - 1]),
                       _lib.ptr(abs_[l - 1]), _lib.ptr(region), slots, P, K, N, _lib.ptr(dstats), _lib.ptr(dbeta),
-                      _lib.ptr(dgamma), st, meta=_gemm_meta("dgrad", P, K, N, fused=True))
+                      _lib.ptr(dgamma), opts, st, meta=_gemm_meta("dgrad", P, K, N, fused=True))
             else:
                 # wide + long outputs: the fused epilogue measured slower than a separate column pass
                 _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dZ), None, None, None, 0, P, K, N,
-                      None, None, None, st, meta=_gemm_meta("dgrad", P, K, N))
+                      None, None, None, opts, st, meta=_gemm_meta("dgrad", P, K, N))
                 dstats = region
                 _call("gb_bn_bwd_stats", dev, _lib.ptr(dZ), _lib.ptr(Ys[l - 1]), _lib.ptr(abs_[l - 1]), None, P, K, 1,
                       _lib.ptr(dstats), _lib.ptr(dbeta), _lib.ptr(dgamma), st)
@@ -594,8 +661,9 @@ class LocalAggPool(Function):
         _call("gb_la_split_w", dev, _lib.ptr(W), _lib.ptr(Wx), _lib.ptr(Wf), N, C, st)
         rows, P = geo.b * geo.n, geo.rows
         G = torch.empty((rows, N), dtype=torch.float32, device=dev)
-        _call("gb_gemm_fwd", dev, _lib.ptr(f), _lib.ptr(Wf), None, _lib.ptr(G), None, 1, rows, C, N, None, st,
-              meta=_gemm_meta("fwd", rows, C, N))
+        ctx.prec = _prec()
+        _call("gb_gemm_fwd", dev, _lib.ptr(f), _lib.ptr(Wf), None, _lib.ptr(G), None, 1, rows, C, N, None,
+              _opts(dev, st, ctx.prec), st, meta=_gemm_meta("fwd", rows, C, N))
         sums = _zeros64(5 * N, dev)  # [sum y, sum y^2, U0, U1, U2]
         stats, u = sums[:2 * N], sums[2 * N:]
         ab = torch.empty(4 * N, dtype=torch.float32, device=dev)
@@ -644,15 +712,15 @@ class LocalAggPool(Function):
             _call("gb_la_wx_grad", dev, _lib.ptr(red), _lib.ptr(u), _lib.ptr(geo.mom), _lib.ptr(Wx), _lib.ptr(ab), P, N,
                   training, _lib.ptr(dWx), st)
             dWf = zbuf[rows * N:].view(N, C)
-            _call("gb_gemm_wgrad", dev, _lib.ptr(dG), _lib.ptr(f), None, _lib.ptr(dWf), rows, C, N, st,
-                  meta=_gemm_meta("wgrad", rows, C, N))
+            _call("gb_gemm_wgrad", dev, _lib.ptr(dG), _lib.ptr(f), None, _lib.ptr(dWf), rows, C, N,
+                  _opts(dev, st, ctx.prec), st, meta=_gemm_meta("wgrad", rows, C, N))
             dW = torch.empty((N, 3 + C), dtype=torch.float32, device=dev)
             _call("gb_la_join_w", dev, _lib.ptr(dWx), _lib.ptr(dWf), _lib.ptr(dW), N, C, st)
         df = None
         if ctx.needs_input_grad[0]:
             df = torch.empty((rows, C), dtype=torch.float32, device=dev)
             _call("gb_gemm_dgrad", dev, _lib.ptr(dG), _lib.ptr(Wf), _lib.ptr(df), None, None, None, 0, rows, C, N,
-                  None, None, None, st, meta=_gemm_meta("dgrad", rows, C, N))
+                  None, None, None, _opts(dev, st, ctx.prec), st, meta=_gemm_meta("dgrad", rows, C, N))
         return df, dW, dgamma, dbeta, None, None
 
 
@@ -773,8 +841,9 @@ class LinearBias(Function):
         P, K = X.shape
         N = W.shape[0]
         Y = torch.empty((P, N), dtype=torch.float32, device=dev)
-        _call("gb_gemm_fwd", dev, _lib.ptr(X), _lib.ptr(W), None, _lib.ptr(Y), None, 1, P, K, N, None, st,
-              meta=_gemm_meta("fwd", P, K, N))
+        ctx.prec = _prec()
+        _call("gb_gemm_fwd", dev, _lib.ptr(X), _lib.ptr(W), None, _lib.ptr(Y), None, 1, P, K, N, None,
+              _opts(dev, st, ctx.prec), st, meta=_gemm_meta("fwd", P, K, N))
         if b is not None:
             ab = torch.cat([torch.ones_like(b), b.detach()])
             _call("gb_affine_act", dev, _lib.ptr(Y), _lib.ptr(ab), None, _lib.ptr(Y), P, N, 0, st)  # in place: y += b
@@ -794,11 +863,11 @@ class LinearBias(Function):
         if ctx.needs_input_grad[0]:
             dX = torch.empty((P, K), dtype=torch.float32, device=dev)
             _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dX), None, None, None, 0, P, K, N, None, None,
-                  None, st, meta=_gemm_meta("dgrad", P, K, N))
+                  None, _opts(dev, st, ctx.prec), st, meta=_gemm_meta("dgrad", P, K, N))
         if ctx.needs_input_grad[1]:
             dW = torch.zeros((N, K), dtype=torch.float32, device=dev)
-            _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(X), None, _lib.ptr(dW), P, K, N, st,
-                  meta=_gemm_meta("wgrad", P, K, N))
+            _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(X), None, _lib.ptr(dW), P, K, N,
+                  _opts(dev, st, ctx.prec), st, meta=_gemm_meta("wgrad", P, K, N))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             sums = _zeros64(2 * N, dev)
             _call("gb_col_stats", dev, _lib.ptr(dY), P, N, _lib.ptr(sums), None, st)

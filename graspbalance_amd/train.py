@@ -3,6 +3,8 @@
 RCCL data-parallel gradient reduction.  (The reference script itself cannot run as shipped: it imports
 the absent ``graspnet.GraspNet_MSCQ`` and dataset class names that do not exist — SURVEY.md §0.)
 """
+import contextlib
+
 import torch
 from torch.optim.lr_scheduler import OneCycleLR
 
@@ -15,6 +17,7 @@ from .pytorch_utils import BNMomentumScheduler
 
 import os
 _PREFETCH_AT = os.environ.get("GB_PREFETCH_AT", "sa1")  # A/B switch: "start" | "sa1" | "off"
+_NO_CONTEXT = contextlib.nullcontext()
 
 BN_MOMENTUM_INIT = 0.5
 BN_MOMENTUM_MAX = 0.001
@@ -26,8 +29,9 @@ class Trainer:
                  bucket_mb=16.0, model=None, time_collectives=False, prefetch_sampling=True, mlp_precision=None):
         torch.manual_seed(seed)
         self.device = torch.device(device)
-        if mlp_precision is not None and self.device.type == "cuda":
-            fused_mlp.set_precision(mlp_precision)  # 'bf16': BASELINE configs[4] (process-wide switch of the GEMMs)
+        # 'bf16': BASELINE configs[4].  A property of THIS trainer: every step runs inside fused_mlp.precision(...), the
+        # GEMM calls carry it (GbGemmOpts), so two trainers of one process may differ
+        self.mlp_precision = mlp_precision if self.device.type == "cuda" else None
         self.net = model if model is not None else GraspBalance(
             input_feature_dim=0, num_view=num_view, num_angle=12, num_depth=4, cylinder_radius=0.08,
             hmin=-0.02, hmax_list=[0.01, 0.02, 0.03, 0.04])
@@ -59,17 +63,8 @@ class Trainer:
         loss tensor (no host sync here; the reference's per-key .item() logging is the caller's).
         next_batch: the batch of the FOLLOWING call, if the loop already holds it - its first-level furthest-point
         sampling then runs on a side stream under this step (prefetch.py)."""
-        main = self.prefetch.main if self.prefetch is not None else None
-        if main is None:
+        with (fused_mlp.precision(self.mlp_precision) if self.mlp_precision is not None else _NO_CONTEXT):
             return self._train_step(batch, next_batch)
-        # the step runs on the CU-masked training stream, ordered after / before the caller's current stream
-        caller = torch.cuda.current_stream(self.device)
-        main.wait_stream(caller)
-        with torch.cuda.stream(main):
-            loss = self._train_step(batch, next_batch)
-        caller.wait_stream(main)
-        loss.record_stream(caller)
-        return loss
 
     def _train_step(self, batch, next_batch=None):
         if self.device.type == "cuda":
@@ -86,14 +81,10 @@ class Trainer:
                     self.prefetch.launch(clouds)
                 else:
                     inputs[AFTER_SA1] = lambda: self.prefetch.launch(clouds)
-        if _PREFETCH_AT == "bwd":
-            inputs.pop(AFTER_SA1, None) if self.prefetch is not None else None
         end_points = self.net(inputs)
-        if self.prefetch is not None and next_batch is not None and self.prefetch.pending is None and _PREFETCH_AT != "bwd":
+        if self.prefetch is not None and next_batch is not None and self.prefetch.pending is None:
             self.prefetch.launch(next_batch['point_clouds'])  # a backbone without the hook: start it now
         loss, end_points = get_loss(end_points)
-        if _PREFETCH_AT == "bwd" and self.prefetch is not None and next_batch is not None:
-            self.prefetch.launch(next_batch['point_clouds'])
         loss.backward()
         self.grads.reduce()
         self.optimizer.step()

@@ -13,8 +13,9 @@
  *     int32 indices (int64, 1-based for gb_knn) — the reference's dtype contract
  *     (_ext_src/include/utils.h:10-30);
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); launches are
- *     asynchronous, the library never synchronises, allocates, or keeps mutable global state,
- *     so it is re-entrant from autograd worker threads like the reference launchers;
+ *     asynchronous, the library never synchronises, allocates (workspaces are caller-provided), or
+ *     keeps mutable global state (per-call options travel in GbGemmOpts), so it is re-entrant from
+ *     autograd worker threads like the reference launchers;
  *   - return value: GB_OK (0) or a negative GB_E* code; the library never calls exit() and never
  *     throws (the reference does fprintf+exit(-1), cuda_utils.h:38-47);
  *   - outputs are fully written by the kernels unless stated otherwise ("accumulates into" means
@@ -31,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GB_ABI_VERSION 2
+#define GB_ABI_VERSION 3
 
 enum {
   GB_OK = 0,
@@ -210,28 +211,6 @@ int gb_voxel_mean(const double *pts_sorted, const int64_t *seg_start, double *ou
 int gb_collision_counts(const double *scene, const double *trans, const double *rot, const double *thr,
                         int32_t *counts, int G, long long M, void *stream);
 
-/* Precision of the SharedMLP contractions (gb_gemm_*): GB_PREC_F32 (default; exact fp32 MFMA, the 1e-5-parity
- * configurations) or GB_PREC_BF16 (BASELINE configs[4], "mixed bf16 MLP / fp32 geometry"): operands are rounded to
- * bf16 on their way into the matrix cores, accumulation, BatchNorm statistics and all tensors in memory stay fp32;
- * reductions shorter than 16 stay fp32.  Process-wide; replaces what the reference would get from torch autocast
- * around pytorch_utils.py:61-113.                                                                               */
-#define GB_PREC_F32 0
-#define GB_PREC_BF16 1
-int gb_set_mlp_precision(int precision);
-int gb_get_mlp_precision(void);
-
-/* A stream whose kernels may only run on the compute units set in cu_mask (`words` 32-bit words, bit i = CU i);
- * gb_stream_destroy releases it; gb_device_cu_count reports the current device's CU count.  prefetch.py splits
- * the chip with two such streams: B CUs for the next batch's furthest-point sampling, the rest for the step.   */
-int gb_stream_create_cu_mask(const uint32_t *cu_mask, int words, void **stream);
-int gb_stream_destroy(void *stream);
-int gb_device_cu_count(int *count);
-
-/* Size the persistent GEMM grids for (CUs - count) compute units (0 restores the full device): for callers that keep
- * a long one-workgroup-per-cloud kernel (furthest-point sampling of the NEXT batch) running on a side stream.
- * Process-wide; 0 <= count <= 128.                                                                              */
-int gb_set_reserved_cus(int count);
-
 /* Score transform + per-view maximum of the gathered labels (reference label_generation.py:112-116):
  * out = log(*u_max / label) where label > 0 and offsets[..., 2] (width) <= max_width, else 0;
  * view_scores[row] = max over the ad = A*D grasps of the row.  labels/out (rows, ad), offsets (rows, ad, 3),
@@ -260,6 +239,34 @@ int gb_group_concat_cl(const float *xyz, const float *new_xyz, const int32_t *id
 /* dfeat[b, idx[p], :] += dx0[p, 3:]   (accumulates into dfeat (b,n,c)) */
 int gb_group_concat_cl_grad(const float *dx0, const int32_t *idx, float *dfeat, int b, int n, int m,
                             int ns, int c, void *stream);
+/* Per-call options of the gb_gemm_* entry points (NULL = all defaults).  The library keeps NO state between calls:
+ * what used to be process-wide switches travels with every call, so two threads (autograd workers, two trainers)
+ * may use different settings concurrently.
+ *   precision   : GB_PREC_F32 (default; exact fp32 MFMA, the 1e-5-parity configurations) or GB_PREC_BF16 (BASELINE
+ *                 configs[4], "mixed bf16 MLP / fp32 geometry" - what torch autocast around pytorch_utils.py:61-113 would
+ *                 give the reference): both operands are rounded to bf16 on their way into the matrix cores;
+ *                 accumulation, BatchNorm statistics and all tensors in memory stay fp32; reductions shorter than 16
+ *                 (the xyz-only first layers) stay fp32.
+ *   reserved_cus: size the persistent row-streaming grids for (CUs - reserved_cus) compute units, 0..128: for callers
+ *                 that keep a long one-workgroup-per-cloud kernel (furthest-point sampling of the NEXT batch) resident on
+ *                 a side stream.
+ *   scratch     : caller-owned device workspace (16-byte aligned) of scratch_bytes bytes, used by gb_gemm_fwd /
+ *                 gb_gemm_dgrad for products with few output tiles and a long reduction: the reduction is split over
+ *                 workgroups, every chunk stores its partial product there and the chunks are added in chunk order
+ *                 (bit-reproducible).  GB_GEMM_SCRATCH_BYTES always suffices; with NULL / too small a workspace the
+ *                 product simply runs unsplit (same result to fp32 rounding, slower for those shapes).  The workspace
+ *                 is only touched by kernels on `stream`: calls on one stream may share one.  The reference's
+ *                 wrappers allocate, its launchers never do (ball_query.cpp:13-37) - same split here.           */
+#define GB_PREC_F32 0
+#define GB_PREC_BF16 1
+#define GB_GEMM_SCRATCH_BYTES (320ull * 64 * 128 * 4)
+typedef struct GbGemmOpts {
+  int precision;
+  int reserved_cus;
+  void *scratch;
+  unsigned long long scratch_bytes;
+} GbGemmOpts;
+
 /* The arguments of gb_bn_finalize as a struct: entry points that produce BatchNorm sums take an optional pointer to
  * one and then finish the layer themselves (ab table, running statistics) with a gb_bn_finalize launch from the same
  * call - one host transition per layer instead of two.  training must be 1 (the evaluation-mode table does not depend
@@ -330,7 +337,8 @@ int gb_cyl_rows(const float *xyz, const float *centres, const float *rot, const 
 /* gb_gemm_fwd whose BatchNorm sums weight row p by row_w16[p] (uint16 multiplicities; the array must extend,
  * zero-filled, to the next multiple of 32 rows).                                                              */
 int gb_gemm_fwd_w(const float *x, const float *w, const float *aff, const uint16_t *row_w16, float *y, double *stats,
-                  int stat_slots, long long P, int K, int N, const GbBnFinalize *fin, void *stream);
+                  int stat_slots, long long P, int K, int N, const GbBnFinalize *fin, const GbGemmOpts *opts,
+                  void *stream);
 /* out ((R*D), C) [row r*D + d] = max over the rows of seed r with member bit d of relu(a*y + b); arg = absolute
  * row index of the maximum.  D in {1,2,4}; C % 4 == 0.                                                         */
 int gb_affine_relu_maxpool_members(const float *y, const float *ab, const int32_t *row_mem, const int64_t *off,
@@ -392,12 +400,11 @@ int gb_la_wx_grad(const double *red, const double *u, const double *mom, const f
  * previous layer's BatchNorm + ReLU applied while loading.  stats (optional, fp64 [stat_slots][2N],
  * caller-zeroed) += column sums and sums of squares of Y (BatchNorm batch statistics), spread over the
  * slot rows to avoid same-address atomic contention; gb_bn_finalize sums the rows.
- * Reproducibility: Y holds the same bits on every call (gb_gemm_dgrad's dX likewise).  Products with few output
- * tiles and a long reduction split the reduction over workgroups; each chunk's partial product goes to a scratch
- * buffer the library keeps per (device, stream) - hipMalloc on first use, a few MB, grow-only - and the chunks are
- * added in order.  (gb_gemm_wgrad accumulates with fp32 atomics: last-bit differences between runs.)  */
+ * Reproducibility: Y holds the same bits on every call with the same options (gb_gemm_dgrad's dX likewise; a split
+ * reduction adds its chunks in a fixed order).  gb_gemm_wgrad accumulates with fp32 atomics: last-bit differences
+ * between runs.                                                                                                 */
 int gb_gemm_fwd(const float *x, const float *w, const float *aff, float *y, double *stats, int stat_slots,
-                long long P, int K, int N, const GbBnFinalize *fin, void *stream);
+                long long P, int K, int N, const GbBnFinalize *fin, const GbGemmOpts *opts, void *stream);
 /* dX (P,K) = dY (P,N) W(N,K), W in its natural (N,K) row-major layout.  Optional fused BatchNorm-backward
  * statistics of the previous layer (dX is the gradient of its post-ReLU output): y_prev (P,K) its pre-BN
  * output, ab_prev = [a,b,mean,rstd](K), dstats fp64 [stat_slots][2K] (caller-zeroed) += [sum dA,
@@ -405,11 +412,11 @@ int gb_gemm_fwd(const float *x, const float *w, const float *aff, float *y, doub
  * previous layer's gb_bn_bwd_reduce runs from the same call, the slot rows' total going to dstats_total. */
 int gb_gemm_dgrad(const float *dy, const float *w, float *dx, const float *y_prev, const float *ab_prev,
                   double *dstats, int stat_slots, long long P, int K, int N, double *dstats_total, float *dbeta,
-                  float *dgamma, void *stream);
+                  float *dgamma, const GbGemmOpts *opts, void *stream);
 /* dW (N,K) += dY (P,N)^T f(X (P,K)); accumulates (fp32 atomics, reduction over P split across
  * workgroups).  x_aff (optional) = [a(K), b(K)]: f(x) = relu(a_k x + b_k), as in gb_gemm_fwd.      */
 int gb_gemm_wgrad(const float *dy, const float *x, const float *x_aff, float *dw, long long P, int K, int N,
-                  void *stream);
+                  const GbGemmOpts *opts, void *stream);
 /* Which kernel gb_gemm_fwd (dgrad = 0) / gb_gemm_dgrad (dgrad = 1) launches for 16-byte aligned operands of
  * this shape: 1 = the row-streaming kernel (csrc/gemm_rs.hip), 0 = the LDS-tiled one (csrc/gemm_cl.hip).
  * Pure host-side introspection (no launch), used by bench.py to attribute timings per kernel.      */
@@ -421,7 +428,7 @@ int gb_gemm_uses_rs(long long P, int K, int N, int dgrad, int fused_stats, int h
  * and the moments of x_in (gb_moments3) by gb_la_wx_grad with u = 0.  GB_EINVAL when the shape is not eligible:
  * ask gb_gemm_uses_rs(P, K, N, 1, 2, 0) first.                                                          */
 int gb_gemm_dgrad_first(const float *dy, const float *w, const float *y_prev, const float *ab_prev, const float *x_in,
-                        double *sums, int slots, long long P, int K, int N, void *stream);
+                        double *sums, int slots, long long P, int K, int N, const GbGemmOpts *opts, void *stream);
 /* mom fp64 [12] (caller-zeroed) += [sum_p w_p x (3), sum_p w_p x x^T (3x3)] of x (P,3); w = row_w (P) or 1.   */
 int gb_moments3(const float *x, const float *row_w, long long P, double *mom, void *stream);
 

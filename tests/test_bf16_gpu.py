@@ -45,8 +45,9 @@ def test_bf16_gemms_against_rounded_operand_truth(bf16, P, K, N):
     Y = torch.empty(P, N, device=DEV)
     slots = fused_mlp.STAT_SLOTS if P >= 16384 else 1
     stats = torch.zeros(slots * 2 * N, dtype=torch.float64, device=DEV)
+    opts = fused_mlp._opts(X.device, st, _lib.PREC_BF16)
     fused_mlp._call("gb_gemm_fwd", X.device, _lib.ptr(X), _lib.ptr(W), _lib.ptr(aff), _lib.ptr(Y), _lib.ptr(stats), slots,
-                    P, K, N, None, st)
+                    P, K, N, None, opts, st)
     A = torch.relu(a * X + b)
     want = _r(A) @ _r(W).t()
     assert _rel(Y, want) < 1e-5
@@ -56,11 +57,11 @@ def test_bf16_gemms_against_rounded_operand_truth(bf16, P, K, N):
     # dgrad
     dX = torch.empty(P, K, device=DEV)
     fused_mlp._call("gb_gemm_dgrad", X.device, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dX), None, None, None, 0, P, K, N, None,
-                    None, None, st)
+                    None, None, opts, st)
     assert _rel(dX, _r(dY) @ _r(W)) < 1e-5
     # wgrad with the prologue on X
     dW = torch.zeros(N, K, device=DEV)
-    fused_mlp._call("gb_gemm_wgrad", X.device, _lib.ptr(dY), _lib.ptr(X), _lib.ptr(aff), _lib.ptr(dW), P, K, N, st)
+    fused_mlp._call("gb_gemm_wgrad", X.device, _lib.ptr(dY), _lib.ptr(X), _lib.ptr(aff), _lib.ptr(dW), P, K, N, opts, st)
     assert _rel(dW, _r(dY).t() @ _r(A)) < 2e-5
 
 
@@ -71,13 +72,12 @@ def test_short_reductions_stay_fp32(bf16):
     X = torch.randn(50000, 3, device=DEV)
     W = torch.randn(64, 3, device=DEV)
     out = []
-    for mode in ("bf16", "f32"):
-        fused_mlp.set_precision(mode)
+    for mode in (_lib.PREC_BF16, _lib.PREC_F32):
         Y = torch.empty(50000, 64, device=DEV)
+        st = fused_mlp._s(X)
         fused_mlp._call("gb_gemm_fwd", X.device, _lib.ptr(X), _lib.ptr(W), None, _lib.ptr(Y), None, 1, 50000, 3, 64, None,
-                        fused_mlp._s(X))
+                        fused_mlp._opts(X.device, st, mode), st)
         out.append(Y)
-    fused_mlp.set_precision("bf16")
     assert torch.equal(out[0], out[1])
 
 
@@ -135,10 +135,11 @@ def test_train_step_bf16_at_toy_size():
                                 device=DEV)
     try:
         tr = Trainer(DEV, num_view=30, model=_tiny_net(), steps_per_epoch=10, max_epoch=2, mlp_precision="bf16")
-        assert fused_mlp.get_precision() == "bf16"
-        losses = [float(tr.train_step(batch)) for _ in range(3)]
+        losses = [float(tr.train_step(batch).detach()) for _ in range(3)]
+        assert tr.mlp_precision == "bf16" and fused_mlp.get_precision() == "f32"   # the trainer's, not the thread's
     finally:
         fused_mlp.set_precision("f32")
     ref = Trainer(DEV, num_view=30, model=_tiny_net(), steps_per_epoch=10, max_epoch=2)
-    l0 = float(ref.train_step(batch))
+    l0 = float(ref.train_step(batch).detach())
     assert all(l == l for l in losses) and abs(losses[0] - l0) < 0.05 * abs(l0), (losses, l0)
+    assert losses[0] != l0  # bf16 rounding was really applied inside the trainer's steps

@@ -21,6 +21,21 @@ def _lib():
     return _lib
 
 
+_WS = {}
+
+
+def _opts(precision=0, reserved=0, scratch=True):
+    """ctypes pointer to a GbGemmOpts with a caller-owned workspace (the library allocates nothing)."""
+    import ctypes
+    L = _lib()
+    if scratch and "t" not in _WS:
+        _WS["t"] = torch.empty(L.GEMM_SCRATCH_BYTES, dtype=torch.uint8, device=DEV)
+    ws = _WS["t"] if scratch else None
+    o = L.GemmOpts(precision, reserved, ws.data_ptr() if scratch else None, ws.numel() if scratch else 0)
+    _WS.setdefault("keep", []).append(o)
+    return ctypes.pointer(o)
+
+
 @pytest.mark.parametrize("P,K,N", SHAPES)
 def test_gemm_fwd_stats_and_affine(P, K, N):
     L = _lib()
@@ -29,7 +44,7 @@ def test_gemm_fwd_stats_and_affine(P, K, N):
     W = torch.randn(N, K, device=DEV) / K ** 0.5
     Y = torch.empty(P, N, device=DEV)
     stats = torch.zeros(2 * N, dtype=torch.float64, device=DEV)
-    L.check(L.lib().gb_gemm_fwd(L.ptr(X), L.ptr(W), None, L.ptr(Y), L.ptr(stats), 1, P, K, N, None, None), "fwd")
+    L.check(L.lib().gb_gemm_fwd(L.ptr(X), L.ptr(W), None, L.ptr(Y), L.ptr(stats), 1, P, K, N, None, _opts(), None), "fwd")
     torch.cuda.synchronize()
     ref = X.double() @ W.double().t()
     scale = float(ref.abs().max()) + 1e-12
@@ -39,7 +54,7 @@ def test_gemm_fwd_stats_and_affine(P, K, N):
     # fused BatchNorm+ReLU prologue of the next layer
     aff = torch.cat([torch.randn(K, device=DEV), torch.randn(K, device=DEV)])
     Y2 = torch.empty(P, N, device=DEV)
-    L.check(L.lib().gb_gemm_fwd(L.ptr(X), L.ptr(W), L.ptr(aff), L.ptr(Y2), None, 1, P, K, N, None, None), "fwd aff")
+    L.check(L.lib().gb_gemm_fwd(L.ptr(X), L.ptr(W), L.ptr(aff), L.ptr(Y2), None, 1, P, K, N, None, None, None), "fwd aff")
     torch.cuda.synchronize()
     ref2 = torch.relu(aff[:K] * X + aff[K:]).double() @ W.double().t()
     assert float((Y2.double() - ref2).abs().max()) / (float(ref2.abs().max()) + 1e-12) < 2e-6
@@ -53,9 +68,9 @@ def test_gemm_dgrad_and_wgrad(P, K, N):
     W = torch.randn(N, K, device=DEV)
     dY = torch.randn(P, N, device=DEV)
     dX = torch.empty(P, K, device=DEV)
-    L.check(L.lib().gb_gemm_dgrad(L.ptr(dY), L.ptr(W), L.ptr(dX), None, None, None, 0, P, K, N, None, None, None, None), "dgrad")
+    L.check(L.lib().gb_gemm_dgrad(L.ptr(dY), L.ptr(W), L.ptr(dX), None, None, None, 0, P, K, N, None, None, None, _opts(), None), "dgrad")
     dW = torch.zeros(N, K, device=DEV)
-    L.check(L.lib().gb_gemm_wgrad(L.ptr(dY), L.ptr(X), None, L.ptr(dW), P, K, N, None), "wgrad")
+    L.check(L.lib().gb_gemm_wgrad(L.ptr(dY), L.ptr(X), None, L.ptr(dW), P, K, N, None, None), "wgrad")
     torch.cuda.synchronize()
     rx = dY.double() @ W.double()
     rw = dY.double().t() @ X.double()
@@ -74,7 +89,7 @@ def test_gemm_fused_epilogues_slotted(P, K, N):
     aff = torch.cat([torch.randn(K, device=DEV), torch.randn(K, device=DEV)])
     Y = torch.empty(P, N, device=DEV)
     stats = torch.zeros(slots, 2 * N, dtype=torch.float64, device=DEV)
-    L.check(L.lib().gb_gemm_fwd(L.ptr(X), L.ptr(W), L.ptr(aff), L.ptr(Y), L.ptr(stats), slots, P, K, N, None, None), "fwd")
+    L.check(L.lib().gb_gemm_fwd(L.ptr(X), L.ptr(W), L.ptr(aff), L.ptr(Y), L.ptr(stats), slots, P, K, N, None, _opts(), None), "fwd")
     torch.cuda.synchronize()
     ref = torch.relu(aff[:K] * X + aff[K:]).double() @ W.double().t()
     assert float((Y.double() - ref).abs().max()) / (float(ref.abs().max()) + 1e-12) < 2e-6
@@ -89,7 +104,7 @@ def test_gemm_fused_epilogues_slotted(P, K, N):
     dX = torch.empty(P, K, device=DEV)
     dst = torch.zeros(slots, 2 * K, dtype=torch.float64, device=DEV)
     L.check(L.lib().gb_gemm_dgrad(L.ptr(dY), L.ptr(W), L.ptr(dX), L.ptr(yprev), L.ptr(ab), L.ptr(dst), slots, P, K, N,
-                                  None, None, None, None), "dgrad bn")
+                                  None, None, None, _opts(reserved=8), None), "dgrad bn")
     torch.cuda.synchronize()
     rx = dY.double() @ W.double()
     assert float((dX.double() - rx).abs().max()) / (float(rx.abs().max()) + 1e-12) < 2e-6
@@ -103,29 +118,118 @@ def test_gemm_fused_epilogues_slotted(P, K, N):
 
 @pytest.mark.parametrize("P,K,N", [(1024, 1024, 256), (1024, 256, 1024), (4096, 512, 128), (2048, 1024, 256)])
 def test_split_reduction_products_are_bit_reproducible(P, K, N):
-    """Few-tile / long-reduction forward and dgrad products split the reduction over workgroups; the partial products
-    are stored per chunk and added in chunk order, so repeated calls return identical bits (and stay within fp32
-    rounding of the fp64 product)."""
+    """Few-tile / long-reduction forward and dgrad products split the reduction over workgroups when the CALLER hands
+    over a workspace (GbGemmOpts.scratch: the library allocates nothing): the partial products are stored per chunk
+    and added in chunk order, so repeated calls return identical bits (and stay within fp32 rounding of the fp64
+    product).  Without a workspace - or with one that is too small - the same product runs unsplit: same values to
+    fp32 rounding, also reproducible."""
+    import ctypes
     from graspbalance_amd import _lib as L
     lib = L.lib()
     g = torch.Generator(device=DEV).manual_seed(P + K)
     X = torch.randn(P, K, device=DEV, generator=g)
     W = torch.randn(N, K, device=DEV, generator=g)
     dY = torch.randn(P, N, device=DEV, generator=g)
+    small = torch.empty(4096, dtype=torch.uint8, device=DEV)
+    tiny = L.GemmOpts(0, 0, small.data_ptr(), small.numel())
 
-    def fwd():
+    def fwd(opts):
         Y = torch.full((P, N), float("nan"), device=DEV)
-        L.check(lib.gb_gemm_fwd(L.ptr(X), L.ptr(W), None, L.ptr(Y), None, 1, P, K, N, None, None), "gb_gemm_fwd")
+        L.check(lib.gb_gemm_fwd(L.ptr(X), L.ptr(W), None, L.ptr(Y), None, 1, P, K, N, None, opts, None), "gb_gemm_fwd")
         return Y
 
-    def dgrad():
+    def dgrad(opts):
         dX = torch.full((P, K), float("nan"), device=DEV)
-        L.check(lib.gb_gemm_dgrad(L.ptr(dY), L.ptr(W), L.ptr(dX), None, None, None, 0, P, K, N, None, None, None, None),
-                "gb_gemm_dgrad")
+        L.check(lib.gb_gemm_dgrad(L.ptr(dY), L.ptr(W), L.ptr(dX), None, None, None, 0, P, K, N, None, None, None, opts,
+                                  None), "gb_gemm_dgrad")
         return dX
 
     for fn, want in ((fwd, X.double() @ W.double().t()), (dgrad, dY.double() @ W.double())):
-        first = fn()
-        for _ in range(4):
-            assert torch.equal(fn(), first)
-        assert float((first.double() - want).norm() / want.norm()) < 2e-6
+        results = []
+        for opts in (_opts(), None, ctypes.pointer(tiny)):
+            first = fn(opts)
+            for _ in range(3):
+                assert torch.equal(fn(opts), first)
+            assert float((first.double() - want).norm() / want.norm()) < 2e-6
+            results.append(first)
+        assert torch.equal(results[1], results[2])           # no workspace == too small a workspace: both unsplit
+        assert float((results[0] - results[1]).abs().max()) < 1e-4 * float(want.abs().max())
+
+
+def test_options_are_per_call_two_threads_two_precisions():
+    """The library holds no mode: GbGemmOpts travels with every call.  Two host threads issue the same product
+    concurrently, one with GB_PREC_F32 and one with GB_PREC_BF16 (on two streams, 20 calls each): every fp32 result has
+    the bits of the fp32 product computed alone, every bf16 result those of the bf16 product computed alone - and the
+    two differ.  Invalid options are refused (GB_EINVAL), not ignored."""
+    import ctypes
+    import threading
+    from graspbalance_amd import _lib as L
+    lib = L.lib()
+    P, K, N = 40000, 128, 256
+    torch.manual_seed(5)
+    X = torch.randn(P, K, device=DEV)
+    W = torch.randn(N, K, device=DEV) / K ** 0.5
+
+    def product(precision, stream, out):
+        o = L.GemmOpts(precision, 0, None, 0)
+        with torch.cuda.stream(stream):
+            L.check(lib.gb_gemm_fwd(L.ptr(X), L.ptr(W), None, L.ptr(out), None, 1, P, K, N, None, ctypes.byref(o),
+                                    ctypes.c_void_p(stream.cuda_stream)), "gb_gemm_fwd")
+    alone = {}
+    for prec in (L.PREC_F32, L.PREC_BF16):
+        alone[prec] = torch.empty(P, N, device=DEV)
+        product(prec, torch.cuda.current_stream(), alone[prec])
+    torch.cuda.synchronize()
+    assert not torch.equal(alone[L.PREC_F32], alone[L.PREC_BF16])
+    want = X.double() @ W.double().t()
+    assert float((alone[L.PREC_F32].double() - want).norm() / want.norm()) < 2e-6
+    assert 1e-4 < float((alone[L.PREC_BF16].double() - want).norm() / want.norm()) < 1e-2
+    outs = {prec: [torch.empty(P, N, device=DEV) for _ in range(20)] for prec in alone}
+    streams = {prec: torch.cuda.Stream() for prec in alone}
+    torch.cuda.synchronize()
+
+    def worker(prec):
+        torch.cuda.set_device(0)
+        for out in outs[prec]:
+            product(prec, streams[prec], out)
+    threads = [threading.Thread(target=worker, args=(prec,)) for prec in alone]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    for prec in alone:
+        assert all(torch.equal(o, alone[prec]) for o in outs[prec]), prec
+    bad = L.GemmOpts(7, 0, None, 0)
+    assert lib.gb_gemm_fwd(L.ptr(X), L.ptr(W), None, L.ptr(outs[0][0]), None, 1, P, K, N, None, ctypes.byref(bad), None) == -1
+    bad = L.GemmOpts(0, 500, None, 0)
+    assert lib.gb_gemm_wgrad(L.ptr(X), L.ptr(X), None, L.ptr(outs[0][0]), P, K, K, ctypes.byref(bad), None) == -1
+
+
+def test_fused_nodes_keep_their_forward_precision_in_backward():
+    """fused_mlp.precision is per thread and captured by every fused node at forward time: a backward that runs after
+    the block has exited (and on autograd's worker thread) still uses the forward's precision, and two stacks built
+    under different settings coexist in one graph."""
+    from graspbalance_amd import fused_mlp
+    import torch.nn as nn
+    torch.manual_seed(3)
+    conv, bn = nn.Conv1d(64, 128, 1, bias=False).to(DEV), nn.BatchNorm1d(128).to(DEV)
+    X = torch.randn(20000, 64, device=DEV)
+
+    def run(mode, backward_inside):
+        for p in list(conv.parameters()) + list(bn.parameters()):
+            p.grad = None
+        x = X.clone().requires_grad_(True)
+        with fused_mlp.precision(mode):
+            out = fused_mlp.conv_bn_act(x, conv, bn)
+            if backward_inside:
+                out.square().sum().backward()
+        if not backward_inside:
+            assert fused_mlp.get_precision() == "f32"
+            out.square().sum().backward()
+        return out.detach(), x.grad.clone(), conv.weight.grad.clone()
+    f32 = run("f32", True)
+    a, b = run("bf16", True), run("bf16", False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])     # dgrad: deterministic, same precision either way
+    assert float((a[2] - b[2]).norm() / a[2].norm()) < 1e-5         # wgrad: fp32 atomics, same precision
+    assert float((a[1] - f32[1]).norm() / f32[1].norm()) > 1e-4     # and it is not the fp32 result

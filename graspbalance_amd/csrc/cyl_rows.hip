@@ -79,7 +79,8 @@ __global__ __launch_bounds__(CU_MAXW) void cyl_rows_kernel(const float *__restri
                                                            const int64_t *__restrict__ off, int n, int m, int W,
                                                            float *__restrict__ x0, float *__restrict__ row_w,
                                                            uint16_t *__restrict__ row_w16,
-                                                           int32_t *__restrict__ row_mem) {
+                                                           int32_t *__restrict__ row_mem,
+                                                           int32_t *__restrict__ row_key) {
   const long long r = blockIdx.x;
   const int u = threadIdx.x;
   if (u >= count[r]) return;
@@ -96,6 +97,9 @@ __global__ __launch_bounds__(CU_MAXW) void cyl_rows_kernel(const float *__restri
   row_w[row] = (float)(mt >> 8);
   row_w16[row] = (uint16_t)(mt >> 8);
   row_mem[row] = mt & 0xFF;
+  // (seed << 13) | (multiplicity << 4) | member bits: everything the pooled GEMM epilogue (gemm_rs.hip, RS_STATS_POOL)
+  // needs to know about a row, in one word (multiplicity <= 256 slots, D <= 4 crops, < 2^18 seeds: host-checked)
+  if (row_key) row_key[row] = (int32_t)((r << 13) | ((long long)(mt >> 8) << 4) | (mt & 0xF));
 }
 
 }  // namespace gb
@@ -114,14 +118,15 @@ extern "C" int gb_cyl_unique(const int32_t *idx, int D, long long R, int ns, int
 
 extern "C" int gb_cyl_rows(const float *xyz, const float *centres, const float *rot, const int32_t *sorted,
                            const int32_t *meta, const int32_t *count, const int64_t *off, int b, int n, int m, int W,
-                           float *x0, float *row_w, uint16_t *row_w16, int32_t *row_mem, void *stream) {
+                           float *x0, float *row_w, uint16_t *row_w16, int32_t *row_mem, int32_t *row_key,
+                           void *stream) {
   if (b < 0 || n < 1 || m < 0 || W < 1 || W > CU_MAXW || !xyz || !centres || !rot || !sorted || !meta || !count || !off ||
       !x0 || !row_w || !row_w16 || !row_mem)
     return GB_EINVAL;
   const long long R = (long long)b * m;
   if (R == 0) return GB_OK;
-  if (R > 0x7fffffffLL) return GB_ERANGE;
+  if (R > 0x7fffffffLL || (row_key && R >= (1 << 18))) return GB_ERANGE;
   hipLaunchKernelGGL(cyl_rows_kernel, dim3((unsigned)R), dim3(CU_MAXW), 0, as_stream(stream), xyz, centres, rot, sorted,
-                     meta, count, off, n, m, W, x0, row_w, row_w16, row_mem);
+                     meta, count, off, n, m, W, x0, row_w, row_w16, row_mem, row_key);
   return check_launch("gb_cyl_rows");
 }

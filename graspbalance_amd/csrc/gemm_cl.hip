@@ -39,10 +39,11 @@ struct Operand {
   long long red;    // valid reduction indices [0, red)
   long long ld;
   const float *aff; // optional [a(red), b(red)]: value = relu(a_k * x + b_k)   (OP_KC only)
+  const float *red_w; // optional (OP_RC only) [red]: the value is multiplied by red_w[reduction index] (after aff)
 };
 
 // registers holding one thread's share (ROWS/16 floats... i.e. 4 or 8) of a ROWS x 16 operand tile
-struct Frag { float v[8]; float ca[4], cb[4]; bool ok[2]; };  // data, the affine (a,b) of its 4 channels, row/step validity
+struct Frag { float v[8]; float ca[4], cb[4]; float rw[2]; bool ok[2]; };  // data, affine (a,b) of its 4 channels, reduction weight, validity
 
 template <int KIND, bool VEC, int ROWS>
 __device__ __forceinline__ void load_frag(const Operand &op, long long row0, long long k0, Frag &f) {
@@ -79,6 +80,7 @@ __device__ __forceinline__ void load_frag(const Operand &op, long long row0, lon
       const float *p = op.src + k * op.ld + row;
       const bool kok = k < op.red;
       f.ok[h] = kok;
+      f.rw[h] = (op.red_w && kok) ? op.red_w[k] : 1.f;
       if (VEC && kok && row + 3 < op.rows) {
         const float4 q = *reinterpret_cast<const float4 *>(p);
         f.v[4 * h + 0] = q.x; f.v[4 * h + 1] = q.y; f.v[4 * h + 2] = q.z; f.v[4 * h + 3] = q.w;
@@ -110,6 +112,14 @@ __device__ __forceinline__ void apply_aff(Frag &f) {
       const float z = f.ca[e] * f.v[4 * h + e] + f.cb[e];
       f.v[4 * h + e] = (f.ok[h] && z > 0.f) ? z : 0.f;
     }
+}
+// ... then the per-reduction-index weight of a row-contiguous operand (gb_gemm_gram)
+template <int ROWS>
+__device__ __forceinline__ void apply_red_w(Frag &f) {
+#pragma unroll
+  for (int h = 0; h < ROWS / 64; ++h)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f.v[4 * h + e] *= f.rw[h];
 }
 
 template <int KIND, int ROWS>
@@ -179,6 +189,7 @@ __global__ __launch_bounds__(GTPB, ((GM == 128 && GN == 128 && (EPI == 0 || EPI 
   load_frag<KB, VB, GN>(b, n0, kbeg, fb);
   if (a.aff) apply_aff<GM>(fa);
   if (b.aff) apply_aff<GN>(fb);
+  if constexpr (KA == OP_RC) { if (a.red_w) apply_red_w<GM>(fa); }
   store_frag<KA, GM>(lds_a[0], fa);
   store_frag<KB, GN>(lds_b[0], fb);
   __syncthreads();
@@ -228,6 +239,7 @@ __global__ __launch_bounds__(GTPB, ((GM == 128 && GN == 128 && (EPI == 0 || EPI 
     if (more) {
       if (a.aff) apply_aff<GM>(fa);
       if (b.aff) apply_aff<GN>(fb);
+      if constexpr (KA == OP_RC) { if (a.red_w) apply_red_w<GM>(fa); }
       store_frag<KA, GM>(lds_a[buf ^ 1], fa);
       store_frag<KB, GN>(lds_b[buf ^ 1], fb);
     }
@@ -521,6 +533,45 @@ extern "C" int gb_gemm_fwd_w(const float *x, const float *w, const float *aff, c
   return gemm_fwd_impl(x, w, aff, row_w16, y, stats, stat_slots, P, K, N, fin, opts, stream);
 }
 
+// The last layer of a crop stack (reference modules.py:104-124: SharedMLP's final conv + BatchNorm + ReLU, then
+// max_pool2d over each crop) WITHOUT storing its output: the weighted BatchNorm sums and per-(tile, seed, crop,
+// column) extrema of sign(gamma)*y leave the GEMM's epilogue (csrc/gemm_rs.hip, RS_STATS_POOL); gb_pool_pairs finishes
+// the pooling once the statistics are known.  Only the row-streaming kernel implements it: GB_EINVAL when the shape is
+// not eligible (ask gb_gemm_uses_rs(P, K, N, 0, 3, has_aff)).
+extern "C" int gb_gemm_fwd_pool(const float *x, const float *w, const float *aff, const int32_t *row_key,
+                                const float *gamma, float *pairs, double *stats, int stat_slots, long long P, int K,
+                                int N, int D, const GbBnFinalize *fin, const GbGemmOpts *opts, void *stream) {
+  if (P < 1 || K < 1 || N < 1 || D < 1 || D > 4 || !x || !w || !row_key || !gamma || !pairs || !stats || stat_slots < 1 ||
+      opts_bad(opts) || reinterpret_cast<uintptr_t>(row_key) % 16 || reinterpret_cast<uintptr_t>(pairs) % 8)
+    return GB_EINVAL;
+  if (fin && (!fin->gamma || !fin->beta || !fin->ab || fin->P < 1 || fin->training != 1)) return GB_EINVAL;
+  if (P > 0x7fffffffLL - 64) return GB_ERANGE;
+  const RsPool pool = {row_key, gamma, reinterpret_cast<float2 *>(pairs), D};
+  if (!rs_gemm_try(x, w, nullptr, aff, stats, stat_slots, nullptr, nullptr, P, K, N, 1, RS_STATS_POOL, as_stream(stream),
+                   opts_bf16(opts), opts_reserved(opts), nullptr, nullptr, &pool))
+    return GB_EINVAL;
+  return finalize_after(check_launch("gb_gemm_fwd_pool"), fin, stats, stat_slots, N, stream);
+}
+
+// Dense half of the low-rank backward of a pooled last layer (csrc/crop_bwd.hip): dz (P,K) holds the sparse part S on
+// entry and dX~ = S - w (v + X~ M) on return, X~ = relu(a2*y2 + b2); the BatchNorm-backward sums of the layer that
+// produced y2 (mask a2*y2 + b2 > 0) leave the same epilogue, exactly as in gb_gemm_dgrad.  Row-streaming kernel only.
+extern "C" int gb_crop_bwd_dense(const float *y2, const float *ab2, const float *mmat, const float *vvec,
+                                 const float *row_w, float *dz, double *dstats, int stat_slots, long long P, int K,
+                                 double *dstats_total, float *dbeta, float *dgamma, const GbGemmOpts *opts,
+                                 void *stream) {
+  if (P < 1 || K < 1 || !y2 || !ab2 || !mmat || !vvec || !row_w || !dz || !dstats || stat_slots < 1 || !dbeta || !dgamma ||
+      opts_bad(opts) || reinterpret_cast<uintptr_t>(row_w) % 16)
+    return GB_EINVAL;
+  RsPool lr = {nullptr, nullptr, nullptr, 0, vvec, row_w};
+  if (!rs_gemm_try(y2, mmat, dz, ab2, dstats, stat_slots, y2, ab2, P, K, K, 0, RS_BNBWD_LR, as_stream(stream),
+                   opts_bf16(opts), opts_reserved(opts), nullptr, nullptr, &lr))
+    return GB_EINVAL;
+  const int rc = check_launch("gb_crop_bwd_dense");
+  if (rc != GB_OK) return rc;
+  return gb_bn_bwd_reduce(dstats, stat_slots, K, stat_slots > 1 ? dstats_total : nullptr, dbeta, dgamma, stream);
+}
+
 // dX (P,K) = dY (P,N) W(N,K)   with W in its natural (N,K) row-major layout (no transposed copy).
 // Optional fused BatchNorm-backward statistics of the PREVIOUS layer (whose post-ReLU activation is this
 // GEMM's input, i.e. dX is its dZ): y_prev (P,K) pre-BN output, ab_prev = [a,b,mean,rstd](K),
@@ -604,6 +655,31 @@ extern "C" int gb_gemm_wgrad(const float *dy, const float *x, const float *x_aff
   launch_gemm<OP_RC, OP_RC, EPI_ATOMIC>(a, b, va, vb, dw, K, nullptr, kchunk, (unsigned)chunks, as_stream(stream),
                                         opts_bf16(opts));
   return check_launch("gb_gemm_wgrad");
+}
+
+// G (K,K) += sum_p w_p f(x_p) f(x_p)^T, f = relu(a*x + b) (x_aff, optional), w = row_w (optional): the weighted Gram
+// matrix of a layer's activations - what the weight gradient of a BatchNorm layer behind it needs INSTEAD of the dense
+// product dY^T X when dY is (sparse + affine in y = X W^T) (csrc/crop_bwd.hip).  Same kernel and split of the row
+// reduction as gb_gemm_wgrad (dy := w * f(x)); G is symmetric, both halves are formed.  Caller zeroes G.
+extern "C" int gb_gemm_gram(const float *x, const float *x_aff, const float *row_w, float *gmat, long long P, int K,
+                            const GbGemmOpts *opts, void *stream) {
+  if (P < 0 || K < 1 || !x || !gmat || opts_bad(opts)) return GB_EINVAL;
+  if (P == 0) return GB_OK;
+  Operand a = {x, K, P, K, x_aff, row_w};
+  Operand b = {x, K, P, K, x_aff, nullptr};
+  const long long tiles = (long long)((K + (K <= 64 ? 63 : 127)) / (K <= 64 ? 64 : 128)) *
+                          ((K + (K <= 64 ? 63 : 127)) / (K <= 64 ? 64 : 128));
+  long long chunks = 1024 / tiles;
+  if (chunks < 1) chunks = 1;
+  long long kchunk = (P + chunks - 1) / chunks;
+  kchunk = (kchunk + GK - 1) / GK * GK;
+  if (kchunk < 256) kchunk = 256;
+  chunks = (P + kchunk - 1) / kchunk;
+  if (chunks > 65535) return GB_ERANGE;
+  const bool v = (K % 4 == 0) && aligned16(x);
+  launch_gemm<OP_RC, OP_RC, EPI_ATOMIC>(a, b, v, v, gmat, K, nullptr, kchunk, (unsigned)chunks, as_stream(stream),
+                                        opts_bf16(opts));
+  return check_launch("gb_gemm_gram");
 }
 
 // dgrad into the FIRST layer of a stack whose input x has 3 channels (xyz-only grouped rows): dZ = dY W is formed

@@ -8,14 +8,26 @@ namespace gb {
 enum { RS_STORE = 0,   // D only
        RS_STATS = 1,   // + column sums of D and D^2                       (BatchNorm batch statistics)
        RS_BNBWD = 2,   // + column sums of g and g*xhat, g = D*[a*y+b > 0]  (BatchNorm-backward sums)
-       RS_BNBWD_X = 3 }; // those two + sum g*x_j (j < 3) for the layer's 3-channel input x; D is NOT stored
+       RS_BNBWD_X = 3,   // those two + sum g*x_j (j < 3) for the layer's 3-channel input x; D is NOT stored
+       RS_STATS_POOL = 4,   // RS_STATS with per-row keys; D is NOT stored: per (tile, seed, crop, column) extrema leave
+       RS_BNBWD_LR = 5 };   // RS_BNBWD on D' = D_in - w_row*(D + v_col): D_in = what d holds on entry (read-modify-write)
 
 // D (P,C) = f(A (P,R)) B (R,C);  w_kc = 1: B[r][c] = w[c*R + r], 0: B[r][c] = w[r*C + c].
 // Returns false (nothing launched) when the shape does not suit the kernel; the caller then uses the
 // LDS-tiled kernel.  bf16 / reserved_cus: GbGemmOpts.precision / .reserved_cus of the call.
+// RS_STATS_POOL inputs / outputs (see gemm_rs.hip): row keys, BatchNorm weight, crops per seed, partial extrema
+struct RsPool {
+  const int32_t *key;
+  const float *gamma;
+  float2 *pairs;
+  int D;
+  const float *lr_v = nullptr;     // RS_BNBWD_LR: v (C)
+  const float *lr_roww = nullptr;  // RS_BNBWD_LR: w (P rounded up to 32 readable floats)
+};
+
 bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, double *stats, int slots,
                  const float *epi_y, const float *epi_ab, long long P, int R, int C, int w_kc, int epi,
                  hipStream_t s, bool bf16, int reserved_cus, const float *epi_x = nullptr,
-                 const uint16_t *epi_w16 = nullptr);
+                 const uint16_t *epi_w16 = nullptr, const RsPool *pool = nullptr);
 
 }  // namespace gb

@@ -40,6 +40,13 @@ struct RsArgs {
   const float *epi_ab;  // RS_BNBWD: [a, b, mean, rstd](C)
   const float *epi_x;   // RS_BNBWD_X: (P,3) the 3-channel input of the layer D is the gradient of
   const uint16_t *epi_w16;  // RS_STATS (optional): per-row multiplicity, padded with zeros to a multiple of 32 rows
+  const int32_t *epi_key;   // RS_STATS_POOL: per-row (seed << 13) | (multiplicity << 4) | member bits, zero-padded likewise
+  const float *epi_gamma;   // RS_STATS_POOL: BatchNorm weight (C): its sign decides whether a crop's max of relu(a*y+b)
+                            // sits at the largest or the smallest y
+  float2 *pairs;            // RS_STATS_POOL: [(tile + seed)][D][C] (sign*y, row bits) partial extrema, see pool_epilogue
+  int pool_d;               // RS_STATS_POOL: crops per seed (1..4)
+  const float *lr_v;        // RS_BNBWD_LR: per-column offset v (C)
+  const float *lr_roww;     // RS_BNBWD_LR: per-row weight w (readable up to a multiple of 32 rows)
   long long P;
   int R, C, lda, ldd;
   int w_kc;             // 1: B[r][c] = w[c*R + r] (forward, W (C,R));  0: B[r][c] = w[r*C + c] (dgrad, W (R,C))
@@ -51,7 +58,7 @@ struct RsArgs {
 // BF (GB_PREC_BF16): B lives in LDS as bf16 in [k / 8][C32][8] order - the 8 reduction indices one lane feeds to a
 // v_mfma_f32_32x32x16_bf16 are 16 contiguous bytes - and a lane's 16 fp32 values of A become two bf16x8 operands.
 template <int NT, int EPI, bool BF = false>
-__global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_BNBWD_X) ? 4 : 2)) void gemm_rs_kernel(RsArgs g) {
+__global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_BNBWD_X && EPI != RS_BNBWD_LR) ? 4 : 2)) void gemm_rs_kernel(RsArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int C32 = NT * 32;
   const int rpad = g.nch * RS_CH;
@@ -138,7 +145,8 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
   // (and over the four SIMDs of each) instead of filling the 8 waves of the first workgroups
   long long tile = (long long)wave * gridDim.x + blockIdx.x;
 
-  constexpr bool BNB = EPI == RS_BNBWD || EPI == RS_BNBWD_X;
+  constexpr bool BNB = EPI == RS_BNBWD || EPI == RS_BNBWD_X || EPI == RS_BNBWD_LR;
+  constexpr bool LR = EPI == RS_BNBWD_LR;  // D' = D_in - w_row*(D + v_col), see gemm_rs.h
   constexpr int NS = EPI == RS_BNBWD_X ? 5 : 2;  // column sums per column: [g, g*xhat (, g*x0, g*x1, g*x2)] / [y, y^2]
   double dsum[NT], dsq[NT], dtx[EPI == RS_BNBWD_X ? NT : 1][3];
 #pragma unroll
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
       }
       // RS_BNBWD: the y values the epilogue needs are requested BEFORE the tile's last MFMA block, so their
       // latency hides behind it (registers permitting; otherwise per column tile inside the epilogue)
-      constexpr bool YPRE = BNB && NT <= 4;
+      constexpr bool YPRE = BNB && !LR && NT <= 4;  // (LR also holds D_in and the row weights in its epilogue)
       float yv[YPRE ? NT : 1][16];
       float xr[EPI == RS_BNBWD_X ? 16 : 1][3];  // RS_BNBWD_X: the 3-channel input rows of this tile, same early request
       if constexpr (EPI == RS_BNBWD_X) {
@@ -300,6 +308,61 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
         // 32-bit lane offset.  (The generic path spent ~16 vector instructions per stored element on them: ~10 k cycles
         // per tile beside 32 k cycles of MFMA.)
         const bool full = tile * 32 + 32 <= g.P && g.C == C32;
+        if constexpr (EPI == RS_STATS_POOL) {
+          // Y is NOT stored.  What leaves the tile: the weighted BatchNorm sums (as RS_STATS) and, per (seed in the
+          // tile, crop d, column), the extreme of sign(gamma)*y over the seed's member rows in this tile + the row
+          // holding it - relu(a*y + b) is monotone in y with the sign of a = gamma*rstd, so the crop's pooled value and
+          // its arg-max row follow from these extrema once the statistics are known (pool_pairs_kernel).  A seed's rows
+          // are contiguous, so a (tile, seed) pair is unique and gets the slot tile + seed: plain stores, no atomics.
+          // C == C32 (host-checked); rows >= P carry key 0 (no membership, weight 0) and accumulators of exact zeros.
+          const long long trow = (long long)__builtin_amdgcn_readfirstlane((int)tile) * 32;
+          const long long lastrow = trow + 31 < g.P ? trow + 31 : g.P - 1;
+          const int s_lo = g.epi_key[trow] >> 13, s_hi = g.epi_key[lastrow] >> 13;  // wave-uniform (scalar loads)
+          // the row keys of this lane's 16 rows (rk[r]: row 4h + (r&3) + 8(r>>2)); requested here, not before the
+          // tile's last MFMA block: 16 more live registers there spill (the SIMD's other wave covers the L2 round trip)
+          int rk[16];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int4 k4 = *reinterpret_cast<const int4 *>(g.epi_key + trow + 4 * h + 8 * i);
+            rk[4 * i] = k4.x; rk[4 * i + 1] = k4.y; rk[4 * i + 2] = k4.z; rk[4 * i + 3] = k4.w;
+          }
+          // column tile by column tile (its 16 accumulators are dead afterwards: the register pressure of the dynamic
+          // seed / crop loops stays that of ONE column tile)
+#pragma unroll
+          for (int q = 0; q < NT; ++q) {
+            if (!in(q)) continue;
+            float cs = 0.f, cq = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float v = acc[q][r];
+              const float wv = (float)((rk[r] >> 4) & 0x1FF) * v;
+              cs += wv;
+              cq += wv * v;
+            }
+            dsum[q] += (double)cs;
+            dsq[q] += (double)cq;
+            const float sg = g.epi_gamma[q * 32 + m] < 0.f ? -1.f : 1.f;
+            float kv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { kv[r] = sg * acc[q][r]; acc[q][r] = 0.f; }
+            for (int sd = s_lo; sd <= s_hi; ++sd) {
+              for (int d = 0; d < g.pool_d; ++d) {
+                float best = -INFINITY;
+                int brow = 0x7fffffff;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                  const bool member = (rk[r] >> 13) == sd && ((rk[r] >> d) & 1);
+                  if (member && kv[r] > best) { best = kv[r]; brow = (int)trow + 4 * h + (r & 3) + 8 * (r >> 2); }
+                }
+                const float ob = __shfl_xor(best, 32);
+                const int orow = __shfl_xor(brow, 32);
+                if (ob > best || (ob == best && orow < brow)) { best = ob; brow = orow; }
+                if (h == 0)
+                  g.pairs[((size_t)(tile + sd) * g.pool_d + d) * C32 + q * 32 + m] = make_float2(best, __int_as_float(brow));
+              }
+            }
+          }
+        } else
         if (full) {
           const unsigned lane_off = (unsigned)(4 * h) * (unsigned)g.ldd + (unsigned)m;
           // the tile index is the same in every lane, but derived from threadIdx: tell the compiler (scalar registers,
@@ -307,10 +370,28 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
           const long long trow = (long long)__builtin_amdgcn_readfirstlane((int)tile) * 32;
           bool weighted = false;
           if constexpr (EPI == RS_STATS) weighted = g.epi_w16 != nullptr;
+          float lw[LR ? 16 : 1];
+          if constexpr (LR) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float4 w4 = *reinterpret_cast<const float4 *>(g.lr_roww + trow + 4 * h + 8 * i);
+              lw[4 * i] = w4.x; lw[4 * i + 1] = w4.y; lw[4 * i + 2] = w4.z; lw[4 * i + 3] = w4.w;
+            }
+          }
 #pragma unroll
           for (int q = 0; q < NT; ++q) {
             if (!in(q)) continue;
             float cs = 0.f, cq = 0.f, ct[3] = {0.f, 0.f, 0.f};
+            float din[LR ? 16 : 1];
+            float lv = 0.f;
+            if constexpr (LR) {
+              lv = g.lr_v[q * 32 + m];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const float *dp = g.d + (trow + (r & 3) + 8 * (r >> 2)) * (long long)g.ldd + q * 32;
+                din[r] = dp[lane_off];
+              }
+            }
             if constexpr (BNB && !COEF_REGS) {
               const int col = q * 32 + m;
               ea[q] = g.epi_ab[col];
@@ -328,7 +409,8 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const float v = acc[q][r];
+              float v = acc[q][r];
+              if constexpr (LR) v = din[r] - lw[r] * (v + lv);
               if constexpr (EPI != RS_BNBWD_X) {
                 float *dp = g.d + (trow + (r & 3) + 8 * (r >> 2)) * (long long)g.ldd + q * 32;  // wave-uniform
                 dp[lane_off] = v;
@@ -386,8 +468,9 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const long long row = row0 + (r & 3) + 8 * (r >> 2);
-            const float v = acc[q][r];
+            float v = acc[q][r];
             if (colok && row < g.P) {
+              if constexpr (LR) v = g.d[row * g.ldd + col] - g.lr_roww[row] * (v + g.lr_v[col]);
               if constexpr (EPI != RS_BNBWD_X) g.d[row * g.ldd + col] = v;  // _X: D itself is not needed
               if constexpr (EPI == RS_STATS) {
                 if (g.epi_w16) {  // the row stands for `mult` identical rows of the original batch
@@ -516,8 +599,9 @@ static bool rs_shape_ok(long long P, int R, int C, int epi, bool has_aff, int *n
   const int tiles_c = (C + 31) / 32;
   const int nt = tiles_c <= 2 ? 2 : tiles_c <= 4 ? 4 : tiles_c == 5 ? 5 : tiles_c <= 8 ? 8 : 0;
   if (!nt) return false;
-  if (epi == RS_BNBWD && nt == 8) return false;  // accumulators + y prefetch do not fit the register file
+  if ((epi == RS_BNBWD || epi == RS_BNBWD_LR) && nt == 8) return false;  // accumulators + y prefetch do not fit the register file
   if (epi == RS_BNBWD_X && nt > 2) return false;  // 64-wide first layers only (registers)
+  if (epi == RS_STATS_POOL && C != nt * 32) return false;  // the pooled epilogue has no column bounds checks
   // MFMA work wasted on padding must stay small
   if ((long long)nch * RS_CH * nt * 32 * 4 > (long long)R * C * 5) return false;
   const size_t lds_bytes = ((size_t)nch * RS_CH * nt * 32 + (has_aff ? 2 * nch * RS_CH : 0)) * sizeof(float);
@@ -529,16 +613,20 @@ static bool rs_shape_ok(long long P, int R, int C, int epi, bool has_aff, int *n
 
 bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, double *stats, int slots,
                  const float *epi_y, const float *epi_ab, long long P, int R, int C, int w_kc, int epi,
-                 hipStream_t s, bool bf16, int reserved_cus, const float *epi_x, const uint16_t *epi_w16) {
+                 hipStream_t s, bool bf16, int reserved_cus, const float *epi_x, const uint16_t *epi_w16,
+                 const RsPool *pool) {
   int nt = 0;
   size_t lds_bytes = 0;
   if (!rs_shape_ok(P, R, C, epi, aff != nullptr, &nt, &lds_bytes)) return false;
+  if (epi == RS_STATS_POOL && (!pool || C != nt * 32 || pool->D < 1 || pool->D > 4)) return false;
+  if (epi == RS_BNBWD_LR && (!pool || !pool->lr_v || !pool->lr_roww || !d)) return false;
   if (reinterpret_cast<uintptr_t>(a) % 16 != 0 || (w_kc && reinterpret_cast<uintptr_t>(w) % 16 != 0)) return false;
   const int nch = (R + RS_CH - 1) / RS_CH;
   const int stagger = 1, tail_split = 1;  // both measured to help
-  RsArgs g = {a, w, d, aff, stats, epi_y, epi_ab, epi_x, epi_w16, P, R, C, R, C, w_kc, slots < 1 ? 1 : slots, nch, stagger,
-              tail_split};
-  const int bpc = (nt <= 2 && epi != RS_BNBWD && epi != RS_BNBWD_X && lds_bytes <= 78 * 1024) ? 2 : 1;
+  RsArgs g = {a, w, d, aff, stats, epi_y, epi_ab, epi_x, epi_w16, pool ? pool->key : nullptr,
+              pool ? pool->gamma : nullptr, pool ? pool->pairs : nullptr, pool ? pool->D : 0,
+              pool ? pool->lr_v : nullptr, pool ? pool->lr_roww : nullptr, P, R, C, R, C, w_kc, slots < 1 ? 1 : slots, nch, stagger, tail_split};
+  const int bpc = (nt <= 2 && epi != RS_BNBWD && epi != RS_BNBWD_X && epi != RS_BNBWD_LR && lds_bytes <= 78 * 1024) ? 2 : 1;
   if (epi == RS_BNBWD_X) {
     // the closing per-column reduction reuses the LDS of B as [waves][5][64] doubles = 20 KB: more than the B image of
     // a reduction of <= 64 (16 KB).  (Round 1 launched with the B size only: for a 64 -> 64 second layer - SA1's
@@ -549,8 +637,10 @@ bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, dou
   }
 #define GB_RS(NT_)                                                         \
   do {                                                                     \
-    if (epi == RS_STATS) rs_launch<NT_, RS_STATS>(g, lds_bytes, bpc, s, bf16, reserved_cus);   \
+    if (epi == RS_STATS_POOL) rs_launch<NT_, RS_STATS_POOL>(g, lds_bytes, bpc, s, bf16, reserved_cus); \
+    else if (epi == RS_STATS) rs_launch<NT_, RS_STATS>(g, lds_bytes, bpc, s, bf16, reserved_cus);   \
     else if (epi == RS_BNBWD) rs_launch<NT_, RS_BNBWD>(g, lds_bytes, bpc, s, bf16, reserved_cus); \
+    else if (epi == RS_BNBWD_LR) rs_launch<NT_, RS_BNBWD_LR>(g, lds_bytes, bpc, s, bf16, reserved_cus); \
     else rs_launch<NT_, RS_STORE>(g, lds_bytes, bpc, s, bf16, reserved_cus);                   \
   } while (0)
   if (nt == 2) GB_RS(2);
@@ -567,7 +657,8 @@ bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, dou
 // 1 = gemm_rs_kernel, 0 = gemm_cl_kernel.  Introspection for bench.py's per-kernel roofline accounting.
 extern "C" int gb_gemm_uses_rs(long long P, int K, int N, int dgrad, int fused_stats, int has_aff) {
   const int R = dgrad ? N : K, C = dgrad ? K : N;
-  // fused_stats = 2 (dgrad only): the first-layer form gb_gemm_dgrad_first
-  const int epi = fused_stats ? (dgrad ? (fused_stats == 2 ? gb::RS_BNBWD_X : gb::RS_BNBWD) : gb::RS_STATS) : gb::RS_STORE;
+  // fused_stats = 2 (dgrad only): the first-layer form gb_gemm_dgrad_first; 3 (forward only): gb_gemm_fwd_pool
+  const int epi = fused_stats ? (dgrad ? (fused_stats == 2 ? gb::RS_BNBWD_X : gb::RS_BNBWD)
+                                       : (fused_stats == 3 ? gb::RS_STATS_POOL : gb::RS_STATS)) : gb::RS_STORE;
   return gb::rs_shape_ok(P, R, C, epi, has_aff != 0, nullptr, nullptr) ? 1 : 0;
 }

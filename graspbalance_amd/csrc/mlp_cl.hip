@@ -485,6 +485,45 @@ __global__ __launch_bounds__(CL_TPB) void affine_relu_maxpool_members_kernel(
   }
 }
 
+// Second half of the pooled last layer (gb_gemm_fwd_pool): seed r's rows [off, off + cnt) span the 32-row tiles
+// t0 = off / 32 .. t1 = (off + cnt - 1) / 32, and the GEMM left, for each of them, the extreme of sign(gamma)*y over
+// the seed's members of crop d in that tile at pairs[(t + r)][d][c] (value, row).  With a = gamma*rstd of the same
+// sign, max over the crop of relu(a*y + b) = relu(a*y* + b) at that extreme y*: out, arg (absolute row, the lowest
+// one among equal extremes) and ystar = y* (what the backward needs of the never-stored layer output).
+template <int D>
+__global__ __launch_bounds__(CL_TPB) void pool_pairs_kernel(const float2 *__restrict__ pairs,
+                                                            const int64_t *__restrict__ off,
+                                                            const int32_t *__restrict__ cnt,
+                                                            const float *__restrict__ ab,
+                                                            const float *__restrict__ gamma, float *__restrict__ out,
+                                                            int32_t *__restrict__ arg, float *__restrict__ ystar,
+                                                            long long R, int C) {
+  const int gpb = CL_TPB / C;  // C threads per seed (one column each: consecutive lanes read consecutive pairs)
+  const long long r = (long long)blockIdx.x * gpb + threadIdx.x / C;
+  if (threadIdx.x / C >= gpb || r >= R) return;
+  const int c = threadIdx.x % C;
+  const float a = ab[c], b = ab[C + c], sg = gamma[c] < 0.f ? -1.f : 1.f;
+  const long long u0 = off[r], t0 = u0 / 32, t1 = (u0 + cnt[r] - 1) / 32;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    float best = -INFINITY;
+    int brow = 0x7fffffff;
+    for (long long t = t0; t <= t1; ++t) {  // tiles in row order: a strict > keeps the lowest row among equal values
+      const float2 p = pairs[((size_t)(t + r) * D + d) * C + c];
+      const int row = __float_as_int(p.y);
+      if (p.x > best || (p.x == best && row < brow)) { best = p.x; brow = row; }
+    }
+    const bool any = brow != 0x7fffffff;
+    const float y = any ? sg * best : 0.f;
+    float o = a * y + b;
+    o = (any && o > 0.f) ? o : 0.f;
+    const size_t at = (size_t)(r * D + d) * C + c;
+    out[at] = o;
+    arg[at] = any ? brow : (int)u0;
+    ystar[at] = y;
+  }
+}
+
 // BatchNorm + ReLU + member-max-pool backward for the distinct rows: the gradient of row u sums, over the cylinders
 // d whose arg-max it is, dout*[out > 0]; every COPY of the row also receives the -(dbeta/P + xhat*dgamma/P) terms, so
 // with multiplicity w:  dy[u] = a*(g - w*(dbeta/P) - xhat*(w*dgamma/P)),  P = rows of the original batch.
@@ -856,6 +895,23 @@ extern "C" int gb_affine_relu_maxpool_members(const float *y, const float *ab, c
   if (D == 1) GB_MP(1); else if (D == 2) GB_MP(2); else GB_MP(4);
 #undef GB_MP
   return check_launch("gb_affine_relu_maxpool_members");
+}
+
+extern "C" int gb_pool_pairs(const float *pairs, const int64_t *off, const int32_t *cnt, const float *ab,
+                             const float *gamma, float *out, int32_t *arg, float *ystar, long long R, int D, int C,
+                             void *stream) {
+  if (R < 0 || D < 1 || D > 4 || C < 1 || C > CL_TPB || CL_TPB % C || !pairs || !off || !cnt || !ab || !gamma || !out ||
+      !arg || !ystar || reinterpret_cast<uintptr_t>(pairs) % 8)
+    return GB_EINVAL;
+  if (R == 0) return GB_OK;
+  const int gpb = CL_TPB / C;
+  const dim3 grid((unsigned)((R + gpb - 1) / gpb));
+  const float2 *pp = reinterpret_cast<const float2 *>(pairs);
+#define GB_PP(D_) hipLaunchKernelGGL((pool_pairs_kernel<D_>), grid, dim3(CL_TPB), 0, as_stream(stream), pp, off, cnt, ab, \
+                                     gamma, out, arg, ystar, R, C)
+  if (D == 1) GB_PP(1); else if (D == 2) GB_PP(2); else if (D == 3) GB_PP(3); else GB_PP(4);
+#undef GB_PP
+  return check_launch("gb_pool_pairs");
 }
 
 extern "C" int gb_bn_bwd_apply_members(const float *dout, const float *out, const int32_t *arg, const float *y,

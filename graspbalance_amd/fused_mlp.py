@@ -426,9 +426,19 @@ class MLPStack(Function):
             gamma, beta = params[3 * l + 1], params[3 * l + 2]
             K, N = src.shape[1], W.shape[0]
             stats = stat_arena[stat_off[l]:stat_off[l + 1]] if cfg.training else None
-            Y = _empty_rows(P, N, dev, rows is not None)
             ab = ab_arena[ab_off:ab_off + 4 * N]
             ab_off += 4 * N
+            if (l == L - 1 and l >= 1 and rows is not None and rows.key is not None and _CROP_POOL
+                    and _lib.lib().gb_crop_bwd_ok(K, N, rows.D)
+                    and _lib.lib().gb_gemm_uses_rs(P, K, N, 0, 3, int(aff is not None))
+                    and _lib.lib().gb_gemm_uses_rs(P, K, K, 1, 1, 1)):
+                # the crop stack's last layer: its output is never stored - BatchNorm sums and per-(tile, seed, crop)
+                # extrema leave the GEMM, gb_pool_pairs finishes the max over each crop's members
+                pooled = _pooled_last_layer(dev, st, opts, src, W, aff, gamma, beta, cfg, ab, stats, slots, rows, P, K, N,
+                                            P_stat)
+                Ws.append(W); Ys.append(None); abs_.append(ab)
+                break
+            Y = _empty_rows(P, N, dev, rows is not None)
             # training: the GEMM call finishes the layer's BatchNorm itself (a second launch from the same C call):
             # one Python -> C transition per layer instead of two
             fin = _bn_fin(cfg, gamma, beta, ab, P_stat) if cfg.training else None
@@ -449,6 +459,13 @@ class MLPStack(Function):
         ctx.cfg = (L, P, int(pool_ns), bool(relu_last), [c.training for c in layers], residual is not None)
         ctx.rows = rows
         ctx.prec = prec
+        ctx.pooled = rows is not None and Ys[-1] is None
+        if rows is not None and Ys[-1] is None:
+            out, arg, ystar = pooled
+            ctx.save_for_backward(X0, out, arg, ab_arena, *Ws, *Ys[:-1], ystar)
+            if routing_observer is not None:
+                routing_observer("stack", Ys=Ys, abs=abs_, out=out, arg=arg, pool_ns=0, relu_last=True, rows=rows)
+            return out
         if rows is not None:
             RD = rows.R * rows.D
             out = torch.empty((RD, N), dtype=torch.float32, device=dev)
@@ -488,6 +505,8 @@ class MLPStack(Function):
         saved = ctx.saved_tensors
         X0, s1, s2, ab_arena = saved[0], saved[1], saved[2], saved[3]
         Ws, Ys = saved[4:4 + L], saved[4 + L:4 + 2 * L]
+        if ctx.pooled:  # the last layer's output was never stored: (Y_0 .. Y_{L-2}, ystar) instead of (Y_0 .. Y_{L-1})
+            Ys, ystar = list(saved[4 + L:4 + 2 * L - 1]) + [None], saved[4 + 2 * L - 1]
         widths = [W.shape[0] for W in Ws]
         abs_, off = [], 0
         for n in widths:
@@ -529,10 +548,50 @@ class MLPStack(Function):
         N = widths[-1]
         dstats = d_arena[:2 * N]
         dres = None
-        dY = _empty_rows(P, N, dev, rows is not None)
+        grads = [None] * (3 * L)
+        first = L - 1  # the layer the generic loop below starts at (its dY formed here)
         dbeta, dgamma = bn_grads(L - 1)
         pb, pg = _lib.ptr(dbeta), _lib.ptr(dgamma)
-        if rows is not None:
+        if ctx.pooled:
+            # low rank + sparse (csrc/crop_bwd.hip): dZ of layer L-2, dW / dgamma / dbeta of layer L-1; neither the
+            # layer's output nor its dense gradient exists
+            l, K = L - 1, kin[L - 1]
+            out, arg, W, y2, ab2 = s1, s2, Ws[l], Ys[l - 1], abs_[l - 1]
+            zf = torch.zeros(N * K + K * K, dtype=torch.float32, device=dev)
+            tmat, gmat = zf[:N * K], zf[N * K:]
+            sx = _zeros64(K, dev)
+            dZ = _empty_rows(P, K, dev, True)
+            _call("gb_crop_bwd_sparse", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(ystar),
+                  _lib.ptr(abs_[l]), _lib.ptr(y2), _lib.ptr(ab2), _lib.ptr(W), _lib.ptr(rows.w), _lib.ptr(rows.off),
+                  _lib.ptr(rows.cnt), rows.R, rows.D, K, N, _lib.ptr(dZ), _lib.ptr(tmat), _lib.ptr(dstats), _lib.ptr(sx), st)
+            small = torch.empty(2 * N + K + K * K, dtype=torch.float32, device=dev)
+            ef, vvec, mmat = small[:2 * N], small[2 * N:2 * N + K], small[2 * N + K:]
+            _call("gb_crop_bwd_coef", dev, _lib.ptr(dstats), _lib.ptr(abs_[l]), _lib.ptr(W), K, N, P_stat, int(training[l]),
+                  _lib.ptr(ef), _lib.ptr(vvec), _lib.ptr(mmat), pb, pg, st)
+            grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
+            region = d_arena[d_off[l - 1]:d_off[l]]
+            dst2 = region[slots * 2 * K:] if slots > 1 else region
+            dbeta2, dgamma2 = bn_grads(l - 1)
+            _call("gb_crop_bwd_dense", dev, _lib.ptr(y2), _lib.ptr(ab2), _lib.ptr(mmat), _lib.ptr(vvec), _lib.ptr(rows.w),
+                  _lib.ptr(dZ), _lib.ptr(region), slots, P, K, _lib.ptr(dst2), _lib.ptr(dbeta2), _lib.ptr(dgamma2), opts, st,
+                  meta={"flop": 2.0 * P * K * K, "pkn": (P, K, K), "kernel": "gemm_rs_kernel"})
+            grads[3 * l - 2], grads[3 * l - 1] = dgamma2, dbeta2
+            if need_w[l]:
+                _call("gb_gemm_gram", dev, _lib.ptr(y2), _lib.ptr(ab2), _lib.ptr(rows.w), _lib.ptr(gmat), P, K, opts, st,
+                      meta={"flop": 2.0 * P * K * K, "pkn": (P, K, K), "kernel": "gemm_cl_kernel"})
+                dW = w_arena[w_off[l]:w_off[l + 1]]
+                _call("gb_crop_bwd_dw", dev, _lib.ptr(tmat), _lib.ptr(ef), _lib.ptr(sx), _lib.ptr(W), _lib.ptr(gmat), K, N,
+                      _lib.ptr(dW), st)
+                grads[3 * l] = dW.view(N, K)
+            dY = _empty_rows(P, K, dev, True)
+            _call("gb_bn_bwd_apply_w", dev, _lib.ptr(dZ), _lib.ptr(y2), _lib.ptr(ab2), _lib.ptr(dst2), _lib.ptr(rows.w), P,
+                  P_stat, K, int(training[l - 1]), _lib.ptr(dY), st)
+            first = L - 2
+        else:
+            dY = _empty_rows(P, N, dev, rows is not None)
+        if ctx.pooled:
+            pass
+        elif rows is not None:
             out, arg = s1, s2
             _call("gb_bn_bwd_stats_pool", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(Ys[-1]),
                   _lib.ptr(abs_[-1]), rows.R * rows.D, 0, N, _lib.ptr(dstats), pb, pg, st)  # ns = 0: absolute arg rows
@@ -554,10 +613,9 @@ class MLPStack(Function):
                   int(relu_last), _lib.ptr(dstats), pb, pg, st)
             _call("gb_bn_bwd_apply", dev, _lib.ptr(dout), _lib.ptr(Ys[-1]), _lib.ptr(abs_[-1]), _lib.ptr(residual),
                   _lib.ptr(dstats), P, N, int(relu_last), int(training[-1]), _lib.ptr(dY), _lib.ptr(dres), st)
-        grads = [None] * (3 * L)
         grads[3 * L - 2], grads[3 * L - 1] = dgamma, dbeta
         dX0 = None
-        for l in range(L - 1, -1, -1):
+        for l in range(first, -1, -1):
             W = Ws[l]
             N, K = W.shape
             src, aff = (X0, None) if l == 0 else (Ys[l - 1], abs_[l - 1])
@@ -615,6 +673,37 @@ class MLPStack(Function):
                 _call("gb_bn_bwd_apply", dev, _lib.ptr(dZ), _lib.ptr(Ys[l - 1]), _lib.ptr(abs_[l - 1]), None,
                       _lib.ptr(dstats), P, K, 1, int(training[l - 1]), _lib.ptr(dY), None, st)
         return (dX0, dres, None, None, None, None, *grads)
+
+
+_CROP_POOL = os.environ.get("GB_CROP_POOL", "1") != "0"  # A/B switch: 0 = store the crop stacks' last-layer output
+
+
+def set_crop_pool(flag):
+    global _CROP_POOL
+    _CROP_POOL = bool(flag)
+
+
+def _pooled_last_layer(dev, st, opts, src, W, aff, gamma, beta, cfg, ab, stats, slots, rows, P, K, N, P_stat):
+    """gb_gemm_fwd_pool + gb_pool_pairs -> (out, arg, ystar), each ((R*D), N)."""
+    RD = rows.R * rows.D
+    tiles = (P + 31) // 32
+    pairs = torch.empty(((tiles + rows.R) * rows.D * N, 2), dtype=torch.float32, device=dev)
+    if cfg.training:
+        fin = _bn_fin(cfg, gamma, beta, ab, P_stat)
+    else:
+        fin, stats, slots = None, _zeros64(2 * N, dev), 1   # the kernel always forms the sums; eval ignores them
+    _call("gb_gemm_fwd_pool", dev, _lib.ptr(src), _lib.ptr(W), _lib.ptr(aff), _lib.ptr(rows.key), _lib.ptr(gamma),
+          _lib.ptr(pairs), _lib.ptr(stats), slots, P, K, N, rows.D, fin, opts, st,
+          meta=_gemm_meta("fwd", P, K, N, True, aff is not None))
+    if fin is None:
+        _call("gb_bn_finalize", dev, None, 1, P_stat, N, _lib.ptr(gamma), _lib.ptr(beta), cfg.eps, cfg.momentum,
+              _lib.ptr(cfg.running_mean), _lib.ptr(cfg.running_var), _lib.ptr(ab), 0, st)
+    out = torch.empty((RD, N), dtype=torch.float32, device=dev)
+    arg = torch.empty((RD, N), dtype=torch.int32, device=dev)
+    ystar = torch.empty((RD, N), dtype=torch.float32, device=dev)
+    _call("gb_pool_pairs", dev, _lib.ptr(pairs), _lib.ptr(rows.off), _lib.ptr(rows.cnt), _lib.ptr(ab), _lib.ptr(gamma),
+          _lib.ptr(out), _lib.ptr(arg), _lib.ptr(ystar), rows.R, rows.D, N, st)
+    return out, arg, ystar
 
 
 class LocalGeometry:
@@ -781,11 +870,12 @@ class RowSet:
     """Distinct rows of a batch with duplicates (the D nested cylinder crops of a seed, csrc/cyl_rows.hip): w / w16
     multiplicities (float / uint16 padded to a multiple of 32 rows), mem member bits, off / cnt the rows of each of
     the R seeds, D crops per seed, P_total rows of the full batch."""
-    __slots__ = ("w", "w16", "mem", "off", "cnt", "R", "D", "P_total")
+    __slots__ = ("w", "w16", "mem", "off", "cnt", "R", "D", "P_total", "key")
 
-    def __init__(self, w, w16, mem, off, cnt, R, D, P_total):
+    def __init__(self, w, w16, mem, off, cnt, R, D, P_total, key=None):
         self.w, self.w16, self.mem, self.off, self.cnt = w, w16, mem, off, cnt
         self.R, self.D, self.P_total = int(R), int(D), int(P_total)
+        self.key = key  # (seed << 13) | (multiplicity << 4) | member bits per row, zero-padded to 32 rows (D <= 4)
 
 
 class _ZeroGradFor(Function):
@@ -954,10 +1044,11 @@ def cylinder_rows(idx, xyz, centres, rot):
         w = torch.empty(cap, dtype=torch.float32, device=dev)[:Pu]
         w16 = torch.zeros(cap, dtype=torch.int16, device=dev)[:pad]  # uint16 bits; zero tail for the GEMM epilogue
         mem = torch.empty(cap, dtype=torch.int32, device=dev)[:Pu]
+        key = torch.zeros(cap, dtype=torch.int32, device=dev)[:pad] if (D <= 4 and R < (1 << 18)) else None
         _call("gb_cyl_rows", dev, _lib.ptr(xyz), _lib.ptr(centres), _lib.ptr(rot9), _lib.ptr(scratch[0, i]),
               _lib.ptr(scratch[1, i]), _lib.ptr(count[i]), _lib.ptr(off[i]), B, xyz.shape[1], m, W, _lib.ptr(x0),
-              _lib.ptr(w), _lib.ptr(w16), _lib.ptr(mem), st)
-        out.append((x0, RowSet(w, w16, mem, off[i], count[i], R, D, R * W)))
+              _lib.ptr(w), _lib.ptr(w16), _lib.ptr(mem), _lib.ptr(key), st)
+        out.append((x0, RowSet(w, w16, mem, off[i], count[i], R, D, R * W, key)))
         if routing_observer is not None:
             routing_observer("cyl_rows", rowset=out[-1][1], sorted=scratch[0, i], idx=idx[i])
     return out

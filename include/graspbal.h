@@ -330,10 +330,56 @@ int gb_cyl_unique(const int32_t *idx, int D, long long R, int ns, int32_t *sorte
                   void *stream);
 /* Rows off[r] .. off[r]+count[r]-1 of seed r (off = exclusive prefix sum of count, int64):
 * x0 (P_u,3) = (xyz[b,id] - centre[r]) rotated by rot[r] (3x3) as gb_group_concat_cl mode 2, row_w = multiplicity
- * (row_w16: the same as uint16, for gb_gemm_fwd_w), row_mem = member bits.  W = D*ns is the row pitch of sorted / meta.                                         */
+ * (row_w16: the same as uint16, for gb_gemm_fwd_w), row_mem = member bits, row_key (optional) = (seed << 13) |
+ * (multiplicity << 4) | member bits for gb_gemm_fwd_pool (D <= 4).  W = D*ns is the row pitch of sorted / meta.                                         */
 int gb_cyl_rows(const float *xyz, const float *centres, const float *rot, const int32_t *sorted, const int32_t *meta,
                 const int32_t *count, const int64_t *off, int b, int n, int m, int W, float *x0, float *row_w,
-                uint16_t *row_w16, int32_t *row_mem, void *stream);
+                uint16_t *row_w16, int32_t *row_mem, int32_t *row_key, void *stream);
+/* The LAST layer of a crop stack without ever storing its output (reference modules.py:104-124: the SharedMLP's final
+ * conv + BatchNorm + ReLU, then max_pool2d over each crop; pointnet2_modules.py:176-188 has the same shape).
+ * gb_gemm_fwd_pool: Y = f(X) W^T is formed tile by tile; what leaves the kernel are the weighted BatchNorm sums
+ * (as gb_gemm_fwd_w) and, per (32-row tile t, seed r with rows in t, crop d, column c), the extreme of sign(gamma_c)*y
+ * over the seed's member rows in the tile and the row holding it: pairs[((t + r)*D + d)*N + c] = (value, row as int
+ * bits) - a seed's rows are contiguous, so slot t + r is unique and is written with plain stores.  relu(a*y + b) is
+ * monotone in y with the sign of a = gamma*rstd, so gb_pool_pairs finishes the pooling once the statistics are
+ * known: out ((R*D), N) = the crop's max of relu(a*y + b), arg = the row attaining it (the lowest one among equal
+ * extremes), ystar = that row's y.  row_key (P rounded up to 32, zero tail; 16-byte aligned) from gb_cyl_rows; pairs:
+ * ((P + 31) / 32 + R) * D * N * 2 floats.  N in {64, 128, 160, 256}, D <= 4, P >= 16384, K % 4 == 0: otherwise
+ * GB_EINVAL (ask gb_gemm_uses_rs(P, K, N, 0, 3, has_aff)).  stats as in gb_gemm_fwd (required).              */
+int gb_gemm_fwd_pool(const float *x, const float *w, const float *aff, const int32_t *row_key, const float *gamma,
+                     float *pairs, double *stats, int stat_slots, long long P, int K, int N, int D,
+                     const GbBnFinalize *fin, const GbGemmOpts *opts, void *stream);
+int gb_pool_pairs(const float *pairs, const int64_t *off, const int32_t *cnt, const float *ab, const float *gamma,
+                  float *out, int32_t *arg, float *ystar, long long R, int D, int C, void *stream);
+/* Backward of that layer as "low rank + sparse" (csrc/crop_bwd.hip has the algebra): behind the max-pool the gradient
+ * reaching the layer's BatchNorm is nonzero in one member row per (crop, channel), plus terms affine in y = X~ W^T, so
+ *   dX~ = S - w (v + X~ M),   dW = T - f sx^T - diag(e) W G      (M = W^T diag(e) W and G = sum w X~^T X~ are K x K)
+ * and neither Y nor the dense P x C gradient is ever formed.  X~ = relu(a2*y2 + b2): y2 (P,K) the previous layer's
+ * pre-BatchNorm output, ab2 = its [a,b,mean,rstd](K); ab = this layer's [a,b,mean,rstd](C); w3 (C,K); row_w (P)
+ * multiplicities (readable up to a multiple of 32 rows, 16-byte aligned); P_total = rows of the original batch.
+ *   gb_crop_bwd_ok     : 1 when the shape is implemented (K = 128, C = 256, D <= 4)
+ *   gb_crop_bwd_sparse : sdx (P,K) = S (every row written); tmat (C,K) += T, red fp64 [2C] += [dbeta, dgamma] sums,
+ *                        sx fp64 [K] += sum w X~ (all three caller-zeroed).  dout / out / arg / ystar: ((R*D), C)
+ *   gb_crop_bwd_coef   : ef = [e(C), f(C)], vvec (K), mmat (K,K), dbeta / dgamma (C) fp32 from red; training = 0
+ *                        (running statistics): e = f = 0
+ *   gb_crop_bwd_dense  : dz (P,K): S on entry, dX~ on return; dstats / dbeta / dgamma: the BatchNorm-backward sums of
+ *                        the layer that produced y2, as gb_gemm_dgrad delivers them
+ *   gb_gemm_gram       : gmat (K,K) += sum_p row_w[p] f(x_p) f(x_p)^T, f = relu(a*x + b) (caller-zeroed)
+ *   gb_crop_bwd_dw     : dw (C,K) = T - f sx^T - diag(e) W G                                                   */
+int gb_crop_bwd_ok(int K, int C, int D);
+int gb_crop_bwd_sparse(const float *dout, const float *out, const int32_t *arg, const float *ystar, const float *ab,
+                       const float *y2, const float *ab2, const float *w3, const float *row_w, const int64_t *off,
+                       const int32_t *cnt, long long R, int D, int K, int C, float *sdx, float *tmat, double *red,
+                       double *sx, void *stream);
+int gb_crop_bwd_coef(const double *red, const float *ab, const float *w3, int K, int C, long long P_total, int training,
+                     float *ef, float *vvec, float *mmat, float *dbeta, float *dgamma, void *stream);
+int gb_crop_bwd_dense(const float *y2, const float *ab2, const float *mmat, const float *vvec, const float *row_w,
+                      float *dz, double *dstats, int stat_slots, long long P, int K, double *dstats_total, float *dbeta,
+                      float *dgamma, const GbGemmOpts *opts, void *stream);
+int gb_gemm_gram(const float *x, const float *x_aff, const float *row_w, float *gmat, long long P, int K,
+                 const GbGemmOpts *opts, void *stream);
+int gb_crop_bwd_dw(const float *tmat, const float *ef, const double *sx, const float *w3, const float *gmat, int K,
+                   int C, float *dw, void *stream);
 /* gb_gemm_fwd whose BatchNorm sums weight row p by row_w16[p] (uint16 multiplicities; the array must extend,
  * zero-filled, to the next multiple of 32 rows).                                                              */
 int gb_gemm_fwd_w(const float *x, const float *w, const float *aff, const uint16_t *row_w16, float *y, double *stats,

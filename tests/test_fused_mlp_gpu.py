@@ -293,3 +293,79 @@ def test_grasp_width_grouping_distinct_rows_equals_plain(golden):
             return mod(seeds, cloud, rot, rows=rows), []
         return mod(seeds, cloud, rot, idx=idx[0]), []
     _run(fused, plain, call, tol_grad=2e-3, l2=True)  # torch's own fp32 BatchNorm backward over 131072 rows is the noise here
+
+
+def _crop_case(B=2, N=20000, seeds=1024, seed=3):
+    """A GraspWidthGrouping head on scene clouds with the distinct rows of its four nested crops."""
+    import numpy as np
+    from graspbalance_amd import fused_mlp, fused_ops
+    from graspbalance_amd.modules import GraspWidthGrouping
+    from graspbalance_amd.scene import make_batch
+    from tests.seeded import fill_by_key
+    golden_rot = np.load("tests/golden/g9_views.npz")["rot"]
+    xyz = torch.from_numpy(make_batch(list(range(seed, seed + B)), N)).to(DEV)
+    centres = xyz[:, :seeds].contiguous()
+    rot = torch.from_numpy(golden_rot)[torch.arange(seeds) % 300].unsqueeze(0).repeat(B, 1, 1, 1).contiguous().to(DEV)
+    wg = fill_by_key(GraspWidthGrouping(64, 3, 0.06, -0.02, [0.01, 0.02, 0.03, 0.04]), seed=seed).to(DEV)
+    with torch.no_grad():      # one negative BatchNorm weight per layer: the max of relu(a*y+b) then sits at the SMALLEST y
+        for layer in wg.mlps.children():
+            layer.bn.bn.weight[::7] *= -1.0
+    idx = fused_ops.cylinder_query_multi(xyz, centres, rot, [0.06], -0.02, [0.01, 0.02, 0.03, 0.04], 64)
+    rows = fused_mlp.cylinder_rows(idx, xyz, centres, rot)[0]
+    return wg, xyz, centres, rot, rows
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_pooled_last_layer_forward_equals_stored_output_path(training):
+    """gb_gemm_fwd_pool + gb_pool_pairs (the crop stack's last layer never stored: extrema of sign(gamma)*y per (tile,
+    seed, crop) out of the GEMM epilogue) against the path that stores Y3 and pools it with
+    gb_affine_relu_maxpool_members: same pooled values to rounding (both form relu(a*y+b) from the same fp32 products,
+    but BatchNorm sums add in a different order), same running statistics."""
+    import copy
+    from graspbalance_amd import fused_mlp
+    wg, xyz, centres, rot, rows = _crop_case()
+    assert rows[1].key is not None
+    P = rows[0].shape[0]   # the shapes really take the pooled path (it needs the row-streaming kernel: P >= 16384)
+    assert fused_mlp._lib.lib().gb_gemm_uses_rs(P, 128, 256, 0, 3, 1) == 1 and fused_mlp._lib.lib().gb_crop_bwd_ok(128, 256, 4)
+    res = {}
+    for flag in (True, False):
+        m = copy.deepcopy(wg).train(training)
+        fused_mlp.set_crop_pool(flag)
+        try:
+            with torch.no_grad():
+                res[flag] = (m(centres, xyz, rot, rows=rows, channel_last=True), m.mlps.layer2.bn.bn.running_mean.clone(),
+                             m.mlps.layer2.bn.bn.running_var.clone())
+        finally:
+            fused_mlp.set_crop_pool(True)
+    a, b = res[True], res[False]
+    assert a[0].shape == b[0].shape == (2 * 1024 * 4, 256)
+    scale = float(b[0].abs().max())
+    assert float((a[0] - b[0]).abs().max()) <= 2e-6 * scale, float((a[0] - b[0]).abs().max()) / scale
+    assert float(a[0].min()) >= 0.0 and float((a[0] > 0).float().mean()) > 0.3
+    assert torch.allclose(a[1], b[1], rtol=1e-6, atol=1e-7) and torch.allclose(a[2], b[2], rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_pooled_last_layer_low_rank_backward_equals_dense_backward(training):
+    """Backward of the never-stored last layer as low rank + sparse (gb_crop_bwd_sparse / _coef / _dense / gb_gemm_gram
+    / gb_crop_bwd_dw: a K x K product and a K x K Gram matrix instead of the two dense C x K products) against the dense
+    backward of the stored-output path (gb_bn_bwd_apply_members + dgrad + wgrad): every parameter gradient of the
+    three layers.  (The fp64 statement about both is tests/test_frozen_routing_gpu.py.)"""
+    import copy
+    from graspbalance_amd import fused_mlp
+    wg, xyz, centres, rot, rows = _crop_case()
+    torch.manual_seed(8)
+    wout = torch.randn(2 * 1024 * 4, 256, device=DEV)
+    res = {}
+    for flag in (True, False):
+        m = copy.deepcopy(wg).train(training)
+        fused_mlp.set_crop_pool(flag)
+        try:
+            out = m(centres, xyz, rot, rows=rows, channel_last=True)
+            (out * wout).sum().backward()
+        finally:
+            fused_mlp.set_crop_pool(True)
+        res[flag] = {k: p.grad.clone() for k, p in m.named_parameters()}
+    errs = {k: float((res[True][k] - res[False][k]).norm() / (res[False][k].norm() + 1e-30)) for k in res[True]}
+    print({k: "%.1e" % v for k, v in errs.items()})
+    assert len(errs) == 9 and max(errs.values()) < 5e-5, errs

@@ -218,7 +218,13 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
       long long ntile = tile;
       if (nkc == g.nch) { nkc = 0; ntile = tile + nw; }
       const bool more = ntile < tend;
-      if (more) load_chunk(nxt, ntile, nkc);
+      // RS_STATS_POOL: the next tile's first chunk is requested AFTER this tile's epilogue (its 16 registers are what the
+      // epilogue's row keys need; holding both spilled into scratch, and the epilogue then ran 3x the tile's MFMA time)
+#ifndef GB_DEFER
+#define GB_DEFER 1
+#endif
+      const bool defer = GB_DEFER && EPI == RS_STATS_POOL && kc == g.nch - 1;
+      if (more && !defer) load_chunk(nxt, ntile, nkc);
 
       float av[16];
 #pragma unroll
@@ -342,6 +348,15 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
             dsum[q] += (double)cs;
             dsq[q] += (double)cq;
             const float sg = g.epi_gamma[q * 32 + m] < 0.f ? -1.f : 1.f;
+            if (g.d) {  // optional: keep Y for a caller whose backward wants it (rows >= P are not stored)
+              const unsigned lane_off = (unsigned)(4 * h) * (unsigned)g.ldd + (unsigned)m;
+              const int nrow = (int)(g.P - trow) - 4 * h;    // rows (r&3) + 8(r>>2) below this are valid
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                float *dp = g.d + (trow + (r & 3) + 8 * (r >> 2)) * (long long)g.ldd + q * 32;  // wave-uniform
+                if ((r & 3) + 8 * (r >> 2) < nrow) dp[lane_off] = acc[q][r];
+              }
+            }
             float kv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) { kv[r] = sg * acc[q][r]; acc[q][r] = 0.f; }
@@ -354,8 +369,11 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
                   const bool member = (rk[r] >> 13) == sd && ((rk[r] >> d) & 1);
                   if (member && kv[r] > best) { best = kv[r]; brow = (int)trow + 4 * h + (r & 3) + 8 * (r >> 2); }
                 }
-                const float ob = __shfl_xor(best, 32);
-                const int orow = __shfl_xor(brow, 32);
+                // the other half of the tile's rows sits in lane ^ 32: v_permlane32_swap (no LDS round trip)
+                const auto sb = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+                const auto sr = __builtin_amdgcn_permlane32_swap((unsigned)brow, (unsigned)brow, false, false);
+                const float ob = __uint_as_float(h ? sb[0] : sb[1]);
+                const int orow = (int)(h ? sr[0] : sr[1]);
                 if (ob > best || (ob == best && orow < brow)) { best = ob; brow = orow; }
                 if (h == 0)
                   g.pairs[((size_t)(tile + sd) * g.pool_d + d) * C32 + q * 32 + m] = make_float2(best, __int_as_float(brow));
@@ -505,6 +523,7 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
         }
       }
       if (!more) break;
+      if (defer) load_chunk(nxt, ntile, nkc);
 #pragma unroll
       for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
       kc = nkc;

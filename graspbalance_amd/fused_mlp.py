@@ -420,7 +420,7 @@ class MLPStack(Function):
         stat_arena = _zeros64(stat_off[-1], dev) if stat_off[-1] else None
         ab_arena = torch.empty(4 * sum(widths), dtype=torch.float32, device=dev)
         Ws, Ys, abs_ = [], [], []
-        src, aff, ab_off = X0, None, 0
+        src, aff, ab_off, pooled = X0, None, 0, None
         for l, cfg in enumerate(layers):
             W = params[3 * l].contiguous()
             gamma, beta = params[3 * l + 1], params[3 * l + 2]
@@ -428,15 +428,17 @@ class MLPStack(Function):
             stats = stat_arena[stat_off[l]:stat_off[l + 1]] if cfg.training else None
             ab = ab_arena[ab_off:ab_off + 4 * N]
             ab_off += 4 * N
-            if (l == L - 1 and l >= 1 and rows is not None and rows.key is not None and _CROP_POOL
-                    and _lib.lib().gb_crop_bwd_ok(K, N, rows.D)
-                    and _lib.lib().gb_gemm_uses_rs(P, K, N, 0, 3, int(aff is not None))
-                    and _lib.lib().gb_gemm_uses_rs(P, K, K, 1, 1, 1)):
-                # the crop stack's last layer: its output is never stored - BatchNorm sums and per-(tile, seed, crop)
-                # extrema leave the GEMM, gb_pool_pairs finishes the max over each crop's members
+            if (l == L - 1 and rows is not None and rows.key is not None and _CROP_POOL
+                    and _lib.lib().gb_gemm_uses_rs(P, K, N, 0, 3, int(aff is not None))):
+                # the crop stack's last layer: BatchNorm sums and per-(tile, seed, crop) extrema leave the GEMM,
+                # gb_pool_pairs finishes the max over each crop's members (no pass over the layer's output); with the low
+                # rank + sparse backward the output is not even stored
+                lowrank = (_CROP_LOWRANK and l >= 1 and _lib.lib().gb_crop_bwd_ok(K, N, rows.D)
+                           and _lib.lib().gb_gemm_uses_rs(P, K, K, 1, 1, 1))
+                Y = None if lowrank else _empty_rows(P, N, dev, True)
                 pooled = _pooled_last_layer(dev, st, opts, src, W, aff, gamma, beta, cfg, ab, stats, slots, rows, P, K, N,
-                                            P_stat)
-                Ws.append(W); Ys.append(None); abs_.append(ab)
+                                            P_stat, Y)
+                Ws.append(W); Ys.append(Y); abs_.append(ab)
                 break
             Y = _empty_rows(P, N, dev, rows is not None)
             # training: the GEMM call finishes the layer's BatchNorm itself (a second launch from the same C call):
@@ -460,9 +462,12 @@ class MLPStack(Function):
         ctx.rows = rows
         ctx.prec = prec
         ctx.pooled = rows is not None and Ys[-1] is None
-        if rows is not None and Ys[-1] is None:
+        if pooled is not None:
             out, arg, ystar = pooled
-            ctx.save_for_backward(X0, out, arg, ab_arena, *Ws, *Ys[:-1], ystar)
+            if Ys[-1] is None:
+                ctx.save_for_backward(X0, out, arg, ab_arena, *Ws, *Ys[:-1], ystar)
+            else:
+                ctx.save_for_backward(X0, out, arg, ab_arena, *Ws, *Ys)
             if routing_observer is not None:
                 routing_observer("stack", Ys=Ys, abs=abs_, out=out, arg=arg, pool_ns=0, relu_last=True, rows=rows)
             return out
@@ -557,16 +562,20 @@ class MLPStack(Function):
             # layer's output nor its dense gradient exists
             l, K = L - 1, kin[L - 1]
             out, arg, W, y2, ab2 = s1, s2, Ws[l], Ys[l - 1], abs_[l - 1]
-            zf = torch.zeros(N * K + K * K, dtype=torch.float32, device=dev)
-            tmat, gmat = zf[:N * K], zf[N * K:]
-            sx = _zeros64(K, dev)
+            nb = _lib.lib().gb_crop_bwd_blocks(rows.R)
+            tpart = torch.empty(nb * N * K, dtype=torch.float32, device=dev)       # per-workgroup partials: no zeroing
+            rpart = torch.empty(nb * (2 * N + K) + 2 * N + K, dtype=torch.float64, device=dev)
+            red = rpart[nb * (2 * N + K):]                                          # [dbeta, dgamma, sx] totals
+            sx = red[2 * N:]
+            gmat = torch.zeros(K * K, dtype=torch.float32, device=dev)
             dZ = _empty_rows(P, K, dev, True)
             _call("gb_crop_bwd_sparse", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(ystar),
                   _lib.ptr(abs_[l]), _lib.ptr(y2), _lib.ptr(ab2), _lib.ptr(W), _lib.ptr(rows.w), _lib.ptr(rows.off),
-                  _lib.ptr(rows.cnt), rows.R, rows.D, K, N, _lib.ptr(dZ), _lib.ptr(tmat), _lib.ptr(dstats), _lib.ptr(sx), st)
+                  _lib.ptr(rows.cnt), rows.R, rows.D, K, N, _lib.ptr(dZ), _lib.ptr(tpart), _lib.ptr(rpart), nb,
+                  _lib.ptr(red), st)
             small = torch.empty(2 * N + K + K * K, dtype=torch.float32, device=dev)
             ef, vvec, mmat = small[:2 * N], small[2 * N:2 * N + K], small[2 * N + K:]
-            _call("gb_crop_bwd_coef", dev, _lib.ptr(dstats), _lib.ptr(abs_[l]), _lib.ptr(W), K, N, P_stat, int(training[l]),
+            _call("gb_crop_bwd_coef", dev, _lib.ptr(red), _lib.ptr(abs_[l]), _lib.ptr(W), K, N, P_stat, int(training[l]),
                   _lib.ptr(ef), _lib.ptr(vvec), _lib.ptr(mmat), pb, pg, st)
             grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
             region = d_arena[d_off[l - 1]:d_off[l]]
@@ -580,8 +589,8 @@ class MLPStack(Function):
                 _call("gb_gemm_gram", dev, _lib.ptr(y2), _lib.ptr(ab2), _lib.ptr(rows.w), _lib.ptr(gmat), P, K, opts, st,
                       meta={"flop": 2.0 * P * K * K, "pkn": (P, K, K), "kernel": "gemm_cl_kernel"})
                 dW = w_arena[w_off[l]:w_off[l + 1]]
-                _call("gb_crop_bwd_dw", dev, _lib.ptr(tmat), _lib.ptr(ef), _lib.ptr(sx), _lib.ptr(W), _lib.ptr(gmat), K, N,
-                      _lib.ptr(dW), st)
+                _call("gb_crop_bwd_dw", dev, _lib.ptr(tpart), nb, _lib.ptr(ef), _lib.ptr(sx), _lib.ptr(W), _lib.ptr(gmat), K,
+                      N, _lib.ptr(dW), st)
                 grads[3 * l] = dW.view(N, K)
             dY = _empty_rows(P, K, dev, True)
             _call("gb_bn_bwd_apply_w", dev, _lib.ptr(dZ), _lib.ptr(y2), _lib.ptr(ab2), _lib.ptr(dst2), _lib.ptr(rows.w), P,
@@ -675,16 +684,31 @@ class MLPStack(Function):
         return (dX0, dres, None, None, None, None, *grads)
 
 
-_CROP_POOL = os.environ.get("GB_CROP_POOL", "1") != "0"  # A/B switch: 0 = store the crop stacks' last-layer output
+# The crop stacks' last layer (csrc/gemm_rs.hip RS_STATS_POOL, csrc/crop_bwd.hip):
+#   GB_CROP_POOL=0     the GEMM stores Y3, gb_affine_relu_maxpool_members pools it (round-2 path)
+#   default            the pooling leaves the GEMM epilogue (per-tile extrema) + gb_pool_pairs; Y3 is still stored for the
+#                      dense backward
+#   GB_CROP_LOWRANK=1  Y3 is never stored; backward = low rank + sparse (K x K product, Gram matrix, sparse kernel).
+#                      Correct to 1e-6 of the dense backward (tests), but its sparse kernel is bound by LDS float
+#                      atomics (164 clocks per wave instruction measured) and loses 2.5 ms per launch: opt-in until
+#                      that kernel is rebuilt without them
+_CROP_POOL = os.environ.get("GB_CROP_POOL", "0") != "0"
+_CROP_LOWRANK = os.environ.get("GB_CROP_LOWRANK", "0") == "1"
 
 
-def set_crop_pool(flag):
-    global _CROP_POOL
+def set_crop_pool(flag, lowrank=None):
+    """-> previous (pool, lowrank)."""
+    global _CROP_POOL, _CROP_LOWRANK
+    prev = (_CROP_POOL, _CROP_LOWRANK)
     _CROP_POOL = bool(flag)
+    if lowrank is not None:
+        _CROP_LOWRANK = bool(lowrank)
+    return prev
 
 
-def _pooled_last_layer(dev, st, opts, src, W, aff, gamma, beta, cfg, ab, stats, slots, rows, P, K, N, P_stat):
-    """gb_gemm_fwd_pool + gb_pool_pairs -> (out, arg, ystar), each ((R*D), N)."""
+def _pooled_last_layer(dev, st, opts, src, W, aff, gamma, beta, cfg, ab, stats, slots, rows, P, K, N, P_stat, Y=None):
+    """gb_gemm_fwd_pool + gb_pool_pairs -> (out, arg, ystar), each ((R*D), N).  Y: optional (P, N) buffer that also
+    receives the layer's output."""
     RD = rows.R * rows.D
     tiles = (P + 31) // 32
     pairs = torch.empty(((tiles + rows.R) * rows.D * N, 2), dtype=torch.float32, device=dev)
@@ -693,7 +717,7 @@ def _pooled_last_layer(dev, st, opts, src, W, aff, gamma, beta, cfg, ab, stats, 
     else:
         fin, stats, slots = None, _zeros64(2 * N, dev), 1   # the kernel always forms the sums; eval ignores them
     _call("gb_gemm_fwd_pool", dev, _lib.ptr(src), _lib.ptr(W), _lib.ptr(aff), _lib.ptr(rows.key), _lib.ptr(gamma),
-          _lib.ptr(pairs), _lib.ptr(stats), slots, P, K, N, rows.D, fin, opts, st,
+          _lib.ptr(pairs), _lib.ptr(Y), _lib.ptr(stats), slots, P, K, N, rows.D, fin, opts, st,
           meta=_gemm_meta("fwd", P, K, N, True, aff is not None))
     if fin is None:
         _call("gb_bn_finalize", dev, None, 1, P_stat, N, _lib.ptr(gamma), _lib.ptr(beta), cfg.eps, cfg.momentum,

@@ -345,9 +345,10 @@ int gb_cyl_rows(const float *xyz, const float *centres, const float *rot, const 
  * known: out ((R*D), N) = the crop's max of relu(a*y + b), arg = the row attaining it (the lowest one among equal
  * extremes), ystar = that row's y.  row_key (P rounded up to 32, zero tail; 16-byte aligned) from gb_cyl_rows; pairs:
  * ((P + 31) / 32 + R) * D * N * 2 floats.  N in {64, 128, 160, 256}, D <= 4, P >= 16384, K % 4 == 0: otherwise
- * GB_EINVAL (ask gb_gemm_uses_rs(P, K, N, 0, 3, has_aff)).  stats as in gb_gemm_fwd (required).              */
+ * GB_EINVAL (ask gb_gemm_uses_rs(P, K, N, 0, 3, has_aff)).  stats as in gb_gemm_fwd (required).  y (optional, (P,N)):
+ * Y is stored as well, for a caller whose backward wants it (the dense backward: gb_bn_bwd_apply_members).      */
 int gb_gemm_fwd_pool(const float *x, const float *w, const float *aff, const int32_t *row_key, const float *gamma,
-                     float *pairs, double *stats, int stat_slots, long long P, int K, int N, int D,
+                     float *pairs, float *y, double *stats, int stat_slots, long long P, int K, int N, int D,
                      const GbBnFinalize *fin, const GbGemmOpts *opts, void *stream);
 int gb_pool_pairs(const float *pairs, const int64_t *off, const int32_t *cnt, const float *ab, const float *gamma,
                   float *out, int32_t *arg, float *ystar, long long R, int D, int C, void *stream);
@@ -358,19 +359,23 @@ int gb_pool_pairs(const float *pairs, const int64_t *off, const int32_t *cnt, co
  * pre-BatchNorm output, ab2 = its [a,b,mean,rstd](K); ab = this layer's [a,b,mean,rstd](C); w3 (C,K); row_w (P)
  * multiplicities (readable up to a multiple of 32 rows, 16-byte aligned); P_total = rows of the original batch.
  *   gb_crop_bwd_ok     : 1 when the shape is implemented (K = 128, C = 256, D <= 4)
- *   gb_crop_bwd_sparse : sdx (P,K) = S (every row written); tmat (C,K) += T, red fp64 [2C] += [dbeta, dgamma] sums,
- *                        sx fp64 [K] += sum w X~ (all three caller-zeroed).  dout / out / arg / ystar: ((R*D), C)
+ *   gb_crop_bwd_blocks : nb = workgroups gb_crop_bwd_sparse launches for R seeds (its partial buffers' leading dimension)
+ *   gb_crop_bwd_sparse : sdx (P,K) = S (every row written); tpart [nb][C][K] / rpart fp64 [nb][2C + K] = per-workgroup
+ *                        partial sums of T and of [dbeta, dgamma, sx] (plain stores, no zeroing needed); red fp64
+ *                        [2C + K] = their totals [dbeta (C), dgamma (C), sx = sum w X~ (K)].  dout / out / arg /
+ *                        ystar: ((R*D), C)
  *   gb_crop_bwd_coef   : ef = [e(C), f(C)], vvec (K), mmat (K,K), dbeta / dgamma (C) fp32 from red; training = 0
  *                        (running statistics): e = f = 0
  *   gb_crop_bwd_dense  : dz (P,K): S on entry, dX~ on return; dstats / dbeta / dgamma: the BatchNorm-backward sums of
  *                        the layer that produced y2, as gb_gemm_dgrad delivers them
  *   gb_gemm_gram       : gmat (K,K) += sum_p row_w[p] f(x_p) f(x_p)^T, f = relu(a*x + b) (caller-zeroed)
- *   gb_crop_bwd_dw     : dw (C,K) = T - f sx^T - diag(e) W G                                                   */
+ *   gb_crop_bwd_dw     : dw (C,K) = T - f sx^T - diag(e) W G, T = the nb partials of tpart summed in order; sx = red + 2C */
 int gb_crop_bwd_ok(int K, int C, int D);
+int gb_crop_bwd_blocks(long long R);
 int gb_crop_bwd_sparse(const float *dout, const float *out, const int32_t *arg, const float *ystar, const float *ab,
                        const float *y2, const float *ab2, const float *w3, const float *row_w, const int64_t *off,
-                       const int32_t *cnt, long long R, int D, int K, int C, float *sdx, float *tmat, double *red,
-                       double *sx, void *stream);
+                       const int32_t *cnt, long long R, int D, int K, int C, float *sdx, float *tpart, double *rpart,
+                       int nb, double *red, void *stream);
 int gb_crop_bwd_coef(const double *red, const float *ab, const float *w3, int K, int C, long long P_total, int training,
                      float *ef, float *vvec, float *mmat, float *dbeta, float *dgamma, void *stream);
 int gb_crop_bwd_dense(const float *y2, const float *ab2, const float *mmat, const float *vvec, const float *row_w,
@@ -378,8 +383,8 @@ int gb_crop_bwd_dense(const float *y2, const float *ab2, const float *mmat, cons
                       float *dgamma, const GbGemmOpts *opts, void *stream);
 int gb_gemm_gram(const float *x, const float *x_aff, const float *row_w, float *gmat, long long P, int K,
                  const GbGemmOpts *opts, void *stream);
-int gb_crop_bwd_dw(const float *tmat, const float *ef, const double *sx, const float *w3, const float *gmat, int K,
-                   int C, float *dw, void *stream);
+int gb_crop_bwd_dw(const float *tpart, int nb, const float *ef, const double *sx, const float *w3, const float *gmat,
+                   int K, int C, float *dw, void *stream);
 /* gb_gemm_fwd whose BatchNorm sums weight row p by row_w16[p] (uint16 multiplicities; the array must extend,
  * zero-filled, to the next multiple of 32 rows).                                                              */
 int gb_gemm_fwd_w(const float *x, const float *w, const float *aff, const uint16_t *row_w16, float *y, double *stats,

@@ -330,13 +330,13 @@ def test_pooled_last_layer_forward_equals_stored_output_path(training):
     res = {}
     for flag in (True, False):
         m = copy.deepcopy(wg).train(training)
-        fused_mlp.set_crop_pool(flag)
+        prev = fused_mlp.set_crop_pool(flag)
         try:
             with torch.no_grad():
                 res[flag] = (m(centres, xyz, rot, rows=rows, channel_last=True), m.mlps.layer2.bn.bn.running_mean.clone(),
                              m.mlps.layer2.bn.bn.running_var.clone())
         finally:
-            fused_mlp.set_crop_pool(True)
+            fused_mlp.set_crop_pool(*prev)
     a, b = res[True], res[False]
     assert a[0].shape == b[0].shape == (2 * 1024 * 4, 256)
     scale = float(b[0].abs().max())
@@ -357,15 +357,16 @@ def test_pooled_last_layer_low_rank_backward_equals_dense_backward(training):
     torch.manual_seed(8)
     wout = torch.randn(2 * 1024 * 4, 256, device=DEV)
     res = {}
-    for flag in (True, False):
+    for name, (pool, lowrank) in {"lowrank": (True, True), "pooled": (True, False), "stored": (False, False)}.items():
         m = copy.deepcopy(wg).train(training)
-        fused_mlp.set_crop_pool(flag)
+        prev = fused_mlp.set_crop_pool(pool, lowrank)
         try:
             out = m(centres, xyz, rot, rows=rows, channel_last=True)
             (out * wout).sum().backward()
         finally:
-            fused_mlp.set_crop_pool(True)
-        res[flag] = {k: p.grad.clone() for k, p in m.named_parameters()}
-    errs = {k: float((res[True][k] - res[False][k]).norm() / (res[False][k].norm() + 1e-30)) for k in res[True]}
-    print({k: "%.1e" % v for k, v in errs.items()})
-    assert len(errs) == 9 and max(errs.values()) < 5e-5, errs
+            fused_mlp.set_crop_pool(*prev)
+        res[name] = {k: p.grad.clone() for k, p in m.named_parameters()}
+    for name in ("lowrank", "pooled"):   # pooled: the default (pooling out of the GEMM epilogue, dense backward)
+        errs = {k: float((res[name][k] - res["stored"][k]).norm() / (res["stored"][k].norm() + 1e-30)) for k in res[name]}
+        print(name, {k: "%.1e" % v for k, v in errs.items()})
+        assert len(errs) == 9 and max(errs.values()) < 5e-5, (name, errs)

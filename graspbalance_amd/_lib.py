@@ -79,7 +79,8 @@ SIGNATURES = {
     "gb_moments3": [_P, _P, _L, _P, _P],
     "gb_cyl_unique": [_P, _I, _L, _I, _P, _P, _P, _P],
     "gb_cyl_rows": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
-    "gb_gemm_fwd_pool": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P],
+    "gb_gemm_fwd_pool": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P],
+    "gb_bn_bwd_apply_members_v": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _L, _I, _P, _P],
     "gb_pool_pairs": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "gb_crop_bwd_ok": [_I, _I, _I],
     "gb_crop_bwd_blocks": [_L],

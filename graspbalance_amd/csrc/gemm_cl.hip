@@ -539,15 +539,18 @@ extern "C" int gb_gemm_fwd_w(const float *x, const float *w, const float *aff, c
 // the pooling once the statistics are known.  Only the row-streaming kernel implements it: GB_EINVAL when the shape is
 // not eligible (ask gb_gemm_uses_rs(P, K, N, 0, 3, has_aff)).
 extern "C" int gb_gemm_fwd_pool(const float *x, const float *w, const float *aff, const int32_t *row_key,
-                                const float *gamma, float *pairs, float *y, double *stats, int stat_slots, long long P,
-                                int K, int N, int D, const GbBnFinalize *fin, const GbGemmOpts *opts, void *stream) {
+                                const float *gamma, float *pairs, int with_rows, float *y, double *stats,
+                                int stat_slots, long long P, int K, int N, int D, const GbBnFinalize *fin,
+                                const GbGemmOpts *opts, void *stream) {
   if (P < 1 || K < 1 || N < 1 || D < 1 || D > 4 || !x || !w || !row_key || !gamma || !pairs || !stats || stat_slots < 1 ||
       opts_bad(opts) || reinterpret_cast<uintptr_t>(row_key) % 16 || reinterpret_cast<uintptr_t>(pairs) % 8)
     return GB_EINVAL;
   if (fin && (!fin->gamma || !fin->beta || !fin->ab || fin->P < 1 || fin->training != 1)) return GB_EINVAL;
   if (P > 0x7fffffffLL - 64) return GB_ERANGE;
   const RsPool pool = {row_key, gamma, reinterpret_cast<float2 *>(pairs), D};
-  if (!rs_gemm_try(x, w, y, aff, stats, stat_slots, nullptr, nullptr, P, K, N, 1, RS_STATS_POOL, as_stream(stream),
+  if (!with_rows && !y) return GB_EINVAL;  // values only: the arg-max row is later found by value in the stored Y
+  if (!rs_gemm_try(x, w, y, aff, stats, stat_slots, nullptr, nullptr, P, K, N, 1, with_rows ? RS_STATS_POOL : RS_STATS_POOL_V,
+                   as_stream(stream),
                    opts_bf16(opts), opts_reserved(opts), nullptr, nullptr, &pool))
     return GB_EINVAL;
   return finalize_after(check_launch("gb_gemm_fwd_pool"), fin, stats, stat_slots, N, stream);

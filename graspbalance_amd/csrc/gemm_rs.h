@@ -10,7 +10,9 @@ enum { RS_STORE = 0,   // D only
        RS_BNBWD = 2,   // + column sums of g and g*xhat, g = D*[a*y+b > 0]  (BatchNorm-backward sums)
        RS_BNBWD_X = 3,   // those two + sum g*x_j (j < 3) for the layer's 3-channel input x; D is NOT stored
        RS_STATS_POOL = 4,   // RS_STATS with per-row keys; D is NOT stored: per (tile, seed, crop, column) extrema leave
-       RS_BNBWD_LR = 5 };   // RS_BNBWD on D' = D_in - w_row*(D + v_col): D_in = what d holds on entry (read-modify-write)
+       RS_BNBWD_LR = 5,     // RS_BNBWD on D' = D_in - w_row*(D + v_col): D_in = what d holds on entry (read-modify-write)
+       RS_STATS_POOL_V = 6 }; // RS_STATS_POOL leaving the extreme VALUES only (pairs = float[(tile + seed)][D][C]): a fifth of the
+                            // epilogue's instructions; the arg-max row is then found by value (y == y*) where y is stored
 
 // D (P,C) = f(A (P,R)) B (R,C);  w_kc = 1: B[r][c] = w[c*R + r], 0: B[r][c] = w[r*C + c].
 // Returns false (nothing launched) when the shape does not suit the kernel; the caller then uses the

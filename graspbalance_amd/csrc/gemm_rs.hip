@@ -223,7 +223,7 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
 #ifndef GB_DEFER
 #define GB_DEFER 1
 #endif
-      const bool defer = GB_DEFER && EPI == RS_STATS_POOL && kc == g.nch - 1;
+      const bool defer = GB_DEFER && (EPI == RS_STATS_POOL || EPI == RS_STATS_POOL_V) && kc == g.nch - 1;
       if (more && !defer) load_chunk(nxt, ntile, nkc);
 
       float av[16];
@@ -314,6 +314,76 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
         // 32-bit lane offset.  (The generic path spent ~16 vector instructions per stored element on them: ~10 k cycles
         // per tile beside 32 k cycles of MFMA.)
         const bool full = tile * 32 + 32 <= g.P && g.C == C32;
+        if constexpr (EPI == RS_STATS_POOL_V) {
+          // As RS_STATS_POOL below, values only: per (seed in the tile, crop, column) max over the member rows of
+          // sign(gamma)*y.  Vector ALU only, no per-element masks in scalar registers: a member mask row of 0 / -inf is
+          // built once per (seed, crop) and shared by the NT column tiles, each element then costs one add and half a
+          // v_max3 (the form that also tracks the row - compare, two selects, mask logic through SGPR pairs - ran 3x the
+          // tile's MFMA time).
+          const long long trow = (long long)__builtin_amdgcn_readfirstlane((int)tile) * 32;
+          const long long lastrow = trow + 31 < g.P ? trow + 31 : g.P - 1;
+          const int s_lo = g.epi_key[trow] >> 13, s_hi = g.epi_key[lastrow] >> 13;  // wave-uniform (scalar loads)
+          int rk[16];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int4 k4 = *reinterpret_cast<const int4 *>(g.epi_key + trow + 4 * h + 8 * i);
+            rk[4 * i] = k4.x; rk[4 * i + 1] = k4.y; rk[4 * i + 2] = k4.z; rk[4 * i + 3] = k4.w;
+          }
+          const unsigned lane_off = (unsigned)(4 * h) * (unsigned)g.ldd + (unsigned)m;
+          const int nrow = (int)(g.P - trow) - 4 * h;    // rows (r&3) + 8(r>>2) below this are valid
+#pragma unroll
+          for (int q = 0; q < NT; ++q) {
+            if (!in(q)) continue;
+            float cs = 0.f, cq = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float v = acc[q][r];
+              const float wv = (float)((rk[r] >> 4) & 0x1FF) * v;
+              cs += wv;
+              cq += wv * v;
+            }
+            dsum[q] += (double)cs;
+            dsq[q] += (double)cq;
+#ifndef GB_NOSTORE
+#define GB_NOSTORE 0
+#endif
+            if (!GB_NOSTORE && g.d) {  // keep Y for the backward (rows >= P are not stored)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                float *dp = g.d + (trow + (r & 3) + 8 * (r >> 2)) * (long long)g.ldd + q * 32;  // wave-uniform
+                if ((r & 3) + 8 * (r >> 2) < nrow) dp[lane_off] = acc[q][r];
+              }
+            }
+            const float sg = g.epi_gamma[q * 32 + m] < 0.f ? -1.f : 1.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][r] *= sg;   // in place: sign(gamma) * y
+          }
+          float *pv = reinterpret_cast<float *>(g.pairs);
+          for (int sd = s_lo; sd <= s_hi; ++sd) {
+            for (int d = 0; d < g.pool_d; ++d) {
+              float mv[16];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) mv[r] = ((rk[r] >> 13) == sd && ((rk[r] >> d) & 1)) ? 0.f : -INFINITY;
+              float *dst = pv + ((size_t)(tile + sd) * g.pool_d + d) * C32 + m;
+#pragma unroll
+              for (int q = 0; q < NT; ++q) {
+                if (!in(q)) continue;
+                float best = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; r += 2)
+                  best = fmaxf(best, fmaxf(acc[q][r] + mv[r], acc[q][r + 1] + mv[r + 1]));
+                const auto sb = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+                best = fmaxf(best, __uint_as_float(h ? sb[0] : sb[1]));   // the other 16 rows sit in lane ^ 32
+                if (h == 0) dst[q * 32] = best;
+                __builtin_amdgcn_sched_barrier(0);   // one column tile at a time: interleaving all 8 chains spills
+              }
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < NT; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+        } else
         if constexpr (EPI == RS_STATS_POOL) {
           // Y is NOT stored.  What leaves the tile: the weighted BatchNorm sums (as RS_STATS) and, per (seed in the
           // tile, crop d, column), the extreme of sign(gamma)*y over the seed's member rows in this tile + the row
@@ -620,7 +690,7 @@ static bool rs_shape_ok(long long P, int R, int C, int epi, bool has_aff, int *n
   if (!nt) return false;
   if ((epi == RS_BNBWD || epi == RS_BNBWD_LR) && nt == 8) return false;  // accumulators + y prefetch do not fit the register file
   if (epi == RS_BNBWD_X && nt > 2) return false;  // 64-wide first layers only (registers)
-  if (epi == RS_STATS_POOL && C != nt * 32) return false;  // the pooled epilogue has no column bounds checks
+  if ((epi == RS_STATS_POOL || epi == RS_STATS_POOL_V) && C != nt * 32) return false;  // the pooled epilogues have no column bounds checks
   // MFMA work wasted on padding must stay small
   if ((long long)nch * RS_CH * nt * 32 * 4 > (long long)R * C * 5) return false;
   const size_t lds_bytes = ((size_t)nch * RS_CH * nt * 32 + (has_aff ? 2 * nch * RS_CH : 0)) * sizeof(float);
@@ -637,7 +707,7 @@ bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, dou
   int nt = 0;
   size_t lds_bytes = 0;
   if (!rs_shape_ok(P, R, C, epi, aff != nullptr, &nt, &lds_bytes)) return false;
-  if (epi == RS_STATS_POOL && (!pool || C != nt * 32 || pool->D < 1 || pool->D > 4)) return false;
+  if ((epi == RS_STATS_POOL || epi == RS_STATS_POOL_V) && (!pool || C != nt * 32 || pool->D < 1 || pool->D > 4)) return false;
   if (epi == RS_BNBWD_LR && (!pool || !pool->lr_v || !pool->lr_roww || !d)) return false;
   if (reinterpret_cast<uintptr_t>(a) % 16 != 0 || (w_kc && reinterpret_cast<uintptr_t>(w) % 16 != 0)) return false;
   const int nch = (R + RS_CH - 1) / RS_CH;
@@ -657,6 +727,7 @@ bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, dou
 #define GB_RS(NT_)                                                         \
   do {                                                                     \
     if (epi == RS_STATS_POOL) rs_launch<NT_, RS_STATS_POOL>(g, lds_bytes, bpc, s, bf16, reserved_cus); \
+    else if (epi == RS_STATS_POOL_V) rs_launch<NT_, RS_STATS_POOL_V>(g, lds_bytes, bpc, s, bf16, reserved_cus); \
     else if (epi == RS_STATS) rs_launch<NT_, RS_STATS>(g, lds_bytes, bpc, s, bf16, reserved_cus);   \
     else if (epi == RS_BNBWD) rs_launch<NT_, RS_BNBWD>(g, lds_bytes, bpc, s, bf16, reserved_cus); \
     else if (epi == RS_BNBWD_LR) rs_launch<NT_, RS_BNBWD_LR>(g, lds_bytes, bpc, s, bf16, reserved_cus); \

@@ -490,7 +490,7 @@ __global__ __launch_bounds__(CL_TPB) void affine_relu_maxpool_members_kernel(
 // the seed's members of crop d in that tile at pairs[(t + r)][d][c] (value, row).  With a = gamma*rstd of the same
 // sign, max over the crop of relu(a*y + b) = relu(a*y* + b) at that extreme y*: out, arg (absolute row, the lowest
 // one among equal extremes) and ystar = y* (what the backward needs of the never-stored layer output).
-template <int D>
+template <int D, bool ROWS>
 __global__ __launch_bounds__(CL_TPB) void pool_pairs_kernel(const float2 *__restrict__ pairs,
                                                             const int64_t *__restrict__ off,
                                                             const int32_t *__restrict__ cnt,
@@ -509,17 +509,22 @@ __global__ __launch_bounds__(CL_TPB) void pool_pairs_kernel(const float2 *__rest
     float best = -INFINITY;
     int brow = 0x7fffffff;
     for (long long t = t0; t <= t1; ++t) {  // tiles in row order: a strict > keeps the lowest row among equal values
-      const float2 p = pairs[((size_t)(t + r) * D + d) * C + c];
-      const int row = __float_as_int(p.y);
-      if (p.x > best || (p.x == best && row < brow)) { best = p.x; brow = row; }
+      if constexpr (ROWS) {
+        const float2 p = pairs[((size_t)(t + r) * D + d) * C + c];
+        const int row = __float_as_int(p.y);
+        if (p.x > best || (p.x == best && row < brow)) { best = p.x; brow = row; }
+      } else {  // values only (gb_gemm_fwd_pool with_rows = 0): floats
+        const float v = reinterpret_cast<const float *>(pairs)[((size_t)(t + r) * D + d) * C + c];
+        best = fmaxf(best, v);
+      }
     }
-    const bool any = brow != 0x7fffffff;
+    const bool any = ROWS ? brow != 0x7fffffff : best > -INFINITY;
     const float y = any ? sg * best : 0.f;
     float o = a * y + b;
     o = (any && o > 0.f) ? o : 0.f;
     const size_t at = (size_t)(r * D + d) * C + c;
     out[at] = o;
-    arg[at] = any ? brow : (int)u0;
+    if constexpr (ROWS) arg[at] = any ? brow : (int)u0;
     ystar[at] = y;
   }
 }
@@ -527,12 +532,15 @@ __global__ __launch_bounds__(CL_TPB) void pool_pairs_kernel(const float2 *__rest
 // BatchNorm + ReLU + member-max-pool backward for the distinct rows: the gradient of row u sums, over the cylinders
 // d whose arg-max it is, dout*[out > 0]; every COPY of the row also receives the -(dbeta/P + xhat*dgamma/P) terms, so
 // with multiplicity w:  dy[u] = a*(g - w*(dbeta/P) - xhat*(w*dgamma/P)),  P = rows of the original batch.
-template <int D>
+// BYVAL: no arg rows - `arg` is reinterpreted as ystar ((R*D), C) floats and `row_mem` gives the member bits: the gradient
+// of crop d goes to the FIRST row of the seed that is a member of d and whose y equals the crop's extreme y* (the
+// row an arg-max in row order would name; the pooled GEMM epilogue leaves values only).
+template <int D, bool BYVAL = false>
 __global__ __launch_bounds__(CL_TPB) void bn_bwd_apply_members_kernel(
     const float *__restrict__ dout, const float *__restrict__ out, const int32_t *__restrict__ arg,
     const float *__restrict__ y, const float *__restrict__ ab, const double *__restrict__ dstats,
     const float *__restrict__ row_w, const int64_t *__restrict__ off, const int32_t *__restrict__ cnt, long long R,
-    int C, double invP, int training, float *__restrict__ dy) {
+    int C, double invP, int training, float *__restrict__ dy, const int32_t *__restrict__ row_mem = nullptr) {
   const int tpg = C / 4, gpb = CL_TPB / tpg;
   const long long r = (long long)blockIdx.x * gpb + threadIdx.x / tpg;
   if (threadIdx.x / tpg >= gpb || r >= R) return;
@@ -552,7 +560,7 @@ __global__ __launch_bounds__(CL_TPB) void bn_bwd_apply_members_kernel(
     float o[4];
     load_vec<4>(out + (r * D + d) * C + c, o);
     load_vec<4>(dout + (r * D + d) * C + c, g[d]);
-    const int4 q = *reinterpret_cast<const int4 *>(arg + (r * D + d) * C + c);
+    const int4 q = *reinterpret_cast<const int4 *>(arg + (r * D + d) * C + c);   // BYVAL: the bits of ystar
     ar[d][0] = q.x; ar[d][1] = q.y; ar[d][2] = q.z; ar[d][3] = q.w;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -561,6 +569,7 @@ __global__ __launch_bounds__(CL_TPB) void bn_bwd_apply_members_kernel(
   const long long u0 = off[r], u1 = u0 + cnt[r];
   for (long long u = u0; u < u1; u += MEM_RIF_BWD) {
     float v[MEM_RIF_BWD][4], w[MEM_RIF_BWD];
+    int mb[MEM_RIF_BWD];
 #pragma unroll
     for (int q = 0; q < MEM_RIF_BWD; ++q) {
       // unconditional loads from a clamped row index: under `if (u + q < u1)` the four loads were waited for one
@@ -568,6 +577,7 @@ __global__ __launch_bounds__(CL_TPB) void bn_bwd_apply_members_kernel(
       const long long uu = u + q < u1 ? u + q : u1 - 1;
       load_vec<4>(y + uu * C + c, v[q]);
       w[q] = row_w[uu];
+      mb[q] = BYVAL ? row_mem[uu] : 0;
     }
 #pragma unroll
     for (int q = 0; q < MEM_RIF_BWD; ++q)
@@ -577,7 +587,15 @@ __global__ __launch_bounds__(CL_TPB) void bn_bwd_apply_members_kernel(
         for (int t = 0; t < 4; ++t) {
           float gs = 0.f;
 #pragma unroll
-          for (int d = 0; d < D; ++d) gs += (ar[d][t] == (int)(u + q)) ? g[d][t] : 0.f;
+          for (int d = 0; d < D; ++d) {
+            if constexpr (BYVAL) {
+              const bool hit = ((mb[q] >> d) & 1) && v[q][t] == __int_as_float(ar[d][t]);
+              gs += hit ? g[d][t] : 0.f;
+              if (hit) g[d][t] = 0.f;   // first match only (rows are visited in order)
+            } else {
+              gs += (ar[d][t] == (int)(u + q)) ? g[d][t] : 0.f;
+            }
+          }
           if (training) {
             const float xhat = (v[q][t] - km[t]) * kr[t];
             gs = gs - w[q] * k1[t] - xhat * (w[q] * k2[t]);
@@ -901,34 +919,67 @@ extern "C" int gb_pool_pairs(const float *pairs, const int64_t *off, const int32
                              const float *gamma, float *out, int32_t *arg, float *ystar, long long R, int D, int C,
                              void *stream) {
   if (R < 0 || D < 1 || D > 4 || C < 1 || C > CL_TPB || CL_TPB % C || !pairs || !off || !cnt || !ab || !gamma || !out ||
-      !arg || !ystar || reinterpret_cast<uintptr_t>(pairs) % 8)
-    return GB_EINVAL;
+      !ystar || reinterpret_cast<uintptr_t>(pairs) % 8)
+    return GB_EINVAL;  // arg == NULL: `pairs` holds values only (floats)
   if (R == 0) return GB_OK;
   const int gpb = CL_TPB / C;
   const dim3 grid((unsigned)((R + gpb - 1) / gpb));
   const float2 *pp = reinterpret_cast<const float2 *>(pairs);
-#define GB_PP(D_) hipLaunchKernelGGL((pool_pairs_kernel<D_>), grid, dim3(CL_TPB), 0, as_stream(stream), pp, off, cnt, ab, \
-                                     gamma, out, arg, ystar, R, C)
+#define GB_PP(D_)                                                                                                    \
+  do {                                                                                                               \
+    if (arg) hipLaunchKernelGGL((pool_pairs_kernel<D_, true>), grid, dim3(CL_TPB), 0, as_stream(stream), pp, off, cnt, ab, \
+                                gamma, out, arg, ystar, R, C);                                                       \
+    else hipLaunchKernelGGL((pool_pairs_kernel<D_, false>), grid, dim3(CL_TPB), 0, as_stream(stream), pp, off, cnt, ab,    \
+                            gamma, out, arg, ystar, R, C);                                                           \
+  } while (0)
   if (D == 1) GB_PP(1); else if (D == 2) GB_PP(2); else if (D == 3) GB_PP(3); else GB_PP(4);
 #undef GB_PP
   return check_launch("gb_pool_pairs");
+}
+
+static int apply_members_impl(const float *dout, const float *out, const int32_t *arg, const float *ystar, const float *y,
+                              const float *ab, const double *dstats, const float *row_w, const int32_t *row_mem,
+                              const int64_t *off, const int32_t *cnt, long long R, int D, int C, long long P_total,
+                              int training, float *dy, void *stream) {
+  const void *sel = arg ? static_cast<const void *>(arg) : static_cast<const void *>(ystar);
+  if (!dout || !out || !sel || !y || !ab || !row_w || !off || !cnt || !dy || (training && !dstats) || P_total < 1 ||
+      (!arg && !row_mem) || !members_ok(R, D, C, dout, out, sel, y) ||
+      (reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(ab)) % 16)
+    return GB_EINVAL;
+  if (R == 0) return GB_OK;
+  const int gpb = CL_TPB / (C / 4);
+  const dim3 grid((unsigned)((R + gpb - 1) / gpb));
+  const int32_t *sel32 = static_cast<const int32_t *>(sel);
+#define GB_MB(D_)                                                                                                          \
+  do {                                                                                                                     \
+    if (arg) hipLaunchKernelGGL((bn_bwd_apply_members_kernel<D_, false>), grid, dim3(CL_TPB), 0, as_stream(stream), dout, out, \
+                                sel32, y, ab, dstats, row_w, off, cnt, R, C, 1.0 / (double)P_total, training, dy, row_mem);     \
+    else hipLaunchKernelGGL((bn_bwd_apply_members_kernel<D_, true>), grid, dim3(CL_TPB), 0, as_stream(stream), dout, out,      \
+                            sel32, y, ab, dstats, row_w, off, cnt, R, C, 1.0 / (double)P_total, training, dy, row_mem);         \
+  } while (0)
+  if (D == 1) GB_MB(1); else if (D == 2) GB_MB(2); else GB_MB(4);
+#undef GB_MB
+  return check_launch("gb_bn_bwd_apply_members");
 }
 
 extern "C" int gb_bn_bwd_apply_members(const float *dout, const float *out, const int32_t *arg, const float *y,
                                        const float *ab, const double *dstats, const float *row_w, const int64_t *off,
                                        const int32_t *cnt, long long R, int D, int C, long long P_total, int training,
                                        float *dy, void *stream) {
-  if (!dout || !out || !arg || !y || !ab || !row_w || !off || !cnt || !dy || (training && !dstats) || P_total < 1 ||
-      !members_ok(R, D, C, dout, out, arg, y) || (reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(ab)) % 16)
-    return GB_EINVAL;
-  if (R == 0) return GB_OK;
-  const int gpb = CL_TPB / (C / 4);
-  const dim3 grid((unsigned)((R + gpb - 1) / gpb));
-#define GB_MB(D_) hipLaunchKernelGGL((bn_bwd_apply_members_kernel<D_>), grid, dim3(CL_TPB), 0, as_stream(stream), dout, out, \
-                                     arg, y, ab, dstats, row_w, off, cnt, R, C, 1.0 / (double)P_total, training, dy)
-  if (D == 1) GB_MB(1); else if (D == 2) GB_MB(2); else GB_MB(4);
-#undef GB_MB
-  return check_launch("gb_bn_bwd_apply_members");
+  if (!arg) return GB_EINVAL;
+  return apply_members_impl(dout, out, arg, nullptr, y, ab, dstats, row_w, nullptr, off, cnt, R, D, C, P_total, training, dy,
+                            stream);
+}
+
+// ... with the arg-max row found BY VALUE: crop d's gradient goes to the first member row of the seed whose y equals
+// ystar[(r*D + d), c] (gb_pool_pairs after a values-only gb_gemm_fwd_pool); row_mem = the rows' member bits.
+extern "C" int gb_bn_bwd_apply_members_v(const float *dout, const float *out, const float *ystar, const float *y,
+                                         const float *ab, const double *dstats, const float *row_w,
+                                         const int32_t *row_mem, const int64_t *off, const int32_t *cnt, long long R, int D,
+                                         int C, long long P_total, int training, float *dy, void *stream) {
+  if (!ystar) return GB_EINVAL;
+  return apply_members_impl(dout, out, nullptr, ystar, y, ab, dstats, row_w, row_mem, off, cnt, R, D, C, P_total, training,
+                            dy, stream);
 }
 
 extern "C" int gb_bn_bwd_apply_w(const float *dout, const float *y, const float *ab, const double *dstats,

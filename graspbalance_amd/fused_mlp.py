@@ -462,14 +462,17 @@ class MLPStack(Function):
         ctx.rows = rows
         ctx.prec = prec
         ctx.pooled = rows is not None and Ys[-1] is None
+        ctx.by_value = False
         if pooled is not None:
             out, arg, ystar = pooled
             if Ys[-1] is None:
                 ctx.save_for_backward(X0, out, arg, ab_arena, *Ws, *Ys[:-1], ystar)
-            else:
-                ctx.save_for_backward(X0, out, arg, ab_arena, *Ws, *Ys)
+            else:   # values only: the backward finds the arg-max rows by value in the stored output
+                ctx.save_for_backward(X0, out, ystar, ab_arena, *Ws, *Ys)
+                ctx.by_value = True
             if routing_observer is not None:
-                routing_observer("stack", Ys=Ys, abs=abs_, out=out, arg=arg, pool_ns=0, relu_last=True, rows=rows)
+                routing_observer("stack", Ys=Ys, abs=abs_, out=out, pool_ns=0, relu_last=True, rows=rows,
+                                 arg=arg if arg is not None else _arg_rows_by_value(Ys[-1], ystar, rows))
             return out
         if rows is not None:
             RD = rows.R * rows.D
@@ -600,6 +603,15 @@ class MLPStack(Function):
             dY = _empty_rows(P, N, dev, rows is not None)
         if ctx.pooled:
             pass
+        elif rows is not None and ctx.by_value:
+            out, ystar = s1, s2
+            RD = rows.R * rows.D
+            # the crops' extreme y* are saved: the BatchNorm-backward sums need no gather from the layer's output
+            _call("gb_bn_bwd_stats", dev, _lib.ptr(dout), _lib.ptr(ystar), _lib.ptr(abs_[-1]), None, RD, N, 1,
+                  _lib.ptr(dstats), pb, pg, st)
+            _call("gb_bn_bwd_apply_members_v", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(ystar), _lib.ptr(Ys[-1]),
+                  _lib.ptr(abs_[-1]), _lib.ptr(dstats), _lib.ptr(rows.w), _lib.ptr(rows.mem), _lib.ptr(rows.off),
+                  _lib.ptr(rows.cnt), rows.R, rows.D, N, P_stat, int(training[-1]), _lib.ptr(dY), st)
         elif rows is not None:
             out, arg = s1, s2
             _call("gb_bn_bwd_stats_pool", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(Ys[-1]),
@@ -684,15 +696,17 @@ class MLPStack(Function):
         return (dX0, dres, None, None, None, None, *grads)
 
 
-# The crop stacks' last layer (csrc/gemm_rs.hip RS_STATS_POOL, csrc/crop_bwd.hip):
-#   GB_CROP_POOL=0     the GEMM stores Y3, gb_affine_relu_maxpool_members pools it (round-2 path)
-#   default            the pooling leaves the GEMM epilogue (per-tile extrema) + gb_pool_pairs; Y3 is still stored for the
-#                      dense backward
+# The crop stacks' last layer (csrc/gemm_rs.hip RS_STATS_POOL(_V), csrc/crop_bwd.hip):
+#   GB_CROP_POOL=0     the GEMM stores Y3, gb_affine_relu_maxpool_members pools it in a second pass (round-2 path)
+#   default            the pooling leaves the GEMM epilogue as per-(tile, seed, crop) extreme VALUES (a fifth of the
+#                      instructions of the row-tracking form) + gb_pool_pairs; Y3 is still stored and the dense backward
+#                      finds the arg-max rows by value (gb_bn_bwd_apply_members_v), its BatchNorm sums come from the saved
+#                      extremes without a gather: one pass over Y3 less, -0.15 ms per step
 #   GB_CROP_LOWRANK=1  Y3 is never stored; backward = low rank + sparse (K x K product, Gram matrix, sparse kernel).
 #                      Correct to 1e-6 of the dense backward (tests), but its sparse kernel is bound by LDS float
 #                      atomics (164 clocks per wave instruction measured) and loses 2.5 ms per launch: opt-in until
 #                      that kernel is rebuilt without them
-_CROP_POOL = os.environ.get("GB_CROP_POOL", "0") != "0"
+_CROP_POOL = os.environ.get("GB_CROP_POOL", "1") != "0"
 _CROP_LOWRANK = os.environ.get("GB_CROP_LOWRANK", "0") == "1"
 
 
@@ -711,23 +725,46 @@ def _pooled_last_layer(dev, st, opts, src, W, aff, gamma, beta, cfg, ab, stats, 
     receives the layer's output."""
     RD = rows.R * rows.D
     tiles = (P + 31) // 32
-    pairs = torch.empty(((tiles + rows.R) * rows.D * N, 2), dtype=torch.float32, device=dev)
+    with_rows = Y is None   # no stored output to find the arg-max rows in by value: the epilogue must track them
+    # sized for the row count rounded up like the activations (_empty_rows): the distinct-row count changes every step,
+    # and a new allocation size every step means a fresh hipMalloc - a device synchronisation - per radius
+    cap_tiles = (P + _ROW_QUANTUM - 1) // _ROW_QUANTUM * (_ROW_QUANTUM // 32)
+    pairs = torch.empty(((cap_tiles + rows.R) * rows.D * N, 2 if with_rows else 1), dtype=torch.float32, device=dev)
     if cfg.training:
         fin = _bn_fin(cfg, gamma, beta, ab, P_stat)
     else:
         fin, stats, slots = None, _zeros64(2 * N, dev), 1   # the kernel always forms the sums; eval ignores them
     _call("gb_gemm_fwd_pool", dev, _lib.ptr(src), _lib.ptr(W), _lib.ptr(aff), _lib.ptr(rows.key), _lib.ptr(gamma),
-          _lib.ptr(pairs), _lib.ptr(Y), _lib.ptr(stats), slots, P, K, N, rows.D, fin, opts, st,
+          _lib.ptr(pairs), int(with_rows), _lib.ptr(Y), _lib.ptr(stats), slots, P, K, N, rows.D, fin, opts, st,
           meta=_gemm_meta("fwd", P, K, N, True, aff is not None))
     if fin is None:
         _call("gb_bn_finalize", dev, None, 1, P_stat, N, _lib.ptr(gamma), _lib.ptr(beta), cfg.eps, cfg.momentum,
               _lib.ptr(cfg.running_mean), _lib.ptr(cfg.running_var), _lib.ptr(ab), 0, st)
     out = torch.empty((RD, N), dtype=torch.float32, device=dev)
-    arg = torch.empty((RD, N), dtype=torch.int32, device=dev)
+    arg = torch.empty((RD, N), dtype=torch.int32, device=dev) if with_rows else None
     ystar = torch.empty((RD, N), dtype=torch.float32, device=dev)
     _call("gb_pool_pairs", dev, _lib.ptr(pairs), _lib.ptr(rows.off), _lib.ptr(rows.cnt), _lib.ptr(ab), _lib.ptr(gamma),
           _lib.ptr(out), _lib.ptr(arg), _lib.ptr(ystar), rows.R, rows.D, N, st)
     return out, arg, ystar
+
+
+def _arg_rows_by_value(Y, ystar, rows):
+    """Debug / test helper (routing_observer): the arg-max rows the values-only pooled path implies - per (seed, crop,
+    column) the first member row whose y equals y* - as gb_affine_relu_maxpool_members would name them."""
+    R, D, C = rows.R, rows.D, Y.shape[1]
+    P = Y.shape[0]
+    seed = torch.repeat_interleave(torch.arange(R, device=Y.device), rows.cnt.long(), output_size=P)
+    rowidx = torch.arange(P, device=Y.device, dtype=torch.int64).unsqueeze(1).expand(P, C)
+    ys = ystar.view(R, D, C)
+    arg = torch.empty((R, D, C), dtype=torch.int64, device=Y.device)
+    big = torch.iinfo(torch.int64).max
+    for d in range(D):
+        hit = (Y == ys[seed, d]) & ((rows.mem.long() >> d) & 1).bool().unsqueeze(1)
+        cand = torch.where(hit, rowidx, torch.full_like(rowidx, big))
+        first = torch.full((R, C), big, dtype=torch.int64, device=Y.device)
+        first.scatter_reduce_(0, seed.unsqueeze(1).expand(P, C), cand, reduce="amin")
+        arg[:, d] = torch.where(first == big, rows.off.long().unsqueeze(1).expand(R, C), first)
+    return arg.view(R * D, C).to(torch.int32)
 
 
 class LocalGeometry:

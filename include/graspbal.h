@@ -346,10 +346,13 @@ int gb_cyl_rows(const float *xyz, const float *centres, const float *rot, const 
  * extremes), ystar = that row's y.  row_key (P rounded up to 32, zero tail; 16-byte aligned) from gb_cyl_rows; pairs:
  * ((P + 31) / 32 + R) * D * N * 2 floats.  N in {64, 128, 160, 256}, D <= 4, P >= 16384, K % 4 == 0: otherwise
  * GB_EINVAL (ask gb_gemm_uses_rs(P, K, N, 0, 3, has_aff)).  stats as in gb_gemm_fwd (required).  y (optional, (P,N)):
- * Y is stored as well, for a caller whose backward wants it (the dense backward: gb_bn_bwd_apply_members).      */
+ * Y is stored as well, for a caller whose backward wants it (the dense backward: gb_bn_bwd_apply_members).
+ * with_rows = 0: VALUES only - pairs holds one float per entry (half the size), gb_pool_pairs is called with arg =
+ * NULL, and the arg-max row is found by value in the stored y (required then) by gb_bn_bwd_apply_members_v: the
+ * epilogue then costs a fifth of the instructions of the row-tracking form.                                     */
 int gb_gemm_fwd_pool(const float *x, const float *w, const float *aff, const int32_t *row_key, const float *gamma,
-                     float *pairs, float *y, double *stats, int stat_slots, long long P, int K, int N, int D,
-                     const GbBnFinalize *fin, const GbGemmOpts *opts, void *stream);
+                     float *pairs, int with_rows, float *y, double *stats, int stat_slots, long long P, int K, int N,
+                     int D, const GbBnFinalize *fin, const GbGemmOpts *opts, void *stream);
 int gb_pool_pairs(const float *pairs, const int64_t *off, const int32_t *cnt, const float *ab, const float *gamma,
                   float *out, int32_t *arg, float *ystar, long long R, int D, int C, void *stream);
 /* Backward of that layer as "low rank + sparse" (csrc/crop_bwd.hip has the algebra): behind the max-pool the gradient
@@ -401,6 +404,13 @@ int gb_affine_relu_maxpool_members(const float *y, const float *ab, const int32_
 int gb_bn_bwd_apply_members(const float *dout, const float *out, const int32_t *arg, const float *y, const float *ab,
                             const double *dstats, const float *row_w, const int64_t *off, const int32_t *cnt,
                             long long R, int D, int C, long long P_total, int training, float *dy, void *stream);
+/* ... with the arg-max rows found by value: crop d's gradient goes to the FIRST row of the seed (in row order) that is a
+ * member of d (row_mem bit d) and whose y equals ystar[(r*D + d), c] - what gb_pool_pairs leaves after a values-only
+ * gb_gemm_fwd_pool.                                                                                              */
+int gb_bn_bwd_apply_members_v(const float *dout, const float *out, const float *ystar, const float *y, const float *ab,
+                              const double *dstats, const float *row_w, const int32_t *row_mem, const int64_t *off,
+                              const int32_t *cnt, long long R, int D, int C, long long P_total, int training, float *dy,
+                              void *stream);
 /* gb_bn_bwd_apply (ReLU, no residual) for rows with multiplicities: dy = a*(dA*[z>0] - w*dbeta/P - xhat*w*dgamma/P). */
 int gb_bn_bwd_apply_w(const float *dout, const float *y, const float *ab, const double *dstats, const float *row_w,
                       long long rows, long long P_total, int C, int training, float *dy, void *stream);

@@ -7,7 +7,7 @@ wg, xyz, centres, rot, rows = _crop_case(B=4)
 wg.train()
 names = ["gb_crop_bwd_sparse", "gb_crop_bwd_coef", "gb_crop_bwd_dense", "gb_gemm_gram", "gb_crop_bwd_dw", "gb_gemm_fwd_pool",
          "gb_pool_pairs", "gb_gemm_fwd_w", "gb_affine_relu_maxpool_members", "gb_bn_bwd_stats_pool", "gb_bn_bwd_apply_members",
-         "gb_gemm_dgrad", "gb_gemm_wgrad", "gb_bn_bwd_apply_w", "gb_gemm_dgrad_first"]
+         "gb_gemm_dgrad", "gb_gemm_wgrad", "gb_bn_bwd_apply_w", "gb_gemm_dgrad_first", "gb_bn_bwd_apply_members_v", "gb_bn_bwd_stats"]
 for pool, lowrank in ((False, False), (True, False), (True, True)):
     fused_mlp.set_crop_pool(pool, lowrank)
     for it in range(3):

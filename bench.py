@@ -61,7 +61,7 @@ def pmc_traffic(kernel):
     """HBM bytes per launch from the committed PMC passes (profiles/*_pmc_traffic.json: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 corrections applied; the newest
     round that has the kernel wins); None when absent.  Counters cannot be collected from inside this process."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return round(json.load(f)[kernel]["hbm_bytes_per_launch"], 1)
@@ -188,14 +188,94 @@ def cpu_baseline_dense(num_threads, device, repeats=5):
             "feature_rel_err": err, "sample": "1 warm-up + median of %d (CPU %.3f s, HIP %.2f ms per cloud)" % (repeats, c, g * 1e3)}
 
 
+def infer_main(args):
+    """BASELINE configs[2]: full GraspBalance forward (eval mode, running statistics) + pred_decode on B = 4 clouds of
+    20 000 points per GPU, clouds resident in HBM.  Nothing hides the first-level furthest-point sampling here (no next
+    batch is announced): its launch is timed with HIP events inside the timed region and priced against the streaming
+    model like the train line's.  Ranks are independent replicas (inference has no collective)."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no GPU visible)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    from graspbalance_amd import _lib
+    from graspbalance_amd.graspbalance import GraspBalance, pred_decode
+    from graspbalance_amd.scene import make_batch
+    _lib.lib()
+    torch.manual_seed(1234)
+    net = GraspBalance(is_training=False).to(device).eval()
+    clouds = torch.from_numpy(make_batch([1000 * rank + i for i in range(BATCH_PER_GPU)], NUM_POINT)).to(device)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def step():
+        with torch.no_grad():
+            return pred_decode(net({'point_clouds': clouds}))
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    timer = _lib.KernelTimer(["gb_fps", "gb_ball_query"], reserve=64 * args.steps)
+    with timer as kt:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            grasps = step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t[0].item())
+    if rank == 0:
+        ev_bias = _lib.event_pair_overhead_ms(device)
+        big = [(a.elapsed_time(b) - ev_bias, m) for a, b, m in kt.events["gb_fps"] if m["n"] == NUM_POINT]
+        fps_ms = sum(x for x, _ in big) / len(big)
+        meta = big[0][1]
+        fps_bytes = fps_algorithmic_bytes(meta["b"], meta["n"], meta["m"])
+        ball = [(a.elapsed_time(b) - ev_bias, m) for a, b, m in kt.events["gb_ball_query"] if m["n"] == NUM_POINT]
+        ball_ms = sum(x for x, _ in ball) / len(ball)
+        ach = fps_bytes / (fps_ms * 1e-3) / 1e9
+        out = {"metric": "point-clouds/sec forward (inference), 20k-pt GraspNet scene", "value": round(world * BATCH_PER_GPU * args.steps / elapsed, 3),
+               "unit": "point-clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic (make_scene clouds, default-initialised weights)",
+               "config": {"workload": "configs[2]: GraspBalance eval forward + pred_decode, B=%d/GPU, N=%d points"
+                                      % (BATCH_PER_GPU, NUM_POINT), "global_batch": world * BATCH_PER_GPU,
+                          "parallelism": "replicas x%d" % world},
+               "roofline": {"kernel": "cell-order counting sort + fps_pruned_kernel<1024,20> (furthest_point_sampling %d->%d, b=%d), "
+                                      "on the critical path" % (meta["n"], meta["m"], meta["b"]),
+                            "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("fps_pruned_kernel"),
+                            "launch_ms": round(fps_ms, 4), "launches": len(big),
+                            "share_of_step": round(fps_ms / (elapsed / args.steps * 1e3), 3)},
+               "first_level_ball_query_ms": round(ball_ms, 4)}
+        assert len(grasps) == BATCH_PER_GPU and all(g.shape[1] == 17 for g in grasps)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--config", choices=["train", "stress"], default="train",
-                    help="train = BASELINE configs[3] (the headline line); stress = configs[4]: B=8/GPU, N=50000, bf16 MLP")
+    ap.add_argument("--config", choices=["train", "stress", "infer"], default="train",
+                    help="train = BASELINE configs[3] (the headline line); stress = configs[4]: B=8/GPU, N=50000, bf16 MLP; "
+                         "infer = configs[2]: eval forward + pred_decode, B=4, N=20000 (first-level FPS on the critical path)")
     args = ap.parse_args()
     global BATCH_PER_GPU, NUM_POINT
     stress = args.config == "stress"
@@ -204,6 +284,8 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(_spawn_ranks(args.gpus, sys.argv[1:]))  # nothing has touched the GPU in this process
+    if args.config == "infer":
+        return infer_main(args)
 
     import torch
     import torch.distributed as dist
@@ -256,7 +338,8 @@ def main():
     if use_dist:
         trainer.grads.exposed_ms()  # drop the warm-up samples
     # ~250 timed launches per step, two events each: created before the timed region, recorded inside it
-    gemm_names = ["gb_gemm_fwd", "gb_gemm_fwd_w", "gb_gemm_dgrad", "gb_gemm_dgrad_first", "gb_gemm_wgrad"]
+    gemm_names = ["gb_gemm_fwd", "gb_gemm_fwd_w", "gb_gemm_fwd_pool", "gb_gemm_dgrad", "gb_gemm_dgrad_first", "gb_gemm_wgrad",
+                  "gb_crop_bwd_dense", "gb_gemm_gram"]
     timer = _lib.KernelTimer(gemm_names + ["gb_fps", "gb_ball_query", "gb_cylinder_query_multi"],
                              reserve=min(2 * 270 * args.steps, 20000))
     barrier()
@@ -267,6 +350,18 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
     assert bool(torch.isfinite(loss)), "training diverged"
+    # the same step with the first-level FPS inline (no next batch announced): what a loop that cannot look ahead gets -
+    # and the like-for-like figure against round 1's line; outside the timed region, rank-local
+    no_prefetch_ms = None
+    if trainer.prefetch is not None and not use_dist:
+        k2 = max(2, min(5, args.steps))
+        trainer.train_step(batch)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            trainer.train_step(batch)
+        torch.cuda.synchronize()
+        no_prefetch_ms = round((time.perf_counter() - t1) / k2 * 1e3, 3)
     t = torch.tensor([elapsed, 1.0], dtype=torch.float64, device=device)
     ranks_seen = 1
     allreduce = None
@@ -278,6 +373,14 @@ def main():
         # nothing to hide under (after the timed region)
         allreduce = {"exposed_ms": trainer.grads.exposed_ms(), "standalone_ms": trainer.grads.standalone_ms(),
                      "buckets": len(trainer.grads.flat), "bytes": 4 * int(trainer.grads.flat_all.numel())}
+        # the replicas must hold the SAME parameters after the timed steps (identical averaged gradients, identical
+        # updates): an fp64 checksum and a bit-pattern checksum per rank, compared through MIN / MAX all-reduces
+        flat = torch.cat([p.detach().reshape(-1) for p in trainer.net.parameters()])
+        chk = torch.stack([flat.double().sum(), flat.view(torch.int32).double().sum()])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        allreduce["replicas_in_sync"] = bool(torch.equal(lo, hi))
     elapsed = float(t[0].item())
 
     if rank == 0:
@@ -347,7 +450,7 @@ def main():
         ball = [(a.elapsed_time(b) - ev_bias, m) for a, b, m in kt.events["gb_ball_query"] if m["n"] == NUM_POINT]
         if ball:
             ball_ms = sum(x for x, _ in ball) / len(ball)
-            m = ball[-1][1]
+            m = next(mm for _, mm in ball if "args" in mm)   # the first timed launch of the shape keeps its inputs
             new_xyz, xyz = m["args"]
             idx = torch.empty((m["b"], m["m"], m["ns"]), dtype=torch.int32, device=device)
             scanned = torch.empty((m["b"], m["m"]), dtype=torch.int32, device=device)
@@ -373,7 +476,7 @@ def main():
         cyl = [(a.elapsed_time(b) - ev_bias, m) for a, b, m in kt.events["gb_cylinder_query_multi"]]
         if cyl:
             cyl_ms = sum(x for x, _ in cyl) / len(cyl)
-            m = cyl[-1][1]
+            m = next(mm for _, mm in cyl if "args" in mm)
             new_xyz, xyz, rot9 = m["args"]
             # the fused kernel scans a centre until the slowest of its 16 lists is full: max of the 16 single counts
             worst = torch.zeros((m["b"], m["m"]), dtype=torch.int32, device=device)
@@ -414,10 +517,13 @@ def main():
             "roofline_fps_ball": roofline_fps_ball,
             "roofline_cyl": roofline_cyl,
             "ranks_seen": ranks_seen,
+            "prefetch_sampling": trainer.prefetch is not None,
+            "ms_per_step_no_prefetch": no_prefetch_ms,
         }
         if allreduce:
             out["allreduce_ms"] = round(allreduce["standalone_ms"], 4)
             out["allreduce_exposed_ms"] = round(allreduce["exposed_ms"], 4)
+            out["replicas_in_sync"] = allreduce["replicas_in_sync"]
             out["allreduce"] = {"buckets": allreduce["buckets"], "bytes": allreduce["bytes"],
                                 "note": "allreduce_ms = the step's bucket all-reduces back to back with nothing to hide "
                                         "under (median of 5 after the timed region); allreduce_exposed_ms = mean time per "

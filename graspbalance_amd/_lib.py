@@ -158,6 +158,7 @@ class KernelTimer:
         """reserve: events created up front (creating them inside the timed region is host time the step pays)."""
         self.names = set(names)
         self.events = {n: [] for n in names}
+        self.kept = set()
         self._pool = []
         if reserve:
             import torch
@@ -197,6 +198,15 @@ def timed(name, device, meta, launch):
     a.record(s)
     rc = launch()
     b.record(s)
+    if meta is not None and "args" in meta:
+        # tensor references (for bench.py's re-run of the query) are kept for the FIRST timed launch of a shape only:
+        # holding every launch's inputs for the whole timed region pins activations and changes what the caching
+        # allocator does under the measured steps
+        key = (name, meta.get("n"), meta.get("m"), meta.get("ns"))
+        if key in t.kept:
+            meta = {k: v for k, v in meta.items() if k != "args"}
+        else:
+            t.kept.add(key)
     t.events[name].append((a, b, meta))
     return rc
 

@@ -19,4 +19,3 @@ for mode in modes:
     torch.cuda.synchronize()
     print("%s B=%d N=%d: %.1f ms/step, loss %.4f, finite=%s, peak mem %.1f GB" % (mode, B, N, (time.perf_counter() - t0) / 4 * 1e3, float(loss.detach()), bool(torch.isfinite(loss)), torch.cuda.max_memory_allocated() / 1e9))
     del tr
-fused_mlp.set_precision("f32")

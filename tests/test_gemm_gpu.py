@@ -233,3 +233,89 @@ def test_fused_nodes_keep_their_forward_precision_in_backward():
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])     # dgrad: deterministic, same precision either way
     assert float((a[2] - b[2]).norm() / a[2].norm()) < 1e-5         # wgrad: fp32 atomics, same precision
     assert float((a[1] - f32[1]).norm() / f32[1].norm()) > 1e-4     # and it is not the fp32 result
+
+
+@pytest.mark.parametrize("P,D,with_rows,sizes", [
+    (16384 + 17, 4, 0, "mixed"),      # ragged last tile, seeds of 1 .. 256 rows
+    (20000, 4, 1, "mixed"),
+    (16400, 2, 0, "tiny"),            # up to 32 seeds inside one 32-row tile
+    (33000, 1, 1, "big"),             # every seed spans several tiles
+    (16384, 3, 0, "mixed"),
+])
+def test_pooled_gemm_epilogue_against_torch(P, D, with_rows, sizes):
+    """gb_gemm_fwd_pool + gb_pool_pairs on synthetic row sets (random seed sizes, random member bits, some crops of a
+    seed empty, negative BatchNorm weights, a ragged last tile) against plain torch: Y = relu(a*x+b) W^T, weighted
+    BatchNorm sums, per-(seed, crop, column) max of relu(a3*y+b3) over the member rows, y* and - with_rows - the arg
+    row (the lowest row among equal extremes)."""
+    import ctypes
+    L = _lib()
+    lib = L.lib()
+    K, N = 128, 256
+    g = torch.Generator().manual_seed(P + D)
+    lim = {"mixed": 256, "tiny": 3, "big": 200}[sizes]
+    lo = {"mixed": 1, "tiny": 1, "big": 90}[sizes]
+    cnt = []
+    while sum(cnt) < P:
+        cnt.append(int(torch.randint(lo, lim + 1, (1,), generator=g)))
+    cnt[-1] -= sum(cnt) - P
+    if cnt[-1] == 0:
+        cnt.pop()
+    R = len(cnt)
+    cnt_t = torch.tensor(cnt, dtype=torch.int32)
+    off = torch.cumsum(cnt_t.long(), 0) - cnt_t.long()
+    seed = torch.repeat_interleave(torch.arange(R), cnt_t.long())
+    mem = torch.randint(1, 1 << D, (P,), generator=g, dtype=torch.int32)
+    mem[off] |= 1                                              # crop 0 always has a member; other crops may be empty
+    mult = torch.randint(1, 257, (P,), generator=g, dtype=torch.int32)
+    pad = (P + 31) // 32 * 32
+    key = torch.zeros(pad, dtype=torch.int32)
+    key[:P] = (seed.int() << 13) | (mult << 4) | mem
+    X = torch.randn(P, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    aff = torch.cat([torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.3])
+    gamma = torch.randn(N, generator=g)
+    gamma[::5] = -gamma[::5].abs()
+    ab = torch.cat([gamma * (torch.rand(N, generator=g) + 0.5), torch.randn(N, generator=g) * 0.2, torch.zeros(2 * N)])
+    dev = lambda t: t.to(DEV).contiguous()
+    Xd, Wd, affd, keyd, gammad, abd, offd, cntd = map(dev, (X, W, aff, key, gamma, ab, off, cnt_t))
+    tiles = (P + 31) // 32
+    pairs = torch.full(((tiles + R) * D * N, 2 if with_rows else 1), float("nan"), device=DEV)
+    Y = torch.empty(P, N, device=DEV)
+    stats = torch.zeros(2 * N, dtype=torch.float64, device=DEV)
+    L.check(lib.gb_gemm_fwd_pool(L.ptr(Xd), L.ptr(Wd), L.ptr(affd), L.ptr(keyd), L.ptr(gammad), L.ptr(pairs), with_rows,
+                                 L.ptr(Y), L.ptr(stats), 1, P, K, N, D, None, None, None), "gb_gemm_fwd_pool")
+    out = torch.empty(R * D, N, device=DEV)
+    arg = torch.empty(R * D, N, dtype=torch.int32, device=DEV) if with_rows else None
+    ystar = torch.empty(R * D, N, device=DEV)
+    L.check(lib.gb_pool_pairs(L.ptr(pairs), L.ptr(offd), L.ptr(cntd), L.ptr(abd), L.ptr(gammad), L.ptr(out), L.ptr(arg),
+                              L.ptr(ystar), R, D, N, None), "gb_pool_pairs")
+    torch.cuda.synchronize()
+    A = torch.relu(aff[:K] * X + aff[K:]).double()
+    Yref = A @ W.double().t()
+    scale = float(Yref.abs().max())
+    assert float((Y.cpu().double() - Yref).abs().max()) < 2e-6 * scale
+    Yg = Y.cpu()                                                # sums and pooling are judged on the kernel's own fp32 y
+    w, y64 = mult.double().unsqueeze(1), Yg.double()
+    # per tile the kernel adds 16 weighted values in fp32 before going to fp64: error relative to the sum of magnitudes
+    assert bool(((stats[:N].cpu() - (w * y64).sum(0)).abs() <= 3e-7 * (w * y64.abs()).sum(0)).all())
+    assert torch.allclose(stats[N:].cpu(), (w * y64 * y64).sum(0), rtol=1e-6)
+    a3, b3 = ab[:N], ab[N:2 * N]
+    sg = torch.where(gamma < 0, -1.0, 1.0)
+    for d in range(D):
+        member = ((mem >> d) & 1).bool()
+        keyv = torch.where(member.unsqueeze(1), Yg * sg, torch.full_like(Yg, float("-inf")))
+        best = torch.full((R, N), float("-inf")).scatter_reduce_(0, seed.unsqueeze(1).expand(P, N), keyv, reduce="amax")
+        has = torch.isfinite(best)
+        want_y = torch.where(has, best * sg, torch.zeros_like(best))
+        want_out = torch.where(has, torch.relu(a3 * want_y + b3), torch.zeros_like(best))
+        got_y, got_out = ystar.cpu().view(R, D, N)[:, d], out.cpu().view(R, D, N)[:, d]
+        assert torch.equal(got_y, want_y), ("ystar", d)
+        assert torch.equal(got_out, want_out), ("out", d)
+        if with_rows:
+            rowidx = torch.arange(P).unsqueeze(1).expand(P, N)
+            hit = member.unsqueeze(1) & (Yg * sg == best[seed])
+            first = torch.full((R, N), P, dtype=torch.int64).scatter_reduce_(
+                0, seed.unsqueeze(1).expand(P, N), torch.where(hit, rowidx, torch.full_like(rowidx, P)), reduce="amin")
+            want_arg = torch.where(has, first, off.unsqueeze(1).expand(R, N))
+            assert torch.equal(arg.cpu().view(R, D, N)[:, d].long(), want_arg), ("arg", d)
+    assert int((~torch.isfinite(out)).sum()) == 0

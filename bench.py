@@ -102,11 +102,39 @@ def cpu_baseline(num_threads, device, repeats=5):
              (subsample, "pointnet2_cuda", subsample.pointnet2_cuda),
              (upsampling, "pointnet2_cuda", upsampling.pointnet2_cuda), (knn_modules, "knn", knn_modules.knn)]
     torch.set_num_threads(num_threads)
-    gpu_loss = float(Trainer(device).train_step(make_training_batch([0], NUM_POINT, device=device)))
+    gpu_trainer = Trainer(device)
+    probe = make_training_batch([0], NUM_POINT, device=device)['point_clouds']
+    keys = ('sa1_features', 'fp2_features', 'objectness_score', 'view_score', 'grasp_score_pred', 'grasp_width_pred')
+
+    def eval_forward(tr, clouds):   # same seed -> same initial weights on both sides; eval mode: no batch statistics
+        tr.net.eval()
+        tr.net.is_training = tr.net.view_estimator.is_training = tr.net.grasp_generator.is_training = False
+        try:
+            with torch.no_grad():
+                out = tr.net({'point_clouds': clouds})
+            return {k: out[k].detach().float().cpu() for k in keys}, out['grasp_top_view_inds'].cpu()
+        finally:
+            tr.net.train()
+            tr.net.is_training = tr.net.view_estimator.is_training = tr.net.grasp_generator.is_training = True
+    gpu_eval, gpu_views = eval_forward(gpu_trainer, probe)
+    gpu_loss = float(gpu_trainer.train_step(make_training_batch([0], NUM_POINT, device=device)).detach())
     try:
         cpu_backend.install()
         trainer = Trainer("cpu")
         trainer.net.grasp_generator.fused_cylinder = False  # the reference issues 16 separate queries
+        # tight cross-check before anything is timed: the eval-mode forward of the SAME network on the same cloud, HIP
+        # path vs this CPU path, tensor by tensor (the train-step loss below sits behind batch-statistic BatchNorms at
+        # B = 1 and top-view arg-max flips: it agrees to 3e-3 only, which would not catch a wrong term)
+        cpu_eval, cpu_views = eval_forward(trainer, probe.cpu())
+        same = (gpu_views == cpu_views).all(dim=1, keepdim=True)        # seeds whose top view agrees
+        agree_eval = {}
+        for k in keys:
+            a, b = gpu_eval[k].double(), cpu_eval[k].double()
+            agree_eval[k] = float((a - b).norm() / (b.norm() + 1e-30))
+        flips = int((gpu_views != cpu_views).sum())
+        stage1 = max(agree_eval[k] for k in ('sa1_features', 'fp2_features', 'objectness_score', 'view_score'))
+        assert stage1 < 1e-4, "CPU and HIP eval forwards disagree: %r" % agree_eval
+        assert flips > 0 or max(agree_eval.values()) < 1e-4, "CPU and HIP eval forwards disagree: %r" % agree_eval
         # the label generator is device-specific: build on the GPU's generator, move to the host
         batch = {k: ([[t.cpu() for t in per] for per in v] if isinstance(v, list) else v.cpu())
                  for k, v in make_training_batch([0], NUM_POINT, device=device).items()}
@@ -130,7 +158,9 @@ def cpu_baseline(num_threads, device, repeats=5):
             "sample": "train step (fwd+bwd+Adam) on 1 cloud of %d points: 1 warm-up + median of %d steps (%.2f s each), "
                       "oracle C geometry (OpenMP) + torch CPU MLPs" % (NUM_POINT, repeats, med),
             "cpu_model": _cpu_model(), "os_cpu_count": os.cpu_count(), "torch_threads": torch.get_num_threads(),
-            "first_step_loss": {"cpu": round(first, 6), "hip": round(gpu_loss, 6)}}
+            "first_step_loss": {"cpu": round(first, 6), "hip": round(gpu_loss, 6)},
+            "eval_forward_rel_l2_hip_vs_cpu": {k: float("%.2e" % v) for k, v in agree_eval.items()},
+            "eval_top_view_flips": flips}
 
 
 def cpu_baseline_dense(num_threads, device, repeats=5):

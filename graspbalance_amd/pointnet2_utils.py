@@ -13,6 +13,27 @@ from torch.autograd import Function
 from .pointnet2 import _ext  # HIP-backed; raises on CPU tensors like the reference extension
 
 
+class RandomDropout(nn.Module):
+    """API parity with pointnet2_utils.py:35-43.  The reference's forward calls
+    ``pt_utils.feature_dropout_no_scaling`` - a function its own pytorch_utils.py does not define (and hands it the
+    bound method ``self.train``), so calling the reference's module raises AttributeError; nothing in the reference
+    instantiates it.  Same constructor and state (none); forward draws theta ~ U(0, p) like the reference and then applies
+    what the missing helper does upstream (Pointnet2_PyTorch): feature dropout with rate theta WITHOUT rescaling, while
+    training."""
+
+    def __init__(self, p=0.5, inplace=False):
+        super().__init__()
+        self.p = p
+        self.inplace = inplace
+
+    def forward(self, X):
+        theta = torch.Tensor(1).uniform_(0, self.p)[0]
+        if not self.training:
+            return X
+        keep = (torch.rand(X.shape[:2] + (1,) * (X.dim() - 2), device=X.device) >= theta).to(X.dtype)
+        return X.mul_(keep) if self.inplace else X * keep
+
+
 class FurthestPointSampling(Function):
     @staticmethod
     def forward(ctx, xyz, npoint):

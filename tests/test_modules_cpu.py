@@ -143,3 +143,17 @@ def test_sa_module_backward_and_variants(cpu_ext):
     assert out.shape == (2, 5, 4)
     fp = pm.PointnetFPModule(mlp=[6, 4])
     assert fp(xyz.detach(), None, None, torch.randn(2, 6, 1)).shape == (2, 4, 9)
+
+
+def test_random_dropout_mirror():
+    """pointnet2_utils.RandomDropout (reference :35-43; dead code there: its helper does not exist): constructor parity,
+    identity in eval mode, whole channels dropped without rescaling in training mode."""
+    from graspbalance_amd import pointnet2_utils as pu
+    m = pu.RandomDropout(p=0.9)
+    assert m.p == 0.9 and m.inplace is False and list(m.state_dict()) == []
+    x = torch.rand(4, 64, 10) + 0.5
+    assert torch.equal(m.eval()(x), x)
+    torch.manual_seed(0)
+    y = m.train()(x)
+    kept = (y != 0).float().mean(dim=2)
+    assert bool(((kept == 0) | (kept == 1)).all()) and torch.equal(y[y != 0], x[y != 0])

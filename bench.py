@@ -371,12 +371,21 @@ def main():
     gemm_names = ["gb_gemm_fwd", "gb_gemm_fwd_w", "gb_gemm_fwd_pool", "gb_gemm_dgrad", "gb_gemm_dgrad_first", "gb_gemm_wgrad",
                   "gb_crop_bwd_dense", "gb_gemm_gram"]
     timer = _lib.KernelTimer(gemm_names + ["gb_fps", "gb_ball_query", "gb_cylinder_query_multi"],
-                             reserve=min(2 * 270 * args.steps, 20000))
+                             reserve=min(2 * 300 * (args.steps // 4 + 2), 20000))
     barrier()
+    # the HIP-event brackets cost the stream ~2 us per launch (measured: 1.2 ms per step with all ~270 launches of
+    # every step bracketed), so only every 4th timed step is bracketed (at least two): the launch durations are still
+    # taken live inside the timed region, on the launch stream, and the headline is not slowed by its own instrumentation
+    sample_every = 4 if args.steps >= 8 else max(1, args.steps // 2)
+    sampled = 0
     with timer as kt:
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for i in range(args.steps):
+            on = i % sample_every == 0
+            kt.sample(on)
+            sampled += on
             loss = trainer.train_step(batch, next_batch=batch)
+        kt.sample(True)
         barrier()
         elapsed = time.perf_counter() - t0
     assert bool(torch.isfinite(loss)), "training diverged"
@@ -438,13 +447,13 @@ def main():
                 return {"kernel": "%s (v_mfma_f32_32x32x16_bf16, fp32 operands in HBM; %s)" % (kernel, what), "bound": "hbm",
                         "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                         "traffic": None, "launch_ms": round(ms / len(ev), 4), "launches": len(ev),
-                        "ms_per_step": round(ms / args.steps, 3), "tflops": round(achieved, 1),
+                        "ms_per_step": round(ms / sampled, 3), "tflops": round(achieved, 1),
                         "mfma_bf16_frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4)}
             return {"kernel": "%s (v_mfma_f32_32x32x2_f32; %s)" % (kernel, what), "bound": "mfma",
                     "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic(kernel),
                     "launch_ms": round(ms / len(ev), 4), "launches": len(ev),
-                    "ms_per_step": round(ms / args.steps, 3), "gflop_per_launch": round(flop / len(ev) / 1e9, 3)}
+                    "ms_per_step": round(ms / sampled, 3), "gflop_per_launch": round(flop / len(ev) / 1e9, 3)}
 
         if stress:
             out_metric = "point-clouds/sec fwd+bwd, 50k-pt stress scene (BASELINE configs[4])"
@@ -542,6 +551,7 @@ def main():
             "roofline": roofline,
             "roofline_gemm2": roofline_second,
             "event_bias_us": round(ev_bias * 1e3, 2),
+            "event_sampled_steps": sampled,
             "roofline_fps": roofline_fps,
             "roofline_ball": roofline_ball,
             "roofline_fps_ball": roofline_fps_ball,

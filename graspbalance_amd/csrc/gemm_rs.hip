@@ -316,9 +316,8 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
         const bool full = tile * 32 + 32 <= g.P && g.C == C32;
         if constexpr (EPI == RS_STATS_POOL_V) {
           // As RS_STATS_POOL below, values only: per (seed in the tile, crop, column) max over the member rows of
-          // sign(gamma)*y.  Vector ALU only, no per-element masks in scalar registers: a member mask row of 0 / -inf is
-          // built once per (seed, crop) and shared by the NT column tiles, each element then costs one add and half a
-          // v_max3 (the form that also tracks the row - compare, two selects, mask logic through SGPR pairs - ran 3x the
+          // sign(gamma)*y.  The member predicates are formed once per (seed, crop) and shared by the NT column tiles; each
+          // element then costs one select and half a v_max3 (the form that also tracks the row - compare, two selects, mask logic through SGPR pairs - ran 3x the
           // tile's MFMA time).
           const long long trow = (long long)__builtin_amdgcn_readfirstlane((int)tile) * 32;
           const long long lastrow = trow + 31 < g.P ? trow + 31 : g.P - 1;
@@ -331,6 +330,10 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
           }
           const unsigned lane_off = (unsigned)(4 * h) * (unsigned)g.ldd + (unsigned)m;
           const int nrow = (int)(g.P - trow) - 4 * h;    // rows (r&3) + 8(r>>2) below this are valid
+          float *pv = reinterpret_cast<float *>(g.pairs);
+          // column tile by column tile: its 16 accumulators are dead afterwards, so the dynamic (seed, crop) loops run at
+          // the register pressure of ONE column tile (with all NT tiles live across them the allocator spilled > 100
+          // registers and the launch moved 0.8 GB of scratch through HBM)
 #pragma unroll
           for (int q = 0; q < NT; ++q) {
             if (!in(q)) continue;
@@ -344,10 +347,7 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
             }
             dsum[q] += (double)cs;
             dsq[q] += (double)cq;
-#ifndef GB_NOSTORE
-#define GB_NOSTORE 0
-#endif
-            if (!GB_NOSTORE && g.d) {  // keep Y for the backward (rows >= P are not stored)
+            if (g.d) {  // keep Y for the backward (rows >= P are not stored)
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
                 float *dp = g.d + (trow + (r & 3) + 8 * (r >> 2)) * (long long)g.ldd + q * 32;  // wave-uniform
@@ -355,34 +355,25 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
               }
             }
             const float sg = g.epi_gamma[q * 32 + m] < 0.f ? -1.f : 1.f;
+            float kv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[q][r] *= sg;   // in place: sign(gamma) * y
-          }
-          float *pv = reinterpret_cast<float *>(g.pairs);
-          for (int sd = s_lo; sd <= s_hi; ++sd) {
-            for (int d = 0; d < g.pool_d; ++d) {
-              float mv[16];
-#pragma unroll
-              for (int r = 0; r < 16; ++r) mv[r] = ((rk[r] >> 13) == sd && ((rk[r] >> d) & 1)) ? 0.f : -INFINITY;
-              float *dst = pv + ((size_t)(tile + sd) * g.pool_d + d) * C32 + m;
-#pragma unroll
-              for (int q = 0; q < NT; ++q) {
-                if (!in(q)) continue;
+            for (int r = 0; r < 16; ++r) { kv[r] = sg * acc[q][r]; acc[q][r] = 0.f; }   // sign(gamma) * y
+            for (int sd = s_lo; sd <= s_hi; ++sd) {
+              for (int d = 0; d < g.pool_d; ++d) {
+                // membership is the same for the 32 lanes of a tile half: scalar-register lane masks, one select per element
                 float best = -INFINITY;
 #pragma unroll
-                for (int r = 0; r < 16; r += 2)
-                  best = fmaxf(best, fmaxf(acc[q][r] + mv[r], acc[q][r + 1] + mv[r + 1]));
+                for (int r = 0; r < 16; r += 2) {
+                  const bool m0 = (rk[r] >> 13) == sd && ((rk[r] >> d) & 1);
+                  const bool m1 = (rk[r + 1] >> 13) == sd && ((rk[r + 1] >> d) & 1);
+                  best = fmaxf(best, fmaxf(m0 ? kv[r] : -INFINITY, m1 ? kv[r + 1] : -INFINITY));
+                }
                 const auto sb = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
                 best = fmaxf(best, __uint_as_float(h ? sb[0] : sb[1]));   // the other 16 rows sit in lane ^ 32
-                if (h == 0) dst[q * 32] = best;
-                __builtin_amdgcn_sched_barrier(0);   // one column tile at a time: interleaving all 8 chains spills
+                if (h == 0) pv[((size_t)(tile + sd) * g.pool_d + d) * C32 + q * 32 + m] = best;
               }
             }
           }
-#pragma unroll
-          for (int q = 0; q < NT; ++q)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
         } else
         if constexpr (EPI == RS_STATS_POOL) {
           // Y is NOT stored.  What leaves the tile: the weighted BatchNorm sums (as RS_STATS) and, per (seed in the

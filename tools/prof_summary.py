@@ -33,7 +33,10 @@ def main(path, steps=1.0, top=25):
     cats = {}
     for r in rows:
         cats[category(r["Name"])] = cats.get(category(r["Name"]), 0.0) + float(r["TotalDurationNs"])
-    print("total kernel time %.2f ms  (%.2f ms per step over %g steps)" % (total / 1e6, total / 1e6 / steps, steps))
+    print("WHOLE PROCESS, warm-up included (MIOpen find-mode trial kernels, lazy initialisation, the CPU-baseline legs' GPU "
+          "cross-checks): NOT the per-step picture - that is the steady-state file next to this one.")
+    print("total kernel time %.2f ms  (%.2f ms per timed step if it were spread over the %g timed steps)"
+          % (total / 1e6, total / 1e6 / steps, steps))
     for c, t in sorted(cats.items(), key=lambda kv: -kv[1]):
         print("  %-32s %8.2f ms/step  %5.1f%%" % (c, t / 1e6 / steps, 100 * t / total))
     print("%-62s %6s %10s %10s %6s" % ("kernel", "calls", "ms/step", "avg us", "%"))

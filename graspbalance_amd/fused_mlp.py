@@ -149,17 +149,24 @@ _FN = {}
 # taken from the arena may be kept across begin_step() - true for a forward -> backward -> optimizer step; code that
 # keeps several graphs alive simply does not call begin_step() and gets plain torch.zeros.
 _ARENA = {}
+_ARENA32_FLOATS = int(os.environ.get("GB_ZERO_ARENA_MB", "192")) << 18   # fp32 arena capacity (floats); 0 = plain torch.zeros
 
 
 def begin_step(device):
-    """Start a train step on `device`: re-zero what the previous step took from the fp64 arena and rewind it."""
+    """Start a train step on `device`: re-zero what the previous step took from the zero arenas and rewind them.
+    Two arenas: fp64 (BatchNorm sums, moments: ~85 small buffers per step) and fp32 (the atomic-add targets of a step:
+    weight-gradient arenas, scatter targets, per-point sums - ~45 buffers, ~100 MB: one fill instead of 45)."""
     ar = _ARENA.get(str(device))
     if ar is None:
         ar = _ARENA[str(device)] = {"buf": torch.zeros(1 << 20, dtype=torch.float64, device=device), "off": 0,
-                                     "live": True}
-    elif ar["off"]:
-        ar["buf"][:ar["off"]].zero_()
-    ar["off"], ar["live"] = 0, True
+                                     "buf32": torch.zeros(_ARENA32_FLOATS, dtype=torch.float32, device=device)
+                                     if _ARENA32_FLOATS else None, "off32": 0, "live": True}
+    else:
+        if ar["off"]:
+            ar["buf"][:ar["off"]].zero_()
+        if ar["off32"]:
+            ar["buf32"][:ar["off32"]].zero_()
+    ar["off"], ar["off32"], ar["live"] = 0, 0, True
 
 
 def end_arena(device):
@@ -178,6 +185,20 @@ def _zeros64(n, dev):
             ar["off"] = end
             return ar["buf"][off:off + n]
     return torch.zeros(n, dtype=torch.float64, device=dev)
+
+
+def _zeros32(n, dev):
+    """n zero floats (64-byte aligned) for this step: from the fp32 arena inside a Trainer step, torch.zeros otherwise.
+    Like everything taken from the arenas it must not outlive the step (gradients are consumed by the optimizer - and
+    dropped by zero_grad - before the next begin_step)."""
+    ar = _ARENA.get(str(dev))
+    if ar is not None and ar["live"] and ar["buf32"] is not None:
+        off = ar["off32"]
+        end = off + (n + 15) // 16 * 16
+        if end <= ar["buf32"].numel():
+            ar["off32"] = end
+            return ar["buf32"][off:off + n]
+    return torch.zeros(n, dtype=torch.float32, device=dev)
 
 
 def _size_args(args):
@@ -267,7 +288,7 @@ class GroupConcatCL(Function):
         if C > 0 and ctx.needs_input_grad[3]:
             (idx,) = ctx.saved_tensors
             dx0 = dx0.contiguous()
-            dfeat = torch.zeros((B, N, C), dtype=torch.float32, device=dx0.device)
+            dfeat = _zeros32(B * N * C, dx0.device).view(B, N, C)
             _call("gb_group_concat_cl_grad", dx0.device, _lib.ptr(dx0), _lib.ptr(idx), _lib.ptr(dfeat), B, N, m, ns,
                   C, _s(dx0))
         return None, None, None, dfeat, None, None, None
@@ -537,7 +558,7 @@ class MLPStack(Function):
         w_off = [0]
         for l in range(L):
             w_off.append(w_off[-1] + (widths[l] * kin[l] if need_w[l] else 0))
-        w_arena = torch.zeros(w_off[-1], dtype=torch.float32, device=dev) if w_off[-1] else None
+        w_arena = _zeros32(w_off[-1], dev) if w_off[-1] else None
         gb_arena = torch.empty(2 * sum(widths), dtype=torch.float32, device=dev)  # [dbeta, dgamma] per layer
         gb_off = [0]
         for n in widths:
@@ -570,7 +591,7 @@ class MLPStack(Function):
             rpart = torch.empty(nb * (2 * N + K) + 2 * N + K, dtype=torch.float64, device=dev)
             red = rpart[nb * (2 * N + K):]                                          # [dbeta, dgamma, sx] totals
             sx = red[2 * N:]
-            gmat = torch.zeros(K * K, dtype=torch.float32, device=dev)
+            gmat = _zeros32(K * K, dev)
             dZ = _empty_rows(P, K, dev, True)
             _call("gb_crop_bwd_sparse", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(ystar),
                   _lib.ptr(abs_[l]), _lib.ptr(y2), _lib.ptr(ab2), _lib.ptr(W), _lib.ptr(rows.w), _lib.ptr(rows.off),
@@ -778,7 +799,7 @@ class LocalGeometry:
         self.m, self.ns = self.idx.shape[1], self.idx.shape[2]
         self.mode, self.scale = int(mode), float(scale)
         dev = xyz.device
-        pts = torch.zeros(self.b * self.n * 4, dtype=torch.float32, device=dev)
+        pts = _zeros32(self.b * self.n * 4, dev)
         self.cnt, self.dsum = pts[:self.b * self.n], pts[self.b * self.n:]
         self.mom = _zeros64(12, dev)
         _call("gb_la_point_stats", dev, _lib.ptr(self.xyz), _lib.ptr(self.centres), _lib.ptr(self.idx), self.b, self.n,
@@ -845,7 +866,7 @@ class LocalAggPool(Function):
         N, C = Wf.shape
         rows, P = geo.b * geo.n, geo.rows
         # one zero fill for the two atomic-add targets: sg (rows, N) and, when the weight gradient is wanted, dWf (N, C)
-        zbuf = torch.zeros(rows * N + (N * C if ctx.needs_input_grad[1] else 0), dtype=torch.float32, device=dev)
+        zbuf = _zeros32(rows * N + (N * C if ctx.needs_input_grad[1] else 0), dev)
         sg = zbuf[:rows * N].view(rows, N)
         red = _zeros64(5 * N, dev)  # [dbeta, dgamma, T0, T1, T2]
         _call("gb_la_pool_bwd", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(G), _lib.ptr(geo.xyz),
@@ -1016,7 +1037,7 @@ class LinearBias(Function):
             _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dX), None, None, None, 0, P, K, N, None, None,
                   None, _opts(dev, st, ctx.prec), st, meta=_gemm_meta("dgrad", P, K, N))
         if ctx.needs_input_grad[1]:
-            dW = torch.zeros((N, K), dtype=torch.float32, device=dev)
+            dW = _zeros32(N * K, dev).view(N, K)
             _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(X), None, _lib.ptr(dW), P, K, N,
                   _opts(dev, st, ctx.prec), st, meta=_gemm_meta("wgrad", P, K, N))
         if ctx.has_bias and ctx.needs_input_grad[2]:

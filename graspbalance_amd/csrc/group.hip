@@ -418,7 +418,7 @@ __global__ __launch_bounds__(TPB) void label_gather_kernel(const LabelSrcTable s
     for (int e = threadIdx.x; e < V * w4; e += TPB) {
       const int v = e / w4, q = e % w4;
       const float4 x = reinterpret_cast<const float4 *>(src + (size_t)vi[v] * W)[q];
-      reinterpret_cast<float4 *>(dst)[e] = x;
+      if (out) reinterpret_cast<float4 *>(dst)[e] = x;
       if (dcol) {
         const float xv[4] = {x.x, x.y, x.z, x.w};
         if (col_stride == 3 && col_off == 2) {
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(TPB) void label_gather_kernel(const LabelSrcTable s
   } else {
     for (int e = threadIdx.x; e < V * W; e += TPB) {
       const float x = src[(size_t)vi[e / W] * W + e % W];
-      dst[e] = x;
+      if (out) dst[e] = x;
       if (dcol && (e % W) % col_stride == col_off) dcol[(size_t)(e / W) * wc + (e % W) / col_stride] = x;
       if (out_max) { mx = fmaxf(mx, x); nan |= x != x; }
     }
@@ -538,6 +538,80 @@ __global__ void label_finish_kernel(const float *__restrict__ labels, const floa
   }
 }
 
+// out[r, :] = srcs[obj[r]][pt[r], view_inds[obj[r], row_view[r]], :] - the label rows of ONE view per seed (the view the
+// network picked): what label_generation.py:138-157 takes out of the (B,Ns,V,...) tensors, without building them.
+__global__ __launch_bounds__(TPB) void label_gather_view_kernel(const LabelSrcTable srcs, const int32_t *__restrict__ obj,
+                                                                 const int32_t *__restrict__ pt,
+                                                                 const int64_t *__restrict__ view_inds,
+                                                                 const int64_t *__restrict__ row_view,
+                                                                 float *__restrict__ out, int R, int V, int W) {
+  const long long e = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (e >= (long long)R * W) return;
+  const int r = (int)(e / W), w = (int)(e % W);
+  const int o = obj[r];
+  const int64_t v = view_inds[(size_t)o * V + row_view[r]];
+  out[e] = srcs.p[o][((size_t)pt[r] * V + v) * W + w];
+}
+
+// label_finish_kernel reading the labels and the widths straight from the objects' label / offset tensors (two pointer
+// tables): view row (r, v) = seed r's labels of template view v.  Nothing but the per-view maxima and their
+// positions is written: the training step needs no more of the (B,Ns,V,A,D) tensors (the "lean" label matching).
+struct LabelSrcTable2 {
+  const float *lab[LG_MAX_SRC];
+  const float *off[LG_MAX_SRC];
+};
+__global__ void label_scores_kernel(const LabelSrcTable2 srcs, const int32_t *__restrict__ obj,
+                                    const int32_t *__restrict__ pt, const int64_t *__restrict__ view_inds,
+                                    const float *__restrict__ u_max, float max_width, float *__restrict__ view_scores,
+                                    int32_t *__restrict__ view_arg, long long rows, int V, int ad4) {
+  extern __shared__ float s_max[];  // [LF_ROWS][ad4] maxima, then [LF_ROWS][ad4] their positions (as int)
+  int *s_pos = reinterpret_cast<int *>(s_max + LF_ROWS * ad4);
+  const int rl = threadIdx.x / ad4, q = threadIdx.x % ad4;
+  const long long row = (long long)blockIdx.x * LF_ROWS + rl;
+  const float um = *u_max;
+  float best = -INFINITY;
+  int bpos = 4 * q;
+  if (row < rows) {
+    const int r = (int)(row / V), v = (int)(row % V);
+    const int o = obj[r];
+    const size_t at = ((size_t)pt[r] * V + (size_t)view_inds[(size_t)o * V + v]) * ad4 + q;  // group of 4 grasps
+    const float4 l = reinterpret_cast<const float4 *>(srcs.lab[o])[at];
+    const float4 o0 = reinterpret_cast<const float4 *>(srcs.off[o])[3 * at];
+    const float4 o1 = reinterpret_cast<const float4 *>(srcs.off[o])[3 * at + 1];
+    const float4 o2 = reinterpret_cast<const float4 *>(srcs.off[o])[3 * at + 2];
+    const float wv[4] = {o0.z, o1.y, o2.x, o2.w};
+    const float lv[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bool m = lv[t] > 0.f && wv[t] <= max_width;
+      const float c = lv[t] < 1e-30f ? 1e-30f : lv[t];
+      const float rr = m ? logf(um / c) : 0.f;
+      if (rr > best) bpos = 4 * q + t;
+      best = fmaxf(best, rr);
+      if (rr != rr) best = rr;
+    }
+  }
+  s_max[threadIdx.x] = best;
+  s_pos[threadIdx.x] = bpos;
+  __syncthreads();
+  if (threadIdx.x < LF_ROWS) {
+    const long long vr = (long long)blockIdx.x * LF_ROWS + threadIdx.x;
+    if (vr < rows) {
+      float b = -INFINITY;
+      int bp = 0;
+      bool nan = false;
+      for (int i = 0; i < ad4; ++i) {
+        const float v = s_max[threadIdx.x * ad4 + i];
+        nan |= v != v;
+        if (v > b) bp = s_pos[threadIdx.x * ad4 + i];
+        b = fmaxf(b, v);
+      }
+      view_scores[vr] = nan ? NAN : b;
+      if (view_arg) view_arg[vr] = bp;
+    }
+  }
+}
+
 }  // namespace gb
 
 using namespace gb;
@@ -562,7 +636,8 @@ extern "C" int gb_label_finish(const float *labels, const float *offsets, const 
 extern "C" int gb_label_gather(const float *const *srcs, int nsrc, const int32_t *obj, const int32_t *pt,
                                const int64_t *view_inds, float *out, float *out_max, float *out_col, int col_stride,
                                int col_off, int R, int V, int W, void *stream) {
-  if (R < 0 || V < 1 || W < 1 || nsrc < 1 || !srcs || !obj || !pt || !view_inds || !out) return GB_EINVAL;
+  if (R < 0 || V < 1 || W < 1 || nsrc < 1 || !srcs || !obj || !pt || !view_inds || (!out && !out_max && !out_col))
+    return GB_EINVAL;  // out may be NULL: only the maximum and / or the column copy are wanted
   if (nsrc > LG_MAX_SRC) return GB_ERANGE;
   if (out_col && (col_stride < 1 || col_off < 0 || col_off >= col_stride || W % col_stride != 0)) return GB_EINVAL;
   if (R == 0) return GB_OK;
@@ -571,6 +646,43 @@ extern "C" int gb_label_gather(const float *const *srcs, int nsrc, const int32_t
   hipLaunchKernelGGL(label_gather_kernel, dim3(R), dim3(TPB), 0, as_stream(stream), tab, obj, pt, view_inds, out,
                      out_max, out_col, col_stride, col_off, V, W);
   return check_launch("gb_label_gather");
+}
+
+extern "C" int gb_label_gather_view(const float *const *srcs, int nsrc, const int32_t *obj, const int32_t *pt,
+                                    const int64_t *view_inds, const int64_t *row_view, float *out, int R, int V, int W,
+                                    void *stream) {
+  if (R < 0 || V < 1 || W < 1 || nsrc < 1 || !srcs || !obj || !pt || !view_inds || !row_view || !out) return GB_EINVAL;
+  if (nsrc > LG_MAX_SRC) return GB_ERANGE;
+  if (R == 0) return GB_OK;
+  LabelSrcTable tab;
+  for (int i = 0; i < LG_MAX_SRC; ++i) tab.p[i] = i < nsrc ? srcs[i] : nullptr;
+  const long long total = (long long)R * W;
+  hipLaunchKernelGGL(label_gather_view_kernel, dim3((unsigned)((total + TPB - 1) / TPB)), dim3(TPB), 0, as_stream(stream),
+                     tab, obj, pt, view_inds, row_view, out, R, V, W);
+  return check_launch("gb_label_gather_view");
+}
+
+extern "C" int gb_label_scores(const float *const *label_srcs, const float *const *offset_srcs, int nsrc,
+                               const int32_t *obj, const int32_t *pt, const int64_t *view_inds, const float *u_max,
+                               float max_width, float *view_scores, int32_t *view_arg, int R, int V, int ad,
+                               void *stream) {
+  if (R < 0 || V < 1 || ad < 4 || ad % 4 != 0 || ad / 4 * LF_ROWS > 1024 || nsrc < 1 || !label_srcs || !offset_srcs ||
+      !obj || !pt || !view_inds || !u_max || !view_scores)
+    return GB_EINVAL;
+  if (nsrc > LG_MAX_SRC) return GB_ERANGE;
+  if (R == 0) return GB_OK;
+  LabelSrcTable2 tab;
+  for (int i = 0; i < LG_MAX_SRC; ++i) {
+    tab.lab[i] = i < nsrc ? label_srcs[i] : nullptr;
+    tab.off[i] = i < nsrc ? offset_srcs[i] : nullptr;
+    if (i < nsrc && (reinterpret_cast<uintptr_t>(tab.lab[i]) | reinterpret_cast<uintptr_t>(tab.off[i])) % 16) return GB_EINVAL;
+  }
+  const long long rows = (long long)R * V;
+  const int ad4 = ad / 4, threads = LF_ROWS * ad4;
+  hipLaunchKernelGGL(label_scores_kernel, dim3((unsigned)((rows + LF_ROWS - 1) / LF_ROWS)), dim3(threads),
+                     2 * threads * sizeof(float), as_stream(stream), tab, obj, pt, view_inds, u_max, max_width, view_scores,
+                     view_arg, rows, V, ad4);
+  return check_launch("gb_label_scores");
 }
 
 extern "C" int gb_gather(const float *points, const int32_t *idx, float *out, int b, int c, int n,

@@ -195,6 +195,9 @@ def _process_grasp_labels_fused(end_points):
     obj = torch.cat(obj_of_seed, 0).contiguous()
     pt = torch.cat(pt_of_seed, 0).contiguous()
     objl = obj.long()
+    if end_points.get(LEAN) and 'grasp_top_view_inds' in end_points:
+        return _lean_labels(end_points, labels_l, offsets_l, tol_l, obj, pt, view_inds, views_sel, rot_sel, objl,
+                            torch.stack(points, 0), B, Ns, V, A, D)
     label, label_max = _label_gather(labels_l, obj, pt, view_inds, V, A * D, want_max=True)
     offset, width = _label_gather(offsets_l, obj, pt, view_inds, V, A * D * 3, col=(3, 2))
     batch = {
@@ -208,6 +211,60 @@ def _process_grasp_labels_fused(end_points):
         'tolerance': _label_gather(tol_l, obj, pt, view_inds, V, A * D).view(B, Ns, V, A, D),
     }
     return _finish_labels(end_points, batch, B, Ns)
+
+
+LEAN = '_lean_labels'   # end_points flag (train.Trainer sets it): build only what a training step consumes
+
+
+def _table(tensors):
+    import ctypes
+    return ctypes.cast((ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors]), ctypes.c_void_p)
+
+
+def _lean_labels(end_points, labels_l, offsets_l, tol_l, obj, pt, view_inds, views_sel, rot_sel, objl, points, B, Ns, V,
+                 A, D):
+    """The training step's label matching without the (B,Ns,V,A,D[,3]) tensors (1.2 GB written and 2.3 GB moved per step
+    at B = 4, of which the step reads the per-view maxima and ONE view per seed): one read pass for the labels' maximum,
+    one for the view labels (gb_label_scores), then the rows of the view the network picked and of the seed's best view
+    (gb_label_gather_view).  Same values as the full path for every key a train step reads
+    (tests/test_model_gpu.py::test_lean_label_matching_equals_full); the *_all tensors are not produced."""
+    from . import _lib
+    dev = obj.device
+    R, AD = obj.numel(), A * D
+    lib = _lib.lib()
+    st = _lib.current_stream(dev)
+    lab_t, off_t, tol_t = _table(labels_l), _table(offsets_l), _table(tol_l)
+    u_max = torch.full((), float("-inf"), dtype=torch.float32, device=dev)
+    view_scores = torch.empty((B, Ns, V), dtype=torch.float32, device=dev)
+    view_arg = torch.empty((B, Ns, V), dtype=torch.int32, device=dev)
+    with _lib.device_ctx(dev):
+        _lib.check(lib.gb_label_gather(lab_t, len(labels_l), _lib.ptr(obj), _lib.ptr(pt), _lib.ptr(view_inds), None,
+                                       _lib.ptr(u_max), None, 1, 0, R, V, AD, st), "gb_label_gather (max)")
+        _lib.check(lib.gb_label_scores(lab_t, off_t, len(labels_l), _lib.ptr(obj), _lib.ptr(pt), _lib.ptr(view_inds),
+                                       _lib.ptr(u_max), float(GRASP_MAX_WIDTH), _lib.ptr(view_scores), _lib.ptr(view_arg),
+                                       R, V, AD, st), "gb_label_scores")
+        top = end_points['grasp_top_view_inds'].reshape(R).long().contiguous()
+        best_view = view_scores.view(R, V).argmax(dim=1)            # first maximum: with view_arg the flat arg-max of loss.py:31
+        rows = {}
+        for name, tab, n, W, rv in (("label", lab_t, len(labels_l), AD, top), ("offset", off_t, len(offsets_l), AD * 3, top),
+                                    ("tolerance", tol_t, len(tol_l), AD, top), ("best_offset", off_t, len(offsets_l), AD * 3, best_view)):
+            out = torch.empty((R, W), dtype=torch.float32, device=dev)
+            _lib.check(lib.gb_label_gather_view(tab, n, _lib.ptr(obj), _lib.ptr(pt), _lib.ptr(view_inds), _lib.ptr(rv),
+                                                _lib.ptr(out), R, V, W, st), "gb_label_gather_view")
+            rows[name] = out
+    raw, off = rows["label"], rows["offset"].view(R, AD, 3)
+    mask = (raw > 0) & (off[:, :, 2] <= GRASP_MAX_WIDTH)
+    top_label = torch.where(mask, torch.log(u_max / raw.clamp_min(1e-30)), torch.zeros_like(raw))
+    best_ad = torch.gather(view_arg.view(R, V), 1, best_view.unsqueeze(1)).long()                      # (R,1)
+    seed_width = torch.gather(rows["best_offset"].view(R, AD, 3)[:, :, 2], 1, best_ad).view(B, Ns)
+    end_points['batch_grasp_point'] = points
+    end_points['batch_grasp_view'] = torch.index_select(views_sel, 0, objl).view(B, Ns, V, 3)
+    end_points['batch_grasp_view_rot'] = torch.index_select(rot_sel, 0, objl).view(B, Ns, V, 3, 3)
+    end_points['batch_grasp_view_label'] = view_scores
+    end_points['_view_label_arg'] = view_arg
+    end_points['_lean'] = {'label': top_label.view(B, Ns, A, D), 'offset': off.view(B, Ns, A, D, 3),
+                           'tolerance': rows["tolerance"].view(B, Ns, A, D), 'seed_width': seed_width}
+    return end_points
 
 
 def _fusable(end_points):
@@ -277,6 +334,17 @@ def match_grasp_view_and_label(end_points):
     top_view_inds = end_points['grasp_top_view_inds']       # (B,Ns)
     template_views_rot = end_points['batch_grasp_view_rot']  # (B,Ns,V,3,3)
     template_views = end_points['batch_grasp_view']          # (B,Ns,V,3)
+    lean = end_points.get('_lean')
+    if lean is not None:   # the top view's rows were gathered straight from the objects' tensors (_lean_labels)
+        top_rot = _take_view(template_views_rot, top_view_inds)
+        end_points['batch_grasp_view_rot'] = top_rot
+        end_points['batch_grasp_view'] = _take_view(template_views, top_view_inds)
+        end_points['batch_grasp_view_all'] = template_views
+        end_points['batch_grasp_label'] = lean['label']
+        end_points['batch_grasp_offset'] = lean['offset']
+        end_points['batch_grasp_tolerance'] = lean['tolerance']
+        end_points['_seed_width'] = lean['seed_width']
+        return top_rot, lean['label'], lean['offset'], lean['tolerance'], end_points
     grasp_labels = end_points['batch_grasp_label']           # (B,Ns,V,A,D)
     grasp_offsets = end_points['batch_grasp_offset']         # (B,Ns,V,A,D,3)
     grasp_tolerance = end_points['batch_grasp_tolerance']    # (B,Ns,V,A,D)

@@ -57,6 +57,8 @@ _DEFAULT_PRIOR = ScalePrior.uniform()
 
 def generate_reweight_mask(end_points, prior=None):
     prior = prior or _DEFAULT_PRIOR
+    if '_seed_width' in end_points:   # lean label matching: the width at the seed's best label was gathered directly
+        return prior.lookup(end_points['_seed_width'])
     labels = end_points['batch_grasp_label_all']
     B, Ns = labels.shape[:2]
     best = torch.argmax(labels.reshape(B, Ns, -1), dim=2, keepdim=True)
@@ -76,11 +78,12 @@ def _seed_objectness(end_points):
 
 
 def _graspable_label(end_points, objectness_label):
-    labels = end_points['batch_grasp_label_all']
-    B, Ns, V = labels.shape[:3]
     per_view = end_points.get('batch_grasp_view_label')  # process_grasp_labels already took this max of `labels`
-    if per_view is None or end_points.get('_view_label_source') is not labels:
-        per_view = labels.view(B, Ns, V, -1).max(3)[0]
+    if '_seed_width' not in end_points:
+        labels = end_points['batch_grasp_label_all']
+        B, Ns, V = labels.shape[:3]
+        if per_view is None or end_points.get('_view_label_source') is not labels:
+            per_view = labels.view(B, Ns, V, -1).max(3)[0]
     graspable_cnt = torch.sum((per_view > THRESH_BAD).long(), dim=2)
     return (graspable_cnt > 10) * objectness_label
 
@@ -236,11 +239,16 @@ def _get_loss_fused(end_points, prior):
     """get_loss through _FusedGraspLoss: same keys, same values (masked means accumulated in fp64)."""
     f = lambda t: t.contiguous().float()
     view_label = f(end_points['batch_grasp_view_label'])
-    labels_all, view_arg = end_points['batch_grasp_label_all'], end_points.get('_view_label_arg')
-    offsets_all = end_points['batch_grasp_offset_all']
     extra = ()
     weight = None
-    if (view_arg is not None and end_points.get('_view_label_source') is labels_all and offsets_all.is_contiguous()
+    lean = '_seed_width' in end_points
+    labels_all = offsets_all = view_arg = None
+    if not lean:
+        labels_all, view_arg = end_points['batch_grasp_label_all'], end_points.get('_view_label_arg')
+        offsets_all = end_points['batch_grasp_offset_all']
+    if lean:
+        weight = f(generate_reweight_mask(end_points, prior))
+    elif (view_arg is not None and end_points.get('_view_label_source') is labels_all and offsets_all.is_contiguous()
             and offsets_all.dtype == torch.float32 and view_arg.shape == view_label.shape):
         # per-view maxima and their positions came out of gb_label_finish: the arg-max over all views of a seed, the
         # width gather and the prior lookup of generate_reweight_mask happen inside the loss kernel

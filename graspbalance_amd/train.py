@@ -12,6 +12,7 @@ from . import fused_mlp
 from .data_parallel import FlatGradAllReduce, broadcast_module
 from .flat_adam import FlatAdam
 from .graspbalance import GraspBalance
+from .label_generation import LEAN
 from .loss import get_loss
 from .pytorch_utils import BNMomentumScheduler
 
@@ -26,12 +27,14 @@ BN_MOMENTUM_MAX = 0.001
 class Trainer:
     def __init__(self, device, learning_rate=0.001, weight_decay=0.0, bn_decay_step=2, bn_decay_rate=0.5,
                  steps_per_epoch=100, max_epoch=18, num_view=300, seed=1234, distributed=False,
-                 bucket_mb=16.0, model=None, time_collectives=False, prefetch_sampling=True, mlp_precision=None):
+                 bucket_mb=16.0, model=None, time_collectives=False, prefetch_sampling=True, mlp_precision=None,
+                 lean_labels=True):
         torch.manual_seed(seed)
         self.device = torch.device(device)
         # 'bf16': BASELINE configs[4].  A property of THIS trainer: every step runs inside fused_mlp.precision(...), the
         # GEMM calls carry it (GbGemmOpts), so two trainers of one process may differ
         self.mlp_precision = mlp_precision if self.device.type == "cuda" else None
+        self.lean_labels = bool(lean_labels) and os.environ.get("GB_LEAN_LABELS", "1") != "0"  # A/B switch
         self.net = model if model is not None else GraspBalance(
             input_feature_dim=0, num_view=num_view, num_angle=12, num_depth=4, cylinder_radius=0.08,
             hmin=-0.02, hmax_list=[0.01, 0.02, 0.03, 0.04])
@@ -70,6 +73,8 @@ class Trainer:
         if self.device.type == "cuda":
             fused_mlp.begin_step(self.device)  # one re-zeroed arena for the step's small fp64 reduction buffers
         inputs = dict(batch)  # the network adds its outputs to the dict it is given
+        if self.lean_labels:
+            inputs[LEAN] = True  # label matching builds only what this step reads (label_generation._lean_labels)
         if self.prefetch is not None:
             from .prefetch import AFTER_SA1, KEY
             inds = self.prefetch.take(batch['point_clouds'])

@@ -170,7 +170,7 @@ int gb_knn1(const float *ref, const float *query, int64_t *idx, int b, int dim, 
  *   out[r, v, :] = srcs[obj[r]][pt[r], view_inds[obj[r], v], :]     (W floats per (point, view))
  * srcs: HOST array of nsrc (<= 128) device pointers, one (Np_o, V, W) tensor per object - the table travels in the
  * kernel arguments, so fresh label tensors every step cost neither a host-to-device copy nor a lookup cache;
- * obj/pt (R) int32; view_inds (n_objects, V) int64; out (R, V, W).  Composes the reference's two index_selects
+ * obj/pt (R) int32; view_inds (n_objects, V) int64; out (R, V, W), may be NULL when only out_max / out_col are wanted.  Composes the reference's two index_selects
  * (views then seeds) so only the kept rows are copied.  out_max (optional; one float, caller-initialised to
  * -inf) receives the maximum of everything gathered, NaN if any (the `.max()` of label_generation.py:113).
  * out_col (optional, (R, V, W / col_stride)): a contiguous copy of the columns w with w % col_stride == col_off -
@@ -178,6 +178,19 @@ int gb_knn1(const float *ref, const float *query, int64_t *idx, int b, int dim, 
 int gb_label_gather(const float *const *srcs, int nsrc, const int32_t *obj, const int32_t *pt,
                     const int64_t *view_inds, float *out, float *out_max, float *out_col, int col_stride,
                     int col_off, int R, int V, int W, void *stream);
+/* The "lean" label matching of a TRAINING step: of the (B,Ns,V,A,D[,3]) label / offset / tolerance tensors that
+ * label_generation.py:60-116 builds for every seed and all V template views (1.2 GB at B = 4), the step consumes the
+ * per-view maxima (view labels), the rows of ONE view per seed (the view the network picked, :138-157) and one width
+ * per seed (loss.py:29-42).  gb_label_gather with out = NULL gives the labels' maximum in one read pass;
+ *   gb_label_scores     : view_scores / view_arg (R*V) exactly as gb_label_finish, the labels and widths read straight
+ *                         from the objects' label (Np,V,ad) and offset (Np,V,ad,3) tensors (two host pointer tables)
+ *   gb_label_gather_view: out (R,W) = srcs[obj[r]][pt[r], view_inds[obj[r], row_view[r]], :]                      */
+int gb_label_scores(const float *const *label_srcs, const float *const *offset_srcs, int nsrc, const int32_t *obj,
+                    const int32_t *pt, const int64_t *view_inds, const float *u_max, float max_width,
+                    float *view_scores, int32_t *view_arg, int R, int V, int ad, void *stream);
+int gb_label_gather_view(const float *const *srcs, int nsrc, const int32_t *obj, const int32_t *pt,
+                         const int64_t *view_inds, const int64_t *row_view, float *out, int R, int V, int W,
+                         void *stream);
 /* ---- host data path on the GPU (reference data_utils.py:14-72, graspnet_dataset.py:110-136) ----
  * A depth frame becomes the network's input cloud without leaving the device: three passes over the H*W pixels.
  * depth: (H,W) uint16 (depth_is_u16 = 1) or float32; cam5 = HOST [fx, fy, cx, cy, scale] doubles (CameraInfo);

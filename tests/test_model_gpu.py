@@ -246,3 +246,40 @@ def test_sampling_prefetch_on_side_stream_equals_inline_sampling():
     loss = tr.train_step(a)
     assert seen['given'] is not None and bool(torch.isfinite(loss))
     _ = KEY
+
+
+def test_lean_label_matching_equals_full():
+    """The training step's lean label matching (label_generation._lean_labels: gb_label_gather max pass, gb_label_scores,
+    gb_label_gather_view - none of the (B,Ns,V,A,D[,3]) tensors is built) against the full path on the same network
+    outputs: every key the step reads - view labels and their positions, the picked view's labels / offsets / tolerance,
+    rotations, the loss with all its terms and the gradients w.r.t. the predictions."""
+    from graspbalance_amd import label_generation as lg
+    from graspbalance_amd.graspbalance import match_grasp_view_and_label
+    from graspbalance_amd.loss import get_loss
+    from tests.golden import make_golden_r2 as mk
+    res = {}
+    for lean in (False, True):
+        ep = mk.g12_inputs(DEV)
+        if lean:
+            ep[lg.LEAN] = True
+        assert lg._fusable(ep)
+        ep = lg.process_grasp_labels(ep)
+        assert ('_lean' in ep) == lean and ('batch_grasp_label' in ep) != lean
+        rot, labels, offsets, tol, ep = match_grasp_view_and_label(ep)
+        preds = {k: v.clone().requires_grad_(True) for k, v in mk.g13_predictions(DEV).items()}
+        ep.update(preds)
+        loss, ep = get_loss(ep)
+        loss.backward()
+        res[lean] = (ep, rot, labels, offsets, tol, {k: p.grad for k, p in preds.items()})
+    full, lean = res[False], res[True]
+    for k in ('batch_grasp_view_label', '_view_label_arg', 'batch_grasp_point', 'batch_grasp_view', 'batch_grasp_view_rot',
+              'batch_grasp_offset', 'batch_grasp_tolerance', 'graspable_mask'):
+        assert torch.equal(full[0][k], lean[0][k]), k
+    assert torch.equal(full[1], lean[1]) and torch.equal(full[3], lean[3]) and torch.equal(full[4], lean[4])
+    assert torch.allclose(full[2], lean[2], rtol=2e-7, atol=0) and float(lean[2].abs().max()) > 0   # log on two code paths
+    for k in full[0]:
+        if k.startswith('loss/') or 'acc' in k:
+            assert torch.allclose(full[0][k], lean[0][k], rtol=1e-6, atol=1e-7, equal_nan=True), k
+    for k, g in full[5].items():
+        assert torch.allclose(g, lean[5][k], rtol=1e-5, atol=1e-9), k
+    assert 'batch_grasp_label_all' not in lean[0] and 'batch_grasp_offset_all' in full[0]

@@ -84,6 +84,10 @@ SIGNATURES = {
     "gb_gemm_fwd_pool": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P],
     "gb_bn_bwd_apply_members_v": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _L, _I, _P, _P],
     "gb_pool_pairs": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "gb_bn_finalize_lin3": [_P, _P, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P],
+    "gb_gemm_fwd_gen3": [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P, _P],
+    "gb_gemm_wgrad_gen3": [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P],
+    "gb_gemm_dgrad_first_gen3": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P],
     "gb_crop_bwd_ok": [_I, _I, _I],
     "gb_crop_bwd_blocks": [_L],
     "gb_crop_bwd_sparse": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _I, _P, _P],

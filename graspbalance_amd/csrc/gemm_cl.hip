@@ -40,6 +40,8 @@ struct Operand {
   long long ld;
   const float *aff; // optional [a(red), b(red)]: value = relu(a_k * x + b_k)   (OP_KC only)
   const float *red_w; // optional (OP_RC only) [red]: the value is multiplied by red_w[reduction index] (after aff)
+  const float *gen_x; // optional (OP_RC only): src is not read - element (tile row r, reduction index k) = gen_x[k] . gen_w[r],
+  const float *gen_w; //   gen_x (red,3), gen_w (rows,3): the output of a 3-input first layer that was never stored (then aff)
 };
 
 // registers holding one thread's share (ROWS/16 floats... i.e. 4 or 8) of a ROWS x 16 operand tile
@@ -81,6 +83,15 @@ __device__ __forceinline__ void load_frag(const Operand &op, long long row0, lon
       const bool kok = k < op.red;
       f.ok[h] = kok;
       f.rw[h] = (op.red_w && kok) ? op.red_w[k] : 1.f;
+      if (op.gen_x) {
+        const float gx = kok ? op.gen_x[k * 3] : 0.f, gy = kok ? op.gen_x[k * 3 + 1] : 0.f, gz = kok ? op.gen_x[k * 3 + 2] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool rok = row + e < op.rows;
+          const float *wr = op.gen_w + (rok ? (row + e) * 3 : 0);
+          f.v[4 * h + e] = rok ? ((gx * wr[0]) + (gy * wr[1])) + (gz * wr[2]) : 0.f;  // == gemm_rs.hip's lin3
+        }
+      } else
       if (VEC && kok && row + 3 < op.rows) {
         const float4 q = *reinterpret_cast<const float4 *>(p);
         f.v[4 * h + 0] = q.x; f.v[4 * h + 1] = q.y; f.v[4 * h + 2] = q.z; f.v[4 * h + 3] = q.w;
@@ -547,7 +558,11 @@ extern "C" int gb_gemm_fwd_pool(const float *x, const float *w, const float *aff
     return GB_EINVAL;
   if (fin && (!fin->gamma || !fin->beta || !fin->ab || fin->P < 1 || fin->training != 1)) return GB_EINVAL;
   if (P > 0x7fffffffLL - 64) return GB_ERANGE;
-  const RsPool pool = {row_key, gamma, reinterpret_cast<float2 *>(pairs), D};
+  RsPool pool = {};
+  pool.key = row_key;
+  pool.gamma = gamma;
+  pool.pairs = reinterpret_cast<float2 *>(pairs);
+  pool.D = D;
   if (!with_rows && !y) return GB_EINVAL;  // values only: the arg-max row is later found by value in the stored Y
   if (!rs_gemm_try(x, w, y, aff, stats, stat_slots, nullptr, nullptr, P, K, N, 1, with_rows ? RS_STATS_POOL : RS_STATS_POOL_V,
                    as_stream(stream),
@@ -566,13 +581,57 @@ extern "C" int gb_crop_bwd_dense(const float *y2, const float *ab2, const float 
   if (P < 1 || K < 1 || !y2 || !ab2 || !mmat || !vvec || !row_w || !dz || !dstats || stat_slots < 1 || !dbeta || !dgamma ||
       opts_bad(opts) || reinterpret_cast<uintptr_t>(row_w) % 16)
     return GB_EINVAL;
-  RsPool lr = {nullptr, nullptr, nullptr, 0, vvec, row_w};
+  RsPool lr = {};
+  lr.lr_v = vvec;
+  lr.lr_roww = row_w;
   if (!rs_gemm_try(y2, mmat, dz, ab2, dstats, stat_slots, y2, ab2, P, K, K, 0, RS_BNBWD_LR, as_stream(stream),
                    opts_bf16(opts), opts_reserved(opts), nullptr, nullptr, &lr))
     return GB_EINVAL;
   const int rc = check_launch("gb_crop_bwd_dense");
   if (rc != GB_OK) return rc;
   return gb_bn_bwd_reduce(dstats, stat_slots, K, stat_slots > 1 ? dstats_total : nullptr, dbeta, dgamma, stream);
+}
+
+// ---- the 3-input first layer of a stack folded into its consumers (its output Y1 = x0 W1^T is never stored) ----------
+// gb_gemm_fwd_gen3: the SECOND layer's forward, Y (P,N) = relu(a1 * (x0 W1^T) + b1) W^T with BatchNorm sums (optionally
+// row-weighted), its operand formed in registers from x0 (P,3), W1 (K,3) and ab1 = [a1(K), b1(K)].  Row-streaming
+// kernel only: GB_EINVAL when the shape is not eligible (gb_gemm_uses_rs(P, K, N, 0, 1, 1), N <= 128).
+extern "C" int gb_gemm_fwd_gen3(const float *x0, const float *w1, const float *ab1, const float *w,
+                                const uint16_t *row_w16, float *y, double *stats, int stat_slots, long long P, int K,
+                                int N, const GbBnFinalize *fin, const GbGemmOpts *opts, void *stream) {
+  if (P < 1 || K < 1 || N < 1 || !x0 || !w1 || !ab1 || !w || !y || (stats && stat_slots < 1) || opts_bad(opts))
+    return GB_EINVAL;
+  if (fin && (!stats || !fin->gamma || !fin->beta || !fin->ab || fin->P < 1 || fin->training != 1)) return GB_EINVAL;
+  RsPool gen = {};
+  gen.gen_x = x0;
+  gen.gen_w = w1;
+  if (!stats) return GB_EINVAL;  // (the eval-mode caller passes a scratch sum buffer: the kernel always forms the sums)
+  if (!rs_gemm_try(nullptr, w, y, ab1, stats, stat_slots, nullptr, nullptr, P, K, N, 1, RS_STATS, as_stream(stream),
+                   opts_bf16(opts), opts_reserved(opts), nullptr, row_w16, &gen))
+    return GB_EINVAL;
+  return finalize_after(check_launch("gb_gemm_fwd_gen3"), fin, stats, stat_slots, N, stream);
+}
+
+// gb_gemm_wgrad_gen3: dW (N,K) += dY (P,N)^T relu(a1 * (x0 W1^T) + b1)  (gb_gemm_wgrad with the x operand generated)
+extern "C" int gb_gemm_wgrad_gen3(const float *dy, const float *x0, const float *w1, const float *ab1, float *dw,
+                                  long long P, int K, int N, const GbGemmOpts *opts, void *stream) {
+  if (P < 0 || K < 1 || N < 1 || !dy || !x0 || !w1 || !ab1 || !dw || opts_bad(opts)) return GB_EINVAL;
+  if (P == 0) return GB_OK;
+  Operand a = {dy, N, P, N, nullptr, nullptr, nullptr, nullptr};
+  Operand b = {nullptr, K, P, K, ab1, nullptr, x0, w1};
+  const long long tiles = (long long)((N + (N <= 64 ? 63 : 127)) / (N <= 64 ? 64 : 128)) *
+                          ((K + (K <= 64 ? 63 : 127)) / (K <= 64 ? 64 : 128));
+  long long chunks = 1024 / tiles;
+  if (chunks < 1) chunks = 1;
+  long long kchunk = (P + chunks - 1) / chunks;
+  kchunk = (kchunk + GK - 1) / GK * GK;
+  if (kchunk < 256) kchunk = 256;
+  chunks = (P + kchunk - 1) / kchunk;
+  if (chunks > 65535) return GB_ERANGE;
+  const bool va = (N % 4 == 0) && aligned16(dy);
+  launch_gemm<OP_RC, OP_RC, EPI_ATOMIC>(a, b, va, false, dw, K, nullptr, kchunk, (unsigned)chunks, as_stream(stream),
+                                        opts_bf16(opts));
+  return check_launch("gb_gemm_wgrad_gen3");
 }
 
 // dX (P,K) = dY (P,N) W(N,K)   with W in its natural (N,K) row-major layout (no transposed copy).
@@ -701,6 +760,22 @@ extern "C" int gb_gemm_dgrad_first(const float *dy, const float *w, const float 
                    opts_bf16(opts), opts_reserved(opts), x_in))
     return GB_EINVAL;
   return check_launch("gb_gemm_dgrad_first");
+}
+
+// gb_gemm_dgrad_first with the first layer's pre-BatchNorm output re-formed from x_in and its weight w_in (K,3) instead of
+// read from y_prev (the layer was folded into its consumers: gb_gemm_fwd_gen3)
+extern "C" int gb_gemm_dgrad_first_gen3(const float *dy, const float *w, const float *ab_prev, const float *x_in,
+                                        const float *w_in, double *sums, int slots, long long P, int K, int N,
+                                        const GbGemmOpts *opts, void *stream) {
+  if (P < 0 || K < 1 || N < 1 || !dy || !w || !ab_prev || !x_in || !w_in || !sums || slots < 1 || opts_bad(opts))
+    return GB_EINVAL;
+  if (P == 0) return GB_OK;
+  RsPool gen = {};
+  gen.gen_w = w_in;
+  if (!rs_gemm_try(dy, w, nullptr, nullptr, sums, slots, nullptr, ab_prev, P, N, K, 0, RS_BNBWD_X, as_stream(stream),
+                   opts_bf16(opts), opts_reserved(opts), x_in, nullptr, &gen))
+    return GB_EINVAL;
+  return check_launch("gb_gemm_dgrad_first_gen3");
 }
 
 // mom fp64 [12] += [sum_p w_p x (3), sum_p w_p x x^T (3x3)] of x (P,3), w = row_w or 1; caller-zeroed

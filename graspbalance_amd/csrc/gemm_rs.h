@@ -23,6 +23,8 @@ struct RsPool {
   const float *gamma;
   float2 *pairs;
   int D;
+  const float *gen_x = nullptr;    // RS_STATS: generate the A operand from these (P,3) rows (a = nullptr) / RS_BNBWD_X: y
+  const float *gen_w = nullptr;    // ... and this 3-input first-layer weight (R,3) / (C,3)
   const float *lr_v = nullptr;     // RS_BNBWD_LR: v (C)
   const float *lr_roww = nullptr;  // RS_BNBWD_LR: w (P rounded up to 32 readable floats)
 };

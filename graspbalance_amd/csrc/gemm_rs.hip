@@ -45,6 +45,8 @@ struct RsArgs {
                             // sits at the largest or the smallest y
   float2 *pairs;            // RS_STATS_POOL: [(tile + seed)][D][C] (sign*y, row bits) partial extrema, see pool_epilogue
   int pool_d;               // RS_STATS_POOL: crops per seed (1..4)
+  const float *gen_x;       // GEN3 / RS_BNBWD_X: (P,3) rows the A operand / the epilogue's y are generated from
+  const float *gen_w;       // ... with the 3-input first layer's weight (R,3) resp. (C,3): y1 = ((x*w0) + (y*w1)) + (z*w2)
   const float *lr_v;        // RS_BNBWD_LR: per-column offset v (C)
   const float *lr_roww;     // RS_BNBWD_LR: per-row weight w (readable up to a multiple of 32 rows)
   long long P;
@@ -57,7 +59,13 @@ struct RsArgs {
 
 // BF (GB_PREC_BF16): B lives in LDS as bf16 in [k / 8][C32][8] order - the 8 reduction indices one lane feeds to a
 // v_mfma_f32_32x32x16_bf16 are 16 contiguous bytes - and a lane's 16 fp32 values of A become two bf16x8 operands.
-template <int NT, int EPI, bool BF = false>
+// GEN3: the A operand is not read - it is relu(a_k * y1 + b_k) of a 3-input first layer, y1 = x0[row] . W1[k], formed in
+// registers from the row's 12 bytes (gen_x) and a per-k table in LDS: that layer's output is never written or read.
+__device__ __forceinline__ float lin3(float x, float y, float z, float w0, float w1, float w2) {
+  return ((x * w0) + (y * w1)) + (z * w2);   // the ONE evaluation order every consumer of the folded layer uses
+}
+
+template <int NT, int EPI, bool BF = false, bool GEN3 = false>
 __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_BNBWD_X && EPI != RS_BNBWD_LR) ? 4 : 2)) void gemm_rs_kernel(RsArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int C32 = NT * 32;
@@ -137,6 +145,9 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
       s_aff[i] = i < g.R ? g.aff[i] : 0.f;
       s_aff[rpad + i] = i < g.R ? g.aff[g.R + i] : 0.f;
     }
+  float *s_gen = s_aff + 2 * rpad;  // GEN3: [rpad][4] = (w0, w1, w2, 0) of reduction index k
+  if constexpr (GEN3)
+    for (int i = t; i < rpad * 4; i += RS_TPB) s_gen[i] = ((i & 3) < 3 && (i >> 2) < g.R) ? g.gen_w[(i >> 2) * 3 + (i & 3)] : 0.f;
   __syncthreads();
 
   const long long ntiles = (g.P + 31) / 32;
@@ -168,8 +179,24 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
     }
   }
 
+  // RS_BNBWD_X with gen_w: the layer's pre-BatchNorm output is not stored - y = x_in[row] . W1[col] is re-formed from the
+  // input rows the epilogue holds anyway (same lin3 as the forward's GEN3 operand)
+  float gx[EPI == RS_BNBWD_X ? NT : 1][3];
+  if constexpr (EPI == RS_BNBWD_X) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = j * 32 + m;
+#pragma unroll
+      for (int e = 0; e < 3; ++e) gx[j][e] = (g.gen_w && col < g.C) ? g.gen_w[col * 3 + e] : 0.f;
+    }
+  }
   auto load_chunk = [&](float4 (&dst)[4], long long tl, int kc) {
     const long long row = tl * 32 + m;
+    if constexpr (GEN3) {  // the row's xyz (an L1 hit after the tile's first chunk); the values are formed at use
+      const bool ok = row < g.P;
+      dst[0] = make_float4(ok ? g.gen_x[row * 3] : 0.f, ok ? g.gen_x[row * 3 + 1] : 0.f, ok ? g.gen_x[row * 3 + 2] : 0.f, 0.f);
+      return;
+    }
     const int k = kc * RS_CH + h * 16;
     const float *p = g.a + row * g.lda + k;
 #pragma unroll
@@ -227,8 +254,17 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
       if (more && !defer) load_chunk(nxt, ntile, nkc);
 
       float av[16];
+      if constexpr (GEN3) {
+        const float4 *gw = reinterpret_cast<const float4 *>(s_gen) + kc * RS_CH + h * 16;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float4 w = gw[i];
+          av[i] = lin3(cur[0].x, cur[0].y, cur[0].z, w.x, w.y, w.z);
+        }
+      } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) { av[4 * i] = cur[i].x; av[4 * i + 1] = cur[i].y; av[4 * i + 2] = cur[i].z; av[4 * i + 3] = cur[i].w; }
+      }
       if (g.aff) {  // previous layer's BatchNorm + ReLU; channels >= R have a = b = 0 and stay zero
         const float *ca = s_aff + kc * RS_CH + h * 16;
 #pragma unroll
@@ -261,7 +297,7 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
         }
       }
       if constexpr (YPRE) {
-        if (kc == g.nch - 1) {
+        if (kc == g.nch - 1 && !(EPI == RS_BNBWD_X && g.gen_w)) {
 #pragma unroll
           for (int q = 0; q < NT; ++q)
             if (in(q)) {
@@ -506,7 +542,10 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
                 }
               }
               if constexpr (BNB) {
-                const float y = YPRE ? yv[YPRE ? q : 0][r] : yq[r];
+                float y = YPRE ? yv[YPRE ? q : 0][r] : yq[r];
+                if constexpr (EPI == RS_BNBWD_X) {
+                  if (g.gen_w) y = lin3(xr[r][0], xr[r][1], xr[r][2], gx[q][0], gx[q][1], gx[q][2]);
+                }
                 const float gg = (ea[q] * y + eb[q]) > 0.f ? v : 0.f;
                 cs += gg;
                 cq += gg * ((y - em[q]) * er[q]);
@@ -563,7 +602,10 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
                 }
               }
               if constexpr (BNB) {
-                const float y = YPRE ? yv[YPRE ? q : 0][r] : yq[r];
+                float y = YPRE ? yv[YPRE ? q : 0][r] : yq[r];
+                if constexpr (EPI == RS_BNBWD_X) {
+                  if (g.gen_w) y = lin3(xr[r][0], xr[r][1], xr[r][2], gx[q][0], gx[q][1], gx[q][2]);
+                }
                 const float gg = (ea[q] * y + eb[q]) > 0.f ? v : 0.f;
                 cs += gg;
                 cq += gg * ((y - em[q]) * er[q]);
@@ -645,10 +687,10 @@ static int num_cus(int reserved) {
   return (reserved > 0 && n - reserved >= 16) ? n - reserved : n;
 }
 
-template <int NT, int EPI, bool BF>
+template <int NT, int EPI, bool BF, bool GEN3 = false>
 static void rs_launch_p(const RsArgs &g, size_t lds_bytes, int blocks_per_cu, hipStream_t s, int reserved) {
   static std::atomic<unsigned long long> attr_set{0};
-  auto kern = gemm_rs_kernel<NT, EPI, BF>;
+  auto kern = gemm_rs_kernel<NT, EPI, BF, GEN3>;
   allow_dynamic_lds(kern, 160 * 1024, attr_set);
   const long long ntiles = (g.P + 31) / 32;
   long long blocks = ntiles;  // at least one tile per workgroup; all 512 threads stage B either way
@@ -657,7 +699,7 @@ static void rs_launch_p(const RsArgs &g, size_t lds_bytes, int blocks_per_cu, hi
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(RS_TPB), lds_bytes, s, g);
 }
 
-template <int NT, int EPI>
+template <int NT, int EPI, bool GEN3 = false>
 static void rs_launch(const RsArgs &g, size_t lds_bytes, int blocks_per_cu, hipStream_t s, bool bf16, int reserved) {
   if (bf16) {
     // bf16 image of B = half the bytes (+ the affine table); never below what the closing column reduction
@@ -666,9 +708,9 @@ static void rs_launch(const RsArgs &g, size_t lds_bytes, int blocks_per_cu, hipS
     size_t need = lds_bytes - b_fp32 / 2;
     const size_t red = (size_t)RS_WAVES * (EPI == RS_BNBWD_X ? 5 : 2) * NT * 32 * sizeof(double);
     if (EPI != RS_STORE && need < red) need = red;
-    rs_launch_p<NT, EPI, true>(g, need, blocks_per_cu, s, reserved);
+    rs_launch_p<NT, EPI, true, GEN3>(g, need, blocks_per_cu, s, reserved);
   } else {
-    rs_launch_p<NT, EPI, false>(g, lds_bytes, blocks_per_cu, s, reserved);
+    rs_launch_p<NT, EPI, false, GEN3>(g, lds_bytes, blocks_per_cu, s, reserved);
   }
 }
 
@@ -705,8 +747,20 @@ bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, dou
   const int stagger = 1, tail_split = 1;  // both measured to help
   RsArgs g = {a, w, d, aff, stats, epi_y, epi_ab, epi_x, epi_w16, pool ? pool->key : nullptr,
               pool ? pool->gamma : nullptr, pool ? pool->pairs : nullptr, pool ? pool->D : 0,
+              pool ? pool->gen_x : nullptr, pool ? pool->gen_w : nullptr,
               pool ? pool->lr_v : nullptr, pool ? pool->lr_roww : nullptr, P, R, C, R, C, w_kc, slots < 1 ? 1 : slots, nch, stagger, tail_split};
+  const bool gen3 = pool && pool->gen_x && epi == RS_STATS;
+  if (gen3) {  // the A operand is generated from (P,3) rows and a per-k table: 16 more bytes of LDS per reduction index
+    if (!aff || !pool->gen_w || (nt != 2 && nt != 4)) return false;
+    lds_bytes += (size_t)nch * RS_CH * 4 * sizeof(float);
+    if (lds_bytes > 156 * 1024) return false;
+  }
   const int bpc = (nt <= 2 && epi != RS_BNBWD && epi != RS_BNBWD_X && epi != RS_BNBWD_LR && lds_bytes <= 78 * 1024) ? 2 : 1;
+  if (gen3) {
+    if (nt == 2) rs_launch<2, RS_STATS, true>(g, lds_bytes, bpc, s, bf16, reserved_cus);
+    else rs_launch<4, RS_STATS, true>(g, lds_bytes, bpc, s, bf16, reserved_cus);
+    return true;
+  }
   if (epi == RS_BNBWD_X) {
     // the closing per-column reduction reuses the LDS of B as [waves][5][64] doubles = 20 KB: more than the B image of
     // a reduction of <= 64 (16 KB).  (Round 1 launched with the B size only: for a 64 -> 64 second layer - SA1's

@@ -190,6 +190,22 @@ __global__ void bn_finalize_kernel(const double *__restrict__ stats, int slots, 
   ab[3 * C + c] = rstd;
 }
 
+// BatchNorm finalisation of a 3-input linear layer y = x W^T from the 12 moments of its input rows (gb_moments3: s = sum
+// w x, M = sum w x x^T over the batch): sum y_c = W_c . s, sum y_c^2 = W_c^T M W_c - the layer's output is never formed.
+__global__ void bn_finalize_lin3_kernel(const double *__restrict__ mom, const float *__restrict__ w, long long P, int C,
+                                        const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                        float momentum, float *__restrict__ running_mean,
+                                        float *__restrict__ running_var, float *__restrict__ ab) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double w0 = w[c * 3], w1 = w[c * 3 + 1], w2 = w[c * 3 + 2];
+  const double s1 = w0 * mom[0] + w1 * mom[1] + w2 * mom[2];
+  const double s2 = w0 * (w0 * mom[3] + w1 * mom[4] + w2 * mom[5]) + w1 * (w0 * mom[6] + w1 * mom[7] + w2 * mom[8]) +
+                    w2 * (w0 * mom[9] + w1 * mom[10] + w2 * mom[11]);
+  const BnFinalize f = {gamma, beta, running_mean, running_var, ab, P, eps, momentum, 1};
+  bn_finalize_column(f, s1, s2, c, C);
+}
+
 // dst: fp64 [slots][2C] partial BatchNorm-backward sums -> dstats fp64 [2C] (their total, the form
 // gb_bn_bwd_apply reads) and the parameter gradients dbeta = sum dA, dgamma = sum dA*xhat in fp32.
 __global__ void bn_bwd_reduce_kernel(const double *__restrict__ dst, int slots, int C, double *__restrict__ dstats,
@@ -806,6 +822,15 @@ extern "C" int gb_bn_finalize(const double *stats, int slots, long long P, int C
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), stats, slots, P, C, gamma,
                      beta, eps, momentum, running_mean, running_var, ab, training);
   return check_launch("gb_bn_finalize");
+}
+
+extern "C" int gb_bn_finalize_lin3(const double *mom, const float *w, long long P, int C, const float *gamma,
+                                   const float *beta, float eps, float momentum, float *running_mean,
+                                   float *running_var, float *ab, void *stream) {
+  if (C < 1 || P < 1 || !mom || !w || !gamma || !beta || !ab) return GB_EINVAL;
+  hipLaunchKernelGGL(bn_finalize_lin3_kernel, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), mom, w, P, C, gamma,
+                     beta, eps, momentum, running_mean, running_var, ab);
+  return check_launch("gb_bn_finalize_lin3");
 }
 
 extern "C" int gb_bn_bwd_reduce(const double *dst, int slots, int C, double *dstats, float *dbeta, float *dgamma,

@@ -28,6 +28,13 @@ _OWN_GEMM = True  # hand-written MFMA GEMMs (csrc/gemm_cl.hip); False = torch.mm
 
 
 _FIRST_FUSE = os.environ.get("GB_FIRST_FUSE", "1") != "0"  # A/B switch: closed-form backward of xyz-only first layers
+_FIRST_FOLD = os.environ.get("GB_FIRST_FOLD", "1") != "0"  # A/B switch: xyz-only first layers never stored (gen3 kernels)
+
+
+def set_first_fold(flag):
+    global _FIRST_FOLD
+    prev, _FIRST_FOLD = _FIRST_FOLD, bool(flag)
+    return prev
 _LOCAL_AGG = os.environ.get("GB_LOCAL_AGG", "1") != "0"  # A/B switch: 0 = grouped tensor + GEMM for LocalAggregation
 
 
@@ -442,13 +449,49 @@ class MLPStack(Function):
         ab_arena = torch.empty(4 * sum(widths), dtype=torch.float32, device=dev)
         Ws, Ys, abs_ = [], [], []
         src, aff, ab_off, pooled = X0, None, 0, None
+        # xyz-only first layer folded into its consumers (gb_gemm_fwd_gen3 & co.): its output is never stored - 256 bytes
+        # per row written once and read three times (second layer, its wgrad, the first layer's backward) become 12
+        fold = (_FIRST_FOLD and _FIRST_FUSE and X0.shape[1] == 3 and L >= 2 and not ctx.needs_input_grad[0]
+                and (ctx.needs_input_grad[6] or not any(ctx.needs_input_grad))   # its backward is the closed form
+                and widths[0] % 4 == 0 and widths[1] <= 128
+                and (L > 2 or not (rows is not None and rows.key is not None and _CROP_POOL))
+                and bool(_lib.lib().gb_gemm_uses_rs(P, widths[0], widths[1], 0, 1, 1))
+                and bool(_lib.lib().gb_gemm_uses_rs(P, widths[0], widths[1], 1, 2, 0)))
+        mom0 = None
         for l, cfg in enumerate(layers):
             W = params[3 * l].contiguous()
             gamma, beta = params[3 * l + 1], params[3 * l + 2]
-            K, N = src.shape[1], W.shape[0]
+            K, N = (src.shape[1] if src is not None else widths[l - 1]), W.shape[0]
             stats = stat_arena[stat_off[l]:stat_off[l + 1]] if cfg.training else None
             ab = ab_arena[ab_off:ab_off + 4 * N]
             ab_off += 4 * N
+            if fold and l == 0:
+                # BatchNorm of the folded layer from the 12 moments of its input rows (fp64): sum y = W s, sum y^2 = W M W^T
+                mom0 = _zeros64(12, dev)
+                _call("gb_moments3", dev, _lib.ptr(X0), _lib.ptr(rows.w if rows is not None else None), P, _lib.ptr(mom0),
+                      st)
+                if cfg.training:
+                    _call("gb_bn_finalize_lin3", dev, _lib.ptr(mom0), _lib.ptr(W), P_stat, N, _lib.ptr(gamma), _lib.ptr(beta),
+                          cfg.eps, cfg.momentum, _lib.ptr(cfg.running_mean), _lib.ptr(cfg.running_var), _lib.ptr(ab), st)
+                else:
+                    _call("gb_bn_finalize", dev, None, 1, P_stat, N, _lib.ptr(gamma), _lib.ptr(beta), cfg.eps, cfg.momentum,
+                          _lib.ptr(cfg.running_mean), _lib.ptr(cfg.running_var), _lib.ptr(ab), 0, st)
+                Ws.append(W); Ys.append(None); abs_.append(ab)
+                src, aff = None, ab
+                continue
+            if fold and l == 1:
+                Y = _empty_rows(P, N, dev, rows is not None)
+                fin = _bn_fin(cfg, gamma, beta, ab, P_stat) if cfg.training else None
+                st_buf, st_slots = (stats, slots) if cfg.training else (_zeros64(2 * N, dev), 1)
+                _call("gb_gemm_fwd_gen3", dev, _lib.ptr(X0), _lib.ptr(Ws[0]), _lib.ptr(aff), _lib.ptr(W),
+                      _lib.ptr(rows.w16 if rows is not None else None), _lib.ptr(Y), _lib.ptr(st_buf), st_slots, P, K, N,
+                      fin, opts, st, meta=_gemm_meta("fwd", P, K, N, True, True))
+                if fin is None:
+                    _call("gb_bn_finalize", dev, None, 1, P_stat, N, _lib.ptr(gamma), _lib.ptr(beta), cfg.eps, cfg.momentum,
+                          _lib.ptr(cfg.running_mean), _lib.ptr(cfg.running_var), _lib.ptr(ab), 0, st)
+                Ws.append(W); Ys.append(Y); abs_.append(ab)
+                src, aff = Y, ab
+                continue
             if (l == L - 1 and rows is not None and rows.key is not None and _CROP_POOL
                     and _lib.lib().gb_gemm_uses_rs(P, K, N, 0, 3, int(aff is not None))):
                 # the crop stack's last layer: BatchNorm sums and per-(tile, seed, crop) extrema leave the GEMM,
@@ -484,6 +527,8 @@ class MLPStack(Function):
         ctx.prec = prec
         ctx.pooled = rows is not None and Ys[-1] is None
         ctx.by_value = False
+        ctx.fold = fold
+        ctx.mom0 = mom0
         if pooled is not None:
             out, arg, ystar = pooled
             if Ys[-1] is None:
@@ -492,7 +537,7 @@ class MLPStack(Function):
                 ctx.save_for_backward(X0, out, ystar, ab_arena, *Ws, *Ys)
                 ctx.by_value = True
             if routing_observer is not None:
-                routing_observer("stack", Ys=Ys, abs=abs_, out=out, pool_ns=0, relu_last=True, rows=rows,
+                routing_observer("stack", Ys=_observed_ys(Ys, X0, Ws), abs=abs_, out=out, pool_ns=0, relu_last=True, rows=rows,
                                  arg=arg if arg is not None else _arg_rows_by_value(Ys[-1], ystar, rows))
             return out
         if rows is not None:
@@ -503,7 +548,7 @@ class MLPStack(Function):
                   _lib.ptr(rows.off), _lib.ptr(rows.cnt), _lib.ptr(out), _lib.ptr(arg), rows.R, rows.D, N, st)
             ctx.save_for_backward(X0, out, arg, ab_arena, *Ws, *Ys)
             if routing_observer is not None:
-                routing_observer("stack", Ys=Ys, abs=abs_, out=out, arg=arg, pool_ns=0, relu_last=True, rows=rows)
+                routing_observer("stack", Ys=_observed_ys(Ys, X0, Ws), abs=abs_, out=out, arg=arg, pool_ns=0, relu_last=True, rows=rows)
             return out
         if pool_ns:
             R = P // pool_ns
@@ -513,7 +558,7 @@ class MLPStack(Function):
                   pool_ns, N, st)
             ctx.save_for_backward(X0, out, arg, ab_arena, *Ws, *Ys)
             if routing_observer is not None:
-                routing_observer("stack", Ys=Ys, abs=abs_, out=out, arg=arg, pool_ns=int(pool_ns), relu_last=True, rows=None)
+                routing_observer("stack", Ys=_observed_ys(Ys, X0, Ws), abs=abs_, out=out, arg=arg, pool_ns=int(pool_ns), relu_last=True, rows=None)
             return out
         if residual is not None:
             residual = residual.contiguous()
@@ -523,7 +568,7 @@ class MLPStack(Function):
         ctx.save_for_backward(X0, residual if residual is not None else X0.new_empty(0), X0.new_empty(0), ab_arena,
                               *Ws, *Ys)
         if routing_observer is not None:
-            routing_observer("stack", Ys=Ys, abs=abs_, out=out, arg=None, pool_ns=0, relu_last=bool(relu_last), rows=None)
+            routing_observer("stack", Ys=_observed_ys(Ys, X0, Ws), abs=abs_, out=out, arg=None, pool_ns=0, relu_last=bool(relu_last), rows=None)
         return out
 
     @staticmethod
@@ -663,8 +708,12 @@ class MLPStack(Function):
             src, aff = (X0, None) if l == 0 else (Ys[l - 1], abs_[l - 1])
             if need_w[l]:
                 dW = w_arena[w_off[l]:w_off[l + 1]]
-                _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(src), _lib.ptr(aff), _lib.ptr(dW), P, K, N, opts, st,
-                      meta=_gemm_meta("wgrad", P, K, N, aff=aff is not None))
+                if ctx.fold and l == 1:   # the x operand relu(a*y1 + b) is re-formed from the xyz rows
+                    _call("gb_gemm_wgrad_gen3", dev, _lib.ptr(dY), _lib.ptr(X0), _lib.ptr(Ws[0]), _lib.ptr(aff), _lib.ptr(dW), P,
+                          K, N, opts, st, meta=_gemm_meta("wgrad", P, K, N, aff=True))
+                else:
+                    _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(src), _lib.ptr(aff), _lib.ptr(dW), P, K, N, opts, st,
+                          meta=_gemm_meta("wgrad", P, K, N, aff=aff is not None))
                 grads[3 * l] = dW.view(N, K)
             if l == 0:
                 if ctx.needs_input_grad[0]:
@@ -678,11 +727,17 @@ class MLPStack(Function):
                 # BatchNorm gradients and, with the 12 moments of the input rows, its weight gradient in closed form
                 z = _zeros64(slots * 5 * K + 3 * K + 12, dev)
                 sums, u0, mom = z[:slots * 5 * K], z[slots * 5 * K:slots * 5 * K + 3 * K], z[slots * 5 * K + 3 * K:]
-                _call("gb_gemm_dgrad_first", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(Ys[0]), _lib.ptr(abs_[0]),
-                      _lib.ptr(X0), _lib.ptr(sums), slots, P, K, N, opts, st,
-                      meta={"flop": 2.0 * P * K * N, "pkn": (P, K, N), "kernel": "gemm_rs_kernel"})
-                _call("gb_moments3", dev, _lib.ptr(X0), _lib.ptr(rows.w if rows is not None else None), P, _lib.ptr(mom),
-                      st)
+                if ctx.fold:
+                    _call("gb_gemm_dgrad_first_gen3", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(abs_[0]), _lib.ptr(X0),
+                          _lib.ptr(Ws[0]), _lib.ptr(sums), slots, P, K, N, opts, st,
+                          meta={"flop": 2.0 * P * K * N, "pkn": (P, K, N), "kernel": "gemm_rs_kernel"})
+                    mom = ctx.mom0   # the forward's moments of the same rows
+                else:
+                    _call("gb_gemm_dgrad_first", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(Ys[0]), _lib.ptr(abs_[0]),
+                          _lib.ptr(X0), _lib.ptr(sums), slots, P, K, N, opts, st,
+                          meta={"flop": 2.0 * P * K * N, "pkn": (P, K, N), "kernel": "gemm_rs_kernel"})
+                    _call("gb_moments3", dev, _lib.ptr(X0), _lib.ptr(rows.w if rows is not None else None), P,
+                          _lib.ptr(mom), st)
                 red = sums.view(slots, 5 * K).sum(0) if slots > 1 else sums
                 grads[1], grads[2] = param_grads(0, red, 1, None)
                 dW0 = torch.empty((K, 3), dtype=torch.float32, device=dev)
@@ -786,6 +841,15 @@ def _arg_rows_by_value(Y, ystar, rows):
         first.scatter_reduce_(0, seed.unsqueeze(1).expand(P, C), cand, reduce="amin")
         arg[:, d] = torch.where(first == big, rows.off.long().unsqueeze(1).expand(R, C), first)
     return arg.view(R * D, C).to(torch.int32)
+
+
+def _observed_ys(Ys, X0, Ws):
+    """routing_observer helper: the folded first layer's output, re-formed exactly as the kernels do."""
+    if Ys[0] is not None:
+        return Ys
+    W1 = Ws[0]
+    y1 = ((X0[:, 0:1] * W1[:, 0]) + (X0[:, 1:2] * W1[:, 1])) + (X0[:, 2:3] * W1[:, 2])
+    return [y1] + list(Ys[1:])
 
 
 class LocalGeometry:

@@ -503,6 +503,26 @@ int gb_gemm_uses_rs(long long P, int K, int N, int dgrad, int fused_stats, int h
  * ask gb_gemm_uses_rs(P, K, N, 1, 2, 0) first.                                                          */
 int gb_gemm_dgrad_first(const float *dy, const float *w, const float *y_prev, const float *ab_prev, const float *x_in,
                         double *sums, int slots, long long P, int K, int N, const GbGemmOpts *opts, void *stream);
+/* The xyz-only FIRST layer of a stack (3 -> K conv + BatchNorm + ReLU: pytorch_utils.py:61-113 under
+ * pointnet2_modules.py:148-188 / modules.py:104-124) folded into its consumers: its output Y1 = x0 W1^T (P,K) is never
+ * written or read - every consumer re-forms y1 = ((x*w0) + (y*w1)) + (z*w2) from the row's 12 bytes.
+ *   gb_bn_finalize_lin3      : the layer's BatchNorm table ab = [a,b,mean,rstd](K) and running statistics from the 12
+ *                              moments of x0 (gb_moments3): sum y = W1 s, sum y^2 = diag(W1 M W1^T), in fp64
+ *   gb_gemm_fwd_gen3         : the second layer, Y (P,N) = relu(a1*y1 + b1) W^T (+ BatchNorm sums, row weights as
+ *                              gb_gemm_fwd_w); ab1 = [a1(K), b1(K)]
+ *   gb_gemm_wgrad_gen3       : its weight gradient, dW (N,K) += dY^T relu(a1*y1 + b1)
+ *   gb_gemm_dgrad_first_gen3 : gb_gemm_dgrad_first with y_prev re-formed from x_in and w_in = W1
+ * All three GEMM forms: GB_EINVAL when the row-streaming kernel does not take the shape (ask gb_gemm_uses_rs).      */
+int gb_bn_finalize_lin3(const double *mom, const float *w, long long P, int C, const float *gamma, const float *beta,
+                        float eps, float momentum, float *running_mean, float *running_var, float *ab, void *stream);
+int gb_gemm_fwd_gen3(const float *x0, const float *w1, const float *ab1, const float *w, const uint16_t *row_w16,
+                     float *y, double *stats, int stat_slots, long long P, int K, int N, const GbBnFinalize *fin,
+                     const GbGemmOpts *opts, void *stream);
+int gb_gemm_wgrad_gen3(const float *dy, const float *x0, const float *w1, const float *ab1, float *dw, long long P,
+                       int K, int N, const GbGemmOpts *opts, void *stream);
+int gb_gemm_dgrad_first_gen3(const float *dy, const float *w, const float *ab_prev, const float *x_in,
+                             const float *w_in, double *sums, int slots, long long P, int K, int N,
+                             const GbGemmOpts *opts, void *stream);
 /* mom fp64 [12] (caller-zeroed) += [sum_p w_p x (3), sum_p w_p x x^T (3x3)] of x (P,3); w = row_w (P) or 1.   */
 int gb_moments3(const float *x, const float *row_w, long long P, double *mom, void *stream);
 

@@ -184,7 +184,10 @@ def test_local_aggregation_without_grouped_tensor(C, ns, train):
 def test_first_layer_closed_form_backward(train, widths):
     """xyz-only stacks (3 -> 64 -> ... [-> max]): the backward that never writes the first layer's dZ
     (gb_gemm_dgrad_first + moments + closed-form dW) against the layer-by-layer backward.  (64, 64, 128) is SA1's
-    stack: its 64 -> 64 second layer is the shape whose closing LDS reduction once overran the allocation.)"""
+    stack: its 64 -> 64 second layer is the shape whose closing LDS reduction once overran the allocation.)
+    Third variant, the default: the first layer FOLDED into its consumers (gb_bn_finalize_lin3, gb_gemm_fwd_gen3,
+    gb_gemm_wgrad_gen3, gb_gemm_dgrad_first_gen3) - its output is never stored; statistics come from the 12 moments of
+    the input rows, so the forward agrees to rounding instead of bit for bit."""
     import torch.nn as nn
     from graspbalance_amd import fused_mlp
     torch.manual_seed(3)
@@ -203,21 +206,27 @@ def test_first_layer_closed_form_backward(train, widths):
     mods.train(train)
     X0 = (torch.randn(P, 3, device=DEV) * torch.tensor([0.05, 0.02, 0.03], device=DEV) + 0.01).contiguous()
     res = {}
-    for flag in (True, False):
-        fused_mlp._FIRST_FUSE = flag
+    for name, (fuse, fold) in {"fold": (True, True), "fuse": (True, False), "plain": (False, False)}.items():
+        fused_mlp._FIRST_FUSE = fuse
+        prev = fused_mlp.set_first_fold(fold)
         try:
             m = copy.deepcopy(mods)
             out = fused_mlp.conv_bn_act_chain(X0, [(m[i], m[L + i]) for i in range(L)], pool_ns=ns)
             torch.manual_seed(8)
             (out * torch.randn(out.shape, device=out.device)).sum().backward()
-            res[flag] = (out.detach(), {k: v.grad.clone() for k, v in m.named_parameters()})
+            res[name] = (out.detach(), {k: v.grad.clone() for k, v in m.named_parameters()},
+                         m[L].running_mean.clone(), m[L].running_var.clone())
         finally:
             fused_mlp._FIRST_FUSE = True
-    a, b = res[True], res[False]
-    assert torch.equal(a[0], b[0])
+            fused_mlp.set_first_fold(prev)
+    b = res["plain"]
+    assert torch.equal(res["fuse"][0], b[0])
+    _close(res["fold"][0], b[0], 1e-5, "folded forward", True, 1e-3 * float(b[0].abs().max()))
+    assert torch.allclose(res["fold"][2], b[2], rtol=1e-5, atol=1e-8) and torch.allclose(res["fold"][3], b[3], rtol=1e-5)
     floor = 1e-2 * max(float(v.norm()) for v in b[1].values())
-    for k in b[1]:
-        _close(a[1][k], b[1][k], 2e-4, "grad " + k, True, floor)
+    for name in ("fuse", "fold"):
+        for k in b[1]:
+            _close(res[name][1][k], b[1][k], 2e-4, name + " grad " + k, True, floor)
 
 
 def test_cylinder_distinct_rows_against_torch_unique():

@@ -350,7 +350,9 @@ def main():
     from graspbalance_amd.train import Trainer
     _lib.lib()  # fail loudly if the HIP library is missing
 
-    trainer = Trainer(device, distributed=use_dist, time_collectives=use_dist, mlp_precision="bf16" if stress else "f32")
+    # GB_BENCH_PRECISION is a probe switch (what would the step cost with cheaper contractions); the default line is f32
+    prec = os.environ.get("GB_BENCH_PRECISION", "bf16" if stress else "f32")
+    trainer = Trainer(device, distributed=use_dist, time_collectives=use_dist, mlp_precision=prec)
     seeds = [1000 * rank + i for i in range(BATCH_PER_GPU)]
     batch = make_training_batch(seeds, NUM_POINT, device=device)
 
@@ -368,7 +370,8 @@ def main():
     if use_dist:
         trainer.grads.exposed_ms()  # drop the warm-up samples
     # ~250 timed launches per step, two events each: created before the timed region, recorded inside it
-    gemm_names = ["gb_gemm_fwd", "gb_gemm_fwd_w", "gb_gemm_fwd_pool", "gb_gemm_dgrad", "gb_gemm_dgrad_first", "gb_gemm_wgrad",
+    gemm_names = ["gb_gemm_fwd", "gb_gemm_fwd_w", "gb_gemm_fwd_pool", "gb_gemm_fwd_gen3", "gb_gemm_dgrad", "gb_gemm_dgrad_first",
+                  "gb_gemm_dgrad_first_gen3", "gb_gemm_wgrad", "gb_gemm_wgrad_gen3",
                   "gb_crop_bwd_dense", "gb_gemm_gram"]
     timer = _lib.KernelTimer(gemm_names + ["gb_fps", "gb_ball_query", "gb_cylinder_query_multi"],
                              reserve=min(2 * 300 * (args.steps // 4 + 2), 20000))
@@ -438,7 +441,7 @@ def main():
             ms = sum(t for t, _ in ev)
             flop = sum(f for _, f in ev)
             achieved = flop / (ms * 1e-3) / 1e12
-            if stress:
+            if prec == "bf16":
                 # bf16 matrix cores (2.5 PFLOP/s dense) with fp32 tensors in memory: the contraction is bound by
                 # reading X once and writing Y once - algorithmic bytes 4 (P K + P N + K N) per launch
                 byt = sum(4.0 * (m["pkn"][0] * (m["pkn"][1] + m["pkn"][2]) + m["pkn"][1] * m["pkn"][2])
@@ -540,7 +543,7 @@ def main():
             "metric": out_metric,
             "value": round(clouds / elapsed, 3), "unit": "point-clouds/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if stress else "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": prec,
             "data": "synthetic (make_scene clouds + seeded uniform grasp labels; no dataset available)" +
                     (" - REHEARSAL: all ranks on one GPU over gloo, not a measurement" if rehearsal else ""),
             "config": {"workload": "%s: GraspBalance train step fwd+bwd+Adam, B=%d/GPU, N=%d points, "

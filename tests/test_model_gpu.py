@@ -248,6 +248,27 @@ def test_sampling_prefetch_on_side_stream_equals_inline_sampling():
     _ = KEY
 
 
+def test_sampling_prefetch_keeps_its_xyz_copy_of_a_six_channel_cloud_alive():
+    """A (B,N,6) cloud (xyz + colour): the side stream samples a fresh contiguous copy of the coordinates.  While the
+    sampling is pending, the main stream allocates and overwrites same-sized blocks - had the copy been released when
+    launch() returned, the caching allocator would hand its block out here - and the indices must still be the inline
+    ones."""
+    from graspbalance_amd import pointnet2_utils as pu
+    from graspbalance_amd.prefetch import SamplingPrefetch
+    from graspbalance_amd.scene import make_scene
+    xyz = torch.stack([torch.as_tensor(make_scene(40 + i, 20000)) for i in range(2)]).float().to(DEV)
+    cloud6 = torch.cat([xyz, torch.rand_like(xyz)], dim=2).contiguous()
+    want = pu.furthest_point_sample(xyz.contiguous(), 2048)
+    pf = SamplingPrefetch(torch.device(DEV), 2048)
+    for _ in range(3):
+        pf.launch(cloud6)
+        junk = [torch.full((2, 20000, 3), float(k), device=DEV) for k in range(8)]   # same size as the xyz copy
+        inds = pf.take(cloud6)
+        torch.cuda.synchronize()
+        assert inds is not None and torch.equal(inds, want)
+        del junk
+
+
 def test_lean_label_matching_equals_full():
     """The training step's lean label matching (label_generation._lean_labels: gb_label_gather max pass, gb_label_scores,
     gb_label_gather_view - none of the (B,Ns,V,A,D[,3]) tensors is built) against the full path on the same network

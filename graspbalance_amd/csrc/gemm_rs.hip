@@ -367,9 +367,8 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
           const unsigned lane_off = (unsigned)(4 * h) * (unsigned)g.ldd + (unsigned)m;
           const int nrow = (int)(g.P - trow) - 4 * h;    // rows (r&3) + 8(r>>2) below this are valid
           float *pv = reinterpret_cast<float *>(g.pairs);
-          // column tile by column tile: its 16 accumulators are dead afterwards, so the dynamic (seed, crop) loops run at
-          // the register pressure of ONE column tile (with all NT tiles live across them the allocator spilled > 100
-          // registers and the launch moved 0.8 GB of scratch through HBM)
+          // Pass 1, column tile by column tile: weighted BatchNorm sums, the Y store, then the accumulators are turned
+          // into sign(gamma) * y IN PLACE (no second copy of the tile's 128 registers).
 #pragma unroll
           for (int q = 0; q < NT; ++q) {
             if (!in(q)) continue;
@@ -391,25 +390,36 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
               }
             }
             const float sg = g.epi_gamma[q * 32 + m] < 0.f ? -1.f : 1.f;
-            float kv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { kv[r] = sg * acc[q][r]; acc[q][r] = 0.f; }   // sign(gamma) * y
-            for (int sd = s_lo; sd <= s_hi; ++sd) {
-              for (int d = 0; d < g.pool_d; ++d) {
-                // membership is the same for the 32 lanes of a tile half: scalar-register lane masks, one select per element
+            for (int r = 0; r < 16; ++r) acc[q][r] *= sg;
+          }
+          // Pass 2, (seed, crop) outer: the 16 member predicates of a (seed, crop) are the same for every column tile -
+          // formed once (lane masks in scalar register pairs) and reused by the NT tiles, so an element costs one select
+          // and half a max; with the predicates re-formed per column tile the epilogue's vector ALU time was about half
+          // of the tile's MFMA time.
+          for (int sd = s_lo; sd <= s_hi; ++sd) {
+            for (int d = 0; d < g.pool_d; ++d) {
+              bool mem[16];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) mem[r] = (rk[r] >> 13) == sd && ((rk[r] >> d) & 1);
+              float *slot = pv + ((size_t)(tile + sd) * g.pool_d + d) * C32 + m;
+#pragma unroll
+              for (int q = 0; q < NT; ++q) {
+                if (!in(q)) continue;
                 float best = -INFINITY;
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                  const bool m0 = (rk[r] >> 13) == sd && ((rk[r] >> d) & 1);
-                  const bool m1 = (rk[r + 1] >> 13) == sd && ((rk[r + 1] >> d) & 1);
-                  best = fmaxf(best, fmaxf(m0 ? kv[r] : -INFINITY, m1 ? kv[r + 1] : -INFINITY));
-                }
+                for (int r = 0; r < 16; r += 2)
+                  best = fmaxf(best, fmaxf(mem[r] ? acc[q][r] : -INFINITY, mem[r + 1] ? acc[q][r + 1] : -INFINITY));
                 const auto sb = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
                 best = fmaxf(best, __uint_as_float(h ? sb[0] : sb[1]));   // the other 16 rows sit in lane ^ 32
-                if (h == 0) pv[((size_t)(tile + sd) * g.pool_d + d) * C32 + q * 32 + m] = best;
+                if (h == 0) slot[q * 32] = best;
               }
             }
           }
+#pragma unroll
+          for (int q = 0; q < NT; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
         } else
         if constexpr (EPI == RS_STATS_POOL) {
           // Y is NOT stored.  What leaves the tile: the weighted BatchNorm sums (as RS_STATS) and, per (seed in the

@@ -13,6 +13,7 @@ statistics), so state_dicts are unchanged; results equal the unfused path to fp3
 (which only works with an extension bound for CPU, i.e. in the tests).
 """
 import ctypes
+import weakref
 import os
 import threading
 
@@ -237,8 +238,32 @@ def _call(name, dev, *args, meta=None):
         _lib.check(_lib.timed(name, dev, meta, lambda: fn(*args)), name)
 
 
+_TRAIN_TICK = [0]   # bumped by every training-mode BatchNorm finalise: those write the running statistics through raw
+                    # pointers, which torch's version counters do not see
+_EVAL_AB = {}   # id(running_mean buffer) -> (weak reference to it, key, [a, b, mean, rstd] table)
+
+
+def _eval_ab(gamma, beta, running_mean, running_var, eps, N, dev, st):
+    """Eval mode: the layer's [a, b, mean, rstd] table depends on parameters and running statistics only, so it is
+    computed once (gb_bn_finalize without batch sums) and reused until one of them changes - an eval forward of the
+    network used to spend 73 launches per call on it.  Changes are seen through the tensors' version counters and
+    addresses (optimizer steps, load_state_dict, .to()) and through _TRAIN_TICK (this module's own training passes)."""
+    key = (gamma.data_ptr(), gamma._version, beta.data_ptr(), beta._version, running_mean.data_ptr(),
+           running_mean._version, running_var.data_ptr(), running_var._version, float(eps), _TRAIN_TICK[0])
+    slot = id(running_mean)   # (tensors compare element-wise: a dictionary keyed by the tensor itself would not do)
+    hit = _EVAL_AB.get(slot)
+    if hit is not None and hit[0]() is running_mean and hit[1] == key:
+        return hit[2]
+    ab = torch.empty(4 * N, dtype=torch.float32, device=dev)
+    _call("gb_bn_finalize", dev, None, 1, 1, N, _lib.ptr(gamma), _lib.ptr(beta), float(eps), 0.0, _lib.ptr(running_mean),
+          _lib.ptr(running_var), _lib.ptr(ab), 0, st)
+    _EVAL_AB[slot] = (weakref.ref(running_mean, lambda _, slot=slot: _EVAL_AB.pop(slot, None)), key, ab)
+    return ab
+
+
 def _bn_fin(cfg, gamma, beta, ab, P_stat):
     """ctypes GbBnFinalize of a layer, by reference."""
+    _TRAIN_TICK[0] += 1
     f = _lib.BnFinalize(gamma.data_ptr(), beta.data_ptr(),
                         cfg.running_mean.data_ptr() if cfg.running_mean is not None else None,
                         cfg.running_var.data_ptr() if cfg.running_var is not None else None, ab.data_ptr(), P_stat,
@@ -333,8 +358,12 @@ class LinearBNAct(Function):
             Y = torch.mm(X, W.t())
             if training:
                 _call("gb_col_stats", dev, _lib.ptr(Y), P, Cout, _lib.ptr(stats), None, _s(Y))
-        _call("gb_bn_finalize", dev, _lib.ptr(stats), slots, P, Cout, _lib.ptr(gamma), _lib.ptr(beta), float(eps),
-              float(momentum), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(ab), int(training), _s(Y))
+        if training:
+            _TRAIN_TICK[0] += 1
+            _call("gb_bn_finalize", dev, _lib.ptr(stats), slots, P, Cout, _lib.ptr(gamma), _lib.ptr(beta), float(eps),
+                  float(momentum), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(ab), 1, _s(Y))
+        else:
+            ab = _eval_ab(gamma, beta, running_mean, running_var, eps, Cout, dev, _s(Y))
         ctx.cfg = (P, Cout, bool(training), bool(relu), int(pool_ns))
         ctx.prec = _prec()
         if pool_ns:
@@ -467,15 +496,16 @@ class MLPStack(Function):
             ab_off += 4 * N
             if fold and l == 0:
                 # BatchNorm of the folded layer from the 12 moments of its input rows (fp64): sum y = W s, sum y^2 = W M W^T
-                mom0 = _zeros64(12, dev)
-                _call("gb_moments3", dev, _lib.ptr(X0), _lib.ptr(rows.w if rows is not None else None), P, _lib.ptr(mom0),
-                      st)
+                if cfg.training or any(ctx.needs_input_grad):   # (the backward's closed-form weight gradient reads them too)
+                    mom0 = _zeros64(12, dev)
+                    _call("gb_moments3", dev, _lib.ptr(X0), _lib.ptr(rows.w if rows is not None else None), P,
+                          _lib.ptr(mom0), st)
                 if cfg.training:
+                    _TRAIN_TICK[0] += 1
                     _call("gb_bn_finalize_lin3", dev, _lib.ptr(mom0), _lib.ptr(W), P_stat, N, _lib.ptr(gamma), _lib.ptr(beta),
                           cfg.eps, cfg.momentum, _lib.ptr(cfg.running_mean), _lib.ptr(cfg.running_var), _lib.ptr(ab), st)
                 else:
-                    _call("gb_bn_finalize", dev, None, 1, P_stat, N, _lib.ptr(gamma), _lib.ptr(beta), cfg.eps, cfg.momentum,
-                          _lib.ptr(cfg.running_mean), _lib.ptr(cfg.running_var), _lib.ptr(ab), 0, st)
+                    ab = _eval_ab(gamma, beta, cfg.running_mean, cfg.running_var, cfg.eps, N, dev, st)
                 Ws.append(W); Ys.append(None); abs_.append(ab)
                 src, aff = None, ab
                 continue
@@ -487,8 +517,7 @@ class MLPStack(Function):
                       _lib.ptr(rows.w16 if rows is not None else None), _lib.ptr(Y), _lib.ptr(st_buf), st_slots, P, K, N,
                       fin, opts, st, meta=_gemm_meta("fwd", P, K, N, True, True))
                 if fin is None:
-                    _call("gb_bn_finalize", dev, None, 1, P_stat, N, _lib.ptr(gamma), _lib.ptr(beta), cfg.eps, cfg.momentum,
-                          _lib.ptr(cfg.running_mean), _lib.ptr(cfg.running_var), _lib.ptr(ab), 0, st)
+                    ab = _eval_ab(gamma, beta, cfg.running_mean, cfg.running_var, cfg.eps, N, dev, st)
                 Ws.append(W); Ys.append(Y); abs_.append(ab)
                 src, aff = Y, ab
                 continue
@@ -500,6 +529,8 @@ class MLPStack(Function):
                 lowrank = (_CROP_LOWRANK and l >= 1 and _lib.lib().gb_crop_bwd_ok(K, N, rows.D)
                            and _lib.lib().gb_gemm_uses_rs(P, K, K, 1, 1, 1))
                 Y = None if lowrank else _empty_rows(P, N, dev, True)
+                if not cfg.training:
+                    ab = _eval_ab(gamma, beta, cfg.running_mean, cfg.running_var, cfg.eps, N, dev, st)
                 pooled = _pooled_last_layer(dev, st, opts, src, W, aff, gamma, beta, cfg, ab, stats, slots, rows, P, K, N,
                                             P_stat, Y)
                 Ws.append(W); Ys.append(Y); abs_.append(ab)
@@ -516,9 +547,7 @@ class MLPStack(Function):
                 _call("gb_gemm_fwd", dev, _lib.ptr(src), _lib.ptr(W), _lib.ptr(aff), _lib.ptr(Y), _lib.ptr(stats), slots,
                       P, K, N, fin, opts, st, meta=_gemm_meta("fwd", P, K, N, stats is not None, aff is not None))
             if fin is None:
-                _call("gb_bn_finalize", dev, _lib.ptr(stats), slots, P_stat, N, _lib.ptr(gamma), _lib.ptr(beta), cfg.eps,
-                      cfg.momentum, _lib.ptr(cfg.running_mean), _lib.ptr(cfg.running_var), _lib.ptr(ab),
-                      int(cfg.training), st)
+                ab = _eval_ab(gamma, beta, cfg.running_mean, cfg.running_var, cfg.eps, N, dev, st)
             Ws.append(W); Ys.append(Y); abs_.append(ab)
             src, aff = Y, ab  # ab[:2N] = [a, b] is exactly the next GEMM's prologue table
         N = widths[-1]
@@ -529,6 +558,10 @@ class MLPStack(Function):
         ctx.by_value = False
         ctx.fold = fold
         ctx.mom0 = mom0
+        if not all(c.training for c in layers):
+            # eval-mode layers use cached tables (_eval_ab), not slices of the arena: a backward through this node (rare:
+            # gradients in eval mode) reads the arena, so gather them once - and skip it when nothing needs a gradient
+            ab_arena = torch.cat(abs_) if any(ctx.needs_input_grad) else ab_arena
         if pooled is not None:
             out, arg, ystar = pooled
             if Ys[-1] is None:
@@ -813,9 +846,7 @@ def _pooled_last_layer(dev, st, opts, src, W, aff, gamma, beta, cfg, ab, stats, 
     _call("gb_gemm_fwd_pool", dev, _lib.ptr(src), _lib.ptr(W), _lib.ptr(aff), _lib.ptr(rows.key), _lib.ptr(gamma),
           _lib.ptr(pairs), int(with_rows), _lib.ptr(Y), _lib.ptr(stats), slots, P, K, N, rows.D, fin, opts, st,
           meta=_gemm_meta("fwd", P, K, N, True, aff is not None))
-    if fin is None:
-        _call("gb_bn_finalize", dev, None, 1, P_stat, N, _lib.ptr(gamma), _lib.ptr(beta), cfg.eps, cfg.momentum,
-              _lib.ptr(cfg.running_mean), _lib.ptr(cfg.running_var), _lib.ptr(ab), 0, st)
+    # eval: `ab` is the caller's cached table (_eval_ab)
     out = torch.empty((RD, N), dtype=torch.float32, device=dev)
     arg = torch.empty((RD, N), dtype=torch.int32, device=dev) if with_rows else None
     ystar = torch.empty((RD, N), dtype=torch.float32, device=dev)
@@ -907,8 +938,7 @@ class LocalAggPool(Function):
                   _lib.ptr(geo.mom), rows, N, _lib.ptr(stats), _lib.ptr(u),
                   _bn_fin(cfg, gamma, beta, ab, P), st)
         else:
-            _call("gb_bn_finalize", dev, _lib.ptr(stats), 1, P, N, _lib.ptr(gamma), _lib.ptr(beta), cfg.eps,
-                  cfg.momentum, _lib.ptr(cfg.running_mean), _lib.ptr(cfg.running_var), _lib.ptr(ab), 0, st)
+            ab = _eval_ab(gamma, beta, cfg.running_mean, cfg.running_var, cfg.eps, N, dev, st)
         R = geo.b * geo.m
         out = torch.empty((R, N), dtype=torch.float32, device=dev)
         arg = torch.empty((R, N), dtype=torch.int32, device=dev)

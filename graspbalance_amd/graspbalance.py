@@ -160,7 +160,55 @@ class GraspBalance(nn.Module):
 
 
 def pred_decode(end_points):
-    """Per cloud (Ng,17) grasps: score, width, height, depth, rotation (9), centre (3), object id."""
+    """Per cloud (Ng,17) grasps: score, width, height, depth, rotation (9), centre (3), object id
+    (graspbalance.py:139-192).  Same element-wise arithmetic as the reference's per-cloud loop, on the whole batch at
+    once; the objectness mask is read back ONCE (B x Ns booleans) and the kept seeds of all clouds are gathered by index -
+    the loop's 7 x B masked selections were 28 synchronisations and ~140 launches of an inference call."""
+    objectness_score = end_points['objectness_score'].float()          # (B,2,Ns)
+    grasp_score = end_points['grasp_score_pred'].float()               # (B,A,Ns,D)
+    B, Ns = objectness_score.shape[0], objectness_score.shape[2]
+    grasp_center = end_points['fp2_xyz'].float()
+    approaching = -end_points['grasp_top_view_xyz'].float()
+    grasp_width = torch.clamp(1.2 * end_points['grasp_width_pred'], min=0, max=GRASP_MAX_WIDTH)
+    grasp_tolerance = end_points['grasp_tolerance_pred']
+    # best in-plane angle per (seed, depth), then best depth per seed
+    angle_cls = torch.argmax(end_points['grasp_angle_cls_pred'], 1)    # (B,Ns,D)
+    grasp_angle = angle_cls.float() / 12 * np.pi
+    pick_a = angle_cls.unsqueeze(1)
+    grasp_score = torch.gather(grasp_score, 1, pick_a).squeeze(1)
+    grasp_width = torch.gather(grasp_width, 1, pick_a).squeeze(1)
+    grasp_tolerance = torch.gather(grasp_tolerance, 1, pick_a).squeeze(1)
+    pick_d = torch.argmax(grasp_score, 2, keepdims=True)               # (B,Ns,1)
+    grasp_depth = (pick_d.float() + 1) * 0.01
+    grasp_score = torch.gather(grasp_score, 2, pick_d)
+    grasp_angle = torch.gather(grasp_angle, 2, pick_d)
+    grasp_width = torch.gather(grasp_width, 2, pick_d)
+    grasp_tolerance = torch.gather(grasp_tolerance, 2, pick_d)
+    keep = torch.argmax(objectness_score, 1) == 1                      # (B,Ns)
+    graspable_confident = torch.softmax(objectness_score, dim=1)[:, 1, :].unsqueeze(2)
+    grasp_score = grasp_score * graspable_confident
+    keep_host = keep.cpu()                                             # the one synchronisation
+    counts = keep_host.sum(1).tolist()
+    idx = keep_host.reshape(-1).nonzero().squeeze(1).to(keep.device, non_blocking=True)
+
+    def sel(t):
+        return t.reshape(B * Ns, -1).index_select(0, idx)
+    grasp_score, grasp_width, grasp_depth = sel(grasp_score), sel(grasp_width), sel(grasp_depth)
+    approaching, grasp_angle = sel(approaching), sel(grasp_angle)
+    grasp_center, grasp_tolerance = sel(grasp_center), sel(grasp_tolerance)
+    grasp_score = grasp_score * grasp_tolerance / GRASP_MAX_TOLERANCE
+    Ng = grasp_angle.size(0)
+    rotation_matrix = batch_viewpoint_params_to_matrix(approaching.view(Ng, 3), grasp_angle.view(Ng)).view(Ng, 9)
+    grasp_height = 0.02 * torch.ones_like(grasp_score)
+    obj_ids = -1 * torch.ones_like(grasp_score)
+    preds = torch.cat([grasp_score, grasp_width, grasp_height, grasp_depth, rotation_matrix, grasp_center, obj_ids],
+                      axis=-1)
+    return list(torch.split(preds, counts, 0))
+
+
+def _pred_decode_loop(end_points):
+    """The reference's composition (graspbalance.py:139-192), cloud by cloud: seven boolean-mask selections per cloud, each a
+    device -> host synchronisation.  Kept as the checker of pred_decode."""
     grasp_preds = []
     for i in range(len(end_points['point_clouds'])):
         objectness_score = end_points['objectness_score'][i].float()

@@ -137,6 +137,49 @@ def test_eval_mode_uses_running_statistics():
         assert torch.equal(v, before[k]), "eval must not touch " + k
 
 
+def test_eval_affine_tables_are_cached_and_follow_every_change():
+    """Eval mode: a layer's [a, b, mean, rstd] table is computed once and reused (fused_mlp._eval_ab) until its
+    parameters or running statistics change.  Every way they change in this code base must invalidate it: an optimizer
+    step (in place), load_state_dict (in place), a training pass of the fused path itself (running statistics written
+    by the kernels through raw pointers) - each time the fused eval forward must equal the plain composition again."""
+    from graspbalance_amd import _lib, fused_mlp, pointnet2_modules as pm
+    from graspbalance_amd.scene import make_batch
+    torch.manual_seed(7)
+    sa = pm.PointnetSAModuleVotes(npoint=256, radius=0.1, nsample=16, mlp=[0, 16, 32], use_xyz=True,
+                                  normalize_xyz=True).to(DEV)
+    xyz = torch.from_numpy(make_batch([3], 2048)).to(DEV)
+
+    def check(what):
+        sa.eval()
+        with torch.no_grad():
+            a = sa(xyz)[1]
+            fused_mlp.set_enabled(False)
+            try:
+                b = sa(xyz)[1]
+            finally:
+                fused_mlp.set_enabled(True)
+        _close(a, b, 1e-5, what)
+
+    sa.train(); sa(xyz)
+    check("first eval")
+    with _lib.KernelTimer(["gb_bn_finalize", "gb_bn_finalize_lin3"]) as kt:   # a second eval forward launches no finalise
+        sa.eval()
+        with torch.no_grad():
+            sa(xyz)
+    torch.cuda.synchronize()
+    assert not kt.events["gb_bn_finalize"] and not kt.events["gb_bn_finalize_lin3"]
+    opt = torch.optim.SGD(sa.parameters(), lr=0.5)
+    sa.train(); sa(xyz)[1].square().mean().backward(); opt.step()
+    check("after an optimizer step")
+    sa.train()
+    for _ in range(2):
+        sa(xyz)                                    # running statistics move, parameters do not
+    check("after training passes")
+    state = {k: (v * 1.5 if v.dtype.is_floating_point else v) for k, v in sa.state_dict().items()}
+    sa.load_state_dict(state)
+    check("after load_state_dict")
+
+
 @pytest.mark.parametrize("C,ns,train", [(32, 16, True), (64, 24, True), (32, 16, False)])
 def test_local_aggregation_without_grouped_tensor(C, ns, train):
     """LocalAggPool (conv commuted with the gather, csrc/local_agg.hip) against the grouped-tensor execution of

@@ -78,6 +78,10 @@ def test_pred_decode_matches_reference(golden):
     preds = pred_decode(mk.g14_inputs())
     for i, p in enumerate(preds):
         check_summary(g14, "cloud%d" % i, p, 1e-6)
+    # the batched formulation vs the reference's cloud-by-cloud composition: the same bits
+    from graspbalance_amd.graspbalance import _pred_decode_loop
+    loop = _pred_decode_loop(mk.g14_inputs())
+    assert len(loop) == len(preds) and all(torch.equal(a, b) for a, b in zip(loop, preds))
 
 
 def test_backbone_matches_reference(cpu, golden):

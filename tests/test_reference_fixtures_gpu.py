@@ -51,8 +51,13 @@ def test_pred_decode_matches_reference_gpu(golden):
     from graspbalance_amd.graspbalance import pred_decode
     from tests.seeded import check_summary
     g14 = golden.load("g14_pred_decode")
-    for i, p in enumerate(pred_decode(mk.g14_inputs(DEV))):
+    preds = pred_decode(mk.g14_inputs(DEV))
+    for i, p in enumerate(preds):
         check_summary(g14, "cloud%d" % i, p, 1e-6)
+    # one read-back of the objectness mask + index gathers == the reference's 7 masked selections per cloud, bit for bit
+    from graspbalance_amd.graspbalance import _pred_decode_loop
+    loop = _pred_decode_loop(mk.g14_inputs(DEV))
+    assert len(loop) == len(preds) and all(torch.equal(a, b) for a, b in zip(loop, preds))
 
 
 def test_object_balance_sampling_matches_reference_gpu(golden):

@@ -563,7 +563,7 @@ extern "C" int gb_gemm_fwd_pool(const float *x, const float *w, const float *aff
   pool.gamma = gamma;
   pool.pairs = reinterpret_cast<float2 *>(pairs);
   pool.D = D;
-  if (!with_rows && !y) return GB_EINVAL;  // values only: the arg-max row is later found by value in the stored Y
+  // values only and no Y: a forward-only caller (inference) - nothing can find the arg-max rows afterwards
   if (!rs_gemm_try(x, w, y, aff, stats, stat_slots, nullptr, nullptr, P, K, N, 1, with_rows ? RS_STATS_POOL : RS_STATS_POOL_V,
                    as_stream(stream),
                    opts_bf16(opts), opts_reserved(opts), nullptr, nullptr, &pool))

@@ -528,11 +528,12 @@ class MLPStack(Function):
                 # rank + sparse backward the output is not even stored
                 lowrank = (_CROP_LOWRANK and l >= 1 and _lib.lib().gb_crop_bwd_ok(K, N, rows.D)
                            and _lib.lib().gb_gemm_uses_rs(P, K, K, 1, 1, 1))
-                Y = None if lowrank else _empty_rows(P, N, dev, True)
+                fwd_only = not any(ctx.needs_input_grad)   # inference: the layer's output is not stored at all
+                Y = None if (lowrank or fwd_only) else _empty_rows(P, N, dev, True)
                 if not cfg.training:
                     ab = _eval_ab(gamma, beta, cfg.running_mean, cfg.running_var, cfg.eps, N, dev, st)
                 pooled = _pooled_last_layer(dev, st, opts, src, W, aff, gamma, beta, cfg, ab, stats, slots, rows, P, K, N,
-                                            P_stat, Y)
+                                            P_stat, Y, with_rows=(Y is None and not fwd_only))
                 Ws.append(W); Ys.append(Y); abs_.append(ab)
                 break
             Y = _empty_rows(P, N, dev, rows is not None)
@@ -829,12 +830,15 @@ def set_crop_pool(flag, lowrank=None):
     return prev
 
 
-def _pooled_last_layer(dev, st, opts, src, W, aff, gamma, beta, cfg, ab, stats, slots, rows, P, K, N, P_stat, Y=None):
+def _pooled_last_layer(dev, st, opts, src, W, aff, gamma, beta, cfg, ab, stats, slots, rows, P, K, N, P_stat, Y=None,
+                       with_rows=None):
     """gb_gemm_fwd_pool + gb_pool_pairs -> (out, arg, ystar), each ((R*D), N).  Y: optional (P, N) buffer that also
-    receives the layer's output."""
+    receives the layer's output.  with_rows: the epilogue tracks the arg-max rows (default: whenever there is no stored
+    output to find them in by value; a forward-only caller passes False and gets the values alone)."""
     RD = rows.R * rows.D
     tiles = (P + 31) // 32
-    with_rows = Y is None   # no stored output to find the arg-max rows in by value: the epilogue must track them
+    if with_rows is None:
+        with_rows = Y is None
     # sized for the row count rounded up like the activations (_empty_rows): the distinct-row count changes every step,
     # and a new allocation size every step means a fresh hipMalloc - a device synchronisation - per radius
     cap_tiles = (P + _ROW_QUANTUM - 1) // _ROW_QUANTUM * (_ROW_QUANTUM // 32)

@@ -361,8 +361,9 @@ int gb_cyl_rows(const float *xyz, const float *centres, const float *rot, const 
  * GB_EINVAL (ask gb_gemm_uses_rs(P, K, N, 0, 3, has_aff)).  stats as in gb_gemm_fwd (required).  y (optional, (P,N)):
  * Y is stored as well, for a caller whose backward wants it (the dense backward: gb_bn_bwd_apply_members).
  * with_rows = 0: VALUES only - pairs holds one float per entry (half the size), gb_pool_pairs is called with arg =
- * NULL, and the arg-max row is found by value in the stored y (required then) by gb_bn_bwd_apply_members_v: the
- * epilogue then costs a fifth of the instructions of the row-tracking form.                                     */
+ * NULL, and the arg-max row is found by value in the stored y by gb_bn_bwd_apply_members_v: the epilogue then costs
+ * a fifth of the instructions of the row-tracking form.  with_rows = 0 and y = NULL: a forward-only caller
+ * (inference) - the layer's output is neither stored nor traceable afterwards.                                  */
 int gb_gemm_fwd_pool(const float *x, const float *w, const float *aff, const int32_t *row_key, const float *gamma,
                      float *pairs, int with_rows, float *y, double *stats, int stat_slots, long long P, int K, int N,
                      int D, const GbBnFinalize *fin, const GbGemmOpts *opts, void *stream);

@@ -319,3 +319,14 @@ def test_pooled_gemm_epilogue_against_torch(P, D, with_rows, sizes):
             want_arg = torch.where(has, first, off.unsqueeze(1).expand(R, N))
             assert torch.equal(arg.cpu().view(R, D, N)[:, d].long(), want_arg), ("arg", d)
     assert int((~torch.isfinite(out)).sum()) == 0
+    if not with_rows:
+        # forward-only form (inference): values only and no stored output - the same pooled values, bit for bit
+        pairs2 = torch.full_like(pairs, float("nan"))
+        stats2 = torch.zeros_like(stats)
+        L.check(lib.gb_gemm_fwd_pool(L.ptr(Xd), L.ptr(Wd), L.ptr(affd), L.ptr(keyd), L.ptr(gammad), L.ptr(pairs2), 0, None,
+                                     L.ptr(stats2), 1, P, K, N, D, None, None, None), "gb_gemm_fwd_pool (no y)")
+        out2, ystar2 = torch.empty_like(out), torch.empty_like(ystar)
+        L.check(lib.gb_pool_pairs(L.ptr(pairs2), L.ptr(offd), L.ptr(cntd), L.ptr(abd), L.ptr(gammad), L.ptr(out2), None,
+                                  L.ptr(ystar2), R, D, N, None), "gb_pool_pairs")
+        torch.cuda.synchronize()
+        assert torch.equal(out2, out) and torch.equal(ystar2, ystar) and torch.equal(stats2, stats)

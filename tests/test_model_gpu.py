@@ -304,3 +304,24 @@ def test_lean_label_matching_equals_full():
     for k, g in full[5].items():
         assert torch.allclose(g, lean[5][k], rtol=1e-5, atol=1e-9), k
     assert 'batch_grasp_label_all' not in lean[0] and 'batch_grasp_offset_all' in full[0]
+
+
+def test_predictor_with_announced_next_batch_returns_the_same_grasps():
+    """predict.Predictor: eval forward + pred_decode; with the next batch announced its first-level sampling runs on a
+    side stream under the current forward and is consumed by the next call - same grasps bit for bit as the inline
+    path, for alternating batches, and an unannounced batch is simply sampled inline."""
+    from tests.seeded import fill_by_key
+    from tests.test_model_cpu import _tiny_net
+    from graspbalance_amd.predict import Predictor
+    from graspbalance_amd.scene import make_batch
+    net = fill_by_key(_tiny_net(training=False), seed=5)
+    a = {'point_clouds': torch.from_numpy(make_batch([0, 1], 3000)).to(DEV)}
+    b = {'point_clouds': torch.from_numpy(make_batch([2, 3], 3000)).to(DEV)}
+    plain = Predictor(net, DEV, prefetch_sampling=False)
+    want_a, want_b = plain(a), plain(b)
+    piped = Predictor(net, DEV)
+    got = [piped(a, next_batch=b), piped(b, next_batch=a), piped(a), piped(b)]
+    torch.cuda.synchronize()
+    for g, w in zip(got, (want_a, want_b, want_a, want_b)):
+        assert len(g) == len(w) and all(torch.equal(x, y) for x, y in zip(g, w))
+    assert piped.prefetch.pending is None

@@ -396,6 +396,8 @@ def main():
     sample_every = 4 if args.steps >= 8 else max(1, args.steps // 2)
     sampled = 0
     with timer as kt:
+        from graspbalance_amd import fused_mlp as _fm
+        _fm.SYNC_WAIT[0] = 0.0
         t0 = time.perf_counter()
         for i in range(args.steps):
             on = i % sample_every == 0
@@ -403,6 +405,10 @@ def main():
             sampled += on
             loss = trainer.train_step(batch, next_batch=batch)
         kt.sample(True)
+        # how long the host WORKED to enqueue the K steps: each step waits once for the GPU (the crop row counts), and that
+        # wait is taken out.  Well below `elapsed`: the step is GPU-bound.  Close to it: the step is host-bound and the
+        # line says more about the box's CPU (and its other tenants) than about the kernels.
+        host_enqueue = time.perf_counter() - t0 - _fm.SYNC_WAIT[0]   # minus the time spent waiting for the GPU in them
         barrier()
         elapsed = time.perf_counter() - t0
     assert bool(torch.isfinite(loss)), "training diverged"
@@ -575,7 +581,7 @@ def main():
             "roofline_cyl": roofline_cyl,
             "ranks_seen": ranks_seen,
             "prefetch_sampling": trainer.prefetch is not None,
-            "ms_per_step_no_prefetch": no_prefetch_ms,
+            "ms_per_step_no_prefetch": no_prefetch_ms, "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
         }
         if allreduce:
             out["allreduce_ms"] = round(allreduce["standalone_ms"], 4)

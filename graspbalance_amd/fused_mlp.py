@@ -16,6 +16,7 @@ import ctypes
 import weakref
 import os
 import threading
+import time
 
 import torch
 from torch.autograd import Function
@@ -238,6 +239,7 @@ def _call(name, dev, *args, meta=None):
         _lib.check(_lib.timed(name, dev, meta, lambda: fn(*args)), name)
 
 
+SYNC_WAIT = [0.0]  # seconds the host spent waiting in the step's one device -> host read (cylinder_rows)
 _TRAIN_TICK = [0]   # bumped by every training-mode BatchNorm finalise: those write the running statistics through raw
                     # pointers, which torch's version counters do not see
 _EVAL_AB = {}   # id(running_mean buffer) -> (weak reference to it, key, [a, b, mean, rstd] table)
@@ -1214,7 +1216,9 @@ def cylinder_rows(idx, xyz, centres, rot):
               _lib.ptr(count[i]), st)
     ends = torch.cumsum(count, dim=1, dtype=torch.int64)
     off = (ends - count).contiguous()
+    t_sync = time.perf_counter()
     totals = ends[:, -1].tolist()  # the one host synchronisation: row counts size the activations
+    SYNC_WAIT[0] += time.perf_counter() - t_sync   # (bench.py: host-bound or GPU-bound? a host that arrives late waits ~0)
     out = []
     for i in range(nr):
         Pu = int(totals[i])

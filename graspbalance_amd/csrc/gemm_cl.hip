@@ -47,7 +47,7 @@ struct Operand {
 // registers holding one thread's share (ROWS/16 floats... i.e. 4 or 8) of a ROWS x 16 operand tile
 struct Frag { float v[8]; float ca[4], cb[4]; float rw[2]; bool ok[2]; };  // data, affine (a,b) of its 4 channels, reduction weight, validity
 
-template <int KIND, bool VEC, int ROWS, bool GEN = false>
+template <int KIND, bool VEC, int ROWS, bool GEN = false, bool RW = false>
 __device__ __forceinline__ void load_frag(const Operand &op, long long row0, long long k0, Frag &f) {
   const int t = threadIdx.x;
   constexpr int TPK = ROWS / 4;        // OP_RC: threads covering the tile rows of one reduction index
@@ -82,7 +82,7 @@ __device__ __forceinline__ void load_frag(const Operand &op, long long row0, lon
       const float *p = op.src + k * op.ld + row;
       const bool kok = k < op.red;
       f.ok[h] = kok;
-      f.rw[h] = (op.red_w && kok) ? op.red_w[k] : 1.f;
+      if constexpr (RW) f.rw[h] = kok ? op.red_w[k] : 1.f;   // (gb_gemm_gram only: a template switch like GEN)
       if constexpr (GEN) {   // a template switch: the plain loaders must not carry this branch (it cost every wgrad 15-35 %)
         const float gx = kok ? op.gen_x[k * 3] : 0.f, gy = kok ? op.gen_x[k * 3 + 1] : 0.f, gz = kok ? op.gen_x[k * 3 + 2] : 0.f;
 #pragma unroll
@@ -161,7 +161,11 @@ enum { EPI_STORE = 0,
 // D[i,j] = sum_k A[i,k] B[j,k] over k in [kbeg, kend);  D is (a.rows x b.rows) with leading dim ldd
 // 128 x 128 tiles of the store / atomic kernels need 132-136 VGPRs as written: asking for four waves per SIMD
 // (<= 128 registers) buys a fourth resident workgroup per CU
-template <int KA, int KB, bool VA, bool VB, int EPI, int GM, int GN, bool BF = false, bool GENB = false>
+// XOP: 0 plain operands; XOP_GENB: B is generated (gb_gemm_wgrad_gen3); XOP_RWA: A carries per-reduction-index weights
+// (gb_gemm_gram).  Compile-time, so that the plain instantiations carry neither: as run-time branches in the loaders they
+// cost every split-K product 15-35 % (registers: the 128 x 128 tile spilled under its 128-VGPR cap).
+enum { XOP_NONE = 0, XOP_GENB = 1, XOP_RWA = 2 };
+template <int KA, int KB, bool VA, bool VB, int EPI, int GM, int GN, bool BF = false, int XOP = XOP_NONE>
 __global__ __launch_bounds__(GTPB, ((GM == 128 && GN == 128 && (EPI == 0 || EPI == 2) && !BF) ? 4 : 1)) void gemm_cl_kernel(Operand a, Operand b, float *__restrict__ d, long long ldd,
                                                         double *__restrict__ stats, long long kchunk,
                                                         int tiles_n, int stat_slots,
@@ -196,11 +200,11 @@ __global__ __launch_bounds__(GTPB, ((GM == 128 && GN == 128 && (EPI == 0 || EPI 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   Frag fa, fb;
-  load_frag<KA, VA, GM>(a, m0, kbeg, fa);
-  load_frag<KB, VB, GN, GENB>(b, n0, kbeg, fb);
+  load_frag<KA, VA, GM, false, XOP == XOP_RWA>(a, m0, kbeg, fa);
+  load_frag<KB, VB, GN, XOP == XOP_GENB>(b, n0, kbeg, fb);
   if (a.aff) apply_aff<GM>(fa);
   if (b.aff) apply_aff<GN>(fb);
-  if constexpr (KA == OP_RC) { if (a.red_w) apply_red_w<GM>(fa); }
+  if constexpr (KA == OP_RC && XOP == XOP_RWA) apply_red_w<GM>(fa);
   store_frag<KA, GM>(lds_a[0], fa);
   store_frag<KB, GN>(lds_b[0], fb);
   __syncthreads();
@@ -208,8 +212,8 @@ __global__ __launch_bounds__(GTPB, ((GM == 128 && GN == 128 && (EPI == 0 || EPI 
   for (long long k0 = kbeg; k0 < kend; k0 += GK) {
     const bool more = k0 + GK < kend;
     if (more) {
-      load_frag<KA, VA, GM>(a, m0, k0 + GK, fa);
-      load_frag<KB, VB, GN, GENB>(b, n0, k0 + GK, fb);
+      load_frag<KA, VA, GM, false, XOP == XOP_RWA>(a, m0, k0 + GK, fa);
+      load_frag<KB, VB, GN, XOP == XOP_GENB>(b, n0, k0 + GK, fb);
     }
     if constexpr (BF) {
       // bf16 matrix cores: ONE v_mfma_f32_32x32x16_bf16 per 32x32 tile and step; a lane supplies the 8 reduction
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(GTPB, ((GM == 128 && GN == 128 && (EPI == 0 || EPI 
     if (more) {
       if (a.aff) apply_aff<GM>(fa);
       if (b.aff) apply_aff<GN>(fb);
-      if constexpr (KA == OP_RC) { if (a.red_w) apply_red_w<GM>(fa); }
+      if constexpr (KA == OP_RC && XOP == XOP_RWA) apply_red_w<GM>(fa);
       store_frag<KA, GM>(lds_a[buf ^ 1], fa);
       store_frag<KB, GN>(lds_b[buf ^ 1], fb);
     }
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(GTPB) void wgrad_smallk_kernel(const float *__restr
 
 static inline bool aligned16(const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
 
-template <int KA, int KB, int EPI, int BM, int BN, bool GENB = false>
+template <int KA, int KB, int EPI, int BM, int BN, int XOP = XOP_NONE>
 static void launch_tile(const Operand &a, const Operand &b, bool va, bool vb, float *d, long long ldd, double *stats,
                         long long kchunk, unsigned chunks, hipStream_t s, bool bf16, int stat_slots, const float *epi_y,
                         const float *epi_ab, const uint16_t *epi_w16, long long dchunk) {
@@ -391,9 +395,9 @@ static void launch_tile(const Operand &a, const Operand &b, bool va, bool vb, fl
   const dim3 grid((unsigned)(tiles_m * tiles_n), chunks);
   const bool bf = bf16 && a.red >= 16;  // GB_PREC_BF16; short reductions (xyz-only first layers) stay fp32
 #define GB_L(VA_, VB_, BF_)                                                                                       \
-  hipLaunchKernelGGL((gemm_cl_kernel<KA, KB, VA_, VB_, EPI, BM, BN, BF_, GENB>), grid, dim3(GTPB), 0, s, a, b, d, ldd, \
+  hipLaunchKernelGGL((gemm_cl_kernel<KA, KB, VA_, VB_, EPI, BM, BN, BF_, XOP>), grid, dim3(GTPB), 0, s, a, b, d, ldd, \
                      stats, kchunk, tiles_n, stat_slots, epi_y, epi_ab, epi_w16, dchunk)
-  if constexpr (GENB) {  // B is generated (gb_gemm_wgrad_gen3): never a vector load of it
+  if constexpr (XOP == XOP_GENB) {  // B is generated (gb_gemm_wgrad_gen3): never a vector load of it
     if (bf) { if (va) GB_L(true, false, true); else GB_L(false, false, true); }
     else { if (va) GB_L(true, false, false); else GB_L(false, false, false); }
   } else
@@ -413,7 +417,7 @@ static void launch_tile(const Operand &a, const Operand &b, bool va, bool vb, fl
 
 // tile choice: 64-wide where the dimension is <= 64 (a 128 tile would waste half of its MFMAs) and
 // 64-tall when 128-tall tiles would leave most of the 256 CUs without a workgroup
-template <int KA, int KB, int EPI, bool GENB = false>
+template <int KA, int KB, int EPI, int XOP = XOP_NONE>
 static void launch_gemm(const Operand &a, const Operand &b, bool va, bool vb, float *d, long long ldd, double *stats,
                         long long kchunk, unsigned chunks, hipStream_t s, bool bf16, int stat_slots = 1,
                         const float *epi_y = nullptr, const float *epi_ab = nullptr, const uint16_t *epi_w16 = nullptr,
@@ -423,10 +427,10 @@ static void launch_gemm(const Operand &a, const Operand &b, bool va, bool vb, fl
   const bool bn64 = b.rows <= 64 || (((a.rows + 63) / 64) * ((b.rows + 63) / 64) * chunks <= 1024);
   const long long blocks128 = ((a.rows + 127) / 128) * ((b.rows + (bn64 ? 63 : 127)) / (bn64 ? 64 : 128)) * chunks;
   const bool bm64 = a.rows <= 64 || blocks128 < 512;
-  if (bm64 && bn64) launch_tile<KA, KB, EPI, 64, 64, GENB>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, bf16, stat_slots, epi_y, epi_ab, epi_w16, dchunk);
-  else if (bm64) launch_tile<KA, KB, EPI, 64, 128, GENB>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, bf16, stat_slots, epi_y, epi_ab, epi_w16, dchunk);
-  else if (bn64) launch_tile<KA, KB, EPI, 128, 64, GENB>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, bf16, stat_slots, epi_y, epi_ab, epi_w16, dchunk);
-  else launch_tile<KA, KB, EPI, 128, 128, GENB>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, bf16, stat_slots, epi_y, epi_ab, epi_w16, dchunk);
+  if (bm64 && bn64) launch_tile<KA, KB, EPI, 64, 64, XOP>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, bf16, stat_slots, epi_y, epi_ab, epi_w16, dchunk);
+  else if (bm64) launch_tile<KA, KB, EPI, 64, 128, XOP>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, bf16, stat_slots, epi_y, epi_ab, epi_w16, dchunk);
+  else if (bn64) launch_tile<KA, KB, EPI, 128, 64, XOP>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, bf16, stat_slots, epi_y, epi_ab, epi_w16, dchunk);
+  else launch_tile<KA, KB, EPI, 128, 128, XOP>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, bf16, stat_slots, epi_y, epi_ab, epi_w16, dchunk);
 }
 
 // out[i] = ((part0[i] + part1[i]) + part2[i]) + ...   (chunks copies of `elems` floats, summed in chunk order)
@@ -633,7 +637,7 @@ extern "C" int gb_gemm_wgrad_gen3(const float *dy, const float *x0, const float 
   chunks = (P + kchunk - 1) / kchunk;
   if (chunks > 65535) return GB_ERANGE;
   const bool va = (N % 4 == 0) && aligned16(dy);
-  launch_gemm<OP_RC, OP_RC, EPI_ATOMIC, true>(a, b, va, false, dw, K, nullptr, kchunk, (unsigned)chunks,
+  launch_gemm<OP_RC, OP_RC, EPI_ATOMIC, XOP_GENB>(a, b, va, false, dw, K, nullptr, kchunk, (unsigned)chunks,
                                               as_stream(stream), opts_bf16(opts));
   return check_launch("gb_gemm_wgrad_gen3");
 }
@@ -743,8 +747,12 @@ extern "C" int gb_gemm_gram(const float *x, const float *x_aff, const float *row
   chunks = (P + kchunk - 1) / kchunk;
   if (chunks > 65535) return GB_ERANGE;
   const bool v = (K % 4 == 0) && aligned16(x);
-  launch_gemm<OP_RC, OP_RC, EPI_ATOMIC>(a, b, v, v, gmat, K, nullptr, kchunk, (unsigned)chunks, as_stream(stream),
-                                        opts_bf16(opts));
+  if (row_w)
+    launch_gemm<OP_RC, OP_RC, EPI_ATOMIC, XOP_RWA>(a, b, v, v, gmat, K, nullptr, kchunk, (unsigned)chunks,
+                                                   as_stream(stream), opts_bf16(opts));
+  else
+    launch_gemm<OP_RC, OP_RC, EPI_ATOMIC>(a, b, v, v, gmat, K, nullptr, kchunk, (unsigned)chunks, as_stream(stream),
+                                          opts_bf16(opts));
   return check_launch("gb_gemm_gram");
 }
 

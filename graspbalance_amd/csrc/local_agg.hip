@@ -333,9 +333,13 @@ __global__ __launch_bounds__(LA_TPB) void la_point_grad_kernel(const float *__re
 __global__ void la_wx_grad_kernel(const double *__restrict__ red, const double *__restrict__ u,
                                   const double *__restrict__ mom, const float *__restrict__ wx,
                                   const float *__restrict__ ab, double invP, int C, int training,
-                                  float *__restrict__ dwx) {
+                                  float *__restrict__ dwx, float *__restrict__ dbeta, float *__restrict__ dgamma) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
+  if (dbeta) {  // gb_la_wx_grad_g: the BatchNorm parameter gradients are the first two sums, converted
+    dbeta[c] = (float)red[c];
+    dgamma[c] = (float)red[C + c];
+  }
   const double a = ab[c], mean = ab[2 * C + c], rstd = ab[3 * C + c];
   const double m1 = training ? red[c] * invP : 0.0, m2 = training ? red[C + c] * invP : 0.0;
 #pragma unroll
@@ -467,6 +471,17 @@ extern "C" int gb_la_wx_grad(const double *red, const double *u, const double *m
                              long long P, int C, int training, float *dwx, void *stream) {
   if (C < 1 || P < 1 || !red || !u || !mom || !wx || !ab || !dwx) return GB_EINVAL;
   hipLaunchKernelGGL(la_wx_grad_kernel, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), red, u, mom, wx, ab,
-                     1.0 / (double)P, C, training, dwx);
+                     1.0 / (double)P, C, training, dwx, nullptr, nullptr);
   return check_launch("gb_la_wx_grad");
+}
+
+// gb_la_wx_grad that also writes the BatchNorm parameter gradients dbeta = red[0:C], dgamma = red[C:2C] in fp32 (what a
+// one-slot gb_bn_bwd_reduce launch would do)
+extern "C" int gb_la_wx_grad_g(const double *red, const double *u, const double *mom, const float *wx, const float *ab,
+                               long long P, int C, int training, float *dwx, float *dbeta, float *dgamma,
+                               void *stream) {
+  if (C < 1 || P < 1 || !red || !u || !mom || !wx || !ab || !dwx || !dbeta || !dgamma) return GB_EINVAL;
+  hipLaunchKernelGGL(la_wx_grad_kernel, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), red, u, mom, wx, ab,
+                     1.0 / (double)P, C, training, dwx, dbeta, dgamma);
+  return check_launch("gb_la_wx_grad_g");
 }

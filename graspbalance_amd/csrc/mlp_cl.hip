@@ -393,7 +393,8 @@ __global__ __launch_bounds__(CL_TPB) void bn_bwd_apply_rows_kernel(const float *
                                                                     const double *__restrict__ dstats, long long P,
                                                                     int C, int relu, int training,
                                                                     float *__restrict__ dy, float *__restrict__ dres,
-                                                                    int rows_per_block) {
+                                                                    int rows_per_block, float *__restrict__ dbeta,
+                                                                    float *__restrict__ dgamma) {
   const int tpr = C / 4, rpp = CL_TPB / tpr;  // threads per row, rows per pass
   const int cg = threadIdx.x % tpr, rl = threadIdx.x / tpr;
   if (rl >= rpp) return;
@@ -408,6 +409,15 @@ __global__ __launch_bounds__(CL_TPB) void bn_bwd_apply_rows_kernel(const float *
   for (int t = 0; t < 4; ++t) {
     k1[t] = training ? (float)(dstats[c + t] * invP) : 0.f;
     k2[t] = training ? (float)(dstats[C + c + t] * invP) : 0.f;
+  }
+  if (dbeta && blockIdx.x == 0 && rl == 0) {
+    // gb_bn_bwd_apply_g: the layer's parameter gradients (fp32) are the sums this kernel reads anyway - the separate
+    // gb_bn_bwd_reduce launch of a one-slot-row layer only converted them (41 launches of ~5 us per train step)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      dbeta[c + t] = (float)dstats[c + t];
+      dgamma[c + t] = (float)dstats[C + c + t];
+    }
   }
   const long long r0 = (long long)blockIdx.x * rows_per_block;
   long long r1 = r0 + rows_per_block;
@@ -897,11 +907,12 @@ extern "C" int gb_bn_bwd_stats(const float *dout, const float *y, const float *a
   return reduce_after(check_launch("gb_bn_bwd_stats"), dstats, 1, C, nullptr, dbeta, dgamma, stream);
 }
 
-extern "C" int gb_bn_bwd_apply(const float *dout, const float *y, const float *ab, const float *residual,
-                               const double *dstats, long long P, int C, int relu, int training, float *dy,
-                               float *dres, void *stream) {
+static int bn_bwd_apply_impl(const float *dout, const float *y, const float *ab, const float *residual,
+                             const double *dstats, long long P, int C, int relu, int training, float *dy, float *dres,
+                             float *dbeta, float *dgamma, void *stream) {
   if (P < 0 || C < 1 || !dout || !y || !ab || !dy || (training && !dstats)) return GB_EINVAL;
-  if (P == 0) return GB_OK;
+  if ((!dbeta != !dgamma) || (dbeta && !dstats)) return GB_EINVAL;
+  if (P == 0) return dbeta ? gb_bn_bwd_reduce(dstats, 1, C, nullptr, dbeta, dgamma, stream) : GB_OK;
   const bool vec = C % 4 == 0 && (reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dout) |
                                   reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(dy) |
                                   reinterpret_cast<uintptr_t>(dres)) % 16 == 0;
@@ -910,14 +921,35 @@ extern "C" int gb_bn_bwd_apply(const float *dout, const float *y, const float *a
     long long rpb = (P + 4095) / 4096;  // ~4096 workgroups, each a whole number of 4-row passes
     rpb = (rpb + 4 * rpp - 1) / (4 * rpp) * (4 * rpp);
     hipLaunchKernelGGL(bn_bwd_apply_rows_kernel, dim3((unsigned)((P + rpb - 1) / rpb)), dim3(CL_TPB), 0,
-                       as_stream(stream), dout, y, ab, residual, dstats, P, C, relu, training, dy, dres, (int)rpb);
-  } else if (vec)
+                       as_stream(stream), dout, y, ab, residual, dstats, P, C, relu, training, dy, dres, (int)rpb, dbeta,
+                       dgamma);
+    return check_launch("gb_bn_bwd_apply");
+  }
+  if (vec)
     hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(blocks_for(P * C / 4)), dim3(CL_TPB), 0, as_stream(stream), dout,
                        y, ab, residual, dstats, P, C, relu, training, dy, dres);
   else
     hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(blocks_for(P * C)), dim3(CL_TPB), 0, as_stream(stream), dout, y,
                        ab, residual, dstats, P, C, relu, training, dy, dres);
-  return check_launch("gb_bn_bwd_apply");
+  const int rc = check_launch("gb_bn_bwd_apply");
+  if (rc != GB_OK || !dbeta) return rc;
+  return gb_bn_bwd_reduce(dstats, 1, C, nullptr, dbeta, dgamma, stream);  // the generic kernels do not emit them
+}
+
+extern "C" int gb_bn_bwd_apply(const float *dout, const float *y, const float *ab, const float *residual,
+                               const double *dstats, long long P, int C, int relu, int training, float *dy,
+                               float *dres, void *stream) {
+  return bn_bwd_apply_impl(dout, y, ab, residual, dstats, P, C, relu, training, dy, dres, nullptr, nullptr, stream);
+}
+
+// gb_bn_bwd_apply that also emits the layer's parameter gradients dbeta = sum dA, dgamma = sum dA*xhat in fp32 from the
+// SAME fp64 sums (dstats: one slot row, i.e. already the totals): saves the gb_bn_bwd_reduce launch whose only work for
+// such a layer is that conversion.
+extern "C" int gb_bn_bwd_apply_g(const float *dout, const float *y, const float *ab, const float *residual,
+                                 const double *dstats, long long P, int C, int relu, int training, float *dy,
+                                 float *dres, float *dbeta, float *dgamma, void *stream) {
+  if (!dbeta || !dgamma) return GB_EINVAL;
+  return bn_bwd_apply_impl(dout, y, ab, residual, dstats, P, C, relu, training, dy, dres, dbeta, dgamma, stream);
 }
 
 static bool members_ok(long long R, int D, int C, const void *a, const void *b, const void *c, const void *d) {

@@ -775,10 +775,11 @@ class MLPStack(Function):
                     _call("gb_moments3", dev, _lib.ptr(X0), _lib.ptr(rows.w if rows is not None else None), P,
                           _lib.ptr(mom), st)
                 red = sums.view(slots, 5 * K).sum(0) if slots > 1 else sums
-                grads[1], grads[2] = param_grads(0, red, 1, None)
+                dbeta0, dgamma0 = bn_grads(0)
+                grads[1], grads[2] = dgamma0, dbeta0
                 dW0 = torch.empty((K, 3), dtype=torch.float32, device=dev)
-                _call("gb_la_wx_grad", dev, _lib.ptr(red), _lib.ptr(u0), _lib.ptr(mom), _lib.ptr(Ws[0]), _lib.ptr(abs_[0]),
-                      P_stat, K, int(training[0]), _lib.ptr(dW0), st)
+                _call("gb_la_wx_grad_g", dev, _lib.ptr(red), _lib.ptr(u0), _lib.ptr(mom), _lib.ptr(Ws[0]), _lib.ptr(abs_[0]),
+                      P_stat, K, int(training[0]), _lib.ptr(dW0), _lib.ptr(dbeta0), _lib.ptr(dgamma0), st)
                 grads[0] = dW0
                 break
             # gradient of layer l-1's post-ReLU output + that layer's BatchNorm-backward sums in one launch
@@ -786,11 +787,16 @@ class MLPStack(Function):
             region = d_arena[d_off[l - 1]:d_off[l]]
             dbeta, dgamma = bn_grads(l - 1)
             grads[3 * l - 2], grads[3 * l - 1] = dgamma, dbeta
+            emit = False   # the apply pass below writes dbeta / dgamma itself (gb_bn_bwd_apply_g)
             if fused[l - 1]:
                 dstats = region[slots * 2 * K:] if slots > 1 else region  # the slot rows' total
+                # one slot row: the sums ARE the totals, and all gb_bn_bwd_reduce would do is convert them to fp32 - the
+                # apply pass reads them anyway and does that (one launch less per layer of the few-row stacks)
+                emit = slots == 1 and rows is None
                 _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dZ), _lib.ptr(Ys[l - 1]),
-                      _lib.ptr(abs_[l - 1]), _lib.ptr(region), slots, P, K, N, _lib.ptr(dstats), _lib.ptr(dbeta),
-                      _lib.ptr(dgamma), opts, st, meta=_gemm_meta("dgrad", P, K, N, fused=True))
+                      _lib.ptr(abs_[l - 1]), _lib.ptr(region), slots, P, K, N, None if emit else _lib.ptr(dstats),
+                      None if emit else _lib.ptr(dbeta), None if emit else _lib.ptr(dgamma), opts, st,
+                      meta=_gemm_meta("dgrad", P, K, N, fused=True))
             else:
                 # wide + long outputs: the fused epilogue measured slower than a separate column pass
                 _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dZ), None, None, None, 0, P, K, N,
@@ -802,6 +808,10 @@ class MLPStack(Function):
             if rows is not None:
                 _call("gb_bn_bwd_apply_w", dev, _lib.ptr(dZ), _lib.ptr(Ys[l - 1]), _lib.ptr(abs_[l - 1]), _lib.ptr(dstats),
                       _lib.ptr(rows.w), P, P_stat, K, int(training[l - 1]), _lib.ptr(dY), st)
+            elif emit:
+                _call("gb_bn_bwd_apply_g", dev, _lib.ptr(dZ), _lib.ptr(Ys[l - 1]), _lib.ptr(abs_[l - 1]), None,
+                      _lib.ptr(dstats), P, K, 1, int(training[l - 1]), _lib.ptr(dY), None, _lib.ptr(dbeta),
+                      _lib.ptr(dgamma), st)
             else:
                 _call("gb_bn_bwd_apply", dev, _lib.ptr(dZ), _lib.ptr(Ys[l - 1]), _lib.ptr(abs_[l - 1]), None,
                       _lib.ptr(dstats), P, K, 1, int(training[l - 1]), _lib.ptr(dY), None, st)
@@ -974,14 +984,15 @@ class LocalAggPool(Function):
               geo.n, geo.m, geo.ns, N, geo.mode, geo.scale, st)
         small = torch.empty(5 * N + N * C, dtype=torch.float32, device=dev)  # dbeta, dgamma, dWx (N,3), then dWf
         dbeta, dgamma, dWx = small[:N], small[N:2 * N], small[2 * N:5 * N].view(N, 3)
-        _call("gb_bn_bwd_reduce", dev, _lib.ptr(red), 1, N, None, _lib.ptr(dbeta), _lib.ptr(dgamma), st)
+        if not ctx.needs_input_grad[1]:   # (otherwise gb_la_wx_grad_g below converts the two sums: one launch less)
+            _call("gb_bn_bwd_reduce", dev, _lib.ptr(red), 1, N, None, _lib.ptr(dbeta), _lib.ptr(dgamma), st)
         dG = torch.empty((rows, N), dtype=torch.float32, device=dev)
         _call("gb_la_point_grad", dev, _lib.ptr(sg), _lib.ptr(G), _lib.ptr(geo.cnt), _lib.ptr(geo.dsum), _lib.ptr(Wx),
               _lib.ptr(ab), _lib.ptr(red), P, rows, N, training, _lib.ptr(dG), st)
         dW = None
         if ctx.needs_input_grad[1]:
-            _call("gb_la_wx_grad", dev, _lib.ptr(red), _lib.ptr(u), _lib.ptr(geo.mom), _lib.ptr(Wx), _lib.ptr(ab), P, N,
-                  training, _lib.ptr(dWx), st)
+            _call("gb_la_wx_grad_g", dev, _lib.ptr(red), _lib.ptr(u), _lib.ptr(geo.mom), _lib.ptr(Wx), _lib.ptr(ab), P, N,
+                  training, _lib.ptr(dWx), _lib.ptr(dbeta), _lib.ptr(dgamma), st)
             dWf = zbuf[rows * N:].view(N, C)
             _call("gb_gemm_wgrad", dev, _lib.ptr(dG), _lib.ptr(f), None, _lib.ptr(dWf), rows, C, N,
                   _opts(dev, st, ctx.prec), st, meta=_gemm_meta("wgrad", rows, C, N))

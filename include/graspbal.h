@@ -318,6 +318,11 @@ int gb_bn_bwd_stats(const float *dout, const float *y, const float *ab, const fl
 int gb_bn_bwd_apply(const float *dout, const float *y, const float *ab, const float *residual,
                     const double *dstats, long long P, int C, int relu, int training, float *dy, float *dres,
                     void *stream);
+/* gb_bn_bwd_apply that also writes the layer's parameter gradients dbeta (C), dgamma (C) in fp32 from the same fp64 sums
+ * (dstats must then be the totals, i.e. come from ONE slot row): what a separate gb_bn_bwd_reduce launch would do. */
+int gb_bn_bwd_apply_g(const float *dout, const float *y, const float *ab, const float *residual, const double *dstats,
+                      long long P, int C, int relu, int training, float *dy, float *dres, float *dbeta, float *dgamma,
+                      void *stream);
 int gb_bn_bwd_stats_pool(const float *dout, const float *out, const int32_t *arg, const float *y,
                          const float *ab, long long R, int ns, int C, double *dstats, float *dbeta, float *dgamma,
                          void *stream);
@@ -468,6 +473,9 @@ int gb_la_point_grad(const float *sg, const float *G, const float *cnt, const fl
 /* dwx (C,3): gradient of Wx.                                                                            */
 int gb_la_wx_grad(const double *red, const double *u, const double *mom, const float *wx, const float *ab,
                   long long P, int C, int training, float *dwx, void *stream);
+/* ... and the BatchNorm parameter gradients dbeta (C) = red[0:C], dgamma (C) = red[C:2C] in fp32 from the same launch. */
+int gb_la_wx_grad_g(const double *red, const double *u, const double *mom, const float *wx, const float *ab, long long P,
+                    int C, int training, float *dwx, float *dbeta, float *dgamma, void *stream);
 
 /* ---- fp32 MFMA GEMMs of the channel-last SharedMLP (csrc/gemm_cl.hip) — replace the cuBLAS/cuDNN
  * 1x1 convolutions the reference reaches through torch (pytorch_utils.py:61-113) ------------------- */

@@ -46,6 +46,8 @@ SIGNATURES = {
     "gb_group_concat_cl": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
     "gb_group_concat_cl_grad": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gb_col_stats": [_P, _L, _I, _P, _P, _P],
+    "gb_split_col_stats": [_P, _I, _P, _L, _I, _P, _P, _P],
+    "gb_split_bn_bwd_stats": [_P, _I, _P, _P, _P, _L, _I, _P, _P],
     "gb_bn_finalize": [_P, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _I, _P],
     "gb_affine_act": [_P, _P, _P, _P, _L, _I, _I, _P],
     "gb_affine_relu_maxpool": [_P, _P, _P, _P, _L, _I, _I, _P],

@@ -526,7 +526,10 @@ static int gemm_fwd_impl(const float *x, const float *w, const float *aff, const
     launch_gemm<OP_KC, OP_KC, EPI_STORE>(a, b, v, v, part, N, nullptr, kchunk, (unsigned)chunks, as_stream(stream), bf16, 1,
                                          nullptr, nullptr, nullptr, (long long)P * N);
     int rc = check_launch("gb_gemm_fwd");
-    if (rc == GB_OK) rc = split_reduce(part, chunks, (long long)P * N, y, as_stream(stream));
+    if (rc != GB_OK) return rc;
+    if (stats && N % 4 == 0 && aligned16(part) && aligned16(y) && (long long)P * N % 4 == 0)
+      return gb_split_col_stats(part, chunks, y, P, N, stats, fin, stream);   // reduce + column sums in one sweep
+    rc = split_reduce(part, chunks, (long long)P * N, y, as_stream(stream));
     if (rc != GB_OK || !stats) return rc;
     return gb_col_stats(y, P, N, stats, fin, stream);
   }
@@ -680,7 +683,10 @@ extern "C" int gb_gemm_dgrad(const float *dy, const float *w, float *dx, const f
     launch_gemm<OP_KC, OP_RC, EPI_STORE>(a, b, va, vb, part, K, nullptr, kchunk, (unsigned)chunks, as_stream(stream), bf16, 1,
                                          nullptr, nullptr, nullptr, (long long)P * K);
     int rc = check_launch("gb_gemm_dgrad");
-    if (rc == GB_OK) rc = split_reduce(part, chunks, (long long)P * K, dx, as_stream(stream));
+    if (rc != GB_OK) return rc;
+    if (dstats && K % 4 == 0 && aligned16(part) && aligned16(dx) && aligned16(y_prev))   // reduce + BN sums in one sweep
+      return done(gb_split_bn_bwd_stats(part, chunks, dx, y_prev, ab_prev, P, K, dstats, stream));
+    rc = split_reduce(part, chunks, (long long)P * K, dx, as_stream(stream));
     if (rc != GB_OK || !dstats) return rc;
     return done(gb_bn_bwd_stats(dx, y_prev, ab_prev, nullptr, P, K, 1, dstats, nullptr, nullptr, stream));
   }

@@ -164,6 +164,27 @@ __global__ __launch_bounds__(CL_TPB) void col_stats_kernel(const float *__restri
   });
 }
 
+// The closing pass of a split forward product (csrc/gemm_cl.hip): y = ((part_0 + part_1) + part_2) + ... in chunk order
+// (bit-reproducible) AND the column sums of y and y^2 in the same sweep - what split_reduce_kernel followed by
+// col_stats_kernel did in two launches and a second read of y.  C % 4 == 0, 16-byte aligned.
+__global__ __launch_bounds__(CL_TPB) void split_col_stats_kernel(const float *__restrict__ part, int chunks,
+                                                                  long long elems, float *__restrict__ y, long long P,
+                                                                  int C, int rpb, double *__restrict__ sum,
+                                                                  double *__restrict__ sumsq) {
+  col_reduce2<4>(P, C, rpb, sum, sumsq, [&](long long r, int c, float *v1, float *v2) {
+    const long long i = r * C + c;
+    float4 acc = *reinterpret_cast<const float4 *>(part + i);
+    for (int q = 1; q < chunks; ++q) {
+      const float4 v = *reinterpret_cast<const float4 *>(part + (long long)q * elems + i);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4 *>(y + i) = acc;
+    v1[0] = acc.x; v1[1] = acc.y; v1[2] = acc.z; v1[3] = acc.w;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v2[t] = v1[t] * v1[t];
+  });
+}
+
 // stats: [sum(C), sumsq(C)] fp64 in;  ab: [a(C), b(C), mean(C), rstd(C)] fp32 out
 __global__ void bn_finalize_kernel(const double *__restrict__ stats, int slots, long long P, int C,
                                    const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
@@ -336,6 +357,36 @@ __global__ __launch_bounds__(CL_TPB) void bn_bwd_stats_kernel(const float *__res
         if (residual) z += rs[t];
         if (!(z > 0.f)) gg = 0.f;
       }
+      v1[t] = gg;
+      v2[t] = gg * ((yy[t] - ab[2 * C + c + t]) * ab[3 * C + c + t]);
+    }
+  });
+}
+
+// The closing pass of a split dgrad product: dz = the chunk-ordered sum of the partial products, stored, and the
+// BatchNorm-backward sums of the layer dz is the gradient of (ReLU mask from its pre-BN output y) in the same sweep -
+// split_reduce_kernel + bn_bwd_stats_kernel<4> in one launch and one read of dz less.
+__global__ __launch_bounds__(CL_TPB) void split_bn_bwd_stats_kernel(const float *__restrict__ part, int chunks,
+                                                                     long long elems, float *__restrict__ dz,
+                                                                     const float *__restrict__ y,
+                                                                     const float *__restrict__ ab, long long P, int C,
+                                                                     int rpb, double *__restrict__ dbeta,
+                                                                     double *__restrict__ dgamma) {
+  col_reduce2<4>(P, C, rpb, dbeta, dgamma, [&](long long r, int c, float *v1, float *v2) {
+    const long long i = r * C + c;
+    float4 acc = *reinterpret_cast<const float4 *>(part + i);
+    for (int q = 1; q < chunks; ++q) {
+      const float4 v = *reinterpret_cast<const float4 *>(part + (long long)q * elems + i);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4 *>(dz + i) = acc;
+    const float g[4] = {acc.x, acc.y, acc.z, acc.w};
+    float yy[4];
+    load_vec<4>(y + i, yy);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float z = ab[c + t] * yy[t] + ab[C + c + t];
+      const float gg = z > 0.f ? g[t] : 0.f;
       v1[t] = gg;
       v2[t] = gg * ((yy[t] - ab[2 * C + c + t]) * ab[3 * C + c + t]);
     }
@@ -823,6 +874,23 @@ extern "C" int gb_col_stats(const float *y, long long P, int C, double *stats, c
                         fin->running_var, fin->ab, 1, stream);
 }
 
+// y (P,C) = the chunk-ordered sum of `chunks` partial products (each P*C floats, back to back in `part`), its BatchNorm
+// column sums into stats [2C] (caller-zeroed) and, with fin, the layer's finalisation - one launch for the first two.
+// C % 4 == 0 and 16-byte aligned part / y: otherwise GB_EINVAL (gemm_cl.hip then takes the two-launch path).
+extern "C" int gb_split_col_stats(const float *part, int chunks, float *y, long long P, int C, double *stats,
+                                  const GbBnFinalize *fin, void *stream) {
+  if (P < 1 || C < 4 || C % 4 || chunks < 1 || !part || !y || !stats || !fin_ok(fin) ||
+      (reinterpret_cast<uintptr_t>(part) | reinterpret_cast<uintptr_t>(y)) % 16)
+    return GB_EINVAL;
+  const int rpb = rows_per_block(P);
+  hipLaunchKernelGGL(split_col_stats_kernel, dim3((unsigned)((P + rpb - 1) / rpb)), dim3(CL_TPB), 0, as_stream(stream), part,
+                     chunks, P * C, y, P, C, rpb, stats, stats + C);
+  const int rc = check_launch("gb_split_col_stats");
+  if (rc != GB_OK || !fin) return rc;
+  return gb_bn_finalize(stats, 1, fin->P, C, fin->gamma, fin->beta, fin->eps, fin->momentum, fin->running_mean,
+                        fin->running_var, fin->ab, 1, stream);
+}
+
 extern "C" int gb_bn_finalize(const double *stats, int slots, long long P, int C, const float *gamma, const float *beta,
                               float eps, float momentum, float *running_mean, float *running_var, float *ab,
                               int training, void *stream) {
@@ -905,6 +973,20 @@ extern "C" int gb_bn_bwd_stats(const float *dout, const float *y, const float *a
     hipLaunchKernelGGL((bn_bwd_stats_kernel<1>), grid, dim3(CL_TPB), 0, as_stream(stream), dout, y, ab, residual, P,
                        C, rpb, relu, dstats, dstats + C);
   return reduce_after(check_launch("gb_bn_bwd_stats"), dstats, 1, C, nullptr, dbeta, dgamma, stream);
+}
+
+// dz (P,C) = chunk-ordered sum of `chunks` partial products (back to back in part) + the BatchNorm-backward sums
+// dstats [2C] (caller-zeroed) of the ReLU layer whose pre-BN output is y and whose table is ab, in one launch.
+// C % 4 == 0, 16-byte aligned part / dz / y (else GB_EINVAL: gemm_cl.hip then takes the two-launch path).
+extern "C" int gb_split_bn_bwd_stats(const float *part, int chunks, float *dz, const float *y, const float *ab, long long P,
+                                     int C, double *dstats, void *stream) {
+  if (P < 1 || C < 4 || C % 4 || chunks < 1 || !part || !dz || !y || !ab || !dstats ||
+      (reinterpret_cast<uintptr_t>(part) | reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(y)) % 16)
+    return GB_EINVAL;
+  const int rpb = rows_per_block(P);
+  hipLaunchKernelGGL(split_bn_bwd_stats_kernel, dim3((unsigned)((P + rpb - 1) / rpb)), dim3(CL_TPB), 0, as_stream(stream),
+                     part, chunks, P * C, dz, y, ab, P, C, rpb, dstats, dstats + C);
+  return check_launch("gb_split_bn_bwd_stats");
 }
 
 static int bn_bwd_apply_impl(const float *dout, const float *y, const float *ab, const float *residual,

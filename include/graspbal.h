@@ -295,6 +295,15 @@ typedef struct GbBnFinalize {
 
 /* stats[0:C] += column sums of y (P,C), stats[C:2C] += column sums of y*y; fp64, caller zeroes.  fin: optional */
 int gb_col_stats(const float *y, long long P, int C, double *stats, const GbBnFinalize *fin, void *stream);
+/* The closing pass of a split forward product: y (P,C) = the chunk-ordered sum of `chunks` partial products (P*C floats
+ * each, back to back in part), the column sums of y and y^2 into stats [2C] (caller-zeroed) in the same sweep and, with
+ * fin, the BatchNorm finalisation.  C % 4 == 0, part / y 16-byte aligned (else GB_EINVAL). */
+int gb_split_col_stats(const float *part, int chunks, float *y, long long P, int C, double *stats,
+                       const GbBnFinalize *fin, void *stream);
+/* ... and of a split dgrad product: dz = the chunk-ordered sum, and the BatchNorm-backward sums dstats [2C]
+ * (caller-zeroed: sum g, sum g*xhat with g = dz*[a*y+b > 0]) of the ReLU layer with pre-BN output y and table ab. */
+int gb_split_bn_bwd_stats(const float *part, int chunks, float *dz, const float *y, const float *ab, long long P, int C,
+                          double *dstats, void *stream);
 /* ab[0:C] = a = gamma*rstd, ab[C:2C] = b = beta - mean*a, ab[2C:3C] = mean, ab[3C:4C] = rstd.
  * `stats` is [slots][2C] (slot rows are summed; gb_col_stats fills one row, gb_gemm_fwd spreads its
  * epilogue atomics over `stat_slots` rows).

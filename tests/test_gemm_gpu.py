@@ -154,6 +154,28 @@ def test_split_reduction_products_are_bit_reproducible(P, K, N):
             results.append(first)
         assert torch.equal(results[1], results[2])           # no workspace == too small a workspace: both unsplit
         assert float((results[0] - results[1]).abs().max()) < 1e-4 * float(want.abs().max())
+    # with statistics the closing pass of a split product is ONE sweep (gb_split_col_stats / gb_split_bn_bwd_stats: the
+    # chunk-ordered sum and the column sums together): the same output bits as the plain split, sums to fp32 rounding
+    Y0, dX0 = fwd(_opts()), dgrad(_opts())
+    Y = torch.full((P, N), float("nan"), device=DEV)
+    stats = torch.zeros(2 * N, dtype=torch.float64, device=DEV)
+    L.check(lib.gb_gemm_fwd(L.ptr(X), L.ptr(W), None, L.ptr(Y), L.ptr(stats), 1, P, K, N, None, _opts(), None), "fwd+stats")
+    assert torch.equal(Y, Y0)
+    assert torch.allclose(stats[:N], Y.double().sum(0), rtol=1e-6, atol=1e-6 * float(Y.abs().max()) * P ** 0.5)
+    assert torch.allclose(stats[N:], (Y.double() ** 2).sum(0), rtol=1e-6)
+    yprev = torch.randn(P, K, device=DEV, generator=g)
+    ab = torch.cat([torch.rand(K, device=DEV, generator=g) + 0.5, torch.randn(K, device=DEV, generator=g) * 0.3,
+                    torch.randn(K, device=DEV, generator=g) * 0.1, torch.rand(K, device=DEV, generator=g) + 0.5]).contiguous()
+    dX = torch.full((P, K), float("nan"), device=DEV)
+    dst = torch.zeros(2 * K, dtype=torch.float64, device=DEV)
+    L.check(lib.gb_gemm_dgrad(L.ptr(dY), L.ptr(W), L.ptr(dX), L.ptr(yprev), L.ptr(ab), L.ptr(dst), 1, P, K, N, None, None,
+                              None, _opts(), None), "dgrad+sums")
+    assert torch.equal(dX, dX0)
+    gg = torch.where(ab[:K] * yprev + ab[K:2 * K] > 0, dX, torch.zeros_like(dX)).double()
+    xhat = ((yprev - ab[2 * K:3 * K]) * ab[3 * K:]).double()
+    scale = float(gg.abs().max()) * P ** 0.5
+    assert torch.allclose(dst[:K], gg.sum(0), rtol=1e-5, atol=1e-5 * scale)
+    assert torch.allclose(dst[K:], (gg * xhat).sum(0), rtol=1e-5, atol=1e-5 * scale * float(xhat.abs().max()))
 
 
 def test_options_are_per_call_two_threads_two_precisions():

@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libgraspbal_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 GB_OK = 0
 _ERRNAMES = {-1: "GB_EINVAL", -2: "GB_ELAUNCH", -3: "GB_ERANGE"}
@@ -87,6 +87,7 @@ SIGNATURES = {
     "gb_cyl_rows": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "gb_gemm_fwd_pool": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P],
     "gb_bn_bwd_apply_members_v": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _L, _I, _P, _P],
+    "gb_bn_bwd_apply_members_vs": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _L, _I, _P, _P],
     "gb_pool_pairs": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "gb_bn_finalize_lin3": [_P, _P, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P],
     "gb_gemm_fwd_gen3": [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P, _P],
@@ -103,6 +104,7 @@ SIGNATURES = {
     "gb_affine_relu_maxpool_members": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "gb_bn_bwd_apply_members": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _L, _I, _P, _P],
     "gb_bn_bwd_apply_w": [_P, _P, _P, _P, _P, _L, _L, _I, _I, _P, _P],
+    "gb_bn_bwd_apply_ws": [_P, _P, _I, _P, _P, _P, _L, _L, _I, _I, _P, _P],
 }
 
 
@@ -151,10 +153,11 @@ class GemmOpts(_c.Structure):
     """GbGemmOpts of include/graspbal.h: the per-call options of the gb_gemm_* entry points (precision, CUs left to a
     side-stream kernel, caller-owned split-reduction workspace)."""
     _fields_ = [("precision", _c.c_int), ("reserved_cus", _c.c_int), ("scratch", _c.c_void_p),
-                ("scratch_bytes", _c.c_ulonglong)]
+                ("scratch_bytes", _c.c_ulonglong), ("storage", _c.c_int)]
 
 
 PREC_F32, PREC_BF16 = 0, 1
+STORE_X_BF16, STORE_Y_BF16, STORE_YPREV_BF16 = 1, 2, 4   # GbGemmOpts.storage bits (bf16 precision only)
 GEMM_SCRATCH_BYTES = 320 * 64 * 128 * 4
 
 

@@ -42,12 +42,13 @@ struct Operand {
   const float *red_w; // optional (OP_RC only) [red]: the value is multiplied by red_w[reduction index] (after aff)
   const float *gen_x; // optional (OP_RC only): src is not read - element (tile row r, reduction index k) = gen_x[k] . gen_w[r],
   const float *gen_w; //   gen_x (red,3), gen_w (rows,3): the output of a 3-input first layer that was never stored (then aff)
+  int bf16;           // (bf16 kernels, OP_RC only) src points at bf16 elements (GbGemmOpts.storage & GB_STORE_X_BF16)
 };
 
 // registers holding one thread's share (ROWS/16 floats... i.e. 4 or 8) of a ROWS x 16 operand tile
 struct Frag { float v[8]; float ca[4], cb[4]; float rw[2]; bool ok[2]; };  // data, affine (a,b) of its 4 channels, reduction weight, validity
 
-template <int KIND, bool VEC, int ROWS, bool GEN = false, bool RW = false>
+template <int KIND, bool VEC, int ROWS, bool GEN = false, bool RW = false, bool SB = false>
 __device__ __forceinline__ void load_frag(const Operand &op, long long row0, long long k0, Frag &f) {
   const int t = threadIdx.x;
   constexpr int TPK = ROWS / 4;        // OP_RC: threads covering the tile rows of one reduction index
@@ -90,6 +91,18 @@ __device__ __forceinline__ void load_frag(const Operand &op, long long row0, lon
           const bool rok = row + e < op.rows;
           const float *wr = op.gen_w + (rok ? (row + e) * 3 : 0);
           f.v[4 * h + e] = rok ? ((gx * wr[0]) + (gy * wr[1])) + (gz * wr[2]) : 0.f;  // == gemm_rs.hip's lin3
+        }
+      } else
+      if (SB && op.bf16) {   // SB: a bf16-precision instantiation (the fp32 kernels do not carry this branch)
+        const uint16_t *pb = reinterpret_cast<const uint16_t *>(op.src) + k * op.ld + row;
+        if (VEC && kok && row + 3 < op.rows) {   // 4 consecutive elements = 8 bytes (VEC: ld % 4 == 0, aligned base)
+          const uint2 u = *reinterpret_cast<const uint2 *>(pb);
+          f.v[4 * h + 0] = __uint_as_float(u.x << 16); f.v[4 * h + 1] = __uint_as_float(u.x & 0xFFFF0000u);
+          f.v[4 * h + 2] = __uint_as_float(u.y << 16); f.v[4 * h + 3] = __uint_as_float(u.y & 0xFFFF0000u);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            f.v[4 * h + e] = (kok && row + e < op.rows) ? __uint_as_float((unsigned)pb[e] << 16) : 0.f;
         }
       } else
       if (VEC && kok && row + 3 < op.rows) {
@@ -201,7 +214,7 @@ __global__ __launch_bounds__(GTPB, ((GM == 128 && GN == 128 && (EPI == 0 || EPI 
 
   Frag fa, fb;
   load_frag<KA, VA, GM, false, XOP == XOP_RWA>(a, m0, kbeg, fa);
-  load_frag<KB, VB, GN, XOP == XOP_GENB>(b, n0, kbeg, fb);
+  load_frag<KB, VB, GN, XOP == XOP_GENB, false, BF>(b, n0, kbeg, fb);
   if (a.aff) apply_aff<GM>(fa);
   if (b.aff) apply_aff<GN>(fb);
   if constexpr (KA == OP_RC && XOP == XOP_RWA) apply_red_w<GM>(fa);
@@ -213,7 +226,7 @@ __global__ __launch_bounds__(GTPB, ((GM == 128 && GN == 128 && (EPI == 0 || EPI 
     const bool more = k0 + GK < kend;
     if (more) {
       load_frag<KA, VA, GM, false, XOP == XOP_RWA>(a, m0, k0 + GK, fa);
-      load_frag<KB, VB, GN, XOP == XOP_GENB>(b, n0, k0 + GK, fb);
+      load_frag<KB, VB, GN, XOP == XOP_GENB, false, BF>(b, n0, k0 + GK, fb);
     }
     if constexpr (BF) {
       // bf16 matrix cores: ONE v_mfma_f32_32x32x16_bf16 per 32x32 tile and step; a lane supplies the 8 reduction
@@ -505,9 +518,14 @@ static int gemm_fwd_impl(const float *x, const float *w, const float *aff, const
     return GB_EINVAL;
   if (P == 0) return fin ? GB_EINVAL : GB_OK;
   if (P / 64 * ((N + 63) / 64) > 0x7fffffffLL) return GB_ERANGE;
+  RsPool sp = {};
+  sp.storage = opts_storage(opts) & (GB_STORE_X_BF16 | GB_STORE_Y_BF16);
+  if (opts_storage(opts) & GB_STORE_YPREV_BF16) return GB_EINVAL;
   if (rs_gemm_try(x, w, y, aff, stats, stat_slots, nullptr, nullptr, P, K, N, 1, stats ? RS_STATS : RS_STORE,
-                  as_stream(stream), bf16, opts_reserved(opts), nullptr, stats ? row_w16 : nullptr))
+                  as_stream(stream), bf16, opts_reserved(opts), nullptr, stats ? row_w16 : nullptr,
+                  sp.storage ? &sp : nullptr))
     return finalize_after(check_launch("gb_gemm_fwd"), fin, stats, stat_slots, N, stream);
+  if (sp.storage) return GB_EINVAL;  // bf16 tensors are only read / written by the row-streaming kernel
   Operand a = {x, P, K, K, aff};
   Operand b = {w, N, K, K, nullptr};
   const bool v = (K % 4 == 0) && aligned16(x) && aligned16(w);
@@ -574,6 +592,8 @@ extern "C" int gb_gemm_fwd_pool(const float *x, const float *w, const float *aff
   pool.gamma = gamma;
   pool.pairs = reinterpret_cast<float2 *>(pairs);
   pool.D = D;
+  pool.storage = opts_storage(opts) & (GB_STORE_X_BF16 | GB_STORE_Y_BF16);
+  if (opts_storage(opts) & GB_STORE_YPREV_BF16) return GB_EINVAL;
   // values only and no Y: a forward-only caller (inference) - nothing can find the arg-max rows afterwards
   if (!rs_gemm_try(x, w, y, aff, stats, stat_slots, nullptr, nullptr, P, K, N, 1, with_rows ? RS_STATS_POOL : RS_STATS_POOL_V,
                    as_stream(stream),
@@ -592,6 +612,7 @@ extern "C" int gb_crop_bwd_dense(const float *y2, const float *ab2, const float 
   if (P < 1 || K < 1 || !y2 || !ab2 || !mmat || !vvec || !row_w || !dz || !dstats || stat_slots < 1 || !dbeta || !dgamma ||
       opts_bad(opts) || reinterpret_cast<uintptr_t>(row_w) % 16)
     return GB_EINVAL;
+  if (opts_storage(opts)) return GB_EINVAL;  // this entry reads and writes fp32 tensors only
   RsPool lr = {};
   lr.lr_v = vvec;
   lr.lr_roww = row_w;
@@ -616,6 +637,8 @@ extern "C" int gb_gemm_fwd_gen3(const float *x0, const float *w1, const float *a
   RsPool gen = {};
   gen.gen_x = x0;
   gen.gen_w = w1;
+  gen.storage = opts_storage(opts) & GB_STORE_Y_BF16;
+  if (opts_storage(opts) & ~GB_STORE_Y_BF16) return GB_EINVAL;
   if (!stats) return GB_EINVAL;  // (the eval-mode caller passes a scratch sum buffer: the kernel always forms the sums)
   if (!rs_gemm_try(nullptr, w, y, ab1, stats, stat_slots, nullptr, nullptr, P, K, N, 1, RS_STATS, as_stream(stream),
                    opts_bf16(opts), opts_reserved(opts), nullptr, row_w16, &gen))
@@ -627,9 +650,10 @@ extern "C" int gb_gemm_fwd_gen3(const float *x0, const float *w1, const float *a
 extern "C" int gb_gemm_wgrad_gen3(const float *dy, const float *x0, const float *w1, const float *ab1, float *dw,
                                   long long P, int K, int N, const GbGemmOpts *opts, void *stream) {
   if (P < 0 || K < 1 || N < 1 || !dy || !x0 || !w1 || !ab1 || !dw || opts_bad(opts)) return GB_EINVAL;
+  if (opts_storage(opts)) return GB_EINVAL;  // this entry reads and writes fp32 tensors only
   if (P == 0) return GB_OK;
-  Operand a = {dy, N, P, N, nullptr, nullptr, nullptr, nullptr};
-  Operand b = {nullptr, K, P, K, ab1, nullptr, x0, w1};
+  Operand a = {dy, N, P, N, nullptr, nullptr, nullptr, nullptr, 0};
+  Operand b = {nullptr, K, P, K, ab1, nullptr, x0, w1, 0};
   const long long tiles = (long long)((N + (N <= 64 ? 63 : 127)) / (N <= 64 ? 64 : 128)) *
                           ((K + (K <= 64 ? 63 : 127)) / (K <= 64 ? 64 : 128));
   long long chunks = 1024 / tiles;
@@ -665,9 +689,13 @@ extern "C" int gb_gemm_dgrad(const float *dy, const float *w, float *dx, const f
   };
   if (P == 0) return GB_OK;
   if (P / 64 * ((K + 63) / 64) > 0x7fffffffLL) return GB_ERANGE;
+  RsPool sp = {};
+  sp.storage = opts_storage(opts) & GB_STORE_YPREV_BF16;
+  if (opts_storage(opts) & ~GB_STORE_YPREV_BF16) return GB_EINVAL;
   if (rs_gemm_try(dy, w, dx, nullptr, dstats, stat_slots, y_prev, ab_prev, P, N, K, 0, dstats ? RS_BNBWD : RS_STORE,
-                  as_stream(stream), bf16, opts_reserved(opts)))
+                  as_stream(stream), bf16, opts_reserved(opts), nullptr, nullptr, sp.storage ? &sp : nullptr))
     return done(check_launch("gb_gemm_dgrad"));
+  if (sp.storage) return GB_EINVAL;  // a bf16 y_prev is only read by the row-streaming kernel
   Operand a = {dy, P, N, N, nullptr};
   Operand b = {w, K, N, K, nullptr};  // tile rows = k, reduction = n, element (k,n) at w[n*K + k]
   const bool va = (N % 4 == 0) && aligned16(dy);
@@ -715,6 +743,9 @@ extern "C" int gb_gemm_wgrad(const float *dy, const float *x, const float *x_aff
   }
   Operand a = {dy, N, P, N, nullptr};  // tile rows = n, reduction = p, element (n,p) at dy[p*N + n]
   Operand b = {x, K, P, K, x_aff};     // tile rows = k, reduction = p, element (k,p) at x[p*K + k]
+  if (opts_storage(opts) & ~GB_STORE_X_BF16) return GB_EINVAL;
+  b.bf16 = (opts_storage(opts) & GB_STORE_X_BF16) ? 1 : 0;   // x as bf16 in HBM (bf16 kernels only: opts_storage)
+  if (b.bf16 && P < 16) return GB_EINVAL;                     // (reductions below 16 stay on the fp32 instruction)
   const long long tiles = (long long)((N + (N <= 64 ? 63 : 127)) / (N <= 64 ? 64 : 128)) *
                           ((K + (K <= 64 ? 63 : 127)) / (K <= 64 ? 64 : 128));
   // split the P reduction so that ~1024 workgroups exist, chunks a multiple of the reduction step
@@ -727,7 +758,7 @@ extern "C" int gb_gemm_wgrad(const float *dy, const float *x, const float *x_aff
   chunks = (P + kchunk - 1) / kchunk;
   if (chunks > 65535) return GB_ERANGE;
   const bool va = (N % 4 == 0) && aligned16(dy);
-  const bool vb = (K % 4 == 0) && aligned16(x);
+  const bool vb = (K % 4 == 0) && aligned16(x);   // (8-byte vector loads of a bf16 x need no more than that)
   launch_gemm<OP_RC, OP_RC, EPI_ATOMIC>(a, b, va, vb, dw, K, nullptr, kchunk, (unsigned)chunks, as_stream(stream),
                                         opts_bf16(opts));
   return check_launch("gb_gemm_wgrad");
@@ -740,6 +771,7 @@ extern "C" int gb_gemm_wgrad(const float *dy, const float *x, const float *x_aff
 extern "C" int gb_gemm_gram(const float *x, const float *x_aff, const float *row_w, float *gmat, long long P, int K,
                             const GbGemmOpts *opts, void *stream) {
   if (P < 0 || K < 1 || !x || !gmat || opts_bad(opts)) return GB_EINVAL;
+  if (opts_storage(opts)) return GB_EINVAL;  // this entry reads and writes fp32 tensors only
   if (P == 0) return GB_OK;
   Operand a = {x, K, P, K, x_aff, row_w};
   Operand b = {x, K, P, K, x_aff, nullptr};
@@ -773,6 +805,7 @@ extern "C" int gb_gemm_dgrad_first(const float *dy, const float *w, const float 
                                    const GbGemmOpts *opts, void *stream) {
   if (P < 0 || K < 1 || N < 1 || !dy || !w || !y_prev || !ab_prev || !x_in || !sums || slots < 1 || opts_bad(opts))
     return GB_EINVAL;
+  if (opts_storage(opts)) return GB_EINVAL;  // this entry reads and writes fp32 tensors only
   if (P == 0) return GB_OK;
   if (!rs_gemm_try(dy, w, nullptr, nullptr, sums, slots, y_prev, ab_prev, P, N, K, 0, RS_BNBWD_X, as_stream(stream),
                    opts_bf16(opts), opts_reserved(opts), x_in))
@@ -787,6 +820,7 @@ extern "C" int gb_gemm_dgrad_first_gen3(const float *dy, const float *w, const f
                                         const GbGemmOpts *opts, void *stream) {
   if (P < 0 || K < 1 || N < 1 || !dy || !w || !ab_prev || !x_in || !w_in || !sums || slots < 1 || opts_bad(opts))
     return GB_EINVAL;
+  if (opts_storage(opts)) return GB_EINVAL;  // this entry reads and writes fp32 tensors only
   if (P == 0) return GB_OK;
   RsPool gen = {};
   gen.gen_w = w_in;

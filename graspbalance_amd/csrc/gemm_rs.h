@@ -27,6 +27,7 @@ struct RsPool {
   const float *gen_w = nullptr;    // ... and this 3-input first-layer weight (R,3) / (C,3)
   const float *lr_v = nullptr;     // RS_BNBWD_LR: v (C)
   const float *lr_roww = nullptr;  // RS_BNBWD_LR: w (P rounded up to 32 readable floats)
+  int storage = 0;                 // GbGemmOpts.storage (GB_STORE_*_BF16): bf16 precision only
 };
 
 bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, double *stats, int slots,

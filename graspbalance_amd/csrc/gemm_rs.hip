@@ -55,6 +55,7 @@ struct RsArgs {
   int slots, nch;       // statistics slot rows ; chunks = ceil(R / 32)
   int stagger;          // delay waves 4-7 by half a tile
   int tail_split;       // cut the tiles of a short last round into column groups
+  int storage;          // BF kernels only: GB_STORE_X_BF16 (a), GB_STORE_Y_BF16 (d), GB_STORE_YPREV_BF16 (epi_y) are bf16 in HBM
 };
 
 // BF (GB_PREC_BF16): B lives in LDS as bf16 in [k / 8][C32][8] order - the 8 reduction indices one lane feeds to a
@@ -65,7 +66,9 @@ __device__ __forceinline__ float lin3(float x, float y, float z, float w0, float
   return ((x * w0) + (y * w1)) + (z * w2);   // the ONE evaluation order every consumer of the folded layer uses
 }
 
-template <int NT, int EPI, bool BF = false, bool GEN3 = false>
+// ST (bf16 kernels): GbGemmOpts.storage as a COMPILE-TIME mode - which of a / d / epi_y are bf16 in HBM.  (As run-time
+// branches the two load / store forms tripled the spills of the bf16 instantiations: <8,1> 78 -> 236 registers.)
+template <int NT, int EPI, bool BF = false, bool GEN3 = false, int ST = 0>
 __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_BNBWD_X && EPI != RS_BNBWD_LR) ? 4 : 2)) void gemm_rs_kernel(RsArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int C32 = NT * 32;
@@ -198,11 +201,53 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
       return;
     }
     const int k = kc * RS_CH + h * 16;
+    if constexpr (BF) {
+      if constexpr ((ST & GB_STORE_X_BF16) != 0) {  // the row's 16 values are 32 bytes of bf16: two 16-byte loads, widened
+        const uint16_t *pb = reinterpret_cast<const uint16_t *>(g.a) + row * g.lda + k;
+        uint4 u[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+        if (row < g.P && k < g.R) {
+          u[0] = *reinterpret_cast<const uint4 *>(pb);
+          u[1] = *reinterpret_cast<const uint4 *>(pb + 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          dst[2 * i] = make_float4(__uint_as_float(u[i].x << 16), __uint_as_float(u[i].x & 0xFFFF0000u),
+                                   __uint_as_float(u[i].y << 16), __uint_as_float(u[i].y & 0xFFFF0000u));
+          dst[2 * i + 1] = make_float4(__uint_as_float(u[i].z << 16), __uint_as_float(u[i].z & 0xFFFF0000u),
+                                       __uint_as_float(u[i].w << 16), __uint_as_float(u[i].w & 0xFFFF0000u));
+        }
+        return;
+      }
+    }
     const float *p = g.a + row * g.lda + k;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       dst[i] = (row < g.P && k + 4 * i < g.R) ? *reinterpret_cast<const float4 *>(p + 4 * i)
                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  // activation tensors that may live in HBM as bf16 (BF kernels, GbGemmOpts.storage): element offset -> value
+  auto st_d = [&](long long off, float v) {
+    if constexpr (BF) {
+      if constexpr ((ST & GB_STORE_Y_BF16) != 0) {
+        reinterpret_cast<__bf16 *>(g.d)[off] = (__bf16)v;
+        return;
+      }
+    }
+    g.d[off] = v;
+  };
+  auto ld_y = [&](long long off) -> float {
+    if constexpr (BF) {
+      if constexpr ((ST & GB_STORE_YPREV_BF16) != 0)
+        return __uint_as_float((unsigned)reinterpret_cast<const uint16_t *>(g.epi_y)[off] << 16);
+    }
+    return g.epi_y[off];
+  };
+  // the value a bf16-stored output will be read back as (statistics and pooled extrema describe THAT)
+  auto rnd_d = [&](float v) -> float {
+    if constexpr (BF) {
+      if constexpr ((ST & GB_STORE_Y_BF16) != 0) return (float)(__bf16)v;
+    }
+    return v;
   };
 
   // The two waves that share a SIMD (w and w+4) run the same program from the same start and would reach their
@@ -305,7 +350,7 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
               for (int r = 0; r < 16; ++r) {
                 const long long row = tile * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
                 const int col = q * 32 + m;
-                yv[q][r] = (col < g.C && row < g.P) ? g.epi_y[row * g.ldd + col] : 0.f;
+                yv[q][r] = (col < g.C && row < g.P) ? ld_y(row * g.ldd + col) : 0.f;
               }
             }
         }
@@ -375,7 +420,8 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
             float cs = 0.f, cq = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const float v = acc[q][r];
+              const float v = rnd_d(acc[q][r]);
+              acc[q][r] = v;
               const float wv = (float)((rk[r] >> 4) & 0x1FF) * v;
               cs += wv;
               cq += wv * v;
@@ -385,8 +431,8 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
             if (g.d) {  // keep Y for the backward (rows >= P are not stored)
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
-                float *dp = g.d + (trow + (r & 3) + 8 * (r >> 2)) * (long long)g.ldd + q * 32;  // wave-uniform
-                if ((r & 3) + 8 * (r >> 2) < nrow) dp[lane_off] = acc[q][r];
+                const long long ro = (trow + (r & 3) + 8 * (r >> 2)) * (long long)g.ldd + q * 32;  // wave-uniform
+                if ((r & 3) + 8 * (r >> 2) < nrow) st_d(ro + lane_off, acc[q][r]);
               }
             }
             const float sg = g.epi_gamma[q * 32 + m] < 0.f ? -1.f : 1.f;
@@ -528,17 +574,20 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
             if constexpr (BNB && !YPRE) {
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
-                const float *yp = g.epi_y + (trow + (r & 3) + 8 * (r >> 2)) * (long long)g.ldd + q * 32;
-                yq[r] = yp[lane_off];
+                yq[r] = ld_y((trow + (r & 3) + 8 * (r >> 2)) * (long long)g.ldd + q * 32 + lane_off);
               }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               float v = acc[q][r];
               if constexpr (LR) v = din[r] - lw[r] * (v + lv);
+              if constexpr (EPI == RS_STATS) v = rnd_d(v);
               if constexpr (EPI != RS_BNBWD_X) {
-                float *dp = g.d + (trow + (r & 3) + 8 * (r >> 2)) * (long long)g.ldd + q * 32;  // wave-uniform
-                dp[lane_off] = v;
+                if constexpr (EPI == RS_STATS) st_d((trow + (r & 3) + 8 * (r >> 2)) * (long long)g.ldd + q * 32 + lane_off, v);
+                else {
+                  float *dp = g.d + (trow + (r & 3) + 8 * (r >> 2)) * (long long)g.ldd + q * 32;  // wave-uniform
+                  dp[lane_off] = v;
+                }
               }
               if constexpr (EPI == RS_STATS) {
                 if (weighted) {
@@ -590,7 +639,7 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const long long row = row0 + (r & 3) + 8 * (r >> 2);
-              yq[r] = (colok && row < g.P) ? g.epi_y[row * g.ldd + col] : 0.f;
+              yq[r] = (colok && row < g.P) ? ld_y(row * g.ldd + col) : 0.f;
             }
           }
 #pragma unroll
@@ -599,7 +648,8 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
             float v = acc[q][r];
             if (colok && row < g.P) {
               if constexpr (LR) v = g.d[row * g.ldd + col] - g.lr_roww[row] * (v + g.lr_v[col]);
-              if constexpr (EPI != RS_BNBWD_X) g.d[row * g.ldd + col] = v;  // _X: D itself is not needed
+              if constexpr (EPI == RS_STATS) { v = rnd_d(v); st_d(row * g.ldd + col, v); }
+              else if constexpr (EPI != RS_BNBWD_X) g.d[row * g.ldd + col] = v;  // _X: D itself is not needed
               if constexpr (EPI == RS_STATS) {
                 if (g.epi_w16) {  // the row stands for `mult` identical rows of the original batch
                   const unsigned pk = (r & 2) ? wq[r >> 2].y : wq[r >> 2].x;
@@ -697,10 +747,10 @@ static int num_cus(int reserved) {
   return (reserved > 0 && n - reserved >= 16) ? n - reserved : n;
 }
 
-template <int NT, int EPI, bool BF, bool GEN3 = false>
+template <int NT, int EPI, bool BF, bool GEN3 = false, int ST = 0>
 static void rs_launch_p(const RsArgs &g, size_t lds_bytes, int blocks_per_cu, hipStream_t s, int reserved) {
   static std::atomic<unsigned long long> attr_set{0};
-  auto kern = gemm_rs_kernel<NT, EPI, BF, GEN3>;
+  auto kern = gemm_rs_kernel<NT, EPI, BF, GEN3, ST>;
   allow_dynamic_lds(kern, 160 * 1024, attr_set);
   const long long ntiles = (g.P + 31) / 32;
   long long blocks = ntiles;  // at least one tile per workgroup; all 512 threads stage B either way
@@ -718,6 +768,19 @@ static void rs_launch(const RsArgs &g, size_t lds_bytes, int blocks_per_cu, hipS
     size_t need = lds_bytes - b_fp32 / 2;
     const size_t red = (size_t)RS_WAVES * (EPI == RS_BNBWD_X ? 5 : 2) * NT * 32 * sizeof(double);
     if (EPI != RS_STORE && need < red) need = red;
+    // the storage modes that exist (rs_gemm_try has checked g.storage against this list): the folded second layer
+    // stores bf16; the pooled last layer reads bf16 rows and may store bf16; dgrad re-reads a bf16 y_prev
+    constexpr int X = GB_STORE_X_BF16, Y = GB_STORE_Y_BF16, YP = GB_STORE_YPREV_BF16;
+    if constexpr (EPI == RS_STATS && GEN3) {
+      if (g.storage == Y) return rs_launch_p<NT, EPI, true, GEN3, Y>(g, need, blocks_per_cu, s, reserved);
+    }
+    if constexpr (EPI == RS_STATS_POOL_V) {
+      if (g.storage == X) return rs_launch_p<NT, EPI, true, GEN3, X>(g, need, blocks_per_cu, s, reserved);
+      if (g.storage == (X | Y)) return rs_launch_p<NT, EPI, true, GEN3, X | Y>(g, need, blocks_per_cu, s, reserved);
+    }
+    if constexpr (EPI == RS_BNBWD) {
+      if (g.storage == YP) return rs_launch_p<NT, EPI, true, GEN3, YP>(g, need, blocks_per_cu, s, reserved);
+    }
     rs_launch_p<NT, EPI, true, GEN3>(g, need, blocks_per_cu, s, reserved);
   } else {
     rs_launch_p<NT, EPI, false, GEN3>(g, lds_bytes, blocks_per_cu, s, reserved);
@@ -758,7 +821,20 @@ bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, dou
   RsArgs g = {a, w, d, aff, stats, epi_y, epi_ab, epi_x, epi_w16, pool ? pool->key : nullptr,
               pool ? pool->gamma : nullptr, pool ? pool->pairs : nullptr, pool ? pool->D : 0,
               pool ? pool->gen_x : nullptr, pool ? pool->gen_w : nullptr,
-              pool ? pool->lr_v : nullptr, pool ? pool->lr_roww : nullptr, P, R, C, R, C, w_kc, slots < 1 ? 1 : slots, nch, stagger, tail_split};
+              pool ? pool->lr_v : nullptr, pool ? pool->lr_roww : nullptr, P, R, C, R, C, w_kc, slots < 1 ? 1 : slots, nch, stagger, tail_split, 0};
+  if (pool && pool->storage) {
+    // bf16 tensors in HBM: only the bf16 kernels read / write them, only these epilogues store or re-read an activation,
+    // and the 16-byte loads of a bf16 row need a reduction length and pitch of whole 8-element groups
+    const int st = pool->storage;
+    if (!bf16) return false;
+    const bool gen = pool->gen_x && epi == RS_STATS;
+    const bool ok = (gen && st == GB_STORE_Y_BF16) ||
+                    (epi == RS_STATS_POOL_V && (st == GB_STORE_X_BF16 || st == (GB_STORE_X_BF16 | GB_STORE_Y_BF16)) &&
+                     R % 16 == 0) ||
+                    (epi == RS_BNBWD && st == GB_STORE_YPREV_BF16);   // = the instantiations of rs_launch
+    if (!ok) return false;
+    g.storage = st;
+  }
   const bool gen3 = pool && pool->gen_x && epi == RS_STATS;
   if (gen3) {  // the A operand is generated from (P,3) rows and a per-k table: 16 more bytes of LDS per reduction index
     if (!aff || !pool->gen_w || (nt != 2 && nt != 4)) return false;

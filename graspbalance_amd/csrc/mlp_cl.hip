@@ -154,6 +154,18 @@ __device__ __forceinline__ void load_vec(const float *p, float *v) {
   }
 }
 
+// 4 consecutive elements of an activation tensor that lives in HBM as fp32 or (bf16 = 1: GbGemmOpts.storage of the GEMM that
+// wrote it) as bf16; idx = element index (a multiple of 4, rows of whole 4-element groups)
+__device__ __forceinline__ void load_act4(const float *p, long long idx, int bf16, float *v) {
+  if (bf16) {
+    const uint2 u = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(p) + idx);
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xFFFF0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xFFFF0000u);
+  } else {
+    load_vec<4>(p + idx, v);
+  }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(CL_TPB) void col_stats_kernel(const float *__restrict__ y, long long P, int C, int rpb,
                                                             double *__restrict__ sum, double *__restrict__ sumsq) {
@@ -617,7 +629,8 @@ __global__ __launch_bounds__(CL_TPB) void bn_bwd_apply_members_kernel(
     const float *__restrict__ dout, const float *__restrict__ out, const int32_t *__restrict__ arg,
     const float *__restrict__ y, const float *__restrict__ ab, const double *__restrict__ dstats,
     const float *__restrict__ row_w, const int64_t *__restrict__ off, const int32_t *__restrict__ cnt, long long R,
-    int C, double invP, int training, float *__restrict__ dy, const int32_t *__restrict__ row_mem = nullptr) {
+    int C, double invP, int training, float *__restrict__ dy, const int32_t *__restrict__ row_mem = nullptr,
+    int y_bf16 = 0) {
   const int tpg = C / 4, gpb = CL_TPB / tpg;
   const long long r = (long long)blockIdx.x * gpb + threadIdx.x / tpg;
   if (threadIdx.x / tpg >= gpb || r >= R) return;
@@ -652,7 +665,7 @@ __global__ __launch_bounds__(CL_TPB) void bn_bwd_apply_members_kernel(
       // unconditional loads from a clamped row index: under `if (u + q < u1)` the four loads were waited for one
       // by one (295 -> 180 us per launch)
       const long long uu = u + q < u1 ? u + q : u1 - 1;
-      load_vec<4>(y + uu * C + c, v[q]);
+      load_act4(y, uu * C + c, y_bf16, v[q]);
       w[q] = row_w[uu];
       mb[q] = BYVAL ? row_mem[uu] : 0;
     }
@@ -690,7 +703,7 @@ __global__ __launch_bounds__(CL_TPB) void bn_bwd_apply_w_kernel(const float *__r
                                                                  const double *__restrict__ dstats,
                                                                  const float *__restrict__ row_w, long long rows, int C,
                                                                  double invP, int training, float *__restrict__ dy,
-                                                                 int rows_per_block) {
+                                                                 int rows_per_block, int y_bf16) {
   const int tpr = C / 4, rpp = CL_TPB / tpr;
   const int cg = threadIdx.x % tpr, rl = threadIdx.x / tpr;
   if (rl >= rpp) return;
@@ -714,7 +727,7 @@ __global__ __launch_bounds__(CL_TPB) void bn_bwd_apply_w_kernel(const float *__r
     for (int u = 0; u < 4; ++u) {
       const long long rr = r + (long long)u * rpp;
       if (rr < r1) {
-        load_vec<4>(y + rr * C + c, yy[u]);
+        load_act4(y, rr * C + c, y_bf16, yy[u]);
         load_vec<4>(dout + rr * C + c, g[u]);
         w[u] = row_w[rr];
       }
@@ -1079,7 +1092,7 @@ extern "C" int gb_pool_pairs(const float *pairs, const int64_t *off, const int32
 static int apply_members_impl(const float *dout, const float *out, const int32_t *arg, const float *ystar, const float *y,
                               const float *ab, const double *dstats, const float *row_w, const int32_t *row_mem,
                               const int64_t *off, const int32_t *cnt, long long R, int D, int C, long long P_total,
-                              int training, float *dy, void *stream) {
+                              int training, float *dy, void *stream, int y_bf16 = 0) {
   const void *sel = arg ? static_cast<const void *>(arg) : static_cast<const void *>(ystar);
   if (!dout || !out || !sel || !y || !ab || !row_w || !off || !cnt || !dy || (training && !dstats) || P_total < 1 ||
       (!arg && !row_mem) || !members_ok(R, D, C, dout, out, sel, y) ||
@@ -1092,9 +1105,9 @@ static int apply_members_impl(const float *dout, const float *out, const int32_t
 #define GB_MB(D_)                                                                                                          \
   do {                                                                                                                     \
     if (arg) hipLaunchKernelGGL((bn_bwd_apply_members_kernel<D_, false>), grid, dim3(CL_TPB), 0, as_stream(stream), dout, out, \
-                                sel32, y, ab, dstats, row_w, off, cnt, R, C, 1.0 / (double)P_total, training, dy, row_mem);     \
+                                sel32, y, ab, dstats, row_w, off, cnt, R, C, 1.0 / (double)P_total, training, dy, row_mem, y_bf16);     \
     else hipLaunchKernelGGL((bn_bwd_apply_members_kernel<D_, true>), grid, dim3(CL_TPB), 0, as_stream(stream), dout, out,      \
-                            sel32, y, ab, dstats, row_w, off, cnt, R, C, 1.0 / (double)P_total, training, dy, row_mem);         \
+                            sel32, y, ab, dstats, row_w, off, cnt, R, C, 1.0 / (double)P_total, training, dy, row_mem, y_bf16);         \
   } while (0)
   if (D == 1) GB_MB(1); else if (D == 2) GB_MB(2); else GB_MB(4);
 #undef GB_MB
@@ -1121,9 +1134,20 @@ extern "C" int gb_bn_bwd_apply_members_v(const float *dout, const float *out, co
                             dy, stream);
 }
 
-extern "C" int gb_bn_bwd_apply_w(const float *dout, const float *y, const float *ab, const double *dstats,
-                                 const float *row_w, long long rows, long long P_total, int C, int training, float *dy,
-                                 void *stream) {
+// gb_bn_bwd_apply_members_v whose y lives in HBM as bf16 (y_bf16 = 1: written by a gb_gemm_fwd_pool call with
+// GB_STORE_Y_BF16, whose pooled extrema ystar are those of the rounded values - the by-value search stays exact)
+extern "C" int gb_bn_bwd_apply_members_vs(const float *dout, const float *out, const float *ystar, const float *y,
+                                          int y_bf16, const float *ab, const double *dstats, const float *row_w,
+                                          const int32_t *row_mem, const int64_t *off, const int32_t *cnt, long long R, int D,
+                                          int C, long long P_total, int training, float *dy, void *stream) {
+  if (!ystar || (y_bf16 != 0 && y_bf16 != 1)) return GB_EINVAL;
+  return apply_members_impl(dout, out, nullptr, ystar, y, ab, dstats, row_w, row_mem, off, cnt, R, D, C, P_total, training,
+                            dy, stream, y_bf16);
+}
+
+static int apply_w_impl(const float *dout, const float *y, int y_bf16, const float *ab, const double *dstats,
+                        const float *row_w, long long rows, long long P_total, int C, int training, float *dy,
+                        void *stream) {
   if (rows < 0 || P_total < 1 || C < 4 || C % 4 != 0 || C / 4 > CL_TPB || !dout || !y || !ab || !row_w || !dy ||
       (training && !dstats))
     return GB_EINVAL;
@@ -1135,8 +1159,22 @@ extern "C" int gb_bn_bwd_apply_w(const float *dout, const float *y, const float 
   long long rpb = (rows + 4095) / 4096;
   rpb = (rpb + 4 * rpp - 1) / (4 * rpp) * (4 * rpp);
   hipLaunchKernelGGL(bn_bwd_apply_w_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(CL_TPB), 0, as_stream(stream),
-                     dout, y, ab, dstats, row_w, rows, C, 1.0 / (double)P_total, training, dy, (int)rpb);
+                     dout, y, ab, dstats, row_w, rows, C, 1.0 / (double)P_total, training, dy, (int)rpb, y_bf16);
   return check_launch("gb_bn_bwd_apply_w");
+}
+
+extern "C" int gb_bn_bwd_apply_w(const float *dout, const float *y, const float *ab, const double *dstats,
+                                 const float *row_w, long long rows, long long P_total, int C, int training, float *dy,
+                                 void *stream) {
+  return apply_w_impl(dout, y, 0, ab, dstats, row_w, rows, P_total, C, training, dy, stream);
+}
+
+// ... with y in HBM as bf16 (y_bf16 = 1: the output of a GEMM call with GB_STORE_Y_BF16)
+extern "C" int gb_bn_bwd_apply_ws(const float *dout, const float *y, int y_bf16, const float *ab, const double *dstats,
+                                  const float *row_w, long long rows, long long P_total, int C, int training, float *dy,
+                                  void *stream) {
+  if (y_bf16 != 0 && y_bf16 != 1) return GB_EINVAL;
+  return apply_w_impl(dout, y, y_bf16, ab, dstats, row_w, rows, P_total, C, training, dy, stream);
 }
 
 extern "C" int gb_bn_bwd_stats_pool(const float *dout, const float *out, const int32_t *arg, const float *y,

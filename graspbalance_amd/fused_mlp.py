@@ -123,16 +123,17 @@ def _prec():
     return getattr(_tls, "prec", _lib.PREC_F32)
 
 
-def _opts(dev, st, prec):
-    """ctypes pointer to the GbGemmOpts of a launch on stream `st` (c_void_p) of `dev` at precision code `prec`."""
-    key = (dev.index, st.value, prec, _RESERVED_CUS)
+def _opts(dev, st, prec, storage=0):
+    """ctypes pointer to the GbGemmOpts of a launch on stream `st` (c_void_p) of `dev` at precision code `prec`;
+    storage: GB_STORE_*_BF16 bits (which activation tensors of the call live in HBM as bf16; bf16 precision only)."""
+    key = (dev.index, st.value, prec, _RESERVED_CUS, storage)
     o = _OPTS.get(key)
     if o is None:
         wkey = (dev.index, st.value)
         ws = _WORKSPACES.get(wkey)
         if ws is None:
             ws = _WORKSPACES[wkey] = torch.empty(_lib.GEMM_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
-        o = _OPTS[key] = (ctypes.pointer(_lib.GemmOpts(prec, _RESERVED_CUS, ws.data_ptr(), ws.numel())), ws)
+        o = _OPTS[key] = (ctypes.pointer(_lib.GemmOpts(prec, _RESERVED_CUS, ws.data_ptr(), ws.numel(), storage)), ws)
     return o[0]
 
 
@@ -488,6 +489,11 @@ class MLPStack(Function):
                 and (L > 2 or not (rows is not None and rows.key is not None and _CROP_POOL))
                 and bool(_lib.lib().gb_gemm_uses_rs(P, widths[0], widths[1], 0, 1, 1))
                 and bool(_lib.lib().gb_gemm_uses_rs(P, widths[0], widths[1], 1, 2, 0)))
+        # bf16 storage mode: the stored outputs Y1 (gb_gemm_fwd_gen3) and Y2 (gb_gemm_fwd_pool) of a crop stack are bf16
+        s16 = bool(prec == _lib.PREC_BF16 and _BF16_STORE and fold and L == 3 and rows is not None and rows.key is not None
+                   and _CROP_POOL and not _CROP_LOWRANK and widths[1] % 16 == 0
+                   and _lib.lib().gb_gemm_uses_rs(P, widths[1], widths[2], 0, 3, 1))
+        ydt = torch.bfloat16 if s16 else torch.float32
         mom0 = None
         for l, cfg in enumerate(layers):
             W = params[3 * l].contiguous()
@@ -512,12 +518,13 @@ class MLPStack(Function):
                 src, aff = None, ab
                 continue
             if fold and l == 1:
-                Y = _empty_rows(P, N, dev, rows is not None)
+                Y = _empty_rows(P, N, dev, rows is not None, ydt)
                 fin = _bn_fin(cfg, gamma, beta, ab, P_stat) if cfg.training else None
                 st_buf, st_slots = (stats, slots) if cfg.training else (_zeros64(2 * N, dev), 1)
                 _call("gb_gemm_fwd_gen3", dev, _lib.ptr(X0), _lib.ptr(Ws[0]), _lib.ptr(aff), _lib.ptr(W),
                       _lib.ptr(rows.w16 if rows is not None else None), _lib.ptr(Y), _lib.ptr(st_buf), st_slots, P, K, N,
-                      fin, opts, st, meta=_gemm_meta("fwd", P, K, N, True, True))
+                      fin, _opts(dev, st, prec, _lib.STORE_Y_BF16) if s16 else opts, st,
+                      meta=_gemm_meta("fwd", P, K, N, True, True))
                 if fin is None:
                     ab = _eval_ab(gamma, beta, cfg.running_mean, cfg.running_var, cfg.eps, N, dev, st)
                 Ws.append(W); Ys.append(Y); abs_.append(ab)
@@ -531,10 +538,13 @@ class MLPStack(Function):
                 lowrank = (_CROP_LOWRANK and l >= 1 and _lib.lib().gb_crop_bwd_ok(K, N, rows.D)
                            and _lib.lib().gb_gemm_uses_rs(P, K, K, 1, 1, 1))
                 fwd_only = not any(ctx.needs_input_grad)   # inference: the layer's output is not stored at all
-                Y = None if (lowrank or fwd_only) else _empty_rows(P, N, dev, True)
+                Y = None if (lowrank or fwd_only) else _empty_rows(P, N, dev, True, ydt)
                 if not cfg.training:
                     ab = _eval_ab(gamma, beta, cfg.running_mean, cfg.running_var, cfg.eps, N, dev, st)
-                pooled = _pooled_last_layer(dev, st, opts, src, W, aff, gamma, beta, cfg, ab, stats, slots, rows, P, K, N,
+                popts = opts
+                if s16:   # its rows operand (Y1) is bf16, and so is its stored output
+                    popts = _opts(dev, st, prec, _lib.STORE_X_BF16 | (_lib.STORE_Y_BF16 if Y is not None else 0))
+                pooled = _pooled_last_layer(dev, st, popts, src, W, aff, gamma, beta, cfg, ab, stats, slots, rows, P, K, N,
                                             P_stat, Y, with_rows=(Y is None and not fwd_only))
                 Ws.append(W); Ys.append(Y); abs_.append(ab)
                 break
@@ -560,6 +570,7 @@ class MLPStack(Function):
         ctx.pooled = rows is not None and Ys[-1] is None
         ctx.by_value = False
         ctx.fold = fold
+        ctx.s16 = s16
         ctx.mom0 = mom0
         if not all(c.training for c in layers):
             # eval-mode layers use cached tables (_eval_ab), not slices of the arena: a backward through this node (rare:
@@ -711,9 +722,9 @@ class MLPStack(Function):
             # the crops' extreme y* are saved: the BatchNorm-backward sums need no gather from the layer's output
             _call("gb_bn_bwd_stats", dev, _lib.ptr(dout), _lib.ptr(ystar), _lib.ptr(abs_[-1]), None, RD, N, 1,
                   _lib.ptr(dstats), pb, pg, st)
-            _call("gb_bn_bwd_apply_members_v", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(ystar), _lib.ptr(Ys[-1]),
-                  _lib.ptr(abs_[-1]), _lib.ptr(dstats), _lib.ptr(rows.w), _lib.ptr(rows.mem), _lib.ptr(rows.off),
-                  _lib.ptr(rows.cnt), rows.R, rows.D, N, P_stat, int(training[-1]), _lib.ptr(dY), st)
+            _call("gb_bn_bwd_apply_members_vs", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(ystar), _lib.ptr(Ys[-1]),
+                  int(ctx.s16), _lib.ptr(abs_[-1]), _lib.ptr(dstats), _lib.ptr(rows.w), _lib.ptr(rows.mem),
+                  _lib.ptr(rows.off), _lib.ptr(rows.cnt), rows.R, rows.D, N, P_stat, int(training[-1]), _lib.ptr(dY), st)
         elif rows is not None:
             out, arg = s1, s2
             _call("gb_bn_bwd_stats_pool", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(Ys[-1]),
@@ -748,7 +759,8 @@ class MLPStack(Function):
                     _call("gb_gemm_wgrad_gen3", dev, _lib.ptr(dY), _lib.ptr(X0), _lib.ptr(Ws[0]), _lib.ptr(aff), _lib.ptr(dW), P,
                           K, N, opts, st, meta=_gemm_meta("wgrad", P, K, N, aff=True))
                 else:
-                    _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(src), _lib.ptr(aff), _lib.ptr(dW), P, K, N, opts, st,
+                    _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(src), _lib.ptr(aff), _lib.ptr(dW), P, K, N,
+                          _opts(dev, st, ctx.prec, _lib.STORE_X_BF16) if (ctx.s16 and l >= 1) else opts, st,
                           meta=_gemm_meta("wgrad", P, K, N, aff=aff is not None))
                 grads[3 * l] = dW.view(N, K)
             if l == 0:
@@ -795,7 +807,8 @@ class MLPStack(Function):
                 emit = slots == 1 and rows is None
                 _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dZ), _lib.ptr(Ys[l - 1]),
                       _lib.ptr(abs_[l - 1]), _lib.ptr(region), slots, P, K, N, None if emit else _lib.ptr(dstats),
-                      None if emit else _lib.ptr(dbeta), None if emit else _lib.ptr(dgamma), opts, st,
+                      None if emit else _lib.ptr(dbeta), None if emit else _lib.ptr(dgamma),
+                      _opts(dev, st, ctx.prec, _lib.STORE_YPREV_BF16) if ctx.s16 else opts, st,
                       meta=_gemm_meta("dgrad", P, K, N, fused=True))
             else:
                 # wide + long outputs: the fused epilogue measured slower than a separate column pass
@@ -806,8 +819,8 @@ class MLPStack(Function):
                       _lib.ptr(dstats), _lib.ptr(dbeta), _lib.ptr(dgamma), st)
             dY = _empty_rows(P, K, dev, rows is not None)
             if rows is not None:
-                _call("gb_bn_bwd_apply_w", dev, _lib.ptr(dZ), _lib.ptr(Ys[l - 1]), _lib.ptr(abs_[l - 1]), _lib.ptr(dstats),
-                      _lib.ptr(rows.w), P, P_stat, K, int(training[l - 1]), _lib.ptr(dY), st)
+                _call("gb_bn_bwd_apply_ws", dev, _lib.ptr(dZ), _lib.ptr(Ys[l - 1]), int(ctx.s16), _lib.ptr(abs_[l - 1]),
+                      _lib.ptr(dstats), _lib.ptr(rows.w), P, P_stat, K, int(training[l - 1]), _lib.ptr(dY), st)
             elif emit:
                 _call("gb_bn_bwd_apply_g", dev, _lib.ptr(dZ), _lib.ptr(Ys[l - 1]), _lib.ptr(abs_[l - 1]), None,
                       _lib.ptr(dstats), P, K, 1, int(training[l - 1]), _lib.ptr(dY), None, _lib.ptr(dbeta),
@@ -828,6 +841,25 @@ class MLPStack(Function):
 #                      Correct to 1e-6 of the dense backward (tests), but its sparse kernel is bound by LDS float
 #                      atomics (164 clocks per wave instruction measured) and loses 2.5 ms per launch: opt-in until
 #                      that kernel is rebuilt without them
+# bf16 precision, OPT-IN (GB_BF16_STORE=1 / set_bf16_storage(True)): the crop stacks' stored pre-BatchNorm outputs
+# (0.8 M x 128 and x 256 per radius at configs[4]: the largest activations of the step) live in HBM as bf16
+# (GbGemmOpts.storage).  Gradients, statistics, parameters, geometry and every other tensor stay fp32.  Correct and
+# tested (tests/test_bf16_gpu.py), but as first built it is SLOWER: configs[4] 28.9 -> 30.1 ms per step (gemm_rs 5.5 ->
+# 6.4 ms, gemm_cl 8.0 -> 8.4): with the accumulator layout of the 32 x 32 MFMA a lane stores / re-reads ONE 2-byte
+# element per instruction (64-byte half lines, store-issue bound) and the split-K wgrad loads 8 bytes per lane instead
+# of 16.  It needs pair-packed stores (a DPP exchange between neighbouring lanes, two column tiles per 128-byte line)
+# and 8-element operand loads before it pays: DESIGN.md section 9.
+_BF16_STORE = os.environ.get("GB_BF16_STORE", "0") == "1"
+
+
+def set_bf16_storage(flag):
+    """-> previous setting."""
+    global _BF16_STORE
+    prev = _BF16_STORE
+    _BF16_STORE = bool(flag)
+    return prev
+
+
 _CROP_POOL = os.environ.get("GB_CROP_POOL", "1") != "0"
 _CROP_LOWRANK = os.environ.get("GB_CROP_LOWRANK", "0") == "1"
 
@@ -876,6 +908,7 @@ def _arg_rows_by_value(Y, ystar, rows):
     column) the first member row whose y equals y* - as gb_affine_relu_maxpool_members would name them."""
     R, D, C = rows.R, rows.D, Y.shape[1]
     P = Y.shape[0]
+    Y = Y.float()   # (bf16 storage mode: exact widening - y* are those rounded values)
     seed = torch.repeat_interleave(torch.arange(R, device=Y.device), rows.cnt.long(), output_size=P)
     rowidx = torch.arange(P, device=Y.device, dtype=torch.int64).unsqueeze(1).expand(P, C)
     ys = ystar.view(R, D, C)
@@ -892,6 +925,7 @@ def _arg_rows_by_value(Y, ystar, rows):
 
 def _observed_ys(Ys, X0, Ws):
     """routing_observer helper: the folded first layer's output, re-formed exactly as the kernels do."""
+    Ys = [y.float() if (y is not None and y.dtype != torch.float32) else y for y in Ys]
     if Ys[0] is not None:
         return Ys
     W1 = Ws[0]
@@ -1049,14 +1083,14 @@ def _count_batch(bn):
 _ROW_QUANTUM = 32768
 
 
-def _empty_rows(P, C, dev, quantised):
-    """(P, C) fp32 activation buffer.  With `quantised` (row counts that change from step to step: the distinct rows
+def _empty_rows(P, C, dev, quantised, dtype=torch.float32):
+    """(P, C) activation buffer (fp32; bf16 for the stored outputs of the bf16 storage mode).  With `quantised` (row counts that change from step to step: the distinct rows
     of the cylinder crops) the allocation is rounded up to a multiple of 32768 rows, so the caching allocator sees
     the same few sizes every step instead of a new one (a new size means a fresh hipMalloc - a device sync)."""
     if not quantised:
-        return torch.empty((P, C), dtype=torch.float32, device=dev)
+        return torch.empty((P, C), dtype=dtype, device=dev)
     cap = (P + _ROW_QUANTUM - 1) // _ROW_QUANTUM * _ROW_QUANTUM
-    return torch.empty((cap, C), dtype=torch.float32, device=dev)[:P]
+    return torch.empty((cap, C), dtype=dtype, device=dev)[:P]
 
 
 class RowSet:

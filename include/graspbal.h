@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GB_ABI_VERSION 3
+#define GB_ABI_VERSION 4
 
 enum {
   GB_OK = 0,
@@ -273,11 +273,25 @@ int gb_group_concat_cl_grad(const float *dx0, const int32_t *idx, float *dfeat, 
 #define GB_PREC_F32 0
 #define GB_PREC_BF16 1
 #define GB_GEMM_SCRATCH_BYTES (320ull * 64 * 128 * 4)
+/*   storage     : (GB_PREC_BF16 only) which activation tensors of THIS call live in HBM as bf16 instead of fp32 - the
+ *                 contractions of that mode are bound by operand bytes, not by the matrix cores:
+ *                   GB_STORE_X_BF16  the rows operand (x of gb_gemm_fwd / _fwd_pool / _wgrad: the previous layer's pre-BN
+ *                                    output, its BatchNorm + ReLU applied on load as always)
+ *                   GB_STORE_Y_BF16  the output y of gb_gemm_fwd / _fwd_gen3 / _fwd_pool (rounded to nearest even once,
+ *                                    from the fp32 accumulator; BatchNorm sums and pooled extrema are those of the
+ *                                    ROUNDED values, so that what a later pass reads is what they describe)
+ *                   GB_STORE_YPREV_BF16  y_prev of gb_gemm_dgrad
+ *                 Honoured by the row-streaming kernel (and, for GB_STORE_X_BF16, the split-K wgrad); a call that
+ *                 cannot honour a flag returns GB_EINVAL instead of reading the bytes as fp32.                      */
+#define GB_STORE_X_BF16 1
+#define GB_STORE_Y_BF16 2
+#define GB_STORE_YPREV_BF16 4
 typedef struct GbGemmOpts {
   int precision;
   int reserved_cus;
   void *scratch;
   unsigned long long scratch_bytes;
+  int storage;
 } GbGemmOpts;
 
 /* The arguments of gb_bn_finalize as a struct: entry points that produce BatchNorm sums take an optional pointer to
@@ -442,6 +456,15 @@ int gb_bn_bwd_apply_members_v(const float *dout, const float *out, const float *
 /* gb_bn_bwd_apply (ReLU, no residual) for rows with multiplicities: dy = a*(dA*[z>0] - w*dbeta/P - xhat*w*dgamma/P). */
 int gb_bn_bwd_apply_w(const float *dout, const float *y, const float *ab, const double *dstats, const float *row_w,
                       long long rows, long long P_total, int C, int training, float *dy, void *stream);
+/* The same two passes reading a y that lives in HBM as bf16 (y_bf16 = 1: the output of a gb_gemm_fwd / _fwd_gen3 /
+ * _fwd_pool call with GB_STORE_Y_BF16; the pooled extrema of such a call are those of the rounded values, so the
+ * by-value arg-max search of the members pass stays exact). */
+int gb_bn_bwd_apply_ws(const float *dout, const float *y, int y_bf16, const float *ab, const double *dstats,
+                       const float *row_w, long long rows, long long P_total, int C, int training, float *dy, void *stream);
+int gb_bn_bwd_apply_members_vs(const float *dout, const float *out, const float *ystar, const float *y, int y_bf16,
+                               const float *ab, const double *dstats, const float *row_w, const int32_t *row_mem,
+                               const int64_t *off, const int32_t *cnt, long long R, int D, int C, long long P_total,
+                               int training, float *dy, void *stream);
 
 /* ---- LocalAggregation without the grouped tensor (csrc/local_agg.hip) ---------------------------------
  * Reference: TrainModel/drp.py:32-67 (LocalAggregation.forward :62 = QueryAndGroup -> [dp, fj] ->

@@ -333,21 +333,27 @@ __global__ __launch_bounds__(LA_TPB) void la_point_grad_kernel(const float *__re
 __global__ void la_wx_grad_kernel(const double *__restrict__ red, const double *__restrict__ u,
                                   const double *__restrict__ mom, const float *__restrict__ wx,
                                   const float *__restrict__ ab, double invP, int C, int training,
-                                  float *__restrict__ dwx, float *__restrict__ dbeta, float *__restrict__ dgamma) {
+                                  float *__restrict__ dwx, float *__restrict__ dbeta, float *__restrict__ dgamma,
+                                  int slots) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
+  // red: `slots` rows of [5][C] partial sums (the dgrad epilogue's slot rows), added here in slot order
+  double rs[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int sl = 0; sl < slots; ++sl)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) rs[j] += red[((size_t)sl * 5 + j) * C + c];
   if (dbeta) {  // gb_la_wx_grad_g: the BatchNorm parameter gradients are the first two sums, converted
-    dbeta[c] = (float)red[c];
-    dgamma[c] = (float)red[C + c];
+    dbeta[c] = (float)rs[0];
+    dgamma[c] = (float)rs[1];
   }
   const double a = ab[c], mean = ab[2 * C + c], rstd = ab[3 * C + c];
-  const double m1 = training ? red[c] * invP : 0.0, m2 = training ? red[C + c] * invP : 0.0;
+  const double m1 = training ? rs[0] * invP : 0.0, m2 = training ? rs[1] * invP : 0.0;
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     double wm = 0.0;
 #pragma unroll
     for (int q = 0; q < 3; ++q) wm += (double)wx[c * 3 + q] * mom[3 + 3 * q + j];
-    const double v = red[(size_t)(2 + j) * C + c] - m1 * mom[j] - m2 * rstd * (u[(size_t)j * C + c] - mean * mom[j] + wm);
+    const double v = rs[2 + j] - m1 * mom[j] - m2 * rstd * (u[(size_t)j * C + c] - mean * mom[j] + wm);
     dwx[c * 3 + j] = (float)(a * v);
   }
 }
@@ -471,17 +477,17 @@ extern "C" int gb_la_wx_grad(const double *red, const double *u, const double *m
                              long long P, int C, int training, float *dwx, void *stream) {
   if (C < 1 || P < 1 || !red || !u || !mom || !wx || !ab || !dwx) return GB_EINVAL;
   hipLaunchKernelGGL(la_wx_grad_kernel, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), red, u, mom, wx, ab,
-                     1.0 / (double)P, C, training, dwx, nullptr, nullptr);
+                     1.0 / (double)P, C, training, dwx, nullptr, nullptr, 1);
   return check_launch("gb_la_wx_grad");
 }
 
 // gb_la_wx_grad that also writes the BatchNorm parameter gradients dbeta = red[0:C], dgamma = red[C:2C] in fp32 (what a
-// one-slot gb_bn_bwd_reduce launch would do)
-extern "C" int gb_la_wx_grad_g(const double *red, const double *u, const double *mom, const float *wx, const float *ab,
-                               long long P, int C, int training, float *dwx, float *dbeta, float *dgamma,
-                               void *stream) {
-  if (C < 1 || P < 1 || !red || !u || !mom || !wx || !ab || !dwx || !dbeta || !dgamma) return GB_EINVAL;
+// one-slot gb_bn_bwd_reduce launch would do); red may be `slots` rows of [5][C] partial sums (added in slot order)
+extern "C" int gb_la_wx_grad_g(const double *red, int slots, const double *u, const double *mom, const float *wx,
+                               const float *ab, long long P, int C, int training, float *dwx, float *dbeta,
+                               float *dgamma, void *stream) {
+  if (C < 1 || P < 1 || slots < 1 || !red || !u || !mom || !wx || !ab || !dwx || !dbeta || !dgamma) return GB_EINVAL;
   hipLaunchKernelGGL(la_wx_grad_kernel, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), red, u, mom, wx, ab,
-                     1.0 / (double)P, C, training, dwx, dbeta, dgamma);
+                     1.0 / (double)P, C, training, dwx, dbeta, dgamma, slots);
   return check_launch("gb_la_wx_grad_g");
 }

@@ -786,12 +786,11 @@ class MLPStack(Function):
                           meta={"flop": 2.0 * P * K * N, "pkn": (P, K, N), "kernel": "gemm_rs_kernel"})
                     _call("gb_moments3", dev, _lib.ptr(X0), _lib.ptr(rows.w if rows is not None else None), P,
                           _lib.ptr(mom), st)
-                red = sums.view(slots, 5 * K).sum(0) if slots > 1 else sums
                 dbeta0, dgamma0 = bn_grads(0)
                 grads[1], grads[2] = dgamma0, dbeta0
                 dW0 = torch.empty((K, 3), dtype=torch.float32, device=dev)
-                _call("gb_la_wx_grad_g", dev, _lib.ptr(red), _lib.ptr(u0), _lib.ptr(mom), _lib.ptr(Ws[0]), _lib.ptr(abs_[0]),
-                      P_stat, K, int(training[0]), _lib.ptr(dW0), _lib.ptr(dbeta0), _lib.ptr(dgamma0), st)
+                _call("gb_la_wx_grad_g", dev, _lib.ptr(sums), slots, _lib.ptr(u0), _lib.ptr(mom), _lib.ptr(Ws[0]),
+                      _lib.ptr(abs_[0]), P_stat, K, int(training[0]), _lib.ptr(dW0), _lib.ptr(dbeta0), _lib.ptr(dgamma0), st)
                 grads[0] = dW0
                 break
             # gradient of layer l-1's post-ReLU output + that layer's BatchNorm-backward sums in one launch
@@ -1025,7 +1024,7 @@ class LocalAggPool(Function):
               _lib.ptr(ab), _lib.ptr(red), P, rows, N, training, _lib.ptr(dG), st)
         dW = None
         if ctx.needs_input_grad[1]:
-            _call("gb_la_wx_grad_g", dev, _lib.ptr(red), _lib.ptr(u), _lib.ptr(geo.mom), _lib.ptr(Wx), _lib.ptr(ab), P, N,
+            _call("gb_la_wx_grad_g", dev, _lib.ptr(red), 1, _lib.ptr(u), _lib.ptr(geo.mom), _lib.ptr(Wx), _lib.ptr(ab), P, N,
                   training, _lib.ptr(dWx), _lib.ptr(dbeta), _lib.ptr(dgamma), st)
             dWf = zbuf[rows * N:].view(N, C)
             _call("gb_gemm_wgrad", dev, _lib.ptr(dG), _lib.ptr(f), None, _lib.ptr(dWf), rows, C, N,

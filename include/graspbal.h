@@ -505,9 +505,10 @@ int gb_la_point_grad(const float *sg, const float *G, const float *cnt, const fl
 /* dwx (C,3): gradient of Wx.                                                                            */
 int gb_la_wx_grad(const double *red, const double *u, const double *mom, const float *wx, const float *ab,
                   long long P, int C, int training, float *dwx, void *stream);
-/* ... and the BatchNorm parameter gradients dbeta (C) = red[0:C], dgamma (C) = red[C:2C] in fp32 from the same launch. */
-int gb_la_wx_grad_g(const double *red, const double *u, const double *mom, const float *wx, const float *ab, long long P,
-                    int C, int training, float *dwx, float *dbeta, float *dgamma, void *stream);
+/* ... and the BatchNorm parameter gradients dbeta (C) = red[0:C], dgamma (C) = red[C:2C] in fp32 from the same launch;
+ * red may be `slots` rows of [5][C] partial sums (a dgrad epilogue's slot rows), added in slot order. */
+int gb_la_wx_grad_g(const double *red, int slots, const double *u, const double *mom, const float *wx, const float *ab,
+                    long long P, int C, int training, float *dwx, float *dbeta, float *dgamma, void *stream);
 
 /* ---- fp32 MFMA GEMMs of the channel-last SharedMLP (csrc/gemm_cl.hip) — replace the cuBLAS/cuDNN
  * 1x1 convolutions the reference reaches through torch (pytorch_utils.py:61-113) ------------------- */

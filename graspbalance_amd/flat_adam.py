@@ -66,6 +66,10 @@ class FlatAdam(Optimizer):
             torch._foreach_copy_(have_v, have_g)
         self._steps += 1
         self._step_t += 1
+        # the parameters are views of ONE flat buffer and the update below writes that buffer: the views' own version
+        # counters do not move, so tell the eval-mode BatchNorm table cache (fused_mlp._eval_ab) that parameters changed
+        from . import fused_mlp
+        fused_mlp._TRAIN_TICK[0] += 1
         if self._fused:
             torch._fused_adam_([self._flat_p], [self._flat_g], [self._exp_avg], [self._exp_avg_sq], [], [self._step_t],
                                lr=float(lr), beta1=beta1, beta2=beta2, weight_decay=wd, eps=eps, amsgrad=False,

@@ -325,3 +325,35 @@ def test_predictor_with_announced_next_batch_returns_the_same_grasps():
     for g, w in zip(got, (want_a, want_b, want_a, want_b)):
         assert len(g) == len(w) and all(torch.equal(x, y) for x, y in zip(g, w))
     assert piped.prefetch.pending is None
+
+
+def test_eval_tables_follow_trainer_steps():
+    """The eval-mode BatchNorm tables are cached (fused_mlp._eval_ab).  A Trainer updates the parameters through
+    FlatAdam - views of one flat buffer, whose own version counters do not move - and the running statistics through the
+    kernels' raw pointers: after train steps the fused eval forward must still equal the plain composition on the SAME
+    (updated) network, i.e. the cache must have been dropped."""
+    from tests.test_model_cpu import _tiny_net
+    from graspbalance_amd import fused_mlp
+    from graspbalance_amd.synthetic import make_training_batch
+    from graspbalance_amd.train import Trainer
+    tr = Trainer(DEV, num_view=30, model=_tiny_net(), steps_per_epoch=10, max_epoch=2)
+    batch = make_training_batch(range(2), num_point=3000, num_objects=2, grasp_points_per_object=20, num_view=30,
+                                device=DEV)
+    backbone = tr.net.view_estimator.FeatureExtraction   # (the whole network's stage 2 wants labels when built for training)
+
+    def eval_out(fused):
+        backbone.eval()
+        fused_mlp.set_enabled(fused)
+        try:
+            with torch.no_grad():
+                return backbone(batch['point_clouds'])[0].clone()
+        finally:
+            fused_mlp.set_enabled(True)
+            backbone.train()
+    before = eval_out(True)                     # fills the cache
+    for _ in range(2):
+        tr.train_step(batch)
+    after, plain = eval_out(True), eval_out(False)
+    torch.cuda.synchronize()
+    assert float((after - before).norm() / before.norm()) > 1e-3          # the network did change
+    assert float((after - plain).norm() / plain.norm()) < 1e-4, "stale eval-mode BatchNorm tables"

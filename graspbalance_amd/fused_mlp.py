@@ -846,8 +846,8 @@ class MLPStack(Function):
 # tested (tests/test_bf16_gpu.py), but as first built it is SLOWER: configs[4] 28.9 -> 30.1 ms per step (gemm_rs 5.5 ->
 # 6.4 ms, gemm_cl 8.0 -> 8.4): with the accumulator layout of the 32 x 32 MFMA a lane stores / re-reads ONE 2-byte
 # element per instruction (64-byte half lines, store-issue bound) and the split-K wgrad loads 8 bytes per lane instead
-# of 16.  It needs pair-packed stores (a DPP exchange between neighbouring lanes, two column tiles per 128-byte line)
-# and 8-element operand loads before it pays: DESIGN.md section 9.
+# of 16.  Pair-packed stores (a DPP exchange between neighbouring lanes, whole 128-byte lines) were measured too and
+# made it worse (gemm_rs 7.4 ms: more spills in an epilogue that already spills): DESIGN.md section 5.5.
 _BF16_STORE = os.environ.get("GB_BF16_STORE", "0") == "1"
 
 

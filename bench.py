@@ -385,8 +385,7 @@ def main():
         trainer.grads.exposed_ms()  # drop the warm-up samples
     # ~250 timed launches per step, two events each: created before the timed region, recorded inside it
     gemm_names = ["gb_gemm_fwd", "gb_gemm_fwd_w", "gb_gemm_fwd_pool", "gb_gemm_fwd_gen3", "gb_gemm_dgrad", "gb_gemm_dgrad_first",
-                  "gb_gemm_dgrad_first_gen3", "gb_gemm_wgrad", "gb_gemm_wgrad_gen3",
-                  "gb_crop_bwd_dense", "gb_gemm_gram"]
+                  "gb_gemm_dgrad_first_gen3", "gb_gemm_wgrad", "gb_gemm_wgrad_gen3"]
     timer = _lib.KernelTimer(gemm_names + ["gb_fps", "gb_ball_query", "gb_cylinder_query_multi"],
                              reserve=min(2 * 300 * (args.steps // 4 + 2), 20000))
     barrier()

@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libgraspbal_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 GB_OK = 0
 _ERRNAMES = {-1: "GB_EINVAL", -2: "GB_ELAUNCH", -3: "GB_ERANGE"}
@@ -82,29 +82,21 @@ SIGNATURES = {
     "gb_gemm_wgrad": [_P, _P, _P, _P, _L, _I, _I, _P, _P],
     "gb_gemm_uses_rs": [_L, _I, _I, _I, _I, _I],
     "gb_gemm_dgrad_first": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P],
-    "gb_moments3": [_P, _P, _L, _P, _P],
-    "gb_cyl_unique": [_P, _I, _L, _I, _P, _P, _P, _P],
-    "gb_cyl_rows": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
-    "gb_gemm_fwd_pool": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P],
+    "gb_moments3": [_P, _P, _L, _P, _P, _P],
+    "gb_cyl_unique": [_P, _I, _I, _L, _I, _P, _P, _P, _P],
+    "gb_cyl_scan": [_P, _I, _L, _P, _P, _P],
+    "gb_cyl_rows": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _P, _P, _P, _P, _P, _P],
+    "gb_gemm_fwd_pool": [_P, _P, _P, _P, _P, _P, _L, _L, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P],
     "gb_bn_bwd_apply_members_v": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _L, _I, _P, _P],
-    "gb_bn_bwd_apply_members_vs": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _L, _I, _P, _P],
-    "gb_pool_pairs": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "gb_pool_pairs": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "gb_bn_finalize_lin3": [_P, _P, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P],
     "gb_gemm_fwd_gen3": [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P, _P],
     "gb_gemm_wgrad_gen3": [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P],
     "gb_gemm_dgrad_first_gen3": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P],
-    "gb_crop_bwd_ok": [_I, _I, _I],
-    "gb_crop_bwd_blocks": [_L],
-    "gb_crop_bwd_sparse": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _I, _P, _P],
-    "gb_crop_bwd_coef": [_P, _P, _P, _I, _I, _L, _I, _P, _P, _P, _P, _P, _P],
-    "gb_crop_bwd_dense": [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _P, _P, _P, _P, _P],
-    "gb_gemm_gram": [_P, _P, _P, _P, _L, _I, _P, _P],
-    "gb_crop_bwd_dw": [_P, _I, _P, _P, _P, _P, _I, _I, _P, _P],
     "gb_gemm_fwd_w": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P, _P],
     "gb_affine_relu_maxpool_members": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "gb_bn_bwd_apply_members": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _L, _I, _P, _P],
-    "gb_bn_bwd_apply_w": [_P, _P, _P, _P, _P, _L, _L, _I, _I, _P, _P],
-    "gb_bn_bwd_apply_ws": [_P, _P, _I, _P, _P, _P, _L, _L, _I, _I, _P, _P],
+    "gb_bn_bwd_apply_w": [_P, _P, _P, _P, _P, _L, _L, _I, _I, _P, _P, _P],
 }
 
 
@@ -153,11 +145,10 @@ class GemmOpts(_c.Structure):
     """GbGemmOpts of include/graspbal.h: the per-call options of the gb_gemm_* entry points (precision, CUs left to a
     side-stream kernel, caller-owned split-reduction workspace)."""
     _fields_ = [("precision", _c.c_int), ("reserved_cus", _c.c_int), ("scratch", _c.c_void_p),
-                ("scratch_bytes", _c.c_ulonglong), ("storage", _c.c_int)]
+                ("scratch_bytes", _c.c_ulonglong), ("rows_dev", _c.c_void_p)]
 
 
 PREC_F32, PREC_BF16 = 0, 1
-STORE_X_BF16, STORE_Y_BF16, STORE_YPREV_BF16 = 1, 2, 4   # GbGemmOpts.storage bits (bf16 precision only)
 GEMM_SCRATCH_BYTES = 320 * 64 * 128 * 4
 
 
@@ -250,10 +241,6 @@ def event_pair_overhead_ms(device, pairs=64):
 FPS_PRUNE_MIN_N, FPS_PRUNE_MAX_N, FPS_PRUNE_MIN_M = 8192, 64512, 128  # gb_fps_pruned: n <= 1024 * 63 rows of 64
 _fps_prune = os.environ.get("GB_FPS_PRUNE", "1") != "0"  # A/B switch
 _fps_cell_order = os.environ.get("GB_FPS_CELL_ORDER", "1") != "0"  # A/B switch: visiting order by counting sort
-FPS_MULTI_PICK = 0x100
-# up to four samples per selection round (fps_multi_kernel: same outputs, 3.5x fewer rounds - but a round costs 4.5 us
-# against 1.0 us as built, so it is slower: 2.55 vs 2.05 ms; opt-in until the selection is moved to one wave)
-_fps_multi = os.environ.get("GB_FPS_MULTI", "0") == "1"
 FPS_PREFIX_MAX_N = 4096
 _fps_prefix = os.environ.get("GB_FPS_PREFIX", "1") != "0"  # A/B switch
 
@@ -274,8 +261,6 @@ def fps(points, temp, output, b, n, m, flags, stream):
                 return rc
             perm = torch.argsort(keys, dim=1).to(torch.int32)
         scratch = torch.empty((b, n, 4), dtype=torch.float32, device=points.device) if n > 20480 else None
-        if _fps_multi:
-            flags |= FPS_MULTI_PICK
         return lib().gb_fps_pruned(ptr(points), ptr(perm), ptr(temp), ptr(output), b, n, m, flags, ptr(scratch), stream)
     if _fps_prefix and n <= FPS_PREFIX_MAX_N and 64 <= m <= n:
         # small clouds are usually the centres of the previous level, i.e. already in farthest-point order: verify

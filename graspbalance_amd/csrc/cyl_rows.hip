@@ -12,8 +12,9 @@ namespace gb {
 
 constexpr int CU_MAXW = 256;  // D*ns slots per seed handled by one workgroup
 
-// One workgroup (CU_MAXW threads) per seed.  idx: (D, R, ns) int32.  sorted / meta: (R, W) with W = D*ns, the
-// distinct ids of a seed compacted to the front in increasing order; meta = (multiplicity << 8) | member bits.
+// One workgroup (CU_MAXW threads) per seed (blockIdx.x) of each of the nr query sets (blockIdx.y: the radii of stage 2).
+// idx: (nr, D, R, ns) int32.  sorted / meta: (nr, R, W) with W = D*ns, the distinct ids of a seed compacted to the front
+// in increasing order; meta = (multiplicity << 8) | member bits; count (nr, R).
 __global__ __launch_bounds__(CU_MAXW) void cyl_unique_kernel(const int32_t *__restrict__ idx, int D, long long R, int ns,
                                                              int32_t *__restrict__ sorted, int32_t *__restrict__ meta,
                                                              int32_t *__restrict__ count) {
@@ -21,6 +22,10 @@ __global__ __launch_bounds__(CU_MAXW) void cyl_unique_kernel(const int32_t *__re
   __shared__ int wsum[CU_MAXW / 64];
   const long long r = blockIdx.x;
   const int t = threadIdx.x, W = D * ns;
+  idx += (size_t)blockIdx.y * D * R * ns;
+  sorted += (size_t)blockIdx.y * R * W;
+  meta += (size_t)blockIdx.y * R * W;
+  count += (size_t)blockIdx.y * R;
   unsigned k = 0xFFFFFFFFu;
   if (t < W) {
     const int d = t / ns, s = t % ns;
@@ -68,23 +73,74 @@ __global__ __launch_bounds__(CU_MAXW) void cyl_unique_kernel(const int32_t *__re
   }
 }
 
+// off (nr, R) int64 = exclusive prefix sums of count (nr, R) along R, total (nr) = the sums: one workgroup per query set.
+__global__ __launch_bounds__(1024) void cyl_scan_kernel(const int32_t *__restrict__ count, long long R,
+                                                        int64_t *__restrict__ off, long long *__restrict__ total) {
+  __shared__ long long wtot[16];
+  __shared__ long long carry;
+  count += (size_t)blockIdx.x * R;
+  off += (size_t)blockIdx.x * R;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t == 0) carry = 0;
+  __syncthreads();
+  for (long long r0 = 0; r0 < R; r0 += 1024) {
+    const long long r = r0 + t;
+    const long long c = r < R ? count[r] : 0;
+    long long incl = c;   // inclusive scan within the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const long long o = __shfl_up(incl, d);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    long long base = carry;
+    for (int w = 0; w < wave; ++w) base += wtot[w];
+    if (r < R) off[r] = base + incl - c;
+    __syncthreads();
+    if (t == 1023) carry = base + incl;
+    __syncthreads();
+  }
+  if (t == 0) total[blockIdx.x] = carry;
+}
+
 // x0 (P_u,3) = (xyz[b, id] - centre[seed]) rotated by the seed's matrix (gb_group_concat_cl mode 2 arithmetic),
 // row_w (P_u) = multiplicity (also as uint16 in row_w16, for the GEMM epilogues), row_mem (P_u) = member bits;
-// row index = off[seed] + u.
+// row index = off[seed] + u.  Query set blockIdx.y writes at row stride `cap` of every output; the last seed's workgroup
+// also zeroes row_w16 / row_key on [P_u, P_u rounded up to 32): the GEMM epilogues read whole 32-row tiles.
 __global__ __launch_bounds__(CU_MAXW) void cyl_rows_kernel(const float *__restrict__ xyz, const float *__restrict__ centres,
                                                            const float *__restrict__ rot,
                                                            const int32_t *__restrict__ sorted,
                                                            const int32_t *__restrict__ meta,
                                                            const int32_t *__restrict__ count,
                                                            const int64_t *__restrict__ off, int n, int m, int W,
-                                                           float *__restrict__ x0, float *__restrict__ row_w,
-                                                           uint16_t *__restrict__ row_w16,
+                                                           long long R, long long cap, float *__restrict__ x0,
+                                                           float *__restrict__ row_w, uint16_t *__restrict__ row_w16,
                                                            int32_t *__restrict__ row_mem,
                                                            int32_t *__restrict__ row_key) {
   const long long r = blockIdx.x;
+  const size_t set = blockIdx.y;
+  sorted += set * R * W;
+  meta += set * R * W;
+  count += set * R;
+  off += set * R;
+  x0 += set * cap * 3;
+  row_w += set * cap;
+  row_w16 += set * cap;
+  row_mem += set * cap;
+  if (row_key) row_key += set * cap;
   const int u = threadIdx.x;
-  if (u >= count[r]) return;
+  const int cnt = count[r];
+  if (r == R - 1 && u < 32) {
+    const long long pu = off[r] + cnt, row = pu + u;
+    if (row < (pu + 31) / 32 * 32 && row < cap) {
+      row_w16[row] = 0;
+      if (row_key) row_key[row] = 0;
+    }
+  }
+  if (u >= cnt) return;
   const long long row = off[r] + u;
+  if (row >= cap) return;   // (a capacity below the row total: the caller's error, never a write out of bounds)
   const int bi = (int)(r / m);
   const int id = sorted[r * W + u];
   const int mt = meta[r * W + u];
@@ -97,7 +153,7 @@ __global__ __launch_bounds__(CU_MAXW) void cyl_rows_kernel(const float *__restri
   row_w[row] = (float)(mt >> 8);
   row_w16[row] = (uint16_t)(mt >> 8);
   row_mem[row] = mt & 0xFF;
-  // (seed << 13) | (multiplicity << 4) | member bits: everything the pooled GEMM epilogue (gemm_rs.hip, RS_STATS_POOL)
+  // (seed << 13) | (multiplicity << 4) | member bits: everything the pooled GEMM epilogue (gemm_rs.hip, RS_STATS_POOL_V)
   // needs to know about a row, in one word (multiplicity <= 256 slots, D <= 4 crops, < 2^18 seeds: host-checked)
   if (row_key) row_key[row] = (int32_t)((r << 13) | ((long long)(mt >> 8) << 4) | (mt & 0xF));
 }
@@ -106,27 +162,34 @@ __global__ __launch_bounds__(CU_MAXW) void cyl_rows_kernel(const float *__restri
 
 using namespace gb;
 
-extern "C" int gb_cyl_unique(const int32_t *idx, int D, long long R, int ns, int32_t *sorted, int32_t *meta,
+extern "C" int gb_cyl_unique(const int32_t *idx, int nr, int D, long long R, int ns, int32_t *sorted, int32_t *meta,
                              int32_t *count, void *stream) {
-  if (D < 1 || D > 8 || R < 0 || ns < 1 || D * ns > CU_MAXW || !idx || !sorted || !meta || !count) return GB_EINVAL;
+  if (nr < 1 || nr > 65535 || D < 1 || D > 8 || R < 0 || ns < 1 || D * ns > CU_MAXW || !idx || !sorted || !meta || !count)
+    return GB_EINVAL;
   if (R == 0) return GB_OK;
   if (R > 0x7fffffffLL) return GB_ERANGE;
-  hipLaunchKernelGGL(cyl_unique_kernel, dim3((unsigned)R), dim3(CU_MAXW), 0, as_stream(stream), idx, D, R, ns, sorted,
-                     meta, count);
+  hipLaunchKernelGGL(cyl_unique_kernel, dim3((unsigned)R, (unsigned)nr), dim3(CU_MAXW), 0, as_stream(stream), idx, D, R, ns,
+                     sorted, meta, count);
   return check_launch("gb_cyl_unique");
 }
 
+extern "C" int gb_cyl_scan(const int32_t *count, int nr, long long R, int64_t *off, long long *total, void *stream) {
+  if (nr < 1 || R < 0 || !count || !off || !total) return GB_EINVAL;
+  hipLaunchKernelGGL(cyl_scan_kernel, dim3((unsigned)nr), dim3(1024), 0, as_stream(stream), count, R, off, total);
+  return check_launch("gb_cyl_scan");
+}
+
 extern "C" int gb_cyl_rows(const float *xyz, const float *centres, const float *rot, const int32_t *sorted,
-                           const int32_t *meta, const int32_t *count, const int64_t *off, int b, int n, int m, int W,
-                           float *x0, float *row_w, uint16_t *row_w16, int32_t *row_mem, int32_t *row_key,
-                           void *stream) {
-  if (b < 0 || n < 1 || m < 0 || W < 1 || W > CU_MAXW || !xyz || !centres || !rot || !sorted || !meta || !count || !off ||
-      !x0 || !row_w || !row_w16 || !row_mem)
+                           const int32_t *meta, const int32_t *count, const int64_t *off, int nr, int b, int n, int m,
+                           int W, long long cap, float *x0, float *row_w, uint16_t *row_w16, int32_t *row_mem,
+                           int32_t *row_key, void *stream) {
+  if (nr < 1 || nr > 65535 || b < 0 || n < 1 || m < 0 || W < 1 || W > CU_MAXW || cap < 32 || cap % 32 || !xyz || !centres ||
+      !rot || !sorted || !meta || !count || !off || !x0 || !row_w || !row_w16 || !row_mem)
     return GB_EINVAL;
   const long long R = (long long)b * m;
   if (R == 0) return GB_OK;
   if (R > 0x7fffffffLL || (row_key && R >= (1 << 18))) return GB_ERANGE;
-  hipLaunchKernelGGL(cyl_rows_kernel, dim3((unsigned)R), dim3(CU_MAXW), 0, as_stream(stream), xyz, centres, rot, sorted,
-                     meta, count, off, n, m, W, x0, row_w, row_w16, row_mem, row_key);
+  hipLaunchKernelGGL(cyl_rows_kernel, dim3((unsigned)R, (unsigned)nr), dim3(CU_MAXW), 0, as_stream(stream), xyz, centres,
+                     rot, sorted, meta, count, off, n, m, W, R, cap, x0, row_w, row_w16, row_mem, row_key);
   return check_launch("gb_cyl_rows");
 }

@@ -263,289 +263,6 @@ __global__ __launch_bounds__(BLOCK) void fps_pruned_kernel(const float *__restri
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// MULTI-PICK variant of the pruned kernel: up to KC samples per block-wide selection instead of one.
-//
-// Exactness argument.  Let T be the running min-distances after the samples so far and c_1, c_2, ... the points in
-// the reference's selection order (T descending, tie key ascending).  The next sample is c_1.  The one after it is
-// c_2 PROVIDED that (i) c_2 is not lowered by c_1's update, d(c_2, c_1) >= T[c_2] > 0, and (ii) after that update no
-// other point beats c_2.  Points of rows other than c_1's cannot: the update only lowers values and c_2 already
-// beat them.  Only the row that held c_1 can - it is updated tentatively and its new maximum compared with c_2.
-// By induction c_1 .. c_L are the next L samples if every c_i is unaffected by c_1 .. c_{i-1} and the rows that held
-// c_1 .. c_{i-1}, updated by (at least) their own sample and its predecessors, hold nothing that beats c_i.  A row
-// maximum can only fall with further updates and c_L is the weakest candidate, so comparing every such row with c_L
-// is sufficient.  Whatever the test rejects is simply picked in a later round, so the sample sequence is the
-// reference's bit for bit under every tie rule; T = 0 candidates (only duplicates left) are never multi-picked.
-//
-// The candidates are the top KC ROW RECORDS (one point per row: its maximum), found from every wave's two best
-// records; if a wave contributes both of its entries, what lies beyond them is unknown and the list stops there.
-// On the bench clouds a top-4 selection needs ~600 rounds for 2048 samples instead of 2047.
-template <int BLOCK, int P>
-__global__ __launch_bounds__(BLOCK) void fps_multi_kernel(const float *__restrict__ xyz,
-                                                           const int32_t *__restrict__ perm,
-                                                           float *__restrict__ temp_io,
-                                                           int32_t *__restrict__ idx, int n, int m, int skip,
-                                                           int bs_log2) {
-  static_assert(P <= 32, "row records live in lanes 0..P-1");
-  constexpr int W = BLOCK / 64;
-  constexpr int KC = 4;
-  static_assert(2 * W <= 64, "two entries per wave must fit one wave's lanes");
-  extern __shared__ unsigned s_tie[];  // [BLOCK * P] tie key of each sorted position
-  __shared__ float s_cv[2][2 * W];     // every wave's two best row records: value, key, register slot
-  __shared__ unsigned s_ck[2][2 * W];
-  __shared__ int s_cs[2][2 * W];
-  __shared__ float s_mv[2][KC];        // maximum (value, key) of a candidate's row after its tentative update
-  __shared__ unsigned s_mk[2][KC];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float *pts = xyz + (size_t)blockIdx.x * n * 3;
-  const int32_t *pm = perm + (size_t)blockIdx.x * n;
-  int32_t *out = idx + (size_t)blockIdx.x * m;
-  float *tio = temp_io ? temp_io + (size_t)blockIdx.x * n : nullptr;
-
-  float px[P], py[P], pz[P], pt[P];
-  float lox = INFINITY, loy = INFINITY, loz = INFINITY, hix = -INFINITY, hiy = -INFINITY, hiz = -INFINITY;
-  float rmax = -2.0f;
-  unsigned rkey = 0xFFFFFFFFu;
-#pragma unroll
-  for (int p = 0; p < P; ++p) {
-    const int k = (p * W + wave) * 64 + lane;
-    float x = 0.f, y = 0.f, z = 0.f, t = -INFINITY;  // -inf: never a candidate
-    unsigned key = 0xFFFFFFFFu;
-    if (k < n) {
-      const int o = pm[k];
-      const f3 v = reinterpret_cast<const f3 *>(pts)[o];
-      x = v.x; y = v.y; z = v.z;
-      t = tio ? tio[o] : 1e10f;
-      key = fps_key(o, bs_log2);
-      if (skip) {
-        const float mag = ((x * x) + (y * y)) + (z * z);
-        if (mag < 1e-3f) t = -INFINITY;
-      }
-    }
-    px[p] = x; py[p] = y; pz[p] = z; pt[p] = t;
-    s_tie[k] = key;
-    const bool cand = t >= 0.f;
-    const float bhx = wave_max_f32(cand ? x : -INFINITY), blx = -wave_max_f32(cand ? -x : -INFINITY);
-    const float bhy = wave_max_f32(cand ? y : -INFINITY), bly = -wave_max_f32(cand ? -y : -INFINITY);
-    const float bhz = wave_max_f32(cand ? z : -INFINITY), blz = -wave_max_f32(cand ? -z : -INFINITY);
-    const bool any = __builtin_amdgcn_ballot_w64(cand) != 0ull;
-    if (lane == p) {
-      lox = blx; loy = bly; loz = blz; hix = bhx; hiy = bhy; hiz = bhz;
-      rmax = any ? 3.0e38f : -1.0f;  // > any squared distance: forces the row's first update
-      rkey = fps_key(0, bs_log2);
-    }
-  }
-  __syncthreads();
-
-  // the samples of the current round (wave-uniform): coordinates, how many
-  float sx[KC], sy[KC], sz[KC];
-  int L = 1;
-  sx[0] = pts[0]; sy[0] = pts[1]; sz[0] = pts[2];
-#pragma unroll
-  for (int i = 1; i < KC; ++i) { sx[i] = 0.f; sy[i] = 0.f; sz[i] = 0.f; }
-  if (tid == 0) out[0] = 0;
-  int j = 1;  // samples written so far
-#ifdef GB_FPS_DEBUG
-  long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = clock64();
-#define GB_TICK(I) { const long long now_ = clock64(); tph[I] += now_ - tlast; tlast = now_; }
-#else
-#define GB_TICK(I)
-#endif
-  for (int round = 0;; ++round) {
-    // ---- apply the round's L samples: a row is touched by sample s iff s's box bound is below the row's maximum
-    // (the reference never applies its LAST sample: the caller's running min-distances end one update short)
-    const int La = j >= m ? L - 1 : L;
-    unsigned long long need_s[KC];
-    unsigned long long need = 0ull;
-#pragma unroll
-    for (int i = 0; i < KC; ++i) {
-      need_s[i] = 0ull;
-      if (i < La) {
-        const float ex = fmaxf(fmaxf(lox - sx[i], sx[i] - hix), 0.f);
-        const float ey = fmaxf(fmaxf(loy - sy[i], sy[i] - hiy), 0.f);
-        const float ez = fmaxf(fmaxf(loz - sz[i], sz[i] - hiz), 0.f);
-        const float lb = ((ex * ex) + (ey * ey)) + (ez * ez);
-        need_s[i] = __builtin_amdgcn_ballot_w64(lb < rmax);
-        need |= need_s[i];
-      }
-    }
-    if (need != 0ull) {
-#pragma unroll
-      for (int p = 0; p < P; ++p) {
-        if (need & (1ull << p)) {  // wave-uniform
-          const unsigned kk = s_tie[(p * W + wave) * 64 + lane];
-          float d2 = pt[p];
-#pragma unroll
-          for (int i = 0; i < KC; ++i) {
-            if (need_s[i] & (1ull << p)) {  // wave-uniform
-              const float dx = px[p] - sx[i], dy = py[p] - sy[i], dz = pz[p] - sz[i];
-              d2 = __builtin_fminf(((dx * dx) + (dy * dy)) + (dz * dz), d2);
-            }
-          }
-          pt[p] = d2;
-          const float mx = wave_max_f32(d2);
-          const unsigned long long eq = __builtin_amdgcn_ballot_w64(d2 == mx);
-          unsigned kmin;
-          if (__builtin_popcountll(eq) == 1)
-            kmin = (unsigned)__builtin_amdgcn_readlane((int)kk, __builtin_ctzll(eq));
-          else
-            kmin = wave_min_u32(d2 == mx ? kk : 0xFFFFFFFFu);
-          if (lane == p) { rmax = mx; rkey = kmin; }
-        }
-      }
-    }
-    GB_TICK(0)
-    if (j >= m) {
-#ifdef GB_FPS_DEBUG
-      if (tid == 0 && blockIdx.x == 0)
-        printf("fps_multi: %d rounds for %d samples; cycles/round: update %lld top2+barrier %lld top4 %lld coords+indep %lld validate %lld accept %lld\n",
-               round + 1, m, tph[0] / (round + 1), tph[1] / (round + 1), tph[2] / (round + 1), tph[3] / (round + 1),
-               tph[4] / (round + 1), tph[5] / (round + 1));
-#endif
-      break;
-    }
-
-    // ---- every wave's two best row records -> LDS
-    const int buf = round & 1;
-    {
-      const float w1 = wave_max_f32(rmax);
-      const unsigned k1 = wave_min_u32(rmax == w1 ? rkey : 0xFFFFFFFFu);
-      const unsigned long long b1 = __builtin_amdgcn_ballot_w64(rmax == w1 && rkey == k1);
-      const int p1 = b1 ? __builtin_ctzll(b1) : 0;
-      const float r2 = lane == p1 ? -3.0f : rmax;
-      const float w2 = wave_max_f32(r2);
-      const unsigned k2 = wave_min_u32(r2 == w2 ? rkey : 0xFFFFFFFFu);
-      const unsigned long long b2 = __builtin_amdgcn_ballot_w64(r2 == w2 && rkey == k2 && lane != p1);
-      const int p2 = b2 ? __builtin_ctzll(b2) : 0;
-      if (lane == 0) {
-        s_cv[buf][2 * wave] = w1; s_ck[buf][2 * wave] = k1; s_cs[buf][2 * wave] = p1;
-        s_cv[buf][2 * wave + 1] = b2 ? w2 : -3.0f; s_ck[buf][2 * wave + 1] = k2; s_cs[buf][2 * wave + 1] = p2;
-      }
-    }
-    __syncthreads();
-    GB_TICK(1)
-    // ---- the block's top KC of those 2 W entries (every wave computes the same)
-    float cv = lane < 2 * W ? s_cv[buf][lane] : -4.0f;
-    const unsigned ck = lane < 2 * W ? s_ck[buf][lane] : 0xFFFFFFFFu;
-    float v[KC];
-    unsigned key[KC];
-    int ent[KC];
-    int kc = 0;            // valid candidates
-    unsigned taken = 0u;   // waves that already gave an entry
-#pragma unroll
-    for (int i = 0; i < KC; ++i) {
-      v[i] = -1.0f; key[i] = 0u; ent[i] = 0;
-      if (kc == i) {
-        const float wv = wave_max_f32(cv);
-        const unsigned wk = wave_min_u32(cv == wv ? ck : 0xFFFFFFFFu);
-        const unsigned long long bb = __builtin_amdgcn_ballot_w64(cv == wv && ck == wk);
-        const int e = bb ? __builtin_ctzll(bb) : 0;
-        // the first candidate is always taken (a negative value means "no candidate": index 0, as the reference's tree)
-        if (i == 0 || wv > 0.0f) {
-          v[i] = wv; key[i] = wk; ent[i] = e;
-          kc = i + 1;
-          if (taken & (1u << (e >> 1))) kc |= 0x100;  // second entry of a wave: nothing beyond it is known
-          taken |= 1u << (e >> 1);
-          if (lane == e) cv = -5.0f;
-        }
-      }
-    }
-    kc &= 0xff;
-    GB_TICK(2)
-    const int first = v[0] < 0.0f ? 0 : fps_unkey(key[0], bs_log2);
-    int so[KC];
-    so[0] = first;
-#pragma unroll
-    for (int i = 1; i < KC; ++i) so[i] = i < kc ? fps_unkey(key[i], bs_log2) : 0;
-    float cx[KC], cy[KC], cz[KC];
-#pragma unroll
-    for (int i = 0; i < KC; ++i) { cx[i] = pts[so[i] * 3 + 0]; cy[i] = pts[so[i] * 3 + 1]; cz[i] = pts[so[i] * 3 + 2]; }
-    // ---- (i) a candidate must not be lowered by the ones before it
-    int L1 = 1;
-    if (v[0] > 0.0f) {
-#pragma unroll
-      for (int i = 1; i < KC; ++i) {
-        if (L1 == i && i < kc) {
-          bool ok = true;
-#pragma unroll
-          for (int a = 0; a < KC; ++a) {
-            if (a < i) {
-              const float dx = cx[i] - cx[a], dy = cy[i] - cy[a], dz = cz[i] - cz[a];
-              ok = ok && !((((dx * dx) + (dy * dy)) + (dz * dz)) < v[i]);
-            }
-          }
-          if (ok) L1 = i + 1;
-        }
-      }
-    }
-    if (L1 > m - j) L1 = m - j;
-    GB_TICK(3)
-    // ---- (ii) the rows that held candidates 0 .. L1-2, updated by their own and the earlier candidates
-    int Lacc = 1;
-    if (L1 > 1) {
-#pragma unroll
-      for (int a = 0; a < KC - 1; ++a) {
-        if (a < L1 - 1 && (ent[a] >> 1) == wave) {  // wave-uniform
-          const int pa = s_cs[buf][ent[a]];
-#pragma unroll
-          for (int p = 0; p < P; ++p) {
-            if (p == pa) {
-              float t = pt[p];
-#pragma unroll
-              for (int b = 0; b < KC - 1; ++b) {
-                if (b <= a) {
-                  const float dx = px[p] - cx[b], dy = py[p] - cy[b], dz = pz[p] - cz[b];
-                  t = __builtin_fminf(((dx * dx) + (dy * dy)) + (dz * dz), t);
-                }
-              }
-              const unsigned kk = s_tie[(p * W + wave) * 64 + lane];
-              const float mx = wave_max_f32(t);
-              const unsigned km = wave_min_u32(t == mx ? kk : 0xFFFFFFFFu);
-              if (lane == 0) { s_mv[buf][a] = mx; s_mk[buf][a] = km; }
-            }
-          }
-        }
-      }
-      __syncthreads();
-      // the longest prefix whose last candidate beats every such row
-#pragma unroll
-      for (int l = 2; l <= KC; ++l) {
-        if (l <= L1) {
-          bool ok = true;
-#pragma unroll
-          for (int a = 0; a < KC - 1; ++a) {
-            if (a < l - 1) {
-              const float mv = s_mv[buf][a];
-              const unsigned mk = s_mk[buf][a];
-              ok = ok && (v[l - 1] > mv || (v[l - 1] == mv && key[l - 1] < mk));
-            }
-          }
-          if (ok) Lacc = l;
-        }
-      }
-    }
-    GB_TICK(4)
-    L = Lacc;
-#pragma unroll
-    for (int i = 0; i < KC; ++i) { sx[i] = cx[i]; sy[i] = cy[i]; sz[i] = cz[i]; }
-    if (tid == 0) {
-#pragma unroll
-      for (int i = 0; i < KC; ++i)
-        if (i < L) out[j + i] = so[i];
-    }
-    j += L;
-    GB_TICK(5)
-  }
-#undef GB_TICK
-  if (tio) {
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const int k = (p * W + wave) * 64 + lane;
-      if (k < n && pt[p] >= 0.0f) tio[pm[k]] = pt[p];
-    }
-  }
-}
-
 // The same for clouds beyond one CU's register file (20 480 < n <= 65 536): only the running min-distances stay in
 // registers (P <= 64 per lane); a row's coordinates and tie keys are re-read from a sorted (x, y, z, key) copy in
 // global memory - one 16-byte coalesced load per lane - but only for the few rows a sample actually touches, so the
@@ -1119,17 +836,6 @@ extern "C" int gb_fps_pruned(const float *xyz, const int32_t *perm, float *temp,
                        temp, idx, n, m, skip, bs_log2);                                                        \
     return check_launch("gb_fps_pruned");                                                                      \
   }
-  // GB_FPS_MULTI_PICK: several samples per block-wide selection (fps_multi_kernel; same outputs)
-#define GB_PM(PV)                                                                                              \
-  if (p_need <= PV) {                                                                                          \
-    static std::atomic<unsigned long long> attr{0};                                                            \
-    allow_dynamic_lds(fps_multi_kernel<1024, PV>, 1024 * PV * 4, attr);                                        \
-    hipLaunchKernelGGL((fps_multi_kernel<1024, PV>), dim3(b), dim3(1024), 1024 * PV * sizeof(unsigned), s, xyz, perm, \
-                       temp, idx, n, m, skip, bs_log2);                                                        \
-    return check_launch("gb_fps_pruned");                                                                      \
-  }
-  if (flags & GB_FPS_MULTI_PICK) { GB_PM(4) GB_PM(8) GB_PM(12) GB_PM(16) GB_PM(20) }
-#undef GB_PM
   GB_PR(4) GB_PR(8) GB_PR(12) GB_PR(16) GB_PR(20)
 #undef GB_PR
 #define GB_PB(PV)                                                                                               \

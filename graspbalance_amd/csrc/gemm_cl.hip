@@ -39,16 +39,14 @@ struct Operand {
   long long red;    // valid reduction indices [0, red)
   long long ld;
   const float *aff; // optional [a(red), b(red)]: value = relu(a_k * x + b_k)   (OP_KC only)
-  const float *red_w; // optional (OP_RC only) [red]: the value is multiplied by red_w[reduction index] (after aff)
   const float *gen_x; // optional (OP_RC only): src is not read - element (tile row r, reduction index k) = gen_x[k] . gen_w[r],
   const float *gen_w; //   gen_x (red,3), gen_w (rows,3): the output of a 3-input first layer that was never stored (then aff)
-  int bf16;           // (bf16 kernels, OP_RC only) src points at bf16 elements (GbGemmOpts.storage & GB_STORE_X_BF16)
 };
 
 // registers holding one thread's share (ROWS/16 floats... i.e. 4 or 8) of a ROWS x 16 operand tile
-struct Frag { float v[8]; float ca[4], cb[4]; float rw[2]; bool ok[2]; };  // data, affine (a,b) of its 4 channels, reduction weight, validity
+struct Frag { float v[8]; float ca[4], cb[4]; bool ok[2]; };  // data, affine (a,b) of its 4 channels, validity
 
-template <int KIND, bool VEC, int ROWS, bool GEN = false, bool RW = false, bool SB = false>
+template <int KIND, bool VEC, int ROWS, bool GEN = false>
 __device__ __forceinline__ void load_frag(const Operand &op, long long row0, long long k0, Frag &f) {
   const int t = threadIdx.x;
   constexpr int TPK = ROWS / 4;        // OP_RC: threads covering the tile rows of one reduction index
@@ -83,7 +81,6 @@ __device__ __forceinline__ void load_frag(const Operand &op, long long row0, lon
       const float *p = op.src + k * op.ld + row;
       const bool kok = k < op.red;
       f.ok[h] = kok;
-      if constexpr (RW) f.rw[h] = kok ? op.red_w[k] : 1.f;   // (gb_gemm_gram only: a template switch like GEN)
       if constexpr (GEN) {   // a template switch: the plain loaders must not carry this branch (it cost every wgrad 15-35 %)
         const float gx = kok ? op.gen_x[k * 3] : 0.f, gy = kok ? op.gen_x[k * 3 + 1] : 0.f, gz = kok ? op.gen_x[k * 3 + 2] : 0.f;
 #pragma unroll
@@ -91,18 +88,6 @@ __device__ __forceinline__ void load_frag(const Operand &op, long long row0, lon
           const bool rok = row + e < op.rows;
           const float *wr = op.gen_w + (rok ? (row + e) * 3 : 0);
           f.v[4 * h + e] = rok ? ((gx * wr[0]) + (gy * wr[1])) + (gz * wr[2]) : 0.f;  // == gemm_rs.hip's lin3
-        }
-      } else
-      if (SB && op.bf16) {   // SB: a bf16-precision instantiation (the fp32 kernels do not carry this branch)
-        const uint16_t *pb = reinterpret_cast<const uint16_t *>(op.src) + k * op.ld + row;
-        if (VEC && kok && row + 3 < op.rows) {   // 4 consecutive elements = 8 bytes (VEC: ld % 4 == 0, aligned base)
-          const uint2 u = *reinterpret_cast<const uint2 *>(pb);
-          f.v[4 * h + 0] = __uint_as_float(u.x << 16); f.v[4 * h + 1] = __uint_as_float(u.x & 0xFFFF0000u);
-          f.v[4 * h + 2] = __uint_as_float(u.y << 16); f.v[4 * h + 3] = __uint_as_float(u.y & 0xFFFF0000u);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            f.v[4 * h + e] = (kok && row + e < op.rows) ? __uint_as_float((unsigned)pb[e] << 16) : 0.f;
         }
       } else
       if (VEC && kok && row + 3 < op.rows) {
@@ -137,15 +122,6 @@ __device__ __forceinline__ void apply_aff(Frag &f) {
       f.v[4 * h + e] = (f.ok[h] && z > 0.f) ? z : 0.f;
     }
 }
-// ... then the per-reduction-index weight of a row-contiguous operand (gb_gemm_gram)
-template <int ROWS>
-__device__ __forceinline__ void apply_red_w(Frag &f) {
-#pragma unroll
-  for (int h = 0; h < ROWS / 64; ++h)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) f.v[4 * h + e] *= f.rw[h];
-}
-
 template <int KIND, int ROWS>
 __device__ __forceinline__ void store_frag(float *lds, const Frag &f) {
   const int t = threadIdx.x;
@@ -174,17 +150,31 @@ enum { EPI_STORE = 0,
 // D[i,j] = sum_k A[i,k] B[j,k] over k in [kbeg, kend);  D is (a.rows x b.rows) with leading dim ldd
 // 128 x 128 tiles of the store / atomic kernels need 132-136 VGPRs as written: asking for four waves per SIMD
 // (<= 128 registers) buys a fourth resident workgroup per CU
-// XOP: 0 plain operands; XOP_GENB: B is generated (gb_gemm_wgrad_gen3); XOP_RWA: A carries per-reduction-index weights
-// (gb_gemm_gram).  Compile-time, so that the plain instantiations carry neither: as run-time branches in the loaders they
-// cost every split-K product 15-35 % (registers: the 128 x 128 tile spilled under its 128-VGPR cap).
-enum { XOP_NONE = 0, XOP_GENB = 1, XOP_RWA = 2 };
+// XOP: 0 plain operands; XOP_GENB: B is generated (gb_gemm_wgrad_gen3).  Compile-time, so that the plain instantiations do
+// not carry it: as a run-time branch in the loaders it cost every split-K product 15-35 % (registers: the 128 x 128 tile
+// spilled under its 128-VGPR cap).
+enum { XOP_NONE = 0, XOP_GENB = 1 };
 template <int KA, int KB, bool VA, bool VB, int EPI, int GM, int GN, bool BF = false, int XOP = XOP_NONE>
 __global__ __launch_bounds__(GTPB, ((GM == 128 && GN == 128 && (EPI == 0 || EPI == 2) && !BF) ? 4 : 1)) void gemm_cl_kernel(Operand a, Operand b, float *__restrict__ d, long long ldd,
                                                         double *__restrict__ stats, long long kchunk,
                                                         int tiles_n, int stat_slots,
                                                         const float *__restrict__ epi_y,
                                                         const float *__restrict__ epi_ab,
-                                                        const uint16_t *__restrict__ epi_w16, long long dchunk) {
+                                                        const uint16_t *__restrict__ epi_w16, long long dchunk,
+                                                        const long long *__restrict__ red_dev) {
+  // red_dev (split-K products over rows, EPI_ATOMIC): the reduction length is the caller's device-side row count (<= the
+  // host-side capacity a.red the grid was sized for); the gridDim.y chunks re-divide it among themselves
+  if constexpr (EPI == EPI_ATOMIC) {
+    if (red_dev) {
+      long long pd = *red_dev;
+      pd = pd < a.red ? (pd > 0 ? pd : 0) : a.red;
+      a.red = pd;
+      b.red = pd;
+      kchunk = ((pd + gridDim.y - 1) / gridDim.y + GK - 1) / GK * GK;
+      if (kchunk < 256) kchunk = 256;
+      if ((long long)blockIdx.y * kchunk >= pd) return;
+    }
+  }
   // dchunk != 0: reduction chunk blockIdx.y stores its partial product to its own copy of D (split_reduce_kernel sums
   // the copies in chunk order: same bits on every run, which accumulating with atomics does not give)
   d += (long long)blockIdx.y * dchunk;
@@ -213,11 +203,10 @@ __global__ __launch_bounds__(GTPB, ((GM == 128 && GN == 128 && (EPI == 0 || EPI 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   Frag fa, fb;
-  load_frag<KA, VA, GM, false, XOP == XOP_RWA>(a, m0, kbeg, fa);
-  load_frag<KB, VB, GN, XOP == XOP_GENB, false, BF>(b, n0, kbeg, fb);
+  load_frag<KA, VA, GM>(a, m0, kbeg, fa);
+  load_frag<KB, VB, GN, XOP == XOP_GENB>(b, n0, kbeg, fb);
   if (a.aff) apply_aff<GM>(fa);
   if (b.aff) apply_aff<GN>(fb);
-  if constexpr (KA == OP_RC && XOP == XOP_RWA) apply_red_w<GM>(fa);
   store_frag<KA, GM>(lds_a[0], fa);
   store_frag<KB, GN>(lds_b[0], fb);
   __syncthreads();
@@ -225,8 +214,8 @@ __global__ __launch_bounds__(GTPB, ((GM == 128 && GN == 128 && (EPI == 0 || EPI 
   for (long long k0 = kbeg; k0 < kend; k0 += GK) {
     const bool more = k0 + GK < kend;
     if (more) {
-      load_frag<KA, VA, GM, false, XOP == XOP_RWA>(a, m0, k0 + GK, fa);
-      load_frag<KB, VB, GN, XOP == XOP_GENB, false, BF>(b, n0, k0 + GK, fb);
+      load_frag<KA, VA, GM>(a, m0, k0 + GK, fa);
+      load_frag<KB, VB, GN, XOP == XOP_GENB>(b, n0, k0 + GK, fb);
     }
     if constexpr (BF) {
       // bf16 matrix cores: ONE v_mfma_f32_32x32x16_bf16 per 32x32 tile and step; a lane supplies the 8 reduction
@@ -267,7 +256,6 @@ __global__ __launch_bounds__(GTPB, ((GM == 128 && GN == 128 && (EPI == 0 || EPI 
     if (more) {
       if (a.aff) apply_aff<GM>(fa);
       if (b.aff) apply_aff<GN>(fb);
-      if constexpr (KA == OP_RC && XOP == XOP_RWA) apply_red_w<GM>(fa);
       store_frag<KA, GM>(lds_a[buf ^ 1], fa);
       store_frag<KB, GN>(lds_b[buf ^ 1], fb);
     }
@@ -402,14 +390,14 @@ static inline bool aligned16(const void *p) { return reinterpret_cast<uintptr_t>
 template <int KA, int KB, int EPI, int BM, int BN, int XOP = XOP_NONE>
 static void launch_tile(const Operand &a, const Operand &b, bool va, bool vb, float *d, long long ldd, double *stats,
                         long long kchunk, unsigned chunks, hipStream_t s, bool bf16, int stat_slots, const float *epi_y,
-                        const float *epi_ab, const uint16_t *epi_w16, long long dchunk) {
+                        const float *epi_ab, const uint16_t *epi_w16, long long dchunk, const long long *red_dev) {
   const int tiles_n = (int)((b.rows + BN - 1) / BN);
   const long long tiles_m = (a.rows + BM - 1) / BM;
   const dim3 grid((unsigned)(tiles_m * tiles_n), chunks);
   const bool bf = bf16 && a.red >= 16;  // GB_PREC_BF16; short reductions (xyz-only first layers) stay fp32
 #define GB_L(VA_, VB_, BF_)                                                                                       \
   hipLaunchKernelGGL((gemm_cl_kernel<KA, KB, VA_, VB_, EPI, BM, BN, BF_, XOP>), grid, dim3(GTPB), 0, s, a, b, d, ldd, \
-                     stats, kchunk, tiles_n, stat_slots, epi_y, epi_ab, epi_w16, dchunk)
+                     stats, kchunk, tiles_n, stat_slots, epi_y, epi_ab, epi_w16, dchunk, red_dev)
   if constexpr (XOP == XOP_GENB) {  // B is generated (gb_gemm_wgrad_gen3): never a vector load of it
     if (bf) { if (va) GB_L(true, false, true); else GB_L(false, false, true); }
     else { if (va) GB_L(true, false, false); else GB_L(false, false, false); }
@@ -434,16 +422,16 @@ template <int KA, int KB, int EPI, int XOP = XOP_NONE>
 static void launch_gemm(const Operand &a, const Operand &b, bool va, bool vb, float *d, long long ldd, double *stats,
                         long long kchunk, unsigned chunks, hipStream_t s, bool bf16, int stat_slots = 1,
                         const float *epi_y = nullptr, const float *epi_ab = nullptr, const uint16_t *epi_w16 = nullptr,
-                        long long dchunk = 0) {
+                        long long dchunk = 0, const long long *red_dev = nullptr) {
   // ... and 64 x 64 tiles while those number at most four per CU: the pointwise C -> 4C -> C pairs on a few thousand
   // rows then run on 2-4x as many workgroups (measured: the ten such shapes of the step 735 -> 621 us in total)
   const bool bn64 = b.rows <= 64 || (((a.rows + 63) / 64) * ((b.rows + 63) / 64) * chunks <= 1024);
   const long long blocks128 = ((a.rows + 127) / 128) * ((b.rows + (bn64 ? 63 : 127)) / (bn64 ? 64 : 128)) * chunks;
   const bool bm64 = a.rows <= 64 || blocks128 < 512;
-  if (bm64 && bn64) launch_tile<KA, KB, EPI, 64, 64, XOP>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, bf16, stat_slots, epi_y, epi_ab, epi_w16, dchunk);
-  else if (bm64) launch_tile<KA, KB, EPI, 64, 128, XOP>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, bf16, stat_slots, epi_y, epi_ab, epi_w16, dchunk);
-  else if (bn64) launch_tile<KA, KB, EPI, 128, 64, XOP>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, bf16, stat_slots, epi_y, epi_ab, epi_w16, dchunk);
-  else launch_tile<KA, KB, EPI, 128, 128, XOP>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, bf16, stat_slots, epi_y, epi_ab, epi_w16, dchunk);
+  if (bm64 && bn64) launch_tile<KA, KB, EPI, 64, 64, XOP>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, bf16, stat_slots, epi_y, epi_ab, epi_w16, dchunk, red_dev);
+  else if (bm64) launch_tile<KA, KB, EPI, 64, 128, XOP>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, bf16, stat_slots, epi_y, epi_ab, epi_w16, dchunk, red_dev);
+  else if (bn64) launch_tile<KA, KB, EPI, 128, 64, XOP>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, bf16, stat_slots, epi_y, epi_ab, epi_w16, dchunk, red_dev);
+  else launch_tile<KA, KB, EPI, 128, 128, XOP>(a, b, va, vb, d, ldd, stats, kchunk, chunks, s, bf16, stat_slots, epi_y, epi_ab, epi_w16, dchunk, red_dev);
 }
 
 // out[i] = ((part0[i] + part1[i]) + part2[i]) + ...   (chunks copies of `elems` floats, summed in chunk order)
@@ -518,14 +506,11 @@ static int gemm_fwd_impl(const float *x, const float *w, const float *aff, const
     return GB_EINVAL;
   if (P == 0) return fin ? GB_EINVAL : GB_OK;
   if (P / 64 * ((N + 63) / 64) > 0x7fffffffLL) return GB_ERANGE;
-  RsPool sp = {};
-  sp.storage = opts_storage(opts) & (GB_STORE_X_BF16 | GB_STORE_Y_BF16);
-  if (opts_storage(opts) & GB_STORE_YPREV_BF16) return GB_EINVAL;
   if (rs_gemm_try(x, w, y, aff, stats, stat_slots, nullptr, nullptr, P, K, N, 1, stats ? RS_STATS : RS_STORE,
-                  as_stream(stream), bf16, opts_reserved(opts), nullptr, stats ? row_w16 : nullptr,
-                  sp.storage ? &sp : nullptr))
+                  as_stream(stream), bf16, opts_reserved(opts), nullptr, stats ? row_w16 : nullptr, nullptr,
+                  opts_rows(opts)))
     return finalize_after(check_launch("gb_gemm_fwd"), fin, stats, stat_slots, N, stream);
-  if (sp.storage) return GB_EINVAL;  // bf16 tensors are only read / written by the row-streaming kernel
+  if (opts_rows(opts)) return GB_EINVAL;  // a device-side row count: row-streaming kernel only
   Operand a = {x, P, K, K, aff};
   Operand b = {w, N, K, K, nullptr};
   const bool v = (K % 4 == 0) && aligned16(x) && aligned16(w);
@@ -575,11 +560,12 @@ extern "C" int gb_gemm_fwd_w(const float *x, const float *w, const float *aff, c
 
 // The last layer of a crop stack (reference modules.py:104-124: SharedMLP's final conv + BatchNorm + ReLU, then
 // max_pool2d over each crop) WITHOUT storing its output: the weighted BatchNorm sums and per-(tile, seed, crop,
-// column) extrema of sign(gamma)*y leave the GEMM's epilogue (csrc/gemm_rs.hip, RS_STATS_POOL); gb_pool_pairs finishes
+// column) extrema of sign(gamma)*y leave the GEMM's epilogue (csrc/gemm_rs.hip, RS_STATS_POOL_V); gb_pool_pairs finishes
 // the pooling once the statistics are known.  Only the row-streaming kernel implements it: GB_EINVAL when the shape is
 // not eligible (ask gb_gemm_uses_rs(P, K, N, 0, 3, has_aff)).
 extern "C" int gb_gemm_fwd_pool(const float *x, const float *w, const float *aff, const int32_t *row_key,
-                                const float *gamma, float *pairs, int with_rows, float *y, double *stats,
+                                const float *gamma, float *pairs, long long pairs_elems, long long seeds, float *y,
+                                double *stats,
                                 int stat_slots, long long P, int K, int N, int D, const GbBnFinalize *fin,
                                 const GbGemmOpts *opts, void *stream) {
   if (P < 1 || K < 1 || N < 1 || D < 1 || D > 4 || !x || !w || !row_key || !gamma || !pairs || !stats || stat_slots < 1 ||
@@ -587,41 +573,18 @@ extern "C" int gb_gemm_fwd_pool(const float *x, const float *w, const float *aff
     return GB_EINVAL;
   if (fin && (!fin->gamma || !fin->beta || !fin->ab || fin->P < 1 || fin->training != 1)) return GB_EINVAL;
   if (P > 0x7fffffffLL - 64) return GB_ERANGE;
+  // slot (tile + seed) of D*N floats for every (32-row tile, seed id < seeds) pair the keys can name
+  if (seeds < 1 || pairs_elems < ((P + 31) / 32 + seeds) * (long long)D * N) return GB_ERANGE;
   RsPool pool = {};
   pool.key = row_key;
   pool.gamma = gamma;
   pool.pairs = reinterpret_cast<float2 *>(pairs);
   pool.D = D;
-  pool.storage = opts_storage(opts) & (GB_STORE_X_BF16 | GB_STORE_Y_BF16);
-  if (opts_storage(opts) & GB_STORE_YPREV_BF16) return GB_EINVAL;
-  // values only and no Y: a forward-only caller (inference) - nothing can find the arg-max rows afterwards
-  if (!rs_gemm_try(x, w, y, aff, stats, stat_slots, nullptr, nullptr, P, K, N, 1, with_rows ? RS_STATS_POOL : RS_STATS_POOL_V,
-                   as_stream(stream),
-                   opts_bf16(opts), opts_reserved(opts), nullptr, nullptr, &pool))
+  // no Y: a forward-only caller (inference) - nothing can find the arg-max rows afterwards
+  if (!rs_gemm_try(x, w, y, aff, stats, stat_slots, nullptr, nullptr, P, K, N, 1, RS_STATS_POOL_V, as_stream(stream),
+                   opts_bf16(opts), opts_reserved(opts), nullptr, nullptr, &pool, opts_rows(opts)))
     return GB_EINVAL;
   return finalize_after(check_launch("gb_gemm_fwd_pool"), fin, stats, stat_slots, N, stream);
-}
-
-// Dense half of the low-rank backward of a pooled last layer (csrc/crop_bwd.hip): dz (P,K) holds the sparse part S on
-// entry and dX~ = S - w (v + X~ M) on return, X~ = relu(a2*y2 + b2); the BatchNorm-backward sums of the layer that
-// produced y2 (mask a2*y2 + b2 > 0) leave the same epilogue, exactly as in gb_gemm_dgrad.  Row-streaming kernel only.
-extern "C" int gb_crop_bwd_dense(const float *y2, const float *ab2, const float *mmat, const float *vvec,
-                                 const float *row_w, float *dz, double *dstats, int stat_slots, long long P, int K,
-                                 double *dstats_total, float *dbeta, float *dgamma, const GbGemmOpts *opts,
-                                 void *stream) {
-  if (P < 1 || K < 1 || !y2 || !ab2 || !mmat || !vvec || !row_w || !dz || !dstats || stat_slots < 1 || !dbeta || !dgamma ||
-      opts_bad(opts) || reinterpret_cast<uintptr_t>(row_w) % 16)
-    return GB_EINVAL;
-  if (opts_storage(opts)) return GB_EINVAL;  // this entry reads and writes fp32 tensors only
-  RsPool lr = {};
-  lr.lr_v = vvec;
-  lr.lr_roww = row_w;
-  if (!rs_gemm_try(y2, mmat, dz, ab2, dstats, stat_slots, y2, ab2, P, K, K, 0, RS_BNBWD_LR, as_stream(stream),
-                   opts_bf16(opts), opts_reserved(opts), nullptr, nullptr, &lr))
-    return GB_EINVAL;
-  const int rc = check_launch("gb_crop_bwd_dense");
-  if (rc != GB_OK) return rc;
-  return gb_bn_bwd_reduce(dstats, stat_slots, K, stat_slots > 1 ? dstats_total : nullptr, dbeta, dgamma, stream);
 }
 
 // ---- the 3-input first layer of a stack folded into its consumers (its output Y1 = x0 W1^T is never stored) ----------
@@ -637,11 +600,9 @@ extern "C" int gb_gemm_fwd_gen3(const float *x0, const float *w1, const float *a
   RsPool gen = {};
   gen.gen_x = x0;
   gen.gen_w = w1;
-  gen.storage = opts_storage(opts) & GB_STORE_Y_BF16;
-  if (opts_storage(opts) & ~GB_STORE_Y_BF16) return GB_EINVAL;
   if (!stats) return GB_EINVAL;  // (the eval-mode caller passes a scratch sum buffer: the kernel always forms the sums)
   if (!rs_gemm_try(nullptr, w, y, ab1, stats, stat_slots, nullptr, nullptr, P, K, N, 1, RS_STATS, as_stream(stream),
-                   opts_bf16(opts), opts_reserved(opts), nullptr, row_w16, &gen))
+                   opts_bf16(opts), opts_reserved(opts), nullptr, row_w16, &gen, opts_rows(opts)))
     return GB_EINVAL;
   return finalize_after(check_launch("gb_gemm_fwd_gen3"), fin, stats, stat_slots, N, stream);
 }
@@ -650,10 +611,9 @@ extern "C" int gb_gemm_fwd_gen3(const float *x0, const float *w1, const float *a
 extern "C" int gb_gemm_wgrad_gen3(const float *dy, const float *x0, const float *w1, const float *ab1, float *dw,
                                   long long P, int K, int N, const GbGemmOpts *opts, void *stream) {
   if (P < 0 || K < 1 || N < 1 || !dy || !x0 || !w1 || !ab1 || !dw || opts_bad(opts)) return GB_EINVAL;
-  if (opts_storage(opts)) return GB_EINVAL;  // this entry reads and writes fp32 tensors only
   if (P == 0) return GB_OK;
-  Operand a = {dy, N, P, N, nullptr, nullptr, nullptr, nullptr, 0};
-  Operand b = {nullptr, K, P, K, ab1, nullptr, x0, w1, 0};
+  Operand a = {dy, N, P, N, nullptr, nullptr, nullptr};
+  Operand b = {nullptr, K, P, K, ab1, x0, w1};
   const long long tiles = (long long)((N + (N <= 64 ? 63 : 127)) / (N <= 64 ? 64 : 128)) *
                           ((K + (K <= 64 ? 63 : 127)) / (K <= 64 ? 64 : 128));
   long long chunks = 1024 / tiles;
@@ -665,7 +625,8 @@ extern "C" int gb_gemm_wgrad_gen3(const float *dy, const float *x0, const float 
   if (chunks > 65535) return GB_ERANGE;
   const bool va = (N % 4 == 0) && aligned16(dy);
   launch_gemm<OP_RC, OP_RC, EPI_ATOMIC, XOP_GENB>(a, b, va, false, dw, K, nullptr, kchunk, (unsigned)chunks,
-                                              as_stream(stream), opts_bf16(opts));
+                                              as_stream(stream), opts_bf16(opts), 1, nullptr, nullptr, nullptr, 0,
+                                              opts_rows(opts));
   return check_launch("gb_gemm_wgrad_gen3");
 }
 
@@ -689,13 +650,10 @@ extern "C" int gb_gemm_dgrad(const float *dy, const float *w, float *dx, const f
   };
   if (P == 0) return GB_OK;
   if (P / 64 * ((K + 63) / 64) > 0x7fffffffLL) return GB_ERANGE;
-  RsPool sp = {};
-  sp.storage = opts_storage(opts) & GB_STORE_YPREV_BF16;
-  if (opts_storage(opts) & ~GB_STORE_YPREV_BF16) return GB_EINVAL;
   if (rs_gemm_try(dy, w, dx, nullptr, dstats, stat_slots, y_prev, ab_prev, P, N, K, 0, dstats ? RS_BNBWD : RS_STORE,
-                  as_stream(stream), bf16, opts_reserved(opts), nullptr, nullptr, sp.storage ? &sp : nullptr))
+                  as_stream(stream), bf16, opts_reserved(opts), nullptr, nullptr, nullptr, opts_rows(opts)))
     return done(check_launch("gb_gemm_dgrad"));
-  if (sp.storage) return GB_EINVAL;  // a bf16 y_prev is only read by the row-streaming kernel
+  if (opts_rows(opts)) return GB_EINVAL;  // a device-side row count: row-streaming kernel only
   Operand a = {dy, P, N, N, nullptr};
   Operand b = {w, K, N, K, nullptr};  // tile rows = k, reduction = n, element (k,n) at w[n*K + k]
   const bool va = (N % 4 == 0) && aligned16(dy);
@@ -733,7 +691,8 @@ extern "C" int gb_gemm_wgrad(const float *dy, const float *x, const float *x_aff
                              int N, const GbGemmOpts *opts, void *stream) {
   if (P < 0 || K < 1 || N < 1 || !dy || !x || !dw || opts_bad(opts)) return GB_EINVAL;
   if (P == 0) return GB_OK;
-  if (K <= 4 && !x_aff && N % 4 == 0 && N / 4 <= GTPB && P >= 4096 && reinterpret_cast<uintptr_t>(dy) % 16 == 0) {
+  if (K <= 4 && !x_aff && N % 4 == 0 && N / 4 <= GTPB && P >= 4096 && reinterpret_cast<uintptr_t>(dy) % 16 == 0 &&
+      !opts_rows(opts)) {
     const dim3 grid((unsigned)((P + WSK_ROWS - 1) / WSK_ROWS));
     if (K == 1) hipLaunchKernelGGL(wgrad_smallk_kernel<1>, grid, dim3(GTPB), 0, as_stream(stream), dy, x, dw, P, N);
     else if (K == 2) hipLaunchKernelGGL(wgrad_smallk_kernel<2>, grid, dim3(GTPB), 0, as_stream(stream), dy, x, dw, P, N);
@@ -743,9 +702,6 @@ extern "C" int gb_gemm_wgrad(const float *dy, const float *x, const float *x_aff
   }
   Operand a = {dy, N, P, N, nullptr};  // tile rows = n, reduction = p, element (n,p) at dy[p*N + n]
   Operand b = {x, K, P, K, x_aff};     // tile rows = k, reduction = p, element (k,p) at x[p*K + k]
-  if (opts_storage(opts) & ~GB_STORE_X_BF16) return GB_EINVAL;
-  b.bf16 = (opts_storage(opts) & GB_STORE_X_BF16) ? 1 : 0;   // x as bf16 in HBM (bf16 kernels only: opts_storage)
-  if (b.bf16 && P < 16) return GB_EINVAL;                     // (reductions below 16 stay on the fp32 instruction)
   const long long tiles = (long long)((N + (N <= 64 ? 63 : 127)) / (N <= 64 ? 64 : 128)) *
                           ((K + (K <= 64 ? 63 : 127)) / (K <= 64 ? 64 : 128));
   // split the P reduction so that ~1024 workgroups exist, chunks a multiple of the reduction step
@@ -758,40 +714,10 @@ extern "C" int gb_gemm_wgrad(const float *dy, const float *x, const float *x_aff
   chunks = (P + kchunk - 1) / kchunk;
   if (chunks > 65535) return GB_ERANGE;
   const bool va = (N % 4 == 0) && aligned16(dy);
-  const bool vb = (K % 4 == 0) && aligned16(x);   // (8-byte vector loads of a bf16 x need no more than that)
+  const bool vb = (K % 4 == 0) && aligned16(x);
   launch_gemm<OP_RC, OP_RC, EPI_ATOMIC>(a, b, va, vb, dw, K, nullptr, kchunk, (unsigned)chunks, as_stream(stream),
-                                        opts_bf16(opts));
+                                        opts_bf16(opts), 1, nullptr, nullptr, nullptr, 0, opts_rows(opts));
   return check_launch("gb_gemm_wgrad");
-}
-
-// G (K,K) += sum_p w_p f(x_p) f(x_p)^T, f = relu(a*x + b) (x_aff, optional), w = row_w (optional): the weighted Gram
-// matrix of a layer's activations - what the weight gradient of a BatchNorm layer behind it needs INSTEAD of the dense
-// product dY^T X when dY is (sparse + affine in y = X W^T) (csrc/crop_bwd.hip).  Same kernel and split of the row
-// reduction as gb_gemm_wgrad (dy := w * f(x)); G is symmetric, both halves are formed.  Caller zeroes G.
-extern "C" int gb_gemm_gram(const float *x, const float *x_aff, const float *row_w, float *gmat, long long P, int K,
-                            const GbGemmOpts *opts, void *stream) {
-  if (P < 0 || K < 1 || !x || !gmat || opts_bad(opts)) return GB_EINVAL;
-  if (opts_storage(opts)) return GB_EINVAL;  // this entry reads and writes fp32 tensors only
-  if (P == 0) return GB_OK;
-  Operand a = {x, K, P, K, x_aff, row_w};
-  Operand b = {x, K, P, K, x_aff, nullptr};
-  const long long tiles = (long long)((K + (K <= 64 ? 63 : 127)) / (K <= 64 ? 64 : 128)) *
-                          ((K + (K <= 64 ? 63 : 127)) / (K <= 64 ? 64 : 128));
-  long long chunks = 1024 / tiles;
-  if (chunks < 1) chunks = 1;
-  long long kchunk = (P + chunks - 1) / chunks;
-  kchunk = (kchunk + GK - 1) / GK * GK;
-  if (kchunk < 256) kchunk = 256;
-  chunks = (P + kchunk - 1) / kchunk;
-  if (chunks > 65535) return GB_ERANGE;
-  const bool v = (K % 4 == 0) && aligned16(x);
-  if (row_w)
-    launch_gemm<OP_RC, OP_RC, EPI_ATOMIC, XOP_RWA>(a, b, v, v, gmat, K, nullptr, kchunk, (unsigned)chunks,
-                                                   as_stream(stream), opts_bf16(opts));
-  else
-    launch_gemm<OP_RC, OP_RC, EPI_ATOMIC>(a, b, v, v, gmat, K, nullptr, kchunk, (unsigned)chunks, as_stream(stream),
-                                          opts_bf16(opts));
-  return check_launch("gb_gemm_gram");
 }
 
 // dgrad into the FIRST layer of a stack whose input x has 3 channels (xyz-only grouped rows): dZ = dY W is formed
@@ -805,10 +731,9 @@ extern "C" int gb_gemm_dgrad_first(const float *dy, const float *w, const float 
                                    const GbGemmOpts *opts, void *stream) {
   if (P < 0 || K < 1 || N < 1 || !dy || !w || !y_prev || !ab_prev || !x_in || !sums || slots < 1 || opts_bad(opts))
     return GB_EINVAL;
-  if (opts_storage(opts)) return GB_EINVAL;  // this entry reads and writes fp32 tensors only
   if (P == 0) return GB_OK;
   if (!rs_gemm_try(dy, w, nullptr, nullptr, sums, slots, y_prev, ab_prev, P, N, K, 0, RS_BNBWD_X, as_stream(stream),
-                   opts_bf16(opts), opts_reserved(opts), x_in))
+                   opts_bf16(opts), opts_reserved(opts), x_in, nullptr, nullptr, opts_rows(opts)))
     return GB_EINVAL;
   return check_launch("gb_gemm_dgrad_first");
 }
@@ -820,12 +745,11 @@ extern "C" int gb_gemm_dgrad_first_gen3(const float *dy, const float *w, const f
                                         const GbGemmOpts *opts, void *stream) {
   if (P < 0 || K < 1 || N < 1 || !dy || !w || !ab_prev || !x_in || !w_in || !sums || slots < 1 || opts_bad(opts))
     return GB_EINVAL;
-  if (opts_storage(opts)) return GB_EINVAL;  // this entry reads and writes fp32 tensors only
   if (P == 0) return GB_OK;
   RsPool gen = {};
   gen.gen_w = w_in;
   if (!rs_gemm_try(dy, w, nullptr, nullptr, sums, slots, nullptr, ab_prev, P, N, K, 0, RS_BNBWD_X, as_stream(stream),
-                   opts_bf16(opts), opts_reserved(opts), x_in, nullptr, &gen))
+                   opts_bf16(opts), opts_reserved(opts), x_in, nullptr, &gen, opts_rows(opts)))
     return GB_EINVAL;
   return check_launch("gb_gemm_dgrad_first_gen3");
 }
@@ -833,7 +757,12 @@ extern "C" int gb_gemm_dgrad_first_gen3(const float *dy, const float *w, const f
 // mom fp64 [12] += [sum_p w_p x (3), sum_p w_p x x^T (3x3)] of x (P,3), w = row_w or 1; caller-zeroed
 namespace gb {
 __global__ __launch_bounds__(GTPB) void moments3_kernel(const float *__restrict__ x, const float *__restrict__ rw,
-                                                        long long P, double *__restrict__ mom) {
+                                                        long long P, double *__restrict__ mom,
+                                                        const long long *__restrict__ rows_dev) {
+  if (rows_dev) {   // the caller's device-side row count (<= the capacity P)
+    const long long pd = *rows_dev;
+    P = pd < P ? (pd > 0 ? pd : 0) : P;
+  }
   // few workgroups, each striding over the rows: the 12 results are same-address fp64 atomics, which serialise
   // (one per wave of a 512-block grid cost 190 us; one per workgroup of a 64-block grid is free)
   __shared__ double part[GTPB / 64][12];
@@ -878,11 +807,12 @@ __global__ __launch_bounds__(GTPB) void moments3_kernel(const float *__restrict_
 }
 }  // namespace gb
 
-extern "C" int gb_moments3(const float *x, const float *row_w, long long P, double *mom, void *stream) {
+extern "C" int gb_moments3(const float *x, const float *row_w, long long P, double *mom, const long long *rows_dev,
+                           void *stream) {
   if (P < 0 || !x || !mom) return GB_EINVAL;
   if (P == 0) return GB_OK;
   long long blocks = (P + 8 * GTPB - 1) / (8 * GTPB);
   if (blocks > 128) blocks = 128;
-  hipLaunchKernelGGL(moments3_kernel, dim3((unsigned)blocks), dim3(GTPB), 0, as_stream(stream), x, row_w, P, mom);
+  hipLaunchKernelGGL(moments3_kernel, dim3((unsigned)blocks), dim3(GTPB), 0, as_stream(stream), x, row_w, P, mom, rows_dev);
   return check_launch("gb_moments3");
 }

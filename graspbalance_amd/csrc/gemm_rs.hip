@@ -47,15 +47,13 @@ struct RsArgs {
   int pool_d;               // RS_STATS_POOL: crops per seed (1..4)
   const float *gen_x;       // GEN3 / RS_BNBWD_X: (P,3) rows the A operand / the epilogue's y are generated from
   const float *gen_w;       // ... with the 3-input first layer's weight (R,3) resp. (C,3): y1 = ((x*w0) + (y*w1)) + (z*w2)
-  const float *lr_v;        // RS_BNBWD_LR: per-column offset v (C)
-  const float *lr_roww;     // RS_BNBWD_LR: per-row weight w (readable up to a multiple of 32 rows)
+  const long long *rows_dev;  // optional (device): the actual row count, <= P (GbGemmOpts.rows_dev); P is then the capacity
   long long P;
   int R, C, lda, ldd;
   int w_kc;             // 1: B[r][c] = w[c*R + r] (forward, W (C,R));  0: B[r][c] = w[r*C + c] (dgrad, W (R,C))
   int slots, nch;       // statistics slot rows ; chunks = ceil(R / 32)
   int stagger;          // delay waves 4-7 by half a tile
   int tail_split;       // cut the tiles of a short last round into column groups
-  int storage;          // BF kernels only: GB_STORE_X_BF16 (a), GB_STORE_Y_BF16 (d), GB_STORE_YPREV_BF16 (epi_y) are bf16 in HBM
 };
 
 // BF (GB_PREC_BF16): B lives in LDS as bf16 in [k / 8][C32][8] order - the 8 reduction indices one lane feeds to a
@@ -66,10 +64,8 @@ __device__ __forceinline__ float lin3(float x, float y, float z, float w0, float
   return ((x * w0) + (y * w1)) + (z * w2);   // the ONE evaluation order every consumer of the folded layer uses
 }
 
-// ST (bf16 kernels): GbGemmOpts.storage as a COMPILE-TIME mode - which of a / d / epi_y are bf16 in HBM.  (As run-time
-// branches the two load / store forms tripled the spills of the bf16 instantiations: <8,1> 78 -> 236 registers.)
-template <int NT, int EPI, bool BF = false, bool GEN3 = false, int ST = 0>
-__global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_BNBWD_X && EPI != RS_BNBWD_LR) ? 4 : 2)) void gemm_rs_kernel(RsArgs g) {
+template <int NT, int EPI, bool BF = false, bool GEN3 = false>
+__global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_BNBWD_X) ? 4 : 2)) void gemm_rs_kernel(RsArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int C32 = NT * 32;
   const int rpad = g.nch * RS_CH;
@@ -153,14 +149,19 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
     for (int i = t; i < rpad * 4; i += RS_TPB) s_gen[i] = ((i & 3) < 3 && (i >> 2) < g.R) ? g.gen_w[(i >> 2) * 3 + (i & 3)] : 0.f;
   __syncthreads();
 
-  const long long ntiles = (g.P + 31) / 32;
+  // rows of this launch: the caller's device-side count when there is one (it is not known on the host: no read-back)
+  long long gP = g.P;
+  if (g.rows_dev) {
+    const long long pd = *g.rows_dev;
+    gP = pd < g.P ? (pd > 0 ? pd : 0) : g.P;
+  }
+  const long long ntiles = (gP + 31) / 32;
   const long long nw = (long long)gridDim.x * RS_WAVES;
   // wave w of every workgroup before wave w+1 of any: with fewer tiles than waves the work spreads over all CUs
   // (and over the four SIMDs of each) instead of filling the 8 waves of the first workgroups
   long long tile = (long long)wave * gridDim.x + blockIdx.x;
 
-  constexpr bool BNB = EPI == RS_BNBWD || EPI == RS_BNBWD_X || EPI == RS_BNBWD_LR;
-  constexpr bool LR = EPI == RS_BNBWD_LR;  // D' = D_in - w_row*(D + v_col), see gemm_rs.h
+  constexpr bool BNB = EPI == RS_BNBWD || EPI == RS_BNBWD_X;
   constexpr int NS = EPI == RS_BNBWD_X ? 5 : 2;  // column sums per column: [g, g*xhat (, g*x0, g*x1, g*x2)] / [y, y^2]
   double dsum[NT], dsq[NT], dtx[EPI == RS_BNBWD_X ? NT : 1][3];
 #pragma unroll
@@ -196,60 +197,17 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
   auto load_chunk = [&](float4 (&dst)[4], long long tl, int kc) {
     const long long row = tl * 32 + m;
     if constexpr (GEN3) {  // the row's xyz (an L1 hit after the tile's first chunk); the values are formed at use
-      const bool ok = row < g.P;
+      const bool ok = row < gP;
       dst[0] = make_float4(ok ? g.gen_x[row * 3] : 0.f, ok ? g.gen_x[row * 3 + 1] : 0.f, ok ? g.gen_x[row * 3 + 2] : 0.f, 0.f);
       return;
     }
     const int k = kc * RS_CH + h * 16;
-    if constexpr (BF) {
-      if constexpr ((ST & GB_STORE_X_BF16) != 0) {  // the row's 16 values are 32 bytes of bf16: two 16-byte loads, widened
-        const uint16_t *pb = reinterpret_cast<const uint16_t *>(g.a) + row * g.lda + k;
-        uint4 u[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-        if (row < g.P && k < g.R) {
-          u[0] = *reinterpret_cast<const uint4 *>(pb);
-          u[1] = *reinterpret_cast<const uint4 *>(pb + 8);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          dst[2 * i] = make_float4(__uint_as_float(u[i].x << 16), __uint_as_float(u[i].x & 0xFFFF0000u),
-                                   __uint_as_float(u[i].y << 16), __uint_as_float(u[i].y & 0xFFFF0000u));
-          dst[2 * i + 1] = make_float4(__uint_as_float(u[i].z << 16), __uint_as_float(u[i].z & 0xFFFF0000u),
-                                       __uint_as_float(u[i].w << 16), __uint_as_float(u[i].w & 0xFFFF0000u));
-        }
-        return;
-      }
-    }
     const float *p = g.a + row * g.lda + k;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      dst[i] = (row < g.P && k + 4 * i < g.R) ? *reinterpret_cast<const float4 *>(p + 4 * i)
+      dst[i] = (row < gP && k + 4 * i < g.R) ? *reinterpret_cast<const float4 *>(p + 4 * i)
                                               : make_float4(0.f, 0.f, 0.f, 0.f);
   };
-  // activation tensors that may live in HBM as bf16 (BF kernels, GbGemmOpts.storage): element offset -> value
-  auto st_d = [&](long long off, float v) {
-    if constexpr (BF) {
-      if constexpr ((ST & GB_STORE_Y_BF16) != 0) {
-        reinterpret_cast<__bf16 *>(g.d)[off] = (__bf16)v;
-        return;
-      }
-    }
-    g.d[off] = v;
-  };
-  auto ld_y = [&](long long off) -> float {
-    if constexpr (BF) {
-      if constexpr ((ST & GB_STORE_YPREV_BF16) != 0)
-        return __uint_as_float((unsigned)reinterpret_cast<const uint16_t *>(g.epi_y)[off] << 16);
-    }
-    return g.epi_y[off];
-  };
-  // the value a bf16-stored output will be read back as (statistics and pooled extrema describe THAT)
-  auto rnd_d = [&](float v) -> float {
-    if constexpr (BF) {
-      if constexpr ((ST & GB_STORE_Y_BF16) != 0) return (float)(__bf16)v;
-    }
-    return v;
-  };
-
   // The two waves that share a SIMD (w and w+4) run the same program from the same start and would reach their
   // MFMA phases and their epilogues together; delaying the upper four by half a tile's worth of MFMA time lets one
   // partner's epilogue (stores, statistics) run under the other's MFMAs (+2-4 % on the 1 M-row layers).
@@ -290,12 +248,12 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
       long long ntile = tile;
       if (nkc == g.nch) { nkc = 0; ntile = tile + nw; }
       const bool more = ntile < tend;
-      // RS_STATS_POOL: the next tile's first chunk is requested AFTER this tile's epilogue (its 16 registers are what the
+      // RS_STATS_POOL_V: the next tile's first chunk is requested AFTER this tile's epilogue (its 16 registers are what the
       // epilogue's row keys need; holding both spilled into scratch, and the epilogue then ran 3x the tile's MFMA time)
 #ifndef GB_DEFER
 #define GB_DEFER 1
 #endif
-      const bool defer = GB_DEFER && (EPI == RS_STATS_POOL || EPI == RS_STATS_POOL_V) && kc == g.nch - 1;
+      const bool defer = GB_DEFER && EPI == RS_STATS_POOL_V && kc == g.nch - 1;
       if (more && !defer) load_chunk(nxt, ntile, nkc);
 
       float av[16];
@@ -320,7 +278,7 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
       }
       // RS_BNBWD: the y values the epilogue needs are requested BEFORE the tile's last MFMA block, so their
       // latency hides behind it (registers permitting; otherwise per column tile inside the epilogue)
-      constexpr bool YPRE = BNB && !LR && NT <= 4;  // (LR also holds D_in and the row weights in its epilogue)
+      constexpr bool YPRE = BNB && NT <= 4;
       float yv[YPRE ? NT : 1][16];
       float xr[EPI == RS_BNBWD_X ? 16 : 1][3];  // RS_BNBWD_X: the 3-channel input rows of this tile, same early request
       if constexpr (EPI == RS_BNBWD_X) {
@@ -329,7 +287,7 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
           for (int r = 0; r < 16; ++r) {
             const long long row = tile * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) xr[r][j] = row < g.P ? g.epi_x[row * 3 + j] : 0.f;
+            for (int j = 0; j < 3; ++j) xr[r][j] = row < gP ? g.epi_x[row * 3 + j] : 0.f;
           }
         }
       }
@@ -350,7 +308,7 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
               for (int r = 0; r < 16; ++r) {
                 const long long row = tile * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
                 const int col = q * 32 + m;
-                yv[q][r] = (col < g.C && row < g.P) ? ld_y(row * g.ldd + col) : 0.f;
+                yv[q][r] = (col < g.C && row < gP) ? g.epi_y[row * g.ldd + col] : 0.f;
               }
             }
         }
@@ -394,14 +352,14 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
         // per-element bounds checks and 64-bit index arithmetic: one uniform row pointer per accumulator register plus a
         // 32-bit lane offset.  (The generic path spent ~16 vector instructions per stored element on them: ~10 k cycles
         // per tile beside 32 k cycles of MFMA.)
-        const bool full = tile * 32 + 32 <= g.P && g.C == C32;
+        const bool full = tile * 32 + 32 <= gP && g.C == C32;
         if constexpr (EPI == RS_STATS_POOL_V) {
           // As RS_STATS_POOL below, values only: per (seed in the tile, crop, column) max over the member rows of
           // sign(gamma)*y.  The member predicates are formed once per (seed, crop) and shared by the NT column tiles; each
           // element then costs one select and half a v_max3 (the form that also tracks the row - compare, two selects, mask logic through SGPR pairs - ran 3x the
           // tile's MFMA time).
           const long long trow = (long long)__builtin_amdgcn_readfirstlane((int)tile) * 32;
-          const long long lastrow = trow + 31 < g.P ? trow + 31 : g.P - 1;
+          const long long lastrow = trow + 31 < gP ? trow + 31 : gP - 1;
           const int s_lo = g.epi_key[trow] >> 13, s_hi = g.epi_key[lastrow] >> 13;  // wave-uniform (scalar loads)
           int rk[16];
 #pragma unroll
@@ -410,7 +368,7 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
             rk[4 * i] = k4.x; rk[4 * i + 1] = k4.y; rk[4 * i + 2] = k4.z; rk[4 * i + 3] = k4.w;
           }
           const unsigned lane_off = (unsigned)(4 * h) * (unsigned)g.ldd + (unsigned)m;
-          const int nrow = (int)(g.P - trow) - 4 * h;    // rows (r&3) + 8(r>>2) below this are valid
+          const int nrow = (int)(gP - trow) - 4 * h;    // rows (r&3) + 8(r>>2) below this are valid
           float *pv = reinterpret_cast<float *>(g.pairs);
           // Pass 1, column tile by column tile: weighted BatchNorm sums, the Y store, then the accumulators are turned
           // into sign(gamma) * y IN PLACE (no second copy of the tile's 128 registers).
@@ -420,8 +378,7 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
             float cs = 0.f, cq = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const float v = rnd_d(acc[q][r]);
-              acc[q][r] = v;
+              const float v = acc[q][r];
               const float wv = (float)((rk[r] >> 4) & 0x1FF) * v;
               cs += wv;
               cq += wv * v;
@@ -432,7 +389,7 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
                 const long long ro = (trow + (r & 3) + 8 * (r >> 2)) * (long long)g.ldd + q * 32;  // wave-uniform
-                if ((r & 3) + 8 * (r >> 2) < nrow) st_d(ro + lane_off, acc[q][r]);
+                if ((r & 3) + 8 * (r >> 2) < nrow) g.d[ro + lane_off] = acc[q][r];
               }
             }
             const float sg = g.epi_gamma[q * 32 + m] < 0.f ? -1.f : 1.f;
@@ -467,73 +424,6 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
         } else
-        if constexpr (EPI == RS_STATS_POOL) {
-          // Y is NOT stored.  What leaves the tile: the weighted BatchNorm sums (as RS_STATS) and, per (seed in the
-          // tile, crop d, column), the extreme of sign(gamma)*y over the seed's member rows in this tile + the row
-          // holding it - relu(a*y + b) is monotone in y with the sign of a = gamma*rstd, so the crop's pooled value and
-          // its arg-max row follow from these extrema once the statistics are known (pool_pairs_kernel).  A seed's rows
-          // are contiguous, so a (tile, seed) pair is unique and gets the slot tile + seed: plain stores, no atomics.
-          // C == C32 (host-checked); rows >= P carry key 0 (no membership, weight 0) and accumulators of exact zeros.
-          const long long trow = (long long)__builtin_amdgcn_readfirstlane((int)tile) * 32;
-          const long long lastrow = trow + 31 < g.P ? trow + 31 : g.P - 1;
-          const int s_lo = g.epi_key[trow] >> 13, s_hi = g.epi_key[lastrow] >> 13;  // wave-uniform (scalar loads)
-          // the row keys of this lane's 16 rows (rk[r]: row 4h + (r&3) + 8(r>>2)); requested here, not before the
-          // tile's last MFMA block: 16 more live registers there spill (the SIMD's other wave covers the L2 round trip)
-          int rk[16];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int4 k4 = *reinterpret_cast<const int4 *>(g.epi_key + trow + 4 * h + 8 * i);
-            rk[4 * i] = k4.x; rk[4 * i + 1] = k4.y; rk[4 * i + 2] = k4.z; rk[4 * i + 3] = k4.w;
-          }
-          // column tile by column tile (its 16 accumulators are dead afterwards: the register pressure of the dynamic
-          // seed / crop loops stays that of ONE column tile)
-#pragma unroll
-          for (int q = 0; q < NT; ++q) {
-            if (!in(q)) continue;
-            float cs = 0.f, cq = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const float v = acc[q][r];
-              const float wv = (float)((rk[r] >> 4) & 0x1FF) * v;
-              cs += wv;
-              cq += wv * v;
-            }
-            dsum[q] += (double)cs;
-            dsq[q] += (double)cq;
-            const float sg = g.epi_gamma[q * 32 + m] < 0.f ? -1.f : 1.f;
-            if (g.d) {  // optional: keep Y for a caller whose backward wants it (rows >= P are not stored)
-              const unsigned lane_off = (unsigned)(4 * h) * (unsigned)g.ldd + (unsigned)m;
-              const int nrow = (int)(g.P - trow) - 4 * h;    // rows (r&3) + 8(r>>2) below this are valid
-#pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                float *dp = g.d + (trow + (r & 3) + 8 * (r >> 2)) * (long long)g.ldd + q * 32;  // wave-uniform
-                if ((r & 3) + 8 * (r >> 2) < nrow) dp[lane_off] = acc[q][r];
-              }
-            }
-            float kv[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { kv[r] = sg * acc[q][r]; acc[q][r] = 0.f; }
-            for (int sd = s_lo; sd <= s_hi; ++sd) {
-              for (int d = 0; d < g.pool_d; ++d) {
-                float best = -INFINITY;
-                int brow = 0x7fffffff;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                  const bool member = (rk[r] >> 13) == sd && ((rk[r] >> d) & 1);
-                  if (member && kv[r] > best) { best = kv[r]; brow = (int)trow + 4 * h + (r & 3) + 8 * (r >> 2); }
-                }
-                // the other half of the tile's rows sits in lane ^ 32: v_permlane32_swap (no LDS round trip)
-                const auto sb = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
-                const auto sr = __builtin_amdgcn_permlane32_swap((unsigned)brow, (unsigned)brow, false, false);
-                const float ob = __uint_as_float(h ? sb[0] : sb[1]);
-                const int orow = (int)(h ? sr[0] : sr[1]);
-                if (ob > best || (ob == best && orow < brow)) { best = ob; brow = orow; }
-                if (h == 0)
-                  g.pairs[((size_t)(tile + sd) * g.pool_d + d) * C32 + q * 32 + m] = make_float2(best, __int_as_float(brow));
-              }
-            }
-          }
-        } else
         if (full) {
           const unsigned lane_off = (unsigned)(4 * h) * (unsigned)g.ldd + (unsigned)m;
           // the tile index is the same in every lane, but derived from threadIdx: tell the compiler (scalar registers,
@@ -541,28 +431,10 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
           const long long trow = (long long)__builtin_amdgcn_readfirstlane((int)tile) * 32;
           bool weighted = false;
           if constexpr (EPI == RS_STATS) weighted = g.epi_w16 != nullptr;
-          float lw[LR ? 16 : 1];
-          if constexpr (LR) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const float4 w4 = *reinterpret_cast<const float4 *>(g.lr_roww + trow + 4 * h + 8 * i);
-              lw[4 * i] = w4.x; lw[4 * i + 1] = w4.y; lw[4 * i + 2] = w4.z; lw[4 * i + 3] = w4.w;
-            }
-          }
 #pragma unroll
           for (int q = 0; q < NT; ++q) {
             if (!in(q)) continue;
             float cs = 0.f, cq = 0.f, ct[3] = {0.f, 0.f, 0.f};
-            float din[LR ? 16 : 1];
-            float lv = 0.f;
-            if constexpr (LR) {
-              lv = g.lr_v[q * 32 + m];
-#pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                const float *dp = g.d + (trow + (r & 3) + 8 * (r >> 2)) * (long long)g.ldd + q * 32;
-                din[r] = dp[lane_off];
-              }
-            }
             if constexpr (BNB && !COEF_REGS) {
               const int col = q * 32 + m;
               ea[q] = g.epi_ab[col];
@@ -574,20 +446,15 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
             if constexpr (BNB && !YPRE) {
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
-                yq[r] = ld_y((trow + (r & 3) + 8 * (r >> 2)) * (long long)g.ldd + q * 32 + lane_off);
+                yq[r] = g.epi_y[(trow + (r & 3) + 8 * (r >> 2)) * (long long)g.ldd + q * 32 + lane_off];
               }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               float v = acc[q][r];
-              if constexpr (LR) v = din[r] - lw[r] * (v + lv);
-              if constexpr (EPI == RS_STATS) v = rnd_d(v);
               if constexpr (EPI != RS_BNBWD_X) {
-                if constexpr (EPI == RS_STATS) st_d((trow + (r & 3) + 8 * (r >> 2)) * (long long)g.ldd + q * 32 + lane_off, v);
-                else {
-                  float *dp = g.d + (trow + (r & 3) + 8 * (r >> 2)) * (long long)g.ldd + q * 32;  // wave-uniform
-                  dp[lane_off] = v;
-                }
+                float *dp = g.d + (trow + (r & 3) + 8 * (r >> 2)) * (long long)g.ldd + q * 32;  // wave-uniform
+                dp[lane_off] = v;
               }
               if constexpr (EPI == RS_STATS) {
                 if (weighted) {
@@ -639,17 +506,15 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const long long row = row0 + (r & 3) + 8 * (r >> 2);
-              yq[r] = (colok && row < g.P) ? ld_y(row * g.ldd + col) : 0.f;
+              yq[r] = (colok && row < gP) ? g.epi_y[row * g.ldd + col] : 0.f;
             }
           }
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const long long row = row0 + (r & 3) + 8 * (r >> 2);
             float v = acc[q][r];
-            if (colok && row < g.P) {
-              if constexpr (LR) v = g.d[row * g.ldd + col] - g.lr_roww[row] * (v + g.lr_v[col]);
-              if constexpr (EPI == RS_STATS) { v = rnd_d(v); st_d(row * g.ldd + col, v); }
-              else if constexpr (EPI != RS_BNBWD_X) g.d[row * g.ldd + col] = v;  // _X: D itself is not needed
+            if (colok && row < gP) {
+              if constexpr (EPI != RS_BNBWD_X) g.d[row * g.ldd + col] = v;  // _X: D itself is not needed
               if constexpr (EPI == RS_STATS) {
                 if (g.epi_w16) {  // the row stands for `mult` identical rows of the original batch
                   const unsigned pk = (r & 2) ? wq[r >> 2].y : wq[r >> 2].x;
@@ -747,12 +612,12 @@ static int num_cus(int reserved) {
   return (reserved > 0 && n - reserved >= 16) ? n - reserved : n;
 }
 
-template <int NT, int EPI, bool BF, bool GEN3 = false, int ST = 0>
+template <int NT, int EPI, bool BF, bool GEN3 = false>
 static void rs_launch_p(const RsArgs &g, size_t lds_bytes, int blocks_per_cu, hipStream_t s, int reserved) {
   static std::atomic<unsigned long long> attr_set{0};
-  auto kern = gemm_rs_kernel<NT, EPI, BF, GEN3, ST>;
+  auto kern = gemm_rs_kernel<NT, EPI, BF, GEN3>;
   allow_dynamic_lds(kern, 160 * 1024, attr_set);
-  const long long ntiles = (g.P + 31) / 32;
+  const long long ntiles = (g.P + 31) / 32;   // (with rows_dev: of the row CAPACITY - the grid does not depend on the count)
   long long blocks = ntiles;  // at least one tile per workgroup; all 512 threads stage B either way
   const long long cap = (long long)num_cus(reserved) * blocks_per_cu;
   if (blocks > cap) blocks = cap;
@@ -768,19 +633,6 @@ static void rs_launch(const RsArgs &g, size_t lds_bytes, int blocks_per_cu, hipS
     size_t need = lds_bytes - b_fp32 / 2;
     const size_t red = (size_t)RS_WAVES * (EPI == RS_BNBWD_X ? 5 : 2) * NT * 32 * sizeof(double);
     if (EPI != RS_STORE && need < red) need = red;
-    // the storage modes that exist (rs_gemm_try has checked g.storage against this list): the folded second layer
-    // stores bf16; the pooled last layer reads bf16 rows and may store bf16; dgrad re-reads a bf16 y_prev
-    constexpr int X = GB_STORE_X_BF16, Y = GB_STORE_Y_BF16, YP = GB_STORE_YPREV_BF16;
-    if constexpr (EPI == RS_STATS && GEN3) {
-      if (g.storage == Y) return rs_launch_p<NT, EPI, true, GEN3, Y>(g, need, blocks_per_cu, s, reserved);
-    }
-    if constexpr (EPI == RS_STATS_POOL_V) {
-      if (g.storage == X) return rs_launch_p<NT, EPI, true, GEN3, X>(g, need, blocks_per_cu, s, reserved);
-      if (g.storage == (X | Y)) return rs_launch_p<NT, EPI, true, GEN3, X | Y>(g, need, blocks_per_cu, s, reserved);
-    }
-    if constexpr (EPI == RS_BNBWD) {
-      if (g.storage == YP) return rs_launch_p<NT, EPI, true, GEN3, YP>(g, need, blocks_per_cu, s, reserved);
-    }
     rs_launch_p<NT, EPI, true, GEN3>(g, need, blocks_per_cu, s, reserved);
   } else {
     rs_launch_p<NT, EPI, false, GEN3>(g, lds_bytes, blocks_per_cu, s, reserved);
@@ -794,9 +646,9 @@ static bool rs_shape_ok(long long P, int R, int C, int epi, bool has_aff, int *n
   const int tiles_c = (C + 31) / 32;
   const int nt = tiles_c <= 2 ? 2 : tiles_c <= 4 ? 4 : tiles_c == 5 ? 5 : tiles_c <= 8 ? 8 : 0;
   if (!nt) return false;
-  if ((epi == RS_BNBWD || epi == RS_BNBWD_LR) && nt == 8) return false;  // accumulators + y prefetch do not fit the register file
+  if (epi == RS_BNBWD && nt == 8) return false;  // accumulators + y prefetch do not fit the register file
   if (epi == RS_BNBWD_X && nt > 2) return false;  // 64-wide first layers only (registers)
-  if ((epi == RS_STATS_POOL || epi == RS_STATS_POOL_V) && C != nt * 32) return false;  // the pooled epilogues have no column bounds checks
+  if (epi == RS_STATS_POOL_V && C != nt * 32) return false;  // the pooled epilogues have no column bounds checks
   // MFMA work wasted on padding must stay small
   if ((long long)nch * RS_CH * nt * 32 * 4 > (long long)R * C * 5) return false;
   const size_t lds_bytes = ((size_t)nch * RS_CH * nt * 32 + (has_aff ? 2 * nch * RS_CH : 0)) * sizeof(float);
@@ -809,39 +661,25 @@ static bool rs_shape_ok(long long P, int R, int C, int epi, bool has_aff, int *n
 bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, double *stats, int slots,
                  const float *epi_y, const float *epi_ab, long long P, int R, int C, int w_kc, int epi,
                  hipStream_t s, bool bf16, int reserved_cus, const float *epi_x, const uint16_t *epi_w16,
-                 const RsPool *pool) {
+                 const RsPool *pool, const long long *rows_dev) {
   int nt = 0;
   size_t lds_bytes = 0;
   if (!rs_shape_ok(P, R, C, epi, aff != nullptr, &nt, &lds_bytes)) return false;
-  if ((epi == RS_STATS_POOL || epi == RS_STATS_POOL_V) && (!pool || C != nt * 32 || pool->D < 1 || pool->D > 4)) return false;
-  if (epi == RS_BNBWD_LR && (!pool || !pool->lr_v || !pool->lr_roww || !d)) return false;
+  if (epi == RS_STATS_POOL_V && (!pool || C != nt * 32 || pool->D < 1 || pool->D > 4)) return false;
   if (reinterpret_cast<uintptr_t>(a) % 16 != 0 || (w_kc && reinterpret_cast<uintptr_t>(w) % 16 != 0)) return false;
   const int nch = (R + RS_CH - 1) / RS_CH;
   const int stagger = 1, tail_split = 1;  // both measured to help
   RsArgs g = {a, w, d, aff, stats, epi_y, epi_ab, epi_x, epi_w16, pool ? pool->key : nullptr,
               pool ? pool->gamma : nullptr, pool ? pool->pairs : nullptr, pool ? pool->D : 0,
               pool ? pool->gen_x : nullptr, pool ? pool->gen_w : nullptr,
-              pool ? pool->lr_v : nullptr, pool ? pool->lr_roww : nullptr, P, R, C, R, C, w_kc, slots < 1 ? 1 : slots, nch, stagger, tail_split, 0};
-  if (pool && pool->storage) {
-    // bf16 tensors in HBM: only the bf16 kernels read / write them, only these epilogues store or re-read an activation,
-    // and the 16-byte loads of a bf16 row need a reduction length and pitch of whole 8-element groups
-    const int st = pool->storage;
-    if (!bf16) return false;
-    const bool gen = pool->gen_x && epi == RS_STATS;
-    const bool ok = (gen && st == GB_STORE_Y_BF16) ||
-                    (epi == RS_STATS_POOL_V && (st == GB_STORE_X_BF16 || st == (GB_STORE_X_BF16 | GB_STORE_Y_BF16)) &&
-                     R % 16 == 0) ||
-                    (epi == RS_BNBWD && st == GB_STORE_YPREV_BF16);   // = the instantiations of rs_launch
-    if (!ok) return false;
-    g.storage = st;
-  }
+              rows_dev, P, R, C, R, C, w_kc, slots < 1 ? 1 : slots, nch, stagger, tail_split};
   const bool gen3 = pool && pool->gen_x && epi == RS_STATS;
   if (gen3) {  // the A operand is generated from (P,3) rows and a per-k table: 16 more bytes of LDS per reduction index
     if (!aff || !pool->gen_w || (nt != 2 && nt != 4)) return false;
     lds_bytes += (size_t)nch * RS_CH * 4 * sizeof(float);
     if (lds_bytes > 156 * 1024) return false;
   }
-  const int bpc = (nt <= 2 && epi != RS_BNBWD && epi != RS_BNBWD_X && epi != RS_BNBWD_LR && lds_bytes <= 78 * 1024) ? 2 : 1;
+  const int bpc = (nt <= 2 && epi != RS_BNBWD && epi != RS_BNBWD_X && lds_bytes <= 78 * 1024) ? 2 : 1;
   if (gen3) {
     if (nt == 2) rs_launch<2, RS_STATS, true>(g, lds_bytes, bpc, s, bf16, reserved_cus);
     else rs_launch<4, RS_STATS, true>(g, lds_bytes, bpc, s, bf16, reserved_cus);
@@ -857,11 +695,9 @@ bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, dou
   }
 #define GB_RS(NT_)                                                         \
   do {                                                                     \
-    if (epi == RS_STATS_POOL) rs_launch<NT_, RS_STATS_POOL>(g, lds_bytes, bpc, s, bf16, reserved_cus); \
-    else if (epi == RS_STATS_POOL_V) rs_launch<NT_, RS_STATS_POOL_V>(g, lds_bytes, bpc, s, bf16, reserved_cus); \
+    if (epi == RS_STATS_POOL_V) rs_launch<NT_, RS_STATS_POOL_V>(g, lds_bytes, bpc, s, bf16, reserved_cus); \
     else if (epi == RS_STATS) rs_launch<NT_, RS_STATS>(g, lds_bytes, bpc, s, bf16, reserved_cus);   \
     else if (epi == RS_BNBWD) rs_launch<NT_, RS_BNBWD>(g, lds_bytes, bpc, s, bf16, reserved_cus); \
-    else if (epi == RS_BNBWD_LR) rs_launch<NT_, RS_BNBWD_LR>(g, lds_bytes, bpc, s, bf16, reserved_cus); \
     else rs_launch<NT_, RS_STORE>(g, lds_bytes, bpc, s, bf16, reserved_cus);                   \
   } while (0)
   if (nt == 2) GB_RS(2);
@@ -880,6 +716,6 @@ extern "C" int gb_gemm_uses_rs(long long P, int K, int N, int dgrad, int fused_s
   const int R = dgrad ? N : K, C = dgrad ? K : N;
   // fused_stats = 2 (dgrad only): the first-layer form gb_gemm_dgrad_first; 3 (forward only): gb_gemm_fwd_pool
   const int epi = fused_stats ? (dgrad ? (fused_stats == 2 ? gb::RS_BNBWD_X : gb::RS_BNBWD)
-                                       : (fused_stats == 3 ? gb::RS_STATS_POOL : gb::RS_STATS)) : gb::RS_STORE;
+                                       : (fused_stats == 3 ? gb::RS_STATS_POOL_V : gb::RS_STATS)) : gb::RS_STORE;
   return gb::rs_shape_ok(P, R, C, epi, has_aff != 0, nullptr, nullptr) ? 1 : 0;
 }

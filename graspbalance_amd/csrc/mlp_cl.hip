@@ -154,18 +154,6 @@ __device__ __forceinline__ void load_vec(const float *p, float *v) {
   }
 }
 
-// 4 consecutive elements of an activation tensor that lives in HBM as fp32 or (bf16 = 1: GbGemmOpts.storage of the GEMM that
-// wrote it) as bf16; idx = element index (a multiple of 4, rows of whole 4-element groups)
-__device__ __forceinline__ void load_act4(const float *p, long long idx, int bf16, float *v) {
-  if (bf16) {
-    const uint2 u = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(p) + idx);
-    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xFFFF0000u);
-    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xFFFF0000u);
-  } else {
-    load_vec<4>(p + idx, v);
-  }
-}
-
 template <int VEC>
 __global__ __launch_bounds__(CL_TPB) void col_stats_kernel(const float *__restrict__ y, long long P, int C, int rpb,
                                                             double *__restrict__ sum, double *__restrict__ sumsq) {
@@ -576,44 +564,33 @@ __global__ __launch_bounds__(CL_TPB) void affine_relu_maxpool_members_kernel(
 
 // Second half of the pooled last layer (gb_gemm_fwd_pool): seed r's rows [off, off + cnt) span the 32-row tiles
 // t0 = off / 32 .. t1 = (off + cnt - 1) / 32, and the GEMM left, for each of them, the extreme of sign(gamma)*y over
-// the seed's members of crop d in that tile at pairs[(t + r)][d][c] (value, row).  With a = gamma*rstd of the same
-// sign, max over the crop of relu(a*y + b) = relu(a*y* + b) at that extreme y*: out, arg (absolute row, the lowest
-// one among equal extremes) and ystar = y* (what the backward needs of the never-stored layer output).
-template <int D, bool ROWS>
-__global__ __launch_bounds__(CL_TPB) void pool_pairs_kernel(const float2 *__restrict__ pairs,
+// the seed's members of crop d in that tile at pairs[(t + r)][d][c].  With a = gamma*rstd of the same sign, max over
+// the crop of relu(a*y + b) = relu(a*y* + b) at that extreme y*: out and ystar = y* (what the backward needs: it finds
+// the arg-max row by value in the stored output).  A seed without rows wrote no slot: out = ystar = 0.
+template <int D>
+__global__ __launch_bounds__(CL_TPB) void pool_pairs_kernel(const float *__restrict__ pairs,
                                                             const int64_t *__restrict__ off,
                                                             const int32_t *__restrict__ cnt,
                                                             const float *__restrict__ ab,
                                                             const float *__restrict__ gamma, float *__restrict__ out,
-                                                            int32_t *__restrict__ arg, float *__restrict__ ystar,
-                                                            long long R, int C) {
-  const int gpb = CL_TPB / C;  // C threads per seed (one column each: consecutive lanes read consecutive pairs)
+                                                            float *__restrict__ ystar, long long R, int C) {
+  const int gpb = CL_TPB / C;  // C threads per seed (one column each: consecutive lanes read consecutive slots)
   const long long r = (long long)blockIdx.x * gpb + threadIdx.x / C;
   if (threadIdx.x / C >= gpb || r >= R) return;
   const int c = threadIdx.x % C;
   const float a = ab[c], b = ab[C + c], sg = gamma[c] < 0.f ? -1.f : 1.f;
-  const long long u0 = off[r], t0 = u0 / 32, t1 = (u0 + cnt[r] - 1) / 32;
+  const long long u0 = off[r], n = cnt[r];
+  const long long t0 = u0 / 32, t1 = n > 0 ? (u0 + n - 1) / 32 : t0 - 1;   // no rows: no tile wrote a slot of this seed
 #pragma unroll
   for (int d = 0; d < D; ++d) {
     float best = -INFINITY;
-    int brow = 0x7fffffff;
-    for (long long t = t0; t <= t1; ++t) {  // tiles in row order: a strict > keeps the lowest row among equal values
-      if constexpr (ROWS) {
-        const float2 p = pairs[((size_t)(t + r) * D + d) * C + c];
-        const int row = __float_as_int(p.y);
-        if (p.x > best || (p.x == best && row < brow)) { best = p.x; brow = row; }
-      } else {  // values only (gb_gemm_fwd_pool with_rows = 0): floats
-        const float v = reinterpret_cast<const float *>(pairs)[((size_t)(t + r) * D + d) * C + c];
-        best = fmaxf(best, v);
-      }
-    }
-    const bool any = ROWS ? brow != 0x7fffffff : best > -INFINITY;
+    for (long long t = t0; t <= t1; ++t) best = fmaxf(best, pairs[((size_t)(t + r) * D + d) * C + c]);
+    const bool any = best > -INFINITY;
     const float y = any ? sg * best : 0.f;
     float o = a * y + b;
     o = (any && o > 0.f) ? o : 0.f;
     const size_t at = (size_t)(r * D + d) * C + c;
     out[at] = o;
-    if constexpr (ROWS) arg[at] = any ? brow : (int)u0;
     ystar[at] = y;
   }
 }
@@ -629,8 +606,7 @@ __global__ __launch_bounds__(CL_TPB) void bn_bwd_apply_members_kernel(
     const float *__restrict__ dout, const float *__restrict__ out, const int32_t *__restrict__ arg,
     const float *__restrict__ y, const float *__restrict__ ab, const double *__restrict__ dstats,
     const float *__restrict__ row_w, const int64_t *__restrict__ off, const int32_t *__restrict__ cnt, long long R,
-    int C, double invP, int training, float *__restrict__ dy, const int32_t *__restrict__ row_mem = nullptr,
-    int y_bf16 = 0) {
+    int C, double invP, int training, float *__restrict__ dy, const int32_t *__restrict__ row_mem = nullptr) {
   const int tpg = C / 4, gpb = CL_TPB / tpg;
   const long long r = (long long)blockIdx.x * gpb + threadIdx.x / tpg;
   if (threadIdx.x / tpg >= gpb || r >= R) return;
@@ -665,7 +641,7 @@ __global__ __launch_bounds__(CL_TPB) void bn_bwd_apply_members_kernel(
       // unconditional loads from a clamped row index: under `if (u + q < u1)` the four loads were waited for one
       // by one (295 -> 180 us per launch)
       const long long uu = u + q < u1 ? u + q : u1 - 1;
-      load_act4(y, uu * C + c, y_bf16, v[q]);
+      load_vec<4>(y + uu * C + c, v[q]);
       w[q] = row_w[uu];
       mb[q] = BYVAL ? row_mem[uu] : 0;
     }
@@ -703,7 +679,12 @@ __global__ __launch_bounds__(CL_TPB) void bn_bwd_apply_w_kernel(const float *__r
                                                                  const double *__restrict__ dstats,
                                                                  const float *__restrict__ row_w, long long rows, int C,
                                                                  double invP, int training, float *__restrict__ dy,
-                                                                 int rows_per_block, int y_bf16) {
+                                                                 int rows_per_block,
+                                                                 const long long *__restrict__ rows_dev) {
+  if (rows_dev) {   // the caller's device-side row count (<= the capacity `rows` the grid was sized for)
+    const long long pd = *rows_dev;
+    rows = pd < rows ? (pd > 0 ? pd : 0) : rows;
+  }
   const int tpr = C / 4, rpp = CL_TPB / tpr;
   const int cg = threadIdx.x % tpr, rl = threadIdx.x / tpr;
   if (rl >= rpp) return;
@@ -727,7 +708,7 @@ __global__ __launch_bounds__(CL_TPB) void bn_bwd_apply_w_kernel(const float *__r
     for (int u = 0; u < 4; ++u) {
       const long long rr = r + (long long)u * rpp;
       if (rr < r1) {
-        load_act4(y, rr * C + c, y_bf16, yy[u]);
+        load_vec<4>(y + rr * C + c, yy[u]);
         load_vec<4>(dout + rr * C + c, g[u]);
         w[u] = row_w[rr];
       }
@@ -1048,7 +1029,7 @@ extern "C" int gb_bn_bwd_apply_g(const float *dout, const float *y, const float 
 }
 
 static bool members_ok(long long R, int D, int C, const void *a, const void *b, const void *c, const void *d) {
-  return R >= 0 && (D == 1 || D == 2 || D == 4) && C >= 16 && C % 4 == 0 && C / 4 <= CL_TPB &&
+  return R >= 0 && D >= 1 && D <= 4 && C >= 16 && C % 4 == 0 && C / 4 <= CL_TPB &&
          (reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
           reinterpret_cast<uintptr_t>(d)) % 16 == 0;
 }
@@ -1062,28 +1043,21 @@ extern "C" int gb_affine_relu_maxpool_members(const float *y, const float *ab, c
   const dim3 grid((unsigned)((R + gpb - 1) / gpb));
 #define GB_MP(D_) hipLaunchKernelGGL((affine_relu_maxpool_members_kernel<D_>), grid, dim3(CL_TPB), 0, as_stream(stream), y, \
                                      ab, row_mem, off, cnt, out, arg, R, C)
-  if (D == 1) GB_MP(1); else if (D == 2) GB_MP(2); else GB_MP(4);
+  if (D == 1) GB_MP(1); else if (D == 2) GB_MP(2); else if (D == 3) GB_MP(3); else GB_MP(4);
 #undef GB_MP
   return check_launch("gb_affine_relu_maxpool_members");
 }
 
 extern "C" int gb_pool_pairs(const float *pairs, const int64_t *off, const int32_t *cnt, const float *ab,
-                             const float *gamma, float *out, int32_t *arg, float *ystar, long long R, int D, int C,
-                             void *stream) {
+                             const float *gamma, float *out, float *ystar, long long R, int D, int C, void *stream) {
   if (R < 0 || D < 1 || D > 4 || C < 1 || C > CL_TPB || CL_TPB % C || !pairs || !off || !cnt || !ab || !gamma || !out ||
-      !ystar || reinterpret_cast<uintptr_t>(pairs) % 8)
-    return GB_EINVAL;  // arg == NULL: `pairs` holds values only (floats)
+      !ystar)
+    return GB_EINVAL;
   if (R == 0) return GB_OK;
   const int gpb = CL_TPB / C;
   const dim3 grid((unsigned)((R + gpb - 1) / gpb));
-  const float2 *pp = reinterpret_cast<const float2 *>(pairs);
-#define GB_PP(D_)                                                                                                    \
-  do {                                                                                                               \
-    if (arg) hipLaunchKernelGGL((pool_pairs_kernel<D_, true>), grid, dim3(CL_TPB), 0, as_stream(stream), pp, off, cnt, ab, \
-                                gamma, out, arg, ystar, R, C);                                                       \
-    else hipLaunchKernelGGL((pool_pairs_kernel<D_, false>), grid, dim3(CL_TPB), 0, as_stream(stream), pp, off, cnt, ab,    \
-                            gamma, out, arg, ystar, R, C);                                                           \
-  } while (0)
+#define GB_PP(D_) hipLaunchKernelGGL((pool_pairs_kernel<D_>), grid, dim3(CL_TPB), 0, as_stream(stream), pairs, off, cnt, ab, \
+                                     gamma, out, ystar, R, C)
   if (D == 1) GB_PP(1); else if (D == 2) GB_PP(2); else if (D == 3) GB_PP(3); else GB_PP(4);
 #undef GB_PP
   return check_launch("gb_pool_pairs");
@@ -1092,7 +1066,7 @@ extern "C" int gb_pool_pairs(const float *pairs, const int64_t *off, const int32
 static int apply_members_impl(const float *dout, const float *out, const int32_t *arg, const float *ystar, const float *y,
                               const float *ab, const double *dstats, const float *row_w, const int32_t *row_mem,
                               const int64_t *off, const int32_t *cnt, long long R, int D, int C, long long P_total,
-                              int training, float *dy, void *stream, int y_bf16 = 0) {
+                              int training, float *dy, void *stream) {
   const void *sel = arg ? static_cast<const void *>(arg) : static_cast<const void *>(ystar);
   if (!dout || !out || !sel || !y || !ab || !row_w || !off || !cnt || !dy || (training && !dstats) || P_total < 1 ||
       (!arg && !row_mem) || !members_ok(R, D, C, dout, out, sel, y) ||
@@ -1105,11 +1079,11 @@ static int apply_members_impl(const float *dout, const float *out, const int32_t
 #define GB_MB(D_)                                                                                                          \
   do {                                                                                                                     \
     if (arg) hipLaunchKernelGGL((bn_bwd_apply_members_kernel<D_, false>), grid, dim3(CL_TPB), 0, as_stream(stream), dout, out, \
-                                sel32, y, ab, dstats, row_w, off, cnt, R, C, 1.0 / (double)P_total, training, dy, row_mem, y_bf16);     \
+                                sel32, y, ab, dstats, row_w, off, cnt, R, C, 1.0 / (double)P_total, training, dy, row_mem);     \
     else hipLaunchKernelGGL((bn_bwd_apply_members_kernel<D_, true>), grid, dim3(CL_TPB), 0, as_stream(stream), dout, out,      \
-                            sel32, y, ab, dstats, row_w, off, cnt, R, C, 1.0 / (double)P_total, training, dy, row_mem, y_bf16);         \
+                            sel32, y, ab, dstats, row_w, off, cnt, R, C, 1.0 / (double)P_total, training, dy, row_mem);         \
   } while (0)
-  if (D == 1) GB_MB(1); else if (D == 2) GB_MB(2); else GB_MB(4);
+  if (D == 1) GB_MB(1); else if (D == 2) GB_MB(2); else if (D == 3) GB_MB(3); else GB_MB(4);
 #undef GB_MB
   return check_launch("gb_bn_bwd_apply_members");
 }
@@ -1134,47 +1108,23 @@ extern "C" int gb_bn_bwd_apply_members_v(const float *dout, const float *out, co
                             dy, stream);
 }
 
-// gb_bn_bwd_apply_members_v whose y lives in HBM as bf16 (y_bf16 = 1: written by a gb_gemm_fwd_pool call with
-// GB_STORE_Y_BF16, whose pooled extrema ystar are those of the rounded values - the by-value search stays exact)
-extern "C" int gb_bn_bwd_apply_members_vs(const float *dout, const float *out, const float *ystar, const float *y,
-                                          int y_bf16, const float *ab, const double *dstats, const float *row_w,
-                                          const int32_t *row_mem, const int64_t *off, const int32_t *cnt, long long R, int D,
-                                          int C, long long P_total, int training, float *dy, void *stream) {
-  if (!ystar || (y_bf16 != 0 && y_bf16 != 1)) return GB_EINVAL;
-  return apply_members_impl(dout, out, nullptr, ystar, y, ab, dstats, row_w, row_mem, off, cnt, R, D, C, P_total, training,
-                            dy, stream, y_bf16);
-}
-
-static int apply_w_impl(const float *dout, const float *y, int y_bf16, const float *ab, const double *dstats,
-                        const float *row_w, long long rows, long long P_total, int C, int training, float *dy,
-                        void *stream) {
+// rows_dev (optional, device): the actual row count when `rows` is only the capacity the caller sized its buffers for
+extern "C" int gb_bn_bwd_apply_w(const float *dout, const float *y, const float *ab, const double *dstats,
+                                 const float *row_w, long long rows, long long P_total, int C, int training, float *dy,
+                                 const long long *rows_dev, void *stream) {
   if (rows < 0 || P_total < 1 || C < 4 || C % 4 != 0 || C / 4 > CL_TPB || !dout || !y || !ab || !row_w || !dy ||
       (training && !dstats))
     return GB_EINVAL;
   if ((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(ab) |
-       reinterpret_cast<uintptr_t>(dy)) % 16)
+       reinterpret_cast<uintptr_t>(dy)) % 16 || reinterpret_cast<uintptr_t>(rows_dev) % 8)
     return GB_EINVAL;
   if (rows == 0) return GB_OK;
   const int rpp = CL_TPB / (C / 4);
   long long rpb = (rows + 4095) / 4096;
   rpb = (rpb + 4 * rpp - 1) / (4 * rpp) * (4 * rpp);
   hipLaunchKernelGGL(bn_bwd_apply_w_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(CL_TPB), 0, as_stream(stream),
-                     dout, y, ab, dstats, row_w, rows, C, 1.0 / (double)P_total, training, dy, (int)rpb, y_bf16);
+                     dout, y, ab, dstats, row_w, rows, C, 1.0 / (double)P_total, training, dy, (int)rpb, rows_dev);
   return check_launch("gb_bn_bwd_apply_w");
-}
-
-extern "C" int gb_bn_bwd_apply_w(const float *dout, const float *y, const float *ab, const double *dstats,
-                                 const float *row_w, long long rows, long long P_total, int C, int training, float *dy,
-                                 void *stream) {
-  return apply_w_impl(dout, y, 0, ab, dstats, row_w, rows, P_total, C, training, dy, stream);
-}
-
-// ... with y in HBM as bf16 (y_bf16 = 1: the output of a GEMM call with GB_STORE_Y_BF16)
-extern "C" int gb_bn_bwd_apply_ws(const float *dout, const float *y, int y_bf16, const float *ab, const double *dstats,
-                                  const float *row_w, long long rows, long long P_total, int C, int training, float *dy,
-                                  void *stream) {
-  if (y_bf16 != 0 && y_bf16 != 1) return GB_EINVAL;
-  return apply_w_impl(dout, y, y_bf16, ab, dstats, row_w, rows, P_total, C, training, dy, stream);
 }
 
 extern "C" int gb_bn_bwd_stats_pool(const float *dout, const float *out, const int32_t *arg, const float *y,

@@ -33,6 +33,10 @@ class FlatAdam(Optimizer):
         self._exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
         self._exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
         self._step_t = torch.zeros((), dtype=torch.float32, device=dev)
+        # the learning rate as a device scalar: a step captured in a HIP graph (train.Trainer) must not bake the schedule's
+        # current value into the update launch - set_lr_tensor(lr) before every replay instead
+        self._lr_t = torch.zeros((), dtype=torch.float32, device=dev)
+        self.tensor_lr = False
         self._steps = 0
         self._grad_views = []
         off = 0
@@ -48,13 +52,10 @@ class FlatAdam(Optimizer):
         self._fused = dev.type == "cuda" and hasattr(torch, "_fused_adam_")
 
     @torch.no_grad()
-    def step(self, closure=None):
-        loss = None
-        if closure is not None:
-            with torch.enable_grad():
-                loss = closure()
-        group = self.param_groups[0]
-        lr, (beta1, beta2), eps, wd = group['lr'], group['betas'], group['eps'], group['weight_decay']
+    def pack(self):
+        """Gather the parameters' gradients into the flat gradient buffer (one multi-tensor copy; gradients that already
+        are views of it - after the flat-bucket all-reduce - cost nothing).  step() does this itself unless told the
+        buffer is packed already (a step split around a collective: pack, all-reduce the buffer, step(packed=True))."""
         have_v, have_g = [], []
         for v, p in zip(self._grad_views, self._params):
             if p.grad is None:
@@ -64,6 +65,27 @@ class FlatAdam(Optimizer):
                 have_g.append(p.grad)
         if have_v:
             torch._foreach_copy_(have_v, have_g)
+
+    def set_lr_tensor(self, lr=None):
+        """Write the group's (or the given) learning rate into the device scalar the tensor_lr update reads."""
+        self._lr_t.fill_(float(self.param_groups[0]['lr'] if lr is None else lr))
+
+    def count_step(self):
+        """Host-side bookkeeping of one update that ran without this object's step() (a replayed HIP graph of it)."""
+        self._steps += 1
+        from . import fused_mlp
+        fused_mlp._TRAIN_TICK[0] += 1
+
+    @torch.no_grad()
+    def step(self, closure=None, packed=False):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        group = self.param_groups[0]
+        lr, (beta1, beta2), eps, wd = group['lr'], group['betas'], group['eps'], group['weight_decay']
+        if not packed:
+            self.pack()
         self._steps += 1
         self._step_t += 1
         # the parameters are views of ONE flat buffer and the update below writes that buffer: the views' own version
@@ -71,9 +93,10 @@ class FlatAdam(Optimizer):
         from . import fused_mlp
         fused_mlp._TRAIN_TICK[0] += 1
         if self._fused:
+            # tensor_lr: the kernel reads the rate from self._lr_t (fp32: the schedule's value rounded once)
             torch._fused_adam_([self._flat_p], [self._flat_g], [self._exp_avg], [self._exp_avg_sq], [], [self._step_t],
-                               lr=float(lr), beta1=beta1, beta2=beta2, weight_decay=wd, eps=eps, amsgrad=False,
-                               maximize=False, grad_scale=None, found_inf=None)
+                               lr=self._lr_t if self.tensor_lr else float(lr), beta1=beta1, beta2=beta2, weight_decay=wd,
+                               eps=eps, amsgrad=False, maximize=False, grad_scale=None, found_inf=None)
         else:  # torch.optim.Adam's single-tensor arithmetic
             g = self._flat_g
             if wd != 0:

@@ -123,18 +123,21 @@ def _prec():
     return getattr(_tls, "prec", _lib.PREC_F32)
 
 
-def _opts(dev, st, prec, storage=0):
+def _opts(dev, st, prec, rows_dev=None):
     """ctypes pointer to the GbGemmOpts of a launch on stream `st` (c_void_p) of `dev` at precision code `prec`;
-    storage: GB_STORE_*_BF16 bits (which activation tensors of the call live in HBM as bf16; bf16 precision only)."""
-    key = (dev.index, st.value, prec, _RESERVED_CUS, storage)
+    rows_dev: one-element int64 device tensor holding the call's actual row count (GbGemmOpts.rows_dev) or None."""
+    key = (dev.index, st.value, prec, _RESERVED_CUS)
     o = _OPTS.get(key)
     if o is None:
         wkey = (dev.index, st.value)
         ws = _WORKSPACES.get(wkey)
         if ws is None:
             ws = _WORKSPACES[wkey] = torch.empty(_lib.GEMM_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
-        o = _OPTS[key] = (ctypes.pointer(_lib.GemmOpts(prec, _RESERVED_CUS, ws.data_ptr(), ws.numel(), storage)), ws)
-    return o[0]
+        o = _OPTS[key] = (ctypes.pointer(_lib.GemmOpts(prec, _RESERVED_CUS, ws.data_ptr(), ws.numel(), None)), ws)
+    if rows_dev is None:
+        return o[0]
+    # (not cached: the count's address changes from step to step; the struct only has to outlive the synchronous call)
+    return ctypes.pointer(_lib.GemmOpts(prec, _RESERVED_CUS, o[1].data_ptr(), o[1].numel(), rows_dev.data_ptr()))
 
 
 def set_own_gemm(flag):
@@ -466,7 +469,10 @@ class MLPStack(Function):
         dev = X0.device
         st = _s(X0)  # one stream lookup per call, not one per launch
         prec = _prec()
-        opts = _opts(dev, st, prec)
+        # rows given by a device-side count (RowSet.rows_dev: X0 and every activation are sized for the row CAPACITY, the
+        # kernels read the count): every launch that depends on the row count takes it
+        rdev = rows.rows_dev if rows is not None else None
+        opts = _opts(dev, st, prec, rdev)
         L = len(layers)
         P_stat = rows.P_total if rows is not None else X0.shape[0]  # rows of the batch the BatchNorm sums stand for
         X0 = X0.contiguous()
@@ -489,11 +495,8 @@ class MLPStack(Function):
                 and (L > 2 or not (rows is not None and rows.key is not None and _CROP_POOL))
                 and bool(_lib.lib().gb_gemm_uses_rs(P, widths[0], widths[1], 0, 1, 1))
                 and bool(_lib.lib().gb_gemm_uses_rs(P, widths[0], widths[1], 1, 2, 0)))
-        # bf16 storage mode: the stored outputs Y1 (gb_gemm_fwd_gen3) and Y2 (gb_gemm_fwd_pool) of a crop stack are bf16
-        s16 = bool(prec == _lib.PREC_BF16 and _BF16_STORE and fold and L == 3 and rows is not None and rows.key is not None
-                   and _CROP_POOL and not _CROP_LOWRANK and widths[1] % 16 == 0
-                   and _lib.lib().gb_gemm_uses_rs(P, widths[1], widths[2], 0, 3, 1))
-        ydt = torch.bfloat16 if s16 else torch.float32
+        if rdev is not None and not (fold and L == 3 and rows.key is not None and _CROP_POOL):
+            raise RuntimeError("fused_mlp: a device-side row count needs the folded 3-layer crop stack (crop_static_ok)")
         mom0 = None
         for l, cfg in enumerate(layers):
             W = params[3 * l].contiguous()
@@ -507,7 +510,7 @@ class MLPStack(Function):
                 if cfg.training or any(ctx.needs_input_grad):   # (the backward's closed-form weight gradient reads them too)
                     mom0 = _zeros64(12, dev)
                     _call("gb_moments3", dev, _lib.ptr(X0), _lib.ptr(rows.w if rows is not None else None), P,
-                          _lib.ptr(mom0), st)
+                          _lib.ptr(mom0), _lib.ptr(rdev), st)
                 if cfg.training:
                     _TRAIN_TICK[0] += 1
                     _call("gb_bn_finalize_lin3", dev, _lib.ptr(mom0), _lib.ptr(W), P_stat, N, _lib.ptr(gamma), _lib.ptr(beta),
@@ -518,13 +521,12 @@ class MLPStack(Function):
                 src, aff = None, ab
                 continue
             if fold and l == 1:
-                Y = _empty_rows(P, N, dev, rows is not None, ydt)
+                Y = _empty_rows(P, N, dev, rows is not None and rdev is None)
                 fin = _bn_fin(cfg, gamma, beta, ab, P_stat) if cfg.training else None
                 st_buf, st_slots = (stats, slots) if cfg.training else (_zeros64(2 * N, dev), 1)
                 _call("gb_gemm_fwd_gen3", dev, _lib.ptr(X0), _lib.ptr(Ws[0]), _lib.ptr(aff), _lib.ptr(W),
                       _lib.ptr(rows.w16 if rows is not None else None), _lib.ptr(Y), _lib.ptr(st_buf), st_slots, P, K, N,
-                      fin, _opts(dev, st, prec, _lib.STORE_Y_BF16) if s16 else opts, st,
-                      meta=_gemm_meta("fwd", P, K, N, True, True))
+                      fin, opts, st, meta=_gemm_meta("fwd", P, K, N, True, True))
                 if fin is None:
                     ab = _eval_ab(gamma, beta, cfg.running_mean, cfg.running_var, cfg.eps, N, dev, st)
                 Ws.append(W); Ys.append(Y); abs_.append(ab)
@@ -533,19 +535,13 @@ class MLPStack(Function):
             if (l == L - 1 and rows is not None and rows.key is not None and _CROP_POOL
                     and _lib.lib().gb_gemm_uses_rs(P, K, N, 0, 3, int(aff is not None))):
                 # the crop stack's last layer: BatchNorm sums and per-(tile, seed, crop) extrema leave the GEMM,
-                # gb_pool_pairs finishes the max over each crop's members (no pass over the layer's output); with the low
-                # rank + sparse backward the output is not even stored
-                lowrank = (_CROP_LOWRANK and l >= 1 and _lib.lib().gb_crop_bwd_ok(K, N, rows.D)
-                           and _lib.lib().gb_gemm_uses_rs(P, K, K, 1, 1, 1))
+                # gb_pool_pairs finishes the max over each crop's members (no pass over the layer's output)
                 fwd_only = not any(ctx.needs_input_grad)   # inference: the layer's output is not stored at all
-                Y = None if (lowrank or fwd_only) else _empty_rows(P, N, dev, True, ydt)
+                Y = None if fwd_only else _empty_rows(P, N, dev, rdev is None)
                 if not cfg.training:
                     ab = _eval_ab(gamma, beta, cfg.running_mean, cfg.running_var, cfg.eps, N, dev, st)
-                popts = opts
-                if s16:   # its rows operand (Y1) is bf16, and so is its stored output
-                    popts = _opts(dev, st, prec, _lib.STORE_X_BF16 | (_lib.STORE_Y_BF16 if Y is not None else 0))
-                pooled = _pooled_last_layer(dev, st, popts, src, W, aff, gamma, beta, cfg, ab, stats, slots, rows, P, K, N,
-                                            P_stat, Y, with_rows=(Y is None and not fwd_only))
+                pooled = _pooled_last_layer(dev, st, opts, src, W, aff, gamma, beta, cfg, ab, stats, slots, rows, P, K, N,
+                                            P_stat, Y)
                 Ws.append(W); Ys.append(Y); abs_.append(ab)
                 break
             Y = _empty_rows(P, N, dev, rows is not None)
@@ -567,25 +563,21 @@ class MLPStack(Function):
         ctx.cfg = (L, P, int(pool_ns), bool(relu_last), [c.training for c in layers], residual is not None)
         ctx.rows = rows
         ctx.prec = prec
-        ctx.pooled = rows is not None and Ys[-1] is None
         ctx.by_value = False
         ctx.fold = fold
-        ctx.s16 = s16
         ctx.mom0 = mom0
         if not all(c.training for c in layers):
             # eval-mode layers use cached tables (_eval_ab), not slices of the arena: a backward through this node (rare:
             # gradients in eval mode) reads the arena, so gather them once - and skip it when nothing needs a gradient
             ab_arena = torch.cat(abs_) if any(ctx.needs_input_grad) else ab_arena
         if pooled is not None:
-            out, arg, ystar = pooled
-            if Ys[-1] is None:
-                ctx.save_for_backward(X0, out, arg, ab_arena, *Ws, *Ys[:-1], ystar)
-            else:   # values only: the backward finds the arg-max rows by value in the stored output
+            out, ystar = pooled
+            if Ys[-1] is not None:   # the backward finds the arg-max rows by value in the stored output
                 ctx.save_for_backward(X0, out, ystar, ab_arena, *Ws, *Ys)
                 ctx.by_value = True
-            if routing_observer is not None:
-                routing_observer("stack", Ys=_observed_ys(Ys, X0, Ws), abs=abs_, out=out, pool_ns=0, relu_last=True, rows=rows,
-                                 arg=arg if arg is not None else _arg_rows_by_value(Ys[-1], ystar, rows))
+                if routing_observer is not None:
+                    routing_observer("stack", Ys=_observed_ys(Ys, X0, Ws), abs=abs_, out=out, pool_ns=0, relu_last=True,
+                                     rows=rows, arg=_arg_rows_by_value(Ys[-1], ystar, rows))
             return out
         if rows is not None:
             RD = rows.R * rows.D
@@ -626,8 +618,6 @@ class MLPStack(Function):
         saved = ctx.saved_tensors
         X0, s1, s2, ab_arena = saved[0], saved[1], saved[2], saved[3]
         Ws, Ys = saved[4:4 + L], saved[4 + L:4 + 2 * L]
-        if ctx.pooled:  # the last layer's output was never stored: (Y_0 .. Y_{L-2}, ystar) instead of (Y_0 .. Y_{L-1})
-            Ys, ystar = list(saved[4 + L:4 + 2 * L - 1]) + [None], saved[4 + 2 * L - 1]
         widths = [W.shape[0] for W in Ws]
         abs_, off = [], 0
         for n in widths:
@@ -635,7 +625,9 @@ class MLPStack(Function):
             off += 4 * n
         dev = dout.device
         st = _s(dout)  # one stream lookup per call, not one per launch
-        opts = _opts(dev, st, ctx.prec)  # the forward's precision (this is autograd's thread)
+        rdev = rows.rows_dev if rows is not None else None   # device-side row count: P is the capacity (see forward)
+        opts = _opts(dev, st, ctx.prec, rdev)  # the forward's precision (this is autograd's thread)
+        quant = rows is not None and rdev is None
         dout = dout.contiguous()
         slots = STAT_SLOTS if P >= 16384 else 1
         # zero-filled arenas: fp64 BatchNorm-backward sums ([2N] last layer, then per layer l<L-1 the slot rows
@@ -673,57 +665,15 @@ class MLPStack(Function):
         first = L - 1  # the layer the generic loop below starts at (its dY formed here)
         dbeta, dgamma = bn_grads(L - 1)
         pb, pg = _lib.ptr(dbeta), _lib.ptr(dgamma)
-        if ctx.pooled:
-            # low rank + sparse (csrc/crop_bwd.hip): dZ of layer L-2, dW / dgamma / dbeta of layer L-1; neither the
-            # layer's output nor its dense gradient exists
-            l, K = L - 1, kin[L - 1]
-            out, arg, W, y2, ab2 = s1, s2, Ws[l], Ys[l - 1], abs_[l - 1]
-            nb = _lib.lib().gb_crop_bwd_blocks(rows.R)
-            tpart = torch.empty(nb * N * K, dtype=torch.float32, device=dev)       # per-workgroup partials: no zeroing
-            rpart = torch.empty(nb * (2 * N + K) + 2 * N + K, dtype=torch.float64, device=dev)
-            red = rpart[nb * (2 * N + K):]                                          # [dbeta, dgamma, sx] totals
-            sx = red[2 * N:]
-            gmat = _zeros32(K * K, dev)
-            dZ = _empty_rows(P, K, dev, True)
-            _call("gb_crop_bwd_sparse", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(ystar),
-                  _lib.ptr(abs_[l]), _lib.ptr(y2), _lib.ptr(ab2), _lib.ptr(W), _lib.ptr(rows.w), _lib.ptr(rows.off),
-                  _lib.ptr(rows.cnt), rows.R, rows.D, K, N, _lib.ptr(dZ), _lib.ptr(tpart), _lib.ptr(rpart), nb,
-                  _lib.ptr(red), st)
-            small = torch.empty(2 * N + K + K * K, dtype=torch.float32, device=dev)
-            ef, vvec, mmat = small[:2 * N], small[2 * N:2 * N + K], small[2 * N + K:]
-            _call("gb_crop_bwd_coef", dev, _lib.ptr(red), _lib.ptr(abs_[l]), _lib.ptr(W), K, N, P_stat, int(training[l]),
-                  _lib.ptr(ef), _lib.ptr(vvec), _lib.ptr(mmat), pb, pg, st)
-            grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
-            region = d_arena[d_off[l - 1]:d_off[l]]
-            dst2 = region[slots * 2 * K:] if slots > 1 else region
-            dbeta2, dgamma2 = bn_grads(l - 1)
-            _call("gb_crop_bwd_dense", dev, _lib.ptr(y2), _lib.ptr(ab2), _lib.ptr(mmat), _lib.ptr(vvec), _lib.ptr(rows.w),
-                  _lib.ptr(dZ), _lib.ptr(region), slots, P, K, _lib.ptr(dst2), _lib.ptr(dbeta2), _lib.ptr(dgamma2), opts, st,
-                  meta={"flop": 2.0 * P * K * K, "pkn": (P, K, K), "kernel": "gemm_rs_kernel"})
-            grads[3 * l - 2], grads[3 * l - 1] = dgamma2, dbeta2
-            if need_w[l]:
-                _call("gb_gemm_gram", dev, _lib.ptr(y2), _lib.ptr(ab2), _lib.ptr(rows.w), _lib.ptr(gmat), P, K, opts, st,
-                      meta={"flop": 2.0 * P * K * K, "pkn": (P, K, K), "kernel": "gemm_cl_kernel"})
-                dW = w_arena[w_off[l]:w_off[l + 1]]
-                _call("gb_crop_bwd_dw", dev, _lib.ptr(tpart), nb, _lib.ptr(ef), _lib.ptr(sx), _lib.ptr(W), _lib.ptr(gmat), K,
-                      N, _lib.ptr(dW), st)
-                grads[3 * l] = dW.view(N, K)
-            dY = _empty_rows(P, K, dev, True)
-            _call("gb_bn_bwd_apply_w", dev, _lib.ptr(dZ), _lib.ptr(y2), _lib.ptr(ab2), _lib.ptr(dst2), _lib.ptr(rows.w), P,
-                  P_stat, K, int(training[l - 1]), _lib.ptr(dY), st)
-            first = L - 2
-        else:
-            dY = _empty_rows(P, N, dev, rows is not None)
-        if ctx.pooled:
-            pass
-        elif rows is not None and ctx.by_value:
+        dY = _empty_rows(P, N, dev, quant)
+        if rows is not None and ctx.by_value:
             out, ystar = s1, s2
             RD = rows.R * rows.D
             # the crops' extreme y* are saved: the BatchNorm-backward sums need no gather from the layer's output
             _call("gb_bn_bwd_stats", dev, _lib.ptr(dout), _lib.ptr(ystar), _lib.ptr(abs_[-1]), None, RD, N, 1,
                   _lib.ptr(dstats), pb, pg, st)
-            _call("gb_bn_bwd_apply_members_vs", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(ystar), _lib.ptr(Ys[-1]),
-                  int(ctx.s16), _lib.ptr(abs_[-1]), _lib.ptr(dstats), _lib.ptr(rows.w), _lib.ptr(rows.mem),
+            _call("gb_bn_bwd_apply_members_v", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(ystar), _lib.ptr(Ys[-1]),
+                  _lib.ptr(abs_[-1]), _lib.ptr(dstats), _lib.ptr(rows.w), _lib.ptr(rows.mem),
                   _lib.ptr(rows.off), _lib.ptr(rows.cnt), rows.R, rows.D, N, P_stat, int(training[-1]), _lib.ptr(dY), st)
         elif rows is not None:
             out, arg = s1, s2
@@ -759,8 +709,7 @@ class MLPStack(Function):
                     _call("gb_gemm_wgrad_gen3", dev, _lib.ptr(dY), _lib.ptr(X0), _lib.ptr(Ws[0]), _lib.ptr(aff), _lib.ptr(dW), P,
                           K, N, opts, st, meta=_gemm_meta("wgrad", P, K, N, aff=True))
                 else:
-                    _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(src), _lib.ptr(aff), _lib.ptr(dW), P, K, N,
-                          _opts(dev, st, ctx.prec, _lib.STORE_X_BF16) if (ctx.s16 and l >= 1) else opts, st,
+                    _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(src), _lib.ptr(aff), _lib.ptr(dW), P, K, N, opts, st,
                           meta=_gemm_meta("wgrad", P, K, N, aff=aff is not None))
                 grads[3 * l] = dW.view(N, K)
             if l == 0:
@@ -785,7 +734,7 @@ class MLPStack(Function):
                           _lib.ptr(X0), _lib.ptr(sums), slots, P, K, N, opts, st,
                           meta={"flop": 2.0 * P * K * N, "pkn": (P, K, N), "kernel": "gemm_rs_kernel"})
                     _call("gb_moments3", dev, _lib.ptr(X0), _lib.ptr(rows.w if rows is not None else None), P,
-                          _lib.ptr(mom), st)
+                          _lib.ptr(mom), _lib.ptr(rdev), st)
                 dbeta0, dgamma0 = bn_grads(0)
                 grads[1], grads[2] = dgamma0, dbeta0
                 dW0 = torch.empty((K, 3), dtype=torch.float32, device=dev)
@@ -794,7 +743,7 @@ class MLPStack(Function):
                 grads[0] = dW0
                 break
             # gradient of layer l-1's post-ReLU output + that layer's BatchNorm-backward sums in one launch
-            dZ = _empty_rows(P, K, dev, rows is not None)
+            dZ = _empty_rows(P, K, dev, quant)
             region = d_arena[d_off[l - 1]:d_off[l]]
             dbeta, dgamma = bn_grads(l - 1)
             grads[3 * l - 2], grads[3 * l - 1] = dgamma, dbeta
@@ -806,8 +755,7 @@ class MLPStack(Function):
                 emit = slots == 1 and rows is None
                 _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dZ), _lib.ptr(Ys[l - 1]),
                       _lib.ptr(abs_[l - 1]), _lib.ptr(region), slots, P, K, N, None if emit else _lib.ptr(dstats),
-                      None if emit else _lib.ptr(dbeta), None if emit else _lib.ptr(dgamma),
-                      _opts(dev, st, ctx.prec, _lib.STORE_YPREV_BF16) if ctx.s16 else opts, st,
+                      None if emit else _lib.ptr(dbeta), None if emit else _lib.ptr(dgamma), opts, st,
                       meta=_gemm_meta("dgrad", P, K, N, fused=True))
             else:
                 # wide + long outputs: the fused epilogue measured slower than a separate column pass
@@ -816,10 +764,10 @@ class MLPStack(Function):
                 dstats = region
                 _call("gb_bn_bwd_stats", dev, _lib.ptr(dZ), _lib.ptr(Ys[l - 1]), _lib.ptr(abs_[l - 1]), None, P, K, 1,
                       _lib.ptr(dstats), _lib.ptr(dbeta), _lib.ptr(dgamma), st)
-            dY = _empty_rows(P, K, dev, rows is not None)
+            dY = _empty_rows(P, K, dev, quant)
             if rows is not None:
-                _call("gb_bn_bwd_apply_ws", dev, _lib.ptr(dZ), _lib.ptr(Ys[l - 1]), int(ctx.s16), _lib.ptr(abs_[l - 1]),
-                      _lib.ptr(dstats), _lib.ptr(rows.w), P, P_stat, K, int(training[l - 1]), _lib.ptr(dY), st)
+                _call("gb_bn_bwd_apply_w", dev, _lib.ptr(dZ), _lib.ptr(Ys[l - 1]), _lib.ptr(abs_[l - 1]),
+                      _lib.ptr(dstats), _lib.ptr(rows.w), P, P_stat, K, int(training[l - 1]), _lib.ptr(dY), _lib.ptr(rdev), st)
             elif emit:
                 _call("gb_bn_bwd_apply_g", dev, _lib.ptr(dZ), _lib.ptr(Ys[l - 1]), _lib.ptr(abs_[l - 1]), None,
                       _lib.ptr(dstats), P, K, 1, int(training[l - 1]), _lib.ptr(dY), None, _lib.ptr(dbeta),
@@ -830,91 +778,86 @@ class MLPStack(Function):
         return (dX0, dres, None, None, None, None, *grads)
 
 
-# The crop stacks' last layer (csrc/gemm_rs.hip RS_STATS_POOL(_V), csrc/crop_bwd.hip):
-#   GB_CROP_POOL=0     the GEMM stores Y3, gb_affine_relu_maxpool_members pools it in a second pass (round-2 path)
-#   default            the pooling leaves the GEMM epilogue as per-(tile, seed, crop) extreme VALUES (a fifth of the
-#                      instructions of the row-tracking form) + gb_pool_pairs; Y3 is still stored and the dense backward
-#                      finds the arg-max rows by value (gb_bn_bwd_apply_members_v), its BatchNorm sums come from the saved
-#                      extremes without a gather: one pass over Y3 less, -0.15 ms per step
-#   GB_CROP_LOWRANK=1  Y3 is never stored; backward = low rank + sparse (K x K product, Gram matrix, sparse kernel).
-#                      Correct to 1e-6 of the dense backward (tests), but its sparse kernel is bound by LDS float
-#                      atomics (164 clocks per wave instruction measured) and loses 2.5 ms per launch: opt-in until
-#                      that kernel is rebuilt without them
-# bf16 precision, OPT-IN (GB_BF16_STORE=1 / set_bf16_storage(True)): the crop stacks' stored pre-BatchNorm outputs
-# (0.8 M x 128 and x 256 per radius at configs[4]: the largest activations of the step) live in HBM as bf16
-# (GbGemmOpts.storage).  Gradients, statistics, parameters, geometry and every other tensor stay fp32.  Correct and
-# tested (tests/test_bf16_gpu.py), but as first built it is SLOWER: configs[4] 28.9 -> 30.1 ms per step (gemm_rs 5.5 ->
-# 6.4 ms, gemm_cl 8.0 -> 8.4): with the accumulator layout of the 32 x 32 MFMA a lane stores / re-reads ONE 2-byte
-# element per instruction (64-byte half lines, store-issue bound) and the split-K wgrad loads 8 bytes per lane instead
-# of 16.  Pair-packed stores (a DPP exchange between neighbouring lanes, whole 128-byte lines) were measured too and
-# made it worse (gemm_rs 7.4 ms: more spills in an epilogue that already spills): DESIGN.md section 5.5.
-_BF16_STORE = os.environ.get("GB_BF16_STORE", "0") == "1"
-
-
-def set_bf16_storage(flag):
-    """-> previous setting."""
-    global _BF16_STORE
-    prev = _BF16_STORE
-    _BF16_STORE = bool(flag)
-    return prev
-
-
+# The crop stacks' last layer (csrc/gemm_rs.hip RS_STATS_POOL_V):
+#   GB_CROP_POOL=0     the GEMM stores Y3, gb_affine_relu_maxpool_members pools it in a second pass (the generic form: any
+#                      width, any number of crops <= 4)
+#   default            the pooling leaves the GEMM epilogue as per-(tile, seed, crop) extreme VALUES + gb_pool_pairs; Y3 is
+#                      still stored and the dense backward finds the arg-max rows by value (gb_bn_bwd_apply_members_v),
+#                      its BatchNorm sums come from the saved extremes without a gather: one pass over Y3 less
+# (Round 3's low-rank + sparse backward of this layer, the bf16 storage of its activations and the multi-pick FPS were
+# measured slower than these defaults and removed in round 4: DESIGN.md section 6.)
 _CROP_POOL = os.environ.get("GB_CROP_POOL", "1") != "0"
-_CROP_LOWRANK = os.environ.get("GB_CROP_LOWRANK", "0") == "1"
 
 
-def set_crop_pool(flag, lowrank=None):
-    """-> previous (pool, lowrank)."""
-    global _CROP_POOL, _CROP_LOWRANK
-    prev = (_CROP_POOL, _CROP_LOWRANK)
-    _CROP_POOL = bool(flag)
-    if lowrank is not None:
-        _CROP_LOWRANK = bool(lowrank)
+def set_crop_pool(flag):
+    """-> previous setting."""
+    global _CROP_POOL
+    prev, _CROP_POOL = _CROP_POOL, bool(flag)
     return prev
 
 
-def _pooled_last_layer(dev, st, opts, src, W, aff, gamma, beta, cfg, ab, stats, slots, rows, P, K, N, P_stat, Y=None,
-                       with_rows=None):
-    """gb_gemm_fwd_pool + gb_pool_pairs -> (out, arg, ystar), each ((R*D), N).  Y: optional (P, N) buffer that also
-    receives the layer's output.  with_rows: the epilogue tracks the arg-max rows (default: whenever there is no stored
-    output to find them in by value; a forward-only caller passes False and gets the values alone)."""
+# Row counts that only exist on the device (the distinct rows of the cylinder crops): with static rows the activations
+# are sized for the CAPACITY (every slot of every crop distinct) and every kernel reads the count itself
+# (GbGemmOpts.rows_dev) - no device -> host read anywhere in the step, which is what lets train.Trainer capture the
+# whole step in a HIP graph.  GB_STATIC_ROWS=0: read the counts back and size the activations exactly (one
+# synchronisation per step, 2.6x less activation memory for the crop stacks).
+_STATIC_ROWS = os.environ.get("GB_STATIC_ROWS", "1") != "0"
+
+
+def set_static_rows(flag):
+    """-> previous setting."""
+    global _STATIC_ROWS
+    prev, _STATIC_ROWS = _STATIC_ROWS, bool(flag)
+    return prev
+
+
+def crop_static_ok(cap, widths, D):
+    """Can a crop stack 3 -> widths[0] -> widths[1] -> widths[2] run on a row CAPACITY of `cap` rows with the count on the
+    device?  Only the default execution knows how: first layer folded, second on the row-streaming GEMM, last pooled in
+    its epilogue (MLPStack.forward makes the same choices from the same conditions)."""
+    L = _lib.lib()
+    return bool(_STATIC_ROWS and _FIRST_FOLD and _FIRST_FUSE and _CROP_POOL and len(widths) == 3 and D <= 4
+                and widths[0] % 4 == 0 and widths[1] <= 128
+                and L.gb_gemm_uses_rs(cap, widths[0], widths[1], 0, 1, 1) and L.gb_gemm_uses_rs(cap, widths[0], widths[1], 1, 2, 0)
+                and L.gb_gemm_uses_rs(cap, widths[1], widths[2], 0, 3, 1) and L.gb_gemm_uses_rs(cap, widths[1], widths[2], 1, 1, 0))
+
+
+def _pooled_last_layer(dev, st, opts, src, W, aff, gamma, beta, cfg, ab, stats, slots, rows, P, K, N, P_stat, Y=None):
+    """gb_gemm_fwd_pool + gb_pool_pairs -> (out, ystar), each ((R*D), N).  Y: optional (P, N) buffer that also receives
+    the layer's output (a forward-only caller passes None: nothing can find the arg-max rows afterwards)."""
     RD = rows.R * rows.D
-    tiles = (P + 31) // 32
-    if with_rows is None:
-        with_rows = Y is None
     # sized for the row count rounded up like the activations (_empty_rows): the distinct-row count changes every step,
     # and a new allocation size every step means a fresh hipMalloc - a device synchronisation - per radius
     cap_tiles = (P + _ROW_QUANTUM - 1) // _ROW_QUANTUM * (_ROW_QUANTUM // 32)
-    pairs = torch.empty(((cap_tiles + rows.R) * rows.D * N, 2 if with_rows else 1), dtype=torch.float32, device=dev)
+    pairs = torch.empty((cap_tiles + rows.R) * rows.D * N, dtype=torch.float32, device=dev)
     if cfg.training:
         fin = _bn_fin(cfg, gamma, beta, ab, P_stat)
     else:
         fin, stats, slots = None, _zeros64(2 * N, dev), 1   # the kernel always forms the sums; eval ignores them
     _call("gb_gemm_fwd_pool", dev, _lib.ptr(src), _lib.ptr(W), _lib.ptr(aff), _lib.ptr(rows.key), _lib.ptr(gamma),
-          _lib.ptr(pairs), int(with_rows), _lib.ptr(Y), _lib.ptr(stats), slots, P, K, N, rows.D, fin, opts, st,
+          _lib.ptr(pairs), pairs.numel(), rows.R, _lib.ptr(Y), _lib.ptr(stats), slots, P, K, N, rows.D, fin, opts, st,
           meta=_gemm_meta("fwd", P, K, N, True, aff is not None))
     # eval: `ab` is the caller's cached table (_eval_ab)
     out = torch.empty((RD, N), dtype=torch.float32, device=dev)
-    arg = torch.empty((RD, N), dtype=torch.int32, device=dev) if with_rows else None
     ystar = torch.empty((RD, N), dtype=torch.float32, device=dev)
     _call("gb_pool_pairs", dev, _lib.ptr(pairs), _lib.ptr(rows.off), _lib.ptr(rows.cnt), _lib.ptr(ab), _lib.ptr(gamma),
-          _lib.ptr(out), _lib.ptr(arg), _lib.ptr(ystar), rows.R, rows.D, N, st)
-    return out, arg, ystar
+          _lib.ptr(out), _lib.ptr(ystar), rows.R, rows.D, N, st)
+    return out, ystar
 
 
 def _arg_rows_by_value(Y, ystar, rows):
     """Debug / test helper (routing_observer): the arg-max rows the values-only pooled path implies - per (seed, crop,
     column) the first member row whose y equals y* - as gb_affine_relu_maxpool_members would name them."""
     R, D, C = rows.R, rows.D, Y.shape[1]
-    P = Y.shape[0]
-    Y = Y.float()   # (bf16 storage mode: exact widening - y* are those rounded values)
+    P = int(rows.cnt.sum())   # (with a device-side row count Y is sized for the capacity)
+    Y = Y[:P]
     seed = torch.repeat_interleave(torch.arange(R, device=Y.device), rows.cnt.long(), output_size=P)
     rowidx = torch.arange(P, device=Y.device, dtype=torch.int64).unsqueeze(1).expand(P, C)
     ys = ystar.view(R, D, C)
     arg = torch.empty((R, D, C), dtype=torch.int64, device=Y.device)
     big = torch.iinfo(torch.int64).max
     for d in range(D):
-        hit = (Y == ys[seed, d]) & ((rows.mem.long() >> d) & 1).bool().unsqueeze(1)
+        hit = (Y == ys[seed, d]) & ((rows.mem[:P].long() >> d) & 1).bool().unsqueeze(1)
         cand = torch.where(hit, rowidx, torch.full_like(rowidx, big))
         first = torch.full((R, C), big, dtype=torch.int64, device=Y.device)
         first.scatter_reduce_(0, seed.unsqueeze(1).expand(P, C), cand, reduce="amin")
@@ -1096,12 +1039,15 @@ class RowSet:
     """Distinct rows of a batch with duplicates (the D nested cylinder crops of a seed, csrc/cyl_rows.hip): w / w16
     multiplicities (float / uint16 padded to a multiple of 32 rows), mem member bits, off / cnt the rows of each of
     the R seeds, D crops per seed, P_total rows of the full batch."""
-    __slots__ = ("w", "w16", "mem", "off", "cnt", "R", "D", "P_total", "key")
+    __slots__ = ("w", "w16", "mem", "off", "cnt", "R", "D", "P_total", "key", "rows_dev")
 
-    def __init__(self, w, w16, mem, off, cnt, R, D, P_total, key=None):
+    def __init__(self, w, w16, mem, off, cnt, R, D, P_total, key=None, rows_dev=None):
         self.w, self.w16, self.mem, self.off, self.cnt = w, w16, mem, off, cnt
         self.R, self.D, self.P_total = int(R), int(D), int(P_total)
         self.key = key  # (seed << 13) | (multiplicity << 4) | member bits per row, zero-padded to 32 rows (D <= 4)
+        # one-element int64 device tensor = the number of rows, when the host never learns it: every per-row array (and
+        # the x0 that goes with this set) is then sized for the capacity R * D * ns and kernels take the count from here
+        self.rows_dev = rows_dev
 
 
 class _ZeroGradFor(Function):
@@ -1232,6 +1178,11 @@ def shared_mlp_cl(X, shared_mlp, pool_ns=0, rows=None):
     return conv_bn_act_chain(X, layers, pool_ns=pool_ns, rows=rows)
 
 
+def shared_mlp_widths(shared_mlp):
+    """Output widths of a pytorch_utils.SharedMLP's layers."""
+    return [layer.conv.weight.shape[0] for layer in shared_mlp.children()]
+
+
 _CYL_DEDUP = os.environ.get("GB_CYL_DEDUP", "1") != "0"  # A/B switch: distinct rows for the nested cylinder crops
 
 
@@ -1244,39 +1195,51 @@ def set_cyl_dedup(flag):
     _CYL_DEDUP = bool(flag)
 
 
-def cylinder_rows(idx, xyz, centres, rot):
+def cylinder_rows(idx, xyz, centres, rot, static=False):
     """idx (nr, D, B, m, ns) int32 from fused_ops.cylinder_query_multi -> per radius (x0 (P_u,3), RowSet): the DISTINCT
-    (seed, point) rows of the D nested crops of every seed, rotated into the seed's frame (csrc/cyl_rows.hip).  One
-    device->host read of the nr row counts (the allocation sizes) is the only synchronisation."""
+    (seed, point) rows of the D nested crops of every seed, rotated into the seed's frame (csrc/cyl_rows.hip; three
+    launches for all radii).  static=False: one device -> host read of the nr row counts sizes the outputs exactly (the
+    step's only synchronisation).  static=True (callers check crop_static_ok): no read - x0 and the per-row arrays have
+    the capacity R * D * ns rows and RowSet.rows_dev holds the count on the device."""
     nr, D, B, m, ns = idx.shape
     R, W, dev = B * m, D * ns, idx.device
     idx = idx.contiguous()
     xyz, centres, rot9 = xyz.contiguous(), centres.contiguous(), rot.reshape(B, m, 9).contiguous()
     scratch = torch.empty((2, nr, R, W), dtype=torch.int32, device=dev)
     count = torch.empty((nr, R), dtype=torch.int32, device=dev)
+    off = torch.empty((nr, R), dtype=torch.int64, device=dev)
+    total = torch.empty(nr, dtype=torch.int64, device=dev)
     st = _s(idx)
-    for i in range(nr):
-        _call("gb_cyl_unique", dev, _lib.ptr(idx[i]), D, R, ns, _lib.ptr(scratch[0, i]), _lib.ptr(scratch[1, i]),
-              _lib.ptr(count[i]), st)
-    ends = torch.cumsum(count, dim=1, dtype=torch.int64)
-    off = (ends - count).contiguous()
-    t_sync = time.perf_counter()
-    totals = ends[:, -1].tolist()  # the one host synchronisation: row counts size the activations
-    SYNC_WAIT[0] += time.perf_counter() - t_sync   # (bench.py: host-bound or GPU-bound? a host that arrives late waits ~0)
+    _call("gb_cyl_unique", dev, _lib.ptr(idx), nr, D, R, ns, _lib.ptr(scratch[0]), _lib.ptr(scratch[1]), _lib.ptr(count), st)
+    _call("gb_cyl_scan", dev, _lib.ptr(count), nr, R, _lib.ptr(off), _lib.ptr(total), st)
+    if static:
+        totals = None
+        cap = (R * W + 31) // 32 * 32
+    else:
+        t_sync = time.perf_counter()
+        totals = total.tolist()  # the one host synchronisation: row counts size the activations
+        SYNC_WAIT[0] += time.perf_counter() - t_sync   # (bench.py: host-bound or GPU-bound? a host that arrives late waits ~0)
+        cap = (max(totals) + _ROW_QUANTUM - 1) // _ROW_QUANTUM * _ROW_QUANTUM  # allocation sizes that repeat from step to step
+    x0 = torch.empty((nr, cap, 3), dtype=torch.float32, device=dev)
+    w = torch.empty((nr, cap), dtype=torch.float32, device=dev)
+    w16 = torch.empty((nr, cap), dtype=torch.int16, device=dev)   # uint16 bits; the kernel zeroes the tail of the last tile
+    mem = torch.empty((nr, cap), dtype=torch.int32, device=dev)
+    key = torch.empty((nr, cap), dtype=torch.int32, device=dev) if (D <= 4 and R < (1 << 18)) else None
+    _call("gb_cyl_rows", dev, _lib.ptr(xyz), _lib.ptr(centres), _lib.ptr(rot9), _lib.ptr(scratch[0]), _lib.ptr(scratch[1]),
+          _lib.ptr(count), _lib.ptr(off), nr, B, xyz.shape[1], m, W, cap, _lib.ptr(x0), _lib.ptr(w), _lib.ptr(w16),
+          _lib.ptr(mem), _lib.ptr(key), st)
     out = []
     for i in range(nr):
-        Pu = int(totals[i])
-        pad = (Pu + 31) // 32 * 32
-        cap = (Pu + _ROW_QUANTUM - 1) // _ROW_QUANTUM * _ROW_QUANTUM  # allocation sizes that repeat from step to step
-        x0 = torch.empty((cap, 3), dtype=torch.float32, device=dev)[:Pu]
-        w = torch.empty(cap, dtype=torch.float32, device=dev)[:Pu]
-        w16 = torch.zeros(cap, dtype=torch.int16, device=dev)[:pad]  # uint16 bits; zero tail for the GEMM epilogue
-        mem = torch.empty(cap, dtype=torch.int32, device=dev)[:Pu]
-        key = torch.zeros(cap, dtype=torch.int32, device=dev)[:pad] if (D <= 4 and R < (1 << 18)) else None
-        _call("gb_cyl_rows", dev, _lib.ptr(xyz), _lib.ptr(centres), _lib.ptr(rot9), _lib.ptr(scratch[0, i]),
-              _lib.ptr(scratch[1, i]), _lib.ptr(count[i]), _lib.ptr(off[i]), B, xyz.shape[1], m, W, _lib.ptr(x0),
-              _lib.ptr(w), _lib.ptr(w16), _lib.ptr(mem), _lib.ptr(key), st)
-        out.append((x0, RowSet(w, w16, mem, off[i], count[i], R, D, R * W, key)))
+        if static:
+            rs = RowSet(w[i], w16[i], mem[i], off[i], count[i], R, D, R * W, key[i] if key is not None else None,
+                        rows_dev=total[i:i + 1])
+            out.append((x0[i], rs))
+        else:
+            Pu = int(totals[i])
+            pad = (Pu + 31) // 32 * 32
+            rs = RowSet(w[i, :Pu], w16[i, :pad], mem[i, :Pu], off[i], count[i], R, D, R * W,
+                        key[i, :pad] if key is not None else None)
+            out.append((x0[i, :Pu], rs))
         if routing_observer is not None:
             routing_observer("cyl_rows", rowset=out[-1][1], sorted=scratch[0, i], idx=idx[i])
     return out

@@ -104,7 +104,11 @@ class GraspPoseStage2_seed_features_multi_scale(nn.Module):
             if (fused_mlp.cyl_dedup_enabled() and cl
                     and len(g0.hmax_list) in (1, 2, 4) and len(g0.hmax_list) * g0.nsample <= 256):
                 # the crops of a seed are nested: run each MLP on the distinct (seed, point) rows only
-                rows = fused_mlp.cylinder_rows(idx, pointcloud, seed_xyz, rot)
+                # (no read-back of the row counts where every scale's stack can take them from the device)
+                cap = seed_xyz.size(0) * seed_xyz.size(1) * len(g0.hmax_list) * g0.nsample
+                static = all(fused_mlp.crop_static_ok(cap, fused_mlp.shared_mlp_widths(g.mlps), len(g.hmax_list))
+                             for g in groups)
+                rows = fused_mlp.cylinder_rows(idx, pointcloud, seed_xyz, rot, static=static)
                 scales = [g(seed_xyz, pointcloud, rot, rows=rows[i], channel_last=True) for i, g in enumerate(groups)]
             else:
                 scales = [g(seed_xyz, pointcloud, rot, idx=idx[i], channel_last=cl) for i, g in enumerate(groups)]

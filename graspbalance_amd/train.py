@@ -2,6 +2,17 @@
 :107-108, BN-momentum schedule :110-113, per-batch body :138-155) on the GraspBalance model, plus the
 RCCL data-parallel gradient reduction.  (The reference script itself cannot run as shipped: it imports
 the absent ``graspnet.GraspNet_MSCQ`` and dataset class names that do not exist — SURVEY.md §0.)
+
+HIP-graph execution (``Trainer(graph=True)``, the default on a GPU).  A train step is ~1000 kernel launches and 15-19 ms
+of Python to enqueue them - as long as the GPU itself needs.  Nothing in the step depends on a value the host has to
+see (the one row count that used to be read back stays on the device: fused_mlp.set_static_rows), so the whole step -
+forward, label matching, loss, backward, Adam, the next batch's first-level sampling on its side stream - is captured
+ONCE into a HIP graph and replayed: one launch call per step.  What varies between steps lives in device memory the
+graph reads: the batch (static input buffers: ``Trainer.resident``), the learning rate (a device scalar), Adam's step
+count.  A change of anything that was baked into launch arguments (tensor shapes of the batch, the BatchNorm momentum
+of the epoch, whether a next batch is announced) captures another graph; all graphs share one memory pool.  With more
+than one rank the gradient all-reduce sits BETWEEN two graphs (forward + backward + pack | RCCL all-reduce of the flat
+buckets | Adam): collectives are not captured.
 """
 import contextlib
 
@@ -18,6 +29,7 @@ from .pytorch_utils import BNMomentumScheduler
 
 import os
 _PREFETCH_AT = os.environ.get("GB_PREFETCH_AT", "sa1")  # A/B switch: "start" | "sa1" | "off"
+_GRAPH_DEFAULT = os.environ.get("GB_GRAPH", "1") != "0"  # A/B switch: 0 = every step enqueued launch by launch
 _NO_CONTEXT = contextlib.nullcontext()
 
 BN_MOMENTUM_INIT = 0.5
@@ -28,7 +40,7 @@ class Trainer:
     def __init__(self, device, learning_rate=0.001, weight_decay=0.0, bn_decay_step=2, bn_decay_rate=0.5,
                  steps_per_epoch=100, max_epoch=18, num_view=300, seed=1234, distributed=False,
                  bucket_mb=16.0, model=None, time_collectives=False, prefetch_sampling=True, mlp_precision=None,
-                 lean_labels=True):
+                 lean_labels=True, graph=None):
         torch.manual_seed(seed)
         self.device = torch.device(device)
         # 'bf16': BASELINE configs[4].  A property of THIS trainer: every step runs inside fused_mlp.precision(...), the
@@ -60,6 +72,13 @@ class Trainer:
         if prefetch_sampling and _PREFETCH_AT != "off" and self.device.type == "cuda" and sa1 is not None and sa1.npoint:
             from .prefetch import SamplingPrefetch
             self.prefetch = SamplingPrefetch(self.device, sa1.npoint)
+        # HIP-graph replay of the step (module docstring); needs the sync-free step (static rows) and a GPU
+        self.graph = (_GRAPH_DEFAULT if graph is None else bool(graph)) and self.device.type == "cuda"
+        self.distributed = bool(distributed)
+        self._graphs = {}        # signature -> _StepGraph
+        self._pool = None        # memory pool shared by the graphs (one replays at a time)
+        self._static = None      # _StaticBatch: the input buffers the graphs read
+        self.graph_replays = 0
 
     def train_step(self, batch, next_batch=None):
         """forward -> loss -> backward -> gradient all-reduce -> Adam step -> LR step.  Returns the
@@ -67,6 +86,16 @@ class Trainer:
         next_batch: the batch of the FOLLOWING call, if the loop already holds it - its first-level furthest-point
         sampling then runs on a side stream under this step (prefetch.py)."""
         with (fused_mlp.precision(self.mlp_precision) if self.mlp_precision is not None else _NO_CONTEXT):
+            if self.graph:
+                return self._graph_step(batch, next_batch)
+            return self._train_step(batch, next_batch)
+
+    def train_step_eager(self, batch, next_batch=None):
+        """The same step enqueued launch by launch (what graph=False does): for tools that bracket single launches with
+        events (bench.py's roofline leg), and the reference point of the graph's parity test."""
+        with (fused_mlp.precision(self.mlp_precision) if self.mlp_precision is not None else _NO_CONTEXT):
+            if self._static is not None:
+                self._static.valid_sampling = None   # the eager step runs its own prefetch protocol
             return self._train_step(batch, next_batch)
 
     def _train_step(self, batch, next_batch=None):
@@ -96,3 +125,245 @@ class Trainer:
         self.grads.zero_grad()  # .grad = None: the next backward assigns instead of accumulating
         self.scheduler.step()
         return loss
+
+    # ---- HIP-graph execution ----------------------------------------------------------------------------------------
+    def resident(self, batch):
+        """Copy `batch` into this trainer's static input buffers and return the batch made of THOSE tensors: steps on it
+        replay the graph without any staging copy (a data loader would write its next batch into them directly)."""
+        if not self.graph:
+            return batch
+        if self._static is None or self._static.signature != _signature(batch):
+            self._static = _StaticBatch(batch, self.prefetch.npoint if self.prefetch is not None else 0)
+        else:
+            self._static.load(batch)
+        return self._static.batch
+
+    def _bn_momentum(self):
+        for m in self.net.modules():
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d, torch.nn.BatchNorm3d)):
+                return m.momentum
+        return None
+
+    def _graph_step(self, batch, next_batch):
+        announced = self.prefetch is not None and next_batch is not None
+        sig = _signature(batch)
+        if self._static is None or self._static.signature != sig:
+            self._static = _StaticBatch(batch, self.prefetch.npoint if self.prefetch is not None else 0)
+        st = self._static
+        st.load(batch)                                   # no copies when `batch` is st.batch (Trainer.resident)
+        if announced:
+            st.load_next(next_batch['point_clouds'])
+        key = (sig, announced, self._bn_momentum(), self.mlp_precision, fused_mlp.get_precision())
+        g = self._graphs.get(key)
+        if g is None:
+            g = self._graphs[key] = self._capture(st, announced)
+        if announced and st.samp_for != st.cloud_id():
+            # the graph takes the current batch's first-level samples from st.inds: nobody sampled this batch ahead
+            with torch.no_grad():
+                from . import pointnet2_utils
+                st.inds.copy_(pointnet2_utils.furthest_point_sample(st.batch['point_clouds'][..., 0:3].contiguous(),
+                                                                   self.prefetch.npoint))
+        self.optimizer.set_lr_tensor()
+        g.fwd_bwd.replay()
+        if g.update is not None:                         # data parallel: the collective sits between the two graphs
+            self.grads.reduce_flat()
+            g.update.replay()
+        self.optimizer.count_step()
+        self.scheduler.step()
+        self.graph_replays += 1
+        if announced:
+            st.moved_next_in()   # the graph's tail put the announced clouds and their samples into the current slots
+        return g.loss
+
+    def _capture(self, st, announced):
+        """One eager step on the static buffers (everything lazy gets built: caches, workspaces, the allocator's pool),
+        model / optimizer state restored, then the same code under stream capture."""
+        dev = self.device
+        opt = self.optimizer
+        opt.tensor_lr = True
+        opt.set_lr_tensor()
+        keep = {k: v.detach().clone() for k, v in self.net.state_dict().items()}
+        keep_opt = (opt._exp_avg.clone(), opt._exp_avg_sq.clone(), opt._step_t.clone(), opt._steps)
+        tick = fused_mlp._TRAIN_TICK[0]
+        torch.cuda.synchronize(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._body(st, announced, part="all")
+                self.grads.zero_grad()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+
+        def restore():
+            with torch.no_grad():
+                sd = self.net.state_dict()
+                for k, v in keep.items():
+                    sd[k].copy_(v)
+                opt._exp_avg.copy_(keep_opt[0]); opt._exp_avg_sq.copy_(keep_opt[1]); opt._step_t.copy_(keep_opt[2])
+                opt._steps = keep_opt[3]
+            fused_mlp._TRAIN_TICK[0] = tick + 1
+        restore()
+        if self._pool is None:
+            self._pool = torch.cuda.graph_pool_handle()
+        g = _StepGraph()
+        g.fwd_bwd = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize(dev)
+        if self.distributed:
+            with torch.cuda.graph(g.fwd_bwd, pool=self._pool):
+                g.loss = self._body(st, announced, part="fwd_bwd")
+            g.update = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g.update, pool=self._pool):
+                self._body(st, announced, part="update")
+        else:
+            with torch.cuda.graph(g.fwd_bwd, pool=self._pool):
+                g.loss = self._body(st, announced, part="all")
+        # (capture launches nothing, but the python side effects of the step ran: undo them)
+        self.grads.zero_grad()
+        restore()
+        return g
+
+    def _body(self, st, announced, part):
+        """The step on the static buffers.  part: "all" | "fwd_bwd" (ends with the gradients packed into the flat buffer)
+        | "update" (Adam on the flat buffer)."""
+        if part == "update":
+            self.optimizer.step(packed=True)
+            return None
+        from .prefetch import AFTER_SA1, KEY
+        dev = self.device
+        fused_mlp.begin_step(dev)
+        inputs = dict(st.batch)
+        if self.lean_labels:
+            inputs[LEAN] = True
+        cur = torch.cuda.current_stream(dev)
+        side = self.prefetch.side if self.prefetch is not None else None
+        launched = []
+        if announced:
+            inputs[KEY] = st.inds
+
+            def launch_next():
+                from . import pointnet2_utils
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    st.inds_next.copy_(pointnet2_utils.furthest_point_sample(st.next_clouds[..., 0:3].contiguous(),
+                                                                            self.prefetch.npoint))
+                fused_mlp.set_reserved_cus(min(st.next_clouds.shape[0], 128))
+                launched.append(True)
+            if _PREFETCH_AT == "start":
+                launch_next()
+            else:
+                inputs[AFTER_SA1] = launch_next
+        try:
+            end_points = self.net(inputs)
+            if announced and not launched:
+                launch_next()
+            loss, end_points = get_loss(end_points)
+            loss.backward()
+        finally:
+            fused_mlp.set_reserved_cus(0)
+        if part == "fwd_bwd":
+            with torch.no_grad():
+                self.optimizer.pack()
+        else:
+            self.grads.reduce()          # (single process: a no-op; "all" is never captured with several ranks)
+            self.optimizer.step()
+        if announced:
+            cur.wait_stream(side)        # join: the graph ends with the next batch's samples in place
+            with torch.no_grad():
+                st.inds.copy_(st.inds_next)
+                st.batch['point_clouds'].copy_(st.next_clouds)
+        return loss.detach()
+
+
+class _StepGraph:
+    __slots__ = ("fwd_bwd", "update", "loss")
+
+    def __init__(self):
+        self.fwd_bwd = self.update = self.loss = None
+
+
+def _leaves(obj, path=()):
+    """(path, tensor) of every tensor in a collated batch (dict of tensors / nested lists of tensors)."""
+    if torch.is_tensor(obj):
+        yield path, obj
+    elif isinstance(obj, dict):
+        for k in obj:
+            yield from _leaves(obj[k], path + (k,))
+    elif isinstance(obj, (list, tuple)):
+        for i, v in enumerate(obj):
+            yield from _leaves(v, path + (i,))
+
+
+def _signature(batch):
+    return tuple((p, tuple(t.shape), t.dtype) for p, t in _leaves(batch) if p and not str(p[0]).startswith('_'))
+
+
+def _token(t):
+    return (t.data_ptr(), tuple(t.shape), t._version)
+
+
+class _StaticBatch:
+    """Device buffers with the shapes of one batch, at fixed addresses: what the captured step reads.  `batch` has the
+    structure of the batch it was built from; `next_clouds` / `inds` / `inds_next` serve the sampling prefetch (the graph
+    samples next_clouds on the side stream and ends by moving next_clouds -> batch['point_clouds'], inds_next -> inds).
+    Which source tensor every buffer currently mirrors is tracked by (address, shape, version) tokens, so a loop that keeps
+    passing the same resident tensors - or the static buffers themselves - pays for no copy."""
+
+    def __init__(self, batch, npoint):
+        self.signature = _signature(batch)
+
+        def clone(obj):
+            if torch.is_tensor(obj):
+                return obj.detach().clone().contiguous()
+            if isinstance(obj, dict):
+                return {k: clone(v) for k, v in obj.items() if not str(k).startswith('_')}
+            if isinstance(obj, (list, tuple)):
+                return [clone(v) for v in obj]
+            return obj
+        self.batch = clone(batch)
+        self._dst = dict(_leaves(self.batch))
+        self.loaded = {p: _token(t) for p, t in _leaves(batch) if p in self._dst}   # source each buffer mirrors
+        clouds = self.batch['point_clouds']
+        self.next_clouds = self.inds = self.inds_next = None
+        self.next_src = None       # source next_clouds mirrors
+        self.samp_for = None       # cloud_id() the samples in `inds` belong to
+        if npoint:
+            self.next_clouds = torch.empty_like(clouds)
+            self.inds = torch.zeros((clouds.shape[0], npoint), dtype=torch.int32, device=clouds.device)
+            self.inds_next = torch.zeros_like(self.inds)
+
+    def cloud_id(self):
+        """Identity of what batch['point_clouds'] holds: the source it mirrors + its own version (in-place writes)."""
+        return (self.loaded[('point_clouds',)], self.batch['point_clouds']._version)
+
+    def load(self, batch):
+        """Make the static buffers hold `batch`; tensors that ARE the static ones, or that a buffer already mirrors, are
+        not copied."""
+        if batch is self.batch:
+            return
+        with torch.no_grad():
+            for p, t in _leaves(batch):
+                d = self._dst.get(p)
+                if d is None or d.data_ptr() == t.data_ptr():
+                    continue
+                tok = _token(t)
+                if self.loaded.get(p) != tok:
+                    d.copy_(t, non_blocking=True)
+                    self.loaded[p] = tok
+
+    def load_next(self, clouds):
+        cur = self.batch['point_clouds']
+        src = ("self", self.cloud_id()) if clouds.data_ptr() == cur.data_ptr() else _token(clouds)
+        if src != self.next_src:
+            with torch.no_grad():
+                self.next_clouds.copy_(clouds, non_blocking=True)
+            self.next_src = src
+
+    def moved_next_in(self):
+        """Bookkeeping after a replay that announced a next batch: batch['point_clouds'] now holds next_clouds' content
+        and `inds` its samples (device-side copies at the end of the graph: no version counter moved)."""
+        if self.next_src[0] != "self":      # ("self", ...): the same content as before
+            self.loaded[('point_clouds',)] = self.next_src
+        self.samp_for = self.cloud_id()
+        if self.next_src[0] == "self":
+            self.next_src = ("self", self.cloud_id())

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GB_ABI_VERSION 4
+#define GB_ABI_VERSION 5
 
 enum {
   GB_OK = 0,
@@ -55,9 +55,6 @@ enum {
 #define GB_FPS_TIE_TREE512  0x10u
 #define GB_FPS_TIE_TREE1024 0x20u
 #define GB_FPS_TIE_MASK     0x30u
-/* gb_fps_pruned only, n <= 20480: pick up to four samples per block-wide selection (same outputs, fewer dependent
- * rounds: see fps_multi_kernel in csrc/fps.hip) */
-#define GB_FPS_MULTI_PICK   0x100u
 
 int gb_abi_version(void);
 /* last launch error text of the calling thread ("" if none) */
@@ -273,25 +270,21 @@ int gb_group_concat_cl_grad(const float *dx0, const int32_t *idx, float *dfeat, 
 #define GB_PREC_F32 0
 #define GB_PREC_BF16 1
 #define GB_GEMM_SCRATCH_BYTES (320ull * 64 * 128 * 4)
-/*   storage     : (GB_PREC_BF16 only) which activation tensors of THIS call live in HBM as bf16 instead of fp32 - the
- *                 contractions of that mode are bound by operand bytes, not by the matrix cores:
- *                   GB_STORE_X_BF16  the rows operand (x of gb_gemm_fwd / _fwd_pool / _wgrad: the previous layer's pre-BN
- *                                    output, its BatchNorm + ReLU applied on load as always)
- *                   GB_STORE_Y_BF16  the output y of gb_gemm_fwd / _fwd_gen3 / _fwd_pool (rounded to nearest even once,
- *                                    from the fp32 accumulator; BatchNorm sums and pooled extrema are those of the
- *                                    ROUNDED values, so that what a later pass reads is what they describe)
- *                   GB_STORE_YPREV_BF16  y_prev of gb_gemm_dgrad
- *                 Honoured by the row-streaming kernel (and, for GB_STORE_X_BF16, the split-K wgrad); a call that
- *                 cannot honour a flag returns GB_EINVAL instead of reading the bytes as fp32.                      */
-#define GB_STORE_X_BF16 1
-#define GB_STORE_Y_BF16 2
-#define GB_STORE_YPREV_BF16 4
+/*   rows_dev    : optional DEVICE pointer (8-byte aligned) to the actual row count of this call, 0 <= *rows_dev <= P.  The
+ *                 P argument is then only the CAPACITY the caller sized its buffers (and the library its grid) for: the
+ *                 kernels read the count themselves, so a caller whose row count is produced on the device (the
+ *                 distinct rows of the cylinder crops, gb_cyl_unique / gb_cyl_rows) never has to read it back - no
+ *                 host synchronisation, and the whole step can be captured in a HIP graph.  Rows [*rows_dev, P) are
+ *                 neither read nor written.  Honoured by gb_gemm_fwd_gen3, gb_gemm_fwd_pool, gb_gemm_wgrad,
+ *                 gb_gemm_wgrad_gen3, gb_gemm_dgrad_first_gen3 and by gb_gemm_fwd / gb_gemm_dgrad / gb_gemm_dgrad_first
+ *                 on the row-streaming kernel (ask gb_gemm_uses_rs); every other case returns GB_EINVAL rather than
+ *                 ignore it.                                                                                       */
 typedef struct GbGemmOpts {
   int precision;
   int reserved_cus;
   void *scratch;
   unsigned long long scratch_bytes;
-  int storage;
+  const long long *rows_dev;
 } GbGemmOpts;
 
 /* The arguments of gb_bn_finalize as a struct: entry points that produce BatchNorm sums take an optional pointer to
@@ -365,78 +358,48 @@ int gb_bn_bwd_reduce(const double *dst, int slots, int C, double *dstats, float 
  * hmax = 0.01..0.04, stacked and sent through ONE SharedMLP, then max_pool2d over the samples of each crop).  A point
  * lying in several of a seed's cylinders gives identical rows; the MLP runs on the distinct rows, weighted by their
  * multiplicity in the BatchNorm sums, and each crop's max runs over its members.                              */
-/* idx (D, R, ns) int32 (R = b*m seeds).  Per seed: sorted (R, D*ns) = its distinct point ids, ascending, compacted
- * to the front; meta (R, D*ns) = (multiplicity << 8) | member bits (bit d: in crop d); count (R).  D*ns <= 256.  */
-int gb_cyl_unique(const int32_t *idx, int D, long long R, int ns, int32_t *sorted, int32_t *meta, int32_t *count,
+/* nr query sets at once (the radii of stage 2): idx (nr, D, R, ns) int32 (R = b*m seeds).  Per set and seed: sorted
+ * (nr, R, D*ns) = its distinct point ids, ascending, compacted to the front; meta (nr, R, D*ns) = (multiplicity << 8) |
+ * member bits (bit d: in crop d); count (nr, R).  D*ns <= 256.                                                     */
+int gb_cyl_unique(const int32_t *idx, int nr, int D, long long R, int ns, int32_t *sorted, int32_t *meta, int32_t *count,
                   void *stream);
-/* Rows off[r] .. off[r]+count[r]-1 of seed r (off = exclusive prefix sum of count, int64):
-* x0 (P_u,3) = (xyz[b,id] - centre[r]) rotated by rot[r] (3x3) as gb_group_concat_cl mode 2, row_w = multiplicity
- * (row_w16: the same as uint16, for gb_gemm_fwd_w), row_mem = member bits, row_key (optional) = (seed << 13) |
- * (multiplicity << 4) | member bits for gb_gemm_fwd_pool (D <= 4).  W = D*ns is the row pitch of sorted / meta.                                         */
+/* off (nr, R) int64 = exclusive prefix sums of count (nr, R) along R; total (nr) int64 = the row count P_u of each set,
+ * ON THE DEVICE: what GbGemmOpts.rows_dev / the rows_dev arguments take, so that no caller has to read it back.   */
+int gb_cyl_scan(const int32_t *count, int nr, long long R, int64_t *off, long long *total, void *stream);
+/* Rows off[r] .. off[r]+count[r]-1 of seed r, for each of the nr sets at row stride `cap` (the caller's row capacity per
+ * set, a multiple of 32, >= the set's total; rows beyond it are dropped, never written out of bounds):
+ * x0 (nr, cap, 3) = (xyz[b,id] - centre[r]) rotated by rot[r] (3x3) as gb_group_concat_cl mode 2, row_w (nr, cap) =
+ * multiplicity (row_w16: the same as uint16, for gb_gemm_fwd_w), row_mem = member bits, row_key (optional) = (seed << 13)
+ * | (multiplicity << 4) | member bits for gb_gemm_fwd_pool (D <= 4).  row_w16 / row_key are zero on [P_u, P_u rounded up
+ * to 32).  W = D*ns is the row pitch of sorted / meta.                                                              */
 int gb_cyl_rows(const float *xyz, const float *centres, const float *rot, const int32_t *sorted, const int32_t *meta,
-                const int32_t *count, const int64_t *off, int b, int n, int m, int W, float *x0, float *row_w,
-                uint16_t *row_w16, int32_t *row_mem, int32_t *row_key, void *stream);
+                const int32_t *count, const int64_t *off, int nr, int b, int n, int m, int W, long long cap, float *x0,
+                float *row_w, uint16_t *row_w16, int32_t *row_mem, int32_t *row_key, void *stream);
 /* The LAST layer of a crop stack without ever storing its output (reference modules.py:104-124: the SharedMLP's final
  * conv + BatchNorm + ReLU, then max_pool2d over each crop; pointnet2_modules.py:176-188 has the same shape).
  * gb_gemm_fwd_pool: Y = f(X) W^T is formed tile by tile; what leaves the kernel are the weighted BatchNorm sums
  * (as gb_gemm_fwd_w) and, per (32-row tile t, seed r with rows in t, crop d, column c), the extreme of sign(gamma_c)*y
- * over the seed's member rows in the tile and the row holding it: pairs[((t + r)*D + d)*N + c] = (value, row as int
- * bits) - a seed's rows are contiguous, so slot t + r is unique and is written with plain stores.  relu(a*y + b) is
- * monotone in y with the sign of a = gamma*rstd, so gb_pool_pairs finishes the pooling once the statistics are
- * known: out ((R*D), N) = the crop's max of relu(a*y + b), arg = the row attaining it (the lowest one among equal
- * extremes), ystar = that row's y.  row_key (P rounded up to 32, zero tail; 16-byte aligned) from gb_cyl_rows; pairs:
- * ((P + 31) / 32 + R) * D * N * 2 floats.  N in {64, 128, 160, 256}, D <= 4, P >= 16384, K % 4 == 0: otherwise
- * GB_EINVAL (ask gb_gemm_uses_rs(P, K, N, 0, 3, has_aff)).  stats as in gb_gemm_fwd (required).  y (optional, (P,N)):
- * Y is stored as well, for a caller whose backward wants it (the dense backward: gb_bn_bwd_apply_members).
- * with_rows = 0: VALUES only - pairs holds one float per entry (half the size), gb_pool_pairs is called with arg =
- * NULL, and the arg-max row is found by value in the stored y by gb_bn_bwd_apply_members_v: the epilogue then costs
- * a fifth of the instructions of the row-tracking form.  with_rows = 0 and y = NULL: a forward-only caller
- * (inference) - the layer's output is neither stored nor traceable afterwards.                                  */
+ * over the seed's member rows in the tile: pairs[((t + r)*D + d)*N + c] - a seed's rows are contiguous, so slot
+ * t + r is unique and is written with plain stores.  relu(a*y + b) is monotone in y with the sign of a = gamma*rstd,
+ * so gb_pool_pairs finishes the pooling once the statistics are known: out ((R*D), N) = the crop's max of
+ * relu(a*y + b), ystar = the y attaining it (0 / 0 for a crop or a seed without rows).  row_key (P rounded up to 32,
+ * zero tail; 16-byte aligned) from gb_cyl_rows, seed ids < seeds; pairs: pairs_elems >= ((P + 31) / 32 + seeds) * D * N
+ * floats (else GB_ERANGE).  N in {64, 128, 160, 256}, D <= 4, P >= 16384, K % 4 == 0: otherwise GB_EINVAL (ask
+ * gb_gemm_uses_rs(P, K, N, 0, 3, has_aff)).  stats as in gb_gemm_fwd (required).  y (optional, (P,N)): Y is stored as
+ * well, for a caller whose backward wants it: gb_bn_bwd_apply_members_v finds the arg-max rows in it by value
+ * (y == ystar).  y = NULL: a forward-only caller (inference) - the layer's output is neither stored nor traceable.  */
 int gb_gemm_fwd_pool(const float *x, const float *w, const float *aff, const int32_t *row_key, const float *gamma,
-                     float *pairs, int with_rows, float *y, double *stats, int stat_slots, long long P, int K, int N,
-                     int D, const GbBnFinalize *fin, const GbGemmOpts *opts, void *stream);
+                     float *pairs, long long pairs_elems, long long seeds, float *y, double *stats, int stat_slots,
+                     long long P, int K, int N, int D, const GbBnFinalize *fin, const GbGemmOpts *opts, void *stream);
 int gb_pool_pairs(const float *pairs, const int64_t *off, const int32_t *cnt, const float *ab, const float *gamma,
-                  float *out, int32_t *arg, float *ystar, long long R, int D, int C, void *stream);
-/* Backward of that layer as "low rank + sparse" (csrc/crop_bwd.hip has the algebra): behind the max-pool the gradient
- * reaching the layer's BatchNorm is nonzero in one member row per (crop, channel), plus terms affine in y = X~ W^T, so
- *   dX~ = S - w (v + X~ M),   dW = T - f sx^T - diag(e) W G      (M = W^T diag(e) W and G = sum w X~^T X~ are K x K)
- * and neither Y nor the dense P x C gradient is ever formed.  X~ = relu(a2*y2 + b2): y2 (P,K) the previous layer's
- * pre-BatchNorm output, ab2 = its [a,b,mean,rstd](K); ab = this layer's [a,b,mean,rstd](C); w3 (C,K); row_w (P)
- * multiplicities (readable up to a multiple of 32 rows, 16-byte aligned); P_total = rows of the original batch.
- *   gb_crop_bwd_ok     : 1 when the shape is implemented (K = 128, C = 256, D <= 4)
- *   gb_crop_bwd_blocks : nb = workgroups gb_crop_bwd_sparse launches for R seeds (its partial buffers' leading dimension)
- *   gb_crop_bwd_sparse : sdx (P,K) = S (every row written); tpart [nb][C][K] / rpart fp64 [nb][2C + K] = per-workgroup
- *                        partial sums of T and of [dbeta, dgamma, sx] (plain stores, no zeroing needed); red fp64
- *                        [2C + K] = their totals [dbeta (C), dgamma (C), sx = sum w X~ (K)].  dout / out / arg /
- *                        ystar: ((R*D), C)
- *   gb_crop_bwd_coef   : ef = [e(C), f(C)], vvec (K), mmat (K,K), dbeta / dgamma (C) fp32 from red; training = 0
- *                        (running statistics): e = f = 0
- *   gb_crop_bwd_dense  : dz (P,K): S on entry, dX~ on return; dstats / dbeta / dgamma: the BatchNorm-backward sums of
- *                        the layer that produced y2, as gb_gemm_dgrad delivers them
- *   gb_gemm_gram       : gmat (K,K) += sum_p row_w[p] f(x_p) f(x_p)^T, f = relu(a*x + b) (caller-zeroed)
- *   gb_crop_bwd_dw     : dw (C,K) = T - f sx^T - diag(e) W G, T = the nb partials of tpart summed in order; sx = red + 2C */
-int gb_crop_bwd_ok(int K, int C, int D);
-int gb_crop_bwd_blocks(long long R);
-int gb_crop_bwd_sparse(const float *dout, const float *out, const int32_t *arg, const float *ystar, const float *ab,
-                       const float *y2, const float *ab2, const float *w3, const float *row_w, const int64_t *off,
-                       const int32_t *cnt, long long R, int D, int K, int C, float *sdx, float *tpart, double *rpart,
-                       int nb, double *red, void *stream);
-int gb_crop_bwd_coef(const double *red, const float *ab, const float *w3, int K, int C, long long P_total, int training,
-                     float *ef, float *vvec, float *mmat, float *dbeta, float *dgamma, void *stream);
-int gb_crop_bwd_dense(const float *y2, const float *ab2, const float *mmat, const float *vvec, const float *row_w,
-                      float *dz, double *dstats, int stat_slots, long long P, int K, double *dstats_total, float *dbeta,
-                      float *dgamma, const GbGemmOpts *opts, void *stream);
-int gb_gemm_gram(const float *x, const float *x_aff, const float *row_w, float *gmat, long long P, int K,
-                 const GbGemmOpts *opts, void *stream);
-int gb_crop_bwd_dw(const float *tpart, int nb, const float *ef, const double *sx, const float *w3, const float *gmat,
-                   int K, int C, float *dw, void *stream);
+                  float *out, float *ystar, long long R, int D, int C, void *stream);
 /* gb_gemm_fwd whose BatchNorm sums weight row p by row_w16[p] (uint16 multiplicities; the array must extend,
  * zero-filled, to the next multiple of 32 rows).                                                              */
 int gb_gemm_fwd_w(const float *x, const float *w, const float *aff, const uint16_t *row_w16, float *y, double *stats,
                   int stat_slots, long long P, int K, int N, const GbBnFinalize *fin, const GbGemmOpts *opts,
                   void *stream);
 /* out ((R*D), C) [row r*D + d] = max over the rows of seed r with member bit d of relu(a*y + b); arg = absolute
- * row index of the maximum.  D in {1,2,4}; C % 4 == 0.                                                         */
+ * row index of the maximum.  D <= 4; C % 4 == 0.                                                               */
 int gb_affine_relu_maxpool_members(const float *y, const float *ab, const int32_t *row_mem, const int64_t *off,
                                    const int32_t *cnt, float *out, int32_t *arg, long long R, int D, int C,
                                    void *stream);
@@ -453,18 +416,12 @@ int gb_bn_bwd_apply_members_v(const float *dout, const float *out, const float *
                               const double *dstats, const float *row_w, const int32_t *row_mem, const int64_t *off,
                               const int32_t *cnt, long long R, int D, int C, long long P_total, int training, float *dy,
                               void *stream);
-/* gb_bn_bwd_apply (ReLU, no residual) for rows with multiplicities: dy = a*(dA*[z>0] - w*dbeta/P - xhat*w*dgamma/P). */
+/* gb_bn_bwd_apply (ReLU, no residual) for rows with multiplicities: dy = a*(dA*[z>0] - w*dbeta/P - xhat*w*dgamma/P).
+ * rows_dev (optional, device, 8-byte aligned): the actual row count when `rows` is the caller's capacity
+ * (GbGemmOpts.rows_dev has the story).                                                                            */
 int gb_bn_bwd_apply_w(const float *dout, const float *y, const float *ab, const double *dstats, const float *row_w,
-                      long long rows, long long P_total, int C, int training, float *dy, void *stream);
-/* The same two passes reading a y that lives in HBM as bf16 (y_bf16 = 1: the output of a gb_gemm_fwd / _fwd_gen3 /
- * _fwd_pool call with GB_STORE_Y_BF16; the pooled extrema of such a call are those of the rounded values, so the
- * by-value arg-max search of the members pass stays exact). */
-int gb_bn_bwd_apply_ws(const float *dout, const float *y, int y_bf16, const float *ab, const double *dstats,
-                       const float *row_w, long long rows, long long P_total, int C, int training, float *dy, void *stream);
-int gb_bn_bwd_apply_members_vs(const float *dout, const float *out, const float *ystar, const float *y, int y_bf16,
-                               const float *ab, const double *dstats, const float *row_w, const int32_t *row_mem,
-                               const int64_t *off, const int32_t *cnt, long long R, int D, int C, long long P_total,
-                               int training, float *dy, void *stream);
+                      long long rows, long long P_total, int C, int training, float *dy, const long long *rows_dev,
+                      void *stream);
 
 /* ---- LocalAggregation without the grouped tensor (csrc/local_agg.hip) ---------------------------------
  * Reference: TrainModel/drp.py:32-67 (LocalAggregation.forward :62 = QueryAndGroup -> [dp, fj] ->
@@ -565,8 +522,9 @@ int gb_gemm_wgrad_gen3(const float *dy, const float *x0, const float *w1, const 
 int gb_gemm_dgrad_first_gen3(const float *dy, const float *w, const float *ab_prev, const float *x_in,
                              const float *w_in, double *sums, int slots, long long P, int K, int N,
                              const GbGemmOpts *opts, void *stream);
-/* mom fp64 [12] (caller-zeroed) += [sum_p w_p x (3), sum_p w_p x x^T (3x3)] of x (P,3); w = row_w (P) or 1.   */
-int gb_moments3(const float *x, const float *row_w, long long P, double *mom, void *stream);
+/* mom fp64 [12] (caller-zeroed) += [sum_p w_p x (3), sum_p w_p x x^T (3x3)] of x (P,3); w = row_w (P) or 1.
+ * rows_dev (optional, device): the actual row count, <= P (see GbGemmOpts.rows_dev).                           */
+int gb_moments3(const float *x, const float *row_w, long long P, double *mom, const long long *rows_dev, void *stream);
 
 /* ---- the training loss (TrainModel/loss.py:44-179) ------------------------------------------------------------
  * gb_grasp_loss_fwd: every term of get_loss in three launches.  Tensors as the reference holds them: obj_score

@@ -143,50 +143,3 @@ def test_train_step_bf16_at_toy_size():
     l0 = float(ref.train_step(batch).detach())
     assert all(l == l for l in losses) and abs(losses[0] - l0) < 0.05 * abs(l0), (losses, l0)
     assert losses[0] != l0  # bf16 rounding was really applied inside the trainer's steps
-
-
-def test_crop_stack_bf16_storage_vs_fp32_storage(golden):
-    """bf16 precision with the crop stack's stored outputs (Y1 of gb_gemm_fwd_gen3, Y2 of gb_gemm_fwd_pool) in HBM as
-    bf16 (GbGemmOpts.storage; opt-in: fused_mlp.set_bf16_storage) against the same mode with fp32 storage: the stored tensors really are bf16,
-    the pooled output moves by bf16 rounding only, the by-value arg-max search of the backward still finds a row for every
-    (seed, crop, channel) - the pooled extrema are those of the ROUNDED values - and the gradients agree at the level
-    bf16 noise allows."""
-    from graspbalance_amd import fused_mlp, fused_ops
-    from graspbalance_amd.modules import GraspWidthGrouping
-    from graspbalance_amd.scene import make_batch
-    from tests.seeded import fill_by_key
-    xyz = torch.from_numpy(make_batch([0, 1], 8192)).to(DEV)
-    wg = fill_by_key(GraspWidthGrouping(64, 3, 0.06, -0.02, [0.01, 0.02, 0.03, 0.04]), seed=3).to(DEV).train()
-    seeds = xyz[:, :256].contiguous()
-    rot = torch.from_numpy(golden.load("g9_views")["rot"])[:256].unsqueeze(0).repeat(2, 1, 1, 1).contiguous().to(DEV)
-    idx = fused_ops.cylinder_query_multi(xyz, seeds, rot, [0.06], -0.02, [0.01, 0.02, 0.03, 0.04], 64)
-    rows = fused_mlp.cylinder_rows(idx, xyz, seeds, rot)[0]
-    res, seen = {}, {}
-
-    def observe(kind, **kw):
-        if kind == "stack":
-            seen.setdefault("arg", []).append(kw["arg"])
-    for store in (True, False):
-        prev = fused_mlp.set_bf16_storage(store)
-        fused_mlp.set_precision("bf16")
-        fused_mlp.routing_observer = observe if store else None
-        try:
-            m = copy.deepcopy(wg)
-            out = m(seeds, xyz, rot, rows=rows)
-            torch.manual_seed(5)
-            (out * torch.randn(out.shape, device=out.device)).sum().backward()
-            res[store] = (out.detach(), [p.grad.clone() for p in m.parameters()])
-        finally:
-            fused_mlp.routing_observer = None
-            fused_mlp.set_precision("f32")
-            fused_mlp.set_bf16_storage(prev)
-    a, b = res[True], res[False]
-    rel = _rel(a[0], b[0].double())
-    assert 1e-6 < rel < 1e-2, rel                  # it changed something, by rounding only
-    # every (seed, crop, channel) of a non-empty crop has a row whose stored y equals the pooled extreme
-    arg = seen["arg"][0]
-    assert arg.shape[0] == rows[1].R * rows[1].D and int((arg < 0).sum()) == 0
-    num = sum(float((x - y).norm()) ** 2 for x, y in zip(a[1], b[1])) ** 0.5
-    den = sum(float(y.norm()) ** 2 for y in b[1]) ** 0.5
-    print("bf16 storage vs fp32 storage: fwd %.2e, dparams %.2e" % (rel, num / den))
-    assert num / den < 0.2, num / den

@@ -46,17 +46,10 @@ def test_train_step_gradients_toy_size_frozen_routing():
     _check(fill_by_key(_tiny_net(), seed=9).to(DEV).train(), batch, "toy")
 
 
-@pytest.mark.parametrize("lowrank", [False, True])
-def test_train_step_gradients_full_size_frozen_routing(lowrank):
+def test_train_step_gradients_full_size_frozen_routing():
     """The real network (SA_SPECS of backbone.py, 300 views) on B = 2 clouds of 20 000 points: the shapes of BASELINE
-    configs[3] at half the batch (the fp64 plain composition of stage 2 holds (2,256,4096,64) doubles several times).
-    lowrank: the crop stacks' last layer never stored, its backward as low rank + sparse (opt-in path)."""
-    from graspbalance_amd import fused_mlp
+    configs[3] at half the batch (the fp64 plain composition of stage 2 holds (2,256,4096,64) doubles several times)."""
     from graspbalance_amd.graspbalance import GraspBalance
     from graspbalance_amd.synthetic import make_training_batch
     batch = make_training_batch([0, 1], num_point=20000, device=DEV)
-    prev = fused_mlp.set_crop_pool(True, lowrank)
-    try:
-        _check(fill_by_key(GraspBalance(), seed=11).to(DEV).train(), batch, "full size (lowrank=%s)" % lowrank)
-    finally:
-        fused_mlp.set_crop_pool(*prev)
+    _check(fill_by_key(GraspBalance(), seed=11).to(DEV).train(), batch, "full size")

@@ -347,7 +347,7 @@ def test_grasp_width_grouping_distinct_rows_equals_plain(golden):
     _run(fused, plain, call, tol_grad=2e-3, l2=True)  # torch's own fp32 BatchNorm backward over 131072 rows is the noise here
 
 
-def _crop_case(B=2, N=20000, seeds=1024, seed=3):
+def _crop_case(B=2, N=20000, seeds=1024, seed=3, static=False):
     """A GraspWidthGrouping head on scene clouds with the distinct rows of its four nested crops."""
     import numpy as np
     from graspbalance_amd import fused_mlp, fused_ops
@@ -364,61 +364,74 @@ def _crop_case(B=2, N=20000, seeds=1024, seed=3):
             layer.bn.bn.weight[::7] *= -1.0
     idx = fused_ops.cylinder_query_multi(xyz, centres, rot, [0.06], -0.02, [0.01, 0.02, 0.03, 0.04], 64)
     rows = fused_mlp.cylinder_rows(idx, xyz, centres, rot)[0]
+    if static:   # the same rows with their count on the device only: buffers of the capacity R * D * ns
+        assert fused_mlp.crop_static_ok(B * seeds * 4 * 64, [64, 128, 256], 4)
+        rows_s = fused_mlp.cylinder_rows(idx, xyz, centres, rot, static=True)[0]
+        assert rows_s[1].rows_dev is not None and int(rows_s[1].rows_dev) == rows[0].shape[0]
+        assert rows_s[0].shape[0] == B * seeds * 4 * 64
+        with torch.no_grad():   # whatever lies beyond the count must not matter
+            rows_s[0][rows[0].shape[0]:] = float("nan")
+            rows_s[1].w[rows[0].shape[0]:] = float("nan")
+        return wg, xyz, centres, rot, rows, rows_s
     return wg, xyz, centres, rot, rows
 
 
 @pytest.mark.parametrize("training", [True, False])
 def test_pooled_last_layer_forward_equals_stored_output_path(training):
-    """gb_gemm_fwd_pool + gb_pool_pairs (the crop stack's last layer never stored: extrema of sign(gamma)*y per (tile,
-    seed, crop) out of the GEMM epilogue) against the path that stores Y3 and pools it with
+    """gb_gemm_fwd_pool + gb_pool_pairs (the crop stack's last layer pooled out of the GEMM epilogue: extrema of
+    sign(gamma)*y per (tile, seed, crop)) against the path that stores Y3 and pools it with
     gb_affine_relu_maxpool_members: same pooled values to rounding (both form relu(a*y+b) from the same fp32 products,
-    but BatchNorm sums add in a different order), same running statistics."""
+    but BatchNorm sums add in a different order), same running statistics.  And the same stack on rows whose count the
+    host never sees (static rows: GbGemmOpts.rows_dev) gives the pooled path's results bit for bit."""
     import copy
     from graspbalance_amd import fused_mlp
-    wg, xyz, centres, rot, rows = _crop_case()
+    wg, xyz, centres, rot, rows, rows_s = _crop_case(static=True)
     assert rows[1].key is not None
     P = rows[0].shape[0]   # the shapes really take the pooled path (it needs the row-streaming kernel: P >= 16384)
-    assert fused_mlp._lib.lib().gb_gemm_uses_rs(P, 128, 256, 0, 3, 1) == 1 and fused_mlp._lib.lib().gb_crop_bwd_ok(128, 256, 4)
+    assert fused_mlp._lib.lib().gb_gemm_uses_rs(P, 128, 256, 0, 3, 1) == 1
     res = {}
-    for flag in (True, False):
+    for name, (flag, rw) in {"pooled": (True, rows), "stored": (False, rows), "static": (True, rows_s)}.items():
         m = copy.deepcopy(wg).train(training)
         prev = fused_mlp.set_crop_pool(flag)
         try:
             with torch.no_grad():
-                res[flag] = (m(centres, xyz, rot, rows=rows, channel_last=True), m.mlps.layer2.bn.bn.running_mean.clone(),
+                res[name] = (m(centres, xyz, rot, rows=rw, channel_last=True), m.mlps.layer2.bn.bn.running_mean.clone(),
                              m.mlps.layer2.bn.bn.running_var.clone())
         finally:
-            fused_mlp.set_crop_pool(*prev)
-    a, b = res[True], res[False]
+            fused_mlp.set_crop_pool(prev)
+    a, b, c = res["pooled"], res["stored"], res["static"]
     assert a[0].shape == b[0].shape == (2 * 1024 * 4, 256)
     scale = float(b[0].abs().max())
     assert float((a[0] - b[0]).abs().max()) <= 2e-6 * scale, float((a[0] - b[0]).abs().max()) / scale
     assert float(a[0].min()) >= 0.0 and float((a[0] > 0).float().mean()) > 0.3
     assert torch.allclose(a[1], b[1], rtol=1e-6, atol=1e-7) and torch.allclose(a[2], b[2], rtol=1e-5, atol=1e-8)
+    # BatchNorm sums are fp64 atomics (order-free to ~1e-16), everything else is the same arithmetic on the same rows
+    assert float((c[0] - a[0]).abs().max()) <= 1e-6 * scale and bool(torch.isfinite(c[0]).all())
+    assert torch.allclose(c[1], a[1], rtol=1e-6, atol=1e-7) and torch.allclose(c[2], a[2], rtol=1e-6, atol=1e-9)
 
 
 @pytest.mark.parametrize("training", [True, False])
-def test_pooled_last_layer_low_rank_backward_equals_dense_backward(training):
-    """Backward of the never-stored last layer as low rank + sparse (gb_crop_bwd_sparse / _coef / _dense / gb_gemm_gram
-    / gb_crop_bwd_dw: a K x K product and a K x K Gram matrix instead of the two dense C x K products) against the dense
-    backward of the stored-output path (gb_bn_bwd_apply_members + dgrad + wgrad): every parameter gradient of the
-    three layers.  (The fp64 statement about both is tests/test_frozen_routing_gpu.py.)"""
+def test_pooled_last_layer_backward_equals_stored_output_backward(training):
+    """Backward of the pooled last layer (arg-max rows found by value: gb_bn_bwd_apply_members_v) - on exactly sized rows
+    and on rows whose count lives on the device - against the dense backward of the stored-output path
+    (gb_bn_bwd_apply_members + dgrad + wgrad): every parameter gradient of the three layers.  (The fp64 statement about
+    them is tests/test_frozen_routing_gpu.py.)"""
     import copy
     from graspbalance_amd import fused_mlp
-    wg, xyz, centres, rot, rows = _crop_case()
+    wg, xyz, centres, rot, rows, rows_s = _crop_case(static=True)
     torch.manual_seed(8)
     wout = torch.randn(2 * 1024 * 4, 256, device=DEV)
     res = {}
-    for name, (pool, lowrank) in {"lowrank": (True, True), "pooled": (True, False), "stored": (False, False)}.items():
+    for name, (pool, rw) in {"pooled": (True, rows), "static": (True, rows_s), "stored": (False, rows)}.items():
         m = copy.deepcopy(wg).train(training)
-        prev = fused_mlp.set_crop_pool(pool, lowrank)
+        prev = fused_mlp.set_crop_pool(pool)
         try:
-            out = m(centres, xyz, rot, rows=rows, channel_last=True)
+            out = m(centres, xyz, rot, rows=rw, channel_last=True)
             (out * wout).sum().backward()
         finally:
-            fused_mlp.set_crop_pool(*prev)
+            fused_mlp.set_crop_pool(prev)
         res[name] = {k: p.grad.clone() for k, p in m.named_parameters()}
-    for name in ("lowrank", "pooled"):   # pooled: the default (pooling out of the GEMM epilogue, dense backward)
+    for name in ("pooled", "static"):   # pooled: the default (pooling out of the GEMM epilogue, dense backward)
         errs = {k: float((res[name][k] - res["stored"][k]).norm() / (res["stored"][k].norm() + 1e-30)) for k in res[name]}
         print(name, {k: "%.1e" % v for k, v in errs.items()})
         assert len(errs) == 9 and max(errs.values()) < 5e-5, (name, errs)

@@ -1,5 +1,7 @@
 """GPU: the hand-written fp32 MFMA GEMMs (csrc/gemm_cl.hip) against fp64 torch references.
 fp32 MFMA is an exact k-ordered fmaf chain, so the error bound is the usual fp32 dot-product bound."""
+import ctypes
+
 import pytest
 import torch
 
@@ -257,42 +259,53 @@ def test_fused_nodes_keep_their_forward_precision_in_backward():
     assert float((a[1] - f32[1]).norm() / f32[1].norm()) > 1e-4     # and it is not the fp32 result
 
 
-@pytest.mark.parametrize("P,D,with_rows,sizes", [
-    (16384 + 17, 4, 0, "mixed"),      # ragged last tile, seeds of 1 .. 256 rows
-    (20000, 4, 1, "mixed"),
-    (16400, 2, 0, "tiny"),            # up to 32 seeds inside one 32-row tile
-    (33000, 1, 1, "big"),             # every seed spans several tiles
-    (16384, 3, 0, "mixed"),
+@pytest.mark.parametrize("P,D,sizes,cap_extra", [
+    (20000, 4, "mixed", 0),
+    (16400, 2, "tiny", 0),            # up to 32 seeds inside one 32-row tile
+    (33000, 1, "big", 0),             # every seed spans several tiles
+    (16384, 3, "mixed", 0),
+    (20000, 4, "mixed", 13000),       # the row count lives on the device (GbGemmOpts.rows_dev); buffers have capacity
+    (17000, 4, "empty", 4000),        # ... and the first, the last and some inner seeds have no rows at all
+    (16900, 2, "empty", 0),
 ])
-def test_pooled_gemm_epilogue_against_torch(P, D, with_rows, sizes):
+def test_pooled_gemm_epilogue_against_torch(P, D, sizes, cap_extra):
     """gb_gemm_fwd_pool + gb_pool_pairs on synthetic row sets (random seed sizes, random member bits, some crops of a
-    seed empty, negative BatchNorm weights, a ragged last tile) against plain torch: Y = relu(a*x+b) W^T, weighted
-    BatchNorm sums, per-(seed, crop, column) max of relu(a3*y+b3) over the member rows, y* and - with_rows - the arg
-    row (the lowest row among equal extremes)."""
-    import ctypes
+    seed empty, seeds without rows, negative BatchNorm weights, a ragged last tile) against plain torch: Y =
+    relu(a*x+b) W^T, weighted BatchNorm sums, per-(seed, crop, column) max of relu(a3*y+b3) over the member rows and
+    y*.  cap_extra > 0: the buffers hold P + cap_extra rows (garbage beyond P) and the kernels take the row count from
+    the device - results identical, nothing beyond row P written."""
     L = _lib()
     lib = L.lib()
     K, N = 128, 256
     g = torch.Generator().manual_seed(P + D)
-    lim = {"mixed": 256, "tiny": 3, "big": 200}[sizes]
-    lo = {"mixed": 1, "tiny": 1, "big": 90}[sizes]
+    lim = {"mixed": 256, "tiny": 3, "big": 200, "empty": 120}[sizes]
+    lo = {"mixed": 1, "tiny": 1, "big": 90, "empty": 1}[sizes]
     cnt = []
     while sum(cnt) < P:
         cnt.append(int(torch.randint(lo, lim + 1, (1,), generator=g)))
     cnt[-1] -= sum(cnt) - P
     if cnt[-1] == 0:
         cnt.pop()
+    if sizes == "empty":   # seeds without rows: the first, the last, and every 7th in between
+        full, cnt = cnt, [0]
+        for i, c in enumerate(full):
+            cnt.append(c)
+            if i % 7 == 3:
+                cnt.append(0)
+        cnt.append(0)
     R = len(cnt)
     cnt_t = torch.tensor(cnt, dtype=torch.int32)
     off = torch.cumsum(cnt_t.long(), 0) - cnt_t.long()
     seed = torch.repeat_interleave(torch.arange(R), cnt_t.long())
     mem = torch.randint(1, 1 << D, (P,), generator=g, dtype=torch.int32)
-    mem[off] |= 1                                              # crop 0 always has a member; other crops may be empty
+    mem[off[cnt_t > 0]] |= 1                                   # crop 0 of a seed with rows has a member; other crops may be empty
     mult = torch.randint(1, 257, (P,), generator=g, dtype=torch.int32)
-    pad = (P + 31) // 32 * 32
-    key = torch.zeros(pad, dtype=torch.int32)
+    cap = (P + cap_extra + 31) // 32 * 32
+    key = torch.full((cap,), 0x7fffffff, dtype=torch.int32)    # garbage beyond the 32-row tile of the last row
+    key[:(P + 31) // 32 * 32] = 0
     key[:P] = (seed.int() << 13) | (mult << 4) | mem
-    X = torch.randn(P, K, generator=g)
+    X = torch.full((cap if cap_extra else P, K), float("nan"))
+    X[:P] = torch.randn(P, K, generator=g)
     W = torch.randn(N, K, generator=g) / K ** 0.5
     aff = torch.cat([torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.3])
     gamma = torch.randn(N, generator=g)
@@ -300,18 +313,26 @@ def test_pooled_gemm_epilogue_against_torch(P, D, with_rows, sizes):
     ab = torch.cat([gamma * (torch.rand(N, generator=g) + 0.5), torch.randn(N, generator=g) * 0.2, torch.zeros(2 * N)])
     dev = lambda t: t.to(DEV).contiguous()
     Xd, Wd, affd, keyd, gammad, abd, offd, cntd = map(dev, (X, W, aff, key, gamma, ab, off, cnt_t))
-    tiles = (P + 31) // 32
-    pairs = torch.full(((tiles + R) * D * N, 2 if with_rows else 1), float("nan"), device=DEV)
-    Y = torch.empty(P, N, device=DEV)
+    Pc = X.shape[0]                                            # the P argument: the capacity when the count is on the device
+    rows_dev = torch.tensor([P], dtype=torch.int64, device=DEV) if cap_extra else None
+    ws = torch.empty(L.GEMM_SCRATCH_BYTES, dtype=torch.uint8, device=DEV)
+    opts = ctypes.pointer(L.GemmOpts(L.PREC_F32, 0, ws.data_ptr(), ws.numel(), L.ptr(rows_dev)))
+    tiles = (Pc + 31) // 32
+    pairs = torch.full(((tiles + R) * D * N,), float("nan"), device=DEV)
+    Y = torch.full((Pc, N), 12345.0, device=DEV)
     stats = torch.zeros(2 * N, dtype=torch.float64, device=DEV)
-    L.check(lib.gb_gemm_fwd_pool(L.ptr(Xd), L.ptr(Wd), L.ptr(affd), L.ptr(keyd), L.ptr(gammad), L.ptr(pairs), with_rows,
-                                 L.ptr(Y), L.ptr(stats), 1, P, K, N, D, None, None, None), "gb_gemm_fwd_pool")
+    # too small a pairs buffer is refused, not overrun
+    assert lib.gb_gemm_fwd_pool(L.ptr(Xd), L.ptr(Wd), L.ptr(affd), L.ptr(keyd), L.ptr(gammad), L.ptr(pairs),
+                                pairs.numel() - 1, R, L.ptr(Y), L.ptr(stats), 1, Pc, K, N, D, None, opts, None) == -3
+    L.check(lib.gb_gemm_fwd_pool(L.ptr(Xd), L.ptr(Wd), L.ptr(affd), L.ptr(keyd), L.ptr(gammad), L.ptr(pairs), pairs.numel(),
+                                 R, L.ptr(Y), L.ptr(stats), 1, Pc, K, N, D, None, opts, None), "gb_gemm_fwd_pool")
     out = torch.empty(R * D, N, device=DEV)
-    arg = torch.empty(R * D, N, dtype=torch.int32, device=DEV) if with_rows else None
     ystar = torch.empty(R * D, N, device=DEV)
-    L.check(lib.gb_pool_pairs(L.ptr(pairs), L.ptr(offd), L.ptr(cntd), L.ptr(abd), L.ptr(gammad), L.ptr(out), L.ptr(arg),
+    L.check(lib.gb_pool_pairs(L.ptr(pairs), L.ptr(offd), L.ptr(cntd), L.ptr(abd), L.ptr(gammad), L.ptr(out),
                               L.ptr(ystar), R, D, N, None), "gb_pool_pairs")
     torch.cuda.synchronize()
+    assert bool((Y[P:] == 12345.0).all()), "rows beyond the device-side count were written"
+    X, Y = X[:P], Y[:P]
     A = torch.relu(aff[:K] * X + aff[K:]).double()
     Yref = A @ W.double().t()
     scale = float(Yref.abs().max())
@@ -333,22 +354,15 @@ def test_pooled_gemm_epilogue_against_torch(P, D, with_rows, sizes):
         got_y, got_out = ystar.cpu().view(R, D, N)[:, d], out.cpu().view(R, D, N)[:, d]
         assert torch.equal(got_y, want_y), ("ystar", d)
         assert torch.equal(got_out, want_out), ("out", d)
-        if with_rows:
-            rowidx = torch.arange(P).unsqueeze(1).expand(P, N)
-            hit = member.unsqueeze(1) & (Yg * sg == best[seed])
-            first = torch.full((R, N), P, dtype=torch.int64).scatter_reduce_(
-                0, seed.unsqueeze(1).expand(P, N), torch.where(hit, rowidx, torch.full_like(rowidx, P)), reduce="amin")
-            want_arg = torch.where(has, first, off.unsqueeze(1).expand(R, N))
-            assert torch.equal(arg.cpu().view(R, D, N)[:, d].long(), want_arg), ("arg", d)
     assert int((~torch.isfinite(out)).sum()) == 0
-    if not with_rows:
-        # forward-only form (inference): values only and no stored output - the same pooled values, bit for bit
-        pairs2 = torch.full_like(pairs, float("nan"))
-        stats2 = torch.zeros_like(stats)
-        L.check(lib.gb_gemm_fwd_pool(L.ptr(Xd), L.ptr(Wd), L.ptr(affd), L.ptr(keyd), L.ptr(gammad), L.ptr(pairs2), 0, None,
-                                     L.ptr(stats2), 1, P, K, N, D, None, None, None), "gb_gemm_fwd_pool (no y)")
-        out2, ystar2 = torch.empty_like(out), torch.empty_like(ystar)
-        L.check(lib.gb_pool_pairs(L.ptr(pairs2), L.ptr(offd), L.ptr(cntd), L.ptr(abd), L.ptr(gammad), L.ptr(out2), None,
-                                  L.ptr(ystar2), R, D, N, None), "gb_pool_pairs")
-        torch.cuda.synchronize()
-        assert torch.equal(out2, out) and torch.equal(ystar2, ystar) and torch.equal(stats2, stats)
+    # forward-only form (inference): no stored output - the same pooled values, bit for bit
+    pairs2 = torch.full_like(pairs, float("nan"))
+    stats2 = torch.zeros_like(stats)
+    L.check(lib.gb_gemm_fwd_pool(L.ptr(Xd), L.ptr(Wd), L.ptr(affd), L.ptr(keyd), L.ptr(gammad), L.ptr(pairs2),
+                                 pairs2.numel(), R, None, L.ptr(stats2), 1, Pc, K, N, D, None, opts, None),
+            "gb_gemm_fwd_pool (no y)")
+    out2, ystar2 = torch.empty_like(out), torch.empty_like(ystar)
+    L.check(lib.gb_pool_pairs(L.ptr(pairs2), L.ptr(offd), L.ptr(cntd), L.ptr(abd), L.ptr(gammad), L.ptr(out2),
+                              L.ptr(ystar2), R, D, N, None), "gb_pool_pairs")
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out) and torch.equal(ystar2, ystar) and torch.equal(stats2, stats)

@@ -530,42 +530,3 @@ def test_fps_cell_order_is_a_coherent_permutation(orc):
                                             _lib.ptr(scratch), None), "gb_fps_pruned")
         torch.cuda.synchronize()
         assert torch.equal(idx.cpu(), orc.furthest_point_sampling(xyz, m, flags))
-
-
-def test_fps_multi_pick_is_the_same_sequence(orc):
-    """fps_multi_kernel (GB_FPS_MULTI_PICK: up to four samples per block-wide selection, accepted only while provably
-    the reference's next picks) against the oracle: scenes with exact duplicates, a lattice full of exact ties, every
-    tie rule, with and without the near-origin skip, and a running-temp continuation."""
-    from graspbalance_amd import _lib
-    from graspbalance_amd.scene import make_batch
-    L = _lib.lib()
-    g = torch.Generator().manual_seed(7)
-    lattice = torch.randint(0, 24, (2, 9000, 3), generator=g).float() * 0.03125 + 0.25
-    clouds = [(torch.from_numpy(make_batch([0, 1, 2], 20000)), 2048), (torch.from_numpy(make_batch([5], 8192)), 1500),
-              (lattice, 700), (torch.rand(2, 12000, 3, generator=g) * 0.2 - 0.1, 600)]
-    for xyz, m in clouds:
-        B, N, _ = xyz.shape
-        dev = xyz.to(DEV)
-        perm = torch.empty(B, N, dtype=torch.int32, device=DEV)
-        _lib.check(L.gb_fps_cell_order(_lib.ptr(dev), _lib.ptr(perm), B, N, None), "order")
-        for tie, otie in ((_lib.FPS_TIE_LOWEST, orc.FPS_TIE_LOWEST), (_lib.FPS_TIE_TREE512, orc.FPS_TIE_TREE512),
-                          (_lib.FPS_TIE_TREE1024, orc.FPS_TIE_TREE1024)):
-            for skip in (0, _lib.FPS_SKIP_NEAR_ORIGIN):
-                idx = torch.zeros(B, m, dtype=torch.int32, device=DEV)
-                _lib.check(L.gb_fps_pruned(_lib.ptr(dev), _lib.ptr(perm), None, _lib.ptr(idx), B, N, m,
-                                           tie | skip | _lib.FPS_MULTI_PICK, None, None), "fps")
-                want = orc.furthest_point_sampling(xyz, m, otie | (orc.FPS_SKIP_NEAR_ORIGIN if skip else 0))
-                assert torch.equal(idx.cpu(), want), (N, m, tie, skip)
-    # continuation from a running temp (the caller's min-distances): two halves == one run
-    xyz, m = clouds[0]
-    B, N, _ = xyz.shape
-    dev = xyz.to(DEV)
-    perm = torch.empty(B, N, dtype=torch.int32, device=DEV)
-    _lib.check(L.gb_fps_cell_order(_lib.ptr(dev), _lib.ptr(perm), B, N, None), "order")
-    temp = torch.full((B, N), 1e10, device=DEV)
-    idx = torch.zeros(B, 300, dtype=torch.int32, device=DEV)
-    _lib.check(L.gb_fps_pruned(_lib.ptr(dev), _lib.ptr(perm), _lib.ptr(temp), _lib.ptr(idx), B, N, 300,
-                               _lib.FPS_TIE_TREE512 | _lib.FPS_MULTI_PICK, None, None), "fps")
-    ref_temp = torch.full((B, N), 1e10)
-    want = orc.furthest_point_sampling(xyz, 300, orc.FPS_TIE_TREE512, temp=ref_temp)
-    assert torch.equal(idx.cpu(), want) and torch.equal(temp.cpu(), ref_temp)

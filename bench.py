@@ -9,6 +9,12 @@ the metric "fwd+bwd ... 1/2/4/8 MI355X" is quoted on; it fits one GPU).
 
 One JSON line on rank 0.  A step = GraspBalance forward (training mode, label matching included) ->
 loss -> backward -> flat-bucket RCCL all-reduce -> Adam -> LR step, on a batch already resident in HBM.
+
+Execution: the step is captured once in a HIP graph (train.Trainer(graph=True)) and the K timed steps replay it - one
+launch call per step instead of ~1000 (GB_GRAPH=0: every step enqueued launch by launch, as in rounds 1-3).  A replayed
+graph cannot be bracketed launch by launch, so the per-kernel roofline figures come from a few EAGER steps of the same
+trainer right after the timed region (the same kernels on the same shapes: `roofline.measured_on` says so); the
+rocprofv3 kernel trace of this command (profiles/) sees the replayed launches themselves.
 """
 import argparse
 import json
@@ -35,6 +41,52 @@ VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 # lane-instructions per scanned (centre, candidate) pair, from the kernels' arithmetic:
 BALL_OPS_PER_PAIR = 9        # 3 sub, 3 mul, 2 add, 1 compare
 CYL16_OPS_PER_PAIR = 30      # 3 sub, 9 mul + 6 add (rotate), 2 mul + 1 add (radial), 4 + 4 + 1 compares (4 radii x 4 hmax, hmin)
+
+
+def _pin_rank_to_cores(local_rank, local_world):
+    """Give this rank its own host cores BEFORE anything initialises the GPU: the cores of its GPU's NUMA node (sysfs:
+    amdgpu PCI functions in bus order = HIP's device order on this image) shared evenly among the ranks on that node, or -
+    where sysfs does not say - an even slice of the cores this process may use.  Eight Python ranks left to the
+    scheduler migrate across sockets and contend for the cores that enqueue their steps.  Returns a short description
+    for the JSON line (never raises: pinning is an optimisation)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        if local_world <= 1 or len(allowed) < 2 * local_world:
+            return {"cores": len(allowed), "numa_aware": False, "pinned": False}
+        nodes = []
+        base = "/sys/bus/pci/drivers/amdgpu"
+        if os.path.isdir(base):
+            for dev in sorted(d for d in os.listdir(base) if ":" in d):
+                try:
+                    with open(os.path.join(base, dev, "numa_node")) as f:
+                        nodes.append(int(f.read().strip()))
+                except (OSError, ValueError):
+                    nodes.append(-1)
+        mine = None
+        if len(nodes) >= local_world and nodes[local_rank] >= 0:
+            node = nodes[local_rank]
+            try:
+                with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+                    cpus = set()
+                    for part in f.read().strip().split(","):
+                        lo, _, hi = part.partition("-")
+                        cpus.update(range(int(lo), int(hi or lo) + 1))
+                cpus = sorted(cpus & set(allowed))
+                peers = [r for r in range(local_world) if nodes[r] == node]
+                share = len(cpus) // len(peers)
+                if share >= 1:
+                    k = peers.index(local_rank)
+                    mine = cpus[k * share:(k + 1) * share]
+            except (OSError, ValueError):
+                mine = None
+        numa = mine is not None
+        if mine is None:
+            share = len(allowed) // local_world
+            mine = allowed[local_rank * share:(local_rank + 1) * share]
+        os.sched_setaffinity(0, mine)
+        return {"cores": len(mine), "numa_aware": numa, "pinned": True}
+    except Exception as e:  # noqa: BLE001
+        return {"cores": None, "numa_aware": False, "pinned": False, "error": repr(e)[:80]}
 
 
 def _spawn_ranks(n, argv):
@@ -102,7 +154,7 @@ def cpu_baseline(num_threads, device, repeats=5):
              (subsample, "pointnet2_cuda", subsample.pointnet2_cuda),
              (upsampling, "pointnet2_cuda", upsampling.pointnet2_cuda), (knn_modules, "knn", knn_modules.knn)]
     torch.set_num_threads(num_threads)
-    gpu_trainer = Trainer(device)
+    gpu_trainer = Trainer(device, graph=False)   # one step: nothing to replay
     probe = make_training_batch([0], NUM_POINT, device=device)['point_clouds']
     keys = ('sa1_features', 'fp2_features', 'objectness_score', 'view_score', 'grasp_score_pred', 'grasp_width_pred')
 
@@ -339,6 +391,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d was launched with WORLD_SIZE=%d" % (args.gpus, world))
+    affinity = _pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))   # before any GPU call
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible)")
     # GB_REHEARSE_ON_ONE_GPU=1 (not a measurement: the line says so): every rank uses device 0 and the collectives run
@@ -369,6 +422,8 @@ def main():
     trainer = Trainer(device, distributed=use_dist, time_collectives=use_dist, mlp_precision=prec)
     seeds = [1000 * rank + i for i in range(BATCH_PER_GPU)]
     batch = make_training_batch(seeds, NUM_POINT, device=device)
+    # graph execution: the trainer's static input buffers ARE the resident batch (no staging copy in the steps)
+    batch = trainer.resident(batch)
 
     def barrier():
         torch.cuda.synchronize()
@@ -378,39 +433,45 @@ def main():
 
     # the loop holds its next batch (here: the same resident batch), so every step announces it: the first-level
     # FPS of step t+1 runs on a side stream under step t - once per step, inside the timed region, never cached
-    for _ in range(args.warmup):
+    # (graph execution: the capture happens in the first warm-up step)
+    for _ in range(max(args.warmup, 1 if trainer.graph else 0)):
         trainer.train_step(batch, next_batch=batch)
     barrier()
     if use_dist:
         trainer.grads.exposed_ms()  # drop the warm-up samples
-    # ~250 timed launches per step, two events each: created before the timed region, recorded inside it
+    from graspbalance_amd import fused_mlp as _fm
+    _fm.SYNC_WAIT[0] = 0.0
+    replays0 = trainer.graph_replays
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = trainer.train_step(batch, next_batch=batch)
+    # how long the host WORKED to enqueue the K steps (a step waits for the GPU nowhere any more: the crop row counts
+    # stay on the device).  Well below `elapsed`: the step is GPU-bound.  Close to it: the step is host-bound and the
+    # line says more about the box's CPU (and its other tenants) than about the kernels.
+    host_enqueue = time.perf_counter() - t0 - _fm.SYNC_WAIT[0]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    assert bool(torch.isfinite(loss)), "training diverged"
+    assert not trainer.graph or trainer.graph_replays - replays0 == args.steps, "a timed step did not replay the graph"
+    # ---- per-kernel durations: the same step enqueued launch by launch, every launch of interest bracketed with HIP
+    # events on its stream (the brackets cost ~2 us per launch, and a replayed graph cannot be bracketed at all): AFTER the
+    # timed region, same trainer, same resident batch, same kernels
     gemm_names = ["gb_gemm_fwd", "gb_gemm_fwd_w", "gb_gemm_fwd_pool", "gb_gemm_fwd_gen3", "gb_gemm_dgrad", "gb_gemm_dgrad_first",
                   "gb_gemm_dgrad_first_gen3", "gb_gemm_wgrad", "gb_gemm_wgrad_gen3"]
+    sampled = max(2, min(5, args.steps // 4))
     timer = _lib.KernelTimer(gemm_names + ["gb_fps", "gb_ball_query", "gb_cylinder_query_multi"],
-                             reserve=min(2 * 300 * (args.steps // 4 + 2), 20000))
+                             reserve=min(2 * 300 * (sampled + 2), 20000))
+    trainer.train_step_eager(batch, next_batch=batch)   # (announces the next sampling for the first bracketed step)
     barrier()
-    # the HIP-event brackets cost the stream ~2 us per launch (measured: 1.2 ms per step with all ~270 launches of
-    # every step bracketed), so only every 4th timed step is bracketed (at least two): the launch durations are still
-    # taken live inside the timed region, on the launch stream, and the headline is not slowed by its own instrumentation
-    sample_every = 4 if args.steps >= 8 else max(1, args.steps // 2)
-    sampled = 0
     with timer as kt:
-        from graspbalance_amd import fused_mlp as _fm
-        _fm.SYNC_WAIT[0] = 0.0
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            on = i % sample_every == 0
-            kt.sample(on)
-            sampled += on
-            loss = trainer.train_step(batch, next_batch=batch)
         kt.sample(True)
-        # how long the host WORKED to enqueue the K steps: each step waits once for the GPU (the crop row counts), and that
-        # wait is taken out.  Well below `elapsed`: the step is GPU-bound.  Close to it: the step is host-bound and the
-        # line says more about the box's CPU (and its other tenants) than about the kernels.
-        host_enqueue = time.perf_counter() - t0 - _fm.SYNC_WAIT[0]   # minus the time spent waiting for the GPU in them
-        barrier()
-        elapsed = time.perf_counter() - t0
-    assert bool(torch.isfinite(loss)), "training diverged"
+        t1 = time.perf_counter()
+        for _ in range(sampled):
+            trainer.train_step_eager(batch, next_batch=batch)
+        eager_host = time.perf_counter() - t1
+        torch.cuda.synchronize()
+        eager_ms = (time.perf_counter() - t1) / sampled * 1e3
     # the same step with the first-level FPS inline (no next batch announced): what a loop that cannot look ahead gets -
     # and the like-for-like figure against round 1's line; outside the timed region, rank-local
     no_prefetch_ms = None
@@ -423,12 +484,13 @@ def main():
             trainer.train_step(batch)
         torch.cuda.synchronize()
         no_prefetch_ms = round((time.perf_counter() - t1) / k2 * 1e3, 3)
-    t = torch.tensor([elapsed, 1.0], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed, 1.0, host_enqueue], dtype=torch.float64, device=device)
     ranks_seen = 1
     allreduce = None
     if use_dist:
         dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
-        dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
+        dist.all_reduce(t[1:2], op=dist.ReduceOp.SUM)
+        dist.all_reduce(t[2:], op=dist.ReduceOp.MAX)     # the slowest rank's host work: a host-bound rank shows here
         ranks_seen = int(t[1].item())
         # exposed: what the compute stream waited for inside the timed steps; standalone: the same collectives with
         # nothing to hide under (after the timed region)
@@ -443,6 +505,7 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         allreduce["replicas_in_sync"] = bool(torch.equal(lo, hi))
     elapsed = float(t[0].item())
+    host_enqueue_max = float(t[2].item())
 
     if rank == 0:
         clouds = world * BATCH_PER_GPU * args.steps
@@ -581,7 +644,18 @@ def main():
             "ranks_seen": ranks_seen,
             "prefetch_sampling": trainer.prefetch is not None,
             "ms_per_step_no_prefetch": no_prefetch_ms, "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
+            "host_enqueue_ms_per_step_max_over_ranks": round(host_enqueue_max / args.steps * 1e3, 3),
+            "execution": ("hip-graph replay: the step captured once (warm-up), %d replays timed, %d graph(s) captured"
+                          % (args.steps, len(trainer._graphs))) if trainer.graph
+                         else "eager: every launch of every step enqueued by the host",
+            "ms_per_step_eager": round(eager_ms, 3), "host_enqueue_ms_per_step_eager": round(eager_host / sampled * 1e3, 3),
+            "cpu_affinity": affinity,
         }
+        for r in (out["roofline"], out["roofline_gemm2"], out["roofline_fps"], out["roofline_ball"], out["roofline_fps_ball"],
+                  out["roofline_cyl"]):
+            if r:
+                r["measured_on"] = ("%d eager steps of the same trainer right after the timed region (HIP events around every "
+                                    "launch; the timed steps replay a graph)" % sampled)
         if allreduce:
             out["allreduce_ms"] = round(allreduce["standalone_ms"], 4)
             out["allreduce_exposed_ms"] = round(allreduce["exposed_ms"], 4)

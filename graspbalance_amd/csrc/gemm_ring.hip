@@ -1,0 +1,430 @@
+// fp32 MFMA GEMM for the FEW-ROW products of the channel-last SharedMLP path (gfx950, v_mfma_f32_32x32x2_f32): the
+// C -> 4C -> C pointwise pairs of the 15 InvResMLP blocks on 1 024 .. 8 192 rows, the feature-propagation stacks and the
+// Conv1d grasp heads on 4 096 / 16 384 rows (reference drp.py:97-106, pointnet2_modules.py:402-435, modules.py:49-175) -
+// forward, dgrad and wgrad.  These launches have 64 .. 1 024 output tiles and 4 .. 32 reduction steps each: what bounds
+// them is not the matrix cores but how long a workgroup waits for its operands (csrc/gemm_cl.hip fetches one 16-deep step
+// ahead through registers: 512 MFMA cycles of cover against 500 - 900 cycles of L2 / HBM latency, waves parked at
+// s_waitcnt 30 - 59 % of the time - profiles/r03_fewrow_sq_counters.txt).
+//
+// Structure: an LDS ring of S = 4 stages filled by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write), three
+// 32-deep reduction steps in flight, ONE raw s_barrier per step.
+//   step t:  s_waitcnt vmcnt(pieces of the stages after t)   - the issuing wave's share of stage t has landed
+//            s_barrier                                       - every wave's share has; and everybody is done reading stage t-1
+//            issue the DMA of stage t+3 into the slot of stage t-1
+//            ds_read the fragments of stage t, MFMA
+// The prologue issues three stages (and the BatchNorm table of the operand prologue) before the first wait, so the cold
+// first loads of a short-lived workgroup overlap each other instead of the first steps.
+//
+// LDS images (an LDS-DMA instruction writes 64 x 16 bytes lane-linearly: the image is shaped by choosing each lane's
+// SOURCE address):
+//   reduction-contiguous operand (X (P,K) of forward, dY (P,N) of dgrad, W (N,K) of forward): [row][8 chunks of 4 floats],
+//     chunk c of row r at position c ^ ((r >> 1) & 7): a lane's ds_read_b128 of "its" chunk is bank-conflict free.  Lane
+//     (m, h) of a 32-row block reads chunks 2c' + h, c' = 0..3, and feeds element e of chunk c' to MFMA slice 4c' + e: the
+//     reduction index that lane half h contributes to slice (c', e) is 4 (2c' + h) + e - any bijection is legal as long as
+//     both operands use it.
+//   row-contiguous operand (W (N,K) of dgrad: element (k, n) at w[n K + k]; dY and X of wgrad): [reduction index][cols] as
+//     in memory; lane (j, h) reads one float of row "the reduction index of its slice": 32 consecutive floats per half wave.
+// Operand prologue relu(a x + b) (the previous layer's BatchNorm + ReLU) is applied to the fragments after the ds_read;
+// the (a, b) table travels through LDS-DMA as well (an ordinary load in flight would make the compiler drain the ring).
+// Epilogues as csrc/gemm_cl.hip: store, store + BatchNorm column sums (fp64 atomics over slot rows), store + the
+// BatchNorm-backward sums of the previous layer, fp32 atomics (split-K wgrad), partial products of a split reduction.
+//
+// Eligibility (ring_gemm_try returns false otherwise and the caller uses csrc/gemm_cl.hip): fp32 precision, reduction
+// length a multiple of 32, leading dimensions and tile-row counts multiples of 4, 16-byte aligned operands, no row weights.
+#include "gb_common.h"
+#include "gemm_ring.h"
+
+namespace gb {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int RG_TPB = 256, RG_BK = 32, RG_STAGES = 4;
+
+struct RingOp {
+  const float *src;
+  long long rows;    // valid tile-row indices [0, rows)
+  long long ld;      // leading dimension in floats (of the row index for RK_KC, of the reduction index for RK_RC)
+  const float *aff;  // optional: RK_KC [a(red), b(red)] by reduction index ; RK_RC [a(rows), b(rows)] by tile-row index
+};
+
+struct RingArgs {
+  RingOp a, b;
+  float *d;
+  long long ldd;
+  long long red;      // reduction length (multiple of 32)
+  long long kchunk;   // reduction indices per blockIdx.y (multiple of 32)
+  long long dchunk;   // != 0: chunk blockIdx.y stores its partial product at d + blockIdx.y * dchunk
+  double *stats;      // RG_STATS / RG_BNBWD: fp64 [stat_slots][2 * b.rows]
+  int stat_slots;
+  const float *epi_y;   // RG_BNBWD: (a.rows, b.rows) pitch ldd, pre-BatchNorm output of the layer D is the gradient of
+  const float *epi_ab;  // RG_BNBWD: [a, b, mean, rstd](b.rows)
+  int tiles_n;
+};
+
+#define RG_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+
+template <int N>
+__device__ __forceinline__ void rg_wait_vm() {
+  if constexpr (N == 0) RG_WAIT_VM(0);
+  else if constexpr (N == 2) RG_WAIT_VM(2);
+  else if constexpr (N == 4) RG_WAIT_VM(4);
+  else if constexpr (N == 6) RG_WAIT_VM(6);
+  else if constexpr (N == 8) RG_WAIT_VM(8);
+  else if constexpr (N == 12) RG_WAIT_VM(12);
+  else if constexpr (N == 16) RG_WAIT_VM(16);
+  else if constexpr (N == 24) RG_WAIT_VM(24);
+  else static_assert(N < 0, "add the count");
+}
+
+__device__ __forceinline__ void rg_glds16(const float *src, float *lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                   (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
+}
+
+// KA / KB: RK_KC or RK_RC.  BM x BN block tile, 4 waves as 2 x 2, each (BM/2) x (BN/2) = MT x NT MFMA tiles of 32 x 32.
+// AFFA: operand A (RK_KC) carries a.aff by reduction index; AFFB: operand B (RK_RC) carries b.aff by tile-row index.
+template <int KA, int KB, int BM, int BN, int EPI, bool AFFA, bool AFFB>
+__global__ __launch_bounds__(RG_TPB, (BM == 128 && BN == 128) ? 1 : 2) void gemm_ring_kernel(RingArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // ALL LDS of the kernel (a second object would make
+                                                                 // the compiler drain the DMA ring before every read)
+  constexpr int A_FL = BM * RG_BK, B_FL = BN * RG_BK, ST_FL = A_FL + B_FL;
+  constexpr int PA = BM / 8, PB = BN / 8, NPW = (PA + PB) / 4;    // 1 KB pieces per stage: A, B; per wave
+  constexpr int MT = BM / 64, NT = BN / 64;
+  static_assert(!AFFA || KA == RK_KC, "a.aff is indexed by the reduction index");
+  static_assert(!AFFB || KB == RK_RC, "b.aff is indexed by the tile-row index");
+  float *tab = lds + RG_STAGES * ST_FL;   // AFFA: [2][kchunk] ; AFFB: [2][BN]
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int m = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const long long m0 = (long long)(blockIdx.x / g.tiles_n) * BM;
+  const long long n0 = (long long)(blockIdx.x % g.tiles_n) * BN;
+  const long long kbeg = (long long)blockIdx.y * g.kchunk;
+  long long kend = kbeg + g.kchunk;
+  if (kend > g.red) kend = g.red;
+  const int T = (int)((kend - kbeg) / RG_BK);   // reduction steps of this workgroup (>= 1: host-checked)
+  float *dout = g.d + (long long)blockIdx.y * g.dchunk;
+
+  // ---- this lane's source address for each of the wave's NPW pieces of a stage (advanced by one step per issue)
+  const float *src[NPW];
+  long long adv[NPW];
+  int dst_off[NPW];
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) {
+    const int pid = wave + 4 * i;
+    const bool isA = pid < PA;
+    const int p = isA ? pid : pid - PA;
+    const RingOp &op = isA ? g.a : g.b;
+    const int kind = isA ? KA : KB;
+    const int q = p * 64 + lane;
+    dst_off[i] = (isA ? 0 : A_FL) + p * 256;
+    if (kind == RK_KC) {
+      const int r = q >> 3, c = (q & 7) ^ ((r >> 1) & 7);
+      long long row = (isA ? m0 : n0) + r;
+      if (row > op.rows - 1) row = op.rows - 1;            // rows beyond the operand: a valid duplicate, masked at the end
+      src[i] = op.src + row * op.ld + kbeg + 4 * c;
+      adv[i] = RG_BK;
+    } else {
+      constexpr int CPRA = BM / 4, CPRB = BN / 4;          // 16-byte chunks per reduction row of the image
+      const int cpr = isA ? CPRA : CPRB;
+      const int rr = q / cpr, cc = q % cpr;
+      long long col = (isA ? m0 : n0) + 4 * cc;
+      if (col > op.rows - 4) col = op.rows - 4;            // (rows % 4 == 0)
+      src[i] = op.src + (kbeg + rr) * op.ld + col;
+      adv[i] = (long long)RG_BK * op.ld;
+    }
+  }
+  auto issue_stage = [&](int slot) {
+    float *base = lds + slot * ST_FL;
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      rg_glds16(src[i], base + dst_off[i]);
+      src[i] += adv[i];
+    }
+  };
+
+  // ---- prologue: the operand prologue's table, then three stages - all before the first wait
+  constexpr bool TAB = AFFA || AFFB;
+  if constexpr (AFFA) {
+    // [a(kchunk), b(kchunk)]: 2 * kchunk floats = kchunk / 128 pieces per half; the waves split them
+    const int per_half = (int)(g.kchunk / 256);     // pieces of 1 KB per half (kchunk % 256 == 0: host-checked)
+    for (int p = wave; p < 2 * per_half; p += 4) {
+      const int half = p >= per_half, pp = half ? p - per_half : p;
+      long long k = kbeg + pp * 256 + lane * 4;
+      if (k > g.red - 4) k = g.red - 4;
+      rg_glds16(g.a.aff + (half ? g.red : 0) + k, tab + (size_t)half * g.kchunk + pp * 256);
+    }
+  }
+  if constexpr (AFFB) {
+    // [a(BN), b(BN)] of this tile's columns: BN / 4 chunks per half; wave 0 (a) and wave 1 (b), lanes < BN / 4
+    if (wave < 2) {
+      long long col = n0 + 4 * (lane % (BN / 4));
+      if (col > g.b.rows - 4) col = g.b.rows - 4;
+      rg_glds16(g.b.aff + (wave ? g.b.rows : 0) + col, tab + wave * 256);   // (lanes >= BN / 4 repeat: harmless)
+    }
+  }
+  // vmcnt bookkeeping: every wave has issued the same number of table pieces only in the AFFB case of waves 0 / 1 and in
+  // the AFFA case when 2 * per_half is a multiple of 4.  The first wait below therefore is vmcnt(0)-safe by construction:
+  // the table is OLDER than every stage, so "all but the youngest N" covers it for any N <= what was issued after it.
+  const int pre = T < RG_STAGES - 1 ? T : RG_STAGES - 1;
+  for (int s = 0; s < pre; ++s) issue_stage(s);
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float fa_b[NT], fb_b[NT];   // AFFB: this lane's column coefficients
+  (void)fa_b; (void)fb_b;
+
+  for (int step = 0; step < T; ++step) {
+    // stages issued so far: min(T, step + 3); the ones after `step` may stay in flight
+    const int ahead = (T - 1 - step) < (RG_STAGES - 2) ? (T - 1 - step) : (RG_STAGES - 2);
+    if (ahead >= 2) rg_wait_vm<2 * NPW>();
+    else if (ahead == 1) rg_wait_vm<NPW>();
+    else rg_wait_vm<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the previous step's fragment reads have retired: WAR on its slot)
+    __builtin_amdgcn_s_barrier();
+    if (step + RG_STAGES - 1 < T) issue_stage((step + RG_STAGES - 1) % RG_STAGES);
+    if constexpr (AFFB) {
+      if (step == 0) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          fa_b[j] = tab[wn * (BN / 2) + j * 32 + m];
+          fb_b[j] = tab[256 + wn * (BN / 2) + j * 32 + m];
+        }
+      }
+    }
+    const float *As = lds + (step % RG_STAGES) * ST_FL;
+    const float *Bs = As + A_FL;
+    const int kk = step * RG_BK;   // offset of this step inside the chunk (table index)
+#pragma unroll
+    for (int cq = 0; cq < 4; ++cq) {
+      // ---- fragments of MFMA slices 4cq .. 4cq+3
+      float av[MT][4], bv[NT][4];
+      if constexpr (KA == RK_KC) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int r = wm * (BM / 2) + i * 32 + m;
+          const float4 q = *reinterpret_cast<const float4 *>(As + (r * 8 + ((2 * cq + h) ^ ((r >> 1) & 7))) * 4);
+          av[i][0] = q.x; av[i][1] = q.y; av[i][2] = q.z; av[i][3] = q.w;
+        }
+        if constexpr (AFFA) {
+          const float4 ta = *reinterpret_cast<const float4 *>(tab + kk + 4 * (2 * cq + h));
+          const float4 tb = *reinterpret_cast<const float4 *>(tab + g.kchunk + kk + 4 * (2 * cq + h));
+          const float ca[4] = {ta.x, ta.y, ta.z, ta.w}, cb[4] = {tb.x, tb.y, tb.z, tb.w};
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float z = ca[e] * av[i][e] + cb[e];
+              av[i][e] = z > 0.f ? z : 0.f;
+            }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            av[i][e] = As[(KB == RK_RC ? 2 * (4 * cq + e) + h : 4 * (2 * cq + h) + e) * BM + wm * (BM / 2) + i * 32 + m];
+      }
+      if constexpr (KB == RK_KC) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int r = wn * (BN / 2) + j * 32 + m;
+          const float4 q = *reinterpret_cast<const float4 *>(Bs + (r * 8 + ((2 * cq + h) ^ ((r >> 1) & 7))) * 4);
+          bv[j][0] = q.x; bv[j][1] = q.y; bv[j][2] = q.z; bv[j][3] = q.w;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            // the reduction index this lane half contributes to slice 4cq + e: the KC partner's order, or the natural one
+            const int rr = KA == RK_KC ? 4 * (2 * cq + h) + e : 2 * (4 * cq + e) + h;
+            float v = Bs[rr * BN + wn * (BN / 2) + j * 32 + m];
+            if constexpr (AFFB) {
+              const float z = fa_b[j] * v + fb_b[j];
+              v = z > 0.f ? z : 0.f;
+            }
+            bv[j][e] = v;
+          }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: acc[i][j][r] = D[m0 + wm*BM/2 + i*32 + (r&3) + 8*(r>>2) + 4*h][n0 + wn*BN/2 + j*32 + m]
+  float csum[NT], csq[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const long long col = n0 + wn * (BN / 2) + j * 32 + m;
+      const bool colok = col < g.b.rows;
+      float ea = 0.f, eb = 0.f, emean = 0.f, erstd = 0.f;
+      if constexpr (EPI == RG_BNBWD) {
+        if (colok) {
+          ea = g.epi_ab[col]; eb = g.epi_ab[g.b.rows + col]; emean = g.epi_ab[2 * g.b.rows + col];
+          erstd = g.epi_ab[3 * g.b.rows + col];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long long row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float v = acc[i][j][r];
+        if (row < g.a.rows && colok) {
+          if constexpr (EPI == RG_ATOMIC) atomicAdd(dout + row * g.ldd + col, v);
+          else dout[row * g.ldd + col] = v;
+          if constexpr (EPI == RG_STATS) {
+            csum[j] += v;
+            csq[j] += v * v;
+          }
+          if constexpr (EPI == RG_BNBWD) {
+            const float y = g.epi_y[row * g.ldd + col];
+            const float gg = (ea * y + eb) > 0.f ? v : 0.f;
+            csum[j] += gg;
+            csq[j] += gg * ((y - emean) * erstd);
+          }
+        }
+      }
+    }
+  if constexpr (EPI == RG_STATS || EPI == RG_BNBWD) {
+    // column partials: lanes l and l+32 hold the same column; then the two row-waves (wm) through LDS (the ring is dead)
+    __syncthreads();
+    float *s_col = lds;   // [2][2][BN]
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      csum[j] += __shfl_xor(csum[j], 32);
+      csq[j] += __shfl_xor(csq[j], 32);
+      if (h == 0) {
+        s_col[(0 * 2 + wm) * BN + wn * (BN / 2) + j * 32 + m] = csum[j];
+        s_col[(1 * 2 + wm) * BN + wn * (BN / 2) + j * 32 + m] = csq[j];
+      }
+    }
+    __syncthreads();
+    if (t < BN) {
+      const long long col = n0 + t;
+      if (col < g.b.rows) {
+        double *st = g.stats + (size_t)((blockIdx.x / g.tiles_n) % g.stat_slots) * 2 * g.b.rows;
+        atomicAdd(st + col, (double)s_col[(0 * 2 + 0) * BN + t] + (double)s_col[(0 * 2 + 1) * BN + t]);
+        atomicAdd(st + g.b.rows + col, (double)s_col[(1 * 2 + 0) * BN + t] + (double)s_col[(1 * 2 + 1) * BN + t]);
+      }
+    }
+  }
+}
+
+static inline bool rg_aligned16(const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
+
+template <int KA, int KB, int BM, int BN, int EPI, bool AFFA, bool AFFB>
+static void rg_launch(const RingArgs &g, long long tiles_m, unsigned chunks, hipStream_t s) {
+  static std::atomic<unsigned long long> attr_set{0};
+  auto kern = gemm_ring_kernel<KA, KB, BM, BN, EPI, AFFA, AFFB>;
+  allow_dynamic_lds(kern, 160 * 1024, attr_set);
+  size_t lds = (size_t)RG_STAGES * (BM + BN) * RG_BK * sizeof(float);
+  if (AFFA) lds += 2 * (size_t)g.kchunk * sizeof(float);
+  if (AFFB) lds += 2 * 256 * sizeof(float);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * g.tiles_n), chunks), dim3(RG_TPB), lds, s, g);
+}
+
+template <int KA, int KB, int EPI, bool AFFA, bool AFFB>
+static void rg_launch_tile(RingArgs &g, bool big, unsigned chunks, hipStream_t s) {
+  if (big) {
+    g.tiles_n = (int)((g.b.rows + 127) / 128);
+    rg_launch<KA, KB, 128, 128, EPI, AFFA, AFFB>(g, (g.a.rows + 127) / 128, chunks, s);
+  } else {
+    g.tiles_n = (int)((g.b.rows + 63) / 64);
+    rg_launch<KA, KB, 64, 64, EPI, AFFA, AFFB>(g, (g.a.rows + 63) / 64, chunks, s);
+  }
+}
+
+// Tile and split of one product (M x N output, reduction `red`): 128 x 128 tiles when they alone give every CU work,
+// else 64 x 64; `want_split`: the caller can take partial products (a workspace for forward / dgrad, atomics for wgrad).
+void ring_plan(long long M, long long N, long long red, bool want_split, long long max_chunks, RingPlan *p) {
+  const long long t128 = ((M + 127) / 128) * ((N + 127) / 128), t64 = ((M + 63) / 64) * ((N + 63) / 64);
+  p->big = t128 >= 224;
+  const long long tiles = p->big ? t128 : t64;
+  long long chunks = 1;
+  if (want_split && tiles < 192 && red >= 512) {
+    chunks = 320 / tiles;
+    if (chunks > red / 256) chunks = red / 256;   // at least 8 steps per workgroup, table pieces of whole kilobytes
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks < 1) chunks = 1;
+  }
+  long long kc = (red + chunks - 1) / chunks;
+  kc = (kc + 255) / 256 * 256;
+  if (kc > red) kc = red;
+  p->kchunk = kc;
+  p->chunks = (int)((red + kc - 1) / kc);
+}
+
+bool ring_gemm_try(int kind, const float *a, const float *b, const float *aff, float *d, long long P, int K, int N,
+                   double *stats, int stat_slots, const float *epi_y, const float *epi_ab, const RingPlan &plan,
+                   long long dchunk, hipStream_t s) {
+  RingArgs g = {};
+  g.d = d;
+  g.stats = stats;
+  g.stat_slots = stat_slots < 1 ? 1 : stat_slots;
+  g.epi_y = epi_y;
+  g.epi_ab = epi_ab;
+  g.kchunk = plan.kchunk;
+  g.dchunk = dchunk;
+  const unsigned chunks = (unsigned)plan.chunks;
+  if (!rg_aligned16(a) || !rg_aligned16(b) || !rg_aligned16(d) || (aff && !rg_aligned16(aff))) return false;
+  if (plan.kchunk % RG_BK != 0 || plan.kchunk < RG_BK || chunks < 1 || chunks > 65535) return false;
+  if (kind == RING_FWD) {
+    // Y (P,N) = f(X (P,K)) W (N,K)^T: both reduction-contiguous
+    if (K % RG_BK != 0 || K % 4 != 0 || P < 1 || N < 1) return false;
+    if (aff && (plan.kchunk % 256 != 0 || K % 4 != 0 || 2 * plan.kchunk * sizeof(float) > 24 * 1024)) return false;
+    g.a = {a, P, K, aff};
+    g.b = {b, N, K, nullptr};
+    g.ldd = N;
+    g.red = K;
+    if (chunks > 1 && (stats || !dchunk)) return false;   // partial products carry no statistics
+#define GB_RF(EPI_)                                                                                   \
+    do {                                                                                              \
+      if (aff) rg_launch_tile<RK_KC, RK_KC, EPI_, true, false>(g, plan.big, chunks, s);               \
+      else rg_launch_tile<RK_KC, RK_KC, EPI_, false, false>(g, plan.big, chunks, s);                  \
+    } while (0)
+    if (stats) GB_RF(RG_STATS); else GB_RF(RG_STORE);
+#undef GB_RF
+    return true;
+  }
+  if (kind == RING_DGRAD) {
+    // dX (P,K) = dY (P,N) W (N,K): A reduction-contiguous, B row-contiguous (element (k, n) at w[n K + k])
+    if (N % RG_BK != 0 || K % 4 != 0 || N % 4 != 0 || P < 1 || aff) return false;
+    g.a = {a, P, N, nullptr};
+    g.b = {b, K, K, nullptr};
+    g.ldd = K;
+    g.red = N;
+    if (chunks > 1 && (stats || !dchunk)) return false;
+    if (stats) rg_launch_tile<RK_KC, RK_RC, RG_BNBWD, false, false>(g, plan.big, chunks, s);
+    else rg_launch_tile<RK_KC, RK_RC, RG_STORE, false, false>(g, plan.big, chunks, s);
+    return true;
+  }
+  if (kind == RING_WGRAD) {
+    // dW (N,K) += dY (P,N)^T f(X (P,K)): both row-contiguous, reduction over the P rows, fp32 atomics into dW
+    if (P % RG_BK != 0 || K % 4 != 0 || N % 4 != 0 || K < 4 || N < 4 || stats) return false;
+    g.a = {a, N, N, nullptr};
+    g.b = {b, K, K, aff};
+    g.ldd = K;
+    g.red = P;
+    if (aff) rg_launch_tile<RK_RC, RK_RC, RG_ATOMIC, false, true>(g, plan.big, chunks, s);
+    else rg_launch_tile<RK_RC, RK_RC, RG_ATOMIC, false, false>(g, plan.big, chunks, s);
+    return true;
+  }
+  return false;
+}
+
+}  // namespace gb

@@ -62,6 +62,7 @@ class FlatGradAllReduce:
         self._works = [None] * len(self.buckets)
         self._arrived = [0] * len(self.buckets)
         self._next = 0
+        self.hold = False   # True: the hooks only count (a step whose collectives run after backward: reduce_flat)
         self.timing = timing
         self._stall_events = []
         self.flat_all, self.views, self.flat = None, [], []
@@ -110,6 +111,8 @@ class FlatGradAllReduce:
         self._works[b] = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
 
     def _on_grad(self, p):
+        if self.hold:
+            return
         b = self._bucket_of[id(p)]
         self._arrived[b] += 1
         # issue in bucket order only: every rank must launch the same sequence of collectives
@@ -136,6 +139,26 @@ class FlatGradAllReduce:
                 flat.div_(self.world_size)
             for v, p in zip(self.views[b], self.buckets[b]):
                 p.grad = v
+
+    def reduce_flat(self):
+        """All-reduce (mean) the flat gradient buffer bucket by bucket and wait: for a step that packs its gradients into
+        the buffer itself and applies the update from it (train.Trainer's HIP-graph step: forward + backward + pack and
+        the Adam update are two captured graphs, the collectives run between them, uncaptured)."""
+        if not dist.is_initialized():
+            return
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        if self.timing:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        works = [dist.all_reduce(flat, op=op, group=self.group, async_op=True) for flat in self.flat]
+        for w in works:
+            w.wait()
+        if not self._avg:
+            for flat in self.flat:
+                flat.div_(self.world_size)
+        if self.timing:
+            ev[1].record()
+            self._stall_events.append(ev)
 
     def exposed_ms(self):
         """Mean time per step the compute stream waited for the collectives (timing=True; call after a device
@@ -172,3 +195,5 @@ def broadcast_module(module, src=0, process_group=None):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src, group=process_group)
+    from . import fused_mlp
+    fused_mlp.invalidate_eval_tables()   # written through .data: no version counter moved

@@ -220,11 +220,15 @@ class DRP(nn.Module):
                 hook = end_points.pop('_after_sa1', None)
                 if hook is not None:
                     hook()
+            hooks = end_points.get('_after_level')     # {level: callable}: run once that set-abstraction level is enqueued
+            if hooks and level in hooks:
+                hooks.pop(level)()
             xyz, features = run_stage(getattr(self, 'InvResMLP_blocks%d' % level), xyz, features)
             if level <= 2:
                 end_points['sa%d_inds' % level] = fps_inds
             end_points['sa%d_xyz' % level] = xyz
             end_points['sa%d_features' % level] = features
+        end_points.pop('_after_level', None)
         features = self.fp1(end_points['sa3_xyz'], end_points['sa4_xyz'], end_points['sa3_features'],
                             end_points['sa4_features'])
         features = self.fp2(end_points['sa2_xyz'], end_points['sa3_xyz'], end_points['sa2_features'], features)

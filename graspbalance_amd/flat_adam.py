@@ -86,6 +86,8 @@ class FlatAdam(Optimizer):
         lr, (beta1, beta2), eps, wd = group['lr'], group['betas'], group['eps'], group['weight_decay']
         if not packed:
             self.pack()
+        if self.tensor_lr and not (self._lr_t.is_cuda and torch.cuda.is_current_stream_capturing()):
+            self.set_lr_tensor(lr)   # (a captured step reads whatever the caller put there before each replay)
         self._steps += 1
         self._step_t += 1
         # the parameters are views of ONE flat buffer and the update below writes that buffer: the views' own version
@@ -123,3 +125,5 @@ class FlatAdam(Optimizer):
         for k, v in state_dict['param_groups'][0].items():
             if k != 'params':
                 self.param_groups[0][k] = v
+        from . import fused_mlp
+        fused_mlp.invalidate_eval_tables()

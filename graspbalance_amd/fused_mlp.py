@@ -175,10 +175,13 @@ def begin_step(device):
                                      "buf32": torch.zeros(_ARENA32_FLOATS, dtype=torch.float32, device=device)
                                      if _ARENA32_FLOATS else None, "off32": 0, "live": True}
     else:
-        if ar["off"]:
-            ar["buf"][:ar["off"]].zero_()
-        if ar["off32"]:
-            ar["buf32"][:ar["off32"]].zero_()
+        # up to the HIGH-WATER mark of all steps so far, not just the previous one's: a step replayed from a HIP graph
+        # dirties what it took when it was captured, whatever ran (and moved the offsets) on the host since
+        ar["hw"], ar["hw32"] = max(ar.get("hw", 0), ar["off"]), max(ar.get("hw32", 0), ar["off32"])
+        if ar["hw"]:
+            ar["buf"][:ar["hw"]].zero_()
+        if ar["hw32"]:
+            ar["buf32"][:ar["hw32"]].zero_()
     ar["off"], ar["off32"], ar["live"] = 0, 0, True
 
 
@@ -249,6 +252,13 @@ _TRAIN_TICK = [0]   # bumped by every training-mode BatchNorm finalise: those wr
 _EVAL_AB = {}   # id(running_mean buffer) -> (weak reference to it, key, [a, b, mean, rstd] table)
 
 
+def invalidate_eval_tables():
+    """Forget the cached eval-mode BatchNorm tables.  The cache follows version counters, addresses and this module's
+    own training passes; a write through ``.data`` (broadcasts, EMA / weight averaging, a foreign optimizer) moves none
+    of them - such code calls this afterwards.  (data_parallel.broadcast_module, FlatAdam.step / load_state_dict do.)"""
+    _TRAIN_TICK[0] += 1
+
+
 def _eval_ab(gamma, beta, running_mean, running_var, eps, N, dev, st):
     """Eval mode: the layer's [a, b, mean, rstd] table depends on parameters and running statistics only, so it is
     computed once (gb_bn_finalize without batch sums) and reused until one of them changes - an eval forward of the
@@ -259,11 +269,15 @@ def _eval_ab(gamma, beta, running_mean, running_var, eps, N, dev, st):
     slot = id(running_mean)   # (tensors compare element-wise: a dictionary keyed by the tensor itself would not do)
     hit = _EVAL_AB.get(slot)
     if hit is not None and hit[0]() is running_mean and hit[1] == key:
+        if hit[3] != st.value:   # built on another stream: order this stream behind the launch that wrote the table
+            torch.cuda.current_stream(dev).wait_event(hit[4])
         return hit[2]
     ab = torch.empty(4 * N, dtype=torch.float32, device=dev)
     _call("gb_bn_finalize", dev, None, 1, 1, N, _lib.ptr(gamma), _lib.ptr(beta), float(eps), 0.0, _lib.ptr(running_mean),
           _lib.ptr(running_var), _lib.ptr(ab), 0, st)
-    _EVAL_AB[slot] = (weakref.ref(running_mean, lambda _, slot=slot: _EVAL_AB.pop(slot, None)), key, ab)
+    done = torch.cuda.Event()
+    done.record(torch.cuda.current_stream(dev))
+    _EVAL_AB[slot] = (weakref.ref(running_mean, lambda _, slot=slot: _EVAL_AB.pop(slot, None)), key, ab, st.value, done)
     return ab
 
 
@@ -277,18 +291,32 @@ def _bn_fin(cfg, gamma, beta, ab, P_stat):
     return ctypes.byref(f)
 
 
-def _gemm_meta(kind, P, K, N, fused=False, aff=False):
+def _gemm_meta(kind, P, K, N, fused=False, aff=False, rows_dev=None):
     """Timing metadata of a GEMM launch (only built while a KernelTimer is active): FLOP, shape and which
-    kernel the C entry dispatches to (gemm_rs_kernel / gemm_cl_kernel)."""
+    kernel the C entry dispatches to (gemm_rs_kernel / gemm_cl_kernel).  rows_dev: the launch's device-side row count -
+    read back HERE (a synchronisation: timing runs only) so that the FLOP count is that of the rows actually multiplied,
+    not of the capacity P."""
     if _lib.KernelTimer.active is None:
         return None
+    cap = P
+    if rows_dev is not None:
+        P = int(rows_dev)
     if kind == "wgrad":
         smallk = K <= 4 and not aff and N % 4 == 0 and N <= 1024 and P >= 4096  # gb_gemm_wgrad's dispatch rule
         kernel = "wgrad_smallk_kernel" if smallk else "gemm_cl_kernel"
     else:
-        rs = _lib.lib().gb_gemm_uses_rs(P, K, N, int(kind == "dgrad"), int(fused), int(aff))
+        rs = _lib.lib().gb_gemm_uses_rs(cap, K, N, int(kind == "dgrad"), int(fused), int(aff))
         kernel = "gemm_rs_kernel" if rs else "gemm_cl_kernel"
     return {"flop": 2.0 * P * K * N, "pkn": (P, K, N), "kernel": kernel}
+
+
+def _first_meta(P, K, N, rows_dev):
+    """_gemm_meta of the closed-form first-layer dgrad (always the row-streaming kernel)."""
+    if _lib.KernelTimer.active is None:
+        return None
+    if rows_dev is not None:
+        P = int(rows_dev)
+    return {"flop": 2.0 * P * K * N, "pkn": (P, K, N), "kernel": "gemm_rs_kernel"}
 
 
 def _wgrad(dY, X):
@@ -526,7 +554,7 @@ class MLPStack(Function):
                 st_buf, st_slots = (stats, slots) if cfg.training else (_zeros64(2 * N, dev), 1)
                 _call("gb_gemm_fwd_gen3", dev, _lib.ptr(X0), _lib.ptr(Ws[0]), _lib.ptr(aff), _lib.ptr(W),
                       _lib.ptr(rows.w16 if rows is not None else None), _lib.ptr(Y), _lib.ptr(st_buf), st_slots, P, K, N,
-                      fin, opts, st, meta=_gemm_meta("fwd", P, K, N, True, True))
+                      fin, opts, st, meta=_gemm_meta("fwd", P, K, N, True, True, rows_dev=rdev))
                 if fin is None:
                     ab = _eval_ab(gamma, beta, cfg.running_mean, cfg.running_var, cfg.eps, N, dev, st)
                 Ws.append(W); Ys.append(Y); abs_.append(ab)
@@ -551,10 +579,10 @@ class MLPStack(Function):
             if rows is not None and stats is not None:
                 _call("gb_gemm_fwd_w", dev, _lib.ptr(src), _lib.ptr(W), _lib.ptr(aff), _lib.ptr(rows.w16), _lib.ptr(Y),
                       _lib.ptr(stats), slots, P, K, N, fin, opts, st,
-                      meta=_gemm_meta("fwd", P, K, N, True, aff is not None))
+                      meta=_gemm_meta("fwd", P, K, N, True, aff is not None, rows_dev=rdev))
             else:
                 _call("gb_gemm_fwd", dev, _lib.ptr(src), _lib.ptr(W), _lib.ptr(aff), _lib.ptr(Y), _lib.ptr(stats), slots,
-                      P, K, N, fin, opts, st, meta=_gemm_meta("fwd", P, K, N, stats is not None, aff is not None))
+                      P, K, N, fin, opts, st, meta=_gemm_meta("fwd", P, K, N, stats is not None, aff is not None, rows_dev=rdev))
             if fin is None:
                 ab = _eval_ab(gamma, beta, cfg.running_mean, cfg.running_var, cfg.eps, N, dev, st)
             Ws.append(W); Ys.append(Y); abs_.append(ab)
@@ -707,16 +735,16 @@ class MLPStack(Function):
                 dW = w_arena[w_off[l]:w_off[l + 1]]
                 if ctx.fold and l == 1:   # the x operand relu(a*y1 + b) is re-formed from the xyz rows
                     _call("gb_gemm_wgrad_gen3", dev, _lib.ptr(dY), _lib.ptr(X0), _lib.ptr(Ws[0]), _lib.ptr(aff), _lib.ptr(dW), P,
-                          K, N, opts, st, meta=_gemm_meta("wgrad", P, K, N, aff=True))
+                          K, N, opts, st, meta=_gemm_meta("wgrad", P, K, N, aff=True, rows_dev=rdev))
                 else:
                     _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(src), _lib.ptr(aff), _lib.ptr(dW), P, K, N, opts, st,
-                          meta=_gemm_meta("wgrad", P, K, N, aff=aff is not None))
+                          meta=_gemm_meta("wgrad", P, K, N, aff=aff is not None, rows_dev=rdev))
                 grads[3 * l] = dW.view(N, K)
             if l == 0:
                 if ctx.needs_input_grad[0]:
                     dX0 = torch.empty((P, K), dtype=torch.float32, device=dev)
                     _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dX0), None, None, None, 0, P, K, N,
-                          None, None, None, opts, st, meta=_gemm_meta("dgrad", P, K, N))
+                          None, None, None, opts, st, meta=_gemm_meta("dgrad", P, K, N, rows_dev=rdev))
                 break
             if (l == 1 and _FIRST_FUSE and X0.shape[1] == 3 and not ctx.needs_input_grad[0] and need_w[0]
                     and _lib.lib().gb_gemm_uses_rs(P, K, N, 1, 2, 0)):
@@ -727,12 +755,12 @@ class MLPStack(Function):
                 if ctx.fold:
                     _call("gb_gemm_dgrad_first_gen3", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(abs_[0]), _lib.ptr(X0),
                           _lib.ptr(Ws[0]), _lib.ptr(sums), slots, P, K, N, opts, st,
-                          meta={"flop": 2.0 * P * K * N, "pkn": (P, K, N), "kernel": "gemm_rs_kernel"})
+                          meta=_first_meta(P, K, N, rdev))
                     mom = ctx.mom0   # the forward's moments of the same rows
                 else:
                     _call("gb_gemm_dgrad_first", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(Ys[0]), _lib.ptr(abs_[0]),
                           _lib.ptr(X0), _lib.ptr(sums), slots, P, K, N, opts, st,
-                          meta={"flop": 2.0 * P * K * N, "pkn": (P, K, N), "kernel": "gemm_rs_kernel"})
+                          meta=_first_meta(P, K, N, rdev))
                     _call("gb_moments3", dev, _lib.ptr(X0), _lib.ptr(rows.w if rows is not None else None), P,
                           _lib.ptr(mom), _lib.ptr(rdev), st)
                 dbeta0, dgamma0 = bn_grads(0)
@@ -756,11 +784,11 @@ class MLPStack(Function):
                 _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dZ), _lib.ptr(Ys[l - 1]),
                       _lib.ptr(abs_[l - 1]), _lib.ptr(region), slots, P, K, N, None if emit else _lib.ptr(dstats),
                       None if emit else _lib.ptr(dbeta), None if emit else _lib.ptr(dgamma), opts, st,
-                      meta=_gemm_meta("dgrad", P, K, N, fused=True))
+                      meta=_gemm_meta("dgrad", P, K, N, fused=True, rows_dev=rdev))
             else:
                 # wide + long outputs: the fused epilogue measured slower than a separate column pass
                 _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dZ), None, None, None, 0, P, K, N,
-                      None, None, None, opts, st, meta=_gemm_meta("dgrad", P, K, N))
+                      None, None, None, opts, st, meta=_gemm_meta("dgrad", P, K, N, rows_dev=rdev))
                 dstats = region
                 _call("gb_bn_bwd_stats", dev, _lib.ptr(dZ), _lib.ptr(Ys[l - 1]), _lib.ptr(abs_[l - 1]), None, P, K, 1,
                       _lib.ptr(dstats), _lib.ptr(dbeta), _lib.ptr(dgamma), st)
@@ -836,7 +864,7 @@ def _pooled_last_layer(dev, st, opts, src, W, aff, gamma, beta, cfg, ab, stats, 
         fin, stats, slots = None, _zeros64(2 * N, dev), 1   # the kernel always forms the sums; eval ignores them
     _call("gb_gemm_fwd_pool", dev, _lib.ptr(src), _lib.ptr(W), _lib.ptr(aff), _lib.ptr(rows.key), _lib.ptr(gamma),
           _lib.ptr(pairs), pairs.numel(), rows.R, _lib.ptr(Y), _lib.ptr(stats), slots, P, K, N, rows.D, fin, opts, st,
-          meta=_gemm_meta("fwd", P, K, N, True, aff is not None))
+          meta=_gemm_meta("fwd", P, K, N, True, aff is not None, rows_dev=rows.rows_dev))
     # eval: `ab` is the caller's cached table (_eval_ab)
     out = torch.empty((RD, N), dtype=torch.float32, device=dev)
     ystar = torch.empty((RD, N), dtype=torch.float32, device=dev)

@@ -6,8 +6,8 @@ the absent ``graspnet.GraspNet_MSCQ`` and dataset class names that do not exist 
 HIP-graph execution (``Trainer(graph=True)``, the default on a GPU).  A train step is ~1000 kernel launches and 15-19 ms
 of Python to enqueue them - as long as the GPU itself needs.  Nothing in the step depends on a value the host has to
 see (the one row count that used to be read back stays on the device: fused_mlp.set_static_rows), so the whole step -
-forward, label matching, loss, backward, Adam, the next batch's first-level sampling on its side stream - is captured
-ONCE into a HIP graph and replayed: one launch call per step.  What varies between steps lives in device memory the
+forward, label matching, loss, backward, Adam - is captured ONCE into a HIP graph and replayed: one launch call per step
+(plus, on its side stream, the three launches of the next batch's first-level sampling).  What varies between steps lives in device memory the
 graph reads: the batch (static input buffers: ``Trainer.resident``), the learning rate (a device scalar), Adam's step
 count.  A change of anything that was baked into launch arguments (tensor shapes of the batch, the BatchNorm momentum
 of the epoch, whether a next batch is announced) captures another graph; all graphs share one memory pool.  With more
@@ -60,10 +60,24 @@ class Trainer:
                                     epochs=max_epoch)
         bn_lbmd = lambda it: max(BN_MOMENTUM_INIT * bn_decay_rate ** (int(it / bn_decay_step)), BN_MOMENTUM_MAX)
         self.bnm_scheduler = BNMomentumScheduler(self.net, bn_lambda=bn_lbmd, last_epoch=-1)
+        # HIP-graph replay of the step (module docstring); needs the sync-free step (static rows) and a GPU
+        self.graph = (_GRAPH_DEFAULT if graph is None else bool(graph)) and self.device.type == "cuda"
+        # the stream the step is captured on.  Every parameter's AccumulateGrad node is created HERE, with that stream
+        # current, and kept alive: such a node runs on the stream it was created under for as long as it lives, and one
+        # born on the default stream (any earlier forward whose loss is still referenced keeps it alive) drags the
+        # default stream into the capture - a fork the capture never joins (hipStreamEndCapture crashes on it)
+        self._cstream = torch.cuda.Stream(device=self.device) if self.graph else None
+        if self.graph:
+            with torch.cuda.stream(self._cstream):
+                self._acc_nodes = [p.expand_as(p).grad_fn.next_functions[0][0] for p in self.net.parameters()
+                                   if p.requires_grad]
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)   # (eager steps on other streams)
         # the buckets ARE slices of the optimizer's flat gradient buffer: the averaged gradient lands where the
         # update reads it (no second 36 MB copy per step)
-        self.grads = FlatGradAllReduce(self.net, bucket_mb=bucket_mb, timing=time_collectives,
-                                       flat=(self.optimizer._flat_g, self.optimizer._grad_views, self.optimizer._params))
+        with (torch.cuda.stream(self._cstream) if self._cstream is not None else _NO_CONTEXT):
+            self.grads = FlatGradAllReduce(self.net, bucket_mb=bucket_mb, timing=time_collectives,
+                                           flat=(self.optimizer._flat_g, self.optimizer._grad_views,
+                                                 self.optimizer._params))
         self.bnm_scheduler.step()
         self.net.train()
         # first-level FPS of the next batch on a side stream (prefetch.py); needs the caller to pass `next_batch`
@@ -72,8 +86,6 @@ class Trainer:
         if prefetch_sampling and _PREFETCH_AT != "off" and self.device.type == "cuda" and sa1 is not None and sa1.npoint:
             from .prefetch import SamplingPrefetch
             self.prefetch = SamplingPrefetch(self.device, sa1.npoint)
-        # HIP-graph replay of the step (module docstring); needs the sync-free step (static rows) and a GPU
-        self.graph = (_GRAPH_DEFAULT if graph is None else bool(graph)) and self.device.type == "cuda"
         self.distributed = bool(distributed)
         self._graphs = {}        # signature -> _StepGraph
         self._pool = None        # memory pool shared by the graphs (one replays at a time)
@@ -94,8 +106,6 @@ class Trainer:
         """The same step enqueued launch by launch (what graph=False does): for tools that bracket single launches with
         events (bench.py's roofline leg), and the reference point of the graph's parity test."""
         with (fused_mlp.precision(self.mlp_precision) if self.mlp_precision is not None else _NO_CONTEXT):
-            if self._static is not None:
-                self._static.valid_sampling = None   # the eager step runs its own prefetch protocol
             return self._train_step(batch, next_batch)
 
     def _train_step(self, batch, next_batch=None):
@@ -153,17 +163,28 @@ class Trainer:
         st.load(batch)                                   # no copies when `batch` is st.batch (Trainer.resident)
         if announced:
             st.load_next(next_batch['point_clouds'])
-        key = (sig, announced, self._bn_momentum(), self.mlp_precision, fused_mlp.get_precision())
-        g = self._graphs.get(key)
-        if g is None:
-            g = self._graphs[key] = self._capture(st, announced)
         if announced and st.samp_for != st.cloud_id():
             # the graph takes the current batch's first-level samples from st.inds: nobody sampled this batch ahead
             with torch.no_grad():
                 from . import pointnet2_utils
                 st.inds.copy_(pointnet2_utils.furthest_point_sample(st.batch['point_clouds'][..., 0:3].contiguous(),
                                                                    self.prefetch.npoint))
+            st.samp_for = st.cloud_id()
+        key = (sig, announced, self._bn_momentum(), self.mlp_precision, fused_mlp.get_precision())
+        g = self._graphs.get(key)
+        if g is None:
+            g = self._graphs[key] = self._capture(st, announced)
         self.optimizer.set_lr_tensor()
+        if announced:
+            # The next batch's first-level sampling, launched on the side stream BEFORE the replay: it runs under the
+            # first ~2.5 ms of the step.  Not inside the graph: a graph with a forked branch loses ROCm's fast launch path
+            # for linear graphs (measured: hipGraphLaunch 14.6 ms of host time per replay with the branch, 0.33 ms without)
+            cur, side = torch.cuda.current_stream(self.device), self.prefetch.side
+            side.wait_stream(cur)
+            with torch.cuda.stream(side), torch.no_grad():
+                from . import pointnet2_utils
+                st.inds_next.copy_(pointnet2_utils.furthest_point_sample(st.next_clouds[..., 0:3].contiguous(),
+                                                                        self.prefetch.npoint))
         g.fwd_bwd.replay()
         if g.update is not None:                         # data parallel: the collective sits between the two graphs
             self.grads.reduce_flat()
@@ -172,7 +193,11 @@ class Trainer:
         self.scheduler.step()
         self.graph_replays += 1
         if announced:
-            st.moved_next_in()   # the graph's tail put the announced clouds and their samples into the current slots
+            cur.wait_stream(side)
+            with torch.no_grad():   # (.data: device-side moves between static buffers; the identity tokens follow below)
+                st.inds.data.copy_(st.inds_next)
+                st.batch['point_clouds'].data.copy_(st.next_clouds)
+            st.moved_next_in()   # the announced clouds and their samples now sit in the current slots
         return g.loss
 
     def _capture(self, st, announced):
@@ -186,13 +211,13 @@ class Trainer:
         keep_opt = (opt._exp_avg.clone(), opt._exp_avg_sq.clone(), opt._step_t.clone(), opt._steps)
         tick = fused_mlp._TRAIN_TICK[0]
         torch.cuda.synchronize(dev)
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
+        cs = self._cstream
+        cs.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(cs):
             for _ in range(2):
                 self._body(st, announced, part="all")
                 self.grads.zero_grad()
-        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.current_stream(dev).wait_stream(cs)
         torch.cuda.synchronize(dev)
 
         def restore():
@@ -209,14 +234,19 @@ class Trainer:
         g = _StepGraph()
         g.fwd_bwd = torch.cuda.CUDAGraph()
         torch.cuda.synchronize(dev)
+        # a process group's watchdog thread polls its events (hipEventQuery) at any time: under the default "global"
+        # capture mode that call from ANOTHER thread is an error that takes the process down; "thread_local" restricts
+        # only the capturing thread (launches of autograd's worker thread into the capturing stream are captured as ever)
+        import torch.distributed as dist
+        mode = "thread_local" if dist.is_available() and dist.is_initialized() else "global"
         if self.distributed:
-            with torch.cuda.graph(g.fwd_bwd, pool=self._pool):
+            with torch.cuda.graph(g.fwd_bwd, pool=self._pool, stream=cs, capture_error_mode=mode):
                 g.loss = self._body(st, announced, part="fwd_bwd")
             g.update = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g.update, pool=self._pool):
+            with torch.cuda.graph(g.update, pool=self._pool, stream=cs, capture_error_mode=mode):
                 self._body(st, announced, part="update")
         else:
-            with torch.cuda.graph(g.fwd_bwd, pool=self._pool):
+            with torch.cuda.graph(g.fwd_bwd, pool=self._pool, stream=cs, capture_error_mode=mode):
                 g.loss = self._body(st, announced, part="all")
         # (capture launches nothing, but the python side effects of the step ran: undo them)
         self.grads.zero_grad()
@@ -229,49 +259,33 @@ class Trainer:
         if part == "update":
             self.optimizer.step(packed=True)
             return None
-        from .prefetch import AFTER_SA1, KEY
+        from .prefetch import KEY
         dev = self.device
         fused_mlp.begin_step(dev)
         inputs = dict(st.batch)
         if self.lean_labels:
             inputs[LEAN] = True
-        cur = torch.cuda.current_stream(dev)
-        side = self.prefetch.side if self.prefetch is not None else None
-        launched = []
         if announced:
-            inputs[KEY] = st.inds
-
-            def launch_next():
-                from . import pointnet2_utils
-                side.wait_stream(cur)
-                with torch.cuda.stream(side):
-                    st.inds_next.copy_(pointnet2_utils.furthest_point_sample(st.next_clouds[..., 0:3].contiguous(),
-                                                                            self.prefetch.npoint))
-                fused_mlp.set_reserved_cus(min(st.next_clouds.shape[0], 128))
-                launched.append(True)
-            if _PREFETCH_AT == "start":
-                launch_next()
-            else:
-                inputs[AFTER_SA1] = launch_next
+            inputs[KEY] = st.inds            # the current batch's samples: sampled one step ahead (or inline by the caller)
+            # the next batch's sampling runs on the side stream beside this step (launched by _graph_step): the persistent
+            # GEMM grids leave its CUs alone (GbGemmOpts.reserved_cus, baked into the captured launches)
+            # ... while it can still be running: ~2.5 ms, i.e. through the second set-abstraction level
+            fused_mlp.set_reserved_cus(min(st.next_clouds.shape[0], 128))
+            inputs['_after_level'] = {2: lambda: fused_mlp.set_reserved_cus(0)}
+        self.grads.hold = part == "fwd_bwd"   # no collective inside a capture: reduce_flat() runs between the graphs
         try:
             end_points = self.net(inputs)
-            if announced and not launched:
-                launch_next()
             loss, end_points = get_loss(end_points)
             loss.backward()
         finally:
             fused_mlp.set_reserved_cus(0)
+            self.grads.hold = False
         if part == "fwd_bwd":
             with torch.no_grad():
                 self.optimizer.pack()
         else:
             self.grads.reduce()          # (single process: a no-op; "all" is never captured with several ranks)
             self.optimizer.step()
-        if announced:
-            cur.wait_stream(side)        # join: the graph ends with the next batch's samples in place
-            with torch.no_grad():
-                st.inds.copy_(st.inds_next)
-                st.batch['point_clouds'].copy_(st.next_clouds)
         return loss.detach()
 
 

@@ -225,8 +225,9 @@ def test_sampling_prefetch_on_side_stream_equals_inline_sampling():
     pf.launch(b['point_clouds'])
     b['point_clouds'].add_(0.0)                                            # modified in place after the announcement
     assert pf.take(b['point_clouds']) is None
-    # through the trainer: the announced batch's indices reach the network (and are the ones it would compute)
-    tr = Trainer(DEV, num_view=30, model=_tiny_net(), steps_per_epoch=10, max_epoch=2)
+    # through the trainer (its launch-by-launch execution: the HIP-graph step keeps the samples in static buffers instead,
+    # tests/test_graph_step_gpu.py): the announced batch's indices reach the network (and are the ones it would compute)
+    tr = Trainer(DEV, num_view=30, model=_tiny_net(), steps_per_epoch=10, max_epoch=2, graph=False)
     seen = {}
     sa1 = tr.net.view_estimator.FeatureExtraction.sa1
     inner = sa1.forward

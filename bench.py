@@ -459,6 +459,18 @@ def main():
     # timed region, same trainer, same resident batch, same kernels
     gemm_names = ["gb_gemm_fwd", "gb_gemm_fwd_w", "gb_gemm_fwd_pool", "gb_gemm_fwd_gen3", "gb_gemm_dgrad", "gb_gemm_dgrad_first",
                   "gb_gemm_dgrad_first_gen3", "gb_gemm_wgrad", "gb_gemm_wgrad_gen3"]
+    # GB_BENCH_TIMED_ONLY=1 (profiling runs: tools/refresh_profiles.sh): nothing but warm-up and the timed replays, so that
+    # a kernel trace's last steps ARE the timed ones
+    timed_only = os.environ.get("GB_BENCH_TIMED_ONLY") == "1"
+    if timed_only:
+        if rank == 0:
+            print(json.dumps({"metric": "point-clouds/sec fwd+bwd (timed steps only: profiling run)", "value": round(world * BATCH_PER_GPU * args.steps / elapsed, 3),
+                              "ms_per_step": round(elapsed / args.steps * 1e3, 3), "steps": args.steps,
+                              "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 3)}))
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     sampled = max(2, min(5, args.steps // 4))
     timer = _lib.KernelTimer(gemm_names + ["gb_fps", "gb_ball_query", "gb_cylinder_query_multi"],
                              reserve=min(2 * 300 * (sampled + 2), 20000))
@@ -544,11 +556,13 @@ def main():
             out_metric = "point-clouds/sec fwd+bwd, 50k-pt stress scene (BASELINE configs[4])"
         else:
             out_metric = "point-clouds/sec fwd+bwd, 20k-pt GraspNet scene"
-        rl_cl = gemm_roofline("gemm_cl_kernel", "LDS-tiled: split-K wgrad, small / unaligned fwd and dgrad")
+        rl_cl = gemm_roofline("gemm_cl_kernel", "register-staged LDS tiles: tall split-K wgrad, unaligned shapes")
         rl_rs = gemm_roofline("gemm_rs_kernel", "row-streaming: tall fwd+BN-stats and dgrad+BN-backward sums")
-        both = sorted([r for r in (rl_cl, rl_rs) if r], key=lambda r: -r["ms_per_step"])
+        rl_ring = gemm_roofline("gemm_ring_kernel", "LDS-DMA ring: the few-row fwd / dgrad / wgrad products")
+        both = sorted([r for r in (rl_cl, rl_rs, rl_ring) if r], key=lambda r: -r["ms_per_step"])
         roofline = both[0] if both else None
         roofline_second = both[1] if len(both) > 1 else None
+        roofline_third = both[2] if len(both) > 2 else None
         # largest single launch of the step: the first-level FPS (HBM class, streaming-model bytes)
         roofline_fps = None
         fps_ms = 0.0
@@ -635,6 +649,7 @@ def main():
                        "global_batch": world * BATCH_PER_GPU, "parallelism": "dp%d" % world},
             "roofline": roofline,
             "roofline_gemm2": roofline_second,
+            "roofline_gemm3": roofline_third,
             "event_bias_us": round(ev_bias * 1e3, 2),
             "event_sampled_steps": sampled,
             "roofline_fps": roofline_fps,
@@ -651,7 +666,7 @@ def main():
             "ms_per_step_eager": round(eager_ms, 3), "host_enqueue_ms_per_step_eager": round(eager_host / sampled * 1e3, 3),
             "cpu_affinity": affinity,
         }
-        for r in (out["roofline"], out["roofline_gemm2"], out["roofline_fps"], out["roofline_ball"], out["roofline_fps_ball"],
+        for r in (out["roofline"], out["roofline_gemm2"], out["roofline_gemm3"], out["roofline_fps"], out["roofline_ball"], out["roofline_fps_ball"],
                   out["roofline_cyl"]):
             if r:
                 r["measured_on"] = ("%d eager steps of the same trainer right after the timed region (HIP events around every "

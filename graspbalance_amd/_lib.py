@@ -81,6 +81,7 @@ SIGNATURES = {
     "gb_gemm_dgrad": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P, _P, _P, _P],
     "gb_gemm_wgrad": [_P, _P, _P, _P, _L, _I, _I, _P, _P],
     "gb_gemm_uses_rs": [_L, _I, _I, _I, _I, _I],
+    "gb_gemm_kernel_for": [_I, _L, _I, _I, _I, _I],
     "gb_gemm_dgrad_first": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P],
     "gb_moments3": [_P, _P, _L, _P, _P, _P],
     "gb_cyl_unique": [_P, _I, _I, _L, _I, _P, _P, _P, _P],
@@ -145,10 +146,11 @@ class GemmOpts(_c.Structure):
     """GbGemmOpts of include/graspbal.h: the per-call options of the gb_gemm_* entry points (precision, CUs left to a
     side-stream kernel, caller-owned split-reduction workspace)."""
     _fields_ = [("precision", _c.c_int), ("reserved_cus", _c.c_int), ("scratch", _c.c_void_p),
-                ("scratch_bytes", _c.c_ulonglong), ("rows_dev", _c.c_void_p)]
+                ("scratch_bytes", _c.c_ulonglong), ("rows_dev", _c.c_void_p), ("flags", _c.c_int)]
 
 
 PREC_F32, PREC_BF16 = 0, 1
+GEMM_NO_RING = 1   # GbGemmOpts.flags
 GEMM_SCRATCH_BYTES = 320 * 64 * 128 * 4
 
 

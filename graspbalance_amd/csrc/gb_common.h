@@ -124,10 +124,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 inline bool opts_bf16(const GbGemmOpts *o) { return o && o->precision == GB_PREC_BF16; }
 inline int opts_reserved(const GbGemmOpts *o) { return o ? o->reserved_cus : 0; }
 inline const long long *opts_rows(const GbGemmOpts *o) { return o ? o->rows_dev : nullptr; }
+inline bool opts_no_ring(const GbGemmOpts *o) { return o && (o->flags & GB_GEMM_NO_RING); }
 inline bool opts_bad(const GbGemmOpts *o) {
   return o && ((o->precision != GB_PREC_F32 && o->precision != GB_PREC_BF16) || o->reserved_cus < 0 ||
                o->reserved_cus > 128 || (o->scratch && reinterpret_cast<uintptr_t>(o->scratch) % 16 != 0) ||
-               (o->rows_dev && reinterpret_cast<uintptr_t>(o->rows_dev) % 8 != 0));
+               (o->rows_dev && reinterpret_cast<uintptr_t>(o->rows_dev) % 8 != 0) || (o->flags & ~GB_GEMM_NO_RING));
 }
 
 struct __attribute__((packed, aligned(4))) f3 {

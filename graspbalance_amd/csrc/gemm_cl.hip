@@ -21,6 +21,7 @@
 
 #include "gb_common.h"
 #include "gemm_rs.h"
+#include "gemm_ring.h"
 
 namespace gb {
 
@@ -511,6 +512,29 @@ static int gemm_fwd_impl(const float *x, const float *w, const float *aff, const
                   opts_rows(opts)))
     return finalize_after(check_launch("gb_gemm_fwd"), fin, stats, stat_slots, N, stream);
   if (opts_rows(opts)) return GB_EINVAL;  // a device-side row count: row-streaming kernel only
+  if (!bf16 && !(row_w16 && stats) && !opts_no_ring(opts)) {
+    // few-row products: the LDS-DMA ring kernel (csrc/gemm_ring.hip); a long reduction with few output tiles is split
+    // over workgroups into the caller's workspace and closed by the same ordered reduce + column-sum pass as below
+    RingPlan plan;
+    const long long fit = (opts && opts->scratch && P > 0) ? (long long)(opts->scratch_bytes / sizeof(float)) / (P * N) : 1;
+    ring_plan(P, N, K, fit > 1, fit, &plan);
+    if (plan.chunks > 1) {
+      float *part = static_cast<float *>(opts->scratch);
+      if (ring_gemm_try(RING_FWD, x, w, aff, part, P, K, N, nullptr, 1, nullptr, nullptr, plan, (long long)P * N,
+                        as_stream(stream))) {
+        int rc = check_launch("gb_gemm_fwd");
+        if (rc != GB_OK) return rc;
+        if (stats && N % 4 == 0 && aligned16(part) && aligned16(y) && (long long)P * N % 4 == 0)
+          return gb_split_col_stats(part, plan.chunks, y, P, N, stats, fin, stream);
+        rc = split_reduce(part, plan.chunks, (long long)P * N, y, as_stream(stream));
+        if (rc != GB_OK || !stats) return rc;
+        return gb_col_stats(y, P, N, stats, fin, stream);
+      }
+    } else if (ring_gemm_try(RING_FWD, x, w, aff, y, P, K, N, stats, stat_slots, nullptr, nullptr, plan, 0,
+                             as_stream(stream))) {
+      return finalize_after(check_launch("gb_gemm_fwd"), fin, stats, stat_slots, N, stream);
+    }
+  }
   Operand a = {x, P, K, K, aff};
   Operand b = {w, N, K, K, nullptr};
   const bool v = (K % 4 == 0) && aligned16(x) && aligned16(w);
@@ -654,6 +678,27 @@ extern "C" int gb_gemm_dgrad(const float *dy, const float *w, float *dx, const f
                   as_stream(stream), bf16, opts_reserved(opts), nullptr, nullptr, nullptr, opts_rows(opts)))
     return done(check_launch("gb_gemm_dgrad"));
   if (opts_rows(opts)) return GB_EINVAL;  // a device-side row count: row-streaming kernel only
+  if (!bf16 && !opts_no_ring(opts)) {
+    RingPlan plan;
+    const long long fit = (opts && opts->scratch && P > 0) ? (long long)(opts->scratch_bytes / sizeof(float)) / (P * K) : 1;
+    ring_plan(P, K, N, fit > 1, fit, &plan);
+    if (plan.chunks > 1) {
+      float *part = static_cast<float *>(opts->scratch);
+      if (ring_gemm_try(RING_DGRAD, dy, w, nullptr, part, P, K, N, nullptr, 1, nullptr, nullptr, plan, (long long)P * K,
+                        as_stream(stream))) {
+        int rc = check_launch("gb_gemm_dgrad");
+        if (rc != GB_OK) return rc;
+        if (dstats && K % 4 == 0 && aligned16(part) && aligned16(dx) && aligned16(y_prev))
+          return done(gb_split_bn_bwd_stats(part, plan.chunks, dx, y_prev, ab_prev, P, K, dstats, stream));
+        rc = split_reduce(part, plan.chunks, (long long)P * K, dx, as_stream(stream));
+        if (rc != GB_OK || !dstats) return rc;
+        return done(gb_bn_bwd_stats(dx, y_prev, ab_prev, nullptr, P, K, 1, dstats, nullptr, nullptr, stream));
+      }
+    } else if (ring_gemm_try(RING_DGRAD, dy, w, nullptr, dx, P, K, N, dstats, stat_slots, y_prev, ab_prev, plan, 0,
+                             as_stream(stream))) {
+      return done(check_launch("gb_gemm_dgrad"));
+    }
+  }
   Operand a = {dy, P, N, N, nullptr};
   Operand b = {w, K, N, K, nullptr};  // tile rows = k, reduction = n, element (k,n) at w[n*K + k]
   const bool va = (N % 4 == 0) && aligned16(dy);
@@ -699,6 +744,13 @@ extern "C" int gb_gemm_wgrad(const float *dy, const float *x, const float *x_aff
     else if (K == 3) hipLaunchKernelGGL(wgrad_smallk_kernel<3>, grid, dim3(GTPB), 0, as_stream(stream), dy, x, dw, P, N);
     else hipLaunchKernelGGL(wgrad_smallk_kernel<4>, grid, dim3(GTPB), 0, as_stream(stream), dy, x, dw, P, N);
     return check_launch("gb_gemm_wgrad");
+  }
+  if (!opts_bf16(opts) && !opts_rows(opts) && !opts_no_ring(opts) && P <= 131072) {
+    // few-row products: split the P reduction for ~one round of workgroups (fp32 atomics into dW, as below)
+    RingPlan plan;
+    ring_plan(N, K, P, true, 65535, &plan, 1);
+    if (ring_gemm_try(RING_WGRAD, dy, x, x_aff, dw, P, K, N, nullptr, 1, nullptr, nullptr, plan, 0, as_stream(stream)))
+      return check_launch("gb_gemm_wgrad");
   }
   Operand a = {dy, N, P, N, nullptr};  // tile rows = n, reduction = p, element (n,p) at dy[p*N + n]
   Operand b = {x, K, P, K, x_aff};     // tile rows = k, reduction = p, element (k,p) at x[p*K + k]
@@ -815,4 +867,18 @@ extern "C" int gb_moments3(const float *x, const float *row_w, long long P, doub
   if (blocks > 128) blocks = 128;
   hipLaunchKernelGGL(moments3_kernel, dim3((unsigned)blocks), dim3(GTPB), 0, as_stream(stream), x, row_w, P, mom, rows_dev);
   return check_launch("gb_moments3");
+}
+
+// Which kernel a gb_gemm_fwd (kind 0) / gb_gemm_dgrad (1) / gb_gemm_wgrad (2) call of this shape launches for 16-byte
+// aligned fp32 operands and default options: 0 = the register-staged tiles of this file, 1 = the row-streaming kernel
+// (csrc/gemm_rs.hip), 2 = the LDS-DMA ring kernel (csrc/gemm_ring.hip), 3 = the column-reduction wgrad.  Pure host-side
+// introspection (no launch), used by bench.py to attribute timings per kernel.
+extern "C" int gb_gemm_kernel_for(int kind, long long P, int K, int N, int fused_stats, int has_aff) {
+  if (kind == 2) {
+    if (K <= 4 && !has_aff && N % 4 == 0 && N / 4 <= GTPB && P >= 4096) return 3;
+    return (P % 32 == 0 && K % 4 == 0 && N % 4 == 0 && K >= 4 && N >= 4 && P <= 131072) ? 2 : 0;
+  }
+  if (gb_gemm_uses_rs(P, K, N, kind, fused_stats, has_aff)) return 1;
+  if (kind == 0) return K % 32 == 0 ? 2 : 0;
+  return (N % 32 == 0 && K % 4 == 0) ? 2 : 0;
 }

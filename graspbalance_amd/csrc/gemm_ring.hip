@@ -76,6 +76,37 @@ __device__ __forceinline__ void rg_wait_vm() {
   else static_assert(N < 0, "add the count");
 }
 
+#define RG_WAIT_LGKM(N) asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory")
+
+template <int N>
+__device__ __forceinline__ void rg_wait_lgkm() {
+  if constexpr (N == 0) RG_WAIT_LGKM(0);
+  else if constexpr (N == 2) RG_WAIT_LGKM(2);
+  else if constexpr (N == 3) RG_WAIT_LGKM(3);
+  else if constexpr (N == 4) RG_WAIT_LGKM(4);
+  else if constexpr (N == 5) RG_WAIT_LGKM(5);
+  else if constexpr (N == 6) RG_WAIT_LGKM(6);
+  else if constexpr (N == 8) RG_WAIT_LGKM(8);
+  else if constexpr (N == 10) RG_WAIT_LGKM(10);
+  else if constexpr (N == 12) RG_WAIT_LGKM(12);
+  else if constexpr (N > 12) RG_WAIT_LGKM(12);   // (the counter has 4 bits: waiting for fewer outstanding is only stricter)
+  else static_assert(N < 0, "add the count");
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 rg_ds128(unsigned addr) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+
+__device__ __forceinline__ float rg_ds32(unsigned addr) {
+  float v;
+  asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+
 __device__ __forceinline__ void rg_glds16(const float *src, float *lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                    (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
@@ -92,9 +123,11 @@ __global__ __launch_bounds__(RG_TPB, (BM == 128 && BN == 128) ? 1 : 2) void gemm
   constexpr int MT = BM / 64, NT = BN / 64;
   static_assert(!AFFA || KA == RK_KC, "a.aff is indexed by the reduction index");
   static_assert(!AFFB || KB == RK_RC, "b.aff is indexed by the tile-row index");
-  float *tab = lds + RG_STAGES * ST_FL;   // AFFA: [2][kchunk] ; AFFB: [2][BN]
+  float *tab = lds + RG_STAGES * ST_FL;   // AFFA: [2][tstride] (a, b of the chunk's reduction indices) ; AFFB: [2][256]
+  const int tstride = (int)((g.kchunk + 255) / 256 * 256);
 
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform: operand selects below stay scalar
   const int m = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const long long m0 = (long long)(blockIdx.x / g.tiles_n) * BM;
@@ -134,25 +167,26 @@ __global__ __launch_bounds__(RG_TPB, (BM == 128 && BN == 128) ? 1 : 2) void gemm
       adv[i] = (long long)RG_BK * op.ld;
     }
   }
-  auto issue_stage = [&](int slot) {
+  auto issue_part = [&](int slot, int part, int parts) {   // the wave's pieces [part * NPW / parts, (part + 1) * NPW / parts)
     float *base = lds + slot * ST_FL;
 #pragma unroll
-    for (int i = 0; i < NPW; ++i) {
-      rg_glds16(src[i], base + dst_off[i]);
-      src[i] += adv[i];
-    }
+    for (int i = 0; i < NPW; ++i)
+      if (i * parts / NPW == part) {
+        rg_glds16(src[i], base + dst_off[i]);
+        src[i] += adv[i];
+      }
   };
+  auto issue_stage = [&](int slot) { issue_part(slot, 0, 1); };
 
   // ---- prologue: the operand prologue's table, then three stages - all before the first wait
-  constexpr bool TAB = AFFA || AFFB;
   if constexpr (AFFA) {
-    // [a(kchunk), b(kchunk)]: 2 * kchunk floats = kchunk / 128 pieces per half; the waves split them
-    const int per_half = (int)(g.kchunk / 256);     // pieces of 1 KB per half (kchunk % 256 == 0: host-checked)
+    // [a(chunk), b(chunk)] in 1 KB pieces (256 floats; lanes past the end repeat the last chunk); the waves split them
+    const int per_half = tstride / 256;
     for (int p = wave; p < 2 * per_half; p += 4) {
       const int half = p >= per_half, pp = half ? p - per_half : p;
       long long k = kbeg + pp * 256 + lane * 4;
       if (k > g.red - 4) k = g.red - 4;
-      rg_glds16(g.a.aff + (half ? g.red : 0) + k, tab + (size_t)half * g.kchunk + pp * 256);
+      rg_glds16(g.a.aff + (half ? g.red : 0) + k, tab + half * tstride + pp * 256);
     }
   }
   if constexpr (AFFB) {
@@ -177,8 +211,100 @@ __global__ __launch_bounds__(RG_TPB, (BM == 128 && BN == 128) ? 1 : 2) void gemm
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // ---- fragment addresses (bytes, relative to the start of a stage).  Every LDS read of the loop is an inline-asm
+  // ds_read: a read the compiler can see makes it wait vmcnt(0) first (it cannot tell the slot being read from the slots
+  // the DMA is still filling), which would drain the ring at every step.  Waits are therefore placed by hand.
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lds;
+  unsigned a_kc[KA == RK_KC ? MT : 1][4], b_kc[KB == RK_KC ? NT : 1][4];   // [block][cq]: the lane's chunk of group cq
+  unsigned a_rc[KA == RK_RC ? MT : 1], b_rc[KB == RK_RC ? NT : 1];         // [block]: the lane's column, reduction row 0
+  if constexpr (KA == RK_KC) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int r = wm * (BM / 2) + i * 32 + m;
+#pragma unroll
+      for (int cq = 0; cq < 4; ++cq) a_kc[i][cq] = (unsigned)((r * 8 + ((2 * cq + h) ^ ((r >> 1) & 7))) * 16);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a_rc[i] = (unsigned)((h * BM + wm * (BM / 2) + i * 32 + m) * 4);   // natural order: row 2s + h
+  }
+  if constexpr (KB == RK_KC) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int r = wn * (BN / 2) + j * 32 + m;
+#pragma unroll
+      for (int cq = 0; cq < 4; ++cq) b_kc[j][cq] = (unsigned)(A_FL * 4 + (r * 8 + ((2 * cq + h) ^ ((r >> 1) & 7))) * 16);
+    }
+  } else {
+    // the reduction row this lane half contributes to slice (cq, e): 8 cq + 4 h + e beside a KC partner, 8 cq + 2 e + h else
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+      b_rc[j] = (unsigned)(A_FL * 4 + ((KA == RK_KC ? 4 * h : h) * BN + wn * (BN / 2) + j * 32 + m) * 4);
+  }
+  constexpr unsigned RC_E = (KA == RK_KC ? 1 : 2);   // reduction rows between consecutive slices e of a group
+  const unsigned tab0 = lds0 + (unsigned)(RG_STAGES * ST_FL * 4);
+
   float fa_b[NT], fb_b[NT];   // AFFB: this lane's column coefficients
   (void)fa_b; (void)fb_b;
+
+  // one group = MFMA slices 4cq .. 4cq+3 of a step: MT (+2 table) + NT 16-byte reads, or 4 single reads per RC block
+  struct Frag { f32x4 a[MT], b[NT], ta, tb; };
+  auto read_group = [&](Frag &f, unsigned sbase, int cq, int kk) {
+    if constexpr (KA == RK_KC) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) f.a[i] = rg_ds128(sbase + a_kc[i][cq]);
+      if constexpr (AFFA) {
+        f.ta = rg_ds128(tab0 + (unsigned)((kk + 4 * (2 * cq + h)) * 4));
+        f.tb = rg_ds128(tab0 + (unsigned)((tstride + kk + 4 * (2 * cq + h)) * 4));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f.a[i][e] = rg_ds32(sbase + a_rc[i] + (unsigned)((8 * cq + 2 * e) * BM * 4));
+    }
+    if constexpr (KB == RK_KC) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) f.b[j] = rg_ds128(sbase + b_kc[j][cq]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f.b[j][e] = rg_ds32(sbase + b_rc[j] + (unsigned)((8 * cq + RC_E * e) * BN * 4));
+    }
+  };
+  constexpr int READS = (KA == RK_KC ? MT + (AFFA ? 2 : 0) : 4 * MT) + (KB == RK_KC ? NT : 4 * NT);   // per group
+  auto mfma_group = [&](Frag &f, bool dma, int slot, int part) {
+    if constexpr (AFFA) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float z = f.ta[e] * f.a[i][e] + f.tb[e];
+          f.a[i][e] = z > 0.f ? z : 0.f;
+        }
+    }
+    if constexpr (AFFB) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float z = fa_b[j] * f.b[j][e] + fb_b[j];
+          f.b[j][e] = z > 0.f ? z : 0.f;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][e], f.b[j][e], acc[i][j], 0, 0, 0);
+      // this group's share of the next stage's DMA goes out behind the first MFMAs: its issue slots (60 - 180 cycles per
+      // piece) then lie in the shadow of the matrix pipe instead of in front of the step
+      if (e == 0 && dma) issue_part(slot, part, 4);
+    }
+  };
 
   for (int step = 0; step < T; ++step) {
     // stages issued so far: min(T, step + 3); the ones after `step` may stay in flight
@@ -186,100 +312,75 @@ __global__ __launch_bounds__(RG_TPB, (BM == 128 && BN == 128) ? 1 : 2) void gemm
     if (ahead >= 2) rg_wait_vm<2 * NPW>();
     else if (ahead == 1) rg_wait_vm<NPW>();
     else rg_wait_vm<0>();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the previous step's fragment reads have retired: WAR on its slot)
-    __builtin_amdgcn_s_barrier();
-    if (step + RG_STAGES - 1 < T) issue_stage((step + RG_STAGES - 1) % RG_STAGES);
+    __builtin_amdgcn_s_barrier();   // every wave's share of stage `step` has landed; all reads of stage step-1 retired
+    __builtin_amdgcn_sched_barrier(0);
+    const bool dma = step + RG_STAGES - 1 < T;
+    const int nslot = (step + RG_STAGES - 1) % RG_STAGES;
     if constexpr (AFFB) {
       if (step == 0) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          fa_b[j] = tab[wn * (BN / 2) + j * 32 + m];
-          fb_b[j] = tab[256 + wn * (BN / 2) + j * 32 + m];
+          fa_b[j] = rg_ds32(tab0 + (unsigned)((wn * (BN / 2) + j * 32 + m) * 4));
+          fb_b[j] = rg_ds32(tab0 + (unsigned)((256 + wn * (BN / 2) + j * 32 + m) * 4));
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
-    const float *As = lds + (step % RG_STAGES) * ST_FL;
-    const float *Bs = As + A_FL;
+    const unsigned sbase = lds0 + (unsigned)((step % RG_STAGES) * ST_FL * 4);
     const int kk = step * RG_BK;   // offset of this step inside the chunk (table index)
-#pragma unroll
-    for (int cq = 0; cq < 4; ++cq) {
-      // ---- fragments of MFMA slices 4cq .. 4cq+3
-      float av[MT][4], bv[NT][4];
-      if constexpr (KA == RK_KC) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const int r = wm * (BM / 2) + i * 32 + m;
-          const float4 q = *reinterpret_cast<const float4 *>(As + (r * 8 + ((2 * cq + h) ^ ((r >> 1) & 7))) * 4);
-          av[i][0] = q.x; av[i][1] = q.y; av[i][2] = q.z; av[i][3] = q.w;
-        }
-        if constexpr (AFFA) {
-          const float4 ta = *reinterpret_cast<const float4 *>(tab + kk + 4 * (2 * cq + h));
-          const float4 tb = *reinterpret_cast<const float4 *>(tab + g.kchunk + kk + 4 * (2 * cq + h));
-          const float ca[4] = {ta.x, ta.y, ta.z, ta.w}, cb[4] = {tb.x, tb.y, tb.z, tb.w};
-#pragma unroll
-          for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float z = ca[e] * av[i][e] + cb[e];
-              av[i][e] = z > 0.f ? z : 0.f;
-            }
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            av[i][e] = As[(KB == RK_RC ? 2 * (4 * cq + e) + h : 4 * (2 * cq + h) + e) * BM + wm * (BM / 2) + i * 32 + m];
-      }
-      if constexpr (KB == RK_KC) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int r = wn * (BN / 2) + j * 32 + m;
-          const float4 q = *reinterpret_cast<const float4 *>(Bs + (r * 8 + ((2 * cq + h) ^ ((r >> 1) & 7))) * 4);
-          bv[j][0] = q.x; bv[j][1] = q.y; bv[j][2] = q.z; bv[j][3] = q.w;
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            // the reduction index this lane half contributes to slice 4cq + e: the KC partner's order, or the natural one
-            const int rr = KA == RK_KC ? 4 * (2 * cq + h) + e : 2 * (4 * cq + e) + h;
-            float v = Bs[rr * BN + wn * (BN / 2) + j * 32 + m];
-            if constexpr (AFFB) {
-              const float z = fa_b[j] * v + fb_b[j];
-              v = z > 0.f ? z : 0.f;
-            }
-            bv[j][e] = v;
-          }
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
-    }
+    // two fragment sets: the reads of group cq+1 are in flight under the MFMAs of group cq
+    Frag f0, f1;
+    read_group(f0, sbase, 0, kk);
+    read_group(f1, sbase, 1, kk);
+    rg_wait_lgkm<READS>();            // group 0 has arrived (LDS operations retire in order)
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(f0, dma, nslot, 0);
+    read_group(f0, sbase, 2, kk);
+    rg_wait_lgkm<READS>();            // group 1
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(f1, dma, nslot, 1);
+    read_group(f1, sbase, 3, kk);
+    rg_wait_lgkm<READS>();            // group 2
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(f0, dma, nslot, 2);
+    rg_wait_lgkm<0>();                // group 3: every read of this stage has retired before the next barrier
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(f1, dma, nslot, 3);
   }
 
   // ---- epilogue: acc[i][j][r] = D[m0 + wm*BM/2 + i*32 + (r&3) + 8*(r>>2) + 4*h][n0 + wn*BN/2 + j*32 + m]
   float csum[NT], csq[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
+  // RG_BNBWD: every y value and column coefficient the tile needs is requested before the first one is used (one memory
+  // round trip for the tile instead of one per 32 x 32 block)
+  float ea[EPI == RG_BNBWD ? NT : 1], eb[EPI == RG_BNBWD ? NT : 1], em[EPI == RG_BNBWD ? NT : 1], er[EPI == RG_BNBWD ? NT : 1];
+  float yv[EPI == RG_BNBWD ? MT : 1][EPI == RG_BNBWD ? NT : 1][16];
+  if constexpr (EPI == RG_BNBWD) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const long long col = n0 + wn * (BN / 2) + j * 32 + m;
+      const bool ok = col < g.b.rows;
+      ea[j] = ok ? g.epi_ab[col] : 0.f;
+      eb[j] = ok ? g.epi_ab[g.b.rows + col] : 0.f;
+      em[j] = ok ? g.epi_ab[2 * g.b.rows + col] : 0.f;
+      er[j] = ok ? g.epi_ab[3 * g.b.rows + col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long long row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          yv[i][j][r] = (ok && row < g.a.rows) ? g.epi_y[row * g.ldd + col] : 0.f;
+        }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const long long col = n0 + wn * (BN / 2) + j * 32 + m;
       const bool colok = col < g.b.rows;
-      float ea = 0.f, eb = 0.f, emean = 0.f, erstd = 0.f;
-      if constexpr (EPI == RG_BNBWD) {
-        if (colok) {
-          ea = g.epi_ab[col]; eb = g.epi_ab[g.b.rows + col]; emean = g.epi_ab[2 * g.b.rows + col];
-          erstd = g.epi_ab[3 * g.b.rows + col];
-        }
-      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const long long row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -292,10 +393,10 @@ __global__ __launch_bounds__(RG_TPB, (BM == 128 && BN == 128) ? 1 : 2) void gemm
             csq[j] += v * v;
           }
           if constexpr (EPI == RG_BNBWD) {
-            const float y = g.epi_y[row * g.ldd + col];
-            const float gg = (ea * y + eb) > 0.f ? v : 0.f;
+            const float y = yv[i][j][r];
+            const float gg = (ea[j] * y + eb[j]) > 0.f ? v : 0.f;
             csum[j] += gg;
-            csq[j] += gg * ((y - emean) * erstd);
+            csq[j] += gg * ((y - em[j]) * er[j]);
           }
         }
       }
@@ -333,7 +434,7 @@ static void rg_launch(const RingArgs &g, long long tiles_m, unsigned chunks, hip
   auto kern = gemm_ring_kernel<KA, KB, BM, BN, EPI, AFFA, AFFB>;
   allow_dynamic_lds(kern, 160 * 1024, attr_set);
   size_t lds = (size_t)RG_STAGES * (BM + BN) * RG_BK * sizeof(float);
-  if (AFFA) lds += 2 * (size_t)g.kchunk * sizeof(float);
+  if (AFFA) lds += 2 * (size_t)((g.kchunk + 255) / 256 * 256) * sizeof(float);
   if (AFFB) lds += 2 * 256 * sizeof(float);
   hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * g.tiles_n), chunks), dim3(RG_TPB), lds, s, g);
 }
@@ -349,24 +450,40 @@ static void rg_launch_tile(RingArgs &g, bool big, unsigned chunks, hipStream_t s
   }
 }
 
-// Tile and split of one product (M x N output, reduction `red`): 128 x 128 tiles when they alone give every CU work,
-// else 64 x 64; `want_split`: the caller can take partial products (a workspace for forward / dgrad, atomics for wgrad).
-void ring_plan(long long M, long long N, long long red, bool want_split, long long max_chunks, RingPlan *p) {
-  const long long t128 = ((M + 127) / 128) * ((N + 127) / 128), t64 = ((M + 63) / 64) * ((N + 63) / 64);
-  p->big = t128 >= 224;
-  const long long tiles = p->big ? t128 : t64;
-  long long chunks = 1;
-  if (want_split && tiles < 192 && red >= 512) {
-    chunks = 320 / tiles;
-    if (chunks > red / 256) chunks = red / 256;   // at least 8 steps per workgroup, table pieces of whole kilobytes
-    if (chunks > max_chunks) chunks = max_chunks;
-    if (chunks < 1) chunks = 1;
+// Tile and split of one product (M x N output, reduction `red`) by a small cost model (microseconds; constants from
+// tools/ring_prof.sh on MI355X).  A workgroup costs a fixed ~5 us (launch, cold first loads, epilogue) + its reduction
+// steps: 32 x 32 x 2 MFMAs of 64 cycles, 64 per wave and step for a 128 x 128 tile (one workgroup per CU: 136 KB of LDS),
+// 16 for a 64 x 64 tile (two per CU, sharing the matrix pipes).  Splitting the reduction buys more workgroups at the price
+// of a closing pass (forward / dgrad: partial products through the caller's workspace, `pass_bytes` per chunk and
+// `pass_us` for the extra launch) or of more atomics (wgrad: 1.3 TB/s of float atomics).
+void ring_plan(long long M, long long N, long long red, bool want_split, long long max_chunks, RingPlan *p, int atomics) {
+  const double FIXED = 5.0, STEP_BIG = 1.95, STEP_SMALL = 0.49, CUS = 256.0;
+  double best = 1e30;
+  p->big = false; p->chunks = 1; p->kchunk = red;
+  for (int big = 0; big < 2; ++big) {
+    const long long T0 = big ? 128 : 64;
+    if (big && (M < 128 || N < 128)) continue;
+    const long long tiles = ((M + T0 - 1) / T0) * ((N + T0 - 1) / T0);
+    for (long long chunks = 1; chunks <= 64; chunks *= 2) {
+      if (chunks > 1 && (!want_split || chunks > max_chunks)) break;
+      long long kc = (red + chunks - 1) / chunks;
+      kc = (kc + 31) / 32 * 32;
+      if (chunks > 1 && kc < 128) break;
+      const long long nch = (red + kc - 1) / kc;
+      const double steps = (double)(kc / 32);
+      const double wgs = (double)(tiles * nch);
+      double t;
+      if (big) t = ceil(wgs / CUS) * (FIXED + steps * STEP_BIG);
+      else t = ceil(wgs / (2 * CUS)) * (FIXED + steps * STEP_SMALL * (wgs > CUS ? 2.0 : 1.0));
+      if (nch > 1) {
+        const double bytes = (double)M * N * 4.0;
+        t += atomics ? nch * bytes / 1.3e6 : 4.0 + (nch + 1) * bytes / 3.0e6;   // bytes / (TB/s) = 1e-6 us
+      } else if (atomics) {
+        t += (double)M * N * 4.0 / 1.3e6;
+      }
+      if (t < best) { best = t; p->big = big != 0; p->chunks = (int)nch; p->kchunk = kc; }
+    }
   }
-  long long kc = (red + chunks - 1) / chunks;
-  kc = (kc + 255) / 256 * 256;
-  if (kc > red) kc = red;
-  p->kchunk = kc;
-  p->chunks = (int)((red + kc - 1) / kc);
 }
 
 bool ring_gemm_try(int kind, const float *a, const float *b, const float *aff, float *d, long long P, int K, int N,
@@ -386,7 +503,7 @@ bool ring_gemm_try(int kind, const float *a, const float *b, const float *aff, f
   if (kind == RING_FWD) {
     // Y (P,N) = f(X (P,K)) W (N,K)^T: both reduction-contiguous
     if (K % RG_BK != 0 || K % 4 != 0 || P < 1 || N < 1) return false;
-    if (aff && (plan.kchunk % 256 != 0 || K % 4 != 0 || 2 * plan.kchunk * sizeof(float) > 24 * 1024)) return false;
+    if (aff && 2 * (size_t)plan.kchunk * sizeof(float) > 16 * 1024) return false;   // the table's share of the LDS
     g.a = {a, P, K, aff};
     g.b = {b, N, K, nullptr};
     g.ldd = N;

@@ -74,6 +74,7 @@ _PREC_CODE = {"f32": _lib.PREC_F32, "fp32": _lib.PREC_F32, "float32": _lib.PREC_
 _PREC_NAME = {_lib.PREC_F32: "f32", _lib.PREC_BF16: "bf16"}
 _tls = threading.local()
 _RESERVED_CUS = 0
+_GEMM_FLAGS = _lib.GEMM_NO_RING if os.environ.get("GB_RING", "1") == "0" else 0   # A/B switch: few-row GEMM kernel
 _WORKSPACES = {}
 _OPTS = {}
 
@@ -126,18 +127,28 @@ def _prec():
 def _opts(dev, st, prec, rows_dev=None):
     """ctypes pointer to the GbGemmOpts of a launch on stream `st` (c_void_p) of `dev` at precision code `prec`;
     rows_dev: one-element int64 device tensor holding the call's actual row count (GbGemmOpts.rows_dev) or None."""
-    key = (dev.index, st.value, prec, _RESERVED_CUS)
+    key = (dev.index, st.value, prec, _RESERVED_CUS, _GEMM_FLAGS)
     o = _OPTS.get(key)
     if o is None:
         wkey = (dev.index, st.value)
         ws = _WORKSPACES.get(wkey)
         if ws is None:
             ws = _WORKSPACES[wkey] = torch.empty(_lib.GEMM_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
-        o = _OPTS[key] = (ctypes.pointer(_lib.GemmOpts(prec, _RESERVED_CUS, ws.data_ptr(), ws.numel(), None)), ws)
+        o = _OPTS[key] = (ctypes.pointer(_lib.GemmOpts(prec, _RESERVED_CUS, ws.data_ptr(), ws.numel(), None, _GEMM_FLAGS)), ws)
     if rows_dev is None:
         return o[0]
     # (not cached: the count's address changes from step to step; the struct only has to outlive the synchronous call)
-    return ctypes.pointer(_lib.GemmOpts(prec, _RESERVED_CUS, o[1].data_ptr(), o[1].numel(), rows_dev.data_ptr()))
+    return ctypes.pointer(_lib.GemmOpts(prec, _RESERVED_CUS, o[1].data_ptr(), o[1].numel(), rows_dev.data_ptr(),
+                                        _GEMM_FLAGS))
+
+
+def set_ring_gemm(flag):
+    """Few-row fp32 products on the LDS-DMA ring kernel (csrc/gemm_ring.hip; default) or, False, on the register-staged
+    tiles of csrc/gemm_cl.hip (GbGemmOpts.flags = GB_GEMM_NO_RING).  -> previous setting."""
+    global _GEMM_FLAGS
+    prev = not (_GEMM_FLAGS & _lib.GEMM_NO_RING)
+    _GEMM_FLAGS = 0 if flag else _lib.GEMM_NO_RING
+    return prev
 
 
 def set_own_gemm(flag):
@@ -301,12 +312,10 @@ def _gemm_meta(kind, P, K, N, fused=False, aff=False, rows_dev=None):
     cap = P
     if rows_dev is not None:
         P = int(rows_dev)
-    if kind == "wgrad":
-        smallk = K <= 4 and not aff and N % 4 == 0 and N <= 1024 and P >= 4096  # gb_gemm_wgrad's dispatch rule
-        kernel = "wgrad_smallk_kernel" if smallk else "gemm_cl_kernel"
-    else:
-        rs = _lib.lib().gb_gemm_uses_rs(cap, K, N, int(kind == "dgrad"), int(fused), int(aff))
-        kernel = "gemm_rs_kernel" if rs else "gemm_cl_kernel"
+    which = _lib.lib().gb_gemm_kernel_for({"fwd": 0, "dgrad": 1, "wgrad": 2}[kind], cap, K, N, int(fused), int(aff))
+    if which == 2 and (_GEMM_FLAGS & _lib.GEMM_NO_RING or _prec() != _lib.PREC_F32 or rows_dev is not None):
+        which = 0
+    kernel = ("gemm_cl_kernel", "gemm_rs_kernel", "gemm_ring_kernel", "wgrad_smallk_kernel")[which]
     return {"flop": 2.0 * P * K * N, "pkn": (P, K, N), "kernel": kernel}
 
 

@@ -99,14 +99,14 @@ def ObjectBalanceSampling(end_points):
     return _resample_seeds(end_points, picks)
 
 
-# Which grasp heads run on the fused channel-last stack (own MFMA GEMMs) instead of Conv1d / BatchNorm1d through
-# torch: "0" = none (default), "gd" = GraspableDetection, "1" = also the stage-2 tail (scale fusion, gate, the two
-# depth heads).  Measured on one box (tools/ab_bench.sh, ms per step): none 22.6, gd 22.8-23.2, all 23.6-24.7 - the
-# 4 096 / 16 384-row products of the heads are too short for the row-streaming GEMM and too few for the tiled one
-# (MIOpen / rocBLAS are no faster per product, but their conv+BN+ReLU take fewer passes) - and the tail on own
-# kernels moves the grasp scores from 7e-6 to 9e-6..1.5e-5 of the fp64 truth.  The path stays available and tested
-# (tests/test_reference_fixtures_gpu.py) for hosts where launch count matters more than GPU time.
-_HEADS_MODE = os.environ.get("GB_HEADS_FUSED", "0")
+# Which grasp heads run on the fused channel-last stack (own MFMA GEMMs) instead of Conv1d / BatchNorm1d through torch
+# (MIOpen / rocBLAS): "1" = all of them (default since round 4: GraspableDetection and the stage-2 tail - scale fusion,
+# gate, the two depth heads), "gd" = GraspableDetection only, "0" = none.  History (ms per step, one box each): rounds 2-3
+# none 22.6, gd 22.8-23.2, all 23.6-24.7 - the 4 096 / 16 384-row products of the heads were too short for the
+# row-streaming GEMM and too slow on the register-staged tiles; with the LDS-DMA ring kernel (csrc/gemm_ring.hip) all
+# 19.13, gd 19.22, none 19.31.  The tail on own kernels moves the grasp scores from 7e-6 to 9e-6..1.5e-5 of the fp64
+# truth on the by-key random network (tests/test_parity_f64_gpu.py).
+_HEADS_MODE = os.environ.get("GB_HEADS_FUSED", "1")
 _HEADS_FUSED = _HEADS_MODE == "1"
 _GD_FUSED = _HEADS_MODE in ("1", "gd")
 

@@ -279,12 +279,17 @@ int gb_group_concat_cl_grad(const float *dx0, const int32_t *idx, float *dfeat, 
  *                 gb_gemm_wgrad_gen3, gb_gemm_dgrad_first_gen3 and by gb_gemm_fwd / gb_gemm_dgrad / gb_gemm_dgrad_first
  *                 on the row-streaming kernel (ask gb_gemm_uses_rs); every other case returns GB_EINVAL rather than
  *                 ignore it.                                                                                       */
+/*   flags       : GB_GEMM_NO_RING - few-row fp32 products (gb_gemm_fwd / _dgrad / _wgrad) skip the LDS-DMA ring kernel
+ *                 (csrc/gemm_ring.hip) and run on the register-staged tiles of csrc/gemm_cl.hip: an A/B and fallback
+ *                 switch, results equal to fp32 rounding (a different summation order).                            */
+#define GB_GEMM_NO_RING 1
 typedef struct GbGemmOpts {
   int precision;
   int reserved_cus;
   void *scratch;
   unsigned long long scratch_bytes;
   const long long *rows_dev;
+  int flags;
 } GbGemmOpts;
 
 /* The arguments of gb_bn_finalize as a struct: entry points that produce BatchNorm sums take an optional pointer to
@@ -494,6 +499,10 @@ int gb_gemm_wgrad(const float *dy, const float *x, const float *x_aff, float *dw
  * this shape: 1 = the row-streaming kernel (csrc/gemm_rs.hip), 0 = the LDS-tiled one (csrc/gemm_cl.hip).
  * Pure host-side introspection (no launch), used by bench.py to attribute timings per kernel.      */
 int gb_gemm_uses_rs(long long P, int K, int N, int dgrad, int fused_stats, int has_aff);
+/* ... and, for all three products (kind 0 = gb_gemm_fwd, 1 = gb_gemm_dgrad, 2 = gb_gemm_wgrad; fp32, default options):
+ * 0 = register-staged LDS tiles (csrc/gemm_cl.hip), 1 = row-streaming (csrc/gemm_rs.hip), 2 = LDS-DMA ring
+ * (csrc/gemm_ring.hip: the few-row products), 3 = the column-reduction wgrad for <= 4 input channels.             */
+int gb_gemm_kernel_for(int kind, long long P, int K, int N, int fused_stats, int has_aff);
 /* dgrad into the first layer of a stack whose input x_in (P,3) has 3 channels: dZ = dY (P,N) W (N,K) is formed
  * but not stored; sums fp64 [slots][5K] (caller-zeroed) += column sums of [g, g*xhat, g*x_0, g*x_1, g*x_2] with
  * g = dZ*[a*y+b > 0], xhat = (y - mean)*rstd, y = y_prev (P,K) the layer's pre-BatchNorm output, ab_prev =

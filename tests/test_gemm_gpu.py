@@ -15,7 +15,11 @@ SHAPES = [(1000, 3, 64), (4096, 64, 64), (5000, 131, 128), (777, 259, 256), (204
           # ... with a short last round of tiles, which the kernel cuts into column groups (8, 4 and 2 of them)
           (67601, 128, 256), (133003, 64, 64),
           # few input channels: the column-reduction wgrad (wgrad_smallk_kernel)
-          (9001, 3, 64), (5000, 4, 40), (66000, 1, 128)]
+          (9001, 3, 64), (5000, 4, 40), (66000, 1, 128),
+          # the few-row products of the step (csrc/gemm_ring.hip: 64 x 64 and 128 x 128 tiles, split reductions, ragged rows)
+          (4096, 256, 1024), (4096, 1024, 256), (8192, 128, 512), (8192, 512, 128), (2048, 1024, 256), (1024, 1024, 256),
+          (1024, 256, 1024), (16384, 1024, 256), (16384, 256, 128), (4096, 256, 256), (4100, 256, 260), (1000, 512, 96),
+          (96, 1024, 64), (4064, 32, 64)]
 
 
 def _lib():

@@ -11,7 +11,7 @@ from graspbalance_amd.loss import get_loss
 from graspbalance_amd.label_generation import process_grasp_labels
 
 batch = make_training_batch(range(4), 20000, device="cuda:0")
-tr = Trainer("cuda:0")
+tr = Trainer("cuda:0", graph=False)
 for _ in range(3):
     tr.train_step(batch)
 torch.cuda.synchronize()
@@ -55,5 +55,5 @@ for name, ev in report.items():
     n = sum(e.count for e in ev)
     us = sum(e.self_device_time_total for e in ev)
     print("== %-16s %4d launches %8.1f us" % (name, n, us))
-    for e in sorted(ev, key=lambda e: -e.self_device_time_total)[:40]:
+    for e in sorted(ev, key=lambda e: -e.self_device_time_total)[:60]:
         print("      %-26s n=%3d %7.1f us  %s" % (e.key[:26], e.count, e.self_device_time_total, str(e.input_shapes)[:90]))

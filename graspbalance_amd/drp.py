@@ -127,7 +127,7 @@ class InvResMLP(nn.Module):
         p, f = pf
         if fused_mlp.enabled(f) and self.fusable():
             out = self.forward_cl(p, f.transpose(1, 2).contiguous())
-            return [p, out.transpose(1, 2).contiguous()]
+            return [p, out.transpose(1, 2)]
         identity = f
         f = self.pwconv(self.convs([p, f]))
         if f.shape[-1] == identity.shape[-1] and self.use_res:
@@ -153,7 +153,7 @@ def run_stage(blocks, p, f):
     f_cl = f.transpose(1, 2).contiguous()
     for blk in blocks:
         f_cl = blk.forward_cl(p, f_cl, idx, geo)
-    return p, f_cl.transpose(1, 2).contiguous()
+    return p, f_cl.transpose(1, 2)   # a view: the next consumer's transpose(1, 2).contiguous() costs nothing
 
 
 class ResBlock(nn.Module):

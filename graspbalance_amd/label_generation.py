@@ -8,7 +8,7 @@ import torch
 
 from .knn_modules import myknn
 from .loss_utils import (GRASP_MAX_WIDTH, batch_viewpoint_params_to_matrix, generate_grasp_views,
-                         grasp_views_on, transform_point_cloud)
+                         grasp_view_rotations_on, grasp_views_on, transform_point_cloud)
 
 
 def _nearest(ref_points, query_points):
@@ -30,6 +30,22 @@ def _row_ids(sizes, first_obj, device):
         oid = torch.cat([torch.full((n,), first_obj + k, dtype=torch.int32) for k, n in enumerate(sizes)])
         loc = torch.cat([torch.arange(n, dtype=torch.int32) for n in sizes])
         _ROW_ID_CACHE[key] = (oid.to(device), loc.to(device))
+    return _ROW_ID_CACHE[key]
+
+
+def _row_ids_all(sizes, device):
+    """_row_ids of every cloud of the batch, concatenated (object ids count on through the batch)."""
+    key = ("all", sizes, str(device))
+    if key not in _ROW_ID_CACHE:
+        if len(_ROW_ID_CACHE) > 256:
+            _ROW_ID_CACHE.clear()
+        oids, locs, k0 = [], [], 0
+        for sz in sizes:
+            oid, loc = _row_ids(sz, k0, device)
+            oids.append(oid)
+            locs.append(loc)
+            k0 += len(sz)
+        _ROW_ID_CACHE[key] = (torch.cat(oids), torch.cat(locs))
     return _ROW_ID_CACHE[key]
 
 
@@ -164,7 +180,7 @@ def _process_grasp_labels_fused(end_points):
     _, V, A, D = labels_l[0].shape
     view_inds = _assign_views(all_poses, V).contiguous()                         # (Kt,V) int64
     views = grasp_views_on(dev, V)
-    rot_template = batch_viewpoint_params_to_matrix(-views, torch.zeros(V, dtype=views.dtype, device=dev))
+    rot_template = grasp_view_rotations_on(dev, V)   # == batch_viewpoint_params_to_matrix(-views, 0): a constant
     R = all_poses[:, :3, :3]
     views_trans = torch.matmul(R, views.T).transpose(1, 2)                       # (Kt,V,3)
     # R_k @ T_v for every (object, view) as ONE (3 Kt x 3) @ (3 x 3 V) product instead of a 3x3 bmm with Kt*V batches
@@ -174,34 +190,51 @@ def _process_grasp_labels_fused(end_points):
         .view(Kt, 3, V, 3).permute(0, 2, 1, 3)                                   # (Kt,V,3,3), strided
     views_sel = torch.gather(views_trans, 1, view_inds.unsqueeze(-1).expand(-1, -1, 3))
     rot_sel = torch.gather(rot_trans, 1, view_inds.view(-1, V, 1, 1).expand(-1, -1, 3, 3))
-    obj_of_seed, pt_of_seed, points = [], [], []
-    k0 = 0
     gps_l = end_points['grasp_points_list']
     pts_all = _transform_all([gp for gps in gps_l for gp in gps], all_poses)  # every object's grasp points, camera frame
-    p0 = 0
-    for i in range(B):
-        gps = gps_l[i]
-        n_i = sum(int(gp.size(0)) for gp in gps)
-        pts = pts_all[p0:p0 + n_i]  # == cat([transform_point_cloud(gp, pose, '3x4') for the cloud's objects])
-        p0 += n_i
-        # (object id, point id within the object) of every row of pts: depends on the sizes only - built once per
-        # size pattern instead of a full_() + arange() pair per object per step
-        oid, loc = _row_ids(tuple(int(gp.size(0)) for gp in gps), k0, dev)
-        k0 += len(poses_l[i])
-        nn_inds = _nearest(pts, seed_xyzs[i])
-        points.append(torch.index_select(pts, 0, nn_inds))
-        obj_of_seed.append(torch.index_select(oid, 0, nn_inds))
-        pt_of_seed.append(torch.index_select(loc, 0, nn_inds))
-    obj = torch.cat(obj_of_seed, 0).contiguous()
-    pt = torch.cat(pt_of_seed, 0).contiguous()
+    sizes = tuple(tuple(int(gp.size(0)) for gp in gps) for gps in gps_l)
+    per_cloud = [sum(sz) for sz in sizes]
+    if len(set(per_cloud)) == 1 and per_cloud[0] > 0:
+        # every cloud brings the same number of grasp points (always true for a fixed number of points per object): the B
+        # nearest-grasp-point searches are ONE batched kNN launch and the three row gathers one each - the same values
+        # as the per-cloud calls below (the kernel treats batch elements independently; lowest index among equals)
+        n = per_cloud[0]
+        ref = pts_all.view(B, n, 3).transpose(1, 2).contiguous()
+        query = seed_xyzs.transpose(1, 2).contiguous()
+        nn_inds = myknn(ref, query, k=1).view(B, Ns) - 1
+        flat = (nn_inds + torch.arange(B, device=dev, dtype=nn_inds.dtype).view(B, 1) * n).view(-1)
+        oid, loc = _row_ids_all(sizes, dev)
+        points = torch.index_select(pts_all, 0, flat).view(B, Ns, 3)
+        obj = torch.index_select(oid, 0, flat)
+        pt = torch.index_select(loc, 0, flat)
+    else:
+        obj_of_seed, pt_of_seed, points = [], [], []
+        k0 = 0
+        p0 = 0
+        for i in range(B):
+            gps = gps_l[i]
+            n_i = per_cloud[i]
+            pts = pts_all[p0:p0 + n_i]  # == cat([transform_point_cloud(gp, pose, '3x4') for the cloud's objects])
+            p0 += n_i
+            # (object id, point id within the object) of every row of pts: depends on the sizes only - built once per
+            # size pattern instead of a full_() + arange() pair per object per step
+            oid, loc = _row_ids(sizes[i], k0, dev)
+            k0 += len(poses_l[i])
+            nn_inds = _nearest(pts, seed_xyzs[i])
+            points.append(torch.index_select(pts, 0, nn_inds))
+            obj_of_seed.append(torch.index_select(oid, 0, nn_inds))
+            pt_of_seed.append(torch.index_select(loc, 0, nn_inds))
+        obj = torch.cat(obj_of_seed, 0).contiguous()
+        pt = torch.cat(pt_of_seed, 0).contiguous()
+        points = torch.stack(points, 0)
     objl = obj.long()
     if end_points.get(LEAN) and 'grasp_top_view_inds' in end_points:
         return _lean_labels(end_points, labels_l, offsets_l, tol_l, obj, pt, view_inds, views_sel, rot_sel, objl,
-                            torch.stack(points, 0), B, Ns, V, A, D)
+                            points, B, Ns, V, A, D)
     label, label_max = _label_gather(labels_l, obj, pt, view_inds, V, A * D, want_max=True)
     offset, width = _label_gather(offsets_l, obj, pt, view_inds, V, A * D * 3, col=(3, 2))
     batch = {
-        'point': torch.stack(points, 0),
+        'point': points,
         'view': torch.index_select(views_sel, 0, objl).view(B, Ns, V, 3),
         'view_rot': torch.index_select(rot_sel, 0, objl).view(B, Ns, V, 3, 3),
         'label': label.view(B, Ns, V, A, D),

@@ -48,6 +48,21 @@ def grasp_views_on(device, N=300):
     return _VIEW_DEVICE_CACHE[key]
 
 
+_VIEW_ROT_CACHE = {}
+
+
+def grasp_view_rotations_on(device, N=300):
+    """batch_viewpoint_params_to_matrix(-views, 0) of the N template views, (N,3,3), resident on `device` and computed
+    once: a constant of the model (every seed's approach rotation is one of these rows - modules.py:74-79 builds it per
+    seed from the picked template view, label_generation.py:52-54 per object).  Row i equals what the per-seed call
+    returns for template i (the function is row-wise).  Read-only."""
+    key = (N, str(device))
+    if key not in _VIEW_ROT_CACHE:
+        views = grasp_views_on(device, N)
+        _VIEW_ROT_CACHE[key] = batch_viewpoint_params_to_matrix(-views, torch.zeros(N, dtype=views.dtype, device=views.device))
+    return _VIEW_ROT_CACHE[key]
+
+
 def batch_viewpoint_params_to_matrix(batch_towards, batch_angle):
     """Approach vectors (N,3) + in-plane angles (N,) -> rotation matrices (N,3,3) whose first column
     is the normalised approach direction."""

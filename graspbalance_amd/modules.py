@@ -9,7 +9,7 @@ import torch.nn.functional as F
 
 from . import fused_mlp
 from . import pytorch_utils as pt_utils
-from .loss_utils import batch_viewpoint_params_to_matrix, grasp_views_on
+from .loss_utils import batch_viewpoint_params_to_matrix, grasp_view_rotations_on, grasp_views_on
 from .pointnet2_utils import CylinderQueryAndGroup, furthest_point_sample
 
 
@@ -173,8 +173,9 @@ class GraspableDetection(nn.Module):
         top_view_scores, top_view_inds = self._top_view(view_score)
         template_views = grasp_views_on(device, self.num_view)  # (V,3)
         vp_xyz = template_views[top_view_inds]  # (B,num_seed,3) == gather of the expanded templates
-        batch_angle = torch.zeros(B * num_seed, dtype=vp_xyz.dtype, device=vp_xyz.device)
-        vp_rot = batch_viewpoint_params_to_matrix(-vp_xyz.view(-1, 3), batch_angle).view(B, num_seed, 3, 3)
+        # batch_viewpoint_params_to_matrix(-vp_xyz, 0) per seed (modules.py:76-79) is row-wise and its argument one of V
+        # constants: a gather from the V template rotations, computed once (loss_utils.grasp_view_rotations_on)
+        vp_rot = grasp_view_rotations_on(device, self.num_view)[top_view_inds]          # (B,num_seed,3,3)
         end_points['grasp_top_view_inds'] = top_view_inds
         end_points['grasp_top_view_score'] = top_view_scores
         end_points['grasp_top_view_xyz'] = vp_xyz

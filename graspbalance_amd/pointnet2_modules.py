@@ -160,7 +160,9 @@ class PointnetSAModuleVotes(_VotesBase):
         x0 = fused_mlp.group_concat_cl(xyz, new_xyz, idx, feat_cl, mode=1 if self.normalize_xyz else 0,
                                        scale=scale)
         out = fused_mlp.shared_mlp_cl(x0, self.mlp_module, pool_ns=self.nsample)  # (B*m, C_out)
-        return out.view(B, m, -1).transpose(1, 2).contiguous()
+        # (B, C_out, m) as a VIEW of the channel-last result: the next fused consumer transposes it back for free; code that
+        # needs the reference's memory layout calls .contiguous() (values, shape and dtype are the reference's)
+        return out.view(B, m, -1).transpose(1, 2)
 
     def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, inds: torch.Tensor = None):
         if self.npoint is not None:
@@ -261,7 +263,7 @@ class PointnetFPModule(nn.Module):
             dist_recip = 1.0 / (dist + 1e-8)
             norm = torch.sum(dist_recip, dim=2, keepdim=True)
             weight = dist_recip / norm
-            interpolated_feats = pointnet2_utils.three_interpolate(known_feats, idx, weight)
+            interpolated_feats = pointnet2_utils.three_interpolate(known_feats.contiguous(), idx, weight)
         else:
             interpolated_feats = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
         if unknow_feats is not None:
@@ -274,7 +276,7 @@ class PointnetFPModule(nn.Module):
             B, C, n = new_features.shape
             rows = new_features.transpose(1, 2).reshape(B * n, C)
             out = fused_mlp.shared_mlp_cl(rows, self.mlp)
-            return out.view(B, n, -1).transpose(1, 2).contiguous()
+            return out.view(B, n, -1).transpose(1, 2)   # (a view of the channel-last rows: see PointnetSAModuleVotes)
         return self.mlp(new_features.unsqueeze(-1)).squeeze(-1)
 
 

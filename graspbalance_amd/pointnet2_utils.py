@@ -50,12 +50,15 @@ class FurthestPointSampling(Function):
 furthest_point_sample = FurthestPointSampling.apply
 
 
+# The autograd wrappers hand the extension CONTIGUOUS features (a no-op for the reference's own tensors): this package's
+# fused modules return (B,C,N) feature tensors as transposed views of their channel-last results.  The extension shims
+# themselves (pointnet2/_ext.py) keep the reference's strict contiguity check.
 class GatherOperation(Function):
     @staticmethod
     def forward(ctx, features, idx):
         """features (B,C,N), idx (B,npoint) int32 -> (B,C,npoint)."""
         ctx.for_backwards = (idx, features.size(1), features.size(2))
-        return _ext.gather_points(features, idx)
+        return _ext.gather_points(features.contiguous(), idx)
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -87,7 +90,7 @@ class ThreeInterpolate(Function):
     def forward(ctx, features, idx, weight):
         """features (B,c,m), idx (B,n,3), weight (B,n,3) -> (B,c,n)."""
         ctx.three_interpolate_for_backward = (idx, weight, features.size(2))
-        return _ext.three_interpolate(features, idx, weight)
+        return _ext.three_interpolate(features.contiguous(), idx, weight)
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -103,7 +106,7 @@ class GroupingOperation(Function):
     def forward(ctx, features, idx):
         """features (B,C,N), idx (B,npoint,nsample) int32 -> (B,C,npoint,nsample)."""
         ctx.for_backwards = (idx, features.size(2))
-        return _ext.group_points(features, idx)
+        return _ext.group_points(features.contiguous(), idx)
 
     @staticmethod
     def backward(ctx, grad_out):

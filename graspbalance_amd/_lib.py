@@ -43,6 +43,7 @@ SIGNATURES = {
     "gb_three_interpolate": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gb_three_interpolate_grad": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gb_knn1": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "gb_knn": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gb_group_concat_cl": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
     "gb_group_concat_cl_grad": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gb_col_stats": [_P, _L, _I, _P, _P, _P],

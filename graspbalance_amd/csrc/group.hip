@@ -328,6 +328,73 @@ __global__ __launch_bounds__(TPB) void knn1_kernel(const float *__restrict__ ref
   if (q < nq) idx[(size_t)bi * nq + q] = (int64_t)besti + 1;
 }
 
+// k nearest references per query, k <= KNN_MAXK (knn.cu:113-176 / cpu/knn_cpu.cpp:4-55 for any k): a thread keeps its
+// query's k best (distance, index) pairs sorted in registers; a candidate enters only with a STRICTLY smaller distance than
+// an entry and is placed before the first strictly larger one - equal distances stay in index order, which is the order
+// of the reference's stable sorts.  idx (b, k, nq) int64, 1-based, row i = the (i+1)-th nearest.
+constexpr int KNN_MAXK = 16;
+
+template <int KK>
+__global__ __launch_bounds__(TPB) void knnk_kernel(const float *__restrict__ ref, const float *__restrict__ query,
+                                                    int64_t *__restrict__ idx, int dim, int nref, int nq, int k) {
+  __shared__ float s_r[KNN_MAXDIM * KNN_TILE];
+  const int bi = blockIdx.y;
+  const int q = blockIdx.x * TPB + threadIdx.x;
+  const float *r = ref + (size_t)bi * dim * nref;
+  const float *qq = query + (size_t)bi * dim * nq;
+  float qv[KNN_MAXDIM];
+#pragma unroll
+  for (int h = 0; h < KNN_MAXDIM; ++h) qv[h] = (h < dim && q < nq) ? qq[(size_t)h * nq + q] : 0.f;
+  float bd[KK];
+  int bidx[KK];
+#pragma unroll
+  for (int i = 0; i < KK; ++i) { bd[i] = INFINITY; bidx[i] = -1; }
+  for (int base = 0; base < nref; base += KNN_TILE) {
+    const int cntk = nref - base < KNN_TILE ? nref - base : KNN_TILE;
+    __syncthreads();
+    for (int t = threadIdx.x; t < dim * KNN_TILE; t += TPB) {
+      const int h = t / KNN_TILE, kk = t % KNN_TILE;
+      s_r[t] = kk < cntk ? r[(size_t)h * nref + base + kk] : 0.f;
+    }
+    __syncthreads();
+    if (q < nq) {
+      for (int kk = 0; kk < cntk; ++kk) {
+        float d = 0.0f;
+#pragma unroll
+        for (int h = 0; h < KNN_MAXDIM; ++h)
+          if (h < dim) {
+            const float t = s_r[h * KNN_TILE + kk] - qv[h];
+            d = d + (t * t);
+          }
+        // one pass of an insertion: the entry moves down while the slot above it is strictly larger (or still empty);
+        // NaN distances never enter (every comparison with them is false), as in the reference's `<`
+        float cd = d;
+        int ci = base + kk;
+        bool carrying = false, done = false;
+#pragma unroll
+        for (int i = 0; i < KK; ++i) {
+          // the candidate takes the first slot whose entry is strictly larger (or empty); from there on every entry
+          // moves down by one (the one pushed out of slot k-1 is dropped)
+          const bool empty = bidx[i] < 0;
+          const bool take = i < k && !done && (carrying || empty || cd < bd[i]);
+          const float td = bd[i];
+          const int ti = bidx[i];
+          bd[i] = take ? cd : td;
+          bidx[i] = take ? ci : ti;
+          cd = take ? td : cd;
+          ci = take ? ti : ci;
+          carrying = carrying || take;
+          done = done || (take && empty);
+        }
+      }
+    }
+  }
+  if (q < nq)
+#pragma unroll
+    for (int i = 0; i < KK; ++i)
+      if (i < k) idx[((size_t)bi * k + i) * nq + q] = (int64_t)bidx[i] + 1;
+}
+
 // dim == 3 (the only case GraspBalance uses): one WAVE per 4 queries, the 64 lanes split the reference
 // columns (coalesced reads, no LDS), then a DPP arg-min with lowest-index tie-break.  The generic kernel
 // above gives a query to one thread, which leaves a 300 x 300 problem on 2 workgroups.
@@ -739,6 +806,21 @@ extern "C" int gb_three_interpolate_grad(const float *grad_out, const int32_t *i
   hipLaunchKernelGGL(three_interpolate_grad_kernel, dim3(ceil_div(n, TPB), ceil_div(c, CCHUNK), b),
                      dim3(TPB), 0, as_stream(stream), grad_out, idx, weight, grad_points, c, n, m);
   return check_launch("gb_three_interpolate_grad");
+}
+
+extern "C" int gb_knn(const float *ref, const float *query, int64_t *idx, int b, int dim, int nref, int nq, int k,
+                      void *stream) {
+  if (k == 1) return gb_knn1(ref, query, idx, b, dim, nref, nq, stream);
+  if (b < 0 || dim < 1 || dim > KNN_MAXDIM || nref < 1 || nq < 0 || k < 1 || k > KNN_MAXK || k > nref || !ref || !query ||
+      !idx)
+    return GB_EINVAL;
+  if (b == 0 || nq == 0) return GB_OK;
+  if (b > 65535) return GB_ERANGE;
+  const dim3 grid(ceil_div(nq, TPB), b);
+  if (k <= 4) hipLaunchKernelGGL(knnk_kernel<4>, grid, dim3(TPB), 0, as_stream(stream), ref, query, idx, dim, nref, nq, k);
+  else if (k <= 8) hipLaunchKernelGGL(knnk_kernel<8>, grid, dim3(TPB), 0, as_stream(stream), ref, query, idx, dim, nref, nq, k);
+  else hipLaunchKernelGGL(knnk_kernel<16>, grid, dim3(TPB), 0, as_stream(stream), ref, query, idx, dim, nref, nq, k);
+  return check_launch("gb_knn");
 }
 
 extern "C" int gb_knn1(const float *ref, const float *query, int64_t *idx, int b, int dim, int nref,

@@ -730,10 +730,11 @@ class MLPStack(Function):
             residual = s1 if has_res else None
             if has_res and ctx.needs_input_grad[1]:
                 dres = torch.empty((P, N), dtype=torch.float32, device=dev)
+            # (the apply pass reads the two sums anyway and emits dbeta / dgamma itself: no gb_bn_bwd_reduce launch)
             _call("gb_bn_bwd_stats", dev, _lib.ptr(dout), _lib.ptr(Ys[-1]), _lib.ptr(abs_[-1]), _lib.ptr(residual), P, N,
-                  int(relu_last), _lib.ptr(dstats), pb, pg, st)
-            _call("gb_bn_bwd_apply", dev, _lib.ptr(dout), _lib.ptr(Ys[-1]), _lib.ptr(abs_[-1]), _lib.ptr(residual),
-                  _lib.ptr(dstats), P, N, int(relu_last), int(training[-1]), _lib.ptr(dY), _lib.ptr(dres), st)
+                  int(relu_last), _lib.ptr(dstats), None, None, st)
+            _call("gb_bn_bwd_apply_g", dev, _lib.ptr(dout), _lib.ptr(Ys[-1]), _lib.ptr(abs_[-1]), _lib.ptr(residual),
+                  _lib.ptr(dstats), P, N, int(relu_last), int(training[-1]), _lib.ptr(dY), _lib.ptr(dres), pb, pg, st)
         grads[3 * L - 2], grads[3 * L - 1] = dgamma, dbeta
         dX0 = None
         for l in range(first, -1, -1):

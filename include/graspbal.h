@@ -162,6 +162,10 @@ int gb_three_interpolate_grad(const float *grad_out, const int32_t *idx, const f
  * idx (b,1,nq) int64, 1-BASED; the lowest reference index wins ties (stable sort of knn_cpu.cpp). */
 int gb_knn1(const float *ref, const float *query, int64_t *idx, int b, int dim, int nref, int nq,
             void *stream);
+/* ... and for any k <= 16 (knn.h:11-59, cuda/knn.cu:113-176, cpu/knn_cpu.cpp:4-55): idx (b,k,nq) int64, 1-based, row i
+ * = the (i+1)-th nearest reference of each query; equal distances in ascending index order (the reference's stable
+ * insertion / bubble sorts).  k = 1 runs gb_knn1's kernels.  k > nref, k > 16 or dim > 8: GB_EINVAL.              */
+int gb_knn(const float *ref, const float *query, int64_t *idx, int b, int dim, int nref, int nq, int k, void *stream);
 
 /* Grasp-label gather for the training-time label matching (label_generation.py:60-99):
  *   out[r, v, :] = srcs[obj[r]][pt[r], view_inds[obj[r], v], :]     (W floats per (point, view))

@@ -298,6 +298,39 @@ int gbo_three_interpolate_grad(const float *grad_out, const int32_t *idx, const 
   return 0;
 }
 
+/* KNN/Pytorch_CUDA_KNN/cpu/knn_cpu.cpp:4-55 for any k <= nref: squared distances accumulated over the `dim` rows in order,
+ * then the k smallest in ascending order with equal distances in index order (what the reference's stable bubble sort of
+ * the whole row leaves in its first k places).  idx (b,k,nq), 1-based. */
+int gbo_knn(const float *ref, const float *query, int64_t *idx, int b, int dim, int nref, int nq, int k) {
+  if (k < 1 || k > nref) return -1;
+#pragma omp parallel for collapse(2) schedule(static, 64)
+  for (int bi = 0; bi < b; ++bi)
+    for (int q = 0; q < nq; ++q) {
+      const float *r = ref + (size_t)bi * dim * nref;
+      const float *qq = query + (size_t)bi * dim * nq;
+      float bd[64];
+      int64_t bi_[64];
+      int have = 0;
+      for (int c = 0; c < nref; ++c) {
+        float d = 0.0f;
+        for (int h = 0; h < dim; ++h) {
+          const float t = r[(size_t)h * nref + c] - qq[(size_t)h * nq + q];
+          d += t * t;
+        }
+        int pos = have;                       /* after every entry that is <= d: stable */
+        while (pos > 0 && d < bd[pos - 1]) --pos;
+        if (pos >= k) continue;
+        const int last = have < k ? have : k - 1;
+        for (int j = last; j > pos; --j) { bd[j] = bd[j - 1]; bi_[j] = bi_[j - 1]; }
+        bd[pos] = d;
+        bi_[pos] = c + 1;
+        if (have < k) ++have;
+      }
+      for (int i = 0; i < k; ++i) idx[((size_t)bi * k + i) * nq + q] = bi_[i];
+    }
+  return 0;
+}
+
 /* KNN/Pytorch_CUDA_KNN/cpu/knn_cpu.cpp:4-55 with k = 1: squared distance accumulated over the
  * `dim` rows in order, stable bubble sort => lowest index among equal minima, 1-based output. */
 int gbo_knn1(const float *ref, const float *query, int64_t *idx, int b, int dim, int nref, int nq) {

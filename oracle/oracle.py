@@ -148,6 +148,17 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     return out
 
 
+def knn(ref, query, k):
+    """ref (B,dim,nref), query (B,dim,nq) -> (B,k,nq) int64, 1-based, nearest first, equal distances by index."""
+    ref, query = _f32(ref), _f32(query)
+    B, D, NR = ref.shape
+    NQ = query.shape[2]
+    assert 1 <= k <= min(NR, 64)
+    idx = torch.zeros(B, k, NQ, dtype=torch.int64)
+    assert lib().gbo_knn(_p(ref), _p(query), _p(idx), B, D, NR, NQ, k) == 0
+    return idx
+
+
 def knn1(ref, query):
     """ref (B,dim,nref), query (B,dim,nq) -> (B,1,nq) int64, 1-based (KNN/knn_modules.py:11-18)."""
     ref, query = _f32(ref), _f32(query)
@@ -234,5 +245,5 @@ class PBBackend:
 
 def knn_into(ref, query, idx):
     """KNN._C.knn signature (writes 1-based int64 indices into idx)."""
-    idx.copy_(knn1(ref, query))
+    idx.copy_(knn1(ref, query) if idx.shape[1] == 1 else knn(ref, query, idx.shape[1]))
     return 1

@@ -530,3 +530,33 @@ def test_fps_cell_order_is_a_coherent_permutation(orc):
                                             _lib.ptr(scratch), None), "gb_fps_pruned")
         torch.cuda.synchronize()
         assert torch.equal(idx.cpu(), orc.furthest_point_sampling(xyz, m, flags))
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 8, 16])
+def test_knn_any_k_equals_oracle_and_the_reference_build(orc, k):
+    """gb_knn (KNN/Pytorch_CUDA_KNN/knn.h:11-59 for k <= 16; the model itself only uses k = 1): indices of the k nearest
+    references, nearest first, equal distances in index order - against the C oracle on random clouds, on a lattice full
+    of exact ties and on duplicated points, in 3 and 5 dimensions; and, where oracle/_ref/knn_ref.so exists (the
+    reference's own vision.cpp + cpu/knn_cpu.cpp compiled by oracle/build_ref.py), against the reference itself."""
+    from graspbalance_amd.knn_modules import myknn
+    g = torch.Generator().manual_seed(31 + k)
+    cases = [(torch.rand(2, 3, 300, generator=g), torch.rand(2, 3, 97, generator=g)),
+             (torch.randint(0, 5, (1, 3, 400), generator=g).float() * 0.25, torch.randint(0, 5, (1, 3, 64), generator=g).float() * 0.25),
+             (torch.rand(1, 5, 1500, generator=g), torch.rand(1, 5, 300, generator=g)),
+             (torch.rand(1, 3, 40, generator=g).repeat(1, 1, 3), torch.rand(1, 3, 33, generator=g))]
+    try:
+        from oracle.build_ref import load_knn_ref
+        ref_mod = load_knn_ref()
+    except Exception:
+        ref_mod = None
+    for ref, query in cases:
+        if k > ref.shape[2]:
+            continue
+        got = myknn(ref.to(DEV), query.to(DEV), k=k).cpu()
+        want = orc.knn(ref, query, k)
+        assert got.shape == (ref.shape[0], k, query.shape[2]) and got.dtype == torch.int64
+        assert torch.equal(got, want), (k, tuple(ref.shape))
+        if ref_mod is not None and ref.shape[2] <= 400:   # (the reference sorts every row completely: O(nref^2) per query)
+            idx = torch.empty(ref.shape[0], k, query.shape[2], dtype=torch.long)
+            ref_mod.knn(ref.contiguous(), query.contiguous(), idx)
+            assert torch.equal(idx, want), ("reference build", k, tuple(ref.shape))

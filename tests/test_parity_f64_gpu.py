@@ -102,6 +102,32 @@ def test_full_size_eval_forward_hip_vs_oracle_path_vs_f64_truth(monkeypatch):
     assert flips <= 8, flips
 
 
+def test_config3_stated_initialisation_every_tensor_within_1e_5():
+    """SURVEY section 8d C3 exactly as stated: B = 4 clouds of 20 000 points (make_scene seeds 0..3), eval mode, weights
+    from ``torch.manual_seed(1234)`` default initialisation (running statistics 0 / 1).  north_star's bar - features AND
+    grasp scores within 1e-5 of the fp64 truth - asserted outright on every tensor of every cloud, no clause relative to
+    another fp32 path (the by-key random network of the test above needs one for its un-normalised seed features; a
+    network as initialised does not).  The truth replays the HIP run's top-view arg-max (a discrete choice)."""
+    from graspbalance_amd.graspbalance import GraspBalance
+    from graspbalance_amd.scene import make_batch
+    torch.manual_seed(1234)
+    gpu = GraspBalance(is_training=False).to(DEV).eval()
+    clouds = torch.from_numpy(make_batch([0, 1, 2, 3], 20000)).to(DEV)
+    with torch.no_grad():
+        got = gpu({'point_clouds': clouds})
+        views = got['grasp_top_view_inds'].clone()
+        _, truth = _truth_forward(gpu, {'point_clouds': clouds.double()}, views.cpu())
+    for k in ('sa1_inds', 'sa2_inds', 'fp2_inds'):
+        assert torch.equal(got[k], truth[k]), k
+    report = {(k, i): rel(got[k][i], truth[k][i]) for k in VALUE_KEYS for i in range(clouds.shape[0])}
+    print("configs[2]/C3 at the stated initialisation:", {"%s[%d]" % k: "%.1e" % v for k, v in report.items()})
+    worst = max(report.items(), key=lambda kv: kv[1])
+    assert worst[1] <= 1e-5, worst
+    # the free arg-max of the truth picks the same views (near-ties aside)
+    free64 = torch.max(truth['view_score'], dim=2)[1]
+    assert int((free64 != views).sum()) <= 4
+
+
 @pytest.mark.parametrize("B", [1, 4])
 def test_config1_sa_layer_on_20k_cloud(orc, B):
     """BASELINE configs[1]: PointnetSAModuleVotes(npoint=1024, radius=0.04, nsample=32, mlp=[0,64,128]) forward on
@@ -313,10 +339,19 @@ def test_config4_stated_shape_b8_50000_points_bf16(orc):
         flips = float((out["bf16"]['grasp_top_view_inds'] != out["f32"]['grasp_top_view_inds']).float().mean())
         print("configs[4] eval forward, bf16 vs fp32:", {k: "%.1e" % v for k, v in errs.items()}, "top-view flips %.3f" % flips)
         assert torch.equal(out["bf16"]['sa1_inds'], out["f32"]['sa1_inds'])
-        assert 1e-5 < errs['sa1_features'] <= 2e-2      # the mode really changed the arithmetic; bf16-level agreement
-        # measured: backbone / stage 1 <= 1.7e-2, the four grasp tensors 3.5e-2 .. 6.2e-2 (the sigmoid gate on unnormalised
-        # seed features amplifies, see the B = 4 eval test above)
-        assert all(v <= (0.1 if k.startswith('grasp_') else 3e-2) for k, v in errs.items()), errs
+        assert 1e-5 < errs['sa1_features']              # the mode really changed the arithmetic
+        # The bound is DERIVED, not read off a run.  Rounding both operands of a contraction to bf16 (8 significant bits,
+        # round to nearest: relative error <= 2^-9 each, independent) perturbs its output by ~sqrt(2) 2^-9 relative; the
+        # perturbations of the L contractions in front of a tensor add in quadrature (independent roundings through layers
+        # that BatchNorm keeps at unit scale): e(L) ~ 2^-9 sqrt(2 L).  A factor 4 on top covers what a conv + BatchNorm +
+        # ReLU layer does to an incoming perturbation (x 1.2 per layer measured in fp32, DESIGN.md section 3.2, never x 4
+        # in aggregate over these depths).  Depths: contractions on the longest path from the cloud to the tensor.
+        depth = {'sa1_features': 3, 'sa2_features': 3 + 9 + 3, 'sa3_features': 15 + 18 + 3, 'sa4_features': 36 + 9 + 3,
+                 'fp2_features': 48 + 9 + 4, 'objectness_score': 61 + 3, 'view_score': 61 + 3}
+        for k in VALUE_KEYS:
+            L = depth.get(k, 61 + 3 + 1 + 3)            # grasp tensors: crop stack (3) + scale fusion (1) + depth head (3)
+            bound = 4.0 * 2.0 ** -9 * (2.0 * L) ** 0.5
+            assert errs[k] <= bound, (k, errs[k], bound, L)
         tr = Trainer(DEV, steps_per_epoch=10, max_epoch=2, mlp_precision="bf16")
         losses = [float(tr.train_step(batch).detach()) for _ in range(2)]
         torch.cuda.synchronize()

@@ -176,11 +176,43 @@ _ARENA = {}
 _ARENA32_FLOATS = int(os.environ.get("GB_ZERO_ARENA_MB", "192")) << 18   # fp32 arena capacity (floats); 0 = plain torch.zeros
 
 
+def _arena_of(device):
+    """The zero arena buffers are served from: this thread's scoped one (scoped_arena) or the device's shared one."""
+    scoped = getattr(_tls, "arena", None)
+    if scoped is not None and scoped.get("dev") == str(device):
+        return scoped
+    return _ARENA.get(str(device))
+
+
+class scoped_arena:
+    """``with fused_mlp.scoped_arena(device, floats64, floats32):`` - a PRIVATE pair of zero arenas for the calls inside
+    (created on first use, kept on the object).  predict.Predictor runs its forwards in one: an evaluation pass between a
+    training loop's backward() and optimizer.step() must not re-zero the shared arena - weight gradients are views of it."""
+
+    def __init__(self, device, floats64=1 << 17, floats32=1 << 23):
+        self.device, self.sizes, self.arena = torch.device(device), (int(floats64), int(floats32)), None
+
+    def __enter__(self):
+        if self.arena is None:
+            self.arena = {"buf": torch.zeros(self.sizes[0], dtype=torch.float64, device=self.device), "off": 0,
+                          "buf32": torch.zeros(self.sizes[1], dtype=torch.float32, device=self.device)
+                          if self.sizes[1] else None, "off32": 0, "live": False, "dev": str(self.device)}
+        self.prev = getattr(_tls, "arena", None)
+        _tls.arena = self.arena
+        return self
+
+    def __exit__(self, *exc):
+        self.arena["live"] = False
+        _tls.arena = self.prev
+        return False
+
+
 def begin_step(device):
     """Start a train step on `device`: re-zero what the previous step took from the zero arenas and rewind them.
     Two arenas: fp64 (BatchNorm sums, moments: ~85 small buffers per step) and fp32 (the atomic-add targets of a step:
-    weight-gradient arenas, scatter targets, per-point sums - ~45 buffers, ~100 MB: one fill instead of 45)."""
-    ar = _ARENA.get(str(device))
+    weight-gradient arenas, scatter targets, per-point sums - ~45 buffers, ~100 MB: one fill instead of 45).  Inside a
+    scoped_arena the scoped buffers are the ones rewound and served."""
+    ar = _arena_of(device)
     if ar is None:
         ar = _ARENA[str(device)] = {"buf": torch.zeros(1 << 20, dtype=torch.float64, device=device), "off": 0,
                                      "buf32": torch.zeros(_ARENA32_FLOATS, dtype=torch.float32, device=device)
@@ -198,13 +230,13 @@ def begin_step(device):
 
 def end_arena(device):
     """Stop serving buffers from the arena (e.g. before code that keeps results across steps)."""
-    ar = _ARENA.get(str(device))
+    ar = _arena_of(device)
     if ar is not None:
         ar["live"] = False
 
 
 def _zeros64(n, dev):
-    ar = _ARENA.get(str(dev))
+    ar = _arena_of(dev)
     if ar is not None and ar["live"]:
         off = ar["off"]
         end = off + (n + 31) // 32 * 32
@@ -218,7 +250,7 @@ def _zeros32(n, dev):
     """n zero floats (64-byte aligned) for this step: from the fp32 arena inside a Trainer step, torch.zeros otherwise.
     Like everything taken from the arenas it must not outlive the step (gradients are consumed by the optimizer - and
     dropped by zero_grad - before the next begin_step)."""
-    ar = _ARENA.get(str(dev))
+    ar = _arena_of(dev)
     if ar is not None and ar["live"] and ar["buf32"] is not None:
         off = ar["off32"]
         end = off + (n + 15) // 16 * 16

@@ -17,6 +17,9 @@ class Predictor:
         self.net = net.to(device).eval()
         self.device = torch.device(device)
         self.prefetch = None
+        # the forward's small zero-initialised buffers (moment / statistic scratch of the fused kernels) come from a private
+        # arena: the shared one belongs to training loops (weight gradients are views of it until optimizer.step())
+        self._arena = fused_mlp.scoped_arena(self.device) if self.device.type == "cuda" else None
         sa1 = getattr(getattr(getattr(net, "view_estimator", None), "FeatureExtraction", None), "sa1", None)
         if prefetch_sampling and self.device.type == "cuda" and sa1 is not None and sa1.npoint:
             self.prefetch = SamplingPrefetch(self.device, sa1.npoint)
@@ -25,8 +28,13 @@ class Predictor:
     def __call__(self, batch, next_batch=None, decode=True):
         """batch: {'point_clouds': (B,N,3+) ...}.  Returns pred_decode's list of (Ng,17) grasps per cloud (or the
         network's end_points with decode=False).  next_batch: the batch of the following call, if already known."""
-        if self.device.type == "cuda":
+        if self._arena is None:
+            return self._call(batch, next_batch, decode)
+        with self._arena:
             fused_mlp.begin_step(self.device)
+            return self._call(batch, next_batch, decode)
+
+    def _call(self, batch, next_batch, decode):
         inputs = dict(batch)
         if self.prefetch is not None:
             inds = self.prefetch.take(batch['point_clouds'])

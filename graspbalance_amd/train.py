@@ -30,6 +30,13 @@ from .pytorch_utils import BNMomentumScheduler
 import os
 _PREFETCH_AT = os.environ.get("GB_PREFETCH_AT", "sa1")  # A/B switch: "start" | "sa1" | "off"
 _GRAPH_DEFAULT = os.environ.get("GB_GRAPH", "1") != "0"  # A/B switch: 0 = every step enqueued launch by launch
+# Where the graph step launches the next batch's first-level sampling (2.1 ms of one workgroup per cloud on a side stream):
+# "bwd" = between the forward graph and the backward graph, i.e. beside the start of the backward; "start" = before the
+# forward graph.  Measured (tools/fps_interference.py, B = 4 x 20 000): the step's own kernels take 17.2 ms; with the
+# sampling beside the START of the forward 18.5 ms - the first levels' few-row GEMMs are one-tile-per-CU grids, and every
+# one of them waits for the tile that landed on a CU the sampling occupies; beside the backward's first kernels (split-K
+# grids of ~1000 workgroups, persistent row-streaming grids sized for the CUs left over) see DESIGN.md section 5.6.
+_SAMPLE_AT = os.environ.get("GB_SAMPLE_AT", "bwd")
 _NO_CONTEXT = contextlib.nullcontext()
 
 BN_MOMENTUM_INIT = 0.5
@@ -175,28 +182,50 @@ class Trainer:
         if g is None:
             g = self._graphs[key] = self._capture(st, announced)
         self.optimizer.set_lr_tensor()
-        if announced:
-            # The next batch's first-level sampling, launched on the side stream BEFORE the replay: it runs under the
-            # first ~2.5 ms of the step.  Not inside the graph: a graph with a forked branch loses ROCm's fast launch path
-            # for linear graphs (measured: hipGraphLaunch 14.6 ms of host time per replay with the branch, 0.33 ms without)
-            cur, side = torch.cuda.current_stream(self.device), self.prefetch.side
-            side.wait_stream(cur)
+        cur = torch.cuda.current_stream(self.device)
+
+        def sample_next():
+            # The next batch's first-level sampling on the side stream.  Not inside a graph: a graph with a forked branch
+            # loses ROCm's fast launch path for linear graphs (measured: hipGraphLaunch 14.6 ms of host time per replay
+            # with the branch, 0.33 ms without), so it goes out beside two linear graphs.
+            # And WITHOUT making the side stream wait on the main stream where that can be avoided: on this stack a stream
+            # that waits on an event recorded in front of the step costs the step 0.75 ms (tools/fps_interference.py: 17.3
+            # -> 18.05 ms with nothing at all running on the waiting stream).  The ordering the sampling needs is kept by
+            # other means: its outputs rotate through RING slots, and a slot is reused only after the host has seen the
+            # end of the step that read it three steps ago (an event that old has practically always fired: no stall).
+            side = self.prefetch.side
+            slot = st.ring_next()
+            ver = st.batch['point_clouds']._version
+            if st.next_src[0] != "self" or st.side_saw != ver:
+                # the announced clouds were staged by the main stream this step (or the resident ones were written since
+                # the side stream last synchronised with it): a real dependency
+                side.wait_stream(cur)
+                st.side_saw = ver
             with torch.cuda.stream(side), torch.no_grad():
                 from . import pointnet2_utils
-                st.inds_next.copy_(pointnet2_utils.furthest_point_sample(st.next_clouds[..., 0:3].contiguous(),
-                                                                        self.prefetch.npoint))
-        g.fwd_bwd.replay()
-        if g.update is not None:                         # data parallel: the collective sits between the two graphs
+                st.inds_ring[slot].copy_(pointnet2_utils.furthest_point_sample(st.next_clouds[..., 0:3].contiguous(),
+                                                                              self.prefetch.npoint))
+            return slot
+        slot = None
+        if announced and _SAMPLE_AT == "start":
+            slot = sample_next()
+        g.fwd.replay()
+        if announced and _SAMPLE_AT != "start":
+            slot = sample_next()                         # beside the backward: see _SAMPLE_AT
+        g.bwd.replay()
+        if g.update is not None:                         # data parallel: the collective sits between two graphs
             self.grads.reduce_flat()
             g.update.replay()
         self.optimizer.count_step()
         self.scheduler.step()
         self.graph_replays += 1
         if announced:
-            cur.wait_stream(side)
+            cur.wait_stream(self.prefetch.side)
             with torch.no_grad():   # (.data: device-side moves between static buffers; the identity tokens follow below)
-                st.inds.data.copy_(st.inds_next)
-                st.batch['point_clouds'].data.copy_(st.next_clouds)
+                st.inds.data.copy_(st.inds_ring[slot])
+                if st.next_src[0] != "self":
+                    st.batch['point_clouds'].data.copy_(st.next_clouds)
+            st.ring_done(slot, cur)
             st.moved_next_in()   # the announced clouds and their samples now sit in the current slots
         return g.loss
 
@@ -232,68 +261,83 @@ class Trainer:
         if self._pool is None:
             self._pool = torch.cuda.graph_pool_handle()
         g = _StepGraph()
-        g.fwd_bwd = torch.cuda.CUDAGraph()
+        g.fwd, g.bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         torch.cuda.synchronize(dev)
         # a process group's watchdog thread polls its events (hipEventQuery) at any time: under the default "global"
         # capture mode that call from ANOTHER thread is an error that takes the process down; "thread_local" restricts
         # only the capturing thread (launches of autograd's worker thread into the capturing stream are captured as ever)
         import torch.distributed as dist
         mode = "thread_local" if dist.is_available() and dist.is_initialized() else "global"
+        # forward (+ loss) and backward (+ update) are two graphs replayed back to back: the sampling of the next batch is
+        # launched between them (_graph_step); with several ranks the update is a third, behind the all-reduce
+        with torch.cuda.graph(g.fwd, pool=self._pool, stream=cs, capture_error_mode=mode):
+            loss = self._body(st, announced, part="fwd")
+            g.loss = loss.detach()
+        with torch.cuda.graph(g.bwd, pool=self._pool, stream=cs, capture_error_mode=mode):
+            self._body(st, announced, part="bwd_pack" if self.distributed else "bwd_step", loss=loss)
         if self.distributed:
-            with torch.cuda.graph(g.fwd_bwd, pool=self._pool, stream=cs, capture_error_mode=mode):
-                g.loss = self._body(st, announced, part="fwd_bwd")
             g.update = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g.update, pool=self._pool, stream=cs, capture_error_mode=mode):
                 self._body(st, announced, part="update")
-        else:
-            with torch.cuda.graph(g.fwd_bwd, pool=self._pool, stream=cs, capture_error_mode=mode):
-                g.loss = self._body(st, announced, part="all")
+        del loss
         # (capture launches nothing, but the python side effects of the step ran: undo them)
         self.grads.zero_grad()
         restore()
         return g
 
-    def _body(self, st, announced, part):
-        """The step on the static buffers.  part: "all" | "fwd_bwd" (ends with the gradients packed into the flat buffer)
-        | "update" (Adam on the flat buffer)."""
+    def _body(self, st, announced, part, loss=None):
+        """The step on the static buffers.  part: "all" (eager warm-up: everything) | "fwd" (forward + loss, returns the
+        loss with its autograd graph) | "bwd_step" (backward of `loss` + update) | "bwd_pack" (backward, gradients packed
+        into the flat buffer: the all-reduce follows outside) | "update" (Adam on the flat buffer)."""
         if part == "update":
             self.optimizer.step(packed=True)
             return None
-        from .prefetch import KEY
-        dev = self.device
-        fused_mlp.begin_step(dev)
-        inputs = dict(st.batch)
-        if self.lean_labels:
-            inputs[LEAN] = True
-        if announced:
-            inputs[KEY] = st.inds            # the current batch's samples: sampled one step ahead (or inline by the caller)
-            # the next batch's sampling runs on the side stream beside this step (launched by _graph_step): the persistent
-            # GEMM grids leave its CUs alone (GbGemmOpts.reserved_cus, baked into the captured launches)
-            # ... while it can still be running: ~2.5 ms, i.e. through the second set-abstraction level
+        if part in ("all", "fwd"):
+            from .prefetch import KEY
+            fused_mlp.begin_step(self.device)
+            inputs = dict(st.batch)
+            if self.lean_labels:
+                inputs[LEAN] = True
+            if announced:
+                inputs[KEY] = st.inds        # the current batch's samples: sampled one step ahead (or inline by the caller)
+            side_by_side = announced and _SAMPLE_AT == "start"
+            if side_by_side:
+                # the next batch's sampling runs beside this forward: the persistent GEMM grids leave its CUs alone
+                # (GbGemmOpts.reserved_cus, baked into the captured launches) through the second set-abstraction level
+                fused_mlp.set_reserved_cus(min(st.next_clouds.shape[0], 128))
+                inputs['_after_level'] = {2: lambda: fused_mlp.set_reserved_cus(0)}
+            try:
+                end_points = self.net(inputs)
+                loss, end_points = get_loss(end_points)
+            finally:
+                fused_mlp.set_reserved_cus(0)
+            if part == "fwd":
+                return loss
+        # ... backward (+ update).  With the sampling launched beside it the persistent GEMMs of the whole backward are
+        # sized for the CUs it leaves (it ends after ~2.5 of the backward's ~11 ms; 4 of 256 CUs for the rest: 1.5 % of
+        # the row-streaming dgrads)
+        self.grads.hold = part == "bwd_pack"   # no collective inside a capture: reduce_flat() runs between the graphs
+        if announced and _SAMPLE_AT != "start" and part != "all":
             fused_mlp.set_reserved_cus(min(st.next_clouds.shape[0], 128))
-            inputs['_after_level'] = {2: lambda: fused_mlp.set_reserved_cus(0)}
-        self.grads.hold = part == "fwd_bwd"   # no collective inside a capture: reduce_flat() runs between the graphs
         try:
-            end_points = self.net(inputs)
-            loss, end_points = get_loss(end_points)
             loss.backward()
         finally:
             fused_mlp.set_reserved_cus(0)
             self.grads.hold = False
-        if part == "fwd_bwd":
+        if part == "bwd_pack":
             with torch.no_grad():
                 self.optimizer.pack()
         else:
-            self.grads.reduce()          # (single process: a no-op; "all" is never captured with several ranks)
+            self.grads.reduce()          # (single process: a no-op; several ranks only in the eager warm-up)
             self.optimizer.step()
         return loss.detach()
 
 
 class _StepGraph:
-    __slots__ = ("fwd_bwd", "update", "loss")
+    __slots__ = ("fwd", "bwd", "update", "loss")
 
     def __init__(self):
-        self.fwd_bwd = self.update = self.loss = None
+        self.fwd = self.bwd = self.update = self.loss = None
 
 
 def _leaves(obj, path=()):
@@ -318,8 +362,9 @@ def _token(t):
 
 class _StaticBatch:
     """Device buffers with the shapes of one batch, at fixed addresses: what the captured step reads.  `batch` has the
-    structure of the batch it was built from; `next_clouds` / `inds` / `inds_next` serve the sampling prefetch (the graph
-    samples next_clouds on the side stream and ends by moving next_clouds -> batch['point_clouds'], inds_next -> inds).
+    structure of the batch it was built from; `next_clouds` / `inds` / `inds_ring` serve the sampling prefetch (the step
+    samples next_clouds on the side stream into a ring slot and ends by moving next_clouds -> batch['point_clouds'],
+    the slot -> inds).
     Which source tensor every buffer currently mirrors is tracked by (address, shape, version) tokens, so a loop that keeps
     passing the same resident tensors - or the static buffers themselves - pays for no copy."""
 
@@ -338,13 +383,34 @@ class _StaticBatch:
         self._dst = dict(_leaves(self.batch))
         self.loaded = {p: _token(t) for p, t in _leaves(batch) if p in self._dst}   # source each buffer mirrors
         clouds = self.batch['point_clouds']
-        self.next_clouds = self.inds = self.inds_next = None
+        self._next_buf = self.next_clouds_src = self.inds = None
         self.next_src = None       # source next_clouds mirrors
         self.samp_for = None       # cloud_id() the samples in `inds` belong to
         if npoint:
-            self.next_clouds = torch.empty_like(clouds)
+            self._next_buf = torch.empty_like(clouds)
+            self.next_clouds_src = self._next_buf
             self.inds = torch.zeros((clouds.shape[0], npoint), dtype=torch.int32, device=clouds.device)
-            self.inds_next = torch.zeros_like(self.inds)
+            # the side stream's sampling results rotate through three slots (see Trainer._graph_step.sample_next)
+            self.inds_ring = [torch.zeros_like(self.inds) for _ in range(3)]
+            self.ring_events = [None, None, None]
+            self.ring_pos = 0
+            self.side_saw = None       # version of the static clouds the side stream is known to be ordered behind
+
+    def ring_next(self):
+        """The ring slot of this step's sampling; blocks the HOST until the step that last read the slot (three steps
+        ago) has finished - it practically always has."""
+        slot = self.ring_pos % 3
+        self.ring_pos += 1
+        ev = self.ring_events[slot]
+        if ev is not None:
+            ev.synchronize()
+        return slot
+
+    def ring_done(self, slot, stream):
+        ev = self.ring_events[slot]
+        if ev is None:
+            ev = self.ring_events[slot] = torch.cuda.Event()
+        ev.record(stream)
 
     def cloud_id(self):
         """Identity of what batch['point_clouds'] holds: the source it mirrors + its own version (in-place writes)."""
@@ -366,12 +432,23 @@ class _StaticBatch:
                     self.loaded[p] = tok
 
     def load_next(self, clouds):
+        """Stage the announced clouds.  When they ARE the static current clouds (a loop on one resident batch) nothing
+        is copied: the sampling reads that buffer directly - nobody writes it."""
         cur = self.batch['point_clouds']
-        src = ("self", self.cloud_id()) if clouds.data_ptr() == cur.data_ptr() else _token(clouds)
+        if clouds.data_ptr() == cur.data_ptr():
+            self.next_clouds_src = cur
+            self.next_src = ("self", self.cloud_id())
+            return
+        self.next_clouds_src = self._next_buf
+        src = _token(clouds)
         if src != self.next_src:
             with torch.no_grad():
-                self.next_clouds.copy_(clouds, non_blocking=True)
+                self._next_buf.copy_(clouds, non_blocking=True)
             self.next_src = src
+
+    @property
+    def next_clouds(self):
+        return self.next_clouds_src
 
     def moved_next_in(self):
         """Bookkeeping after a replay that announced a next batch: batch['point_clouds'] now holds next_clouds' content

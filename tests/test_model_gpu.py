@@ -358,3 +358,30 @@ def test_eval_tables_follow_trainer_steps():
     torch.cuda.synchronize()
     assert float((after - before).norm() / before.norm()) > 1e-3          # the network did change
     assert float((after - plain).norm() / plain.norm()) < 1e-4, "stale eval-mode BatchNorm tables"
+
+
+def test_predictor_call_between_backward_and_step_leaves_the_gradients_alone():
+    """An evaluation pass in the middle of a training step (validation between backward() and optimizer.step(), or
+    between gradient-accumulation micro-steps): the weight gradients of the fused stacks are views of the shared zero
+    arena, which a Predictor call used to rewind and re-zero.  It now works in a private arena."""
+    from tests.test_model_cpu import _tiny_net
+    from graspbalance_amd import fused_mlp
+    from graspbalance_amd.loss import get_loss
+    from graspbalance_amd.predict import Predictor
+    from graspbalance_amd.synthetic import make_training_batch
+    net = _tiny_net().to(DEV).train()
+    batch = make_training_batch(range(2), num_point=3000, num_objects=2, grasp_points_per_object=20, num_view=30,
+                                device=DEV)
+    fused_mlp.begin_step(torch.device(DEV))
+    loss, _ = get_loss(net(dict(batch)))
+    loss.backward()
+    torch.cuda.synchronize()
+    before = [p.grad.clone() for p in net.parameters()]
+    assert sum(float(g.abs().sum()) for g in before) > 0
+    import copy
+    ev = copy.deepcopy(net)
+    ev.is_training = ev.view_estimator.is_training = ev.grasp_generator.is_training = False
+    Predictor(ev, DEV)({'point_clouds': batch['point_clouds']}, decode=False)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, p.grad) for a, p in zip(before, net.parameters()))
+    fused_mlp.end_arena(torch.device(DEV))

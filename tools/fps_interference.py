@@ -1,0 +1,71 @@
+"""How much does the next batch's first-level sampling on the side stream cost the step it runs beside?  The same
+captured graph replayed (a) with the sampling beside it (the shipped loop), (b) with no sampling launched at all (the
+floor: what the step's own kernels take), (c) with the sampling launched and finished BEFORE the replay (serial)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from graspbalance_amd import pointnet2_utils
+from graspbalance_amd.synthetic import make_training_batch
+from graspbalance_amd.train import Trainer
+dev = torch.device("cuda", 0)
+tr = Trainer(dev)
+batch = tr.resident(make_training_batch(range(4), 20000, device=dev))
+for _ in range(3):
+    tr.train_step(batch, next_batch=batch)
+g = [v for k, v in tr._graphs.items() if k[1]][0]   # (captured with GB_SAMPLE_AT's reserved-CU choice)
+st, side = tr._static, tr.prefetch.side
+HOST = [0.0]
+def timeit(fn, n=20):
+    for _ in range(2): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    HOST[0] = (time.perf_counter() - t0) / n * 1e3
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+def fps():
+    with torch.cuda.stream(side), torch.no_grad():
+        st.inds_ring[0].copy_(pointnet2_utils.furthest_point_sample(st.next_clouds[..., 0:3].contiguous(), 2048))
+def replay():
+    g.fwd.replay(); g.bwd.replay()
+def at_start():
+    cur = torch.cuda.current_stream(); side.wait_stream(cur); fps(); replay(); cur.wait_stream(side)
+def between():
+    cur = torch.cuda.current_stream(); g.fwd.replay(); side.wait_stream(cur); fps(); g.bwd.replay(); cur.wait_stream(side)
+def serial():
+    cur = torch.cuda.current_stream(); side.wait_stream(cur); fps(); cur.wait_stream(side); replay()
+def only_fps():
+    cur = torch.cuda.current_stream(); side.wait_stream(cur); fps(); cur.wait_stream(side)
+for name, fn in (("sampling beside the forward", at_start), ("sampling beside the backward", between), ("graphs alone", replay),
+                 ("sampling, then graphs", serial), ("sampling alone", only_fps)):
+    print("%-30s %.3f ms (host %.2f)" % (name, timeit(fn), HOST[0]), flush=True)
+# ---- is it the sampling kernel, or ANY resident kernel on a second queue?  A one-wave spin kernel of the same length:
+for cyc in (200000, 400000):
+    def spin_only():
+        cur = torch.cuda.current_stream(); side.wait_stream(cur)
+        with torch.cuda.stream(side): torch.cuda._sleep(cyc)
+        cur.wait_stream(side)
+    def spin_beside():
+        cur = torch.cuda.current_stream(); side.wait_stream(cur)
+        with torch.cuda.stream(side): torch.cuda._sleep(cyc)
+        replay(); cur.wait_stream(side)
+    a = timeit(spin_only); b = timeit(spin_beside)
+    print("one-wave spin %7d: alone %.3f ms, graphs beside it %.3f ms (host %.2f)" % (cyc, a, b, HOST[0]), flush=True)
+def ev_only():   # the cross-stream waits without any kernel on the side stream
+    cur = torch.cuda.current_stream(); side.wait_stream(cur); replay(); cur.wait_stream(side)
+print("events only, graphs: %.3f ms (host %.2f)" % (timeit(ev_only), HOST[0]), flush=True)
+def ev_a():   # record on the main stream, wait on the side stream
+    cur = torch.cuda.current_stream(); side.wait_stream(cur); replay()
+def ev_b():   # record on the side stream, wait on the main stream
+    cur = torch.cuda.current_stream(); replay(); cur.wait_stream(side)
+def ev_rec():  # an event recorded on the main stream, nobody waits
+    e = torch.cuda.Event(); e.record(); replay()
+print("main->side only: %.3f ms" % timeit(ev_a), flush=True)
+print("side->main only: %.3f ms" % timeit(ev_b), flush=True)
+print("record only:     %.3f ms" % timeit(ev_rec), flush=True)
+print("graphs alone:    %.3f ms" % timeit(replay), flush=True)
+# (a device-side gate - a one-wave kernel on the side stream polling a counter the main stream bumps - was measured too
+#  and is WORSE: a permanently resident polling wave cost the step 2.2 ms, gates both ways 2.4 ms; kernels not kept)
+def no_main_to_side():   # the sampling launched without waiting for the main stream; the main stream waits for it at the end
+    cur = torch.cuda.current_stream(); fps(); replay(); cur.wait_stream(side)
+print("no main->side wait, sampling: %.3f ms (host %.2f)" % (timeit(no_main_to_side), HOST[0]), flush=True)
+print("graphs alone:                 %.3f ms" % timeit(replay), flush=True)

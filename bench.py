@@ -450,6 +450,7 @@ def main():
     # stay on the device).  Well below `elapsed`: the step is GPU-bound.  Close to it: the step is host-bound and the
     # line says more about the box's CPU (and its other tenants) than about the kernels.
     host_enqueue = time.perf_counter() - t0 - _fm.SYNC_WAIT[0]
+    host_waited = _fm.SYNC_WAIT[0]   # (graph loop: the host runs at most three steps ahead of the GPU and waits there)
     barrier()
     elapsed = time.perf_counter() - t0
     assert bool(torch.isfinite(loss)), "training diverged"
@@ -660,6 +661,7 @@ def main():
             "prefetch_sampling": trainer.prefetch is not None,
             "ms_per_step_no_prefetch": no_prefetch_ms, "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
             "host_enqueue_ms_per_step_max_over_ranks": round(host_enqueue_max / args.steps * 1e3, 3),
+            "host_waiting_for_gpu_ms_per_step": round(host_waited / args.steps * 1e3, 3),
             "execution": ("hip-graph replay: the step captured once (warm-up), %d replays timed, %d graph(s) captured"
                           % (args.steps, len(trainer._graphs))) if trainer.graph
                          else "eager: every launch of every step enqueued by the host",

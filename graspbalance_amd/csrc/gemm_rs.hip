@@ -147,6 +147,13 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
   float *s_gen = s_aff + 2 * rpad;  // GEN3: [rpad][4] = (w0, w1, w2, 0) of reduction index k
   if constexpr (GEN3)
     for (int i = t; i < rpad * 4; i += RS_TPB) s_gen[i] = ((i & 3) < 3 && (i >> 2) < g.R) ? g.gen_w[(i >> 2) * 3 + (i & 3)] : 0.f;
+  // RS_STATS_POOL_V: the fp64 column sums live in LDS, not in registers - [wave pair][2][C32] doubles behind the tables,
+  // updated per tile with ds_add_f64 by the two waves that share them.  With 128 accumulators, 16 row keys and 32
+  // registers of fp64 sums the pooled epilogue spilled 130 registers (0.25 GB of scratch written per launch).
+  constexpr bool LSTAT = EPI == RS_STATS_POOL_V;
+  double *s_st = reinterpret_cast<double *>(s_aff + (g.aff ? 2 * rpad : 0));
+  if constexpr (LSTAT)
+    for (int i = t; i < (RS_WAVES / 2) * 2 * C32; i += RS_TPB) s_st[i] = 0.0;
   __syncthreads();
 
   // rows of this launch: the caller's device-side count when there is one (it is not known on the host: no read-back)
@@ -369,6 +376,7 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
           }
           const unsigned lane_off = (unsigned)(4 * h) * (unsigned)g.ldd + (unsigned)m;
           const int nrow = (int)(gP - trow) - 4 * h;    // rows (r&3) + 8(r>>2) below this are valid
+          const bool dense_tile = trow + 32 <= gP && g.ldd == C32;   // (wave-uniform)
           float *pv = reinterpret_cast<float *>(g.pairs);
           // Pass 1, column tile by column tile: weighted BatchNorm sums, the Y store, then the accumulators are turned
           // into sign(gamma) * y IN PLACE (no second copy of the tile's 128 registers).
@@ -383,13 +391,34 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
               cs += wv;
               cq += wv * v;
             }
-            dsum[q] += (double)cs;
-            dsq[q] += (double)cq;
+            {
+              const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(cs), __float_as_uint(cs), false, false);
+              const auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(cq), __float_as_uint(cq), false, false);
+              cs += __uint_as_float(h ? s1[0] : s1[1]);   // the column's other 16 rows sit in lane ^ 32
+              cq += __uint_as_float(h ? s2[0] : s2[1]);
+              if (h == 0) {
+                double *sp = s_st + (size_t)(wave & 3) * 2 * C32 + q * 32 + m;
+                __hip_atomic_fetch_add(sp, (double)cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(sp + C32, (double)cq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
+            }
             if (g.d) {  // keep Y for the backward (rows >= P are not stored)
+              if (dense_tile) {
+                // a whole tile at the packed pitch (every tile but the last of a launch): ONE uniform tile pointer, one
+                // 32-bit lane offset, and row / column-tile offsets that are compile-time constants (they fit the store's
+                // immediate field up to 3 rows + 7 column tiles; four uniform bases cover the rest).  With a run-time
+                // pitch and a per-row guard every one of the 128 stores sat in its own branch with its own spilled
+                // address: 152 spilled registers, 0.25 GB of scratch written per launch.
+                float *tb = g.d + trow * C32;
+                const unsigned lo = (unsigned)(4 * h) * (unsigned)C32 + (unsigned)m;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tb[lo + (unsigned)(((r & 3) + 8 * (r >> 2)) * C32 + q * 32)] = acc[q][r];
+              } else {
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
                 const long long ro = (trow + (r & 3) + 8 * (r >> 2)) * (long long)g.ldd + q * 32;  // wave-uniform
                 if ((r & 3) + 8 * (r >> 2) < nrow) g.d[ro + lane_off] = acc[q][r];
+              }
               }
             }
             const float sg = g.epi_gamma[q * 32 + m] < 0.f ? -1.f : 1.f;
@@ -569,6 +598,17 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
   if constexpr (EPI != RS_STORE) {
     // per-column totals: lanes l / l+32 share a column, then the 8 waves through LDS (B is dead now)
     __syncthreads();
+    if constexpr (LSTAT) {
+      double *st = g.stats + (size_t)(blockIdx.x % g.slots) * 2 * g.C;
+      for (int i = t; i < 2 * C32; i += RS_TPB) {
+        const int which = i / C32, col = i % C32;
+        double sum = 0.0;
+#pragma unroll
+        for (int w = 0; w < RS_WAVES / 2; ++w) sum += s_st[(size_t)(w * 2 + which) * C32 + col];
+        if (col < g.C) atomicAdd(st + which * g.C + col, sum);
+      }
+      return;
+    }
     double *sd = reinterpret_cast<double *>(lds);  // [wave][NS][C32]
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
@@ -673,6 +713,10 @@ bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, dou
               pool ? pool->gamma : nullptr, pool ? pool->pairs : nullptr, pool ? pool->D : 0,
               pool ? pool->gen_x : nullptr, pool ? pool->gen_w : nullptr,
               rows_dev, P, R, C, R, C, w_kc, slots < 1 ? 1 : slots, nch, stagger, tail_split};
+  if (epi == RS_STATS_POOL_V) {  // + the fp64 column sums: [wave pair][2][C32]
+    lds_bytes += (size_t)(RS_WAVES / 2) * 2 * nt * 32 * sizeof(double);
+    if (lds_bytes > 156 * 1024) return false;
+  }
   const bool gen3 = pool && pool->gen_x && epi == RS_STATS;
   if (gen3) {  // the A operand is generated from (P,3) rows and a per-k table: 16 more bytes of LDS per reduction index
     if (!aff || !pool->gen_w || (nt != 2 && nt != 4)) return false;

@@ -289,7 +289,8 @@ def _call(name, dev, *args, meta=None):
         _lib.check(_lib.timed(name, dev, meta, lambda: fn(*args)), name)
 
 
-SYNC_WAIT = [0.0]  # seconds the host spent waiting in the step's one device -> host read (cylinder_rows)
+SYNC_WAIT = [0.0]  # seconds the host spent WAITING for the device inside steps (the device -> host read of cylinder_rows
+                   # without static rows; the graph loop's three-steps-ahead throttle): bench.py takes it off host work
 _TRAIN_TICK = [0]   # bumped by every training-mode BatchNorm finalise: those write the running statistics through raw
                     # pointers, which torch's version counters do not see
 _EVAL_AB = {}   # id(running_mean buffer) -> (weak reference to it, key, [a, b, mean, rstd] table)

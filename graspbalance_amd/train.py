@@ -16,6 +16,7 @@ buckets | Adam): collectives are not captured.
 """
 import contextlib
 
+import time
 import torch
 from torch.optim.lr_scheduler import OneCycleLR
 
@@ -302,9 +303,10 @@ class Trainer:
                 inputs[KEY] = st.inds        # the current batch's samples: sampled one step ahead (or inline by the caller)
             side_by_side = announced and _SAMPLE_AT == "start"
             if side_by_side:
-                # the next batch's sampling runs beside this forward: the persistent GEMM grids leave its CUs alone
-                # (GbGemmOpts.reserved_cus, baked into the captured launches) through the second set-abstraction level
-                fused_mlp.set_reserved_cus(min(st.next_clouds.shape[0], 128))
+                # the next batch's sampling runs beside this forward: with GB_RESERVE_CUS=1 the persistent GEMM grids
+                # leave its CUs alone (GbGemmOpts.reserved_cus, baked into the captured launches) through the second
+                # set-abstraction level
+                fused_mlp.set_reserved_cus(_reserve(st.next_clouds.shape[0]))
                 inputs['_after_level'] = {2: lambda: fused_mlp.set_reserved_cus(0)}
             try:
                 end_points = self.net(inputs)
@@ -313,12 +315,13 @@ class Trainer:
                 fused_mlp.set_reserved_cus(0)
             if part == "fwd":
                 return loss
-        # ... backward (+ update).  With the sampling launched beside it the persistent GEMMs of the whole backward are
-        # sized for the CUs it leaves (it ends after ~2.5 of the backward's ~11 ms; 4 of 256 CUs for the rest: 1.5 % of
-        # the row-streaming dgrads)
+        # ... backward (+ update).  The sampling launched beside it occupies one CU per cloud for ~2.6 of the backward's
+        # ~11 ms.  Sizing the persistent GEMM grids of the whole captured backward for the CUs it leaves
+        # (GB_RESERVE_CUS=1 -> GbGemmOpts.reserved_cus) measured 0.1 ms SLOWER than letting the few workgroups that find
+        # their CU taken wait (same box, alternating: 17.85 vs 17.75 ms), so nothing is reserved by default.
         self.grads.hold = part == "bwd_pack"   # no collective inside a capture: reduce_flat() runs between the graphs
         if announced and _SAMPLE_AT != "start" and part != "all":
-            fused_mlp.set_reserved_cus(min(st.next_clouds.shape[0], 128))
+            fused_mlp.set_reserved_cus(_reserve(st.next_clouds.shape[0]))
         try:
             loss.backward()
         finally:
@@ -331,6 +334,11 @@ class Trainer:
             self.grads.reduce()          # (single process: a no-op; several ranks only in the eager warm-up)
             self.optimizer.step()
         return loss.detach()
+
+
+def _reserve(clouds):
+    """CUs the persistent GEMM grids leave to the sampling kernel beside them (one workgroup per cloud)."""
+    return min(clouds, 128) if os.environ.get("GB_RESERVE_CUS", "0") != "0" else 0
 
 
 class _StepGraph:
@@ -402,8 +410,10 @@ class _StaticBatch:
         slot = self.ring_pos % 3
         self.ring_pos += 1
         ev = self.ring_events[slot]
-        if ev is not None:
-            ev.synchronize()
+        if ev is not None and not ev.query():
+            t0 = time.perf_counter()
+            ev.synchronize()     # the host is three steps ahead of the GPU: waiting here is throttling, not work
+            fused_mlp.SYNC_WAIT[0] += time.perf_counter() - t0
         return slot
 
     def ring_done(self, slot, stream):

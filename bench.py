@@ -51,7 +51,7 @@ def _pin_rank_to_cores(local_rank, local_world):
     for the JSON line (never raises: pinning is an optimisation)."""
     try:
         allowed = sorted(os.sched_getaffinity(0))
-        if local_world <= 1 or len(allowed) < 2 * local_world:
+        if os.environ.get("GB_BENCH_PIN", "1") == "0" or local_world <= 1 or len(allowed) < 2 * local_world:
             return {"cores": len(allowed), "numa_aware": False, "pinned": False}
         nodes = []
         base = "/sys/bus/pci/drivers/amdgpu"
@@ -437,6 +437,35 @@ def main():
     for _ in range(max(args.warmup, 1 if trainer.graph else 0)):
         trainer.train_step(batch, next_batch=batch)
     barrier()
+    # Guard, outside the timed region: graph replay is the product's default because it is faster, which holds on every
+    # configuration measured (one GPU, one-rank RCCL group) - but that is hardware / runtime behaviour, not a law: with
+    # several processes sharing ONE GPU (the rehearsal mode) every cross-stream dependency costs a scheduling quantum and a
+    # replayed step takes seconds.  Two steps each way - the launch-by-launch reference on a trainer of its own that never
+    # captured anything; a job whose replay is more than twice as slow runs launch by launch and says so in `execution`.
+    # All ranks take the same decision.
+    graph_fallback = None
+    if trainer.graph and os.environ.get("GB_BENCH_GRAPH_GUARD", "1") != "0":
+        def per_step(tr, b, n=2):
+            barrier()
+            t = time.perf_counter()
+            for _ in range(n):
+                tr.train_step(b, next_batch=b)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n * 1e3
+        probe = Trainer(device, distributed=use_dist, mlp_precision=prec, graph=False)
+        per_step(probe, batch, 2)
+        t_eager = per_step(probe, batch)
+        del probe
+        t_graph = per_step(trainer, batch)
+        flag = torch.tensor([1.0 if t_graph > 2.0 * t_eager else 0.0], device=device)
+        if use_dist:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if float(flag.item()) > 0:
+            graph_fallback = "graph replay measured %.1f ms per step against %.1f ms launch by launch on this job" % (t_graph, t_eager)
+            trainer = Trainer(device, distributed=use_dist, time_collectives=use_dist, mlp_precision=prec, graph=False)
+            for _ in range(max(args.warmup, 2)):
+                trainer.train_step(batch, next_batch=batch)
+        barrier()
     if use_dist:
         trainer.grads.exposed_ms()  # drop the warm-up samples
     from graspbalance_amd import fused_mlp as _fm
@@ -664,7 +693,8 @@ def main():
             "host_waiting_for_gpu_ms_per_step": round(host_waited / args.steps * 1e3, 3),
             "execution": ("hip-graph replay: the step captured once (warm-up), %d replays timed, %d graph(s) captured"
                           % (args.steps, len(trainer._graphs))) if trainer.graph
-                         else "eager: every launch of every step enqueued by the host",
+                         else ("eager: every launch of every step enqueued by the host"
+                               + (" (fallback: %s)" % graph_fallback if graph_fallback else "")),
             "ms_per_step_eager": round(eager_ms, 3), "host_enqueue_ms_per_step_eager": round(eager_host / sampled * 1e3, 3),
             "cpu_affinity": affinity,
         }

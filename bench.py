@@ -113,7 +113,7 @@ def pmc_traffic(kernel):
     """HBM bytes per launch from the committed PMC passes (profiles/*_pmc_traffic.json: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 corrections applied; the newest
     round that has the kernel wins); None when absent.  Counters cannot be collected from inside this process."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return round(json.load(f)[kernel]["hbm_bytes_per_launch"], 1)

@@ -498,6 +498,14 @@ static int finalize_after(int rc, const GbBnFinalize *fin, const double *stats, 
                         fin->running_var, fin->ab, 1, stream);
 }
 
+// The PLAIN forward / dgrad products prefer the row-streaming kernel only from 65 536 rows: below, a wave gets <= 4 tiles and
+// the workgroup's weight image (up to 128 KB) is staged for ~50 us of work - the tiled kernels run those products
+// 1.5 - 2x faster (round 4, same-box A/B of the whole step with the threshold at 16 384 / 65 536 / 200 000: 17.73 / 17.42 /
+// 17.60 ms; configs[4] 25.83 / 25.65).  Products that NEED that kernel - a device-side row count, the generated first-layer
+// operand, the pooled epilogue - go there from 16 384 rows as before (rs_shape_ok).
+static constexpr long long RS_PAYS_FROM = 65536;
+static bool rs_pays(long long P, const GbGemmOpts *opts) { return P >= RS_PAYS_FROM || opts_rows(opts) != nullptr; }
+
 static int gemm_fwd_impl(const float *x, const float *w, const float *aff, const uint16_t *row_w16, float *y,
                          double *stats, int stat_slots, long long P, int K, int N, const GbBnFinalize *fin,
                          const GbGemmOpts *opts, void *stream) {
@@ -507,7 +515,8 @@ static int gemm_fwd_impl(const float *x, const float *w, const float *aff, const
     return GB_EINVAL;
   if (P == 0) return fin ? GB_EINVAL : GB_OK;
   if (P / 64 * ((N + 63) / 64) > 0x7fffffffLL) return GB_ERANGE;
-  if (rs_gemm_try(x, w, y, aff, stats, stat_slots, nullptr, nullptr, P, K, N, 1, stats ? RS_STATS : RS_STORE,
+  if (rs_pays(P, opts) &&
+      rs_gemm_try(x, w, y, aff, stats, stat_slots, nullptr, nullptr, P, K, N, 1, stats ? RS_STATS : RS_STORE,
                   as_stream(stream), bf16, opts_reserved(opts), nullptr, stats ? row_w16 : nullptr, nullptr,
                   opts_rows(opts)))
     return finalize_after(check_launch("gb_gemm_fwd"), fin, stats, stat_slots, N, stream);
@@ -674,7 +683,8 @@ extern "C" int gb_gemm_dgrad(const float *dy, const float *w, float *dx, const f
   };
   if (P == 0) return GB_OK;
   if (P / 64 * ((K + 63) / 64) > 0x7fffffffLL) return GB_ERANGE;
-  if (rs_gemm_try(dy, w, dx, nullptr, dstats, stat_slots, y_prev, ab_prev, P, N, K, 0, dstats ? RS_BNBWD : RS_STORE,
+  if (rs_pays(P, opts) &&
+      rs_gemm_try(dy, w, dx, nullptr, dstats, stat_slots, y_prev, ab_prev, P, N, K, 0, dstats ? RS_BNBWD : RS_STORE,
                   as_stream(stream), bf16, opts_reserved(opts), nullptr, nullptr, nullptr, opts_rows(opts)))
     return done(check_launch("gb_gemm_dgrad"));
   if (opts_rows(opts)) return GB_EINVAL;  // a device-side row count: row-streaming kernel only
@@ -878,7 +888,7 @@ extern "C" int gb_gemm_kernel_for(int kind, long long P, int K, int N, int fused
     if (K <= 4 && !has_aff && N % 4 == 0 && N / 4 <= GTPB && P >= 4096) return 3;
     return (P % 32 == 0 && K % 4 == 0 && N % 4 == 0 && K >= 4 && N >= 4 && P <= 131072) ? 2 : 0;
   }
-  if (gb_gemm_uses_rs(P, K, N, kind, fused_stats, has_aff)) return 1;
+  if ((P >= RS_PAYS_FROM || fused_stats >= 2) && gb_gemm_uses_rs(P, K, N, kind, fused_stats, has_aff)) return 1;
   if (kind == 0) return K % 32 == 0 ? 2 : 0;
   return (N % 32 == 0 && K % 4 == 0) ? 2 : 0;
 }

@@ -500,7 +500,9 @@ int gb_gemm_dgrad(const float *dy, const float *w, float *dx, const float *y_pre
 int gb_gemm_wgrad(const float *dy, const float *x, const float *x_aff, float *dw, long long P, int K, int N,
                   const GbGemmOpts *opts, void *stream);
 /* Which kernel gb_gemm_fwd (dgrad = 0) / gb_gemm_dgrad (dgrad = 1) launches for 16-byte aligned operands of
- * this shape: 1 = the row-streaming kernel (csrc/gemm_rs.hip), 0 = the LDS-tiled one (csrc/gemm_cl.hip).
+ * this shape: 1 = the row-streaming kernel CAN run it (csrc/gemm_rs.hip: what the generated-operand, pooled and
+ * device-row-count entries require), 0 = it cannot.  The plain gb_gemm_fwd / gb_gemm_dgrad additionally prefer the tiled
+ * kernels below 65 536 rows (gb_gemm_kernel_for says what actually launches).
  * Pure host-side introspection (no launch), used by bench.py to attribute timings per kernel.      */
 int gb_gemm_uses_rs(long long P, int K, int N, int dgrad, int fused_stats, int has_aff);
 /* ... and, for all three products (kind 0 = gb_gemm_fwd, 1 = gb_gemm_dgrad, 2 = gb_gemm_wgrad; fp32, default options):

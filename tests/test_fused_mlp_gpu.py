@@ -234,7 +234,10 @@ def test_first_layer_closed_form_backward(train, widths):
     import torch.nn as nn
     from graspbalance_amd import fused_mlp
     torch.manual_seed(3)
-    P, ns = 32768 + 64, 64
+    # (65 536+ rows: the size from which the plain products run on the row-streaming kernel like the folded ones do -
+    #  below it the two executions sum their reductions in different orders, a few ReLU masks / arg-max rows flip between
+    #  them and the comparison measures that, 1e-3, instead of the backward formulas)
+    P, ns = 65536 + 64, 64
     chans = (3,) + tuple(widths)
     L = len(widths)
     convs = [nn.Conv2d(a, b, 1, bias=False) for a, b in zip(chans[:-1], chans[1:])]
@@ -318,11 +321,16 @@ def test_grasp_width_grouping_distinct_rows_equals_plain(golden):
     torch.manual_seed(5)
     plain = GraspWidthGrouping(64, 3, 0.06, -0.02, [0.01, 0.02, 0.03, 0.04]).to(DEV).train()
     cloud = torch.from_numpy(make_batch([0, 1], 20000)).to(DEV)
-    seeds = cloud[:, :256].contiguous()
-    rot = torch.from_numpy(golden.load("g9_views")["rot"])[:256].unsqueeze(0).repeat(2, 1, 1, 1).contiguous().to(DEV)
+    # (1024 seeds as in the step: > 65 536 distinct rows, so both executions run their plain products on the same kernel - see
+    #  test_first_layer_closed_form_backward.  The two executions sum their BatchNorm statistics in different orders, so
+    #  a pre-activation within rounding of zero can take a different ReLU branch: 256 / 400 / 1024 seeds agree to 5e-5,
+    #  600 seeds of this cloud hit one such flip - 5.5e-4 on the first layer's weight gradient, on every build tried.)
+    NS = 1024
+    seeds = cloud[:, :NS].contiguous()
+    rot = torch.from_numpy(golden.load("g9_views")["rot"])[torch.arange(NS) % 300].unsqueeze(0).repeat(2, 1, 1, 1).contiguous().to(DEV)
     idx = fused_ops.cylinder_query_multi(cloud, seeds, rot, [0.06], -0.02, [0.01, 0.02, 0.03, 0.04], 64)
     rows = fused_mlp.cylinder_rows(idx, cloud, seeds, rot)[0]
-    assert rows[0].shape[0] < 0.6 * idx[0].numel()  # the crops really overlap on this cloud
+    assert 65536 <= rows[0].shape[0] < 0.6 * idx[0].numel()  # the crops really overlap on this cloud
     res = {}
     for name in ("dedup", "all_rows"):
         m = copy.deepcopy(plain)

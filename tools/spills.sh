@@ -1,9 +1,9 @@
 #!/bin/bash
-# CPU-only: compile each given csrc/*.hip for gfx950 with -Rpass-analysis=kernel-resource-usage and list the kernels that
+# CPU-only (the flags of csrc/Makefile): compile each given csrc/*.hip for gfx950 with -Rpass-analysis=kernel-resource-usage and list the kernels that
 # use scratch memory or spill registers (name, VGPRs, scratch bytes per lane, spills, occupancy).
 cd "$(dirname "$0")/../graspbalance_amd/csrc"
 for f in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -ffp-contract=off -I../../include -c $f.hip -o /tmp/$f.spills.o -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c "
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -munsafe-fp-atomics -fno-fast-math -I../../include -c $f.hip -o /tmp/$f.spills.o -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c "
 import sys,re,subprocess
 cur=None;d={}
 for l in sys.stdin:

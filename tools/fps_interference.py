@@ -69,3 +69,23 @@ def no_main_to_side():   # the sampling launched without waiting for the main st
     cur = torch.cuda.current_stream(); fps(); replay(); cur.wait_stream(side)
 print("no main->side wait, sampling: %.3f ms (host %.2f)" % (timeit(no_main_to_side), HOST[0]), flush=True)
 print("graphs alone:                 %.3f ms" % timeit(replay), flush=True)
+# ---- does the cost scale with how long / on how many CUs the sampling is resident?  (no main->side wait in any of these)
+def fps_var(nclouds, npoint):
+    def fn():
+        cur = torch.cuda.current_stream()
+        with torch.cuda.stream(side), torch.no_grad():
+            pointnet2_utils.furthest_point_sample(st.next_clouds[:nclouds, :, 0:3].contiguous(), npoint)
+        replay(); cur.wait_stream(side)
+    return fn
+def fps_only(nclouds, npoint):
+    def fn():
+        with torch.no_grad():
+            pointnet2_utils.furthest_point_sample(st.next_clouds[:nclouds, :, 0:3].contiguous(), npoint)
+    return fn
+for nc, npnt in ((4, 2048), (4, 1024), (4, 512), (4, 128), (2, 2048), (1, 2048)):
+    alone = timeit(fps_only(nc, npnt)); t = timeit(fps_var(nc, npnt)); base = timeit(replay)
+    print("sampling %d clouds x %4d picks (alone %.2f ms) beside the graphs: %.3f ms, graphs alone %.3f ms -> +%.2f" % (nc, npnt, alone, t, base, t - base), flush=True)
+def after():   # launched after both graph launches
+    cur = torch.cuda.current_stream(); replay(); fps(); cur.wait_stream(side)
+t = timeit(after); base = timeit(replay)
+print("sampling launched after both graphs: %.3f ms vs %.3f" % (t, base), flush=True)

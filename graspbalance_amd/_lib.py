@@ -40,6 +40,7 @@ SIGNATURES = {
     "gb_group": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gb_group_grad": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gb_three_nn": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "gb_interp_weights": [_P, _P, _L, _P],
     "gb_three_interpolate": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gb_three_interpolate_grad": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gb_knn1": [_P, _P, _P, _I, _I, _I, _I, _P],

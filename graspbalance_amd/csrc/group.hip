@@ -787,6 +787,33 @@ extern "C" int gb_three_nn(const float *unknown, const float *known, float *dist
   return check_launch("gb_three_nn");
 }
 
+// The inverse-distance weights PointnetFPModule forms from three_nn's output (pointnet2_modules.py:260-263 + the sqrt of
+// pointnet2_utils.py:84): d = sqrt(d2); r = 1 / (d + 1e-8); w = r / ((r0 + r1) + r2) - five torch launches as one pass,
+// same operations in the same order (correctly rounded sqrt and divisions, no contraction).
+namespace gb {
+__global__ void interp_weights_kernel(const float *__restrict__ dist2, float *__restrict__ weight, long long rows) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  const float r0 = 1.0f / (sqrtf(dist2[i * 3]) + 1e-8f);
+  const float r1 = 1.0f / (sqrtf(dist2[i * 3 + 1]) + 1e-8f);
+  const float r2 = 1.0f / (sqrtf(dist2[i * 3 + 2]) + 1e-8f);
+  const float norm = (r0 + r1) + r2;
+  weight[i * 3] = r0 / norm;
+  weight[i * 3 + 1] = r1 / norm;
+  weight[i * 3 + 2] = r2 / norm;
+}
+}  // namespace gb
+
+extern "C" int gb_interp_weights(const float *dist2, float *weight, long long rows, void *stream) {
+  using namespace gb;
+  if (rows < 0 || !dist2 || !weight) return GB_EINVAL;
+  if (rows == 0) return GB_OK;
+  if ((rows + 255) / 256 > 0x7fffffffLL) return GB_ERANGE;
+  hipLaunchKernelGGL(interp_weights_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, as_stream(stream), dist2,
+                     weight, rows);
+  return check_launch("gb_interp_weights");
+}
+
 extern "C" int gb_three_interpolate(const float *points, const int32_t *idx, const float *weight,
                                     float *out, int b, int c, int m, int n, void *stream) {
   if (b < 0 || c < 0 || m < 1 || n < 0 || !points || !idx || !weight || !out) return GB_EINVAL;

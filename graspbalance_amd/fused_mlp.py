@@ -1135,7 +1135,15 @@ class _ZeroGradFor(Function):
 
     @staticmethod
     def backward(ctx, g):
-        return (g,) + tuple(torch.zeros(sh, dtype=dt, device=dev) for sh, dt, dev in ctx.shapes)
+        # (views of the step's zeroed fp32 arena where there is one: no fill launches)
+        def z(sh, dt, dev):
+            n = 1
+            for d in sh:
+                n *= d
+            if dt == torch.float32 and dev.type == "cuda":
+                return _zeros32(n, dev).view(sh)
+            return torch.zeros(sh, dtype=dt, device=dev)
+        return (g,) + tuple(z(sh, dt, dev) for sh, dt, dev in ctx.shapes)
 
 
 def _stack(X, convs_bns, pool_ns=0, residual=None, relu_last=True, rows=None):
@@ -1157,8 +1165,8 @@ def _stack(X, convs_bns, pool_ns=0, residual=None, relu_last=True, rows=None):
                 cfg.running_mean = bn.running_mean - conv.bias.detach()
         layers.append(cfg)
     out = MLPStack.apply(X, residual, layers, pool_ns, relu_last, rows, *params)
-    for running_mean, bias, momentum in shifts:
-        running_mean.add_(bias, alpha=momentum)
+    if shifts:   # (one launch for the stack's layers)
+        torch._foreach_add_([s[0] for s in shifts], [s[1] for s in shifts], alpha=shifts[0][2])
     if biased and any(b.requires_grad for b in biased) and out.requires_grad:
         out = _ZeroGradFor.apply(out, *biased)
     return out
@@ -1180,8 +1188,7 @@ class LinearBias(Function):
         _call("gb_gemm_fwd", dev, _lib.ptr(X), _lib.ptr(W), None, _lib.ptr(Y), None, 1, P, K, N, None,
               _opts(dev, st, ctx.prec), st, meta=_gemm_meta("fwd", P, K, N))
         if b is not None:
-            ab = torch.cat([torch.ones_like(b), b.detach()])
-            _call("gb_affine_act", dev, _lib.ptr(Y), _lib.ptr(ab), None, _lib.ptr(Y), P, N, 0, st)  # in place: y += b
+            Y.add_(b.detach())     # (one launch; 1 * y + b of the affine pass it replaces is the same value)
         ctx.has_bias = b is not None
         ctx.save_for_backward(X, W)
         return Y

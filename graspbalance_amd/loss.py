@@ -262,7 +262,11 @@ def _get_loss_fused(end_points, prior):
         view_label, _seed_objectness(end_points).contiguous(), weight,
         f(end_points['batch_grasp_label']), f(end_points['batch_grasp_offset']), f(end_points['batch_grasp_tolerance']),
         *extra)
-    vals = out.unbind(0)
+    # (the metrics from a detached view: `out.unbind(0)` under autograd made the engine materialise a zero gradient for
+    #  each of the 13 unused scalars and stack them - 15 launches for nothing)
+    vals = list(out.detach().unbind(0))
+    for k in range(7):       # the loss and its six terms stay differentiable (views: nothing is launched for them)
+        vals[k] = out[k]
     end_points['graspable_mask'] = graspable
     for k, name in enumerate(('loss/overall_loss', 'loss/stage1_graspable_loss', 'loss/stage1_view_loss',
                               'loss/stage2_grasp_score_loss', 'loss/stage2_grasp_angle_class_loss',

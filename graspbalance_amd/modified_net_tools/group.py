@@ -113,7 +113,8 @@ class BallQuery(Function):
         assert xyz.is_contiguous()
         B, N, _ = xyz.size()
         npoint = new_xyz.size(1)
-        idx = torch.zeros((B, npoint, nsample), dtype=torch.int32, device=xyz.device)
+        # (group.py:116 zero-fills; gb_ball_query writes every element, so the fill is not needed)
+        idx = torch.empty((B, npoint, nsample), dtype=torch.int32, device=xyz.device)
         pointnet2_cuda.ball_query_wrapper(B, N, npoint, radius, nsample, new_xyz, xyz, idx)
         ctx.mark_non_differentiable(idx)
         return idx

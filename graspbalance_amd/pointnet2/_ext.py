@@ -48,7 +48,9 @@ def furthest_point_sampling(points, nsamples):
     _require_gpu(points)
     B, N = points.size(0), points.size(1)
     output = torch.empty((B, nsamples), dtype=torch.int32, device=points.device)  # every element is written by the kernel
-    tmp = torch.full((B, N), 1e10, dtype=torch.float32, device=points.device)
+    # (the wrapper's running min-distance buffer `tmp = full(1e10)` - sampling.cpp:81 - never leaves it: the library
+    #  starts from 1e10 itself when given no buffer, one fill launch less per call)
+    tmp = None if N <= 20480 else torch.full((B, N), 1e10, dtype=torch.float32, device=points.device)   # (the streamed forms keep it)
     with _lib.device_ctx(points.device):
         stream = _lib.current_stream(points.device)
         _lib.check(_lib.timed("gb_fps", points.device, {"b": B, "n": N, "m": nsamples},
@@ -186,8 +188,10 @@ def three_nn(unknowns, knows):
     _require_gpu(unknowns)
     B, n = unknowns.size(0), unknowns.size(1)
     m = knows.size(1)
-    idx = torch.zeros((B, n, 3), dtype=torch.int32, device=unknowns.device)
-    dist2 = torch.zeros((B, n, 3), dtype=torch.float32, device=unknowns.device)
+    # (m >= 3: the kernel writes all three slots of every row; fewer known points leave slots at the wrapper's zeros)
+    alloc = torch.empty if m >= 3 else torch.zeros
+    idx = alloc((B, n, 3), dtype=torch.int32, device=unknowns.device)
+    dist2 = alloc((B, n, 3), dtype=torch.float32, device=unknowns.device)
     with _lib.device_ctx(unknowns.device):
         _lib.check(_lib.lib().gb_three_nn(_lib.ptr(unknowns), _lib.ptr(knows), _lib.ptr(dist2), _lib.ptr(idx),
                                           B, n, m, _lib.current_stream(unknowns.device)), "three_nn")

@@ -259,10 +259,15 @@ class PointnetFPModule(nn.Module):
     def forward(self, unknown: torch.Tensor, known: torch.Tensor, unknow_feats: torch.Tensor,
                 known_feats: torch.Tensor) -> torch.Tensor:
         if known is not None:
-            dist, idx = pointnet2_utils.three_nn(unknown, known)
-            dist_recip = 1.0 / (dist + 1e-8)
-            norm = torch.sum(dist_recip, dim=2, keepdim=True)
-            weight = dist_recip / norm
+            if (unknown.is_cuda and unknown.dtype == torch.float32 and known.dtype == torch.float32
+                    and not (unknown.requires_grad or known.requires_grad)):
+                # three_nn + the five element-wise launches of the weights as two kernels (same operations, same order)
+                weight, idx = pointnet2_utils.three_nn_weights(unknown, known)
+            else:
+                dist, idx = pointnet2_utils.three_nn(unknown, known)
+                dist_recip = 1.0 / (dist + 1e-8)
+                norm = torch.sum(dist_recip, dim=2, keepdim=True)
+                weight = dist_recip / norm
             interpolated_feats = pointnet2_utils.three_interpolate(known_feats.contiguous(), idx, weight)
         else:
             interpolated_feats = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))

@@ -85,6 +85,19 @@ class ThreeNN(Function):
 three_nn = ThreeNN.apply
 
 
+def three_nn_weights(unknown, known):
+    """(weight (B,n,3), idx (B,n,3) int32): the three nearest known points of every unknown point and the normalised
+    inverse-distance weights PointnetFPModule forms from them (pointnet2_modules.py:260-263), as two launches."""
+    from . import _lib
+    with torch.no_grad():
+        dist2, idx = _ext.three_nn(unknown.contiguous(), known.contiguous())
+        weight = torch.empty_like(dist2)
+        with _lib.device_ctx(dist2.device):
+            _lib.check(_lib.lib().gb_interp_weights(_lib.ptr(dist2), _lib.ptr(weight), dist2.numel() // 3,
+                                                    _lib.current_stream(dist2.device)), "interp_weights")
+    return weight, idx
+
+
 class ThreeInterpolate(Function):
     @staticmethod
     def forward(ctx, features, idx, weight):

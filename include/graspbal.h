@@ -148,6 +148,10 @@ int gb_group_grad(const float *grad_out, const int32_t *idx, float *grad_points,
  * slots are (+inf, 0) like the reference's 1e40 -> float conversion.                            */
 int gb_three_nn(const float *unknown, const float *known, float *dist2, int32_t *idx, int b, int n,
                 int m, void *stream);
+/* The inverse-distance interpolation weights of PointnetFPModule (reference PointNet/pointnet2_modules.py:260-263 with the
+ * sqrt of pointnet2_utils.py:84) from gb_three_nn's SQUARED distances: dist2, weight (rows, 3) f32;
+ * w_k = r_k / ((r_0 + r_1) + r_2), r_k = 1 / (sqrt(dist2_k) + 1e-8).                                                  */
+int gb_interp_weights(const float *dist2, float *weight, long long rows, void *stream);
 /* out[b,c,j] = sum_t points[b,c,idx[b,j,t]] * weight[b,j,t], evaluated (p1*w1 + p2*w2) + p3*w3.
  * PN interpolate_gpu.cu:77-116, PB :84-117. points (b,c,m), idx/weight (b,n,3), out (b,c,n).      */
 int gb_three_interpolate(const float *points, const int32_t *idx, const float *weight, float *out,

@@ -252,6 +252,27 @@ def test_three_nn_golden(ext, golden):
     assert torch.equal(idx.cpu(), torch.from_numpy(g["idx"])) and torch.equal(d2.cpu(), torch.from_numpy(g["dist2"]))
 
 
+def test_interpolation_weights_equal_the_reference_composition(ext):
+    """gb_interp_weights (pointnet2_utils.three_nn_weights): the PointnetFPModule weights formed from three_nn's squared
+    distances in one pass == sqrt, + 1e-8, 1/x, sum over the three, divide as IEEE float32 operations in that order
+    (the CPU evaluation of the reference lines, pointnet2_modules.py:260-263), bit for bit; duplicates (distance 0) kept."""
+    from graspbalance_amd import pointnet2_utils
+    torch.manual_seed(11)
+    unknown, known = torch.rand(2, 3000, 3), torch.rand(2, 700, 3)
+    unknown[0, :50] = known[0, :50]          # exact hits: d = 0, r = 1e8
+    w, idx = pointnet2_utils.three_nn_weights(unknown.to(DEV), known.to(DEV))
+    d2, idx_ref = ext.three_nn(unknown.to(DEV), known.to(DEV))
+    assert torch.equal(idx, idx_ref)
+    def compose(d2):
+        recip = 1.0 / (torch.sqrt(d2) + 1e-8)
+        return recip / ((recip[..., 0] + recip[..., 1]) + recip[..., 2]).unsqueeze(-1)
+    assert torch.equal(w, compose(d2))                                   # the same launches' worth of torch on the GPU
+    cpu = compose(d2.cpu())
+    print("interp weights vs CPU torch: max abs diff %.2e" % float((w.cpu() - cpu).abs().max()))
+    assert torch.allclose(w.cpu(), cpu, rtol=3e-7, atol=1e-12)
+    assert float((w.sum(-1) - 1).abs().max()) < 1e-6
+
+
 # ----------------------------------------- knn1 ------------------------------------------------
 def test_knn1(orc, golden):
     from graspbalance_amd import _lib

@@ -43,6 +43,13 @@ __global__ void resident(const int *src, int *out, int iters) {
       for (int k = 0; k < 64; ++k) f = f * 1.0001f + 0.5f;
       asm volatile("v_mov_b32 v127, 0" ::: "v127");
       if (MODE == 6 || (i & 7) == 0) __builtin_amdgcn_s_sleep(1);   // a yield point without a barrier
+    } else if (MODE == 12 || MODE == 13) {   // unbalanced like the sampling kernel: few waves work, the rest wait at the barrier
+      if ((threadIdx.x >> 6) < (MODE == 12 ? 1 : 4)) {
+#pragma unroll
+        for (int k = 0; k < 64; ++k) f = f * 1.0001f + 0.5f;
+      }
+      asm volatile("v_mov_b32 v127, 0" ::: "v127");
+      __syncthreads();
     } else if (MODE >= 8) {   // 8: a barrier per 64 FMAs; 9: per 256; 10: per 1024; 11: per 4096
 #pragma unroll
       for (int k = 0; k < 64; ++k) f = f * 1.0001f + 0.5f;
@@ -90,7 +97,8 @@ int main() {
                         {"pure ALU, 1024 threads, 128 VGPRs each", 5, 1024, 4500}, {"pure ALU, 512 threads, 128 VGPRs each", 5, 512, 9000},
                         {"ALU + s_sleep 1 per 64 FMA, 1024 thr, 128 VGPRs", 6, 1024, 3500}, {"ALU + s_sleep 1 per 512 FMA, 1024 thr, 128 VGPRs", 7, 1024, 4300},
                         {"ALU + s_barrier per 64 FMA, 1024 thr, 128 VGPRs", 8, 1024, 4000}, {"ALU + s_barrier per 256 FMA, 1024 thr, 128 VGPRs", 9, 1024, 4300},
-                        {"ALU + s_barrier per 1024 FMA, 1024 thr, 128 VGPRs", 10, 1024, 4400}, {"ALU + s_barrier per 4096 FMA, 1024 thr, 128 VGPRs", 11, 1024, 4450}};
+                        {"ALU + s_barrier per 1024 FMA, 1024 thr, 128 VGPRs", 10, 1024, 4400}, {"ALU + s_barrier per 4096 FMA, 1024 thr, 128 VGPRs", 11, 1024, 4450},
+                        {"1 of 16 waves works, barrier per 64 FMA, 128 VGPRs", 12, 1024, 4400}, {"4 of 16 waves work, barrier per 64 FMA, 128 VGPRs", 13, 1024, 4400}};
   for (const Case &c : cases) {
     const int nb = (c.name[10] == '4' && c.name[12] == 'x') ? 4 : 1;
     auto side_k = [&]() {
@@ -103,6 +111,8 @@ int main() {
         case 6: hipLaunchKernelGGL(resident<6>, dim3(1), dim3(c.threads), 0, side, src, out, c.iters); break;
         case 7: hipLaunchKernelGGL(resident<7>, dim3(1), dim3(c.threads), 0, side, src, out, c.iters); break;
         case 8: hipLaunchKernelGGL(resident<8>, dim3(1), dim3(c.threads), 0, side, src, out, c.iters); break;
+        case 12: hipLaunchKernelGGL(resident<12>, dim3(1), dim3(c.threads), 0, side, src, out, c.iters); break;
+        case 13: hipLaunchKernelGGL(resident<13>, dim3(1), dim3(c.threads), 0, side, src, out, c.iters); break;
         case 9: hipLaunchKernelGGL(resident<9>, dim3(1), dim3(c.threads), 0, side, src, out, c.iters); break;
         case 10: hipLaunchKernelGGL(resident<10>, dim3(1), dim3(c.threads), 0, side, src, out, c.iters); break;
         case 11: hipLaunchKernelGGL(resident<11>, dim3(1), dim3(c.threads), 0, side, src, out, c.iters); break;

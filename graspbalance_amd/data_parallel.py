@@ -8,6 +8,7 @@ reference uses plain BatchNorm, never SyncBN), and the whole fp32 gradient (9.05
 36 MB) is reduced as a few large flat buckets: xGMI is point-to-point, so few big collectives beat
 many per-parameter ones.
 """
+import os
 import torch
 import torch.distributed as dist
 
@@ -150,9 +151,16 @@ class FlatGradAllReduce:
         if self.timing:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        works = [dist.all_reduce(flat, op=op, group=self.group, async_op=True) for flat in self.flat]
-        for w in works:
-            w.wait()
+        if os.environ.get("GB_ALLREDUCE_ASYNC", "0") == "1":
+            works = [dist.all_reduce(flat, op=op, group=self.group, async_op=True) for flat in self.flat]
+            for w in works:
+                w.wait()
+        else:
+            # synchronous form: this torch issues it on the CURRENT stream (no hop to the process group's own stream and
+            # back - the two cross-stream waits cost the graph-replayed step 0.7 ms)
+            # ... and as ONE collective over the whole buffer (the buckets are its contiguous slices; nothing is left to
+            # overlap them with, so fewer, larger messages over the point-to-point xGMI links)
+            dist.all_reduce(self.flat_all, op=op, group=self.group)
         if not self._avg:
             for flat in self.flat:
                 flat.div_(self.world_size)

@@ -140,3 +140,53 @@ for name, k in (("order + pruned, pre-allocated", k_seq), ("... + fills", k_seq_
     def beside_k():
         cur = torch.cuda.current_stream(); k(); g.replay(); cur.wait_stream(side)
     print("%-34s alone %.3f ms; HBM passes beside it %.3f ms (alone %.3f)" % (name, timeit(alone_k, 10), timeit(beside_k, 10), base), flush=True)
+# ---- the un-pruned kernel (every point updated every iteration: no ballot / readlane / LDS key table) at a length that
+#      fits under the main work, with a fresh min-distance array each time
+out_small = torch.zeros((b_, 1100), dtype=torch.int32, device=dev)
+def k_plain_short():
+    with torch.cuda.stream(side):
+        temp.fill_(1e10)
+    L.check(L.lib().gb_fps(L.ptr(xyz), L.ptr(temp), L.ptr(out_small), b_, n_, 1100, flags, sstream), "fps")
+def k_pruned_fresh_short():
+    with torch.cuda.stream(side):
+        temp.fill_(1e10)
+    L.check(L.lib().gb_fps_pruned(L.ptr(xyz), L.ptr(perm), L.ptr(temp), L.ptr(out_small), b_, n_, 1100, flags, None, sstream), "pruned")
+for name, k in (("un-pruned kernel, 1100 picks, fresh", k_plain_short), ("pruned kernel, 1100 picks, fresh", k_pruned_fresh_short)):
+    def alone_k():
+        k(); torch.cuda.current_stream().wait_stream(side)
+    def beside_k():
+        cur = torch.cuda.current_stream(); k(); g.replay(); cur.wait_stream(side)
+    print("%-38s alone %.3f ms; HBM passes beside it %.3f ms (alone %.3f)" % (name, timeit(alone_k, 10), timeit(beside_k, 10), base), flush=True)
+# ---- where in the sampling does the interference come from?  pruned kernel, fresh array, growing number of picks
+for mm in (300, 600, 1100, 1400, 1700, 2048):
+    out_m = torch.zeros((b_, mm), dtype=torch.int32, device=dev)
+    def k_m():
+        with torch.cuda.stream(side):
+            temp.fill_(1e10)
+        L.check(L.lib().gb_fps_pruned(L.ptr(xyz), L.ptr(perm), L.ptr(temp), L.ptr(out_m), b_, n_, mm, flags, None, sstream), "pruned")
+    def alone_k():
+        k_m(); torch.cuda.current_stream().wait_stream(side)
+    def beside_k():
+        cur = torch.cuda.current_stream(); k_m(); g.replay(); cur.wait_stream(side)
+    a = timeit(alone_k, 10); bb = timeit(beside_k, 10)
+    print("pruned kernel, %4d picks: alone %.3f ms; HBM passes beside it %.3f ms (+%.2f)" % (mm, a, bb, bb - base), flush=True)
+# ---- is it the LENGTH of one kernel's residency?  two back-to-back launches of 1024 picks against one of 2048
+out_h = torch.zeros((b_, 1024), dtype=torch.int32, device=dev)
+def k_two():
+    for _ in range(2):
+        with torch.cuda.stream(side):
+            temp.fill_(1e10)
+        L.check(L.lib().gb_fps_pruned(L.ptr(xyz), L.ptr(perm), L.ptr(temp), L.ptr(out_h), b_, n_, 1024, flags, None, sstream), "pruned")
+def k_four():
+    out_q = out_h[:, :512].contiguous()
+    for _ in range(4):
+        with torch.cuda.stream(side):
+            temp.fill_(1e10)
+        L.check(L.lib().gb_fps_pruned(L.ptr(xyz), L.ptr(perm), L.ptr(temp), L.ptr(out_q), b_, n_, 512, flags, None, sstream), "pruned")
+for name, k in (("2 x 1024 picks back to back", k_two), ("4 x 512 picks back to back", k_four)):
+    def alone_k():
+        k(); torch.cuda.current_stream().wait_stream(side)
+    def beside_k():
+        cur = torch.cuda.current_stream(); k(); g.replay(); cur.wait_stream(side)
+    a = timeit(alone_k, 10); bb = timeit(beside_k, 10)
+    print("%-30s alone %.3f ms; HBM passes beside it %.3f ms (+%.2f)" % (name, a, bb, bb - base), flush=True)

@@ -43,6 +43,16 @@ __global__ void resident(const int *src, int *out, int iters) {
       for (int k = 0; k < 64; ++k) f = f * 1.0001f + 0.5f;
       asm volatile("v_mov_b32 v127, 0" ::: "v127");
       if (MODE == 6 || (i & 7) == 0) __builtin_amdgcn_s_sleep(1);   // a yield point without a barrier
+    } else if (MODE >= 14 && MODE <= 16) {   // like the sampling loop: uniform global load + ALU burst (+ a store by thread 0) + barrier
+      const int o = src[idx & 1023];                       // every wave loads the same "winner" (an L2 hit)
+      if (MODE != 16 || ((threadIdx.x >> 6) + i) % 4 == 0) {
+#pragma unroll
+        for (int k = 0; k < 64; ++k) f = f * 1.0001f + (float)o;
+      }
+      asm volatile("v_mov_b32 v127, 0" ::: "v127");
+      if (MODE >= 15 && threadIdx.x == 0) out[1 + (i & 1023)] = o;
+      idx = o;
+      __syncthreads();
     } else if (MODE == 12 || MODE == 13) {   // unbalanced like the sampling kernel: few waves work, the rest wait at the barrier
       if ((threadIdx.x >> 6) < (MODE == 12 ? 1 : 4)) {
 #pragma unroll
@@ -73,7 +83,7 @@ int main() {
   const size_t n = 64u << 20;
   float *x; int *src, *out;
   hipMalloc(&x, n * 4); hipMemset(x, 0, n * 4);
-  hipMalloc(&src, 1024 * 4); hipMalloc(&out, 4);
+  hipMalloc(&src, 1024 * 4); hipMalloc(&out, 4 * 2048);
   std::vector<int> h(1024); for (int i = 0; i < 1024; ++i) h[i] = (i * 37 + 11) & 1023;
   hipMemcpy(src, h.data(), 4096, hipMemcpyHostToDevice);
   hipStream_t mainq, side; hipStreamCreate(&mainq); hipStreamCreate(&side);
@@ -98,7 +108,9 @@ int main() {
                         {"ALU + s_sleep 1 per 64 FMA, 1024 thr, 128 VGPRs", 6, 1024, 3500}, {"ALU + s_sleep 1 per 512 FMA, 1024 thr, 128 VGPRs", 7, 1024, 4300},
                         {"ALU + s_barrier per 64 FMA, 1024 thr, 128 VGPRs", 8, 1024, 4000}, {"ALU + s_barrier per 256 FMA, 1024 thr, 128 VGPRs", 9, 1024, 4300},
                         {"ALU + s_barrier per 1024 FMA, 1024 thr, 128 VGPRs", 10, 1024, 4400}, {"ALU + s_barrier per 4096 FMA, 1024 thr, 128 VGPRs", 11, 1024, 4450},
-                        {"1 of 16 waves works, barrier per 64 FMA, 128 VGPRs", 12, 1024, 4400}, {"4 of 16 waves work, barrier per 64 FMA, 128 VGPRs", 13, 1024, 4400}};
+                        {"1 of 16 waves works, barrier per 64 FMA, 128 VGPRs", 12, 1024, 4400}, {"4 of 16 waves work, barrier per 64 FMA, 128 VGPRs", 13, 1024, 4400},
+                        {"load + 64 FMA + barrier per iteration", 14, 1024, 2500}, {"... + store by thread 0, 80 KB LDS", 15, 1024, 2500},
+                        {"... and only a quarter of the waves working", 16, 1024, 4000}};
   for (const Case &c : cases) {
     const int nb = (c.name[10] == '4' && c.name[12] == 'x') ? 4 : 1;
     auto side_k = [&]() {
@@ -111,6 +123,9 @@ int main() {
         case 6: hipLaunchKernelGGL(resident<6>, dim3(1), dim3(c.threads), 0, side, src, out, c.iters); break;
         case 7: hipLaunchKernelGGL(resident<7>, dim3(1), dim3(c.threads), 0, side, src, out, c.iters); break;
         case 8: hipLaunchKernelGGL(resident<8>, dim3(1), dim3(c.threads), 0, side, src, out, c.iters); break;
+        case 14: hipLaunchKernelGGL(resident<14>, dim3(1), dim3(c.threads), 0, side, src, out, c.iters); break;
+        case 15: hipLaunchKernelGGL(resident<15>, dim3(1), dim3(c.threads), 80 * 1024, side, src, out, c.iters); break;
+        case 16: hipLaunchKernelGGL(resident<16>, dim3(1), dim3(c.threads), 80 * 1024, side, src, out, c.iters); break;
         case 12: hipLaunchKernelGGL(resident<12>, dim3(1), dim3(c.threads), 0, side, src, out, c.iters); break;
         case 13: hipLaunchKernelGGL(resident<13>, dim3(1), dim3(c.threads), 0, side, src, out, c.iters); break;
         case 9: hipLaunchKernelGGL(resident<9>, dim3(1), dim3(c.threads), 0, side, src, out, c.iters); break;

@@ -190,3 +190,26 @@ for name, k in (("2 x 1024 picks back to back", k_two), ("4 x 512 picks back to 
         cur = torch.cuda.current_stream(); k(); g.replay(); cur.wait_stream(side)
     a = timeit(alone_k, 10); bb = timeit(beside_k, 10)
     print("%-30s alone %.3f ms; HBM passes beside it %.3f ms (+%.2f)" % (name, a, bb, bb - base), flush=True)
+# ---- does a pause reset it?  half the picks beside the first half of the work, the other half beside the second half
+def half_work():
+    x = torch.empty(64 << 20, device=dev)
+    def fn():
+        for _ in range(20):
+            x.add_(1.0)
+    return fn
+g_half = capture(half_work())
+base_half = timeit(g_half.replay)
+def k_half():
+    with torch.cuda.stream(side):
+        temp.fill_(1e10)
+    L.check(L.lib().gb_fps_pruned(L.ptr(xyz), L.ptr(perm), L.ptr(temp), L.ptr(out_h), b_, n_, 1024, flags, None, sstream), "pruned")
+def split_with_pause():
+    cur = torch.cuda.current_stream()
+    k_half(); g_half.replay()
+    side.wait_stream(cur)          # the second half starts when the first half of the work is done
+    k_half(); g_half.replay()
+    cur.wait_stream(side)
+def two_halves_alone():
+    g_half.replay(); g_half.replay()
+print("two halves of the work alone %.3f ms; each half beside 1024 picks, second half started after a pause: %.3f ms"
+      % (timeit(two_halves_alone, 10), timeit(split_with_pause, 10)), flush=True)

@@ -38,6 +38,7 @@ _GRAPH_DEFAULT = os.environ.get("GB_GRAPH", "1") != "0"  # A/B switch: 0 = every
 # one of them waits for the tile that landed on a CU the sampling occupies; beside the backward's first kernels (split-K
 # grids of ~1000 workgroups, persistent row-streaming grids sized for the CUs left over) see DESIGN.md section 5.6.
 _SAMPLE_AT = os.environ.get("GB_SAMPLE_AT", "bwd")
+_MAX_SIGNATURES = int(os.environ.get("GB_GRAPH_MAX_SIGNATURES", "4"))
 _NO_CONTEXT = contextlib.nullcontext()
 
 BN_MOMENTUM_INIT = 0.5
@@ -97,7 +98,9 @@ class Trainer:
         self.distributed = bool(distributed)
         self._graphs = {}        # signature -> _StepGraph
         self._pool = None        # memory pool shared by the graphs (one replays at a time)
-        self._static = None      # _StaticBatch: the input buffers the graphs read
+        self._static = None      # _StaticBatch: the input buffers the graphs of the current batch signature read
+        self._statics = {}       # signature -> _StaticBatch (a graph reads the buffers it was captured on: kept with it)
+        self._eager_signatures = set()
         self.graph_replays = 0
 
     def train_step(self, batch, next_batch=None):
@@ -150,11 +153,30 @@ class Trainer:
         replay the graph without any staging copy (a data loader would write its next batch into them directly)."""
         if not self.graph:
             return batch
-        if self._static is None or self._static.signature != _signature(batch):
-            self._static = _StaticBatch(batch, self.prefetch.npoint if self.prefetch is not None else 0)
-        else:
-            self._static.load(batch)
-        return self._static.batch
+        st = self._static_for(_signature(batch), batch)
+        if st is None:
+            return batch
+        st.load(batch)
+        return st.batch
+
+    def _static_for(self, sig, batch):
+        """The static buffers (and with them the captured graphs) of a batch signature; None once more than
+        GB_GRAPH_MAX_SIGNATURES (default 4) different signatures have been seen - every one costs a capture (~1.5 s), its
+        own copy of the inputs and graph memory, so a loader whose shapes keep changing runs launch by launch instead."""
+        st = self._statics.get(sig)
+        if st is None:
+            if sig in self._eager_signatures:
+                return None
+            if len(self._statics) >= _MAX_SIGNATURES:
+                if not self._eager_signatures:
+                    import warnings
+                    warnings.warn("graspbalance_amd.Trainer: more than %d batch signatures (shapes) seen; further new ones "
+                                  "run launch by launch instead of being captured" % _MAX_SIGNATURES)
+                self._eager_signatures.add(sig)
+                return None
+            st = self._statics[sig] = _StaticBatch(batch, self.prefetch.npoint if self.prefetch is not None else 0)
+        self._static = st
+        return st
 
     def _bn_momentum(self):
         for m in self.net.modules():
@@ -165,9 +187,9 @@ class Trainer:
     def _graph_step(self, batch, next_batch):
         announced = self.prefetch is not None and next_batch is not None
         sig = _signature(batch)
-        if self._static is None or self._static.signature != sig:
-            self._static = _StaticBatch(batch, self.prefetch.npoint if self.prefetch is not None else 0)
-        st = self._static
+        st = self._static_for(sig, batch)
+        if st is None:
+            return self._train_step(batch, next_batch)
         st.load(batch)                                   # no copies when `batch` is st.batch (Trainer.resident)
         if announced:
             st.load_next(next_batch['point_clouds'])

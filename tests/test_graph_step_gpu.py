@@ -150,3 +150,29 @@ def test_full_size_graph_step_matches_eager():
     # update only agrees to cos ~0.7 between two EAGER runs)
     moved = (_flat(graph) - p0).abs()
     assert all(bool(torch.isfinite(p).all()) for p in graph.net.parameters()) and float((moved > 0).double().mean()) > 0.9
+
+
+def test_batch_signatures_keep_their_own_buffers_and_graphs_and_too_many_run_launch_by_launch(monkeypatch):
+    """A loader that alternates between two batch shapes: each signature has its own static buffers and graphs (a graph
+    must never be replayed on buffers other than the ones it was captured on), coming back to the first one replays its
+    graph.  Beyond GB_GRAPH_MAX_SIGNATURES a new shape is not captured but run launch by launch, with one warning."""
+    import warnings
+    from graspbalance_amd import train
+    from graspbalance_amd.synthetic import make_training_batch
+    monkeypatch.setattr(train, "_MAX_SIGNATURES", 2)
+    eager, graph = _pair()
+    mk = lambda seeds, npts, gp: make_training_batch(seeds, num_point=npts, num_objects=2, grasp_points_per_object=gp,
+                                                     num_view=30, device=DEV)
+    a, b, c = mk([0, 1], 3000, 20), mk([2, 3], 3000, 24), mk([4, 5], 3000, 28)     # three label shapes = three signatures
+    seq = [a, b, a, b, c, a, c]
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        for i, bt in enumerate(seq):
+            le = float(eager.train_step(bt, next_batch=bt).detach())
+            lg = float(graph.train_step(bt, next_batch=bt))
+            assert abs(le - lg) < (_TOL0 if i == 0 else _TOL) * abs(le), (i, le, lg)
+    assert len(graph._statics) == 2 and len(graph._graphs) == 2
+    assert graph.graph_replays == 5                      # a b a b . a .   (c ran launch by launch, twice)
+    assert sum("batch signatures" in str(w.message) for w in caught) == 1
+    sa, sb = (graph._statics[train._signature(x)] for x in (a, b))
+    assert sa is not sb and torch.equal(sa.batch['point_clouds'], a['point_clouds']) and torch.equal(sb.batch['point_clouds'], b['point_clouds'])

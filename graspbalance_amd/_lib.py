@@ -76,6 +76,9 @@ SIGNATURES = {
     "gb_label_gather": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gb_label_scores": [_P, _P, _I, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _P],
     "gb_label_gather_view": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "gb_label_gather_dt": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "gb_label_scores_dt": [_P, _P, _I, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _P],
+    "gb_label_gather_view_dt": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "gb_grasp_loss_fwd": [_P] * 17 + [_I] * 6 + [_F] * 4 + [_P] * 6,
     "gb_grasp_loss_bwd": [_P] * 17 + [_I] * 6 + [_F] * 4 + [_P] * 11,
     "gb_label_finish": [_P, _P, _P, _P, _F, _P, _P, _P, _L, _I, _P],

@@ -460,8 +460,11 @@ __device__ __forceinline__ void atomic_max_nan(float *addr, float v) {
 // out_max (optional, caller-initialised to -inf): the maximum of everything gathered - the reference's
 // `batch_grasp_label.max()` (label_generation.py:113) without another pass over the (B,Ns,V,A,D) tensor
 constexpr int LG_MAX_SRC = 128;
-struct LabelSrcTable {  // by value in the kernel arguments: no device-side pointer table to build or cache
+struct LabelSrcTable {  // by value in the kernel arguments: no device-side pointer table to build or cache ...
   const float *p[LG_MAX_SRC];
+  const float *const *dev;  // ... unless the caller keeps one (the *_dt entries): a captured launch then follows the table's
+                            // CONTENT, i.e. a replayed graph reads whatever label tensors the table names this step
+  __device__ __forceinline__ const float *at(int o) const { return dev ? dev[o] : p[o]; }
 };
 
 __global__ __launch_bounds__(TPB) void label_gather_kernel(const LabelSrcTable srcs, const int32_t *__restrict__ obj,
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(TPB) void label_gather_kernel(const LabelSrcTable s
   __shared__ float s_m[TPB / 64];
   const int r = blockIdx.x;
   const int o = obj[r];
-  const float *src = srcs.p[o] + (size_t)pt[r] * V * W;
+  const float *src = srcs.at(o) + (size_t)pt[r] * V * W;
   const int64_t *vi = view_inds + (size_t)o * V;
   float *dst = out + (size_t)r * V * W;
   const int wc = out_col ? W / col_stride : 0;
@@ -617,7 +620,7 @@ __global__ __launch_bounds__(TPB) void label_gather_view_kernel(const LabelSrcTa
   const int r = (int)(e / W), w = (int)(e % W);
   const int o = obj[r];
   const int64_t v = view_inds[(size_t)o * V + row_view[r]];
-  out[e] = srcs.p[o][((size_t)pt[r] * V + v) * W + w];
+  out[e] = srcs.at(o)[((size_t)pt[r] * V + v) * W + w];
 }
 
 // label_finish_kernel reading the labels and the widths straight from the objects' label / offset tensors (two pointer
@@ -626,6 +629,7 @@ __global__ __launch_bounds__(TPB) void label_gather_view_kernel(const LabelSrcTa
 struct LabelSrcTable2 {
   const float *lab[LG_MAX_SRC];
   const float *off[LG_MAX_SRC];
+  const float *const *dev_lab, *const *dev_off;   // device-side tables (see LabelSrcTable)
 };
 __global__ void label_scores_kernel(const LabelSrcTable2 srcs, const int32_t *__restrict__ obj,
                                     const int32_t *__restrict__ pt, const int64_t *__restrict__ view_inds,
@@ -642,10 +646,12 @@ __global__ void label_scores_kernel(const LabelSrcTable2 srcs, const int32_t *__
     const int r = (int)(row / V), v = (int)(row % V);
     const int o = obj[r];
     const size_t at = ((size_t)pt[r] * V + (size_t)view_inds[(size_t)o * V + v]) * ad4 + q;  // group of 4 grasps
-    const float4 l = reinterpret_cast<const float4 *>(srcs.lab[o])[at];
-    const float4 o0 = reinterpret_cast<const float4 *>(srcs.off[o])[3 * at];
-    const float4 o1 = reinterpret_cast<const float4 *>(srcs.off[o])[3 * at + 1];
-    const float4 o2 = reinterpret_cast<const float4 *>(srcs.off[o])[3 * at + 2];
+    const float *labp = srcs.dev_lab ? srcs.dev_lab[o] : srcs.lab[o];
+    const float *offp = srcs.dev_off ? srcs.dev_off[o] : srcs.off[o];
+    const float4 l = reinterpret_cast<const float4 *>(labp)[at];
+    const float4 o0 = reinterpret_cast<const float4 *>(offp)[3 * at];
+    const float4 o1 = reinterpret_cast<const float4 *>(offp)[3 * at + 1];
+    const float4 o2 = reinterpret_cast<const float4 *>(offp)[3 * at + 2];
     const float wv[4] = {o0.z, o1.y, o2.x, o2.w};
     const float lv[4] = {l.x, l.y, l.z, l.w};
 #pragma unroll
@@ -700,39 +706,64 @@ extern "C" int gb_label_finish(const float *labels, const float *offsets, const 
   return check_launch("gb_label_finish");
 }
 
-extern "C" int gb_label_gather(const float *const *srcs, int nsrc, const int32_t *obj, const int32_t *pt,
-                               const int64_t *view_inds, float *out, float *out_max, float *out_col, int col_stride,
-                               int col_off, int R, int V, int W, void *stream) {
+static int label_gather_impl(const float *const *srcs, bool dev, int nsrc, const int32_t *obj, const int32_t *pt,
+                             const int64_t *view_inds, float *out, float *out_max, float *out_col, int col_stride,
+                             int col_off, int R, int V, int W, void *stream) {
   if (R < 0 || V < 1 || W < 1 || nsrc < 1 || !srcs || !obj || !pt || !view_inds || (!out && !out_max && !out_col))
     return GB_EINVAL;  // out may be NULL: only the maximum and / or the column copy are wanted
   if (nsrc > LG_MAX_SRC) return GB_ERANGE;
   if (out_col && (col_stride < 1 || col_off < 0 || col_off >= col_stride || W % col_stride != 0)) return GB_EINVAL;
   if (R == 0) return GB_OK;
   LabelSrcTable tab;
-  for (int i = 0; i < LG_MAX_SRC; ++i) tab.p[i] = i < nsrc ? srcs[i] : nullptr;
+  for (int i = 0; i < LG_MAX_SRC; ++i) tab.p[i] = (!dev && i < nsrc) ? srcs[i] : nullptr;
+  tab.dev = dev ? srcs : nullptr;
   hipLaunchKernelGGL(label_gather_kernel, dim3(R), dim3(TPB), 0, as_stream(stream), tab, obj, pt, view_inds, out,
                      out_max, out_col, col_stride, col_off, V, W);
   return check_launch("gb_label_gather");
 }
 
-extern "C" int gb_label_gather_view(const float *const *srcs, int nsrc, const int32_t *obj, const int32_t *pt,
-                                    const int64_t *view_inds, const int64_t *row_view, float *out, int R, int V, int W,
-                                    void *stream) {
+extern "C" int gb_label_gather(const float *const *srcs, int nsrc, const int32_t *obj, const int32_t *pt,
+                               const int64_t *view_inds, float *out, float *out_max, float *out_col, int col_stride,
+                               int col_off, int R, int V, int W, void *stream) {
+  return label_gather_impl(srcs, false, nsrc, obj, pt, view_inds, out, out_max, out_col, col_stride, col_off, R, V, W, stream);
+}
+
+extern "C" int gb_label_gather_dt(const float *const *srcs_dev, int nsrc, const int32_t *obj, const int32_t *pt,
+                                  const int64_t *view_inds, float *out, float *out_max, float *out_col, int col_stride,
+                                  int col_off, int R, int V, int W, void *stream) {
+  return label_gather_impl(srcs_dev, true, nsrc, obj, pt, view_inds, out, out_max, out_col, col_stride, col_off, R, V, W, stream);
+}
+
+static int label_gather_view_impl(const float *const *srcs, bool dev, int nsrc, const int32_t *obj, const int32_t *pt,
+                                  const int64_t *view_inds, const int64_t *row_view, float *out, int R, int V, int W,
+                                  void *stream) {
   if (R < 0 || V < 1 || W < 1 || nsrc < 1 || !srcs || !obj || !pt || !view_inds || !row_view || !out) return GB_EINVAL;
   if (nsrc > LG_MAX_SRC) return GB_ERANGE;
   if (R == 0) return GB_OK;
   LabelSrcTable tab;
-  for (int i = 0; i < LG_MAX_SRC; ++i) tab.p[i] = i < nsrc ? srcs[i] : nullptr;
+  for (int i = 0; i < LG_MAX_SRC; ++i) tab.p[i] = (!dev && i < nsrc) ? srcs[i] : nullptr;
+  tab.dev = dev ? srcs : nullptr;
   const long long total = (long long)R * W;
   hipLaunchKernelGGL(label_gather_view_kernel, dim3((unsigned)((total + TPB - 1) / TPB)), dim3(TPB), 0, as_stream(stream),
                      tab, obj, pt, view_inds, row_view, out, R, V, W);
   return check_launch("gb_label_gather_view");
 }
 
-extern "C" int gb_label_scores(const float *const *label_srcs, const float *const *offset_srcs, int nsrc,
-                               const int32_t *obj, const int32_t *pt, const int64_t *view_inds, const float *u_max,
-                               float max_width, float *view_scores, int32_t *view_arg, int R, int V, int ad,
-                               void *stream) {
+extern "C" int gb_label_gather_view(const float *const *srcs, int nsrc, const int32_t *obj, const int32_t *pt,
+                                    const int64_t *view_inds, const int64_t *row_view, float *out, int R, int V, int W,
+                                    void *stream) {
+  return label_gather_view_impl(srcs, false, nsrc, obj, pt, view_inds, row_view, out, R, V, W, stream);
+}
+
+extern "C" int gb_label_gather_view_dt(const float *const *srcs_dev, int nsrc, const int32_t *obj, const int32_t *pt,
+                                       const int64_t *view_inds, const int64_t *row_view, float *out, int R, int V, int W,
+                                       void *stream) {
+  return label_gather_view_impl(srcs_dev, true, nsrc, obj, pt, view_inds, row_view, out, R, V, W, stream);
+}
+
+static int label_scores_impl(const float *const *label_srcs, const float *const *offset_srcs, bool dev, int nsrc,
+                             const int32_t *obj, const int32_t *pt, const int64_t *view_inds, const float *u_max,
+                             float max_width, float *view_scores, int32_t *view_arg, int R, int V, int ad, void *stream) {
   if (R < 0 || V < 1 || ad < 4 || ad % 4 != 0 || ad / 4 * LF_ROWS > 1024 || nsrc < 1 || !label_srcs || !offset_srcs ||
       !obj || !pt || !view_inds || !u_max || !view_scores)
     return GB_EINVAL;
@@ -740,16 +771,35 @@ extern "C" int gb_label_scores(const float *const *label_srcs, const float *cons
   if (R == 0) return GB_OK;
   LabelSrcTable2 tab;
   for (int i = 0; i < LG_MAX_SRC; ++i) {
-    tab.lab[i] = i < nsrc ? label_srcs[i] : nullptr;
-    tab.off[i] = i < nsrc ? offset_srcs[i] : nullptr;
-    if (i < nsrc && (reinterpret_cast<uintptr_t>(tab.lab[i]) | reinterpret_cast<uintptr_t>(tab.off[i])) % 16) return GB_EINVAL;
+    tab.lab[i] = (!dev && i < nsrc) ? label_srcs[i] : nullptr;
+    tab.off[i] = (!dev && i < nsrc) ? offset_srcs[i] : nullptr;
+    if (!dev && i < nsrc && (reinterpret_cast<uintptr_t>(tab.lab[i]) | reinterpret_cast<uintptr_t>(tab.off[i])) % 16)
+      return GB_EINVAL;   // (device-side tables: the caller vouches for the 16-byte alignment of every tensor)
   }
+  tab.dev_lab = dev ? label_srcs : nullptr;
+  tab.dev_off = dev ? offset_srcs : nullptr;
   const long long rows = (long long)R * V;
   const int ad4 = ad / 4, threads = LF_ROWS * ad4;
   hipLaunchKernelGGL(label_scores_kernel, dim3((unsigned)((rows + LF_ROWS - 1) / LF_ROWS)), dim3(threads),
                      2 * threads * sizeof(float), as_stream(stream), tab, obj, pt, view_inds, u_max, max_width, view_scores,
                      view_arg, rows, V, ad4);
   return check_launch("gb_label_scores");
+}
+
+extern "C" int gb_label_scores(const float *const *label_srcs, const float *const *offset_srcs, int nsrc,
+                               const int32_t *obj, const int32_t *pt, const int64_t *view_inds, const float *u_max,
+                               float max_width, float *view_scores, int32_t *view_arg, int R, int V, int ad,
+                               void *stream) {
+  return label_scores_impl(label_srcs, offset_srcs, false, nsrc, obj, pt, view_inds, u_max, max_width, view_scores, view_arg,
+                           R, V, ad, stream);
+}
+
+extern "C" int gb_label_scores_dt(const float *const *label_srcs_dev, const float *const *offset_srcs_dev, int nsrc,
+                                  const int32_t *obj, const int32_t *pt, const int64_t *view_inds, const float *u_max,
+                                  float max_width, float *view_scores, int32_t *view_arg, int R, int V, int ad,
+                                  void *stream) {
+  return label_scores_impl(label_srcs_dev, offset_srcs_dev, true, nsrc, obj, pt, view_inds, u_max, max_width, view_scores,
+                           view_arg, R, V, ad, stream);
 }
 
 extern "C" int gb_gather(const float *points, const int32_t *idx, float *out, int b, int c, int n,

@@ -247,6 +247,23 @@ def _process_grasp_labels_fused(end_points):
 
 
 LEAN = '_lean_labels'   # end_points flag (train.Trainer sets it): build only what a training step consumes
+TABLES = '_label_tables'  # end_points entry (train._StaticBatch): {list key: int64 device tensor of the tensors' addresses}
+
+
+BY_REFERENCE = ('grasp_labels_list', 'grasp_offsets_list', 'grasp_tolerance_list')
+
+
+def tables_ok(batch):
+    """Can the lean label matching read this batch's label tensors through device-side pointer tables?  (What _fusable
+    asks of them: fp32, contiguous, 16-byte aligned, at most 128 objects, one (V,A,D) for all.)"""
+    if not all(k in batch for k in BY_REFERENCE):
+        return False
+    ts = [t for key in BY_REFERENCE for per in batch[key] for t in per]
+    if not ts or len(ts) > 3 * 128:
+        return False
+    shape = ts[0].shape[1:4]
+    return all(t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and t.data_ptr() % 16 == 0
+               and t.shape[1:4] == shape for t in ts)
 
 
 def _table(tensors):
@@ -266,14 +283,21 @@ def _lean_labels(end_points, labels_l, offsets_l, tol_l, obj, pt, view_inds, vie
     R, AD = obj.numel(), A * D
     lib = _lib.lib()
     st = _lib.current_stream(dev)
-    lab_t, off_t, tol_t = _table(labels_l), _table(offsets_l), _table(tol_l)
+    tables = end_points.get(TABLES)
+    if tables is not None:
+        # device-side pointer tables kept by the caller (train._StaticBatch): a captured step follows their CONTENT
+        lab_t, off_t, tol_t = (tables[k].data_ptr() for k in ('grasp_labels_list', 'grasp_offsets_list', 'grasp_tolerance_list'))
+        gather, scores, gather_view = lib.gb_label_gather_dt, lib.gb_label_scores_dt, lib.gb_label_gather_view_dt
+    else:
+        lab_t, off_t, tol_t = _table(labels_l), _table(offsets_l), _table(tol_l)
+        gather, scores, gather_view = lib.gb_label_gather, lib.gb_label_scores, lib.gb_label_gather_view
     u_max = torch.full((), float("-inf"), dtype=torch.float32, device=dev)
     view_scores = torch.empty((B, Ns, V), dtype=torch.float32, device=dev)
     view_arg = torch.empty((B, Ns, V), dtype=torch.int32, device=dev)
     with _lib.device_ctx(dev):
-        _lib.check(lib.gb_label_gather(lab_t, len(labels_l), _lib.ptr(obj), _lib.ptr(pt), _lib.ptr(view_inds), None,
-                                       _lib.ptr(u_max), None, 1, 0, R, V, AD, st), "gb_label_gather (max)")
-        _lib.check(lib.gb_label_scores(lab_t, off_t, len(labels_l), _lib.ptr(obj), _lib.ptr(pt), _lib.ptr(view_inds),
+        _lib.check(gather(lab_t, len(labels_l), _lib.ptr(obj), _lib.ptr(pt), _lib.ptr(view_inds), None,
+                          _lib.ptr(u_max), None, 1, 0, R, V, AD, st), "gb_label_gather (max)")
+        _lib.check(scores(lab_t, off_t, len(labels_l), _lib.ptr(obj), _lib.ptr(pt), _lib.ptr(view_inds),
                                        _lib.ptr(u_max), float(GRASP_MAX_WIDTH), _lib.ptr(view_scores), _lib.ptr(view_arg),
                                        R, V, AD, st), "gb_label_scores")
         top = end_points['grasp_top_view_inds'].reshape(R).long().contiguous()
@@ -282,8 +306,8 @@ def _lean_labels(end_points, labels_l, offsets_l, tol_l, obj, pt, view_inds, vie
         for name, tab, n, W, rv in (("label", lab_t, len(labels_l), AD, top), ("offset", off_t, len(offsets_l), AD * 3, top),
                                     ("tolerance", tol_t, len(tol_l), AD, top), ("best_offset", off_t, len(offsets_l), AD * 3, best_view)):
             out = torch.empty((R, W), dtype=torch.float32, device=dev)
-            _lib.check(lib.gb_label_gather_view(tab, n, _lib.ptr(obj), _lib.ptr(pt), _lib.ptr(view_inds), _lib.ptr(rv),
-                                                _lib.ptr(out), R, V, W, st), "gb_label_gather_view")
+            _lib.check(gather_view(tab, n, _lib.ptr(obj), _lib.ptr(pt), _lib.ptr(view_inds), _lib.ptr(rv),
+                                   _lib.ptr(out), R, V, W, st), "gb_label_gather_view")
             rows[name] = out
     raw, off = rows["label"], rows["offset"].view(R, AD, 3)
     mask = (raw > 0) & (off[:, :, 2] <= GRASP_MAX_WIDTH)

@@ -39,6 +39,7 @@ _GRAPH_DEFAULT = os.environ.get("GB_GRAPH", "1") != "0"  # A/B switch: 0 = every
 # grids of ~1000 workgroups, persistent row-streaming grids sized for the CUs left over) see DESIGN.md section 5.6.
 _SAMPLE_AT = os.environ.get("GB_SAMPLE_AT", "bwd")
 _MAX_SIGNATURES = int(os.environ.get("GB_GRAPH_MAX_SIGNATURES", "4"))
+_LABEL_TABLES = os.environ.get("GB_LABEL_TABLES", "1") != "0"   # A/B switch: 0 = the label tensors are copied into static buffers
 _NO_CONTEXT = contextlib.nullcontext()
 
 BN_MOMENTUM_INIT = 0.5
@@ -174,7 +175,9 @@ class Trainer:
                                   "run launch by launch instead of being captured" % _MAX_SIGNATURES)
                 self._eager_signatures.add(sig)
                 return None
-            st = self._statics[sig] = _StaticBatch(batch, self.prefetch.npoint if self.prefetch is not None else 0)
+            from .label_generation import tables_ok, BY_REFERENCE
+            by_ref = BY_REFERENCE if (self.lean_labels and _LABEL_TABLES and tables_ok(batch)) else ()
+            st = self._statics[sig] = _StaticBatch(batch, self.prefetch.npoint if self.prefetch is not None else 0, by_ref)
         self._static = st
         return st
 
@@ -321,6 +324,9 @@ class Trainer:
             inputs = dict(st.batch)
             if self.lean_labels:
                 inputs[LEAN] = True
+            if st.tables:
+                from .label_generation import TABLES
+                inputs[TABLES] = st.tables   # the label kernels read the tensors' addresses from here (see _StaticBatch)
             if announced:
                 inputs[KEY] = st.inds        # the current batch's samples: sampled one step ahead (or inline by the caller)
             side_by_side = announced and _SAMPLE_AT == "start"
@@ -398,19 +404,34 @@ class _StaticBatch:
     Which source tensor every buffer currently mirrors is tracked by (address, shape, version) tokens, so a loop that keeps
     passing the same resident tensors - or the static buffers themselves - pays for no copy."""
 
-    def __init__(self, batch, npoint):
+    def __init__(self, batch, npoint, by_reference=()):
         self.signature = _signature(batch)
+        # by_reference: list keys whose (large) tensors are NOT copied - the step reads them through device-side pointer
+        # tables (label_generation.TABLES) that load() rewrites: the grasp label / offset / tolerance tensors, 2.8 GB per
+        # batch at B = 4, staged as 1 KB of addresses
+        self.by_reference = tuple(k for k in by_reference if k in batch)
 
-        def clone(obj):
+        def clone(obj, top=None):
+            if top in self.by_reference:
+                return [list(per) for per in obj]
             if torch.is_tensor(obj):
                 return obj.detach().clone().contiguous()
             if isinstance(obj, dict):
-                return {k: clone(v) for k, v in obj.items() if not str(k).startswith('_')}
+                return {k: clone(v, k) for k, v in obj.items() if not str(k).startswith('_')}
             if isinstance(obj, (list, tuple)):
                 return [clone(v) for v in obj]
             return obj
         self.batch = clone(batch)
-        self._dst = dict(_leaves(self.batch))
+        self._dst = {p: t for p, t in _leaves(self.batch) if p[0] not in self.by_reference}
+        self.tables, self._table_addr, self._table_host, self._table_turn = {}, {}, {}, 0
+        dev = batch['point_clouds'].device
+        for k in self.by_reference:
+            n = sum(len(per) for per in batch[k])
+            self.tables[k] = torch.zeros(n, dtype=torch.int64, device=dev)
+            # (the host may run three steps ahead of the GPU: a pinned buffer is rewritten only four loads later)
+            self._table_host[k] = [torch.zeros(n, dtype=torch.int64).pin_memory() for _ in range(4)]
+            self._table_addr[k] = None
+        self._load_tables(batch)
         self.loaded = {p: _token(t) for p, t in _leaves(batch) if p in self._dst}   # source each buffer mirrors
         clouds = self.batch['point_clouds']
         self._next_buf = self.next_clouds_src = self.inds = None
@@ -448,11 +469,26 @@ class _StaticBatch:
         """Identity of what batch['point_clouds'] holds: the source it mirrors + its own version (in-place writes)."""
         return (self.loaded[('point_clouds',)], self.batch['point_clouds']._version)
 
+    def _load_tables(self, batch):
+        for k in self.by_reference:
+            ts = [t for per in batch[k] for t in per]
+            addr = tuple(t.data_ptr() for t in ts)
+            if addr != self._table_addr[k]:
+                assert len(addr) == self.tables[k].numel() and all(t.is_contiguous() and t.dtype == torch.float32 and a % 16 == 0
+                                                                   for t, a in zip(ts, addr)), k
+                host = self._table_host[k][self._table_turn % 4]
+                host.copy_(torch.tensor(addr, dtype=torch.int64))
+                self.tables[k].copy_(host, non_blocking=True)
+                self._table_addr[k] = addr
+            self.batch[k] = [list(per) for per in batch[k]]     # (keeps the tensors alive while the step reads them)
+        self._table_turn += 1
+
     def load(self, batch):
         """Make the static buffers hold `batch`; tensors that ARE the static ones, or that a buffer already mirrors, are
         not copied."""
         if batch is self.batch:
             return
+        self._load_tables(batch)
         with torch.no_grad():
             for p, t in _leaves(batch):
                 d = self._dst.get(p)

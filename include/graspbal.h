@@ -196,6 +196,19 @@ int gb_label_scores(const float *const *label_srcs, const float *const *offset_s
 int gb_label_gather_view(const float *const *srcs, int nsrc, const int32_t *obj, const int32_t *pt,
                          const int64_t *view_inds, const int64_t *row_view, float *out, int R, int V, int W,
                          void *stream);
+/* The same three entries with the pointer tables in DEVICE memory (nsrc pointers each, every tensor 16-byte aligned): the
+ * launch reads the tensors' addresses from the table when it runs, not when it is enqueued, so a captured / replayed step
+ * follows a table the caller rewrites per batch (1 KB) instead of needing the label tensors copied to fixed addresses
+ * (2.8 GB per batch at B = 4): graspbalance_amd/train.py, _StaticBatch.                                             */
+int gb_label_gather_dt(const float *const *srcs_dev, int nsrc, const int32_t *obj, const int32_t *pt,
+                       const int64_t *view_inds, float *out, float *out_max, float *out_col, int col_stride,
+                       int col_off, int R, int V, int W, void *stream);
+int gb_label_scores_dt(const float *const *label_srcs_dev, const float *const *offset_srcs_dev, int nsrc,
+                       const int32_t *obj, const int32_t *pt, const int64_t *view_inds, const float *u_max,
+                       float max_width, float *view_scores, int32_t *view_arg, int R, int V, int ad, void *stream);
+int gb_label_gather_view_dt(const float *const *srcs_dev, int nsrc, const int32_t *obj, const int32_t *pt,
+                            const int64_t *view_inds, const int64_t *row_view, float *out, int R, int V, int W,
+                            void *stream);
 /* ---- host data path on the GPU (reference data_utils.py:14-72, graspnet_dataset.py:110-136) ----
  * A depth frame becomes the network's input cloud without leaving the device: three passes over the H*W pixels.
  * depth: (H,W) uint16 (depth_is_u16 = 1) or float32; cam5 = HOST [fx, fy, cx, cy, scale] doubles (CameraInfo);

@@ -72,6 +72,10 @@ def test_graph_steps_follow_the_eager_steps():
         assert torch.equal(st.inds, pu.furthest_point_sample(nb['point_clouds'], graph.prefetch.npoint))
         assert all(torch.equal(x, y) for per_s, per_b in zip(st.batch['grasp_labels_list'], b['grasp_labels_list'])
                    for x, y in zip(per_s, per_b))
+        # ... read BY REFERENCE: the replay takes their addresses from the device-side tables (no 2.8 GB staging copy)
+        assert set(st.tables) == {'grasp_labels_list', 'grasp_offsets_list', 'grasp_tolerance_list'}
+        assert st.batch['grasp_offsets_list'][1][1].data_ptr() == b['grasp_offsets_list'][1][1].data_ptr()
+        assert st.tables['grasp_offsets_list'].tolist() == [t.data_ptr() for per in b['grasp_offsets_list'] for t in per]
     assert graph.graph_replays == 6 and len(graph._graphs) == 1
     assert graph.optimizer._steps == eager.optimizer._steps == 6 and float(graph.optimizer._step_t) == 6.0
     assert graph.optimizer.param_groups[0]['lr'] == eager.optimizer.param_groups[0]['lr']

@@ -39,6 +39,7 @@ _GRAPH_DEFAULT = os.environ.get("GB_GRAPH", "1") != "0"  # A/B switch: 0 = every
 # grids of ~1000 workgroups, persistent row-streaming grids sized for the CUs left over) see DESIGN.md section 5.6.
 _SAMPLE_AT = os.environ.get("GB_SAMPLE_AT", "bwd")
 _MAX_SIGNATURES = int(os.environ.get("GB_GRAPH_MAX_SIGNATURES", "4"))
+_HOST_SIDE_ORDER = os.environ.get("GB_HOST_SIDE_ORDER", "1") != "0"   # A/B switch: 0 = the side stream waits on the GPU
 _LABEL_TABLES = os.environ.get("GB_LABEL_TABLES", "1") != "0"   # A/B switch: 0 = the label tensors are copied into static buffers
 _NO_CONTEXT = contextlib.nullcontext()
 
@@ -209,6 +210,10 @@ class Trainer:
             g = self._graphs[key] = self._capture(st, announced)
         self.optimizer.set_lr_tensor()
         cur = torch.cuda.current_stream(self.device)
+        stage_event = None
+        if announced and _HOST_SIDE_ORDER:
+            stage_event = st.stage_event      # everything the sampling reads has been enqueued on `cur` by now
+            stage_event.record(cur)
 
         def sample_next():
             # The next batch's first-level sampling on the side stream.  Not inside a graph: a graph with a forked branch
@@ -224,8 +229,18 @@ class Trainer:
             ver = st.batch['point_clouds']._version
             if st.next_src[0] != "self" or st.side_saw != ver:
                 # the announced clouds were staged by the main stream this step (or the resident ones were written since
-                # the side stream last synchronised with it): a real dependency
-                side.wait_stream(cur)
+                # the side stream last synchronised with it): a real dependency.  Kept on the HOST where possible: a wait
+                # packet that sits unsatisfied in the side queue while the main queue works is what costs the 0.7 ms
+                # (held until the event has fired, the same wait is free - tools/fps_interference.py, "host at most 0
+                # steps ahead").  The forward graph of this step is already enqueued, so the GPU does not idle while the
+                # host waits here for the previous step to end.
+                if _SAMPLE_AT != "start" and stage_event is not None:
+                    if not stage_event.query():
+                        t0 = time.perf_counter()
+                        stage_event.synchronize()
+                        fused_mlp.SYNC_WAIT[0] += time.perf_counter() - t0
+                else:
+                    side.wait_stream(cur)
                 st.side_saw = ver
             with torch.cuda.stream(side), torch.no_grad():
                 from . import pointnet2_utils
@@ -446,6 +461,7 @@ class _StaticBatch:
             self.ring_events = [None, None, None]
             self.ring_pos = 0
             self.side_saw = None       # version of the static clouds the side stream is known to be ordered behind
+            self.stage_event = torch.cuda.Event()
 
     def ring_next(self):
         """The ring slot of this step's sampling; blocks the HOST until the step that last read the slot (three steps

@@ -89,3 +89,17 @@ def after():   # launched after both graph launches
     cur = torch.cuda.current_stream(); replay(); fps(); cur.wait_stream(side)
 t = timeit(after); base = timeit(replay)
 print("sampling launched after both graphs: %.3f ms vs %.3f" % (t, base), flush=True)
+# ---- is the cost of "the side stream waits for the main stream" the TIME its wait packet sits unsatisfied?  The host is
+#      normally up to three steps ahead; here it is held one step / zero steps ahead
+def throttled(fn, ahead):
+    evs = []
+    def run():
+        cur = torch.cuda.current_stream()
+        if len(evs) > ahead:
+            evs.pop(0).synchronize()
+        fn()
+        e = torch.cuda.Event(); e.record(cur); evs.append(e)
+    return run
+for ahead in (3, 1, 0):
+    print("main->side wait only, host at most %d step(s) ahead: %.3f ms;   sampling with that wait: %.3f ms;   graphs alone likewise: %.3f ms"
+          % (ahead, timeit(throttled(ev_a, ahead)), timeit(throttled(at_start, ahead)), timeit(throttled(replay, ahead))), flush=True)

@@ -103,3 +103,24 @@ def throttled(fn, ahead):
 for ahead in (3, 1, 0):
     print("main->side wait only, host at most %d step(s) ahead: %.3f ms;   sampling with that wait: %.3f ms;   graphs alone likewise: %.3f ms"
           % (ahead, timeit(throttled(ev_a, ahead)), timeit(throttled(at_start, ahead)), timeit(throttled(replay, ahead))), flush=True)
+# ---- is it what is queued BEHIND the sampling kernel?  the bare kernels (pre-allocated outputs, no trailing copy), with and
+#      without an event record queued behind them while the graphs run
+from graspbalance_amd import _lib as L
+import ctypes
+xyz_c = st.next_clouds[..., 0:3].contiguous()
+b_, n_ = xyz_c.shape[0], xyz_c.shape[1]
+perm_ = torch.empty((b_, n_), dtype=torch.int32, device=dev)
+out_ = torch.zeros((b_, 2048), dtype=torch.int32, device=dev)
+sstream = ctypes.c_void_p(side.cuda_stream)
+def bare():
+    L.check(L.lib().gb_fps_cell_order(L.ptr(xyz_c), L.ptr(perm_), b_, n_, sstream), "order")
+    L.check(L.lib().gb_fps_pruned(L.ptr(xyz_c), L.ptr(perm_), None, L.ptr(out_), b_, n_, 2048, 0, None, sstream), "pruned")
+def bare_joined():
+    cur = torch.cuda.current_stream(); bare(); replay(); cur.wait_stream(side)
+def bare_host_joined():
+    bare(); replay(); side.synchronize()
+def alone_host():
+    replay(); side.synchronize()
+print("bare sampling kernels, joined by an event wait of the main stream: %.3f ms" % timeit(bare_joined), flush=True)
+print("bare sampling kernels, nothing queued behind them (host-side join): %.3f ms" % timeit(bare_host_joined), flush=True)
+print("graphs alone (host-side join of the idle side stream):             %.3f ms" % timeit(alone_host), flush=True)

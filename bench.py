@@ -696,6 +696,8 @@ def main():
                          else ("eager: every launch of every step enqueued by the host"
                                + (" (fallback: %s)" % graph_fallback if graph_fallback else "")),
             "ms_per_step_eager": round(eager_ms, 3), "host_enqueue_ms_per_step_eager": round(eager_host / sampled * 1e3, 3),
+            "eager_leg": "instrumented (HIP events around every launch of interest, this trainer's autograd nodes live on the "
+                         "capture stream): a graph=False trainer takes 18.1-18.3 ms per step on an idle host (tools/soak.py)",
             "cpu_affinity": affinity,
         }
         for r in (out["roofline"], out["roofline_gemm2"], out["roofline_gemm3"], out["roofline_fps"], out["roofline_ball"], out["roofline_fps_ball"],

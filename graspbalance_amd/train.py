@@ -152,7 +152,10 @@ class Trainer:
     # ---- HIP-graph execution ----------------------------------------------------------------------------------------
     def resident(self, batch):
         """Copy `batch` into this trainer's static input buffers and return the batch made of THOSE tensors: steps on it
-        replay the graph without any staging copy (a data loader would write its next batch into them directly)."""
+        replay the graph without any staging copy (a data loader would write its next batch into them directly).  The
+        large grasp label / offset / tolerance tensors are NOT copied when the lean label matching can read them through
+        device-side pointer tables (_StaticBatch, by_reference): the returned batch holds the caller's own tensors for
+        those keys, and they must stay unchanged while steps on them are in flight."""
         if not self.graph:
             return batch
         st = self._static_for(_signature(batch), batch)

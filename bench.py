@@ -603,9 +603,12 @@ def main():
             fps_bytes = fps_algorithmic_bytes(meta["b"], meta["n"], meta["m"])
             achieved = fps_bytes / (fps_ms * 1e-3) / 1e9
             pruned = _lib._fps_prune and _lib.FPS_PRUNE_MIN_N <= meta["n"] <= _lib.FPS_PRUNE_MAX_N
-            kname = "fps_pruned_kernel" if pruned else "fps_reg_kernel<1024, 20>"
-            order = "cell-order counting sort" if _lib._fps_cell_order else "Morton keys + sort"
-            pk = "fps_pruned_kernel<1024,20>" if meta["n"] <= 20480 else "fps_pruned_big_kernel (rows streamed from a sorted copy)"
+            rows_kernel = meta["n"] <= 20480 and _lib._fps_layout != _lib.FPS_LAYOUT["r4"]
+            kname = ("fps_rows_kernel" if rows_kernel else "fps_pruned_kernel") if pruned else "fps_reg_kernel<1024, 20>"
+            order = {"rows": "row-order (two-level equal-count counting sort)", "cell": "cell-order counting sort",
+                     "morton": "Morton keys + sort"}[_lib._fps_order]
+            pk = ("fps_rows_kernel (run-time indexed row registers)" if rows_kernel else "fps_pruned_kernel<1024,20>") \
+                if meta["n"] <= 20480 else "fps_pruned_big_kernel (rows streamed from a sorted copy)"
             what = order + " + " + pk if pruned else "fps_reg_kernel<1024,20>"
             roofline_fps = {"kernel": "%s (furthest_point_sampling %d->%d, b=%d)" % (what, meta["n"], meta["m"], meta["b"]),
                             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

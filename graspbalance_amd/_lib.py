@@ -19,6 +19,8 @@ FPS_SKIP_NEAR_ORIGIN = 0x1
 FPS_TIE_LOWEST = 0x00
 FPS_TIE_TREE512 = 0x10
 FPS_TIE_TREE1024 = 0x20
+# gb_fps_pruned: how a register-resident cloud is spread over the waves of its CU (graspbal.h GB_FPS_LAYOUT_*)
+FPS_LAYOUT = {"auto": 0x000, "w4": 0x100, "w8": 0x200, "w12": 0x300, "w16": 0x400, "r4": 0x500}
 
 _c = ctypes
 _P, _I, _F, _U, _L = _c.c_void_p, _c.c_int, _c.c_float, _c.c_uint, _c.c_longlong
@@ -30,6 +32,7 @@ SIGNATURES = {
     "gb_fps_pruned": [_P, _P, _P, _P, _I, _I, _I, _U, _P, _P],
     "gb_fps_segments": [_P, _P, _P, _P, _P, _I, _I, _U, _P],
     "gb_fps_cell_order": [_P, _P, _I, _I, _P],
+    "gb_fps_row_order": [_P, _P, _I, _I, _P],
     "gb_fps_morton_keys": [_P, _P, _I, _I, _P],
     "gb_fps_guarded": [_P, _P, _P, _I, _I, _I, _U, _P, _P, _P, _P],
     "gb_gather": [_P, _P, _P, _I, _I, _I, _I, _P],
@@ -247,7 +250,10 @@ def event_pair_overhead_ms(device, pairs=64):
 
 FPS_PRUNE_MIN_N, FPS_PRUNE_MAX_N, FPS_PRUNE_MIN_M = 8192, 64512, 128  # gb_fps_pruned: n <= 1024 * 63 rows of 64
 _fps_prune = os.environ.get("GB_FPS_PRUNE", "1") != "0"  # A/B switch
-_fps_cell_order = os.environ.get("GB_FPS_CELL_ORDER", "1") != "0"  # A/B switch: visiting order by counting sort
+# A/B switch, the visiting order: "rows" (round 5: two levels of equal-count splits, rows are compact), "cell" (round 4:
+# counting sort by 32^3 grid cell), "morton" (30-bit Morton keys + a device sort)
+_fps_order = os.environ.get("GB_FPS_ORDER", "rows")
+_fps_layout = FPS_LAYOUT[os.environ.get("GB_FPS_LAYOUT", "auto")]   # A/B switch: see FPS_LAYOUT
 FPS_PREFIX_MAX_N = 4096
 _fps_prefix = os.environ.get("GB_FPS_PREFIX", "1") != "0"  # A/B switch
 
@@ -257,8 +263,9 @@ def fps(points, temp, output, b, n, m, flags, stream):
     import torch
     if _fps_prune and FPS_PRUNE_MIN_N <= n <= FPS_PRUNE_MAX_N and m >= FPS_PRUNE_MIN_M:
         perm = torch.empty((b, n), dtype=torch.int32, device=points.device)
-        if _fps_cell_order:  # counting sort by grid cell: one launch
-            rc = lib().gb_fps_cell_order(ptr(points), ptr(perm), b, n, stream)
+        if _fps_order != "morton":  # one launch
+            order = lib().gb_fps_row_order if _fps_order == "rows" else lib().gb_fps_cell_order
+            rc = order(ptr(points), ptr(perm), b, n, stream)
             if rc != GB_OK:
                 return rc
         else:                # full 30-bit Morton sort (keys kernel + torch sort)
@@ -268,7 +275,8 @@ def fps(points, temp, output, b, n, m, flags, stream):
                 return rc
             perm = torch.argsort(keys, dim=1).to(torch.int32)
         scratch = torch.empty((b, n, 4), dtype=torch.float32, device=points.device) if n > 20480 else None
-        return lib().gb_fps_pruned(ptr(points), ptr(perm), ptr(temp), ptr(output), b, n, m, flags, ptr(scratch), stream)
+        return lib().gb_fps_pruned(ptr(points), ptr(perm), ptr(temp), ptr(output), b, n, m, flags | _fps_layout,
+                                   ptr(scratch), stream)
     if _fps_prefix and n <= FPS_PREFIX_MAX_N and 64 <= m <= n:
         # small clouds are usually the centres of the previous level, i.e. already in farthest-point order: verify
         # "samples = 0..m-1" in parallel and skip the sequential loop where it holds (identical outputs either way)

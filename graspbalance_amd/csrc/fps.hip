@@ -15,6 +15,8 @@
 //   * arithmetic is the no-FMA order ((dx*dx)+(dy*dy))+(dz*dz) (file built with -ffp-contract=off).
 // Clouds that do not fit the register file of one CU (n > 24576) go through fps_stream_kernel,
 // which keeps the min-distances in the caller's `temp` buffer (L2-resident) instead.
+#include <type_traits>
+
 #include "gb_common.h"
 
 namespace gb {
@@ -263,6 +265,339 @@ __global__ __launch_bounds__(BLOCK) void fps_pruned_kernel(const float *__restri
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 5: the pruned sampling with O(1) row dispatch and the winner's coordinates carried through the reduction.
+// Where the time of fps_pruned_kernel<1024, 20> went (ISA + instruction counts): a wave issues one instruction per
+// 4 cycles and the waves of one SIMD share its vector pipeline, so an iteration costs about
+// (waves per SIMD) x (instructions a wave executes) x 2-4 cycles whether or not the wave had a row to update - with
+// 16 waves every SIMD runs the box test, the 20-branch "which of my rows" chain (3 scalar instructions per row), the
+// 12-step wave arg-max and the cross-wave step FOUR times (4 x ~180 instructions), then waits for the dependent
+// scalar load of the winner's xyz (L2, ~290 cycles).  Here:
+//   * the rows of a wave live in REGISTER VECTORS indexed at run time (s_set_gpr_idx_on: gfx9's VGPR index mode, what
+//     the compiler emits for a wave-uniform subscript of an ext_vector_type value), so the needed rows are walked by
+//     find-first-set with ONE copy of the update code and no per-row branch at all;
+//   * W = 8 waves (two per SIMD) by default: the per-wave fixed work runs twice per SIMD instead of four times;
+//   * a row record keeps the COORDINATES of its arg-max point (three readlanes when the row is updated), the wave
+//     arg-max publishes (d, x, y, z, key) of its candidate in LDS, and after the one barrier every wave reads the W
+//     candidates: the next sample's coordinates come out of that read - no global load in the loop;
+//   * the reductions take the single-holder fast path (ballot + readlane) at both levels; exact ties fall back to
+//     the min-key reduction, so the sequence is the same bit for bit (tests: test_fps_pruned_is_the_same_sequence
+//     runs every layout).
+template <int LO, int HI, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (LO < HI) {
+    f(std::integral_constant<int, LO>{});
+    static_for<LO + 1, HI>(f);
+  }
+}
+// wave max as ONE asm block: the compiler cannot see into an asm statement and pads every separate one with its own
+// hazard nops; written as a whole the six steps need only the two wait states each DPP read is owed
+__device__ __forceinline__ float wave_max_f32_1(float v) {
+  asm volatile(
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float row_max_f32_1(float v) {  // lanes 0..15 (one DPP row), result in every lane of the row
+  asm volatile(
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
+  return v;
+}
+// six independent wave maxima interleaved: no wait states needed between the DPP steps of different chains
+__device__ __forceinline__ void wave_max_f32_x6(float &a, float &b, float &c, float &d, float &e, float &f) {
+#define GB_S6(CTRL)                                          \
+  "v_max_f32_dpp %0, %0, %0 " CTRL "\n\tv_max_f32_dpp %1, %1, %1 " CTRL "\n\tv_max_f32_dpp %2, %2, %2 " CTRL \
+  "\n\tv_max_f32_dpp %3, %3, %3 " CTRL "\n\tv_max_f32_dpp %4, %4, %4 " CTRL "\n\tv_max_f32_dpp %5, %5, %5 " CTRL "\n\t"
+  asm volatile("s_nop 1\n\t" GB_S6("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                   GB_S6("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                       GB_S6("row_half_mirror row_mask:0xf bank_mask:0xf") GB_S6("row_mirror row_mask:0xf bank_mask:0xf")
+                           GB_S6("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                               GB_S6("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1"
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
+#undef GB_S6
+  a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
+  b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
+  c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), 63));
+  d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 63));
+  e = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), 63));
+  f = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), 63));
+}
+// v_writelane_b32: clang has no builtin for it; the LLVM intrinsic is reachable through its name
+extern "C" __device__ int gb_writelane_i32(int value, int lane, int vec) __asm("llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ float rdlane_f(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ float wrlane_f(float vec, float s, int l) {
+  return __int_as_float(gb_writelane_i32(__float_as_int(s), l, __float_as_int(vec)));
+}
+
+// The rows of a wave (one point per lane and row) live in register vectors of 32 or 16 rows ("chunks", at most three:
+// P = C0 + C1 + C2; shorter vectors make the compiler fall back to a chain of selects): x, y, z and the running
+// min-distance t of row q are element q of four vectors, so a wave-uniform RUN-TIME row number subscripts them.
+// (Plain local variables, not members of an aggregate: the optimiser keeps whole-vector locals in registers; inside a
+// struct it fell back to scratch memory.)
+template <int N> struct RowVecT { typedef float T __attribute__((ext_vector_type(N))); };
+template <> struct RowVecT<0> { typedef float T __attribute__((ext_vector_type(4))); };  // unused chunk
+
+template <int W, int C0, int C1, int C2>
+__global__ __launch_bounds__(W * 64) void fps_rows_kernel(const float *__restrict__ xyz,
+                                                           const int32_t *__restrict__ perm,
+                                                           float *__restrict__ temp_io, int32_t *__restrict__ idx,
+                                                           int n, int m, int skip, int bs_log2
+#ifdef GB_FPS_STAMPS
+                                                           , unsigned long long *__restrict__ stamps
+#endif
+) {
+#ifdef GB_FPS_STAMPS  // diagnostic build only (tools/fps_stamps.sh): cycles per phase of every wave, to a buffer of its own
+  unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_rows = 0, st_t;
+#define GB_STAMP0() st_t = __builtin_amdgcn_s_memtime()
+#define GB_STAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[i] += now_ - st_t; st_t = now_; }
+#else
+#define GB_STAMP0()
+#define GB_STAMP(i)
+#endif
+  constexpr int P = C0 + C1 + C2;      // rows per wave
+  static_assert(W <= 16 && P <= 128, "W candidates sit in one DPP row; row records in two sets of 64 lanes");
+  constexpr int S = (P + 63) / 64;     // record sets
+  extern __shared__ unsigned s_tie[];  // [W * P * 64] tie key of each sorted position
+  __shared__ float4 s_cand[2][16];     // (d, x, y, z) of each wave's candidate, double-buffered
+  __shared__ unsigned s_ckey[2][16];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float *pts = xyz + (size_t)blockIdx.x * n * 3;
+  const int32_t *pm = perm + (size_t)blockIdx.x * n;
+  int32_t *out = idx + (size_t)blockIdx.x * m;
+  float *tio = temp_io ? temp_io + (size_t)blockIdx.x * n : nullptr;
+  const float x0 = pts[0], y0 = pts[1], z0 = pts[2];  // the first sample; also what "nobody is a candidate" returns
+
+  typename RowVecT<C0>::T x0v, y0v, z0v, t0v;
+  typename RowVecT<C1>::T x1v, y1v, z1v, t1v;
+  typename RowVecT<C2>::T x2v, y2v, z2v, t2v;
+  // row records: lane l of set s describes row s*64 + l of this wave (= global row (s*64+l)*W + wave).  A record whose
+  // row has no candidate keeps (rmax < 0, key of point 0, coordinates of point 0): when NOBODY has a candidate the
+  // reductions below deliver "index 0" - the reference's result - without a special case
+  float lox[S], loy[S], loz[S], hix[S], hiy[S], hiz[S], rmax[S], ax[S], ay[S], az[S];
+  unsigned rkey[S];
+  const unsigned key_of_0 = fps_key(0, bs_log2);
+#pragma unroll
+  for (int s = 0; s < S; ++s) {  // lanes without a row: empty box, never a candidate
+    lox[s] = loy[s] = loz[s] = INFINITY;
+    hix[s] = hiy[s] = hiz[s] = -INFINITY;
+    rmax[s] = -2.0f;
+    rkey[s] = key_of_0;
+    ax[s] = x0; ay[s] = y0; az[s] = z0;
+  }
+  if (tid < 32) {  // the candidate slots of waves that do not exist never win
+    s_cand[tid >> 4][tid & 15] = make_float4(-3.0f, x0, y0, z0);
+    s_ckey[tid >> 4][tid & 15] = key_of_0;
+  }
+  static_for<0, P>([&](auto pc) __attribute__((always_inline)) {
+    constexpr int p = decltype(pc)::value;
+    const int k = (p * W + wave) * 64 + lane;
+    float x = 0.f, y = 0.f, z = 0.f, t = -INFINITY;  // -inf: never a candidate
+    unsigned key = 0xFFFFFFFFu;
+    if (k < n) {
+      const int o = pm[k];
+      const f3 v = reinterpret_cast<const f3 *>(pts)[o];
+      x = v.x; y = v.y; z = v.z;
+      t = tio ? tio[o] : 1e10f;
+      key = fps_key(o, bs_log2);
+      if (skip) {
+        const float mag = ((x * x) + (y * y)) + (z * z);
+        if (mag < 1e-3f) t = -INFINITY;
+      }
+    }
+    if constexpr (p < C0) { x0v[p] = x; y0v[p] = y; z0v[p] = z; t0v[p] = t; }
+    else if constexpr (p < C0 + C1) { x1v[p - C0] = x; y1v[p - C0] = y; z1v[p - C0] = z; t1v[p - C0] = t; }
+    else { x2v[p - C0 - C1] = x; y2v[p - C0 - C1] = y; z2v[p - C0 - C1] = z; t2v[p - C0 - C1] = t; }
+    s_tie[k] = key;
+    const bool cand = t >= 0.f;
+    float bhx = cand ? x : -INFINITY, bhy = cand ? y : -INFINITY, bhz = cand ? z : -INFINITY;
+    float blx = cand ? -x : -INFINITY, bly = cand ? -y : -INFINITY, blz = cand ? -z : -INFINITY;
+    wave_max_f32_x6(bhx, bhy, bhz, blx, bly, blz);
+    const bool any = __builtin_amdgcn_ballot_w64(cand) != 0ull;
+    constexpr int s = p / 64, l = p % 64;
+    if (lane == l) {
+      lox[s] = -blx; loy[s] = -bly; loz[s] = -blz; hix[s] = bhx; hiy[s] = bhy; hiz[s] = bhz;
+      rmax[s] = any ? 3.0e38f : -1.0f;  // > any squared distance: forces the row's first update
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the unrolled rows from piling their loads up (register pressure)
+  });
+  __syncthreads();
+
+  float x1 = x0, y1 = y0, z1 = z0;  // wave-uniform
+  // wave 0 collects the winners' keys, one lane per iteration, and turns 64 of them into indices at a time
+  unsigned won = key_of_0;           // (sample 0 is point 0)
+#ifdef GB_FPS_STAMPS
+  const unsigned long long st_begin = __builtin_amdgcn_s_memtime(), st_rbegin = __builtin_amdgcn_s_memrealtime();
+#endif
+  for (int j = 1; j < m; ++j) {
+    GB_STAMP0();
+    static_for<0, S>([&](auto sc) __attribute__((always_inline)) {
+      constexpr int s = decltype(sc)::value;
+      const float ex = fmaxf(fmaxf(lox[s] - x1, x1 - hix[s]), 0.f);
+      const float ey = fmaxf(fmaxf(loy[s] - y1, y1 - hiy[s]), 0.f);
+      const float ez = fmaxf(fmaxf(loz[s] - z1, z1 - hiz[s]), 0.f);
+      const float lb = ((ex * ex) + (ey * ey)) + (ez * ez);
+      unsigned long long need = __builtin_amdgcn_ballot_w64(lb < rmax[s]);  // bit l: row s*64+l must be updated
+      GB_STAMP(0);
+#ifdef GB_FPS_STAMPS
+      st_rows += __builtin_popcountll(need);
+#endif
+      while (need != 0ull) {  // wave-uniform
+        const int l = __builtin_ctzll(need);
+        need &= need - 1ull;
+        const int p = s * 64 + l;
+        const unsigned kk = s_tie[(p * W + wave) * 64 + lane];
+        auto update = [&](auto &vx, auto &vy, auto &vz, auto &vt, int q) __attribute__((always_inline)) {
+          const float qx = vx[q], qy = vy[q], qz = vz[q], qt = vt[q];
+          const float dx = qx - x1, dy = qy - y1, dz = qz - z1;
+          const float d = ((dx * dx) + (dy * dy)) + (dz * dz);
+          float d2;  // == fminf(d, t) without the canonicalising v_max the builtin puts in front
+          asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(qt));
+          vt[q] = d2;
+          GB_STAMP(6);
+          const float mx = wave_max_f32_1(d2);
+          // the row's arg-max: almost always a single lane holds the maximum -> its key and coordinates are read
+          // directly and the check "was it the only holder" comes AFTER the record is written (its scalar chain -
+          // count, compare, branch - then runs beside the vector work instead of in front of it); exact ties
+          // (duplicate points, lattice data) redo the record with the holder of the smallest key
+          GB_STAMP(7);
+          const unsigned long long eq = __builtin_amdgcn_ballot_w64(d2 == mx);
+          int L = __builtin_ctzll(eq | (1ull << 63));
+          GB_STAMP(8);
+          auto record = [&](int LL) __attribute__((always_inline)) {
+            const unsigned kwin = (unsigned)__builtin_amdgcn_readlane((int)kk, LL);
+            const float cx = rdlane_f(qx, LL), cy = rdlane_f(qy, LL), cz = rdlane_f(qz, LL);
+            rmax[s] = wrlane_f(rmax[s], mx, l);
+            rkey[s] = (unsigned)gb_writelane_i32((int)kwin, l, (int)rkey[s]);
+            ax[s] = wrlane_f(ax[s], cx, l);
+            ay[s] = wrlane_f(ay[s], cy, l);
+            az[s] = wrlane_f(az[s], cz, l);
+          };
+          record(L);
+          if (__builtin_popcountll(eq) != 1) {
+            const unsigned kmin = wave_min_u32(d2 == mx ? kk : 0xFFFFFFFFu);
+            record(__builtin_ctzll(__builtin_amdgcn_ballot_w64(d2 == mx && kk == kmin) | (1ull << 63)));
+          }
+          GB_STAMP(9);
+        };
+        if (C1 == 0 || p < C0) update(x0v, y0v, z0v, t0v, p);
+        else if (C2 == 0 || p < C0 + C1) update(x1v, y1v, z1v, t1v, p - C0);
+        else update(x2v, y2v, z2v, t2v, p - C0 - C1);
+      }
+    });
+    GB_STAMP(1);
+    // the wave's candidate: arg-max over its row records
+    float v = rmax[0];
+#pragma unroll
+    for (int s = 1; s < S; ++s) v = fmaxf(v, rmax[s]);
+    const float wmax = wave_max_f32_1(v);
+    GB_STAMP(10);
+    unsigned long long eqs[S];
+    int holders = 0;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      eqs[s] = __builtin_amdgcn_ballot_w64(rmax[s] == wmax);
+      holders += __builtin_popcountll(eqs[s]);
+    }
+    unsigned wkey = key_of_0;
+    float wx = x0, wy = y0, wz = z0;
+    auto candidate = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int s = 0; s < S; ++s)
+        if (S == 1 || eqs[s] != 0ull) {  // wave-uniform
+          const int L = __builtin_ctzll(eqs[s] | (1ull << 63));
+          wkey = (unsigned)__builtin_amdgcn_readlane((int)rkey[s], L);
+          wx = rdlane_f(ax[s], L); wy = rdlane_f(ay[s], L); wz = rdlane_f(az[s], L);
+        }
+    };
+    candidate();         // (as in the row update: the single-holder answer first, the check for ties behind it)
+    if (holders != 1) {  // exact tie between rows: the smallest key among the holders
+      unsigned km = 0xFFFFFFFFu;
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const unsigned ks = wave_min_u32(rmax[s] == wmax ? rkey[s] : 0xFFFFFFFFu);
+        km = ks < km ? ks : km;
+      }
+#pragma unroll
+      for (int s = 0; s < S; ++s) eqs[s] = __builtin_amdgcn_ballot_w64(rmax[s] == wmax && rkey[s] == km);
+      // (several records may hold the SAME key only when it is the key of point 0 with point 0's coordinates)
+      candidate();
+    }
+    GB_STAMP(11);
+    const int buf = j & 1;
+    // every lane stores the same values to the same slot: cheaper than masking the wave down to one lane
+    s_cand[buf][wave] = make_float4(wmax, wx, wy, wz);
+    s_ckey[buf][wave] = wkey;
+    GB_STAMP(2);
+    __syncthreads();
+    GB_STAMP(3);
+    // The pick.  (A form that stays in vector registers - the 16 slots reduced by DPP with the coordinates as payload,
+    // a 64-bit compare and five selects per step - was measured: 68 instructions instead of ~30, and because EVERY wave
+    // runs the pick at the same moment the SIMDs' issue slots are what it costs: 1.34 -> 1.88 ms.  Scalar round trips
+    // are slow but they cost the other waves nothing.)
+    const float4 c = s_cand[buf][lane & 15];  // the four DPP rows of the wave all hold the 16 slots
+    const unsigned ck = s_ckey[buf][lane & 15];
+    const float dmax = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(row_max_f32_1(c.x))));
+    unsigned long long e2 = __builtin_amdgcn_ballot_w64(c.x == dmax) & 0xFFFFull;
+    int Lw = __builtin_ctzll(e2 | (1ull << 63));
+    x1 = rdlane_f(c.y, Lw); y1 = rdlane_f(c.z, Lw); z1 = rdlane_f(c.w, Lw);
+    if (__builtin_popcountll(e2) != 1) {  // (the single-holder answer first, the check for ties behind it)
+      const unsigned kq = row_min_u32(c.x == dmax ? ck : 0xFFFFFFFFu);
+      const unsigned kmin = (unsigned)__builtin_amdgcn_readfirstlane((int)kq);
+      e2 = (__builtin_amdgcn_ballot_w64(c.x == dmax && ck == kmin) & 0xFFFFull) | (1ull << 63);
+      Lw = __builtin_ctzll(e2);
+      x1 = rdlane_f(c.y, Lw); y1 = rdlane_f(c.z, Lw); z1 = rdlane_f(c.w, Lw);
+    }
+    GB_STAMP(12);
+    GB_STAMP(13);
+    if (wave == 0) {
+      if ((j & 63) == 0) {  // the keys of samples j-64 .. j-1 are complete
+        out[j - 64 + lane] = fps_unkey(won, bs_log2);
+      }
+      won = (unsigned)gb_writelane_i32(__builtin_amdgcn_readlane((int)ck, Lw), j & 63, (int)won);
+    }
+    GB_STAMP(4);
+  }
+#ifdef GB_FPS_STAMPS
+  if (stamps && lane == 0) {
+    unsigned long long *o = stamps + ((size_t)blockIdx.x * 16 + wave) * 20;
+    for (int i = 0; i < 16; ++i) o[i] = st_acc[i];
+    o[16] = st_rows;
+    o[17] = __builtin_amdgcn_s_memtime() - st_begin;
+    o[18] = __builtin_amdgcn_s_memrealtime() - st_rbegin;
+    o[19] = (unsigned long long)m;
+  }
+#endif
+  if (wave == 0) {
+    const int base = (m - 1) & ~63;  // samples base .. m-1 are still in `won`
+    if (base + lane < m) out[base + lane] = fps_unkey(won, bs_log2);
+  }
+  if (tio) {
+    static_for<0, P>([&](auto pc) __attribute__((always_inline)) {
+      constexpr int p = decltype(pc)::value;
+      const int k = (p * W + wave) * 64 + lane;
+      float t;
+      if constexpr (p < C0) t = t0v[p];
+      else if constexpr (p < C0 + C1) t = t1v[p - C0];
+      else t = t2v[p - C0 - C1];
+      if (k < n && t >= 0.0f) tio[pm[k]] = t;
+    });
+  }
+}
+
 // The same for clouds beyond one CU's register file (20 480 < n <= 65 536): only the running min-distances stay in
 // registers (P <= 64 per lane); a row's coordinates and tie keys are re-read from a sorted (x, y, z, key) copy in
 // global memory - one 16-byte coalesced load per lane - but only for the few rows a sample actually touches, so the
@@ -485,6 +820,164 @@ __global__ __launch_bounds__(1024) void fps_cell_order_kernel(const float *__res
   for (int i = 0; i < PER; ++i) s_bins[tid * PER + i] = base + local[i];
   __syncthreads();
   for (int k = tid; k < n; k += 1024) out[atomicAdd(&s_bins[cell_of(k)], 1)] = k;
+}
+
+// Round 5: a visiting order whose ROWS are compact.  gb_fps_pruned updates a row of 64 consecutive points whenever the
+// new sample comes closer to the row's bounding box than the row's largest min-distance, so what matters is how tight
+// the boxes of the rows are - and 64 consecutive points of a space-filling curve over a uniform grid are not a box: on
+// the bench clouds 11.6 of 313 rows are touched per sample in 32^3-cell Morton order, 8.0 in Hilbert order, 4.9 with the
+// leaves of a kd-tree whose splits fall on multiples of 64 points (CPU simulation of the update rule).  Two levels of
+// equal-count splits along the locally widest axis get all but a tenth of that (5.4 rows), and each level is one
+// counting sort like the one above:
+//   level 1  counting sort of the cloud by its widest-axis coordinate (4096 bins); the sorted sequence is cut into
+//            K ~ sqrt(rows) SLABS at multiples of 64 points - no selection step: a slab is a range of positions;
+//   level 2  every slab is counting-sorted by ITS widest-axis coordinate (1024 bins per slab), so a row - 64
+//            consecutive positions - is a short piece of a thin slab.
+// Points that share a bin keep whatever order the atomics give them (bin width = extent / 4096 resp. / 1024); the
+// samples gb_fps_pruned returns do not depend on the permutation.
+constexpr int SO_BINS1 = 4096, SO_BINS2 = 1024, SO_MAXK = 20, SO_MAXN = 24576;
+__device__ __forceinline__ unsigned so_fkey(float f) {  // order-preserving float -> uint
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float so_funkey(unsigned k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+__device__ __forceinline__ int so_quant(float c, float lo, float scale, int bins) {
+  const float f = (c - lo) * scale;
+  return f >= (float)(bins - 1) ? bins - 1 : (f > 0.f ? (int)f : 0);  // NaN -> 0
+}
+// exclusive scan of s_bins[0 .. 1024*PER) in place (PER consecutive bins per thread, 1024 threads)
+template <int PER>
+__device__ __forceinline__ void so_scan(int *s_bins, int *s_part, int tid, int lane, int wave) {
+  int local[PER], sum = 0;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    local[i] = sum;
+    sum += s_bins[tid * PER + i];
+  }
+  int incl = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(incl, off);
+    if (lane >= off) incl += o;
+  }
+  if (lane == 63) s_part[wave] = incl;
+  __syncthreads();
+  int base = incl - sum;
+  for (int w = 0; w < wave; ++w) base += s_part[w];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) s_bins[tid * PER + i] = base + local[i];
+  __syncthreads();
+}
+__global__ __launch_bounds__(1024) void fps_slab_order_kernel(const float *__restrict__ xyz, int32_t *__restrict__ perm,
+                                                               int n, int K) {
+  extern __shared__ int s_bins[];  // [max(SO_BINS1, SO_MAXK * SO_BINS2)] then the level-1 order as uint16 [n]
+  __shared__ float s_lo[3][16], s_hi[3][16];
+  __shared__ int s_part[16];
+  __shared__ unsigned s_slo[SO_MAXK][3], s_shi[SO_MAXK][3];
+  __shared__ int s_axis[SO_MAXK];
+  __shared__ float s_lo2[SO_MAXK], s_scale2[SO_MAXK];
+  unsigned short *s_perm1 = reinterpret_cast<unsigned short *>(s_bins + SO_MAXK * SO_BINS2);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float *pts = xyz + (size_t)blockIdx.x * n * 3;
+  int32_t *out = perm + (size_t)blockIdx.x * n;
+  const int nrow = (n + 63) / 64;
+  // ---- level 1: the cloud's box, its widest axis, counting sort along it
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int k = tid; k < n; k += 1024)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float v = pts[k * 3 + a];
+      lo[a] = fminf(lo[a], v);
+      hi[a] = fmaxf(hi[a], v);
+    }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float h = wave_max_f32(hi[a]), l = -wave_max_f32(-lo[a]);
+    if (lane == 0) { s_hi[a][wave] = h; s_lo[a][wave] = l; }
+  }
+  for (int i = tid; i < SO_BINS1; i += 1024) s_bins[i] = 0;
+  for (int i = tid; i < SO_MAXK * 3; i += 1024) {
+    (&s_slo[0][0])[i] = 0xFFFFFFFFu;
+    (&s_shi[0][0])[i] = 0u;
+  }
+  __syncthreads();
+  int a1 = 0;
+  float lo1 = 0.f, ext1 = -1.f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float h = s_hi[a][0], l = s_lo[a][0];
+    for (int w = 1; w < 16; ++w) { h = fmaxf(h, s_hi[a][w]); l = fminf(l, s_lo[a][w]); }
+    if (h - l > ext1) { ext1 = h - l; a1 = a; lo1 = l; }  // (NaN extents never win; all NaN: axis 0, scale 0)
+  }
+  const float scale1 = ext1 > 0.f ? (float)(SO_BINS1 - 1) / ext1 : 0.f;
+  for (int k = tid; k < n; k += 1024) atomicAdd(&s_bins[so_quant(pts[k * 3 + a1], lo1, scale1, SO_BINS1)], 1);
+  __syncthreads();
+  so_scan<SO_BINS1 / 1024>(s_bins, s_part, tid, lane, wave);
+  for (int k = tid; k < n; k += 1024)
+    s_perm1[atomicAdd(&s_bins[so_quant(pts[k * 3 + a1], lo1, scale1, SO_BINS1)], 1)] = (unsigned short)k;
+  __syncthreads();
+  // ---- the slabs: slab i = rows [i*nrow/K, (i+1)*nrow/K) of the level-1 order; their boxes (a row lies in ONE slab)
+  auto slab_of_row = [&](int r) {
+    int i = (int)(((long long)r * K) / nrow);
+    while (i + 1 < K && (int)(((long long)(i + 1) * nrow) / K) <= r) ++i;
+    while (i > 0 && (int)(((long long)i * nrow) / K) > r) --i;
+    return i;
+  };
+  for (int r = wave; r < nrow; r += 16) {
+    const int pos = r * 64 + lane;
+    const bool live = pos < n;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (live) {
+      const int k = s_perm1[pos];
+      x = pts[k * 3 + 0]; y = pts[k * 3 + 1]; z = pts[k * 3 + 2];
+    }
+    float bhx = live ? x : -INFINITY, bhy = live ? y : -INFINITY, bhz = live ? z : -INFINITY;
+    float blx = live ? -x : -INFINITY, bly = live ? -y : -INFINITY, blz = live ? -z : -INFINITY;
+    wave_max_f32_x6(bhx, bhy, bhz, blx, bly, blz);
+    if (lane == 0) {
+      const int sl = slab_of_row(r);
+      atomicMax(&s_shi[sl][0], so_fkey(bhx)); atomicMax(&s_shi[sl][1], so_fkey(bhy)); atomicMax(&s_shi[sl][2], so_fkey(bhz));
+      atomicMin(&s_slo[sl][0], so_fkey(-blx)); atomicMin(&s_slo[sl][1], so_fkey(-bly)); atomicMin(&s_slo[sl][2], so_fkey(-blz));
+    }
+  }
+  for (int i = tid; i < K * SO_BINS2; i += 1024) s_bins[i] = 0;  // (perm1 lies behind the bins: untouched)
+  __syncthreads();
+  if (tid < K) {
+    int a2 = 0;
+    float l2 = 0.f, e2 = -1.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float h = so_funkey(s_shi[tid][a]), l = so_funkey(s_slo[tid][a]);
+      if (h - l > e2) { e2 = h - l; a2 = a; l2 = l; }
+    }
+    s_axis[tid] = a2;
+    s_lo2[tid] = l2;
+    s_scale2[tid] = e2 > 0.f ? (float)(SO_BINS2 - 1) / e2 : 0.f;
+  }
+  __syncthreads();
+  // ---- level 2: counting sort of every slab along its own widest axis
+  constexpr int MAXPT = SO_MAXN / 1024;
+  int mybin[MAXPT];
+#pragma unroll
+  for (int i = 0; i < MAXPT; ++i) {
+    const int pos = tid + i * 1024;
+    mybin[i] = -1;
+    if (pos < n) {
+      const int sl = slab_of_row(pos >> 6);
+      const int k = s_perm1[pos];
+      mybin[i] = sl * SO_BINS2 + so_quant(pts[k * 3 + s_axis[sl]], s_lo2[sl], s_scale2[sl], SO_BINS2);
+      atomicAdd(&s_bins[mybin[i]], 1);
+    }
+  }
+  __syncthreads();
+  so_scan<SO_MAXK * SO_BINS2 / 1024>(s_bins, s_part, tid, lane, wave);  // (bins beyond K*SO_BINS2: stale, never read)
+#pragma unroll
+  for (int i = 0; i < MAXPT; ++i) {
+    const int pos = tid + i * 1024;
+    if (pos < n) out[atomicAdd(&s_bins[mybin[i]], 1)] = (int)s_perm1[pos];
+  }
 }
 
 // Fallback for clouds larger than one CU's register file: min-distances stay in `temp` (global).
@@ -810,6 +1303,30 @@ extern "C" int gb_fps_cell_order(const float *xyz, int32_t *perm, int b, int n, 
   return check_launch("gb_fps_cell_order");
 }
 
+extern "C" int gb_fps_row_order(const float *xyz, int32_t *perm, int b, int n, void *stream) {
+  using namespace gb;
+  if (b < 0 || n < 1 || !xyz || !perm) return GB_EINVAL;
+  if ((long long)n * 3 > 0x7fffffffLL) return GB_ERANGE;
+  if (n > SO_MAXN) return gb_fps_cell_order(xyz, perm, b, n, stream);  // the level-1 order no longer fits the LDS
+  if (b == 0) return GB_OK;
+  const int nrow = (n + 63) / 64;
+  int K = 1;
+  while ((2 * K + 1) * (2 * K + 1) <= 4 * nrow) ++K;  // K = round(sqrt(nrow))
+  if (K > SO_MAXK) K = SO_MAXK;
+  const int lds = SO_MAXK * SO_BINS2 * (int)sizeof(int) + ((n + 1) / 2) * 4;
+  static std::atomic<unsigned long long> attr{0};
+  allow_dynamic_lds(fps_slab_order_kernel, SO_MAXK * SO_BINS2 * (int)sizeof(int) + SO_MAXN * 2, attr);
+  hipLaunchKernelGGL(fps_slab_order_kernel, dim3(b), dim3(1024), lds, as_stream(stream), xyz, perm, n, K);
+  return check_launch("gb_fps_row_order");
+}
+
+#ifdef GB_FPS_STAMPS
+static unsigned long long *g_fps_stamps = nullptr;  // diagnostic build only
+extern "C" void gb_debug_fps_stamps(unsigned long long *buf) { g_fps_stamps = buf; }
+#define GB_STAMP_ARG , g_fps_stamps
+#else
+#define GB_STAMP_ARG
+#endif
 extern "C" int gb_fps_pruned(const float *xyz, const int32_t *perm, float *temp, int32_t *idx, int b, int n, int m,
                              unsigned flags, float *scratch, void *stream) {
   using namespace gb;
@@ -827,6 +1344,30 @@ extern "C" int gb_fps_pruned(const float *xyz, const int32_t *perm, float *temp,
     if ((n >> bs_log2) >= (1 << GB_FPS_KEY_SHIFT)) return GB_ERANGE;
   }
   hipStream_t s = as_stream(stream);
+  const unsigned layout = flags & GB_FPS_LAYOUT_MASK;
+  if (layout > GB_FPS_LAYOUT_R4) return GB_EINVAL;
+  if (n <= 1024 * 20 && layout != GB_FPS_LAYOUT_R4) {
+    // round 5: 4 waves (default) or 8 waves per cloud, the winner's coordinates carried through LDS (fps_rows_kernel)
+#define GB_ROWS(WV, A0, A1, A2)                                                                               \
+  if (ceil_div(n, WV * 64) <= A0 + A1 + A2) {                                                                  \
+    static std::atomic<unsigned long long> attr{0};                                                            \
+    constexpr int lds = WV * 64 * (A0 + A1 + A2) * 4;                                                          \
+    allow_dynamic_lds(fps_rows_kernel<WV, A0, A1, A2>, lds, attr);                                             \
+    hipLaunchKernelGGL((fps_rows_kernel<WV, A0, A1, A2>), dim3(b), dim3(WV * 64), lds, s, xyz, perm, temp, idx, n, m, \
+                       skip, bs_log2 GB_STAMP_ARG);                                                            \
+    return check_launch("gb_fps_pruned");                                                                      \
+  }
+    if (layout == GB_FPS_LAYOUT_W16) {
+      GB_ROWS(16, 16, 0, 0) GB_ROWS(16, 16, 4, 0)
+    } else if (layout == GB_FPS_LAYOUT_W12) {
+      GB_ROWS(12, 16, 0, 0) GB_ROWS(12, 32, 0, 0)
+    } else if (layout == GB_FPS_LAYOUT_W4) {
+      GB_ROWS(4, 32, 0, 0) GB_ROWS(4, 32, 32, 0) GB_ROWS(4, 32, 32, 16)
+    } else {
+      GB_ROWS(8, 16, 0, 0) GB_ROWS(8, 32, 0, 0) GB_ROWS(8, 32, 16, 0)
+    }
+#undef GB_ROWS
+  }
   const int p_need = ceil_div(n, 1024);
 #define GB_PR(PV)                                                                                              \
   if (p_need <= PV) {                                                                                          \

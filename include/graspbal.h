@@ -55,6 +55,18 @@ enum {
 #define GB_FPS_TIE_TREE512  0x10u
 #define GB_FPS_TIE_TREE1024 0x20u
 #define GB_FPS_TIE_MASK     0x30u
+/* gb_fps_pruned only - how a register-resident cloud (n <= 20480) is spread over the waves of one CU.  Same outputs
+ * for every layout; AUTO lets the library choose.  W4 / W8 / W12 / W16: that many waves, the rows of a wave in
+ * run-time indexed register vectors, the winner's coordinates carried through the reduction (fps.hip, round 5).
+ * R4 is the round-4 kernel (16 waves, one branch per row, the winner's coordinates re-read from global memory every
+ * iteration), kept for A/B measurements.                                                                            */
+#define GB_FPS_LAYOUT_AUTO  0x000u
+#define GB_FPS_LAYOUT_W4    0x100u
+#define GB_FPS_LAYOUT_W8    0x200u
+#define GB_FPS_LAYOUT_W12   0x300u
+#define GB_FPS_LAYOUT_W16   0x400u
+#define GB_FPS_LAYOUT_R4    0x500u
+#define GB_FPS_LAYOUT_MASK  0x700u
 
 int gb_abi_version(void);
 /* last launch error text of the calling thread ("" if none) */
@@ -81,6 +93,12 @@ int gb_fps_pruned(const float *xyz, const int32_t *perm, float *temp, int32_t *i
  * Morton code of a 32^3 grid cell, one launch; the order inside a cell is not deterministic (gb_fps_pruned's output
  * does not depend on the permutation).                                                                  */
 int gb_fps_cell_order(const float *xyz, int32_t *perm, int b, int n, void *stream);
+/* perm (b,n) int32: the permutation gb_fps_pruned skips most with (round 5) - two levels of equal-count splits along the
+ * locally widest axis, cut at multiples of 64 points, so that a ROW of 64 consecutive points is a short piece of a thin
+ * slab (5.4 of 313 rows touched per sample on a 20 000-point table-top scene; 11.6 in gb_fps_cell_order's order).  One
+ * launch; n > 24576 falls back to gb_fps_cell_order.  Not deterministic inside a bin; gb_fps_pruned's output does not
+ * depend on the permutation.                                                                                 */
+int gb_fps_row_order(const float *xyz, int32_t *perm, int b, int n, void *stream);
 /* keys (b,n) int32: 30-bit Morton code of each point within its cloud's bounding box.                   */
 int gb_fps_morton_keys(const float *xyz, int32_t *keys, int b, int n, void *stream);
 /* Segmented FPS - the per-object sampling loop of ObjectBalanceSampling (TrainModel/modules.py:178-221, one

@@ -355,7 +355,7 @@ def test_fps_pruned_is_the_same_sequence(orc, tie, skip):
     g = torch.Generator().manual_seed(11)
     flags = {"lowest": _lib.FPS_TIE_LOWEST, "tree512": _lib.FPS_TIE_TREE512, "tree1024": _lib.FPS_TIE_TREE1024}[tie] | skip
     cases = []
-    for (B, N, m) in [(2, 9000, 300), (1, 20000, 256), (2, 4100, 128), (1, 70, 70)]:
+    for (B, N, m) in [(2, 9000, 300), (1, 20000, 256), (2, 4100, 128), (1, 70, 70), (1, 8200, 65), (2, 12345, 1), (1, 20480, 193)]:
         xyz = torch.randint(0, 9, (B, N, 3), generator=g).float() * 0.125
         xyz[:, N - N // 3:] = xyz[:, :N // 3]  # exact duplicates
         cases.append((xyz, m))
@@ -377,14 +377,18 @@ def test_fps_pruned_is_the_same_sequence(orc, tie, skip):
                  "random": torch.stack([torch.randperm(N, generator=g) for _ in range(B)]).int().to(DEV)}
         temp_o = torch.full((B, N), 1e10)
         want = orc.furthest_point_sampling(xyz, m, flags, temp=temp_o)
+        # every way the library spreads a register-resident cloud over its CU (round 5: 4 / 8 / 12 / 16 waves with
+        # run-time indexed row registers, and the round-4 kernel) returns the same samples; larger clouds have one form
+        layouts = _lib.FPS_LAYOUT.items() if N <= 20480 else [("auto", 0)]
         for name, perm in perms.items():
-            idx = torch.zeros(B, m, dtype=torch.int32, device=DEV)
-            temp = torch.full((B, N), 1e10, device=DEV)
-            _lib.check(_lib.lib().gb_fps_pruned(_lib.ptr(dev), _lib.ptr(perm.contiguous()), _lib.ptr(temp), _lib.ptr(idx),
-                                                B, N, m, flags, _lib.ptr(scratch), None), "gb_fps_pruned")
-            torch.cuda.synchronize()
-            assert torch.equal(idx.cpu(), want), (tie, skip, name, B, N, m)
-            assert torch.equal(temp.cpu(), temp_o), ("running min-distance state differs", name)
+            for lname, layout in layouts:
+                idx = torch.full((B, m), -7, dtype=torch.int32, device=DEV)
+                temp = torch.full((B, N), 1e10, device=DEV)
+                _lib.check(_lib.lib().gb_fps_pruned(_lib.ptr(dev), _lib.ptr(perm.contiguous()), _lib.ptr(temp), _lib.ptr(idx),
+                                                    B, N, m, flags | layout, _lib.ptr(scratch), None), "gb_fps_pruned")
+                torch.cuda.synchronize()
+                assert torch.equal(idx.cpu(), want), (tie, skip, name, lname, B, N, m)
+                assert torch.equal(temp.cpu(), temp_o), ("running min-distance state differs", name, lname)
 
 
 @pytest.mark.parametrize("tie", ["lowest", "tree512", "tree1024"])
@@ -551,6 +555,64 @@ def test_fps_cell_order_is_a_coherent_permutation(orc):
                                             _lib.ptr(scratch), None), "gb_fps_pruned")
         torch.cuda.synchronize()
         assert torch.equal(idx.cpu(), orc.furthest_point_sampling(xyz, m, flags))
+
+
+def test_fps_row_order_is_a_permutation_with_compact_rows(orc):
+    """gb_fps_row_order (round 5): every cloud's output is a permutation of its indices; its structure is the one the
+    kernel documents - the cloud sorted along its widest axis and cut into K slabs at multiples of 64 points (so slab
+    membership is monotone in that coordinate up to one bin width), every slab sorted along ITS widest axis (monotone up
+    to a bin) - rows of 64 consecutive points are at least twice as compact as in gb_fps_cell_order's order, and
+    gb_fps_pruned on it returns the oracle's samples.  Degenerate inputs: all points equal, n < 64, n = 1."""
+    import torch
+    from graspbalance_amd import _lib
+    cases = [(torch.from_numpy(make_batch([30, 31, 32], 20000)), 300, True), (torch.from_numpy(make_batch([33], 777)), 128, False),
+             (torch.from_numpy(make_batch([34, 35], 24576)), 100, True), (torch.zeros(2, 5000, 3) + 0.25, 64, False),
+             (torch.rand(1, 50, 3, generator=torch.Generator().manual_seed(3)), 50, False), (torch.rand(1, 1, 3) + 1, 1, False),
+             (torch.from_numpy(make_batch([36], 50000)), 150, False)]   # > 24576 points: falls back to the cell order
+    for xyz, m, check_rows in cases:
+        xyz = xyz.clone()
+        B, N = xyz.shape[:2]
+        dev = xyz.to(DEV)
+        perm = torch.full((B, N), -1, dtype=torch.int32, device=DEV)
+        _lib.check(_lib.lib().gb_fps_row_order(_lib.ptr(dev), _lib.ptr(perm), B, N, None), "row_order")
+        torch.cuda.synchronize()
+        p = perm.cpu().long()
+        assert torch.equal(torch.sort(p, dim=1)[0], torch.arange(N).repeat(B, 1)), N
+        walked = torch.gather(xyz, 1, p[:, :, None].expand(-1, -1, 3))
+        if check_rows:
+            nrow = (N + 63) // 64
+            K = int(round(nrow ** 0.5))
+            ext = xyz.max(1)[0] - xyz.min(1)[0]
+            for b in range(B):
+                a1 = int(ext[b].argmax())
+                tol1 = float(ext[b, a1]) / 4095 * 1.01
+                bounds = [(i * nrow) // K * 64 for i in range(K)] + [N]
+                prev_hi = -float("inf")
+                for i in range(K):
+                    slab = walked[b, bounds[i]:bounds[i + 1]]
+                    assert float(slab[:, a1].min()) >= prev_hi - tol1, (N, b, i)   # slabs are ordered along the first axis
+                    prev_hi = float(slab[:, a1].max())
+                    e2 = slab.max(0)[0] - slab.min(0)[0]
+                    a2 = int(e2.argmax())
+                    tol2 = float(e2[a2]) / 1023 * 1.01
+                    c = slab[:, a2]
+                    assert float((c[:-1] - c[1:]).max()) <= tol2, (N, b, i)        # ... and sorted along their own
+            # the point of it: tighter rows than the grid-cell order (sum of the rows' box diagonals)
+            pc = torch.empty_like(perm)
+            _lib.check(_lib.lib().gb_fps_cell_order(_lib.ptr(dev), _lib.ptr(pc), B, N, None), "cell_order")
+            torch.cuda.synchronize()
+
+            def diag_sum(pp):
+                w = torch.gather(xyz, 1, pp.cpu().long()[:, :, None].expand(-1, -1, 3))[:, :N // 64 * 64].view(B, -1, 64, 3)
+                return float((w.max(2)[0] - w.min(2)[0]).norm(dim=-1).sum())
+            assert diag_sum(perm) < 0.7 * diag_sum(pc), (diag_sum(perm), diag_sum(pc))
+        flags = _lib.FPS_TIE_TREE512 | _lib.FPS_SKIP_NEAR_ORIGIN
+        idx = torch.zeros(B, m, dtype=torch.int32, device=DEV)
+        scratch = torch.empty(B, N, 4, device=DEV) if N > 20480 else None
+        _lib.check(_lib.lib().gb_fps_pruned(_lib.ptr(dev), _lib.ptr(perm), None, _lib.ptr(idx), B, N, m, flags,
+                                            _lib.ptr(scratch), None), "gb_fps_pruned")
+        torch.cuda.synchronize()
+        assert torch.equal(idx.cpu(), orc.furthest_point_sampling(xyz, m, flags)), N
 
 
 @pytest.mark.parametrize("k", [1, 2, 3, 5, 8, 16])

@@ -1357,14 +1357,16 @@ extern "C" int gb_fps_pruned(const float *xyz, const int32_t *perm, float *temp,
                        skip, bs_log2 GB_STAMP_ARG);                                                            \
     return check_launch("gb_fps_pruned");                                                                      \
   }
+    // measured on 4 x 20000 -> 2048 (tools/fps_bench.py, row order): 12 waves 1.33 ms, 8 waves 1.46, 16 waves 1.56,
+    // 4 waves 2.42 (its rows spill into accumulation registers, which run-time indexing cannot reach), round 4's 1.84
     if (layout == GB_FPS_LAYOUT_W16) {
       GB_ROWS(16, 16, 0, 0) GB_ROWS(16, 16, 4, 0)
-    } else if (layout == GB_FPS_LAYOUT_W12) {
-      GB_ROWS(12, 16, 0, 0) GB_ROWS(12, 32, 0, 0)
+    } else if (layout == GB_FPS_LAYOUT_W8) {
+      GB_ROWS(8, 16, 0, 0) GB_ROWS(8, 32, 0, 0) GB_ROWS(8, 32, 16, 0)
     } else if (layout == GB_FPS_LAYOUT_W4) {
       GB_ROWS(4, 32, 0, 0) GB_ROWS(4, 32, 32, 0) GB_ROWS(4, 32, 32, 16)
     } else {
-      GB_ROWS(8, 16, 0, 0) GB_ROWS(8, 32, 0, 0) GB_ROWS(8, 32, 16, 0)
+      GB_ROWS(12, 16, 0, 0) GB_ROWS(12, 32, 0, 0)
     }
 #undef GB_ROWS
   }

@@ -347,6 +347,8 @@ __device__ __forceinline__ float wrlane_f(float vec, float s, int l) {
 // min-distance t of row q are element q of four vectors, so a wave-uniform RUN-TIME row number subscripts them.
 // (Plain local variables, not members of an aggregate: the optimiser keeps whole-vector locals in registers; inside a
 // struct it fell back to scratch memory.)
+typedef float fps_f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) float4 fps_lds_f4;
 template <int N> struct RowVecT { typedef float T __attribute__((ext_vector_type(N))); };
 template <> struct RowVecT<0> { typedef float T __attribute__((ext_vector_type(4))); };  // unused chunk
 
@@ -371,8 +373,7 @@ __global__ __launch_bounds__(W * 64) void fps_rows_kernel(const float *__restric
   static_assert(W <= 16 && P <= 128, "W candidates sit in one DPP row; row records in two sets of 64 lanes");
   constexpr int S = (P + 63) / 64;     // record sets
   extern __shared__ unsigned s_tie[];  // [W * P * 64] tie key of each sorted position
-  __shared__ float4 s_cand[2][16];     // (d, x, y, z) of each wave's candidate, double-buffered
-  __shared__ unsigned s_ckey[2][16];
+  __shared__ float4 s_cand[2][16][2];  // {(d, x, y, z), (key, -, -, -)} of each wave's candidate, double-buffered
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const float *pts = xyz + (size_t)blockIdx.x * n * 3;
@@ -399,9 +400,14 @@ __global__ __launch_bounds__(W * 64) void fps_rows_kernel(const float *__restric
     ax[s] = x0; ay[s] = y0; az[s] = z0;
   }
   if (tid < 32) {  // the candidate slots of waves that do not exist never win
-    s_cand[tid >> 4][tid & 15] = make_float4(-3.0f, x0, y0, z0);
-    s_ckey[tid >> 4][tid & 15] = key_of_0;
+    s_cand[tid >> 4][tid & 15][0] = make_float4(-3.0f, x0, y0, z0);
+    s_cand[tid >> 4][tid & 15][1].x = __uint_as_float(key_of_0);
   }
+  // LDS byte addresses of this wave's slot / of the slot this lane reads in the pick, flipped between the two buffers
+  // by one XOR per iteration (buffer j & 1; the loop starts at j = 1)
+  unsigned wslot = (unsigned)(size_t)(fps_lds_f4 *)&s_cand[1][wave][0];
+  unsigned rslot = (unsigned)(size_t)(fps_lds_f4 *)&s_cand[1][lane & 15][0];
+  constexpr unsigned SLOT_FLIP = 16 * 2 * sizeof(float4);
   static_for<0, P>([&](auto pc) __attribute__((always_inline)) {
     constexpr int p = decltype(pc)::value;
     const int k = (p * W + wave) * 64 + lane;
@@ -505,51 +511,48 @@ __global__ __launch_bounds__(W * 64) void fps_rows_kernel(const float *__restric
     for (int s = 1; s < S; ++s) v = fmaxf(v, rmax[s]);
     const float wmax = wave_max_f32_1(v);
     GB_STAMP(10);
-    unsigned long long eqs[S];
+    // ... published by the lane that HOLDS the winning record (no readlanes: the wave is masked down to the holder and
+    // it stores its own registers); almost always there is exactly one holder - exact ties between rows first find the
+    // smallest key among them.  Several lanes can only remain when their records are identical (no candidate anywhere:
+    // every record is "point 0"), and identical stores to one slot are harmless.
+    bool holder[S];
     int holders = 0;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-      eqs[s] = __builtin_amdgcn_ballot_w64(rmax[s] == wmax);
-      holders += __builtin_popcountll(eqs[s]);
+      holder[s] = rmax[s] == wmax;
+      holders += __builtin_popcountll(__builtin_amdgcn_ballot_w64(holder[s]));
     }
-    unsigned wkey = key_of_0;
-    float wx = x0, wy = y0, wz = z0;
-    auto candidate = [&]() __attribute__((always_inline)) {
-#pragma unroll
-      for (int s = 0; s < S; ++s)
-        if (S == 1 || eqs[s] != 0ull) {  // wave-uniform
-          const int L = __builtin_ctzll(eqs[s] | (1ull << 63));
-          wkey = (unsigned)__builtin_amdgcn_readlane((int)rkey[s], L);
-          wx = rdlane_f(ax[s], L); wy = rdlane_f(ay[s], L); wz = rdlane_f(az[s], L);
-        }
-    };
-    candidate();         // (as in the row update: the single-holder answer first, the check for ties behind it)
-    if (holders != 1) {  // exact tie between rows: the smallest key among the holders
+    if (holders != 1) {
       unsigned km = 0xFFFFFFFFu;
 #pragma unroll
       for (int s = 0; s < S; ++s) {
-        const unsigned ks = wave_min_u32(rmax[s] == wmax ? rkey[s] : 0xFFFFFFFFu);
+        const unsigned ks = wave_min_u32(holder[s] ? rkey[s] : 0xFFFFFFFFu);
         km = ks < km ? ks : km;
       }
 #pragma unroll
-      for (int s = 0; s < S; ++s) eqs[s] = __builtin_amdgcn_ballot_w64(rmax[s] == wmax && rkey[s] == km);
-      // (several records may hold the SAME key only when it is the key of point 0 with point 0's coordinates)
-      candidate();
+      for (int s = 0; s < S; ++s) holder[s] = holder[s] && rkey[s] == km;
     }
     GB_STAMP(11);
-    const int buf = j & 1;
-    // every lane stores the same values to the same slot: cheaper than masking the wave down to one lane
-    s_cand[buf][wave] = make_float4(wmax, wx, wy, wz);
-    s_ckey[buf][wave] = wkey;
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+      if (holder[s]) {
+        const fps_f32x4 rec = {rmax[s], ax[s], ay[s], az[s]};
+        asm volatile("ds_write_b128 %0, %1\n\tds_write_b32 %0, %2 offset:16" ::"v"(wslot), "v"(rec), "v"(rkey[s]) : "memory");
+      }
     GB_STAMP(2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the compiler does not know that the asm above wrote LDS)
     __syncthreads();
     GB_STAMP(3);
     // The pick.  (A form that stays in vector registers - the 16 slots reduced by DPP with the coordinates as payload,
     // a 64-bit compare and five selects per step - was measured: 68 instructions instead of ~30, and because EVERY wave
     // runs the pick at the same moment the SIMDs' issue slots are what it costs: 1.34 -> 1.88 ms.  Scalar round trips
     // are slow but they cost the other waves nothing.)
-    const float4 c = s_cand[buf][lane & 15];  // the four DPP rows of the wave all hold the 16 slots
-    const unsigned ck = s_ckey[buf][lane & 15];
+    fps_f32x4 c;  // the four DPP rows of the wave all hold the 16 slots
+    unsigned ck;
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b32 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(c), "=&v"(ck) : "v"(rslot) : "memory");
+    wslot ^= SLOT_FLIP;
+    rslot ^= SLOT_FLIP;
     const float dmax = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(row_max_f32_1(c.x))));
     unsigned long long e2 = __builtin_amdgcn_ballot_w64(c.x == dmax) & 0xFFFFull;
     int Lw = __builtin_ctzll(e2 | (1ull << 63));

@@ -8,6 +8,7 @@ reference uses plain BatchNorm, never SyncBN), and the whole fp32 gradient (9.05
 36 MB) is reduced as a few large flat buckets: xGMI is point-to-point, so few big collectives beat
 many per-parameter ones.
 """
+import contextlib
 import os
 import torch
 import torch.distributed as dist
@@ -30,7 +31,16 @@ class FlatGradAllReduce:
     The flat buffer holds the parameters' gradients in registration order - it is the optimizer's own gradient
     buffer when ``flat`` is given (flat_adam.FlatAdam: the reduced gradient is then already where the update reads
     it, no second copy).  A bucket is a contiguous run of parameters taken from the END of that order (backward
-    produces gradients roughly in reverse registration order), so bucket 0 is complete first.
+    produces gradients roughly in reverse registration order), so bucket 0 is complete first.  With ``cut`` (the
+    index of the first parameter behind the network's gradient cut, drp.grad_cut_param_index) there are exactly two:
+    [cut, end) - 94 % of GraspBalance's parameters, reached first - and [0, cut).
+
+    **One collective schedule for every way a step can run** (ADVICE round 4): per step every rank issues
+    ``all_reduce(flat[0]), all_reduce(flat[1]), ...`` - the same sizes in the same order - whether the step is
+    enqueued launch by launch (post-accumulate hooks issue a bucket as soon as it is complete, ``reduce()`` the
+    rest), replayed from HIP graphs (``issue_packed`` / ``reduce_flat`` between the graphs) or is the first step of a
+    new batch signature on one rank while the others replay (capture warm-ups run WITHOUT collectives: their result is
+    thrown away).  Which mode a rank is in is rank-local state (its own shapes); the collective sequence is not.
 
     Gradients are NOT accumulated into the buffer: ``zero_grad()`` sets every ``.grad`` to None so autograd just
     hands each parameter its freshly computed gradient (no per-parameter add kernel).  A post-accumulate hook per
@@ -44,25 +54,30 @@ class FlatGradAllReduce:
     ``timing=True`` (bench.py): ``reduce()`` brackets its waits with events on the compute stream; ``exposed_ms()``
     returns the time that stream spent stalled on the collectives."""
 
-    def __init__(self, module, bucket_mb=16.0, process_group=None, overlap=True, flat=None, timing=False):
+    def __init__(self, module, bucket_mb=16.0, process_group=None, overlap=True, flat=None, timing=False, cut=None):
         self.group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.params = [p for p in module.parameters() if p.requires_grad]
-        cap = int(bucket_mb * 1024 * 1024 / 4)
+        self.cut = cut if (cut is not None and 0 < cut < len(self.params)) else None
         # buckets: parameter index ranges [lo, hi) walking the registration order from the end
         self.ranges = []
-        hi, n = len(self.params), 0
-        for i in range(len(self.params) - 1, -1, -1):
-            if n and n + self.params[i].numel() > cap:
-                self.ranges.append((i + 1, hi))
-                hi, n = i + 1, 0
-            n += self.params[i].numel()
-        if hi > 0:
-            self.ranges.append((0, hi))
+        if self.cut is not None:
+            self.ranges = [(self.cut, len(self.params)), (0, self.cut)]
+        else:
+            cap = int(bucket_mb * 1024 * 1024 / 4)
+            hi, n = len(self.params), 0
+            for i in range(len(self.params) - 1, -1, -1):
+                if n and n + self.params[i].numel() > cap:
+                    self.ranges.append((i + 1, hi))
+                    hi, n = i + 1, 0
+                n += self.params[i].numel()
+            if hi > 0:
+                self.ranges.append((0, hi))
         self.buckets = [self.params[lo:hi] for lo, hi in self.ranges]
         self._works = [None] * len(self.buckets)
         self._arrived = [0] * len(self.buckets)
         self._next = 0
+        self._flat_next = 0   # (issue_packed / reduce_flat: the next bucket of the schedule)
         self.hold = False   # True: the hooks only count (a step whose collectives run after backward: reduce_flat)
         self.timing = timing
         self._stall_events = []
@@ -92,6 +107,11 @@ class FlatGradAllReduce:
                 for p in bucket:
                     self._bucket_of[id(p)] = b
                     p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def schedule(self):
+        """The step's collectives, in issue order: [(first element, number of elements)] of the flat buffer."""
+        base = self.flat_all.data_ptr() if self.flat_all is not None else 0
+        return [((f.data_ptr() - base) // 4, f.numel()) for f in self.flat]
 
     def zero_grad(self):
         for p in self.params:
@@ -141,29 +161,35 @@ class FlatGradAllReduce:
             for v, p in zip(self.views[b], self.buckets[b]):
                 p.grad = v
 
-    def reduce_flat(self):
-        """All-reduce (mean) the flat gradient buffer bucket by bucket and wait: for a step that packs its gradients into
-        the buffer itself and applies the update from it (train.Trainer's HIP-graph step: forward + backward + pack and
-        the Adam update are two captured graphs, the collectives run between them, uncaptured)."""
+    def issue_packed(self, b, stream=None):
+        """All-reduce (mean) bucket `b`, whose gradients the caller has already packed into the flat buffer, in the
+        synchronous form (this torch enqueues it on the CURRENT stream) on `stream`: a side stream of the caller's, so
+        the collective runs beside whatever the main stream does next.  The caller orders it: the bucket must be packed
+        before `stream` gets here, and the update must wait for `stream`."""
         if not dist.is_initialized():
             return
+        assert b == self._flat_next, "collectives are issued in schedule order on every rank"
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+            dist.all_reduce(self.flat[b], op=op, group=self.group)
+            if not self._avg:
+                self.flat[b].div_(self.world_size)
+        self._flat_next = b + 1
+
+    def reduce_flat(self):
+        """All-reduce (mean) the buckets of the flat gradient buffer that ``issue_packed`` has not taken yet, in schedule
+        order, on the current stream: for a step that packs its gradients into the buffer itself and applies the update
+        from it (train.Trainer's HIP-graph step: the captured graphs end by packing; the collectives run between them,
+        uncaptured).  Synchronous form: this torch issues it on the CURRENT stream (no hop to the process group's own
+        stream and back - two cross-stream waits cost the replayed step 0.7 ms)."""
+        if not dist.is_initialized():
+            return
         if self.timing:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        if os.environ.get("GB_ALLREDUCE_ASYNC", "0") == "1":
-            works = [dist.all_reduce(flat, op=op, group=self.group, async_op=True) for flat in self.flat]
-            for w in works:
-                w.wait()
-        else:
-            # synchronous form: this torch issues it on the CURRENT stream (no hop to the process group's own stream and
-            # back - the two cross-stream waits cost the graph-replayed step 0.7 ms, see DESIGN section 5.6)
-            # ... and as ONE collective over the whole buffer (the buckets are its contiguous slices; nothing is left to
-            # overlap them with, so fewer, larger messages over the point-to-point xGMI links)
-            dist.all_reduce(self.flat_all, op=op, group=self.group)
-        if not self._avg:
-            for flat in self.flat:
-                flat.div_(self.world_size)
+        while self._flat_next < len(self.flat):
+            self.issue_packed(self._flat_next)
+        self._flat_next = 0
         if self.timing:
             ev[1].record()
             self._stall_events.append(ev)

@@ -180,6 +180,29 @@ class ResBlock(nn.Module):
 import os
 _PREFETCH_LEVEL = int(os.environ.get("GB_PREFETCH_LEVEL", "1"))  # A/B switch: after which SA level the sampling of the next batch starts
 
+# the gradient cut of the data-parallel graph step (see DRP.forward): end_points flag / the two tensors it leaves
+GRAD_CUT, GRAD_CUT_OUT, GRAD_CUT_IN, GRAD_CUT_LEVEL = '_grad_cut', '_grad_cut_out', '_grad_cut_in', 2
+
+
+def grad_cut_param_index(net):
+    """Index (in net.parameters() order, trainable ones) of the first parameter BEHIND the gradient cut, or None when the
+    network has no DRP backbone: parameters [index, end) receive their gradients in the first part of the backward."""
+    drp = next((m for m in net.modules() if isinstance(m, DRP)), None)
+    if drp is None:
+        return None
+    first = next(iter(getattr(drp, 'InvResMLP_blocks%d' % GRAD_CUT_LEVEL).parameters()), None)
+    params = [q for q in net.parameters() if q.requires_grad]
+    for i, q in enumerate(params):
+        if q is first:
+            # the slices must be exactly "registered before the cut" / "registered after": true for DRP (sa1, blocks1,
+            # sa2 | blocks2 ... fp2) when the backbone is the first thing the network registers
+            shallow = [t for lvl in range(1, GRAD_CUT_LEVEL + 1) for t in getattr(drp, 'sa%d' % lvl).parameters()]
+            shallow += [t for lvl in range(1, GRAD_CUT_LEVEL) for t in getattr(drp, 'InvResMLP_blocks%d' % lvl).parameters()]
+            same = {id(t) for t in params[:i]} == {id(t) for t in shallow if t.requires_grad}
+            return i if same else None
+    return None
+
+
 # (channels, ball radius, nsample, number of InvResMLP blocks) after SA1..SA4 (drp.py:167-262)
 STAGE_SPECS = ((128, 0.08, 64, 3), (256, 0.2, 32, 6), (256, 0.4, 16, 3), (256, 0.6, 16, 3))
 
@@ -223,6 +246,15 @@ class DRP(nn.Module):
             hooks = end_points.get('_after_level')     # {level: callable}: run once that set-abstraction level is enqueued
             if hooks and level in hooks:
                 hooks.pop(level)()
+            if level == GRAD_CUT_LEVEL and end_points.get(GRAD_CUT) and features is not None and features.requires_grad:
+                # data-parallel graph execution (train.Trainer): the backward is cut HERE into "everything behind" (the
+                # heads, the feature propagation, levels 3-4 and this level's blocks: 94 % of the parameters, reached
+                # first) and "the rest" (levels 1-2), so that the first slice's gradient all-reduce runs under the
+                # second part.  The deep part consumes a detached alias; the caller backpropagates loss -> cut_in,
+                # then cut_out with cut_in.grad.  Same values as one backward.
+                end_points[GRAD_CUT_OUT] = features
+                features = features.detach().requires_grad_()
+                end_points[GRAD_CUT_IN] = features
             xyz, features = run_stage(getattr(self, 'InvResMLP_blocks%d' % level), xyz, features)
             if level <= 2:
                 end_points['sa%d_inds' % level] = fps_inds

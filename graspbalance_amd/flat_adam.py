@@ -52,12 +52,13 @@ class FlatAdam(Optimizer):
         self._fused = dev.type == "cuda" and hasattr(torch, "_fused_adam_")
 
     @torch.no_grad()
-    def pack(self):
+    def pack(self, lo=0, hi=None):
         """Gather the parameters' gradients into the flat gradient buffer (one multi-tensor copy; gradients that already
         are views of it - after the flat-bucket all-reduce - cost nothing).  step() does this itself unless told the
-        buffer is packed already (a step split around a collective: pack, all-reduce the buffer, step(packed=True))."""
+        buffer is packed already (a step split around a collective: pack, all-reduce the buffer, step(packed=True)).
+        lo, hi: only parameters [lo, hi) of the registration order (a backward cut in two: each part packs its slice)."""
         have_v, have_g = [], []
-        for v, p in zip(self._grad_views, self._params):
+        for v, p in zip(self._grad_views[lo:hi], self._params[lo:hi]):
             if p.grad is None:
                 v.zero_()
             elif p.grad is not v:

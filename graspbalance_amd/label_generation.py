@@ -18,51 +18,71 @@ def _nearest(ref_points, query_points):
     return myknn(ref, query, k=1).view(-1) - 1
 
 
-_ROW_ID_CACHE = {}
-_ONES_CACHE = {}
+class _ShapeCache:
+    """Small device constants that depend on a batch's size pattern only (row ids, index templates, padded buffers).
+    Bounded - a loader whose label sizes keep changing must not grow it without end - but an entry that a CAPTURED step
+    used is never evicted: the HIP graph has its address baked in, and a later replay would read whatever the allocator
+    put there since.  ``pinning()`` is held by train.Trainer around its warm-up steps and captures:
+    every entry created or read inside is pinned for the life of the process."""
+    _pin_depth = 0
+
+    def __init__(self, limit):
+        self.limit, self.entries, self.pinned = limit, {}, set()
+
+    def get(self, key, make):
+        ent = self.entries.get(key)
+        if ent is None:
+            if len(self.entries) - len(self.pinned) >= self.limit:
+                for k in [k for k in self.entries if k not in self.pinned]:
+                    del self.entries[k]
+            ent = self.entries[key] = make()
+        if _ShapeCache._pin_depth:
+            self.pinned.add(key)
+        return ent
+
+    @staticmethod
+    @__import__("contextlib").contextmanager
+    def pinning():
+        _ShapeCache._pin_depth += 1
+        try:
+            yield
+        finally:
+            _ShapeCache._pin_depth -= 1
+
+
+_ROW_ID_CACHE = _ShapeCache(256)
+_ONES_CACHE = _ShapeCache(256)
+_PAD_CACHE = _ShapeCache(64)
+pinning = _ShapeCache.pinning
 
 
 def _row_ids(sizes, first_obj, device):
-    key = (sizes, first_obj, str(device))
-    if key not in _ROW_ID_CACHE:
-        if len(_ROW_ID_CACHE) > 256:
-            _ROW_ID_CACHE.clear()
+    def make():
         oid = torch.cat([torch.full((n,), first_obj + k, dtype=torch.int32) for k, n in enumerate(sizes)])
         loc = torch.cat([torch.arange(n, dtype=torch.int32) for n in sizes])
-        _ROW_ID_CACHE[key] = (oid.to(device), loc.to(device))
-    return _ROW_ID_CACHE[key]
+        return oid.to(device), loc.to(device)
+    return _ROW_ID_CACHE.get((sizes, first_obj, str(device)), make)
 
 
 def _row_ids_all(sizes, device):
     """_row_ids of every cloud of the batch, concatenated (object ids count on through the batch)."""
-    key = ("all", sizes, str(device))
-    if key not in _ROW_ID_CACHE:
-        if len(_ROW_ID_CACHE) > 256:
-            _ROW_ID_CACHE.clear()
+    def make():
         oids, locs, k0 = [], [], 0
         for sz in sizes:
             oid, loc = _row_ids(sz, k0, device)
             oids.append(oid)
             locs.append(loc)
             k0 += len(sz)
-        _ROW_ID_CACHE[key] = (torch.cat(oids), torch.cat(locs))
-    return _ROW_ID_CACHE[key]
+        return torch.cat(oids), torch.cat(locs)
+    return _ROW_ID_CACHE.get(("all", sizes, str(device)), make)
 
 
 def _transform_3x4(cloud, pose):
     """transform_point_cloud(cloud, pose, '3x4') with the column of ones taken from a per-size cache (same matmul,
     same values; saves the ones() launch per object)."""
-    key = (int(cloud.size(0)), cloud.dtype, str(cloud.device))
-    ones = _ONES_CACHE.get(key)
-    if ones is None:
-        if len(_ONES_CACHE) > 256:
-            _ONES_CACHE.clear()
-        ones = _ONES_CACHE[key] = cloud.new_ones(cloud.size(0), 1)
+    ones = _ONES_CACHE.get((int(cloud.size(0)), cloud.dtype, str(cloud.device)), lambda: cloud.new_ones(cloud.size(0), 1))
     homo = torch.cat([cloud, ones], dim=1)
     return torch.matmul(pose, homo.T).T[:, :3]
-
-
-_PAD_CACHE = {}
 
 
 def _transform_all(gps_all, all_poses):
@@ -74,16 +94,13 @@ def _transform_all(gps_all, all_poses):
     Returns (T,3), objects one after another."""
     dev = all_poses.device
     sizes = tuple(int(gp.size(0)) for gp in gps_all)
-    key = (sizes, str(dev), all_poses.dtype)
-    ent = _PAD_CACHE.get(key)
-    if ent is None:
-        if len(_PAD_CACHE) > 64:
-            _PAD_CACHE.clear()
+
+    def make():
         nmax = max(sizes)
         flat = torch.cat([torch.arange(n, dtype=torch.int64) + k * nmax for k, n in enumerate(sizes)]).to(dev)
         buf = torch.ones((len(sizes) * nmax, 4), dtype=all_poses.dtype, device=dev)  # column 3 stays 1
-        ent = _PAD_CACHE[key] = (flat, buf, nmax)
-    flat, buf, nmax = ent
+        return flat, buf, nmax
+    flat, buf, nmax = _PAD_CACHE.get((sizes, str(dev), all_poses.dtype), make)
     K = len(sizes)
     buf[:, :3].index_copy_(0, flat, torch.cat(gps_all, 0))  # padding rows keep stale values: never read back
     out = torch.bmm(all_poses, buf.view(K, nmax, 4).transpose(1, 2))  # (K,3,nmax) == matmul(pose, homo.T) per object
@@ -246,6 +263,103 @@ def _process_grasp_labels_fused(end_points):
     return _finish_labels(end_points, batch, B, Ns)
 
 
+# ---- capacity form (round 5; ADVICE round 4: a captured step keyed on every label tensor's shape is useless on the
+# reference's loader, whose per-scene object counts and per-object grasp point counts vary) ---------------------------
+GEOMETRY = '_label_geometry'   # end_points entry (train._StaticBatch): LabelGeometry - the batch's objects at CAPACITY
+LIST_KEYS = ('object_poses_list', 'grasp_points_list', 'grasp_labels_list', 'grasp_offsets_list', 'grasp_tolerance_list')
+FAR = 1.0e18                   # coordinate of a padding grasp point: never anybody's nearest neighbour (its square is finite)
+
+
+def label_needs(batch):
+    """(objects per cloud, grasp points per object) the batch needs at most."""
+    return (max(len(per) for per in batch['grasp_points_list']),
+            max(int(gp.shape[0]) for per in batch['grasp_points_list'] for gp in per))
+
+
+class LabelGeometry:
+    """The object poses and grasp points of a batch in buffers of FIXED shape: `kc` object slots per cloud and `pc` point
+    slots per object, whatever the batch brings (poses (B*kc,3,4), unused slots the identity; points (B*kc*pc,4)
+    homogeneous, unused slots FAR away).  Label matching on it has the same launches, grids and addresses for every
+    batch that fits, so ONE captured step serves a loader whose sizes change from scene to scene; the per-object label
+    tensors themselves are read through the device-side pointer tables (slot b*kc + j)."""
+
+    def __init__(self, B, kc, pc, device):
+        self.B, self.kc, self.pc = B, kc, pc
+        self.poses = torch.zeros((B * kc, 3, 4), dtype=torch.float32, device=device)
+        self.points = torch.empty((B * kc * pc, 4), dtype=torch.float32, device=device)
+        self._eye = torch.eye(3, 4, dtype=torch.float32, device=device)
+        self._pattern = None
+
+    def fits(self, batch):
+        k, n = label_needs(batch)
+        return len(batch['grasp_points_list']) == self.B and k <= self.kc and n <= self.pc
+
+    def slots(self, batch):
+        """Object slot (b*kc + j) of every object of the batch, in list order."""
+        return [b * self.kc + j for b, per in enumerate(batch['grasp_points_list']) for j in range(len(per))]
+
+    def load(self, batch):
+        """Stage the batch's poses and grasp points (eager copies, outside any graph)."""
+        gps = [gp for per in batch['grasp_points_list'] for gp in per]
+        poses = [p for per in batch['object_poses_list'] for p in per]
+        dev = self.poses.device
+        sizes = tuple(int(gp.shape[0]) for gp in gps)
+        slots = self.slots(batch)
+        pattern = (sizes, tuple(slots))
+        if pattern != self._pattern:   # where every packed row goes: depends on the size pattern only
+            rows = torch.cat([torch.arange(n, dtype=torch.int64) + sl * self.pc for n, sl in zip(sizes, slots)])
+            self._rows, self._slots = rows.to(dev), torch.tensor(slots, dtype=torch.int64, device=dev)
+            self._pattern = pattern
+        with torch.no_grad():
+            self.points[:, :3] = FAR
+            self.points[:, 3] = 1.0
+            self.points[:, :3].index_copy_(0, self._rows, torch.cat(gps, 0).to(torch.float32))
+            self.poses.copy_(self._eye.expand_as(self.poses))
+            self.poses.index_copy_(0, self._slots, torch.stack(poses, 0).to(torch.float32))
+
+
+def _match_at_capacity(geo, seed_xyzs):
+    """(points (B,Ns,3), obj (B*Ns) int32 object slot, pt (B*Ns) int32 point within the object) of every seed's nearest
+    grasp point - the reference's per-cloud kNN over the cloud's transformed grasp points (label_generation.py:84) on
+    the padded buffers.  Valid points keep their relative order inside a cloud (objects, then points), so "lowest index
+    among equally near" picks the same point as the packed search."""
+    B, Ns, _ = seed_xyzs.shape
+    Kt, kc, pc = geo.poses.shape[0], geo.kc, geo.pc
+    pts = torch.bmm(geo.poses, geo.points.view(Kt, pc, 4).transpose(1, 2)).transpose(1, 2).reshape(Kt * pc, 3)
+    ref = pts.view(B, kc * pc, 3).transpose(1, 2).contiguous()
+    query = seed_xyzs.transpose(1, 2).contiguous()
+    nn_inds = myknn(ref, query, k=1).view(B, Ns) - 1
+    flat = (nn_inds + torch.arange(B, device=seed_xyzs.device, dtype=nn_inds.dtype).view(B, 1) * (kc * pc)).view(-1)
+    points = torch.index_select(pts, 0, flat).view(B, Ns, 3)
+    obj = torch.div(flat, pc, rounding_mode='floor').to(torch.int32)
+    pt = (flat - obj.long() * pc).to(torch.int32)
+    return points, obj.contiguous(), pt.contiguous()
+
+
+def _process_grasp_labels_at_capacity(end_points):
+    """_process_grasp_labels_fused on a LabelGeometry + device-side pointer tables: no tensor shape depends on how many
+    objects or grasp points the batch has (only the lean form exists: it is what a training step runs)."""
+    geo, tables = end_points[GEOMETRY], end_points[TABLES]
+    seed_xyzs = end_points['fp2_xyz']
+    B, Ns, _ = seed_xyzs.shape
+    dev = seed_xyzs.device
+    V, A, D = geo.vad
+    all_poses = geo.poses
+    view_inds = _assign_views(all_poses, V).contiguous()                         # (Kt,V) int64
+    views = grasp_views_on(dev, V)
+    rot_template = grasp_view_rotations_on(dev, V)
+    R = all_poses[:, :3, :3]
+    views_trans = torch.matmul(R, views.T).transpose(1, 2)                       # (Kt,V,3)
+    Kt = R.size(0)
+    rot_trans = torch.mm(R.reshape(Kt * 3, 3), rot_template.permute(1, 0, 2).reshape(3, V * 3)) \
+        .view(Kt, 3, V, 3).permute(0, 2, 1, 3)                                   # (Kt,V,3,3), strided
+    views_sel = torch.gather(views_trans, 1, view_inds.unsqueeze(-1).expand(-1, -1, 3))
+    rot_sel = torch.gather(rot_trans, 1, view_inds.view(-1, V, 1, 1).expand(-1, -1, 3, 3))
+    points, obj, pt = _match_at_capacity(geo, seed_xyzs)
+    return _lean_labels(end_points, [None] * Kt, [None] * Kt, [None] * Kt, obj, pt, view_inds, views_sel, rot_sel,
+                        obj.long(), points, B, Ns, V, A, D)
+
+
 LEAN = '_lean_labels'   # end_points flag (train.Trainer sets it): build only what a training step consumes
 TABLES = '_label_tables'  # end_points entry (train._StaticBatch): {list key: int64 device tensor of the tensors' addresses}
 
@@ -335,6 +449,8 @@ def _fusable(end_points):
 
 
 def process_grasp_labels(end_points):
+    if end_points.get(GEOMETRY) is not None and end_points.get(LEAN) and 'grasp_top_view_inds' in end_points:
+        return _process_grasp_labels_at_capacity(end_points)
     if _fusable(end_points):
         return _process_grasp_labels_fused(end_points)
     seed_xyzs = end_points['fp2_xyz']  # (B,Ns,3)

@@ -17,6 +17,8 @@ buckets | Adam): collectives are not captured.
 import contextlib
 
 import time
+import weakref
+
 import torch
 from torch.optim.lr_scheduler import OneCycleLR
 
@@ -41,6 +43,7 @@ _SAMPLE_AT = os.environ.get("GB_SAMPLE_AT", "bwd")
 _MAX_SIGNATURES = int(os.environ.get("GB_GRAPH_MAX_SIGNATURES", "4"))
 _HOST_SIDE_ORDER = os.environ.get("GB_HOST_SIDE_ORDER", "1") != "0"   # A/B switch: 0 = the side stream waits on the GPU
 _LABEL_TABLES = os.environ.get("GB_LABEL_TABLES", "1") != "0"   # A/B switch: 0 = the label tensors are copied into static buffers
+_LABEL_CAPACITY = os.environ.get("GB_LABEL_CAPACITY", "1") != "0"   # A/B switch: 0 = a captured step is keyed on every label tensor's shape
 _NO_CONTEXT = contextlib.nullcontext()
 
 BN_MOMENTUM_INIT = 0.5
@@ -85,10 +88,17 @@ class Trainer:
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)   # (eager steps on other streams)
         # the buckets ARE slices of the optimizer's flat gradient buffer: the averaged gradient lands where the
         # update reads it (no second 36 MB copy per step)
+        # where the data-parallel step cuts its backward in two (drp.GRAD_CUT): the parameters behind the cut - 94 % of
+        # them - have their gradients first, and their all-reduce runs under the rest of the backward
+        from .drp import grad_cut_param_index
+        self._cut = grad_cut_param_index(self.net) if distributed and os.environ.get("GB_GRAD_CUT", "1") != "0" else None
         with (torch.cuda.stream(self._cstream) if self._cstream is not None else _NO_CONTEXT):
             self.grads = FlatGradAllReduce(self.net, bucket_mb=bucket_mb, timing=time_collectives,
                                            flat=(self.optimizer._flat_g, self.optimizer._grad_views,
-                                                 self.optimizer._params))
+                                                 self.optimizer._params), cut=self._cut)
+        # the stream the first slice's all-reduce runs on beside the second part of the backward (graph execution)
+        self._comm = torch.cuda.Stream(device=self.device) if (distributed and self.device.type == "cuda") else None
+        self._cut_event = torch.cuda.Event() if self._comm is not None else None
         self.bnm_scheduler.step()
         self.net.train()
         # first-level FPS of the next batch on a side stream (prefetch.py); needs the caller to pass `next_batch`
@@ -158,16 +168,49 @@ class Trainer:
         those keys, and they must stay unchanged while steps on them are in flight."""
         if not self.graph:
             return batch
-        st = self._static_for(_signature(batch), batch)
+        st = self._static_for(self._sig(batch), batch)
         if st is None:
             return batch
         st.load(batch)
         return st.batch
 
+    def _capacity_form(self, batch):
+        """Can this batch's label lists be held at capacity (label_generation.LabelGeometry)?  What the lean label
+        matching needs of them anyway + the switch."""
+        from .label_generation import LIST_KEYS, tables_ok
+        return (self.lean_labels and _LABEL_TABLES and _LABEL_CAPACITY and all(k in batch for k in LIST_KEYS)
+                and tables_ok(batch))
+
+    def _sig(self, batch):
+        """What a captured step is keyed on.  Capacity form: the label lists' own shapes are NOT part of it (only their
+        common (V, A, D)), so batches whose objects / grasp points differ in number share buffers and graphs."""
+        if self._capacity_form(batch):
+            from .label_generation import LIST_KEYS
+            return ("capacity", tuple(batch['grasp_labels_list'][0][0].shape[1:4])) + _signature(batch, skip=LIST_KEYS)
+        return _signature(batch)
+
     def _static_for(self, sig, batch):
         """The static buffers (and with them the captured graphs) of a batch signature; None once more than
         GB_GRAPH_MAX_SIGNATURES (default 4) different signatures have been seen - every one costs a capture (~1.5 s), its
         own copy of the inputs and graph memory, so a loader whose shapes keep changing runs launch by launch instead."""
+        capacity = None
+        if sig and sig[0] == "capacity":
+            # any existing set of buffers of this signature that is large enough serves the batch; a new one is sized
+            # with room to spare (objects per cloud to a multiple of 4 - at most 128 per batch, the pointer tables'
+            # limit -, grasp points per object to a power of two) so that the next larger scene fits it too
+            from .label_generation import label_needs
+            need_k, need_p = label_needs(batch)
+            fit = [v for k, v in self._statics.items() if k[0] == sig and v.geometry.fits(batch)]
+            if fit:
+                self._static = min(fit, key=lambda v: v.geometry.kc * v.geometry.pc)
+                return self._static
+            B = len(batch['grasp_points_list'])
+            kc = min(max(4, -(-need_k // 4) * 4), max(need_k, 128 // max(B, 1)))
+            pc = 64
+            while pc < need_p:
+                pc *= 2
+            capacity = (kc, pc)
+            sig = (sig, kc, pc)
         st = self._statics.get(sig)
         if st is None:
             if sig in self._eager_signatures:
@@ -181,7 +224,8 @@ class Trainer:
                 return None
             from .label_generation import tables_ok, BY_REFERENCE
             by_ref = BY_REFERENCE if (self.lean_labels and _LABEL_TABLES and tables_ok(batch)) else ()
-            st = self._statics[sig] = _StaticBatch(batch, self.prefetch.npoint if self.prefetch is not None else 0, by_ref)
+            st = self._statics[sig] = _StaticBatch(batch, self.prefetch.npoint if self.prefetch is not None else 0, by_ref,
+                                                   capacity=capacity)
         self._static = st
         return st
 
@@ -193,7 +237,7 @@ class Trainer:
 
     def _graph_step(self, batch, next_batch):
         announced = self.prefetch is not None and next_batch is not None
-        sig = _signature(batch)
+        sig = self._sig(batch)
         st = self._static_for(sig, batch)
         if st is None:
             return self._train_step(batch, next_batch)
@@ -207,7 +251,7 @@ class Trainer:
                 st.inds.copy_(pointnet2_utils.furthest_point_sample(st.batch['point_clouds'][..., 0:3].contiguous(),
                                                                    self.prefetch.npoint))
             st.samp_for = st.cloud_id()
-        key = (sig, announced, self._bn_momentum(), self.mlp_precision, fused_mlp.get_precision())
+        key = (id(st), announced, self._bn_momentum(), self.mlp_precision, fused_mlp.get_precision())
         g = self._graphs.get(key)
         if g is None:
             g = self._graphs[key] = self._capture(st, announced)
@@ -230,7 +274,7 @@ class Trainer:
             side = self.prefetch.side
             slot = st.ring_next()
             ver = st.batch['point_clouds']._version
-            if st.next_src[0] != "self" or st.side_saw != ver:
+            if not _is_self(st.next_src) or st.side_saw != ver:
                 # the announced clouds were staged by the main stream this step (or the resident ones were written since
                 # the side stream last synchronised with it): a real dependency.  Kept on the HOST where possible: a wait
                 # packet that sits unsatisfied in the side queue while the main queue works is what costs the 0.7 ms
@@ -257,8 +301,32 @@ class Trainer:
         if announced and _SAMPLE_AT != "start":
             slot = sample_next()                         # beside the backward: see _SAMPLE_AT
         g.bwd.replay()
-        if g.update is not None:                         # data parallel: the collective sits between two graphs
-            self.grads.reduce_flat()
+        if g.update is not None:                         # data parallel: the collectives sit between the graphs
+            if g.bwd2 is not None:
+                # the backward is two graphs, cut where 94 % of the gradient (everything behind level 2 of the backbone)
+                # is complete and packed: that slice's all-reduce runs on the side stream BESIDE the second graph.  The
+                # dependency "slice packed -> collective" is kept on the HOST (the event is waited for here, with the
+                # second graph already enqueued, so the GPU does not idle): a wait packet parked in the side queue while
+                # the main queue works is what costs 0.7 ms on this stack, a satisfied one is free.
+                self._cut_event.record(cur)
+                g.bwd2.replay()
+                if not self._cut_event.query():
+                    t0 = time.perf_counter()
+                    self._cut_event.synchronize()
+                    fused_mlp.SYNC_WAIT[0] += time.perf_counter() - t0
+                tm, self.grads.timing = self.grads.timing, False
+                if tm:   # what the main stream still waits for once its own backward is through
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record(cur)
+                self.grads.issue_packed(0, stream=self._comm)
+                self.grads.reduce_flat()                 # the small second slice, behind the second graph
+                cur.wait_stream(self._comm)              # (a join at the END of the main queue: free)
+                if tm:
+                    ev[1].record(cur)
+                    self.grads._stall_events.append(ev)
+                self.grads.timing = tm
+            else:
+                self.grads.reduce_flat()
             g.update.replay()
         self.optimizer.count_step()
         self.scheduler.step()
@@ -267,7 +335,7 @@ class Trainer:
             cur.wait_stream(self.prefetch.side)
             with torch.no_grad():   # (.data: device-side moves between static buffers; the identity tokens follow below)
                 st.inds.data.copy_(st.inds_ring[slot])
-                if st.next_src[0] != "self":
+                if not _is_self(st.next_src):
                     st.batch['point_clouds'].data.copy_(st.next_clouds)
             st.ring_done(slot, cur)
             st.moved_next_in()   # the announced clouds and their samples now sit in the current slots
@@ -280,6 +348,15 @@ class Trainer:
         opt = self.optimizer
         opt.tensor_lr = True
         opt.set_lr_tensor()
+        # (size-pattern constants the label matching caches - row ids, padded buffers - must outlive the graph that baked
+        # their addresses in: every entry touched from here to the end of the capture is pinned)
+        from .label_generation import pinning
+        with pinning():
+            return self._capture_pinned(st, announced)
+
+    def _capture_pinned(self, st, announced):
+        dev = self.device
+        opt = self.optimizer
         keep = {k: v.detach().clone() for k, v in self.net.state_dict().items()}
         keep_opt = (opt._exp_avg.clone(), opt._exp_avg_sq.clone(), opt._step_t.clone(), opt._steps)
         tick = fused_mlp._TRAIN_TICK[0]
@@ -288,6 +365,9 @@ class Trainer:
         cs.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(cs):
             for _ in range(2):
+                # (no collectives in the warm-up steps, whatever the world size: what they compute is thrown away below,
+                # and another rank may be REPLAYING this step - the collectives every rank issues per step must be the
+                # schedule's, nothing else)
                 self._body(st, announced, part="all")
                 self.grads.zero_grad()
         torch.cuda.current_stream(dev).wait_stream(cs)
@@ -316,10 +396,14 @@ class Trainer:
         # launched between them (_graph_step); with several ranks the update is a third, behind the all-reduce
         with torch.cuda.graph(g.fwd, pool=self._pool, stream=cs, capture_error_mode=mode):
             loss = self._body(st, announced, part="fwd")
-            g.loss = loss.detach()
+            g.loss = loss[0].detach()
         with torch.cuda.graph(g.bwd, pool=self._pool, stream=cs, capture_error_mode=mode):
             self._body(st, announced, part="bwd_pack" if self.distributed else "bwd_step", loss=loss)
         if self.distributed:
+            if loss[1] is not None:   # the rest of the backward, behind the gradient cut
+                g.bwd2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g.bwd2, pool=self._pool, stream=cs, capture_error_mode=mode):
+                    self._body(st, announced, part="bwd_pack2", loss=loss)
             g.update = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g.update, pool=self._pool, stream=cs, capture_error_mode=mode):
                 self._body(st, announced, part="update")
@@ -330,23 +414,31 @@ class Trainer:
         return g
 
     def _body(self, st, announced, part, loss=None):
-        """The step on the static buffers.  part: "all" (eager warm-up: everything) | "fwd" (forward + loss, returns the
-        loss with its autograd graph) | "bwd_step" (backward of `loss` + update) | "bwd_pack" (backward, gradients packed
-        into the flat buffer: the all-reduce follows outside) | "update" (Adam on the flat buffer)."""
+        """The step on the static buffers.  part: "all" (eager warm-up: everything, no collectives) | "fwd" (forward +
+        loss: returns (loss with its autograd graph, gradient cut or None)) | "bwd_step" (backward + update) |
+        "bwd_pack" (backward - up to the gradient cut if there is one - and its gradients packed into the flat buffer:
+        the all-reduce follows outside) | "bwd_pack2" (the backward behind the cut, packed) | "update" (Adam on the
+        flat buffer).  `loss` = what "fwd" returned."""
         if part == "update":
             self.optimizer.step(packed=True)
             return None
+        cut_index = self.grads.cut
         if part in ("all", "fwd"):
+            from .drp import GRAD_CUT, GRAD_CUT_IN, GRAD_CUT_OUT
             from .prefetch import KEY
             fused_mlp.begin_step(self.device)
             inputs = dict(st.batch)
             if self.lean_labels:
                 inputs[LEAN] = True
             if st.tables:
-                from .label_generation import TABLES
+                from .label_generation import GEOMETRY, TABLES
                 inputs[TABLES] = st.tables   # the label kernels read the tensors' addresses from here (see _StaticBatch)
+                if st.geometry is not None:
+                    inputs[GEOMETRY] = st.geometry   # poses / grasp points at capacity: shapes independent of the batch
             if announced:
                 inputs[KEY] = st.inds        # the current batch's samples: sampled one step ahead (or inline by the caller)
+            if self.distributed and cut_index is not None:
+                inputs[GRAD_CUT] = True      # (drp.DRP.forward: the deep part consumes a detached alias of the cut tensor)
             side_by_side = announced and _SAMPLE_AT == "start"
             if side_by_side:
                 # the next batch's sampling runs beside this forward: with GB_RESERVE_CUS=1 the persistent GEMM grids
@@ -356,30 +448,37 @@ class Trainer:
                 inputs['_after_level'] = {2: lambda: fused_mlp.set_reserved_cus(0)}
             try:
                 end_points = self.net(inputs)
+                cut = (end_points[GRAD_CUT_OUT], end_points[GRAD_CUT_IN]) if GRAD_CUT_OUT in end_points else None
                 loss, end_points = get_loss(end_points)
             finally:
                 fused_mlp.set_reserved_cus(0)
+            loss = (loss, cut)
             if part == "fwd":
                 return loss
-        # ... backward (+ update).  The sampling launched beside it occupies one CU per cloud for ~2.6 of the backward's
+        # ... backward (+ update).  The sampling launched beside it occupies one CU per cloud for ~1.5 of the backward's
         # ~11 ms.  Sizing the persistent GEMM grids of the whole captured backward for the CUs it leaves
         # (GB_RESERVE_CUS=1 -> GbGemmOpts.reserved_cus) measured 0.1 ms SLOWER than letting the few workgroups that find
         # their CU taken wait (same box, alternating: 17.85 vs 17.75 ms), so nothing is reserved by default.
-        self.grads.hold = part == "bwd_pack"   # no collective inside a capture: reduce_flat() runs between the graphs
+        loss_t, cut = loss
+        self.grads.hold = True   # no collective inside a capture or a warm-up: they run between the graphs
         if announced and _SAMPLE_AT != "start" and part != "all":
             fused_mlp.set_reserved_cus(_reserve(st.next_clouds.shape[0]))
         try:
-            loss.backward()
+            if part != "bwd_pack2":
+                loss_t.backward()
+            if cut is not None and part in ("all", "bwd_step", "bwd_pack2"):
+                cut[0].backward(cut[1].grad)      # the part of the network in front of the gradient cut
         finally:
             fused_mlp.set_reserved_cus(0)
             self.grads.hold = False
-        if part == "bwd_pack":
-            with torch.no_grad():
-                self.optimizer.pack()
-        else:
-            self.grads.reduce()          # (single process: a no-op; several ranks only in the eager warm-up)
-            self.optimizer.step()
-        return loss.detach()
+        with torch.no_grad():
+            if part == "bwd_pack":
+                self.optimizer.pack(cut_index if cut is not None else 0, None)
+            elif part == "bwd_pack2":
+                self.optimizer.pack(0, cut_index)
+            else:
+                self.optimizer.step()
+        return loss_t.detach()
 
 
 def _reserve(clouds):
@@ -388,10 +487,10 @@ def _reserve(clouds):
 
 
 class _StepGraph:
-    __slots__ = ("fwd", "bwd", "update", "loss")
+    __slots__ = ("fwd", "bwd", "bwd2", "update", "loss")
 
     def __init__(self):
-        self.fwd = self.bwd = self.update = self.loss = None
+        self.fwd = self.bwd = self.bwd2 = self.update = self.loss = None
 
 
 def _leaves(obj, path=()):
@@ -406,12 +505,36 @@ def _leaves(obj, path=()):
             yield from _leaves(v, path + (i,))
 
 
-def _signature(batch):
-    return tuple((p, tuple(t.shape), t.dtype) for p, t in _leaves(batch) if p and not str(p[0]).startswith('_'))
+def _signature(batch, skip=()):
+    """Shapes / dtypes of every tensor of the batch (the keys in `skip` left out: label lists held at capacity)."""
+    return tuple((p, tuple(t.shape), t.dtype) for p, t in _leaves(batch)
+                 if p and not str(p[0]).startswith('_') and p[0] not in skip)
+
+
+TABLE_KEYS = ('grasp_labels_list', 'grasp_offsets_list', 'grasp_tolerance_list')
+
+
+class _Token:
+    """Which source tensor a static buffer currently mirrors: the tensor OBJECT (a weak reference: the batch is not kept
+    alive for this) and its version counter.  Not its address - a fresh batch that reuses a freed allocator block has the
+    same address, shape and version 0 as the one it replaced (the copy was skipped and the graph trained
+    on the previous clouds)."""
+    __slots__ = ("ref", "version")
+
+    def __init__(self, t):
+        self.ref, self.version = weakref.ref(t), t._version
+
+    def matches(self, t):
+        return self.ref() is t and self.version == t._version
 
 
 def _token(t):
-    return (t.data_ptr(), tuple(t.shape), t._version)
+    return _Token(t)
+
+
+def _is_self(src):
+    """_StaticBatch.next_src: ("self", id) when the announced clouds ARE the static current ones, else a _Token."""
+    return isinstance(src, tuple) and src[0] == "self"
 
 
 class _StaticBatch:
@@ -422,12 +545,23 @@ class _StaticBatch:
     Which source tensor every buffer currently mirrors is tracked by (address, shape, version) tokens, so a loop that keeps
     passing the same resident tensors - or the static buffers themselves - pays for no copy."""
 
-    def __init__(self, batch, npoint, by_reference=()):
+    def __init__(self, batch, npoint, by_reference=(), capacity=None):
         self.signature = _signature(batch)
         # by_reference: list keys whose (large) tensors are NOT copied - the step reads them through device-side pointer
         # tables (label_generation.TABLES) that load() rewrites: the grasp label / offset / tolerance tensors, 2.8 GB per
         # batch at B = 4, staged as 1 KB of addresses
         self.by_reference = tuple(k for k in by_reference if k in batch)
+        # capacity = (object slots per cloud, grasp point slots per object): the batch's label lists are then held at
+        # CAPACITY (label_generation.LabelGeometry) - one set of buffers, one captured graph for every batch that fits,
+        # whatever its objects and grasp points number (the reference's loader: both vary from scene to scene)
+        self.geometry = None
+        self._geo_tokens = None
+        if capacity is not None:
+            from .label_generation import LIST_KEYS, LabelGeometry
+            self.by_reference = tuple(k for k in LIST_KEYS if k in batch)
+            self.geometry = LabelGeometry(len(batch['grasp_points_list']), capacity[0], capacity[1],
+                                          batch['point_clouds'].device)
+            self.geometry.vad = tuple(batch['grasp_labels_list'][0][0].shape[1:4])
 
         def clone(obj, top=None):
             if top in self.by_reference:
@@ -444,11 +578,15 @@ class _StaticBatch:
         self.tables, self._table_addr, self._table_host, self._table_turn = {}, {}, {}, 0
         dev = batch['point_clouds'].device
         for k in self.by_reference:
-            n = sum(len(per) for per in batch[k])
+            if self.geometry is not None and k not in TABLE_KEYS:
+                continue    # (poses and grasp points are staged into the geometry's buffers, not read through tables)
+            n = sum(len(per) for per in batch[k]) if self.geometry is None else self.geometry.B * self.geometry.kc
             self.tables[k] = torch.zeros(n, dtype=torch.int64, device=dev)
             # (the host may run three steps ahead of the GPU: a pinned buffer is rewritten only four loads later)
             self._table_host[k] = [torch.zeros(n, dtype=torch.int64).pin_memory() for _ in range(4)]
             self._table_addr[k] = None
+        self._table_events = [None] * 4    # per ring slot: recorded behind the slot's copies to the device
+        self._table_keep = [None] * 4      # per ring slot: the tensors its addresses point at
         self._load_tables(batch)
         self.loaded = {p: _token(t) for p, t in _leaves(batch) if p in self._dst}   # source each buffer mirrors
         clouds = self.batch['point_clouds']
@@ -489,18 +627,60 @@ class _StaticBatch:
         return (self.loaded[('point_clouds',)], self.batch['point_clouds']._version)
 
     def _load_tables(self, batch):
+        """Rewrite the device-side pointer tables for `batch`'s by-reference tensors.  The addresses travel through a ring
+        of pinned host buffers; a slot is rewritten only after ITS copy to the device has executed (an event recorded
+        behind the copy and waited for on the host - which also bounds how far the host runs ahead), and every slot keeps
+        the tensors its addresses point at alive until it is reused, i.e. until the steps that read them are through
+        (the host could overwrite a slot whose copy was still pending, and only the latest batch's label
+        tensors were referenced)."""
+        slot = self._table_turn % len(self._table_events)
+        changed = False
+        if self.geometry is not None:
+            self._load_geometry(batch)
         for k in self.by_reference:
+            if k not in self.tables:
+                self.batch[k] = [list(per) for per in batch[k]]
+                continue
             ts = [t for per in batch[k] for t in per]
             addr = tuple(t.data_ptr() for t in ts)
+            if self.geometry is not None:   # slot b*kc + j; unused slots hold a valid address that nobody follows
+                at = [addr[0]] * self.tables[k].numel()
+                for a, sl in zip(addr, self.geometry.slots(batch)):
+                    at[sl] = a
+                ok = all(t.is_contiguous() and t.dtype == torch.float32 and a % 16 == 0 for t, a in zip(ts, addr))
+                addr = tuple(at)
+            else:
+                ok = all(t.is_contiguous() and t.dtype == torch.float32 and a % 16 == 0 for t, a in zip(ts, addr))
             if addr != self._table_addr[k]:
-                assert len(addr) == self.tables[k].numel() and all(t.is_contiguous() and t.dtype == torch.float32 and a % 16 == 0
-                                                                   for t, a in zip(ts, addr)), k
-                host = self._table_host[k][self._table_turn % 4]
+                assert len(addr) == self.tables[k].numel() and ok, k
+                if not changed:
+                    ev = self._table_events[slot]
+                    if ev is not None and not ev.query():
+                        t0 = time.perf_counter()
+                        ev.synchronize()
+                        fused_mlp.SYNC_WAIT[0] += time.perf_counter() - t0
+                    changed = True
+                host = self._table_host[k][slot]
                 host.copy_(torch.tensor(addr, dtype=torch.int64))
                 self.tables[k].copy_(host, non_blocking=True)
                 self._table_addr[k] = addr
-            self.batch[k] = [list(per) for per in batch[k]]     # (keeps the tensors alive while the step reads them)
-        self._table_turn += 1
+            self.batch[k] = [list(per) for per in batch[k]]
+        if changed:
+            if self._table_events[slot] is None:
+                self._table_events[slot] = torch.cuda.Event()
+            self._table_events[slot].record()
+            # (the tensors whose addresses went out with this slot stay referenced until the slot comes round again)
+            self._table_keep[slot] = [self.batch[k] for k in self.by_reference]
+            self._table_turn += 1
+
+    def _load_geometry(self, batch):
+        """Stage the poses and grasp points into the capacity buffers unless they already mirror these very tensors."""
+        src = [t for k in ('object_poses_list', 'grasp_points_list') for per in batch[k] for t in per]
+        toks = self._geo_tokens
+        if toks is not None and len(toks) == len(src) and all(tok.matches(t) for tok, t in zip(toks, src)):
+            return
+        self.geometry.load(batch)
+        self._geo_tokens = [_token(t) for t in src]
 
     def load(self, batch):
         """Make the static buffers hold `batch`; tensors that ARE the static ones, or that a buffer already mirrors, are
@@ -513,10 +693,10 @@ class _StaticBatch:
                 d = self._dst.get(p)
                 if d is None or d.data_ptr() == t.data_ptr():
                     continue
-                tok = _token(t)
-                if self.loaded.get(p) != tok:
+                tok = self.loaded.get(p)
+                if tok is None or not tok.matches(t):
                     d.copy_(t, non_blocking=True)
-                    self.loaded[p] = tok
+                    self.loaded[p] = _token(t)
 
     def load_next(self, clouds):
         """Stage the announced clouds.  When they ARE the static current clouds (a loop on one resident batch) nothing
@@ -527,11 +707,10 @@ class _StaticBatch:
             self.next_src = ("self", self.cloud_id())
             return
         self.next_clouds_src = self._next_buf
-        src = _token(clouds)
-        if src != self.next_src:
+        if not (isinstance(self.next_src, _Token) and self.next_src.matches(clouds)):
             with torch.no_grad():
                 self._next_buf.copy_(clouds, non_blocking=True)
-            self.next_src = src
+            self.next_src = _token(clouds)
 
     @property
     def next_clouds(self):
@@ -540,8 +719,8 @@ class _StaticBatch:
     def moved_next_in(self):
         """Bookkeeping after a replay that announced a next batch: batch['point_clouds'] now holds next_clouds' content
         and `inds` its samples (device-side copies at the end of the graph: no version counter moved)."""
-        if self.next_src[0] != "self":      # ("self", ...): the same content as before
+        if not _is_self(self.next_src):     # ("self", ...): the same content as before
             self.loaded[('point_clouds',)] = self.next_src
         self.samp_for = self.cloud_id()
-        if self.next_src[0] == "self":
+        if _is_self(self.next_src):
             self.next_src = ("self", self.cloud_id())

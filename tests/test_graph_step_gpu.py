@@ -75,7 +75,9 @@ def test_graph_steps_follow_the_eager_steps():
         # ... read BY REFERENCE: the replay takes their addresses from the device-side tables (no 2.8 GB staging copy)
         assert set(st.tables) == {'grasp_labels_list', 'grasp_offsets_list', 'grasp_tolerance_list'}
         assert st.batch['grasp_offsets_list'][1][1].data_ptr() == b['grasp_offsets_list'][1][1].data_ptr()
-        assert st.tables['grasp_offsets_list'].tolist() == [t.data_ptr() for per in b['grasp_offsets_list'] for t in per]
+        # (held at capacity: slot cloud * kc + object; unused slots hold a valid address nobody follows)
+        got = st.tables['grasp_offsets_list'].tolist()
+        assert [got[sl] for sl in st.geometry.slots(b)] == [t.data_ptr() for per in b['grasp_offsets_list'] for t in per]
     assert graph.graph_replays == 6 and len(graph._graphs) == 1
     assert graph.optimizer._steps == eager.optimizer._steps == 6 and float(graph.optimizer._step_t) == 6.0
     assert graph.optimizer.param_groups[0]['lr'] == eager.optimizer.param_groups[0]['lr']
@@ -164,6 +166,7 @@ def test_batch_signatures_keep_their_own_buffers_and_graphs_and_too_many_run_lau
     from graspbalance_amd import train
     from graspbalance_amd.synthetic import make_training_batch
     monkeypatch.setattr(train, "_MAX_SIGNATURES", 2)
+    monkeypatch.setattr(train, "_LABEL_CAPACITY", False)   # (the pre-round-5 keying: every label tensor's shape counts)
     eager, graph = _pair()
     mk = lambda seeds, npts, gp: make_training_batch(seeds, num_point=npts, num_objects=2, grasp_points_per_object=gp,
                                                      num_view=30, device=DEV)
@@ -180,3 +183,69 @@ def test_batch_signatures_keep_their_own_buffers_and_graphs_and_too_many_run_lau
     assert sum("batch signatures" in str(w.message) for w in caught) == 1
     sa, sb = (graph._statics[train._signature(x)] for x in (a, b))
     assert sa is not sb and torch.equal(sa.batch['point_clouds'], a['point_clouds']) and torch.equal(sb.batch['point_clouds'], b['point_clouds'])
+
+
+def _varied_batch(seeds, objects, points):
+    """A batch whose clouds have different numbers of objects and whose objects have different numbers of grasp points
+    (what the reference's loader produces: graspnet_dataset.py:206-237)."""
+    from graspbalance_amd.label_generation import LIST_KEYS
+    from graspbalance_amd.synthetic import make_training_batch
+    b = make_training_batch(seeds, num_point=3000, num_objects=max(objects), grasp_points_per_object=max(points), num_view=30,
+                            device=DEV)
+    for key in LIST_KEYS:
+        b[key] = [[(t if key == 'object_poses_list' else t[:points[(i + k) % len(points)]].contiguous())
+                   for k, t in enumerate(per[:objects[i]])] for i, per in enumerate(b[key])]
+    return b
+
+
+def test_one_captured_step_serves_batches_whose_label_sizes_vary():
+    """the reference's loader yields a different number of objects per scene and of grasp points per
+    object; a step keyed on those shapes would capture once per batch and give up after four.  Held at capacity
+    (label_generation.LabelGeometry) every batch that fits shares ONE set of static buffers and ONE graph; a batch that
+    does not fit gets a larger set (and its own graph), which then serves the smaller ones too... the losses follow the
+    launch-by-launch trainer fed the same batches."""
+    eager, graph = _pair()
+    batches = [_varied_batch([0, 1], (2, 2), (20, 20)), _varied_batch([2, 3], (1, 2), (17, 9, 20)),
+               _varied_batch([4, 5], (2, 1), (5, 20)), _varied_batch([6, 7], (3, 2), (20, 13, 8)),
+               _varied_batch([8, 9], (2, 2), (70, 66))]          # the last one: more grasp points than the 64 slots
+    order = [0, 1, 2, 3, 1, 0, 4, 2]
+    for i, k in enumerate(order):
+        b = batches[k]
+        nb = batches[order[i + 1]] if i + 1 < len(order) else b
+        le = float(eager.train_step(b, next_batch=nb).detach())
+        lg = float(graph.train_step(b, next_batch=nb))
+        torch.cuda.synchronize()
+        assert abs(le - lg) < (_TOL0 if i == 0 else _TOL) * abs(le), (i, k, le, lg)
+        if i == 5:
+            assert len(graph._statics) == 1 and len(graph._graphs) == 1 and graph.graph_replays == 6
+            st = graph._static
+            assert (st.geometry.kc, st.geometry.pc) == (4, 64)
+    assert len(graph._statics) == 2 and len(graph._graphs) == 2 and graph.graph_replays == len(order)
+    big = max(graph._statics.values(), key=lambda v: v.geometry.pc)
+    assert big.geometry.pc == 128 and graph._static is graph._statics[min(graph._statics, key=lambda kk: kk[2])]
+
+
+def test_fresh_batches_every_step_are_staged_even_when_the_allocator_reuses_their_addresses():
+    """a static buffer used to recognise its source by (address, shape, version) - a new batch built in
+    the block the previous one just freed looked like the old one and was never copied.  Now the source tensor's identity
+    counts: every step of a loop that drops its batch before building the next trains on the new clouds."""
+    from graspbalance_amd.synthetic import make_training_batch
+    _, graph = _pair()
+    mk = lambda s: make_training_batch([s, s + 1], num_point=3000, num_objects=2, grasp_points_per_object=20, num_view=30,
+                                       device=DEV)
+    reused = 0
+    batch = mk(0)
+    for s in range(2, 12, 2):
+        ptr = batch['point_clouds'].data_ptr()
+        graph.train_step(batch)
+        torch.cuda.synchronize()
+        want = batch['point_clouds'].clone()
+        assert torch.equal(graph._static.batch['point_clouds'], want)
+        del batch
+        batch = mk(s)
+        reused += int(batch['point_clouds'].data_ptr() == ptr)
+    # (whether the allocator hands the same block out again is its business; when it does, the copy must still happen)
+    graph.train_step(batch)
+    torch.cuda.synchronize()
+    assert torch.equal(graph._static.batch['point_clouds'], batch['point_clouds'])
+    print("addresses reused:", reused)

@@ -120,3 +120,11 @@ def rel(a, b):
     """relative L2 distance of a from b (both moved to fp64 on b's device)."""
     b = b.detach().double()
     return float((a.detach().double().to(b.device) - b).norm() / (b.norm() + 1e-300))
+
+
+def elem(a, b):
+    """Largest ELEMENT-wise deviation of a from b, relative to max(1, max|b|) (VERDICT round 4 #5a: a norm over half a
+    million elements does not see a handful of wrong ones; this does)."""
+    b = b.detach().double()
+    d = (a.detach().double().to(b.device) - b).abs()
+    return float(d.max() / max(1.0, float(b.abs().max()))) if d.numel() else 0.0

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_bench_line_contract(monkeypatch, capsys):
     sys.path.insert(0, ROOT)
     import bench
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"])
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extra-configs"])
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GB_FORCE_DIST"):
         monkeypatch.delenv(k, raising=False)
     bench.main()
@@ -33,3 +33,26 @@ def test_bench_line_contract(monkeypatch, capsys):
         assert d[k] is not None and 0.0 < d[k]["frac"] < 1.0, (k, d[k])
     assert d["roofline_ball"]["bound"] == "valu" and 0 < d["roofline_ball"]["scanned_frac_of_full"] <= 1
     assert d["ranks_seen"] == 1
+    # round 5: honest side figures - launch-by-launch execution as shipped (not the instrumented leg), the step on
+    # changing data, the memory the capturable step costs, and where `traffic` comes from
+    assert d["ms_per_step_eager"] > 0 and d["ms_per_step_instrumented_leg"] > 0 and d["ms_per_step_changing_data"] > 0
+    assert 1.0 < d["max_memory_allocated_gb"] < 288.0
+    src = r["traffic_source"]
+    assert src["file"].startswith("profiles/") and (r["traffic"] is None) == (not src["valid"])
+
+
+def test_bench_line_carries_the_other_two_configurations():
+    """the default command's line also reports BASELINE configs[2] (eval forward + decode) and
+    configs[4] (B = 8 x 50 000, bf16 contractions) - short legs in child processes after the timed region."""
+    import os
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GB_FORCE_DIST")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    inf, st = d["configs"]["infer"], d["configs"]["stress"]
+    assert "error" not in inf and "error" not in st, (inf, st)
+    assert inf["ms_per_step"] > 0 and "configs[2]" in inf["config"]["workload"] and inf["roofline"]["bound"] == "hbm"
+    assert st["ms_per_step"] > 0 and "configs[4]" in st["config"]["workload"] and st["dtype"] == "bf16"
+    assert abs(st["value"] - 8 / (st["ms_per_step"] * 1e-3)) / st["value"] < 1e-3

@@ -123,6 +123,12 @@ def test_config3_stated_initialisation_every_tensor_within_1e_5():
     print("configs[2]/C3 at the stated initialisation:", {"%s[%d]" % k: "%.1e" % v for k, v in report.items()})
     worst = max(report.items(), key=lambda kv: kv[1])
     assert worst[1] <= 1e-5, worst
+    # ... and element by element (north_star: "grouped features and grasp scores within 1e-5 fp32"): no single value of any
+    # tensor of any cloud is further than 1e-5 * max(1, max|truth|) from the truth
+    report_e = {(k, i): f64_truth.elem(got[k][i], truth[k][i]) for k in VALUE_KEYS for i in range(clouds.shape[0])}
+    print("  element-wise:", {"%s[%d]" % k: "%.1e" % v for k, v in report_e.items()})
+    worst_e = max(report_e.items(), key=lambda kv: kv[1])
+    assert worst_e[1] <= 1e-5, worst_e
     # the free arg-max of the truth picks the same views (near-ties aside)
     free64 = torch.max(truth['view_score'], dim=2)[1]
     assert int((free64 != views).sum()) <= 4
@@ -153,8 +159,10 @@ def test_config1_sa_layer_on_20k_cloud(orc, B):
     finally:
         fused_mlp.set_enabled(True)
     e_fused, e_plain = rel(feats, feats64), rel(feats_plain, feats64)
-    print("configs[1] B=%d: fused %.2e plain %.2e" % (B, e_fused, e_plain))
+    m_fused, m_plain = f64_truth.elem(feats, feats64), f64_truth.elem(feats_plain, feats64)
+    print("configs[1] B=%d: fused %.2e plain %.2e; element-wise fused %.2e plain %.2e" % (B, e_fused, e_plain, m_fused, m_plain))
     assert e_fused <= 1e-5 and e_fused <= 2.0 * e_plain + 2e-7, (e_fused, e_plain)
+    assert m_fused <= 1e-5, m_fused   # every grouped feature, not only their norm (north_star's 1e-5)
 
 
 def _grad_gap(params, params64):

@@ -149,7 +149,12 @@ NETWORK_TOL = {
 
 
 def test_whole_network_matches_reference_gpu(golden):
-    """a15: GraspBalance on the HIP path vs the reference's own run (N = 4096, B = 2, by-key weights)."""
+    """a15: GraspBalance on the HIP path vs the reference's own run (N = 4096, B = 2, by-key weights).
+    What this test is evidence of: the EVAL tensors and the decode (bounded tightly below).  Its train-mode bounds
+    (NETWORK_TOL: `sa4_features` 4e-2, `grad/` 2.0, then "at most twice as far as the plain composition") are GUARDS against
+    gross defects only - a free-running fp32 train step amplifies rounding by ~1.2 per conv + BN + ReLU layer whatever
+    the implementation.  The evidence for the train step's gradients is the frozen-routing harness
+    (tests/test_frozen_routing_gpu.py: every segment's outputs 1e-5, all 253 parameter gradients 1e-4 against fp64)."""
     def run():
         return cases.run_network_case(DEV, golden.load("g15_graspbalance"), cases._prior(golden.load("g13_loss")))
     fused, plain = _fused_and_plain(run)

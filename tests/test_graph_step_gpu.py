@@ -251,35 +251,51 @@ def test_fresh_batches_every_step_are_staged_even_when_the_allocator_reuses_thei
     print("addresses reused:", reused)
 
 
-def test_captured_backward_flat_gradient_equals_the_eager_one_within_the_eager_spread():
+def test_captured_backward_flat_gradient_equals_the_eager_one_within_the_eager_spread(monkeypatch):
     """VERDICT round 4 #5b: the captured backward (another stream topology, static rows at capacity, device-side row
     counts) was only ever compared with the launch-by-launch step through the LOSS.  Here: BASELINE configs[3] at its own
     batch size (B = 4 x 20 000), ONE step from identical state, and the whole flat gradient buffer (what Adam reads:
-    9.05 M values) of the graph trainer against the eager trainer's.  From identical state the two differ only by the order
-    of fp32 atomics (and the routing flips a last bit can cause), exactly like two eager runs do - so the bound is the
-    eager-vs-eager spread measured right here, times a small factor; per parameter tensor the same with the tensor's own
-    spread."""
+    9.05 M values) of the graph trainer against the eager trainer's.
+
+    What bound is meaningful (measured, tools/graph_grad_probe.py, two boxes): when the forward is the same bit for bit
+    (equal losses) the two backward passes differ only by the order of fp32 atomics - eager vs eager 2e-6 .. 7e-4, graph vs
+    eager 2e-6 .. 7e-4, the same distribution; when a last bit of the forward differs, routing decisions (ReLU masks,
+    arg-max rows, top views) flip and the gradient moves by percents whatever the execution (6e-2 seen once, with losses
+    1e-6 apart).  So: with the same label-matching form on both sides the losses must agree bit for bit and the gradient
+    within 4 x the largest eager-vs-eager distance of three eager runs (per tensor: 10 x); with the graph step's own
+    capacity-form label matching (another bmm shape: the matched points may differ in the last bit) the tight bound applies
+    when the losses are equal and a guard of 0.15 otherwise."""
+    from graspbalance_amd import train
     from graspbalance_amd.synthetic import make_training_batch
     from graspbalance_amd.train import Trainer
     batch = make_training_batch([0, 1, 2, 3], num_point=20000, device=DEV)
 
     def first_gradient(graph):
         tr = Trainer(DEV, steps_per_epoch=10, max_epoch=2, graph=graph)     # (same seed: same initial parameters)
-        loss = float(tr.train_step(batch, next_batch=batch))
+        loss = float(tr.train_step(batch, next_batch=batch).detach())
         torch.cuda.synchronize()
         sizes = [p.numel() for p in tr.optimizer._params]
         return tr.optimizer._flat_g.double().clone(), sizes, loss
-    e1, sizes, l1 = first_gradient(False)
-    e2, _, l2 = first_gradient(False)
-    g, _, lg = first_gradient(True)
     rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-300))
-    spread, gap = rel(e2, e1), rel(g, e1)
-    print("flat gradient after one step: eager vs eager %.2e, graph vs eager %.2e; losses %.6f %.6f %.6f" % (spread, gap, l1, l2, lg))
-    assert float(e1.norm()) > 0 and bool(torch.isfinite(g).all())
-    assert gap <= 4.0 * spread + 1e-6, (gap, spread)
-    worst = 0.0
-    for a, b, c in zip(e1.split(sizes), e2.split(sizes), g.split(sizes)):
-        s_t, g_t = rel(b, a), rel(c, a)
-        worst = max(worst, g_t / (s_t + 1e-6))
-        assert g_t <= 10.0 * s_t + 1e-4, (a.numel(), g_t, s_t)
-    print("  worst per-tensor graph/eager gap relative to the tensor's eager spread: %.1f" % worst)
+    eager = [first_gradient(False) for _ in range(3)]
+    sizes = eager[0][1]
+    assert eager[0][2] == eager[1][2] == eager[2][2], "launch-by-launch forward is not reproducible"
+    spread = max(rel(eager[i][0], eager[j][0]) for i in range(3) for j in range(i))
+    per_tensor = [max(rel(a, b), rel(a, c), rel(b, c)) for a, b, c in zip(*(e[0].split(sizes) for e in eager))]
+    for capacity in (False, True):
+        monkeypatch.setattr(train, "_LABEL_CAPACITY", capacity)
+        g, _, lg = first_gradient(True)
+        gap = min(rel(g, e[0]) for e in eager)
+        same_forward = lg == eager[0][2]
+        print("capacity-form labels %s: loss %.8f vs %.8f; flat gradient graph vs eager %.2e, eager vs eager (max of 3) %.2e"
+              % (capacity, lg, eager[0][2], gap, spread))
+        assert float(g.norm()) > 0 and bool(torch.isfinite(g).all())
+        if not capacity:
+            assert same_forward, "the captured forward differs from the launch-by-launch forward"
+        if same_forward:
+            assert gap <= 4.0 * spread + 1e-5, (gap, spread)
+            ref = min(eager, key=lambda e: rel(g, e[0]))[0]
+            for a, c, s_t in zip(ref.split(sizes), g.split(sizes), per_tensor):
+                assert rel(c, a) <= 10.0 * s_t + 1e-4, (a.numel(), rel(c, a), s_t)
+        else:
+            assert abs(lg - eager[0][2]) <= 1e-5 * abs(lg) and gap <= 0.15, (lg, gap)

@@ -48,6 +48,17 @@ def main(fetch_dir, write_dir, pattern, as_json=False):
             n = e["launches_profiled"]
             res[k] = {"launches_profiled": n, "fetch_bytes_per_launch_x2_corrected": e["fetch"] / n,
                       "write_bytes_per_launch": e["write"] / n, "hbm_bytes_per_launch": (e["fetch"] + e["write"]) / n}
+            # the git blob hashes of the kernel's source files AS PROFILED: bench.py reports the traffic only while they
+            # still match (a figure from a file is not a measurement of a changed kernel)
+            try:
+                import os
+                sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+                import bench
+                src = bench.kernel_source_hashes(k)
+                if src:
+                    res[k]["sources"] = src
+            except Exception:
+                pass
         res["_how"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 "
                        "--warmup 1 --no-cpu-baseline; counters in KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md "
                        "(128-B requests tallied at 64 B); mean over all launches of the kernel (all template variants)")

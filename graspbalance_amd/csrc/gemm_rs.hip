@@ -150,7 +150,10 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
   // RS_STATS_POOL_V: the fp64 column sums live in LDS, not in registers - [wave pair][2][C32] doubles behind the tables,
   // updated per tile with ds_add_f64 by the two waves that share them.  With 128 accumulators, 16 row keys and 32
   // registers of fp64 sums the pooled epilogue spilled 130 registers (0.25 GB of scratch written per launch).
-  constexpr bool LSTAT = EPI == RS_STATS_POOL_V;
+  // Round 5: the 256-wide RS_STATS instantiations as well (NT = 8: 128 accumulators + 32 registers of fp64 sums + the
+  // chunk double buffer; the bf16 one spilled 78 registers - the stress configuration's dominant launches)
+  constexpr bool LSTAT = EPI == RS_STATS_POOL_V || (EPI == RS_STATS && NT == 8) || (EPI == RS_BNBWD && BF);
+  static_assert(!(LSTAT && GEN3), "s_gen and s_st would share the LDS behind the tables");
   double *s_st = reinterpret_cast<double *>(s_aff + (g.aff ? 2 * rpad : 0));
   if constexpr (LSTAT)
     for (int i = t; i < (RS_WAVES / 2) * 2 * C32; i += RS_TPB) s_st[i] = 0.0;
@@ -201,6 +204,18 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
       for (int e = 0; e < 3; ++e) gx[j][e] = (g.gen_w && col < g.C) ? g.gen_w[col * 3 + e] : 0.f;
     }
   }
+  // LSTAT: a column tile's two partial sums (this lane: 16 of the column's 32 rows) go to the wave pair's fp64 slots
+  auto lds_stat_add = [&](int q, float cs, float cq) {
+    const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(cs), __float_as_uint(cs), false, false);
+    const auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(cq), __float_as_uint(cq), false, false);
+    cs += __uint_as_float(h ? s1[0] : s1[1]);   // the column's other 16 rows sit in lane ^ 32
+    cq += __uint_as_float(h ? s2[0] : s2[1]);
+    if (h == 0) {
+      double *sp = s_st + (size_t)(wave & 3) * 2 * C32 + q * 32 + m;
+      __hip_atomic_fetch_add(sp, (double)cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(sp + C32, (double)cq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  };
   auto load_chunk = [&](float4 (&dst)[4], long long tl, int kc) {
     const long long row = tl * 32 + m;
     if constexpr (GEN3) {  // the row's xyz (an L1 hit after the tile's first chunk); the values are formed at use
@@ -511,7 +526,8 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
               }
               acc[q][r] = 0.f;
             }
-            if constexpr (EPI != RS_STORE) { dsum[q] += (double)cs; dsq[q] += (double)cq; }
+            if constexpr (LSTAT) lds_stat_add(q, cs, cq);
+            else if constexpr (EPI != RS_STORE) { dsum[q] += (double)cs; dsq[q] += (double)cq; }
             if constexpr (EPI == RS_BNBWD_X) {
 #pragma unroll
               for (int j = 0; j < 3; ++j) dtx[q][j] += (double)ct[j];
@@ -571,7 +587,8 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
             }
             acc[q][r] = 0.f;
           }
-          if constexpr (EPI != RS_STORE) { dsum[q] += (double)cs; dsq[q] += (double)cq; }
+          if constexpr (LSTAT) lds_stat_add(q, cs, cq);
+          else if constexpr (EPI != RS_STORE) { dsum[q] += (double)cs; dsq[q] += (double)cq; }
           if constexpr (EPI == RS_BNBWD_X) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) dtx[q][j] += (double)ct[j];
@@ -713,7 +730,7 @@ bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, dou
               pool ? pool->gamma : nullptr, pool ? pool->pairs : nullptr, pool ? pool->D : 0,
               pool ? pool->gen_x : nullptr, pool ? pool->gen_w : nullptr,
               rows_dev, P, R, C, R, C, w_kc, slots < 1 ? 1 : slots, nch, stagger, tail_split};
-  if (epi == RS_STATS_POOL_V) {  // + the fp64 column sums: [wave pair][2][C32]
+  if (epi == RS_STATS_POOL_V || (epi == RS_STATS && nt == 8) || (epi == RS_BNBWD && bf16)) {  // + the fp64 column sums: [wave pair][2][C32]
     lds_bytes += (size_t)(RS_WAVES / 2) * 2 * nt * 32 * sizeof(double);
     if (lds_bytes > 156 * 1024) return false;
   }
@@ -747,7 +764,11 @@ bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, dou
   if (nt == 2) GB_RS(2);
   else if (nt == 4) GB_RS(4);
   else if (nt == 5) GB_RS(5);
-  else GB_RS(8);
+  else {   // (rs_shape_ok refuses RS_BNBWD at 8 column tiles: no instantiation of it - it would spill 128 registers)
+    if (epi == RS_STATS_POOL_V) rs_launch<8, RS_STATS_POOL_V>(g, lds_bytes, bpc, s, bf16, reserved_cus);
+    else if (epi == RS_STATS) rs_launch<8, RS_STATS>(g, lds_bytes, bpc, s, bf16, reserved_cus);
+    else rs_launch<8, RS_STORE>(g, lds_bytes, bpc, s, bf16, reserved_cus);
+  }
 #undef GB_RS
   return true;
 }

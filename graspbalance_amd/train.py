@@ -72,6 +72,7 @@ class Trainer:
         self.optimizer = FlatAdam(self.net.parameters(), lr=learning_rate, weight_decay=weight_decay)
         self.scheduler = OneCycleLR(self.optimizer, max_lr=learning_rate, steps_per_epoch=steps_per_epoch,
                                     epochs=max_epoch)
+        self._max_lr, self._max_epoch = learning_rate, max_epoch
         bn_lbmd = lambda it: max(BN_MOMENTUM_INIT * bn_decay_rate ** (int(it / bn_decay_step)), BN_MOMENTUM_MAX)
         self.bnm_scheduler = BNMomentumScheduler(self.net, bn_lambda=bn_lbmd, last_epoch=-1)
         # HIP-graph replay of the step (module docstring); needs the sync-free step (static rows) and a GPU
@@ -158,6 +159,30 @@ class Trainer:
         self.grads.zero_grad()  # .grad = None: the next backward assigns instead of accumulating
         self.scheduler.step()
         return loss
+
+    # ---- checkpoints (the reference's dictionary: train.py:96-103, 226-234) --------------------------------------------
+    def save_checkpoint(self, path, epoch, loss=None):
+        """torch.save of {'epoch', 'optimizer_state_dict', 'loss', 'model_state_dict'} - the keys the reference writes
+        after every epoch; the optimizer entry has torch.optim.Adam's layout (FlatAdam.state_dict), so the file loads
+        into the reference's own script and vice versa."""
+        torch.save({'epoch': int(epoch), 'optimizer_state_dict': self.optimizer.state_dict(),
+                    'loss': float(loss) if loss is not None else None,
+                    'model_state_dict': self.net.state_dict()}, path)
+
+    def load_checkpoint(self, path):
+        """Restore model and optimizer from a file of that layout and put the OneCycle schedule where the reference puts
+        it on resume (last_epoch = start_epoch * steps_per_epoch - 1, train.py:107-108) -> start_epoch."""
+        ckpt = torch.load(path, map_location=self.device)
+        self.net.load_state_dict(ckpt['model_state_dict'])
+        self.optimizer.load_state_dict(ckpt['optimizer_state_dict'])
+        fused_mlp.invalidate_eval_tables()
+        start_epoch = int(ckpt.get('epoch', 0))
+        total = self.scheduler.total_steps
+        per_epoch = max(1, total // max(1, getattr(self, "_max_epoch", 1)))
+        self.scheduler = OneCycleLR(self.optimizer, max_lr=self._max_lr, total_steps=total,
+                                    last_epoch=start_epoch * per_epoch - 1)
+        self.bnm_scheduler.step(start_epoch)   # (the reference steps it once per epoch: train.py:136)
+        return start_epoch
 
     # ---- HIP-graph execution ----------------------------------------------------------------------------------------
     def resident(self, batch):

@@ -178,3 +178,32 @@ def test_label_geometry_at_capacity_matches_like_the_packed_lists(cpu):
             assert torch.allclose(points[b], packed[nn], rtol=0, atol=1e-6)
             k0 += len(gps)
     assert not lg.LabelGeometry(2, 2, 64, "cpu").fits(ep) and not lg.LabelGeometry(2, 4, 16, "cpu").fits(ep)
+
+
+def test_checkpoint_has_the_reference_keys_and_resumes(cpu, tmp_path):
+    """Trainer.save_checkpoint / load_checkpoint (train.py:96-103, 226-234 of the reference): the file is the reference's
+    dictionary - 'epoch', 'optimizer_state_dict' in torch.optim.Adam's layout, 'loss', 'model_state_dict' with the
+    reference's 490 keys - and a fresh trainer resumed from it continues bit for bit like the one that wrote it."""
+    import torch
+    from graspbalance_amd.train import Trainer
+    batch = _tiny_batch()
+    a = Trainer("cpu", num_view=30, model=_tiny_net(), steps_per_epoch=2, max_epoch=4)
+    for _ in range(2):
+        a.train_step(batch)
+    path = str(tmp_path / "checkpoint.tar")
+    a.save_checkpoint(path, epoch=1, loss=1.5)
+    ckpt = torch.load(path)
+    assert set(ckpt) == {'epoch', 'optimizer_state_dict', 'loss', 'model_state_dict'} and ckpt['epoch'] == 1
+    assert set(ckpt['optimizer_state_dict']) == {'state', 'param_groups'}
+    st0 = ckpt['optimizer_state_dict']['state'][0]
+    assert set(st0) == {'step', 'exp_avg', 'exp_avg_sq'} and float(st0['step']) == 2.0
+    assert list(ckpt['model_state_dict']) == list(a.net.state_dict())
+    ref = torch.optim.Adam(_tiny_net().parameters())      # the layout loads into torch's own Adam
+    ref.load_state_dict(ckpt['optimizer_state_dict'])
+    b = Trainer("cpu", num_view=30, model=_tiny_net(), steps_per_epoch=2, max_epoch=4)
+    assert b.load_checkpoint(path) == 1
+    assert b.optimizer.param_groups[0]['lr'] == a.optimizer.param_groups[0]['lr']
+    la, lb = a.train_step(batch), b.train_step(batch)
+    assert torch.equal(la.detach(), lb.detach())
+    for p, q in zip(a.net.parameters(), b.net.parameters()):
+        assert torch.equal(p, q)

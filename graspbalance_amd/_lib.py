@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libgraspbal_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 GB_OK = 0
 _ERRNAMES = {-1: "GB_EINVAL", -2: "GB_ELAUNCH", -3: "GB_ERANGE"}

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GB_ABI_VERSION 5
+#define GB_ABI_VERSION 6
 
 enum {
   GB_OK = 0,

@@ -306,6 +306,33 @@ __global__ __launch_bounds__(RG_TPB, (BM == 128 && BN == 128) ? 1 : 2) void gemm
     }
   };
 
+  // RG_BNBWD: every y value and column coefficient the tile's epilogue needs is requested at the START OF THE LAST
+  // reduction step (round 5; it used to be after the loop): the ring has no DMA in flight any more (the wait in front of
+  // the last step is vmcnt(0)), so plain loads do not disturb the hand-counted waits, and the memory round trip for the
+  // tile (1 - 2 us on a 20 - 40 us launch) runs under the step's 16 MT NT MFMAs instead of behind them
+  float ea[EPI == RG_BNBWD ? NT : 1], eb[EPI == RG_BNBWD ? NT : 1], em[EPI == RG_BNBWD ? NT : 1], er[EPI == RG_BNBWD ? NT : 1];
+  float yv[EPI == RG_BNBWD ? MT : 1][EPI == RG_BNBWD ? NT : 1][16];
+  auto prefetch_epilogue = [&]() {
+    if constexpr (EPI == RG_BNBWD) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const long long col = n0 + wn * (BN / 2) + j * 32 + m;
+        const bool ok = col < g.b.rows;
+        ea[j] = ok ? g.epi_ab[col] : 0.f;
+        eb[j] = ok ? g.epi_ab[g.b.rows + col] : 0.f;
+        em[j] = ok ? g.epi_ab[2 * g.b.rows + col] : 0.f;
+        er[j] = ok ? g.epi_ab[3 * g.b.rows + col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const long long row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            yv[i][j][r] = (ok && row < g.a.rows) ? g.epi_y[row * g.ldd + col] : 0.f;
+          }
+      }
+    }
+  };
+
   for (int step = 0; step < T; ++step) {
     // stages issued so far: min(T, step + 3); the ones after `step` may stay in flight
     const int ahead = (T - 1 - step) < (RG_STAGES - 2) ? (T - 1 - step) : (RG_STAGES - 2);
@@ -327,6 +354,7 @@ __global__ __launch_bounds__(RG_TPB, (BM == 128 && BN == 128) ? 1 : 2) void gemm
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if (EPI == RG_BNBWD && step == T - 1) prefetch_epilogue();
     const unsigned sbase = lds0 + (unsigned)((step % RG_STAGES) * ST_FL * 4);
     const int kk = step * RG_BK;   // offset of this step inside the chunk (table index)
     // two fragment sets: the reads of group cq+1 are in flight under the MFMAs of group cq
@@ -353,28 +381,6 @@ __global__ __launch_bounds__(RG_TPB, (BM == 128 && BN == 128) ? 1 : 2) void gemm
   float csum[NT], csq[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
-  // RG_BNBWD: every y value and column coefficient the tile needs is requested before the first one is used (one memory
-  // round trip for the tile instead of one per 32 x 32 block)
-  float ea[EPI == RG_BNBWD ? NT : 1], eb[EPI == RG_BNBWD ? NT : 1], em[EPI == RG_BNBWD ? NT : 1], er[EPI == RG_BNBWD ? NT : 1];
-  float yv[EPI == RG_BNBWD ? MT : 1][EPI == RG_BNBWD ? NT : 1][16];
-  if constexpr (EPI == RG_BNBWD) {
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const long long col = n0 + wn * (BN / 2) + j * 32 + m;
-      const bool ok = col < g.b.rows;
-      ea[j] = ok ? g.epi_ab[col] : 0.f;
-      eb[j] = ok ? g.epi_ab[g.b.rows + col] : 0.f;
-      em[j] = ok ? g.epi_ab[2 * g.b.rows + col] : 0.f;
-      er[j] = ok ? g.epi_ab[3 * g.b.rows + col] : 0.f;
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const long long row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          yv[i][j][r] = (ok && row < g.a.rows) ? g.epi_y[row * g.ldd + col] : 0.f;
-        }
-    }
-  }
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll

@@ -33,6 +33,7 @@ SIGNATURES = {
     "gb_fps_segments": [_P, _P, _P, _P, _P, _I, _I, _U, _P],
     "gb_fps_cell_order": [_P, _P, _I, _I, _P],
     "gb_fps_row_order": [_P, _P, _I, _I, _P],
+    "gb_fps_row_order_ws": [_P, _P, _P, _I, _I, _P],
     "gb_fps_morton_keys": [_P, _P, _I, _I, _P],
     "gb_fps_guarded": [_P, _P, _P, _I, _I, _I, _U, _P, _P, _P, _P],
     "gb_gather": [_P, _P, _P, _I, _I, _I, _I, _P],
@@ -248,7 +249,7 @@ def event_pair_overhead_ms(device, pairs=64):
     return ms[len(ms) // 2]
 
 
-FPS_PRUNE_MIN_N, FPS_PRUNE_MAX_N, FPS_PRUNE_MIN_M = 8192, 64512, 128  # gb_fps_pruned: n <= 1024 * 63 rows of 64
+FPS_PRUNE_MIN_N, FPS_PRUNE_MAX_N, FPS_PRUNE_MIN_M = 8192, 65536, 128  # gb_fps_pruned: n <= 1024 rows of 64
 _fps_prune = os.environ.get("GB_FPS_PRUNE", "1") != "0"  # A/B switch
 # A/B switch, the visiting order: "rows" (round 5: two levels of equal-count splits, rows are compact), "cell" (round 4:
 # counting sort by 32^3 grid cell), "morton" (30-bit Morton keys + a device sort)
@@ -263,9 +264,13 @@ def fps(points, temp, output, b, n, m, flags, stream):
     import torch
     if _fps_prune and FPS_PRUNE_MIN_N <= n <= FPS_PRUNE_MAX_N and m >= FPS_PRUNE_MIN_M:
         perm = torch.empty((b, n), dtype=torch.int32, device=points.device)
-        if _fps_order != "morton":  # one launch
-            order = lib().gb_fps_row_order if _fps_order == "rows" else lib().gb_fps_cell_order
-            rc = order(ptr(points), ptr(perm), b, n, stream)
+        scratch = torch.empty((b, n, 4), dtype=torch.float32, device=points.device) if n > 20480 else None
+        if _fps_order == "rows":   # one launch (the level-1 order of a large cloud goes through the sampling's own scratch)
+            rc = lib().gb_fps_row_order_ws(ptr(points), ptr(perm), ptr(scratch), b, n, stream)
+            if rc != GB_OK:
+                return rc
+        elif _fps_order == "cell":
+            rc = lib().gb_fps_cell_order(ptr(points), ptr(perm), b, n, stream)
             if rc != GB_OK:
                 return rc
         else:                # full 30-bit Morton sort (keys kernel + torch sort)
@@ -274,7 +279,6 @@ def fps(points, temp, output, b, n, m, flags, stream):
             if rc != GB_OK:
                 return rc
             perm = torch.argsort(keys, dim=1).to(torch.int32)
-        scratch = torch.empty((b, n, 4), dtype=torch.float32, device=points.device) if n > 20480 else None
         return lib().gb_fps_pruned(ptr(points), ptr(perm), ptr(temp), ptr(output), b, n, m, flags | _fps_layout,
                                    ptr(scratch), stream)
     if _fps_prefix and n <= FPS_PREFIX_MAX_N and 64 <= m <= n:

@@ -349,14 +349,29 @@ __device__ __forceinline__ float wrlane_f(float vec, float s, int l) {
 // struct it fell back to scratch memory.)
 typedef float fps_f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) float4 fps_lds_f4;
+// (a wave's rows beyond its register vectors - BIG only, rows 48..63 of clouds of more than 49 152 points - keep their
+// min-distances in LDS: [row][thread])
+struct FpsLdsRows {
+  float *base;
+  int stride;
+};
+template <class V> __device__ __forceinline__ float fps_row_get(const V &v, int q) { return v[q]; }
+template <class V> __device__ __forceinline__ void fps_row_set(V &v, int q, float x) { v[q] = x; }
+__device__ __forceinline__ float fps_row_get(const FpsLdsRows &v, int q) { return v.base[q * v.stride]; }
+__device__ __forceinline__ void fps_row_set(FpsLdsRows &v, int q, float x) { v.base[q * v.stride] = x; }
 template <int N> struct RowVecT { typedef float T __attribute__((ext_vector_type(N))); };
 template <> struct RowVecT<0> { typedef float T __attribute__((ext_vector_type(4))); };  // unused chunk
 
-template <int W, int C0, int C1, int C2>
+// BIG (20 480 < n <= 65 536: the cloud no longer fits one CU's registers): only the running min-distances stay in the
+// register vectors; a row's coordinates and tie keys are re-read from a sorted (x, y, z, key) copy in global memory
+// (`sorted`, written by the prologue) - one 16-byte coalesced load per lane, requested one needed row AHEAD of the row
+// being updated - and the tie keys need no LDS table.
+template <int W, int C0, int C1, int C2, bool BIG = false, int LR = 0>
 __global__ __launch_bounds__(W * 64) void fps_rows_kernel(const float *__restrict__ xyz,
                                                            const int32_t *__restrict__ perm,
                                                            float *__restrict__ temp_io, int32_t *__restrict__ idx,
-                                                           int n, int m, int skip, int bs_log2
+                                                           int n, int m, int skip, int bs_log2,
+                                                           float4 *__restrict__ sorted
 #ifdef GB_FPS_STAMPS
                                                            , unsigned long long *__restrict__ stamps
 #endif
@@ -369,7 +384,9 @@ __global__ __launch_bounds__(W * 64) void fps_rows_kernel(const float *__restric
 #define GB_STAMP0()
 #define GB_STAMP(i)
 #endif
-  constexpr int P = C0 + C1 + C2;      // rows per wave
+  constexpr int PR = C0 + C1 + C2;     // rows per wave in register vectors
+  constexpr int P = PR + LR;           // rows per wave (LR more with their min-distances in LDS: BIG only)
+  static_assert(LR == 0 || BIG, "LDS rows: the BIG form only (its LDS is free of the tie-key table)");
   static_assert(W <= 16 && P <= 128, "W candidates sit in one DPP row; row records in two sets of 64 lanes");
   constexpr int S = (P + 63) / 64;     // record sets
   extern __shared__ unsigned s_tie[];  // [W * P * 64] tie key of each sorted position
@@ -385,6 +402,8 @@ __global__ __launch_bounds__(W * 64) void fps_rows_kernel(const float *__restric
   typename RowVecT<C0>::T x0v, y0v, z0v, t0v;
   typename RowVecT<C1>::T x1v, y1v, z1v, t1v;
   typename RowVecT<C2>::T x2v, y2v, z2v, t2v;
+  float4 *srt = BIG ? sorted + (size_t)blockIdx.x * n : nullptr;
+  FpsLdsRows tl = {reinterpret_cast<float *>(s_tie) + tid, W * 64};   // (LR > 0: the dynamic LDS holds [LR][threads] floats)
   // row records: lane l of set s describes row s*64 + l of this wave (= global row (s*64+l)*W + wave).  A record whose
   // row has no candidate keeps (rmax < 0, key of point 0, coordinates of point 0): when NOBODY has a candidate the
   // reductions below deliver "index 0" - the reference's result - without a special case
@@ -408,8 +427,10 @@ __global__ __launch_bounds__(W * 64) void fps_rows_kernel(const float *__restric
   unsigned wslot = (unsigned)(size_t)(fps_lds_f4 *)&s_cand[1][wave][0];
   unsigned rslot = (unsigned)(size_t)(fps_lds_f4 *)&s_cand[1][lane & 15][0];
   constexpr unsigned SLOT_FLIP = 16 * 2 * sizeof(float4);
-  static_for<0, P>([&](auto pc) __attribute__((always_inline)) {
-    constexpr int p = decltype(pc)::value;
+  // one row of the prologue: load the row's points, note its box and "has a candidate" in the row's record lane.
+  // (`store` receives the row's coordinates, min-distance and key; the register rows are walked by a compile-time
+  // loop - their subscripts must be constants -, the LDS rows of the BIG form by an ordinary one)
+  auto prologue_row = [&](int p, auto &&store) __attribute__((always_inline)) {
     const int k = (p * W + wave) * 64 + lane;
     float x = 0.f, y = 0.f, z = 0.f, t = -INFINITY;  // -inf: never a candidate
     unsigned key = 0xFFFFFFFFu;
@@ -424,22 +445,43 @@ __global__ __launch_bounds__(W * 64) void fps_rows_kernel(const float *__restric
         if (mag < 1e-3f) t = -INFINITY;
       }
     }
-    if constexpr (p < C0) { x0v[p] = x; y0v[p] = y; z0v[p] = z; t0v[p] = t; }
-    else if constexpr (p < C0 + C1) { x1v[p - C0] = x; y1v[p - C0] = y; z1v[p - C0] = z; t1v[p - C0] = t; }
-    else { x2v[p - C0 - C1] = x; y2v[p - C0 - C1] = y; z2v[p - C0 - C1] = z; t2v[p - C0 - C1] = t; }
-    s_tie[k] = key;
+    store(x, y, z, t, key, k);
     const bool cand = t >= 0.f;
     float bhx = cand ? x : -INFINITY, bhy = cand ? y : -INFINITY, bhz = cand ? z : -INFINITY;
     float blx = cand ? -x : -INFINITY, bly = cand ? -y : -INFINITY, blz = cand ? -z : -INFINITY;
     wave_max_f32_x6(bhx, bhy, bhz, blx, bly, blz);
     const bool any = __builtin_amdgcn_ballot_w64(cand) != 0ull;
-    constexpr int s = p / 64, l = p % 64;
-    if (lane == l) {
-      lox[s] = -blx; loy[s] = -bly; loz[s] = -blz; hix[s] = bhx; hiy[s] = bhy; hiz[s] = bhz;
-      rmax[s] = any ? 3.0e38f : -1.0f;  // > any squared distance: forces the row's first update
-    }
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+      if (lane == p - s * 64) {   // (p is a constant for the register rows: one set survives)
+        lox[s] = -blx; loy[s] = -bly; loz[s] = -blz; hix[s] = bhx; hiy[s] = bhy; hiz[s] = bhz;
+        rmax[s] = any ? 3.0e38f : -1.0f;  // > any squared distance: forces the row's first update
+      }
     __builtin_amdgcn_sched_barrier(0);  // keep the unrolled rows from piling their loads up (register pressure)
+  };
+  static_for<0, PR>([&](auto pc) __attribute__((always_inline)) {
+    constexpr int p = decltype(pc)::value;
+    prologue_row(p, [&](float x, float y, float z, float t, unsigned key, int k) __attribute__((always_inline)) {
+      if constexpr (BIG) {
+        if constexpr (p < C0) t0v[p] = t;
+        else if constexpr (p < C0 + C1) t1v[p - C0] = t;
+        else t2v[p - C0 - C1] = t;
+        if (k < n) srt[k] = make_float4(x, y, z, __uint_as_float(key));
+      } else {
+        if constexpr (p < C0) { x0v[p] = x; y0v[p] = y; z0v[p] = z; t0v[p] = t; }
+        else if constexpr (p < C0 + C1) { x1v[p - C0] = x; y1v[p - C0] = y; z1v[p - C0] = z; t1v[p - C0] = t; }
+        else { x2v[p - C0 - C1] = x; y2v[p - C0 - C1] = y; z2v[p - C0 - C1] = z; t2v[p - C0 - C1] = t; }
+        s_tie[k] = key;
+      }
+    });
   });
+  if constexpr (LR > 0) {
+    for (int p = PR; p < P; ++p)
+      prologue_row(p, [&](float x, float y, float z, float t, unsigned key, int k) __attribute__((always_inline)) {
+        fps_row_set(tl, p - PR, t);
+        if (k < n) srt[k] = make_float4(x, y, z, __uint_as_float(key));
+      });
+  }
   __syncthreads();
 
   float x1 = x0, y1 = y0, z1 = z0;  // wave-uniform
@@ -461,18 +503,41 @@ __global__ __launch_bounds__(W * 64) void fps_rows_kernel(const float *__restric
 #ifdef GB_FPS_STAMPS
       st_rows += __builtin_popcountll(need);
 #endif
+      // BIG: the (x, y, z, key) of the first needed row is requested here, every further one while its predecessor is
+      // being updated (the load's L2 latency - 300 to 800 cycles - would otherwise sit in front of every row)
+      float4 rowq = make_float4(0.f, 0.f, 0.f, 0.f);
+      auto row_load = [&](unsigned long long nd) __attribute__((always_inline)) {
+        if constexpr (BIG) {
+          if (nd != 0ull) {
+            const int kq = ((s * 64 + __builtin_ctzll(nd)) * W + wave) * 64 + lane;
+            return kq < n ? srt[kq] : make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu));
+          }
+        }
+        return make_float4(0.f, 0.f, 0.f, 0.f);
+      };
+      rowq = row_load(need);
       while (need != 0ull) {  // wave-uniform
         const int l = __builtin_ctzll(need);
         need &= need - 1ull;
         const int p = s * 64 + l;
-        const unsigned kk = s_tie[(p * W + wave) * 64 + lane];
+        unsigned kk;
+        float bx = 0.f, by = 0.f, bz = 0.f;
+        if constexpr (BIG) {
+          kk = __float_as_uint(rowq.w); bx = rowq.x; by = rowq.y; bz = rowq.z;
+          rowq = row_load(need);   // the next needed row's, in flight under this one's update
+        } else {
+          kk = s_tie[(p * W + wave) * 64 + lane];
+        }
         auto update = [&](auto &vx, auto &vy, auto &vz, auto &vt, int q) __attribute__((always_inline)) {
-          const float qx = vx[q], qy = vy[q], qz = vz[q], qt = vt[q];
+          float qx, qy, qz;
+          if constexpr (BIG) { qx = bx; qy = by; qz = bz; }
+          else { qx = vx[q]; qy = vy[q]; qz = vz[q]; }
+          const float qt = fps_row_get(vt, q);
           const float dx = qx - x1, dy = qy - y1, dz = qz - z1;
           const float d = ((dx * dx) + (dy * dy)) + (dz * dz);
           float d2;  // == fminf(d, t) without the canonicalising v_max the builtin puts in front
           asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(qt));
-          vt[q] = d2;
+          fps_row_set(vt, q, d2);
           GB_STAMP(6);
           const float mx = wave_max_f32_1(d2);
           // the row's arg-max: almost always a single lane holds the maximum -> its key and coordinates are read
@@ -499,9 +564,13 @@ __global__ __launch_bounds__(W * 64) void fps_rows_kernel(const float *__restric
           }
           GB_STAMP(9);
         };
-        if (C1 == 0 || p < C0) update(x0v, y0v, z0v, t0v, p);
-        else if (C2 == 0 || p < C0 + C1) update(x1v, y1v, z1v, t1v, p - C0);
-        else update(x2v, y2v, z2v, t2v, p - C0 - C1);
+        // (the comment-only asm statements differ per branch on purpose: with two chunks of the same type the optimiser
+        // otherwise sinks the identical bodies into one block that addresses the vectors through a pointer phi - and a
+        // register vector subscripted through memory lives in scratch)
+        if ((C1 == 0 && LR == 0) || p < C0) { update(x0v, y0v, z0v, t0v, p); asm volatile("; rows chunk 0"); }
+        else if (C1 != 0 && ((C2 == 0 && LR == 0) || p < C0 + C1)) { update(x1v, y1v, z1v, t1v, p - C0); asm volatile("; rows chunk 1"); }
+        else if (C2 != 0 && (LR == 0 || p < PR)) { update(x2v, y2v, z2v, t2v, p - C0 - C1); asm volatile("; rows chunk 2"); }
+        else if constexpr (LR != 0) { update(x0v, y0v, z0v, tl, p - PR); asm volatile("; rows in LDS"); }
       }
     });
     GB_STAMP(1);
@@ -589,7 +658,7 @@ __global__ __launch_bounds__(W * 64) void fps_rows_kernel(const float *__restric
     if (base + lane < m) out[base + lane] = fps_unkey(won, bs_log2);
   }
   if (tio) {
-    static_for<0, P>([&](auto pc) __attribute__((always_inline)) {
+    static_for<0, PR>([&](auto pc) __attribute__((always_inline)) {
       constexpr int p = decltype(pc)::value;
       const int k = (p * W + wave) * 64 + lane;
       float t;
@@ -598,6 +667,13 @@ __global__ __launch_bounds__(W * 64) void fps_rows_kernel(const float *__restric
       else t = t2v[p - C0 - C1];
       if (k < n && t >= 0.0f) tio[pm[k]] = t;
     });
+    if constexpr (LR > 0) {
+      for (int p = PR; p < P; ++p) {
+        const int k = (p * W + wave) * 64 + lane;
+        const float t = fps_row_get(tl, p - PR);
+        if (k < n && t >= 0.0f) tio[pm[k]] = t;
+      }
+    }
   }
 }
 
@@ -838,7 +914,7 @@ __global__ __launch_bounds__(1024) void fps_cell_order_kernel(const float *__res
 //            consecutive positions - is a short piece of a thin slab.
 // Points that share a bin keep whatever order the atomics give them (bin width = extent / 4096 resp. / 1024); the
 // samples gb_fps_pruned returns do not depend on the permutation.
-constexpr int SO_BINS1 = 4096, SO_BINS2 = 1024, SO_MAXK = 20, SO_MAXN = 24576;
+constexpr int SO_BINS1 = 4096, SO_BINS2 = 1024, SO_MAXK = 20, SO_MAXN = 24576, SO_MAXK_WS = 32, SO_MAXN_WS = 65536;
 __device__ __forceinline__ unsigned so_fkey(float f) {  // order-preserving float -> uint
   const unsigned u = __float_as_uint(f);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -873,15 +949,21 @@ __device__ __forceinline__ void so_scan(int *s_bins, int *s_part, int tid, int l
   for (int i = 0; i < PER; ++i) s_bins[tid * PER + i] = base + local[i];
   __syncthreads();
 }
+// WS: the level-1 order lives in a caller's workspace (`ws`, n int32 per cloud) instead of the LDS - clouds of more than
+// 24 576 points, whose 16-bit level-1 order (128 KB at 65 536 points) would not fit beside the level-2 bins
+template <bool WS>
 __global__ __launch_bounds__(1024) void fps_slab_order_kernel(const float *__restrict__ xyz, int32_t *__restrict__ perm,
-                                                               int n, int K) {
-  extern __shared__ int s_bins[];  // [max(SO_BINS1, SO_MAXK * SO_BINS2)] then the level-1 order as uint16 [n]
+                                                               int32_t *__restrict__ ws, int n, int K) {
+  constexpr int MAXK = WS ? SO_MAXK_WS : SO_MAXK;
+  extern __shared__ int s_bins[];  // [MAXK * SO_BINS2] (>= SO_BINS1), then (!WS) the level-1 order as uint16 [n]
   __shared__ float s_lo[3][16], s_hi[3][16];
   __shared__ int s_part[16];
-  __shared__ unsigned s_slo[SO_MAXK][3], s_shi[SO_MAXK][3];
-  __shared__ int s_axis[SO_MAXK];
-  __shared__ float s_lo2[SO_MAXK], s_scale2[SO_MAXK];
-  unsigned short *s_perm1 = reinterpret_cast<unsigned short *>(s_bins + SO_MAXK * SO_BINS2);
+  __shared__ unsigned s_slo[MAXK][3], s_shi[MAXK][3];
+  __shared__ int s_axis[MAXK];
+  __shared__ float s_lo2[MAXK], s_scale2[MAXK];
+  unsigned short *s_perm1 = reinterpret_cast<unsigned short *>(s_bins + MAXK * SO_BINS2);
+  int32_t *g_perm1 = WS ? ws + (size_t)blockIdx.x * n : nullptr;
+  auto perm1_get = [&](int pos) { return WS ? (int)g_perm1[pos] : (int)s_perm1[pos]; };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float *pts = xyz + (size_t)blockIdx.x * n * 3;
   int32_t *out = perm + (size_t)blockIdx.x * n;
@@ -901,7 +983,7 @@ __global__ __launch_bounds__(1024) void fps_slab_order_kernel(const float *__res
     if (lane == 0) { s_hi[a][wave] = h; s_lo[a][wave] = l; }
   }
   for (int i = tid; i < SO_BINS1; i += 1024) s_bins[i] = 0;
-  for (int i = tid; i < SO_MAXK * 3; i += 1024) {
+  for (int i = tid; i < MAXK * 3; i += 1024) {
     (&s_slo[0][0])[i] = 0xFFFFFFFFu;
     (&s_shi[0][0])[i] = 0u;
   }
@@ -918,8 +1000,12 @@ __global__ __launch_bounds__(1024) void fps_slab_order_kernel(const float *__res
   for (int k = tid; k < n; k += 1024) atomicAdd(&s_bins[so_quant(pts[k * 3 + a1], lo1, scale1, SO_BINS1)], 1);
   __syncthreads();
   so_scan<SO_BINS1 / 1024>(s_bins, s_part, tid, lane, wave);
-  for (int k = tid; k < n; k += 1024)
-    s_perm1[atomicAdd(&s_bins[so_quant(pts[k * 3 + a1], lo1, scale1, SO_BINS1)], 1)] = (unsigned short)k;
+  for (int k = tid; k < n; k += 1024) {
+    const int pos = atomicAdd(&s_bins[so_quant(pts[k * 3 + a1], lo1, scale1, SO_BINS1)], 1);
+    if constexpr (WS) g_perm1[pos] = k;
+    else s_perm1[pos] = (unsigned short)k;
+  }
+  if constexpr (WS) __threadfence_block();   // (other waves of this workgroup read the order below: through the L2)
   __syncthreads();
   // ---- the slabs: slab i = rows [i*nrow/K, (i+1)*nrow/K) of the level-1 order; their boxes (a row lies in ONE slab)
   auto slab_of_row = [&](int r) {
@@ -933,7 +1019,7 @@ __global__ __launch_bounds__(1024) void fps_slab_order_kernel(const float *__res
     const bool live = pos < n;
     float x = 0.f, y = 0.f, z = 0.f;
     if (live) {
-      const int k = s_perm1[pos];
+      const int k = WS ? __builtin_nontemporal_load(g_perm1 + pos) : (int)s_perm1[pos];
       x = pts[k * 3 + 0]; y = pts[k * 3 + 1]; z = pts[k * 3 + 2];
     }
     float bhx = live ? x : -INFINITY, bhy = live ? y : -INFINITY, bhz = live ? z : -INFINITY;
@@ -945,7 +1031,7 @@ __global__ __launch_bounds__(1024) void fps_slab_order_kernel(const float *__res
       atomicMin(&s_slo[sl][0], so_fkey(-blx)); atomicMin(&s_slo[sl][1], so_fkey(-bly)); atomicMin(&s_slo[sl][2], so_fkey(-blz));
     }
   }
-  for (int i = tid; i < K * SO_BINS2; i += 1024) s_bins[i] = 0;  // (perm1 lies behind the bins: untouched)
+  for (int i = tid; i < K * SO_BINS2; i += 1024) s_bins[i] = 0;  // (the LDS order lies behind the bins: untouched)
   __syncthreads();
   if (tid < K) {
     int a2 = 0;
@@ -960,27 +1046,48 @@ __global__ __launch_bounds__(1024) void fps_slab_order_kernel(const float *__res
     s_scale2[tid] = e2 > 0.f ? (float)(SO_BINS2 - 1) / e2 : 0.f;
   }
   __syncthreads();
-  // ---- level 2: counting sort of every slab along its own widest axis
-  constexpr int MAXPT = SO_MAXN / 1024;
-  int mybin[MAXPT];
+  // ---- level 2: counting sort of every slab along its own widest axis (the bin of a position is formed twice -
+  // histogram and scatter - from L2-resident data rather than kept in up to 64 registers per thread)
+  auto bin_of = [&](int pos, int &k) {
+    const int sl = slab_of_row(pos >> 6);
+    k = WS ? __builtin_nontemporal_load(g_perm1 + pos) : (int)s_perm1[pos];
+    return sl * SO_BINS2 + so_quant(pts[k * 3 + s_axis[sl]], s_lo2[sl], s_scale2[sl], SO_BINS2);
+  };
+  constexpr int KEEP = WS ? 1 : SO_MAXN / 1024;   // (!WS: a position's bin is kept in a register between the two passes)
+  int mybin[KEEP];
+  if constexpr (!WS) {
 #pragma unroll
-  for (int i = 0; i < MAXPT; ++i) {
-    const int pos = tid + i * 1024;
-    mybin[i] = -1;
-    if (pos < n) {
-      const int sl = slab_of_row(pos >> 6);
-      const int k = s_perm1[pos];
-      mybin[i] = sl * SO_BINS2 + so_quant(pts[k * 3 + s_axis[sl]], s_lo2[sl], s_scale2[sl], SO_BINS2);
-      atomicAdd(&s_bins[mybin[i]], 1);
+    for (int i = 0; i < KEEP; ++i) {
+      const int pos = tid + i * 1024;
+      mybin[i] = -1;
+      if (pos < n) {
+        int k;
+        mybin[i] = bin_of(pos, k);
+        atomicAdd(&s_bins[mybin[i]], 1);
+      }
+    }
+  } else {
+    for (int pos = tid; pos < n; pos += 1024) {
+      int k;
+      atomicAdd(&s_bins[bin_of(pos, k)], 1);
     }
   }
   __syncthreads();
-  so_scan<SO_MAXK * SO_BINS2 / 1024>(s_bins, s_part, tid, lane, wave);  // (bins beyond K*SO_BINS2: stale, never read)
+  so_scan<MAXK * SO_BINS2 / 1024>(s_bins, s_part, tid, lane, wave);  // (bins beyond K*SO_BINS2: stale, never read)
+  if constexpr (!WS) {
 #pragma unroll
-  for (int i = 0; i < MAXPT; ++i) {
-    const int pos = tid + i * 1024;
-    if (pos < n) out[atomicAdd(&s_bins[mybin[i]], 1)] = (int)s_perm1[pos];
+    for (int i = 0; i < KEEP; ++i) {
+      const int pos = tid + i * 1024;
+      if (pos < n) out[atomicAdd(&s_bins[mybin[i]], 1)] = (int)s_perm1[pos];
+    }
+  } else {
+    for (int pos = tid; pos < n; pos += 1024) {
+      int k;
+      const int b = bin_of(pos, k);
+      out[atomicAdd(&s_bins[b], 1)] = k;
+    }
   }
+  (void)perm1_get;
 }
 
 // Fallback for clouds larger than one CU's register file: min-distances stay in `temp` (global).
@@ -1306,21 +1413,38 @@ extern "C" int gb_fps_cell_order(const float *xyz, int32_t *perm, int b, int n, 
   return check_launch("gb_fps_cell_order");
 }
 
-extern "C" int gb_fps_row_order(const float *xyz, int32_t *perm, int b, int n, void *stream) {
+static int fps_row_order_impl(const float *xyz, int32_t *perm, int32_t *ws, int b, int n, void *stream) {
   using namespace gb;
   if (b < 0 || n < 1 || !xyz || !perm) return GB_EINVAL;
   if ((long long)n * 3 > 0x7fffffffLL) return GB_ERANGE;
-  if (n > SO_MAXN) return gb_fps_cell_order(xyz, perm, b, n, stream);  // the level-1 order no longer fits the LDS
+  const bool big = n > SO_MAXN;
+  if (big && (!ws || n > SO_MAXN_WS)) return gb_fps_cell_order(xyz, perm, b, n, stream);  // no room for the level-1 order
   if (b == 0) return GB_OK;
   const int nrow = (n + 63) / 64;
   int K = 1;
   while ((2 * K + 1) * (2 * K + 1) <= 4 * nrow) ++K;  // K = round(sqrt(nrow))
-  if (K > SO_MAXK) K = SO_MAXK;
-  const int lds = SO_MAXK * SO_BINS2 * (int)sizeof(int) + ((n + 1) / 2) * 4;
-  static std::atomic<unsigned long long> attr{0};
-  allow_dynamic_lds(fps_slab_order_kernel, SO_MAXK * SO_BINS2 * (int)sizeof(int) + SO_MAXN * 2, attr);
-  hipLaunchKernelGGL(fps_slab_order_kernel, dim3(b), dim3(1024), lds, as_stream(stream), xyz, perm, n, K);
+  const int kmax = big ? SO_MAXK_WS : SO_MAXK;
+  if (K > kmax) K = kmax;
+  if (big) {
+    const int lds = SO_MAXK_WS * SO_BINS2 * (int)sizeof(int);
+    static std::atomic<unsigned long long> attr{0};
+    allow_dynamic_lds(fps_slab_order_kernel<true>, lds, attr);
+    hipLaunchKernelGGL(fps_slab_order_kernel<true>, dim3(b), dim3(1024), lds, as_stream(stream), xyz, perm, ws, n, K);
+  } else {
+    const int lds = SO_MAXK * SO_BINS2 * (int)sizeof(int) + ((n + 1) / 2) * 4;
+    static std::atomic<unsigned long long> attr{0};
+    allow_dynamic_lds(fps_slab_order_kernel<false>, SO_MAXK * SO_BINS2 * (int)sizeof(int) + SO_MAXN * 2, attr);
+    hipLaunchKernelGGL(fps_slab_order_kernel<false>, dim3(b), dim3(1024), lds, as_stream(stream), xyz, perm, nullptr, n, K);
+  }
   return check_launch("gb_fps_row_order");
+}
+
+extern "C" int gb_fps_row_order(const float *xyz, int32_t *perm, int b, int n, void *stream) {
+  return fps_row_order_impl(xyz, perm, nullptr, b, n, stream);
+}
+
+extern "C" int gb_fps_row_order_ws(const float *xyz, int32_t *perm, int32_t *ws, int b, int n, void *stream) {
+  return fps_row_order_impl(xyz, perm, ws, b, n, stream);
 }
 
 #ifdef GB_FPS_STAMPS
@@ -1334,7 +1458,7 @@ extern "C" int gb_fps_pruned(const float *xyz, const int32_t *perm, float *temp,
                              unsigned flags, float *scratch, void *stream) {
   using namespace gb;
   if (b < 0 || n < 1 || m < 0 || !xyz || !perm || !idx) return GB_EINVAL;
-  if (n > 1024 * 63) return GB_ERANGE;  // 24 rows in registers + 39 in LDS
+  if (n > 1024 * 64 || (n > 1024 * 63 && (flags & GB_FPS_LAYOUT_MASK) == GB_FPS_LAYOUT_R4)) return GB_ERANGE;  // (round 4's kernel: 24 rows in registers + 39 in LDS)
   if (n > 1024 * 20 && (!scratch || reinterpret_cast<uintptr_t>(scratch) % 16 != 0)) return GB_EINVAL;
   if (b == 0 || m == 0) return GB_OK;
   const unsigned tie = flags & GB_FPS_TIE_MASK;
@@ -1357,7 +1481,7 @@ extern "C" int gb_fps_pruned(const float *xyz, const int32_t *perm, float *temp,
     constexpr int lds = WV * 64 * (A0 + A1 + A2) * 4;                                                          \
     allow_dynamic_lds(fps_rows_kernel<WV, A0, A1, A2>, lds, attr);                                             \
     hipLaunchKernelGGL((fps_rows_kernel<WV, A0, A1, A2>), dim3(b), dim3(WV * 64), lds, s, xyz, perm, temp, idx, n, m, \
-                       skip, bs_log2 GB_STAMP_ARG);                                                            \
+                       skip, bs_log2, (float4 *)nullptr GB_STAMP_ARG);                                         \
     return check_launch("gb_fps_pruned");                                                                      \
   }
     // measured on 4 x 20000 -> 2048 (tools/fps_bench.py, row order): 12 waves 1.33 ms, 8 waves 1.46, 16 waves 1.56,
@@ -1384,6 +1508,20 @@ extern "C" int gb_fps_pruned(const float *xyz, const int32_t *perm, float *temp,
   }
   GB_PR(4) GB_PR(8) GB_PR(12) GB_PR(16) GB_PR(20)
 #undef GB_PR
+  if (n > 1024 * 20 && layout != GB_FPS_LAYOUT_R4) {
+    // round 5: the same kernel with only the min-distances in registers (16 waves: the records of up to 64 rows per wave
+    // fill one set of lanes); coordinates and keys come from the sorted copy in `scratch`
+#define GB_ROWS_BIG(A0, A1, LRV)                                                                                    \
+  if (ceil_div(n, 1024) <= A0 + A1 + LRV) {                                                                      \
+    static std::atomic<unsigned long long> attr{0};                                                            \
+    allow_dynamic_lds(fps_rows_kernel<16, A0, A1, 0, true, LRV>, LRV * 1024 * 4, attr);                        \
+    hipLaunchKernelGGL((fps_rows_kernel<16, A0, A1, 0, true, LRV>), dim3(b), dim3(1024), LRV * 1024 * sizeof(float), s, \
+                       xyz, perm, temp, idx, n, m, skip, bs_log2, reinterpret_cast<float4 *>(scratch) GB_STAMP_ARG); \
+    return check_launch("gb_fps_pruned");                                                                      \
+  }
+    GB_ROWS_BIG(32, 0, 0) GB_ROWS_BIG(32, 16, 0) GB_ROWS_BIG(32, 16, 16)
+#undef GB_ROWS_BIG
+  }
 #define GB_PB(PV)                                                                                               \
   if (p_need <= PV) {                                                                                          \
     hipLaunchKernelGGL((fps_pruned_big_kernel<1024, PV, 24>), dim3(b), dim3(1024), 0, s, xyz, perm,                 \

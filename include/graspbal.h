@@ -99,6 +99,10 @@ int gb_fps_cell_order(const float *xyz, int32_t *perm, int b, int n, void *strea
  * launch; n > 24576 falls back to gb_fps_cell_order.  Not deterministic inside a bin; gb_fps_pruned's output does not
  * depend on the permutation.                                                                                 */
 int gb_fps_row_order(const float *xyz, int32_t *perm, int b, int n, void *stream);
+/* The same with a caller's workspace `ws` (b*n int32) for the level-1 order: clouds of 24577 .. 65536 points get the compact
+ * rows too (without `ws`, or beyond 65536 points: gb_fps_cell_order's order).  `ws` may be the `scratch` the following
+ * gb_fps_pruned call takes (it is dead by then).                                                                 */
+int gb_fps_row_order_ws(const float *xyz, int32_t *perm, int32_t *ws, int b, int n, void *stream);
 /* keys (b,n) int32: 30-bit Morton code of each point within its cloud's bounding box.                   */
 int gb_fps_morton_keys(const float *xyz, int32_t *keys, int b, int n, void *stream);
 /* Segmented FPS - the per-object sampling loop of ObjectBalanceSampling (TrainModel/modules.py:178-221, one

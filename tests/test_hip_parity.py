@@ -379,7 +379,7 @@ def test_fps_pruned_is_the_same_sequence(orc, tie, skip):
         want = orc.furthest_point_sampling(xyz, m, flags, temp=temp_o)
         # every way the library spreads a register-resident cloud over its CU (round 5: 4 / 8 / 12 / 16 waves with
         # run-time indexed row registers, and the round-4 kernel) returns the same samples; larger clouds have one form
-        layouts = _lib.FPS_LAYOUT.items() if N <= 20480 else [("auto", 0)]
+        layouts = _lib.FPS_LAYOUT.items() if N <= 20480 else [("auto", 0), ("r4", _lib.FPS_LAYOUT["r4"])]
         for name, perm in perms.items():
             for lname, layout in layouts:
                 idx = torch.full((B, m), -7, dtype=torch.int32, device=DEV)
@@ -568,20 +568,26 @@ def test_fps_row_order_is_a_permutation_with_compact_rows(orc):
     cases = [(torch.from_numpy(make_batch([30, 31, 32], 20000)), 300, True), (torch.from_numpy(make_batch([33], 777)), 128, False),
              (torch.from_numpy(make_batch([34, 35], 24576)), 100, True), (torch.zeros(2, 5000, 3) + 0.25, 64, False),
              (torch.rand(1, 50, 3, generator=torch.Generator().manual_seed(3)), 50, False), (torch.rand(1, 1, 3) + 1, 1, False),
-             (torch.from_numpy(make_batch([36], 50000)), 150, False)]   # > 24576 points: falls back to the cell order
-    for xyz, m, check_rows in cases:
+             (torch.from_numpy(make_batch([36], 50000)), 150, False),   # > 24576 points without a workspace: the cell order
+             (torch.from_numpy(make_batch([37, 38], 50000)), 150, True),  # ... with one (the sampling's scratch): compact rows
+             (torch.from_numpy(make_batch([39], 65536)), 130, True)]
+    for case, (xyz, m, check_rows) in enumerate(cases):
         xyz = xyz.clone()
         B, N = xyz.shape[:2]
         dev = xyz.to(DEV)
         perm = torch.full((B, N), -1, dtype=torch.int32, device=DEV)
-        _lib.check(_lib.lib().gb_fps_row_order(_lib.ptr(dev), _lib.ptr(perm), B, N, None), "row_order")
+        if N > 24576 and check_rows:
+            ws = torch.empty(B, N, 4, device=DEV)
+            _lib.check(_lib.lib().gb_fps_row_order_ws(_lib.ptr(dev), _lib.ptr(perm), _lib.ptr(ws), B, N, None), "row_order_ws")
+        else:
+            _lib.check(_lib.lib().gb_fps_row_order(_lib.ptr(dev), _lib.ptr(perm), B, N, None), "row_order")
         torch.cuda.synchronize()
         p = perm.cpu().long()
         assert torch.equal(torch.sort(p, dim=1)[0], torch.arange(N).repeat(B, 1)), N
         walked = torch.gather(xyz, 1, p[:, :, None].expand(-1, -1, 3))
         if check_rows:
             nrow = (N + 63) // 64
-            K = int(round(nrow ** 0.5))
+            K = min(int(round(nrow ** 0.5)), 32 if N > 24576 else 20)
             ext = xyz.max(1)[0] - xyz.min(1)[0]
             for b in range(B):
                 a1 = int(ext[b].argmax())
@@ -605,7 +611,8 @@ def test_fps_row_order_is_a_permutation_with_compact_rows(orc):
             def diag_sum(pp):
                 w = torch.gather(xyz, 1, pp.cpu().long()[:, :, None].expand(-1, -1, 3))[:, :N // 64 * 64].view(B, -1, 64, 3)
                 return float((w.max(2)[0] - w.min(2)[0]).norm(dim=-1).sum())
-            assert diag_sum(perm) < 0.7 * diag_sum(pc), (diag_sum(perm), diag_sum(pc))
+            # (20 000 points: 0.57; at 50 000+ the 32^3 cells are finer relative to a row and the margin is smaller: 0.80)
+            assert diag_sum(perm) < (0.7 if N <= 24576 else 0.9) * diag_sum(pc), (diag_sum(perm), diag_sum(pc))
         flags = _lib.FPS_TIE_TREE512 | _lib.FPS_SKIP_NEAR_ORIGIN
         idx = torch.zeros(B, m, dtype=torch.int32, device=DEV)
         scratch = torch.empty(B, N, 4, device=DEV) if N > 20480 else None

@@ -25,16 +25,18 @@ print("morton keys            %8.1f us" % timeit(lambda: L.gb_fps_morton_keys(_l
 print("argsort + int32        %8.1f us" % timeit(lambda: torch.argsort(keys, dim=1).to(torch.int32)))
 perm = torch.argsort(keys, dim=1).to(torch.int32)
 for lname, layout in _lib.FPS_LAYOUT.items():
-    if N > 20480 and lname != "auto":
+    if N > 20480 and lname not in ("auto", "r4"):
         continue
-    for oname, fn in (("cell", L.gb_fps_cell_order), ("rows", L.gb_fps_row_order)):
+    wsb = torch.empty(B, N, 4, device="cuda")
+    for oname, fn in (("cell", L.gb_fps_cell_order), ("rows", lambda x, p, b, n, st: L.gb_fps_row_order_ws(x, p, _lib.ptr(wsb), b, n, st))):
         pc = torch.empty(B, N, dtype=torch.int32, device="cuda")
         fn(_lib.ptr(xyz), _lib.ptr(pc), B, N, None)
         t = timeit(lambda: L.gb_fps_pruned(_lib.ptr(xyz), _lib.ptr(pc), None, _lib.ptr(idx), B, N, m, flags | layout, _lib.ptr(scratch), None))
         assert torch.equal(idx, ref), (lname, oname)
         print("gb_fps_pruned %-5s order %-5s %8.1f us  = %.3f us/iteration" % (lname, oname, t, t / max(m - 1, 1)))
 print("cell order             %8.1f us" % timeit(lambda: L.gb_fps_cell_order(_lib.ptr(xyz), _lib.ptr(keys), B, N, None)))
-print("row order              %8.1f us" % timeit(lambda: L.gb_fps_row_order(_lib.ptr(xyz), _lib.ptr(keys), B, N, None)))
+wsb = torch.empty(B, N, 4, device="cuda")
+print("row order              %8.1f us" % timeit(lambda: L.gb_fps_row_order_ws(_lib.ptr(xyz), _lib.ptr(keys), _lib.ptr(wsb), B, N, None)))
 print("gb_fps_pruned (morton) %8.1f us" % timeit(lambda: L.gb_fps_pruned(_lib.ptr(xyz), _lib.ptr(perm), None, _lib.ptr(idx), B, N, m, flags, _lib.ptr(scratch), None)))
 assert torch.equal(idx, ref)
 ident = torch.arange(N, device="cuda", dtype=torch.int32).repeat(B, 1).contiguous()

@@ -521,16 +521,16 @@ static int gemm_fwd_impl(const float *x, const float *w, const float *aff, const
                   opts_rows(opts)))
     return finalize_after(check_launch("gb_gemm_fwd"), fin, stats, stat_slots, N, stream);
   if (opts_rows(opts)) return GB_EINVAL;  // a device-side row count: row-streaming kernel only
-  if (!bf16 && !(row_w16 && stats) && !opts_no_ring(opts)) {
+  if (!(row_w16 && stats) && !opts_no_ring(opts)) {
     // few-row products: the LDS-DMA ring kernel (csrc/gemm_ring.hip); a long reduction with few output tiles is split
     // over workgroups into the caller's workspace and closed by the same ordered reduce + column-sum pass as below
     RingPlan plan;
     const long long fit = (opts && opts->scratch && P > 0) ? (long long)(opts->scratch_bytes / sizeof(float)) / (P * N) : 1;
-    ring_plan(P, N, K, fit > 1, fit, &plan);
+    ring_plan(P, N, K, fit > 1, fit, &plan, 0, bf16);
     if (plan.chunks > 1) {
       float *part = static_cast<float *>(opts->scratch);
       if (ring_gemm_try(RING_FWD, x, w, aff, part, P, K, N, nullptr, 1, nullptr, nullptr, plan, (long long)P * N,
-                        as_stream(stream))) {
+                        as_stream(stream), bf16)) {
         int rc = check_launch("gb_gemm_fwd");
         if (rc != GB_OK) return rc;
         if (stats && N % 4 == 0 && aligned16(part) && aligned16(y) && (long long)P * N % 4 == 0)
@@ -540,7 +540,7 @@ static int gemm_fwd_impl(const float *x, const float *w, const float *aff, const
         return gb_col_stats(y, P, N, stats, fin, stream);
       }
     } else if (ring_gemm_try(RING_FWD, x, w, aff, y, P, K, N, stats, stat_slots, nullptr, nullptr, plan, 0,
-                             as_stream(stream))) {
+                             as_stream(stream), bf16)) {
       return finalize_after(check_launch("gb_gemm_fwd"), fin, stats, stat_slots, N, stream);
     }
   }
@@ -688,14 +688,14 @@ extern "C" int gb_gemm_dgrad(const float *dy, const float *w, float *dx, const f
                   as_stream(stream), bf16, opts_reserved(opts), nullptr, nullptr, nullptr, opts_rows(opts)))
     return done(check_launch("gb_gemm_dgrad"));
   if (opts_rows(opts)) return GB_EINVAL;  // a device-side row count: row-streaming kernel only
-  if (!bf16 && !opts_no_ring(opts)) {
+  if (!opts_no_ring(opts)) {
     RingPlan plan;
     const long long fit = (opts && opts->scratch && P > 0) ? (long long)(opts->scratch_bytes / sizeof(float)) / (P * K) : 1;
-    ring_plan(P, K, N, fit > 1, fit, &plan);
+    ring_plan(P, K, N, fit > 1, fit, &plan, 0, bf16);
     if (plan.chunks > 1) {
       float *part = static_cast<float *>(opts->scratch);
       if (ring_gemm_try(RING_DGRAD, dy, w, nullptr, part, P, K, N, nullptr, 1, nullptr, nullptr, plan, (long long)P * K,
-                        as_stream(stream))) {
+                        as_stream(stream), bf16)) {
         int rc = check_launch("gb_gemm_dgrad");
         if (rc != GB_OK) return rc;
         if (dstats && K % 4 == 0 && aligned16(part) && aligned16(dx) && aligned16(y_prev))
@@ -705,7 +705,7 @@ extern "C" int gb_gemm_dgrad(const float *dy, const float *w, float *dx, const f
         return done(gb_bn_bwd_stats(dx, y_prev, ab_prev, nullptr, P, K, 1, dstats, nullptr, nullptr, stream));
       }
     } else if (ring_gemm_try(RING_DGRAD, dy, w, nullptr, dx, P, K, N, dstats, stat_slots, y_prev, ab_prev, plan, 0,
-                             as_stream(stream))) {
+                             as_stream(stream), bf16)) {
       return done(check_launch("gb_gemm_dgrad"));
     }
   }
@@ -755,11 +755,12 @@ extern "C" int gb_gemm_wgrad(const float *dy, const float *x, const float *x_aff
     else hipLaunchKernelGGL(wgrad_smallk_kernel<4>, grid, dim3(GTPB), 0, as_stream(stream), dy, x, dw, P, N);
     return check_launch("gb_gemm_wgrad");
   }
-  if (!opts_bf16(opts) && !opts_rows(opts) && !opts_no_ring(opts) && P <= 131072) {
+  if (!opts_rows(opts) && !opts_no_ring(opts) && P <= 131072) {
     // few-row products: split the P reduction for ~one round of workgroups (fp32 atomics into dW, as below)
     RingPlan plan;
-    ring_plan(N, K, P, true, 65535, &plan, 1);
-    if (ring_gemm_try(RING_WGRAD, dy, x, x_aff, dw, P, K, N, nullptr, 1, nullptr, nullptr, plan, 0, as_stream(stream)))
+    ring_plan(N, K, P, true, 65535, &plan, 1, opts_bf16(opts));
+    if (ring_gemm_try(RING_WGRAD, dy, x, x_aff, dw, P, K, N, nullptr, 1, nullptr, nullptr, plan, 0, as_stream(stream),
+                      opts_bf16(opts)))
       return check_launch("gb_gemm_wgrad");
   }
   Operand a = {dy, N, P, N, nullptr};  // tile rows = n, reduction = p, element (n,p) at dy[p*N + n]

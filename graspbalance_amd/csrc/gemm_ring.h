@@ -19,15 +19,16 @@ struct RingPlan {
 
 // tile / split choice for an M x N output with reduction length `red`
 void ring_plan(long long M, long long N, long long red, bool want_split, long long max_chunks, RingPlan *plan,
-               int atomics = 0);
+               int atomics = 0, bool bf16 = false);
 
 // kind RING_FWD  : d (P,N) = f(a (P,K)) b (N,K)^T, aff = [a(K), b(K)] or NULL; stats: BatchNorm column sums of d
 //      RING_DGRAD: d (P,K) = a (P,N) b (N,K);  stats (with epi_y, epi_ab): the previous layer's BatchNorm-backward sums
 //      RING_WGRAD: d (N,K) += a (P,N)^T f(b (P,K)), aff = [a(K), b(K)] or NULL (fp32 atomics; plan.chunks splits P)
 // dchunk != 0 (FWD / DGRAD with plan.chunks > 1): chunk c stores its partial product at d + c * dchunk.
+// bf16: operands rounded to bf16 in registers, v_mfma_f32_32x32x16_bf16, fp32 accumulation (GbGemmOpts.precision).
 // Returns false (nothing launched) when the shape / alignment does not suit the kernel.
 bool ring_gemm_try(int kind, const float *a, const float *b, const float *aff, float *d, long long P, int K, int N,
                    double *stats, int stat_slots, const float *epi_y, const float *epi_ab, const RingPlan &plan,
-                   long long dchunk, hipStream_t s);
+                   long long dchunk, hipStream_t s, bool bf16 = false);
 
 }  // namespace gb

@@ -114,7 +114,10 @@ __device__ __forceinline__ void rg_glds16(const float *src, float *lds_dst) {
 
 // KA / KB: RK_KC or RK_RC.  BM x BN block tile, 4 waves as 2 x 2, each (BM/2) x (BN/2) = MT x NT MFMA tiles of 32 x 32.
 // AFFA: operand A (RK_KC) carries a.aff by reduction index; AFFB: operand B (RK_RC) carries b.aff by tile-row index.
-template <int KA, int KB, int BM, int BN, int EPI, bool AFFA, bool AFFB>
+// BF (GbGemmOpts.precision = GB_PREC_BF16, round 5): the fragments - fp32 in LDS as ever - are rounded to bf16 in registers
+// (after the operand prologue) and two reduction groups of four feed one v_mfma_f32_32x32x16_bf16: 2 matrix instructions
+// per 32-deep step and tile pair instead of 16, fp32 accumulation, same epilogues.
+template <int KA, int KB, int BM, int BN, int EPI, bool AFFA, bool AFFB, bool BF = false>
 __global__ __launch_bounds__(RG_TPB, (BM == 128 && BN == 128) ? 1 : 2) void gemm_ring_kernel(RingArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // ALL LDS of the kernel (a second object would make
                                                                  // the compiler drain the DMA ring before every read)
@@ -274,6 +277,50 @@ __global__ __launch_bounds__(RG_TPB, (BM == 128 && BN == 128) ? 1 : 2) void gemm
     }
   };
   constexpr int READS = (KA == RK_KC ? MT + (AFFA ? 2 : 0) : 4 * MT) + (KB == RK_KC ? NT : 4 * NT);   // per group
+  auto prologue_group = [&](Frag &f) {
+    if constexpr (AFFA) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float z = f.ta[e] * f.a[i][e] + f.tb[e];
+          f.a[i][e] = z > 0.f ? z : 0.f;
+        }
+    }
+    if constexpr (AFFB) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float z = fa_b[j] * f.b[j][e] + fb_b[j];
+          f.b[j][e] = z > 0.f ? z : 0.f;
+        }
+    }
+  };
+  // BF: groups (lo, hi) = reduction sub-slots 0..3 and 4..7 of this lane half in one bf16 instruction (any assignment is
+  // legal as long as both operands use it)
+  auto mfma_pair_bf16 = [&](Frag &lo, Frag &hi, bool dma, int slot, int part) {
+    prologue_group(lo);
+    prologue_group(hi);
+    bf16x8 a8[MT], b8[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a8[i][e] = (__bf16)lo.a[i][e]; a8[i][4 + e] = (__bf16)hi.a[i][e]; }
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { b8[j][e] = (__bf16)lo.b[j][e]; b8[j][4 + e] = (__bf16)hi.b[j][e]; }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8[j], acc[i][j], 0, 0, 0);
+    if (dma) {
+      issue_part(slot, part, 4);
+      issue_part(slot, part + 1, 4);
+    }
+  };
   auto mfma_group = [&](Frag &f, bool dma, int slot, int part) {
     if constexpr (AFFA) {
 #pragma unroll
@@ -359,6 +406,20 @@ __global__ __launch_bounds__(RG_TPB, (BM == 128 && BN == 128) ? 1 : 2) void gemm
     const int kk = step * RG_BK;   // offset of this step inside the chunk (table index)
     // two fragment sets: the reads of group cq+1 are in flight under the MFMAs of group cq
     Frag f0, f1;
+    if constexpr (BF) {
+      Frag f2, f3;
+      read_group(f0, sbase, 0, kk);
+      read_group(f1, sbase, 1, kk);
+      read_group(f2, sbase, 2, kk);
+      read_group(f3, sbase, 3, kk);
+      rg_wait_lgkm<2 * READS>();      // groups 0 and 1 have arrived (LDS operations retire in order)
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_pair_bf16(f0, f1, dma, nslot, 0);
+      rg_wait_lgkm<0>();              // every read of this stage has retired before the next barrier
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_pair_bf16(f2, f3, dma, nslot, 2);
+      continue;
+    }
     read_group(f0, sbase, 0, kk);
     read_group(f1, sbase, 1, kk);
     rg_wait_lgkm<READS>();            // group 0 has arrived (LDS operations retire in order)
@@ -434,10 +495,10 @@ __global__ __launch_bounds__(RG_TPB, (BM == 128 && BN == 128) ? 1 : 2) void gemm
 
 static inline bool rg_aligned16(const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
 
-template <int KA, int KB, int BM, int BN, int EPI, bool AFFA, bool AFFB>
+template <int KA, int KB, int BM, int BN, int EPI, bool AFFA, bool AFFB, bool BF>
 static void rg_launch(const RingArgs &g, long long tiles_m, unsigned chunks, hipStream_t s) {
   static std::atomic<unsigned long long> attr_set{0};
-  auto kern = gemm_ring_kernel<KA, KB, BM, BN, EPI, AFFA, AFFB>;
+  auto kern = gemm_ring_kernel<KA, KB, BM, BN, EPI, AFFA, AFFB, BF>;
   allow_dynamic_lds(kern, 160 * 1024, attr_set);
   size_t lds = (size_t)RG_STAGES * (BM + BN) * RG_BK * sizeof(float);
   if (AFFA) lds += 2 * (size_t)((g.kchunk + 255) / 256 * 256) * sizeof(float);
@@ -446,13 +507,15 @@ static void rg_launch(const RingArgs &g, long long tiles_m, unsigned chunks, hip
 }
 
 template <int KA, int KB, int EPI, bool AFFA, bool AFFB>
-static void rg_launch_tile(RingArgs &g, bool big, unsigned chunks, hipStream_t s) {
+static void rg_launch_tile(RingArgs &g, bool big, unsigned chunks, hipStream_t s, bool bf16) {
   if (big) {
     g.tiles_n = (int)((g.b.rows + 127) / 128);
-    rg_launch<KA, KB, 128, 128, EPI, AFFA, AFFB>(g, (g.a.rows + 127) / 128, chunks, s);
+    if (bf16) rg_launch<KA, KB, 128, 128, EPI, AFFA, AFFB, true>(g, (g.a.rows + 127) / 128, chunks, s);
+    else rg_launch<KA, KB, 128, 128, EPI, AFFA, AFFB, false>(g, (g.a.rows + 127) / 128, chunks, s);
   } else {
     g.tiles_n = (int)((g.b.rows + 63) / 64);
-    rg_launch<KA, KB, 64, 64, EPI, AFFA, AFFB>(g, (g.a.rows + 63) / 64, chunks, s);
+    if (bf16) rg_launch<KA, KB, 64, 64, EPI, AFFA, AFFB, true>(g, (g.a.rows + 63) / 64, chunks, s);
+    else rg_launch<KA, KB, 64, 64, EPI, AFFA, AFFB, false>(g, (g.a.rows + 63) / 64, chunks, s);
   }
 }
 
@@ -462,7 +525,12 @@ static void rg_launch_tile(RingArgs &g, bool big, unsigned chunks, hipStream_t s
 // 16 for a 64 x 64 tile (two per CU, sharing the matrix pipes).  Splitting the reduction buys more workgroups at the price
 // of a closing pass (forward / dgrad: partial products through the caller's workspace, `pass_bytes` per chunk and
 // `pass_us` for the extra launch) or of more atomics (wgrad: 1.3 TB/s of float atomics).
-void ring_plan(long long M, long long N, long long red, bool want_split, long long max_chunks, RingPlan *p, int atomics) {
+void ring_plan(long long M, long long N, long long red, bool want_split, long long max_chunks, RingPlan *p, int atomics,
+               bool bf16) {
+  // (bf16: 2 matrix instructions per step and tile pair instead of 16, yet the same plans are the best ones - scaling the
+  // step costs by 0.5 / 0.25 for bf16 moved configs[4] by nothing, 23.86 - 23.94 ms: the few-row products are bound by
+  // what a workgroup waits for, not by its matrix instructions)
+  (void)bf16;
   const double FIXED = 5.0, STEP_BIG = 1.95, STEP_SMALL = 0.49, CUS = 256.0;
   double best = 1e30;
   p->big = false; p->chunks = 1; p->kchunk = red;
@@ -494,7 +562,7 @@ void ring_plan(long long M, long long N, long long red, bool want_split, long lo
 
 bool ring_gemm_try(int kind, const float *a, const float *b, const float *aff, float *d, long long P, int K, int N,
                    double *stats, int stat_slots, const float *epi_y, const float *epi_ab, const RingPlan &plan,
-                   long long dchunk, hipStream_t s) {
+                   long long dchunk, hipStream_t s, bool bf16) {
   RingArgs g = {};
   g.d = d;
   g.stats = stats;
@@ -517,8 +585,8 @@ bool ring_gemm_try(int kind, const float *a, const float *b, const float *aff, f
     if (chunks > 1 && (stats || !dchunk)) return false;   // partial products carry no statistics
 #define GB_RF(EPI_)                                                                                   \
     do {                                                                                              \
-      if (aff) rg_launch_tile<RK_KC, RK_KC, EPI_, true, false>(g, plan.big, chunks, s);               \
-      else rg_launch_tile<RK_KC, RK_KC, EPI_, false, false>(g, plan.big, chunks, s);                  \
+      if (aff) rg_launch_tile<RK_KC, RK_KC, EPI_, true, false>(g, plan.big, chunks, s, bf16);               \
+      else rg_launch_tile<RK_KC, RK_KC, EPI_, false, false>(g, plan.big, chunks, s, bf16);                  \
     } while (0)
     if (stats) GB_RF(RG_STATS); else GB_RF(RG_STORE);
 #undef GB_RF
@@ -532,8 +600,8 @@ bool ring_gemm_try(int kind, const float *a, const float *b, const float *aff, f
     g.ldd = K;
     g.red = N;
     if (chunks > 1 && (stats || !dchunk)) return false;
-    if (stats) rg_launch_tile<RK_KC, RK_RC, RG_BNBWD, false, false>(g, plan.big, chunks, s);
-    else rg_launch_tile<RK_KC, RK_RC, RG_STORE, false, false>(g, plan.big, chunks, s);
+    if (stats) rg_launch_tile<RK_KC, RK_RC, RG_BNBWD, false, false>(g, plan.big, chunks, s, bf16);
+    else rg_launch_tile<RK_KC, RK_RC, RG_STORE, false, false>(g, plan.big, chunks, s, bf16);
     return true;
   }
   if (kind == RING_WGRAD) {
@@ -543,8 +611,8 @@ bool ring_gemm_try(int kind, const float *a, const float *b, const float *aff, f
     g.b = {b, K, K, aff};
     g.ldd = K;
     g.red = P;
-    if (aff) rg_launch_tile<RK_RC, RK_RC, RG_ATOMIC, false, true>(g, plan.big, chunks, s);
-    else rg_launch_tile<RK_RC, RK_RC, RG_ATOMIC, false, false>(g, plan.big, chunks, s);
+    if (aff) rg_launch_tile<RK_RC, RK_RC, RG_ATOMIC, false, true>(g, plan.big, chunks, s, bf16);
+    else rg_launch_tile<RK_RC, RK_RC, RG_ATOMIC, false, false>(g, plan.big, chunks, s, bf16);
     return true;
   }
   return false;

@@ -348,7 +348,7 @@ def _gemm_meta(kind, P, K, N, fused=False, aff=False, rows_dev=None):
     which = _lib.lib().gb_gemm_kernel_for({"fwd": 0, "dgrad": 1, "wgrad": 2}[kind], cap, K, N, int(fused), int(aff))
     if rows_dev is not None and kind != "wgrad":
         which = 1      # a device-side row count: the row-streaming kernel whatever the capacity
-    if which == 2 and (_GEMM_FLAGS & _lib.GEMM_NO_RING or _prec() != _lib.PREC_F32 or rows_dev is not None):
+    if which == 2 and (_GEMM_FLAGS & _lib.GEMM_NO_RING or rows_dev is not None):   # (round 5: the ring kernel has a bf16 form)
         which = 0
     kernel = ("gemm_cl_kernel", "gemm_rs_kernel", "gemm_ring_kernel", "wgrad_smallk_kernel")[which]
     return {"flop": 2.0 * P * K * N, "pkn": (P, K, N), "kernel": kernel}

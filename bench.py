@@ -110,7 +110,7 @@ def fps_algorithmic_bytes(b, n, m):
 
 
 KERNEL_SOURCES = {"gemm_rs_kernel": ("gemm_rs.hip", "gemm_rs.h"), "gemm_ring_kernel": ("gemm_ring.hip", "gemm_ring.h"),
-                  "gemm_cl_kernel": ("gemm_cl.hip",), "fps_rows_kernel": ("fps.hip",), "fps_pruned_kernel": ("fps.hip",),
+                  "gemm_cl_kernel": ("gemm_cl.hip",), "wgrad_direct_kernel": ("gemm_wg.hip", "gemm_wg.h"), "fps_rows_kernel": ("fps.hip",), "fps_pruned_kernel": ("fps.hip",),
                   "fps_reg_kernel<1024, 20>": ("fps.hip",)}
 PMC_FILE = "r05_pmc_traffic.json"
 
@@ -538,7 +538,7 @@ def main():
     # events on its stream (the brackets cost ~2 us per launch, and a replayed graph cannot be bracketed at all): AFTER the
     # timed region, same trainer, same resident batch, same kernels
     gemm_names = ["gb_gemm_fwd", "gb_gemm_fwd_w", "gb_gemm_fwd_pool", "gb_gemm_fwd_gen3", "gb_gemm_dgrad", "gb_gemm_dgrad_first",
-                  "gb_gemm_dgrad_first_gen3", "gb_gemm_wgrad", "gb_gemm_wgrad_gen3"]
+                  "gb_gemm_dgrad_first_gen3", "gb_gemm_wgrad", "gb_gemm_wgrad_gen3", "gb_gemm_dgrad_wgrad"]
     # GB_BENCH_TIMED_ONLY=1 (profiling runs: tools/refresh_profiles.sh): nothing but warm-up and the timed replays, so that
     # a kernel trace's last steps ARE the timed ones
     timed_only = os.environ.get("GB_BENCH_TIMED_ONLY") == "1"
@@ -658,10 +658,12 @@ def main():
         rl_cl = gemm_roofline("gemm_cl_kernel", "register-staged LDS tiles: tall split-K wgrad, unaligned shapes")
         rl_rs = gemm_roofline("gemm_rs_kernel", "row-streaming: tall fwd+BN-stats and dgrad+BN-backward sums")
         rl_ring = gemm_roofline("gemm_ring_kernel", "LDS-DMA ring: the few-row fwd / dgrad / wgrad products")
-        both = sorted([r for r in (rl_cl, rl_rs, rl_ring) if r], key=lambda r: -r["ms_per_step"])
+        rl_wg = gemm_roofline("wgrad_direct_kernel", "register-direct: the tall wgrads, operands straight from HBM into the matrix cores")
+        both = sorted([r for r in (rl_cl, rl_rs, rl_ring, rl_wg) if r], key=lambda r: -r["ms_per_step"])
         roofline = both[0] if both else None
         roofline_second = both[1] if len(both) > 1 else None
         roofline_third = both[2] if len(both) > 2 else None
+        roofline_fourth = both[3] if len(both) > 3 else None
         # largest single launch of the step: the first-level FPS (HBM class, streaming-model bytes)
         roofline_fps = None
         fps_ms = 0.0
@@ -752,6 +754,7 @@ def main():
             "roofline": roofline,
             "roofline_gemm2": roofline_second,
             "roofline_gemm3": roofline_third,
+            "roofline_gemm4": roofline_fourth,
             "event_bias_us": round(ev_bias * 1e3, 2),
             "event_sampled_steps": sampled,
             "roofline_fps": roofline_fps,
@@ -776,7 +779,7 @@ def main():
             "max_memory_allocated_gb": peak_mem_gb,
             "cpu_affinity": affinity,
         }
-        for r in (out["roofline"], out["roofline_gemm2"], out["roofline_gemm3"], out["roofline_fps"], out["roofline_ball"], out["roofline_fps_ball"],
+        for r in (out["roofline"], out["roofline_gemm2"], out["roofline_gemm3"], out["roofline_gemm4"], out["roofline_fps"], out["roofline_ball"], out["roofline_fps_ball"],
                   out["roofline_cyl"]):
             if r:
                 r["measured_on"] = ("%d eager steps of the same trainer right after the timed region (HIP events around every "

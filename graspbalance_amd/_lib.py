@@ -89,6 +89,7 @@ SIGNATURES = {
     "gb_gemm_fwd": [_P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P, _P],
     "gb_gemm_dgrad": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P, _P, _P, _P],
     "gb_gemm_wgrad": [_P, _P, _P, _P, _L, _I, _I, _P, _P],
+    "gb_gemm_dgrad_wgrad": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "gb_gemm_uses_rs": [_L, _I, _I, _I, _I, _I],
     "gb_gemm_kernel_for": [_I, _L, _I, _I, _I, _I],
     "gb_gemm_dgrad_first": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P],
@@ -160,6 +161,8 @@ class GemmOpts(_c.Structure):
 
 PREC_F32, PREC_BF16 = 0, 1
 GEMM_NO_RING = 1   # GbGemmOpts.flags
+GEMM_NO_PAIR = 2
+GEMM_NO_DIRECT = 4
 GEMM_SCRATCH_BYTES = 320 * 64 * 128 * 4
 
 

@@ -128,7 +128,8 @@ inline bool opts_no_ring(const GbGemmOpts *o) { return o && (o->flags & GB_GEMM_
 inline bool opts_bad(const GbGemmOpts *o) {
   return o && ((o->precision != GB_PREC_F32 && o->precision != GB_PREC_BF16) || o->reserved_cus < 0 ||
                o->reserved_cus > 128 || (o->scratch && reinterpret_cast<uintptr_t>(o->scratch) % 16 != 0) ||
-               (o->rows_dev && reinterpret_cast<uintptr_t>(o->rows_dev) % 8 != 0) || (o->flags & ~GB_GEMM_NO_RING));
+               (o->rows_dev && reinterpret_cast<uintptr_t>(o->rows_dev) % 8 != 0) ||
+               (o->flags & ~(GB_GEMM_NO_RING | GB_GEMM_NO_PAIR | GB_GEMM_NO_DIRECT)));
 }
 
 struct __attribute__((packed, aligned(4))) f3 {

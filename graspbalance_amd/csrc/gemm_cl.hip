@@ -22,6 +22,7 @@
 #include "gb_common.h"
 #include "gemm_rs.h"
 #include "gemm_ring.h"
+#include "gemm_wg.h"
 
 namespace gb {
 
@@ -504,6 +505,11 @@ static int finalize_after(int rc, const GbBnFinalize *fin, const double *stats, 
 // 17.60 ms; configs[4] 25.83 / 25.65).  Products that NEED that kernel - a device-side row count, the generated first-layer
 // operand, the pooled epilogue - go there from 16 384 rows as before (rs_shape_ok).
 static constexpr long long RS_PAYS_FROM = 65536;
+// the register-direct wgrad (csrc/gemm_wg.hip): fp32, from WG_PAYS_FROM rows (or a device-side row count)
+constexpr long long WG_PAYS_FROM = 65536;
+static bool wg_pays(long long P, const GbGemmOpts *opts) {
+  return !opts_bf16(opts) && !(opts && (opts->flags & GB_GEMM_NO_DIRECT)) && (P >= WG_PAYS_FROM || opts_rows(opts) != nullptr);
+}
 static bool rs_pays(long long P, const GbGemmOpts *opts) { return P >= RS_PAYS_FROM || opts_rows(opts) != nullptr; }
 
 static int gemm_fwd_impl(const float *x, const float *w, const float *aff, const uint16_t *row_w16, float *y,
@@ -645,6 +651,9 @@ extern "C" int gb_gemm_wgrad_gen3(const float *dy, const float *x0, const float 
                                   long long P, int K, int N, const GbGemmOpts *opts, void *stream) {
   if (P < 0 || K < 1 || N < 1 || !dy || !x0 || !w1 || !ab1 || !dw || opts_bad(opts)) return GB_EINVAL;
   if (P == 0) return GB_OK;
+  if (wg_pays(P, opts) && wg_wgrad_try(dy, nullptr, ab1, x0, w1, dw, P, K, N, opts_rows(opts), opts_reserved(opts),
+                                       as_stream(stream)))
+    return check_launch("gb_gemm_wgrad_gen3");
   Operand a = {dy, N, P, N, nullptr, nullptr, nullptr};
   Operand b = {nullptr, K, P, K, ab1, x0, w1};
   const long long tiles = (long long)((N + (N <= 64 ? 63 : 127)) / (N <= 64 ? 64 : 128)) *
@@ -755,6 +764,10 @@ extern "C" int gb_gemm_wgrad(const float *dy, const float *x, const float *x_aff
     else hipLaunchKernelGGL(wgrad_smallk_kernel<4>, grid, dim3(GTPB), 0, as_stream(stream), dy, x, dw, P, N);
     return check_launch("gb_gemm_wgrad");
   }
+  // many rows: both operands straight from global memory into the matrix cores (csrc/gemm_wg.hip)
+  if (wg_pays(P, opts) && wg_wgrad_try(dy, x, x_aff, nullptr, nullptr, dw, P, K, N, opts_rows(opts), opts_reserved(opts),
+                                       as_stream(stream)))
+    return check_launch("gb_gemm_wgrad");
   if (!opts_rows(opts) && !opts_no_ring(opts) && P <= 131072) {
     // few-row products: split the P reduction for ~one round of workgroups (fp32 atomics into dW, as below)
     RingPlan plan;
@@ -880,13 +893,54 @@ extern "C" int gb_moments3(const float *x, const float *row_w, long long P, doub
   return check_launch("gb_moments3");
 }
 
+// Both gradient products of a layer as one launch of the ring kernel: each alone would run unsplit on 64 x 64 tiles
+// (what the pair kernel gives them; the wgrad's reduction split is the pair kernel's own)
+static bool pair_shape(long long P, int K, int N, long long fit, bool bf16) {
+  if (K <= 4 || P > 131072 || P / 64 * ((K + 63) / 64) > 0x7fffffffLL) return false;
+  if (N % 32 != 0 || P % 32 != 0 || K % 4 != 0 || N % 4 != 0 || P < 64) return false;
+  RingPlan pd, pw;
+  ring_plan(P, K, N, fit > 1, fit, &pd, 0, bf16);
+  ring_plan(N, K, P, true, 65535, &pw, 1, bf16);
+  return !pd.big && pd.chunks == 1 && !pw.big && pw.kchunk % 32 == 0 && pw.chunks >= 1;
+}
+
+// gb_gemm_dgrad + gb_gemm_wgrad of ONE layer (they read the same dY and nothing of each other).  Where both are few-row
+// products of the ring kernel they leave as ONE launch (csrc/gemm_ring.hip, gemm_ring_pair_kernel: the two grids resident
+// together); otherwise exactly the two single calls, wgrad first.  Arguments as of the single entries.
+extern "C" int gb_gemm_dgrad_wgrad(const float *dy, const float *w, float *dx, const float *y_prev, const float *ab_prev,
+                                   double *dstats, int stat_slots, long long P, int K, int N, double *dstats_total,
+                                   float *dbeta, float *dgamma, const float *x, const float *x_aff, float *dw,
+                                   const GbGemmOpts *opts, void *stream) {
+  if (P < 0 || K < 1 || N < 1 || !dy || !w || !dx || !x || !dw || opts_bad(opts)) return GB_EINVAL;
+  if (dstats && (!y_prev || !ab_prev || stat_slots < 1)) return GB_EINVAL;
+  if ((!dbeta != !dgamma) || (dbeta && !dstats)) return GB_EINVAL;
+  if (P == 0) return GB_OK;
+  const long long fit = (opts && opts->scratch) ? (long long)(opts->scratch_bytes / sizeof(float)) / (P * K) : 1;
+  const bool pairable = !opts_rows(opts) && !opts_no_ring(opts) && !(opts && (opts->flags & GB_GEMM_NO_PAIR)) &&
+                        !rs_pays(P, opts) && !wg_pays(P, opts) && pair_shape(P, K, N, fit, opts_bf16(opts));
+  if (pairable && ring_pair_try(dy, w, dx, dstats, stat_slots, y_prev, ab_prev, x, x_aff, dw, P, K, N, as_stream(stream),
+                                opts_bf16(opts))) {
+    const int rc = check_launch("gb_gemm_dgrad_wgrad");
+    if (rc != GB_OK || !dbeta) return rc;
+    return gb_bn_bwd_reduce(dstats, stat_slots, K, stat_slots > 1 ? dstats_total : nullptr, dbeta, dgamma, stream);
+  }
+  const int rc = gb_gemm_wgrad(dy, x, x_aff, dw, P, K, N, opts, stream);
+  if (rc != GB_OK) return rc;
+  return gb_gemm_dgrad(dy, w, dx, y_prev, ab_prev, dstats, stat_slots, P, K, N, dstats_total, dbeta, dgamma, opts, stream);
+}
+
 // Which kernel a gb_gemm_fwd (kind 0) / gb_gemm_dgrad (1) / gb_gemm_wgrad (2) call of this shape launches for 16-byte
 // aligned fp32 operands and default options: 0 = the register-staged tiles of this file, 1 = the row-streaming kernel
-// (csrc/gemm_rs.hip), 2 = the LDS-DMA ring kernel (csrc/gemm_ring.hip), 3 = the column-reduction wgrad.  Pure host-side
+// (csrc/gemm_rs.hip), 2 = the LDS-DMA ring kernel (csrc/gemm_ring.hip), 3 = the column-reduction wgrad, 4 = the
+// register-direct tall wgrad (csrc/gemm_wg.hip).  Pure host-side
 // introspection (no launch), used by bench.py to attribute timings per kernel.
 extern "C" int gb_gemm_kernel_for(int kind, long long P, int K, int N, int fused_stats, int has_aff) {
+  if (kind == 3)  // gb_gemm_dgrad_wgrad: 2 = ONE launch of the ring kernel carries both products, 0 = the two single calls
+    return (P < RS_PAYS_FROM && P < WG_PAYS_FROM && P > 0 && K > 0 &&
+            pair_shape(P, K, N, (long long)(GB_GEMM_SCRATCH_BYTES / sizeof(float)) / (P * K), false)) ? 2 : 0;
   if (kind == 2) {
     if (K <= 4 && !has_aff && N % 4 == 0 && N / 4 <= GTPB && P >= 4096) return 3;
+    if (P >= WG_PAYS_FROM && wg_wgrad_suits(P, K, N, false)) return 4;
     return (P % 32 == 0 && K % 4 == 0 && N % 4 == 0 && K >= 4 && N >= 4 && P <= 131072) ? 2 : 0;
   }
   if ((P >= RS_PAYS_FROM || fused_stats >= 2) && gb_gemm_uses_rs(P, K, N, kind, fused_stats, has_aff)) return 1;

@@ -31,4 +31,9 @@ bool ring_gemm_try(int kind, const float *a, const float *b, const float *aff, f
                    double *stats, int stat_slots, const float *epi_y, const float *epi_ab, const RingPlan &plan,
                    long long dchunk, hipStream_t s, bool bf16 = false);
 
+// one layer's dgrad + wgrad in one launch (gemm_ring_pair_kernel); false = nothing launched, use the two single calls
+bool ring_pair_try(const float *dy, const float *w, float *dx, double *dstats, int stat_slots, const float *y_prev,
+                   const float *ab_prev, const float *x, const float *x_aff, float *dw, long long P, int K, int N,
+                   hipStream_t s, bool bf16);
+
 }  // namespace gb

@@ -117,10 +117,10 @@ __device__ __forceinline__ void rg_glds16(const float *src, float *lds_dst) {
 // BF (GbGemmOpts.precision = GB_PREC_BF16, round 5): the fragments - fp32 in LDS as ever - are rounded to bf16 in registers
 // (after the operand prologue) and two reduction groups of four feed one v_mfma_f32_32x32x16_bf16: 2 matrix instructions
 // per 32-deep step and tile pair instead of 16, fp32 accumulation, same epilogues.
+// The workgroup's program: tile (bx, by) of product `g`, `lds` = ALL dynamic LDS of the kernel (a second LDS object would
+// make the compiler drain the DMA ring before every read).
 template <int KA, int KB, int BM, int BN, int EPI, bool AFFA, bool AFFB, bool BF = false>
-__global__ __launch_bounds__(RG_TPB, (BM == 128 && BN == 128) ? 1 : 2) void gemm_ring_kernel(RingArgs g) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];   // ALL LDS of the kernel (a second object would make
-                                                                 // the compiler drain the DMA ring before every read)
+__device__ __forceinline__ void ring_tile(const RingArgs &g, const unsigned bx, const unsigned by, float *lds) {
   constexpr int A_FL = BM * RG_BK, B_FL = BN * RG_BK, ST_FL = A_FL + B_FL;
   constexpr int PA = BM / 8, PB = BN / 8, NPW = (PA + PB) / 4;    // 1 KB pieces per stage: A, B; per wave
   constexpr int MT = BM / 64, NT = BN / 64;
@@ -133,13 +133,13 @@ __global__ __launch_bounds__(RG_TPB, (BM == 128 && BN == 128) ? 1 : 2) void gemm
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform: operand selects below stay scalar
   const int m = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  const long long m0 = (long long)(blockIdx.x / g.tiles_n) * BM;
-  const long long n0 = (long long)(blockIdx.x % g.tiles_n) * BN;
-  const long long kbeg = (long long)blockIdx.y * g.kchunk;
+  const long long m0 = (long long)(bx / g.tiles_n) * BM;
+  const long long n0 = (long long)(bx % g.tiles_n) * BN;
+  const long long kbeg = (long long)by * g.kchunk;
   long long kend = kbeg + g.kchunk;
   if (kend > g.red) kend = g.red;
   const int T = (int)((kend - kbeg) / RG_BK);   // reduction steps of this workgroup (>= 1: host-checked)
-  float *dout = g.d + (long long)blockIdx.y * g.dchunk;
+  float *dout = g.d + (long long)by * g.dchunk;
 
   // ---- this lane's source address for each of the wave's NPW pieces of a stage (advanced by one step per issue)
   const float *src[NPW];
@@ -485,12 +485,32 @@ __global__ __launch_bounds__(RG_TPB, (BM == 128 && BN == 128) ? 1 : 2) void gemm
     if (t < BN) {
       const long long col = n0 + t;
       if (col < g.b.rows) {
-        double *st = g.stats + (size_t)((blockIdx.x / g.tiles_n) % g.stat_slots) * 2 * g.b.rows;
+        double *st = g.stats + (size_t)((bx / g.tiles_n) % g.stat_slots) * 2 * g.b.rows;
         atomicAdd(st + col, (double)s_col[(0 * 2 + 0) * BN + t] + (double)s_col[(0 * 2 + 1) * BN + t]);
         atomicAdd(st + g.b.rows + col, (double)s_col[(1 * 2 + 0) * BN + t] + (double)s_col[(1 * 2 + 1) * BN + t]);
       }
     }
   }
+}
+
+template <int KA, int KB, int BM, int BN, int EPI, bool AFFA, bool AFFB, bool BF = false>
+__global__ __launch_bounds__(RG_TPB, (BM == 128 && BN == 128) ? 1 : 2) void gemm_ring_kernel(RingArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  ring_tile<KA, KB, BM, BN, EPI, AFFA, AFFB, BF>(g, blockIdx.x, blockIdx.y, lds);
+}
+
+// Round 5 (VERDICT round 4 #1 i): the dgrad and the wgrad of ONE layer in ONE launch.  Both read the same dY and depend
+// on nothing else of each other; alone, each of the few-row products is a grid of ~256 workgroups of 64 x 64 tiles - half
+// of the 512 such workgroups the chip holds - that is bound by what a workgroup waits for, not by the matrix pipes.  In
+// one launch the two grids are resident TOGETHER (two workgroups per CU, one of each), and the launch takes about as long
+// as the slower of the two.  Workgroups [0, nd) run the dgrad (tile bx = id % nd_x, chunk id / nd_x), the rest the wgrad.
+template <int EPI_D, bool AFFB_W, bool BF>
+__global__ __launch_bounds__(RG_TPB, 2) void gemm_ring_pair_kernel(RingArgs gd, RingArgs gw, unsigned nd_x, unsigned nd,
+                                                                   unsigned nw_x) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const unsigned id = blockIdx.x;
+  if (id < nd) ring_tile<RK_KC, RK_RC, 64, 64, EPI_D, false, false, BF>(gd, id % nd_x, id / nd_x, lds);
+  else ring_tile<RK_RC, RK_RC, 64, 64, RG_ATOMIC, false, AFFB_W, BF>(gw, (id - nd) % nw_x, (id - nd) / nw_x, lds);
 }
 
 static inline bool rg_aligned16(const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
@@ -616,6 +636,57 @@ bool ring_gemm_try(int kind, const float *a, const float *b, const float *aff, f
     return true;
   }
   return false;
+}
+
+// dgrad (dX (P,K) = dY (P,N) W (N,K), optional BatchNorm-backward sums of the previous layer) and wgrad
+// (dW (N,K) += dY^T f(X (P,K))) of one layer as ONE launch of 64 x 64-tile workgroups (gemm_ring_pair_kernel).  The dgrad is
+// not split (its reduction N is short where this pays); the wgrad splits the P reduction as ring_plan says.  Returns false
+// (nothing launched) when either product does not suit the ring kernel in this form.
+bool ring_pair_try(const float *dy, const float *w, float *dx, double *dstats, int stat_slots, const float *y_prev,
+                   const float *ab_prev, const float *x, const float *x_aff, float *dw, long long P, int K, int N,
+                   hipStream_t s, bool bf16) {
+  if (!rg_aligned16(dy) || !rg_aligned16(w) || !rg_aligned16(dx) || !rg_aligned16(x) || !rg_aligned16(dw) ||
+      (x_aff && !rg_aligned16(x_aff)))
+    return false;
+  if (N % RG_BK != 0 || P % RG_BK != 0 || K % 4 != 0 || N % 4 != 0 || K < 4 || N < 4 || P < 64) return false;
+  RingPlan pw;
+  ring_plan(N, K, P, true, 65535, &pw, 1, bf16);
+  if (pw.big || pw.kchunk % RG_BK != 0 || pw.chunks < 1) return false;
+  RingArgs gd = {}, gw = {};
+  gd.a = {dy, P, N, nullptr};
+  gd.b = {w, K, K, nullptr};
+  gd.d = dx; gd.ldd = K; gd.red = N; gd.kchunk = N; gd.dchunk = 0;
+  gd.stats = dstats; gd.stat_slots = stat_slots < 1 ? 1 : stat_slots; gd.epi_y = y_prev; gd.epi_ab = ab_prev;
+  gd.tiles_n = (int)((K + 63) / 64);
+  gw.a = {dy, N, N, nullptr};
+  gw.b = {x, K, K, x_aff};
+  gw.d = dw; gw.ldd = K; gw.red = P; gw.kchunk = pw.kchunk; gw.dchunk = 0; gw.stat_slots = 1;
+  gw.tiles_n = (int)((K + 63) / 64);
+  const long long nd_x = ((P + 63) / 64) * gd.tiles_n, nw_x = ((long long)(N + 63) / 64) * gw.tiles_n;
+  const long long total = nd_x + nw_x * pw.chunks;
+  if (total > 0x7fffffffLL || nd_x > 0x7fffffffLL) return false;
+  size_t lds = (size_t)RG_STAGES * (64 + 64) * RG_BK * sizeof(float) + 2 * 256 * sizeof(float);   // (+ the wgrad's table)
+#define GB_RP(EPI_D_, AFF_, BF_)                                                                                \
+  do {                                                                                                          \
+    static std::atomic<unsigned long long> attr_set{0};                                                         \
+    auto kern = gemm_ring_pair_kernel<EPI_D_, AFF_, BF_>;                                                       \
+    allow_dynamic_lds(kern, 160 * 1024, attr_set);                                                              \
+    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(RG_TPB), lds, s, gd, gw, (unsigned)nd_x, (unsigned)nd_x,  \
+                       (unsigned)nw_x);                                                                        \
+  } while (0)
+#define GB_RP2(EPI_D_, AFF_)            \
+  do {                                  \
+    if (bf16) GB_RP(EPI_D_, AFF_, true); \
+    else GB_RP(EPI_D_, AFF_, false);    \
+  } while (0)
+  if (dstats) {
+    if (x_aff) GB_RP2(RG_BNBWD, true); else GB_RP2(RG_BNBWD, false);
+  } else {
+    if (x_aff) GB_RP2(RG_STORE, true); else GB_RP2(RG_STORE, false);
+  }
+#undef GB_RP2
+#undef GB_RP
+  return true;
 }
 
 }  // namespace gb

@@ -1,0 +1,343 @@
+// Tall weight-gradient products without LDS staging (gfx950, fp32 MFMA).
+//
+//   dW (N,K) += dY (P,N)^T f(X (P,K)),   P >> N, K        (the reference reaches it as the weight gradient of its 1x1
+//   convolutions through torch autograd: pytorch_utils.py:61-113 under pointnet2_modules.py:176-188 and modules.py:104-124)
+//
+// Round 5.  The reduction runs over the ROWS, and both operands are row-contiguous.  v_mfma_f32_32x32x2_f32 takes from
+// lane (j = lane & 31, h = lane >> 5) the A element [m = j][k = h] and the B element [k = h][n = j]: with k = the row
+// (p + h) and m / n = a column, the 64 lanes of one MFMA operand are two runs of 32 consecutive floats of two consecutive
+// rows - exactly what a coalesced global load delivers.  So nothing is staged: a lane loads NTW consecutive dY columns
+// (one 16-byte load) and KTW consecutive X columns (one 8-byte load) of its row, which are the operands of NTW x KTW
+// MFMAs (column c of a lane's vector belongs to tile c: tile qn holds the output rows n = nb + NTW*m + qn - a permutation
+// of the output that only the final write has to know).  Per pair of rows a wave issues 2 loads and 8 MFMAs (512 cycles
+// of the matrix pipe); 8 row pairs are in flight per wave (48 registers), two waves per SIMD.  No LDS, no barriers and no
+// ds_read in the loop; every element of dY and X leaves HBM once (waves that share rows sit in one workgroup: L1 / L2).
+// f: the previous layer's BatchNorm + ReLU applied in registers (2 VALU operations per X element); or X is GENERATED from
+// the row's xyz (the folded 3-input first layer, gemm_rs.hip's lin3) - 5 operations per element against 4 x 64 cycles
+// of MFMA that consume it.
+//
+// A workgroup = 8 waves over one contiguous run of rows: WN x WK waves tile the N x K output (each 128 x 64 or 64 x 64),
+// the other factor PS = 8 / (WN * WK) splits the run of rows.  At the end the PS partial outputs are added through LDS
+// (N*K floats in the output's own layout, one round per partial) and leave as N*K coalesced fp32 atomics per workgroup,
+// each workgroup starting at a different offset.  One workgroup per CU.
+#include "gb_common.h"
+#include "gemm_wg.h"
+
+#include <type_traits>
+
+namespace gb {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WG_TPB = 512;
+constexpr int WG_WAVES = 8;
+#ifndef GB_WG_DEPTH
+#define GB_WG_DEPTH 6     // slots (row pairs) per wave
+#endif
+constexpr int WG_DEPTH = GB_WG_DEPTH;
+static_assert(WG_DEPTH % 2 == 0 && WG_DEPTH >= 4 && WG_DEPTH <= 8, "s_waitcnt immediates of wg_wait");
+
+enum { WG_PLAIN = 0, WG_AFF = 1, WG_GEN3 = 2 };
+
+struct WgArgs {
+  const float *dy, *x, *aff, *gen_x, *gen_w;
+  float *dw;
+  long long P;
+  int N, K;
+  const long long *rows_dev;
+};
+
+__device__ __forceinline__ float wg_lin3(float x, float y, float z, float w0, float w1, float w2) {
+  return ((x * w0) + (y * w1)) + (z * w2);  // == gemm_rs.hip's lin3 (the one evaluation order of the folded layer)
+}
+
+// The loads are inline assembly with manual s_waitcnt: left to the compiler, every load of the software pipeline below is
+// sunk to just in front of its first use ("load, s_waitcnt vmcnt(0), multiply"), i.e. no load is in flight while the
+// matrix pipe works.  saddr form: uniform 64-bit base + a 32-bit byte offset per lane.
+template <int V> struct WgVec;
+template <> struct WgVec<4> { typedef float T __attribute__((ext_vector_type(4))); };
+template <> struct WgVec<3> { typedef float T __attribute__((ext_vector_type(3))); };
+template <> struct WgVec<2> { typedef float T __attribute__((ext_vector_type(2))); };
+
+// "+v": the destination is the slot's OWN register, in and out - with a plain output the compiler is free to let the load
+// write a fresh register and copy it into the loop-carried one right away, i.e. while the load is still in flight.
+template <int V>
+__device__ __forceinline__ void wg_load(typename WgVec<V>::T &dst, const float *base, unsigned byte_off) {
+  if constexpr (V == 4) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(byte_off), "s"(base));
+  else if constexpr (V == 3) asm volatile("global_load_dwordx3 %0, %1, %2" : "+v"(dst) : "v"(byte_off), "s"(base));
+  else asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(dst) : "v"(byte_off), "s"(base));
+}
+// the slot's registers pass THROUGH the wait: nothing that reads them can be scheduled in front of it
+template <int N, typename A, typename B>
+__device__ __forceinline__ void wg_wait(A &a, B &b) {
+  static_assert(N >= 0 && N <= 14 && N % 2 == 0, "add the s_waitcnt immediate");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b));
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" : "+v"(a), "+v"(b));
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(a), "+v"(b));
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" : "+v"(a), "+v"(b));
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" : "+v"(a), "+v"(b));
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" : "+v"(a), "+v"(b));
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" : "+v"(a), "+v"(b));
+  else asm volatile("s_waitcnt vmcnt(14)" : "+v"(a), "+v"(b));
+}
+
+template <int NTW, int KTW, int MODE>
+__global__ __launch_bounds__(WG_TPB) void wgrad_direct_kernel(WgArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float s_out[];  // [N][K]
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  int gP = (int)g.P;
+  if (g.rows_dev) {
+    const long long pd = *g.rows_dev;
+    gP = pd < g.P ? (pd > 0 ? (int)pd : 0) : (int)g.P;
+  }
+  const int N = g.N, K = g.K;
+  const int WK = K / (32 * KTW), WNK = (N / (32 * NTW)) * WK, PS = WG_WAVES / WNK;
+  const int sub = wave % WNK, ps = wave / WNK;
+  const int nb = (sub / WK) * 32 * NTW, kb = (sub % WK) * 32 * KTW;
+  // rows of this workgroup (an even number each), then of this wave's share of them
+  const int per_wg = (((gP + (int)gridDim.x - 1) / (int)gridDim.x) + 1) & ~1;
+  const int c0 = (int)blockIdx.x * per_wg;
+  if (c0 >= gP) return;  // (the whole workgroup: nothing to add)
+  const int c1 = c0 + per_wg < gP ? c0 + per_wg : gP;
+  const int per_ps = (((c1 - c0 + PS - 1) / PS) + 1) & ~1;
+  const int r0 = c0 + ps * per_ps;
+  const int r1 = r0 + per_ps < c1 ? r0 + per_ps : c1;
+  const int last = gP - 1;
+
+  f32x16 acc[NTW][KTW];
+#pragma unroll
+  for (int a = 0; a < NTW; ++a)
+#pragma unroll
+    for (int b = 0; b < KTW; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  if (r0 < r1) {
+    // this lane's columns of X: BatchNorm table / first-layer weights in registers
+    float fa[KTW], fb[KTW], gw[MODE == WG_GEN3 ? KTW : 1][3];
+    if constexpr (MODE != WG_PLAIN) {
+#pragma unroll
+      for (int q = 0; q < KTW; ++q) {
+        fa[q] = g.aff[kb + KTW * j + q];
+        fb[q] = g.aff[K + kb + KTW * j + q];
+      }
+    }
+    if constexpr (MODE == WG_GEN3) {
+#pragma unroll
+      for (int q = 0; q < KTW; ++q)
+#pragma unroll
+        for (int e = 0; e < 3; ++e) gw[q][e] = g.gen_w[(kb + KTW * j + q) * 3 + e];
+    }
+    // (the compiler must have these in registers before the pipeline's own loads start: it does not count those)
+    if constexpr (MODE != WG_PLAIN) {
+#pragma unroll
+      for (int q = 0; q < KTW; ++q) asm volatile("" : "+v"(fa[q]), "+v"(fb[q]));
+    }
+    if constexpr (MODE == WG_GEN3) {
+#pragma unroll
+      for (int q = 0; q < KTW; ++q) asm volatile("" : "+v"(gw[q][0]), "+v"(gw[q][1]), "+v"(gw[q][2]));
+    }
+    constexpr int BV = MODE == WG_GEN3 ? 3 : KTW;
+    constexpr int D = WG_DEPTH;
+    typedef typename WgVec<NTW>::T AV;
+    typedef typename WgVec<BV>::T BVT;
+    AV abuf[D];
+    BVT bbuf[D];
+#pragma unroll
+    for (int u = 0; u < D; ++u) {   // (the loads take their destination as an in/out operand)
+      abuf[u] = 0.f;
+      bbuf[u] = 0.f;
+    }
+    const unsigned a_pitch2 = (unsigned)N * 8u, b_pitch2 = (MODE == WG_GEN3 ? 3u : (unsigned)K) * 8u;  // two rows, in bytes
+    // running byte offsets of the NEXT row to request (slots are refilled in step order: always 2 rows further), clamped to
+    // the tensor's last row: rows past the end of this wave's share are requested from valid addresses and multiplied by 0
+    unsigned a_next = (unsigned)(r0 + h) * (a_pitch2 / 2) + (unsigned)(nb + NTW * j) * 4u;
+    unsigned b_next = (unsigned)(r0 + h) * (b_pitch2 / 2) + (MODE == WG_GEN3 ? 0u : (unsigned)(kb + KTW * j) * 4u);
+    const unsigned a_max = (unsigned)last * (a_pitch2 / 2) + (unsigned)(nb + NTW * j) * 4u;
+    const unsigned b_max = (unsigned)last * (b_pitch2 / 2) + (MODE == WG_GEN3 ? 0u : (unsigned)(kb + KTW * j) * 4u);
+    auto request = [&](AV &a, BVT &b) {
+      wg_load<NTW>(a, g.dy, a_next < a_max ? a_next : a_max);
+      if constexpr (MODE == WG_GEN3) wg_load<3>(b, g.gen_x, b_next < b_max ? b_next : b_max);
+      else wg_load<KTW>(b, g.x, b_next < b_max ? b_next : b_max);
+      a_next += a_pitch2;
+      b_next += b_pitch2;
+    };
+    // the X half of a slot -> the B operands of its step (BatchNorm + ReLU, or the generated layer), in four stages of
+    // independent vector instructions: the pipeline below places one stage behind each quarter of the running step's MFMAs
+    auto stage = [&](int st, BVT &b, float (&tmp)[KTW][2], float (&bv)[KTW]) {
+#pragma unroll
+      for (int q = 0; q < KTW; ++q) {
+        if constexpr (MODE == WG_GEN3) {   // wg_lin3(b, gw[q]), then relu(fa * . + fb)
+          if (st == 0) { tmp[q][0] = b[0] * gw[q][0]; tmp[q][1] = b[1] * gw[q][1]; }
+          else if (st == 1) { tmp[q][0] = tmp[q][0] + tmp[q][1]; tmp[q][1] = b[2] * gw[q][2]; }
+          else if (st == 2) { tmp[q][0] = tmp[q][0] + tmp[q][1]; tmp[q][0] = fa[q] * tmp[q][0]; }
+          else { const float z = tmp[q][0] + fb[q]; bv[q] = z > 0.f ? z : 0.f; }
+        } else if constexpr (MODE == WG_AFF) {
+          if (st == 0) tmp[q][0] = fa[q] * b[q];
+          else if (st == 1) tmp[q][0] = tmp[q][0] + fb[q];
+          else if (st == 2) bv[q] = tmp[q][0] > 0.f ? tmp[q][0] : 0.f;
+        } else {
+          if (st == 0) bv[q] = b[q];
+        }
+      }
+    };
+    auto prepare = [&](BVT &b, float (&bv)[KTW]) {
+      float tmp[KTW][2];
+#pragma unroll
+      for (int st = 0; st < 4; ++st) stage(st, b, tmp, bv);
+    };
+#pragma unroll
+    for (int u = 0; u < D; ++u) request(abuf[u], bbuf[u]);
+    // Software pipeline.  Step u multiplies slot u: the dY half feeds the MFMAs straight from the slot's registers, the X
+    // half through `prepare`.  While the 8 MFMAs of step u run, slot u + 1 is waited for and prepared; slot u is requested
+    // again right behind its MFMAs (they read their operands when they issue).  With the preparation in FRONT of its own
+    // MFMAs the two waves of a SIMD - same program, same start - stay in lockstep and the matrix pipe idles while both
+    // prepare (measured: the BatchNorm form 15 % slower than the plain one for 6 more vector instructions per 512 cycles).
+    // NOTHING may copy a slot register between its request and its wait - the compiler does not know the load is in
+    // flight.  The slots are therefore only ever touched by the tied in/out operands of the asm statements and read by
+    // MFMA / prepare after their wait; tools/wg_check_isa.py walks the generated code for exactly that.
+    static_assert(D % 2 == 0 && D >= 4, "the two B operand sets swap roles every step");
+    float bv[2][KTW];
+    wg_wait<2 * (D - 1)>(abuf[0], bbuf[0]);
+    prepare(bbuf[0], bv[0]);
+    // D steps: rows base + 2u + h.  LAST: the wave's final steps (rows >= r1 multiply by zero) - it requests nothing: the
+    // registers of a request nobody consumes are free for the compiler to reuse while the load is still on its way (that
+    // was a memory fault: an address register overwritten by a late arrival), so the waits count down instead.
+    auto trip = [&](auto last_trip, int base) {
+      constexpr bool LAST = decltype(last_trip)::value;
+#pragma unroll
+      for (int u = 0; u < D; ++u) {
+        const int c = u & 1, v = (u + 1) % D;
+        if (!LAST || u + 1 < D) {   // (compile time after unrolling)
+          if constexpr (LAST) {
+            // slots u + 2 .. D - 1 are younger (2 loads each)
+            if (u == 0) wg_wait<2 * (D - 2)>(abuf[v], bbuf[v]);
+            else if (u == 1) wg_wait<(D >= 3 ? 2 * (D - 3) : 0)>(abuf[v], bbuf[v]);
+            else if (u == 2) wg_wait<(D >= 4 ? 2 * (D - 4) : 0)>(abuf[v], bbuf[v]);
+            else if (u == 3) wg_wait<(D >= 5 ? 2 * (D - 5) : 0)>(abuf[v], bbuf[v]);
+            else if (u == 4) wg_wait<(D >= 6 ? 2 * (D - 6) : 0)>(abuf[v], bbuf[v]);
+            else wg_wait<0>(abuf[v], bbuf[v]);
+          } else {
+            wg_wait<2 * (D - 2)>(abuf[v], bbuf[v]);   // slots u + 2 .. u + D - 1 (2 loads each) may still be in flight
+          }
+        }
+        const bool prep = !LAST || u + 1 < D;
+        float av[NTW];
+        if constexpr (LAST) {
+          const bool ok = base + 2 * u + h < r1;
+#pragma unroll
+          for (int q = 0; q < NTW; ++q) av[q] = ok ? abuf[u][q] : 0.f;
+        } else {
+#pragma unroll
+          for (int q = 0; q < NTW; ++q) av[q] = abuf[u][q];
+        }
+        // a quarter of the step's MFMAs, then one stage of the next step's operands: the fences keep the scheduler from
+        // sinking all of the preparation to just in front of the MFMAs that consume it (where the matrix pipe waits for
+        // the chain multiply - add - max; measured +20 % on the BatchNorm form)
+        float tmp[KTW][2];
+        constexpr int QM = NTW * KTW / 4;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+#pragma unroll
+          for (int i = st * QM; i < (st + 1) * QM; ++i)
+            acc[i / KTW][i % KTW] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i / KTW], bv[c][i % KTW], acc[i / KTW][i % KTW], 0, 0, 0);
+          if (prep) stage(st, bbuf[v], tmp, bv[c ^ 1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (!LAST) request(abuf[u], bbuf[u]);
+      }
+    };
+    // every trip but the last one requests; the last one (always run: it also drains the slots) has D or fewer steps
+    int base = r0;
+    for (; base + 2 * D < r1; base += 2 * D) trip(std::false_type{}, base);
+    trip(std::true_type{}, base);
+  }
+
+  // acc[a][b][r] = dW[nb + NTW*((r&3) + 8*(r>>2) + 4*h) + a][kb + KTW*j + b]; the PS partials of an output tile meet in LDS
+  for (int round = 0; round < PS; ++round) {
+    if (ps == round && (round == 0 || r0 < r1)) {
+#pragma unroll
+      for (int a = 0; a < NTW; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float *row = s_out + (nb + NTW * ((r & 3) + 8 * (r >> 2) + 4 * h) + a) * K + kb + KTW * j;
+#pragma unroll
+          for (int b = 0; b < KTW; ++b) {
+            if (round == 0) row[b] = acc[a][b][r];
+            else row[b] += acc[a][b][r];
+          }
+        }
+    }
+    __syncthreads();
+  }
+  const int total = N * K;
+  const int rot = (int)(((unsigned)blockIdx.x * 1024u) % (unsigned)total);  // workgroups finish together: not all on one line
+  for (int i = t; i < total; i += WG_TPB) {
+    int idx = i + rot;
+    if (idx >= total) idx -= total;
+    atomicAdd(g.dw + idx, s_out[idx]);
+  }
+}
+
+static int wg_num_cus(int reserved) {
+  static std::atomic<int> cached{0};  // a device property, not state
+  int n = cached.load(std::memory_order_relaxed);
+  if (!n) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+    cached.store(n, std::memory_order_relaxed);
+  }
+  return (reserved > 0 && n - reserved >= 16) ? n - reserved : n;
+}
+
+// 0: no; 1: 128 x 64 wave tiles (NTW 4, KTW 2); 2: 64 x 64 (NTW 2, KTW 2)
+static int wg_form(long long P, int K, int N, bool gen) {
+  if (P < 1 || N < 64 || K < 64 || N % 64 != 0 || K % 64 != 0) return 0;
+  if ((long long)N * K > 32768) return 0;                                  // the output in LDS: 128 KB
+  if (P * (long long)(N > K ? N : K) >= (1LL << 30) - (1 << 16)) return 0;   // 32-bit byte offsets (+ the look-ahead)
+  if (gen && K != 64) return 0;
+  const int w42 = N % 128 == 0 ? (N / 128) * (K / 64) : 0, w22 = (N / 64) * (K / 64);
+  if (w42 == 1 || w42 == 2 || w42 == 4 || w42 == 8) return 1;
+  if (w22 == 1 || w22 == 2 || w22 == 4 || w22 == 8) return 2;
+  return 0;
+}
+
+bool wg_wgrad_suits(long long P, int K, int N, bool gen) { return wg_form(P, K, N, gen) != 0; }
+
+template <int NTW, int KTW, int MODE>
+static void wg_launch(const WgArgs &g, int reserved, hipStream_t s) {
+  static std::atomic<unsigned long long> attr_set{0};
+  auto kern = wgrad_direct_kernel<NTW, KTW, MODE>;
+  allow_dynamic_lds(kern, 160 * 1024, attr_set);
+  const size_t lds = (size_t)g.N * g.K * sizeof(float);
+  long long blocks = wg_num_cus(reserved);
+  const long long most = (g.P + 2 * WG_WAVES * WG_DEPTH - 1) / (2 * WG_WAVES * WG_DEPTH);  // >= one loop trip per wave
+  if (blocks > most) blocks = most;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WG_TPB), lds, s, g);
+}
+
+bool wg_wgrad_try(const float *dy, const float *x, const float *aff, const float *gen_x, const float *gen_w, float *dw,
+                  long long P, int K, int N, const long long *rows_dev, int reserved_cus, hipStream_t s) {
+  const bool gen = gen_x != nullptr;
+  const int form = wg_form(P, K, N, gen);
+  if (!form || !dy || !dw || (gen ? (!gen_w || !aff || x) : !x)) return false;
+  auto al16 = [](const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+  if (!al16(dy) || (x && !al16(x)) || !al16(dw)) return false;
+  WgArgs g = {dy, x, aff, gen_x, gen_w, dw, P, N, K, rows_dev};
+  const int mode = gen ? WG_GEN3 : (aff ? WG_AFF : WG_PLAIN);
+#define GB_WG(NTW_, KTW_)                                              \
+  do {                                                                 \
+    if (mode == WG_GEN3) wg_launch<NTW_, KTW_, WG_GEN3>(g, reserved_cus, s);      \
+    else if (mode == WG_AFF) wg_launch<NTW_, KTW_, WG_AFF>(g, reserved_cus, s);   \
+    else wg_launch<NTW_, KTW_, WG_PLAIN>(g, reserved_cus, s);                     \
+  } while (0)
+  if (form == 1) GB_WG(4, 2); else GB_WG(2, 2);
+#undef GB_WG
+  return true;
+}
+
+}  // namespace gb

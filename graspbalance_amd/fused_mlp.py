@@ -75,6 +75,9 @@ _PREC_NAME = {_lib.PREC_F32: "f32", _lib.PREC_BF16: "bf16"}
 _tls = threading.local()
 _RESERVED_CUS = 0
 _GEMM_FLAGS = _lib.GEMM_NO_RING if os.environ.get("GB_RING", "1") == "0" else 0   # A/B switch: few-row GEMM kernel
+if os.environ.get("GB_DIRECT", "1") == "0":   # A/B switch: tall wgrads on the LDS tiles instead of csrc/gemm_wg.hip
+    _GEMM_FLAGS |= _lib.GEMM_NO_DIRECT
+_PAIR = os.environ.get("GB_PAIR", "1") != "0"   # A/B switch: dgrad + wgrad of a layer through gb_gemm_dgrad_wgrad
 _WORKSPACES = {}
 _OPTS = {}
 
@@ -147,7 +150,7 @@ def set_ring_gemm(flag):
     tiles of csrc/gemm_cl.hip (GbGemmOpts.flags = GB_GEMM_NO_RING).  -> previous setting."""
     global _GEMM_FLAGS
     prev = not (_GEMM_FLAGS & _lib.GEMM_NO_RING)
-    _GEMM_FLAGS = 0 if flag else _lib.GEMM_NO_RING
+    _GEMM_FLAGS = (_GEMM_FLAGS & ~_lib.GEMM_NO_RING) | (0 if flag else _lib.GEMM_NO_RING)
     return prev
 
 
@@ -335,7 +338,7 @@ def _bn_fin(cfg, gamma, beta, ab, P_stat):
     return ctypes.byref(f)
 
 
-def _gemm_meta(kind, P, K, N, fused=False, aff=False, rows_dev=None):
+def _gemm_meta(kind, P, K, N, fused=False, aff=False, rows_dev=None, prec=None):
     """Timing metadata of a GEMM launch (only built while a KernelTimer is active): FLOP, shape and which
     kernel the C entry dispatches to (gemm_rs_kernel / gemm_cl_kernel).  rows_dev: the launch's device-side row count -
     read back HERE (a synchronisation: timing runs only) so that the FLOP count is that of the rows actually multiplied,
@@ -350,8 +353,17 @@ def _gemm_meta(kind, P, K, N, fused=False, aff=False, rows_dev=None):
         which = 1      # a device-side row count: the row-streaming kernel whatever the capacity
     if which == 2 and (_GEMM_FLAGS & _lib.GEMM_NO_RING or rows_dev is not None):   # (round 5: the ring kernel has a bf16 form)
         which = 0
-    kernel = ("gemm_cl_kernel", "gemm_rs_kernel", "gemm_ring_kernel", "wgrad_smallk_kernel")[which]
+    if which == 4 and (_GEMM_FLAGS & _lib.GEMM_NO_DIRECT or (_prec() if prec is None else prec) == _lib.PREC_BF16):
+        which = 0      # (prec: a backward node multiplies at its forward's precision, not at the thread's current one)
+    kernel = ("gemm_cl_kernel", "gemm_rs_kernel", "gemm_ring_kernel", "wgrad_smallk_kernel", "wgrad_direct_kernel")[which]
     return {"flop": 2.0 * P * K * N, "pkn": (P, K, N), "kernel": kernel}
+
+
+def _pair_meta(P, K, N):
+    """_gemm_meta of a gb_gemm_dgrad_wgrad call that leaves as ONE launch of the ring kernel (both products)."""
+    if _lib.KernelTimer.active is None:
+        return None
+    return {"flop": 4.0 * P * K * N, "pkn": (P, K, N), "kernel": "gemm_ring_kernel", "products": 2}
 
 
 def _first_meta(P, K, N, rows_dev):
@@ -493,7 +505,7 @@ class LinearBNAct(Function):
             if ctx.needs_input_grad[1]:
                 dW = torch.zeros((Cout, Cin), dtype=torch.float32, device=dev)
                 _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(X), None, _lib.ptr(dW), P, Cin, Cout,
-                      _opts(dev, _s(dY), ctx.prec), _s(dY), meta=_gemm_meta("wgrad", P, Cin, Cout))
+                      _opts(dev, _s(dY), ctx.prec), _s(dY), meta=_gemm_meta("wgrad", P, Cin, Cout, prec=ctx.prec))
             if ctx.needs_input_grad[0]:
                 dX = torch.empty((P, Cin), dtype=torch.float32, device=dev)
                 W = W.contiguous()
@@ -776,14 +788,19 @@ class MLPStack(Function):
             W = Ws[l]
             N, K = W.shape
             src, aff = (X0, None) if l == 0 else (Ys[l - 1], abs_[l - 1])
-            if need_w[l]:
+            # both gradient products of the layer from ONE C call (few-row shapes: one launch, csrc/gemm_ring.hip pair kernel)
+            pair = (_PAIR and need_w[l] and l >= 1 and fused[l - 1] and rdev is None and not (ctx.fold and l == 1)
+                    and not (l == 1 and _FIRST_FUSE and X0.shape[1] == 3 and not ctx.needs_input_grad[0] and need_w[0]
+                             and _lib.lib().gb_gemm_uses_rs(P, K, N, 1, 2, 0))
+                    and _lib.lib().gb_gemm_kernel_for(3, P, K, N, 1, 1) == 2)   # (else two calls: per-kernel timing)
+            if need_w[l] and not pair:
                 dW = w_arena[w_off[l]:w_off[l + 1]]
                 if ctx.fold and l == 1:   # the x operand relu(a*y1 + b) is re-formed from the xyz rows
                     _call("gb_gemm_wgrad_gen3", dev, _lib.ptr(dY), _lib.ptr(X0), _lib.ptr(Ws[0]), _lib.ptr(aff), _lib.ptr(dW), P,
-                          K, N, opts, st, meta=_gemm_meta("wgrad", P, K, N, aff=True, rows_dev=rdev))
+                          K, N, opts, st, meta=_gemm_meta("wgrad", P, K, N, aff=True, rows_dev=rdev, prec=ctx.prec))
                 else:
                     _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(src), _lib.ptr(aff), _lib.ptr(dW), P, K, N, opts, st,
-                          meta=_gemm_meta("wgrad", P, K, N, aff=aff is not None, rows_dev=rdev))
+                          meta=_gemm_meta("wgrad", P, K, N, aff=aff is not None, rows_dev=rdev, prec=ctx.prec))
                 grads[3 * l] = dW.view(N, K)
             if l == 0:
                 if ctx.needs_input_grad[0]:
@@ -826,10 +843,18 @@ class MLPStack(Function):
                 # one slot row: the sums ARE the totals, and all gb_bn_bwd_reduce would do is convert them to fp32 - the
                 # apply pass reads them anyway and does that (one launch less per layer of the few-row stacks)
                 emit = slots == 1 and rows is None
-                _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dZ), _lib.ptr(Ys[l - 1]),
-                      _lib.ptr(abs_[l - 1]), _lib.ptr(region), slots, P, K, N, None if emit else _lib.ptr(dstats),
-                      None if emit else _lib.ptr(dbeta), None if emit else _lib.ptr(dgamma), opts, st,
-                      meta=_gemm_meta("dgrad", P, K, N, fused=True, rows_dev=rdev))
+                if pair:
+                    dW = w_arena[w_off[l]:w_off[l + 1]]
+                    _call("gb_gemm_dgrad_wgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dZ), _lib.ptr(Ys[l - 1]),
+                          _lib.ptr(abs_[l - 1]), _lib.ptr(region), slots, P, K, N, None if emit else _lib.ptr(dstats),
+                          None if emit else _lib.ptr(dbeta), None if emit else _lib.ptr(dgamma), _lib.ptr(src),
+                          _lib.ptr(aff), _lib.ptr(dW), opts, st, meta=_pair_meta(P, K, N))
+                    grads[3 * l] = dW.view(N, K)
+                else:
+                    _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dZ), _lib.ptr(Ys[l - 1]),
+                          _lib.ptr(abs_[l - 1]), _lib.ptr(region), slots, P, K, N, None if emit else _lib.ptr(dstats),
+                          None if emit else _lib.ptr(dbeta), None if emit else _lib.ptr(dgamma), opts, st,
+                          meta=_gemm_meta("dgrad", P, K, N, fused=True, rows_dev=rdev))
             else:
                 # wide + long outputs: the fused epilogue measured slower than a separate column pass
                 _call("gb_gemm_dgrad", dev, _lib.ptr(dY), _lib.ptr(W), _lib.ptr(dZ), None, None, None, 0, P, K, N,
@@ -1044,7 +1069,7 @@ class LocalAggPool(Function):
                   training, _lib.ptr(dWx), _lib.ptr(dbeta), _lib.ptr(dgamma), st)
             dWf = zbuf[rows * N:].view(N, C)
             _call("gb_gemm_wgrad", dev, _lib.ptr(dG), _lib.ptr(f), None, _lib.ptr(dWf), rows, C, N,
-                  _opts(dev, st, ctx.prec), st, meta=_gemm_meta("wgrad", rows, C, N))
+                  _opts(dev, st, ctx.prec), st, meta=_gemm_meta("wgrad", rows, C, N, prec=ctx.prec))
             dW = torch.empty((N, 3 + C), dtype=torch.float32, device=dev)
             _call("gb_la_join_w", dev, _lib.ptr(dWx), _lib.ptr(dWf), _lib.ptr(dW), N, C, st)
         df = None
@@ -1209,7 +1234,7 @@ class LinearBias(Function):
         if ctx.needs_input_grad[1]:
             dW = _zeros32(N * K, dev).view(N, K)
             _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(X), None, _lib.ptr(dW), P, K, N,
-                  _opts(dev, st, ctx.prec), st, meta=_gemm_meta("wgrad", P, K, N))
+                  _opts(dev, st, ctx.prec), st, meta=_gemm_meta("wgrad", P, K, N, prec=ctx.prec))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             sums = _zeros64(2 * N, dev)
             _call("gb_col_stats", dev, _lib.ptr(dY), P, N, _lib.ptr(sums), None, st)

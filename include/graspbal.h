@@ -325,7 +325,14 @@ int gb_group_concat_cl_grad(const float *dx0, const int32_t *idx, float *dfeat, 
 /*   flags       : GB_GEMM_NO_RING - few-row fp32 products (gb_gemm_fwd / _dgrad / _wgrad) skip the LDS-DMA ring kernel
  *                 (csrc/gemm_ring.hip) and run on the register-staged tiles of csrc/gemm_cl.hip: an A/B and fallback
  *                 switch, results equal to fp32 rounding (a different summation order).                            */
+/*                 GB_GEMM_NO_PAIR - gb_gemm_dgrad_wgrad issues its two products as two launches even where one
+ *                 launch could carry both (A/B switch; same results up to the order of wgrad's fp32 atomics).        */
+/*                 GB_GEMM_NO_DIRECT - tall fp32 weight gradients (gb_gemm_wgrad / gb_gemm_wgrad_gen3 from 65 536 rows or
+ *                 with rows_dev) skip the register-direct kernel (csrc/gemm_wg.hip) and run on the LDS tiles of
+ *                 csrc/gemm_cl.hip (A/B and fallback switch; same results up to the order of the fp32 additions).    */
 #define GB_GEMM_NO_RING 1
+#define GB_GEMM_NO_PAIR 2
+#define GB_GEMM_NO_DIRECT 4
 typedef struct GbGemmOpts {
   int precision;
   int reserved_cus;
@@ -538,6 +545,16 @@ int gb_gemm_dgrad(const float *dy, const float *w, float *dx, const float *y_pre
  * workgroups).  x_aff (optional) = [a(K), b(K)]: f(x) = relu(a_k x + b_k), as in gb_gemm_fwd.      */
 int gb_gemm_wgrad(const float *dy, const float *x, const float *x_aff, float *dw, long long P, int K, int N,
                   const GbGemmOpts *opts, void *stream);
+/* Both gradient products of ONE layer, which share dY and do not depend on each other (torch autograd issues them as
+ * two cuBLAS calls behind the 1x1 convolutions of pytorch_utils.py:61-113; the reference's stacks that take this form:
+ * pointnet2_modules.py:176-188, modules.py:104-124, drp.py:97-117): dX = dY W with the optional fused BatchNorm-backward
+ * sums exactly as gb_gemm_dgrad, dW += dY^T f(X) exactly as gb_gemm_wgrad.  Few-row products that each fill about half
+ * of the chip (64x64 tiles of the LDS-DMA ring kernel, csrc/gemm_ring.hip) leave as ONE launch whose workgroups are
+ * resident together; every other shape runs gb_gemm_wgrad then gb_gemm_dgrad.  rows_dev: as the single entries.  */
+int gb_gemm_dgrad_wgrad(const float *dy, const float *w, float *dx, const float *y_prev, const float *ab_prev,
+                        double *dstats, int stat_slots, long long P, int K, int N, double *dstats_total, float *dbeta,
+                        float *dgamma, const float *x, const float *x_aff, float *dw, const GbGemmOpts *opts,
+                        void *stream);
 /* Which kernel gb_gemm_fwd (dgrad = 0) / gb_gemm_dgrad (dgrad = 1) launches for 16-byte aligned operands of
  * this shape: 1 = the row-streaming kernel CAN run it (csrc/gemm_rs.hip: what the generated-operand, pooled and
  * device-row-count entries require), 0 = it cannot.  The plain gb_gemm_fwd / gb_gemm_dgrad additionally prefer the tiled
@@ -546,7 +563,9 @@ int gb_gemm_wgrad(const float *dy, const float *x, const float *x_aff, float *dw
 int gb_gemm_uses_rs(long long P, int K, int N, int dgrad, int fused_stats, int has_aff);
 /* ... and, for all three products (kind 0 = gb_gemm_fwd, 1 = gb_gemm_dgrad, 2 = gb_gemm_wgrad; fp32, default options):
  * 0 = register-staged LDS tiles (csrc/gemm_cl.hip), 1 = row-streaming (csrc/gemm_rs.hip), 2 = LDS-DMA ring
- * (csrc/gemm_ring.hip: the few-row products), 3 = the column-reduction wgrad for <= 4 input channels.             */
+ * (csrc/gemm_ring.hip: the few-row products), 3 = the column-reduction wgrad for <= 4 input channels, 4 = the
+ * register-direct tall wgrad (csrc/gemm_wg.hip).  kind 3 = gb_gemm_dgrad_wgrad: 2 when ONE launch of the ring kernel
+ * carries both products, 0 when the call issues the two single products.                                          */
 int gb_gemm_kernel_for(int kind, long long P, int K, int N, int fused_stats, int has_aff);
 /* dgrad into the first layer of a stack whose input x_in (P,3) has 3 channels: dZ = dY (P,N) W (N,K) is formed
  * but not stored; sums fp64 [slots][5K] (caller-zeroed) += column sums of [g, g*xhat, g*x_0, g*x_1, g*x_2] with

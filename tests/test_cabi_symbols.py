@@ -66,3 +66,38 @@ def test_cpu_tensors_raise_like_the_reference():
         _ext.ball_query(torch.rand(1, 2, 3), torch.rand(1, 8, 3), 0.1, 4)
     with pytest.raises(RuntimeError, match="CPU not supported"):
         _ext.three_nn(torch.rand(1, 2, 3), torch.rand(1, 8, 3))
+
+
+@pytest.mark.timeout(600)
+def test_direct_wgrad_never_touches_a_register_in_flight(tmp_path):
+    """csrc/gemm_wg.hip requests its operands with inline-asm loads the compiler cannot see as pending: a register copy
+    (or reuse) between a request and its wait would multiply stale data - or, as happened once, overwrite an address.
+    tools/wg_check_isa.py walks the generated gfx950 code of every instantiation for exactly that (hipcc -S, no GPU)."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "graspbalance_amd", "csrc", "gemm_wg.hip")
+    mk = open(os.path.join(ROOT, "graspbalance_amd", "csrc", "Makefile")).read()
+    flags = re.search(r"^FLAGS\s*:=\s*(.*?)(?<!\\)\n", mk, flags=re.S | re.M).group(1).replace("\\\n", " ").split()
+    flags = [f.replace("$(ARCH)", "gfx950") for f in flags]
+    out = str(tmp_path / "gemm_wg.s")
+    subprocess.run([hipcc] + flags + ["--cuda-device-only", "-S", src, "-o", out], check=True, cwd=str(tmp_path))
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "wg_check_isa.py"), out], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert res.stdout.count(", ok") == res.stdout.count("wgrad_direct_kernel") >= 6, res.stdout
+
+
+def test_the_in_flight_checker_sees_a_planted_hazard(tmp_path):
+    import subprocess
+    import sys
+    bad = tmp_path / "bad.s"
+    bad.write_text("_ZN2gb19wgrad_direct_kernelILi9ELi9ELi9EEEvNS_6WgArgsE:\n"
+                   "\t;;#ASMSTART\n\tglobal_load_dwordx4 v[10:13], v1, s[2:3]\n\t;;#ASMEND\n"
+                   "\t;;#ASMSTART\n\tglobal_load_dwordx2 v[20:21], v2, s[4:5]\n\t;;#ASMEND\n"
+                   "\tv_mov_b32_e32 v30, v11\n"            # copies a register whose load has not been waited for
+                   "\t;;#ASMSTART\n\ts_waitcnt vmcnt(0)\n\t;;#ASMEND\n\tv_mov_b32_e32 v31, v12\n\ts_endpgm\n")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "wg_check_isa.py"), str(bad)], capture_output=True, text=True)
+    assert res.returncode == 1 and "v_mov_b32_e32 v30, v11" in res.stdout and "v31" not in res.stdout, res.stdout

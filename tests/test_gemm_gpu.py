@@ -122,6 +122,117 @@ def test_gemm_fused_epilogues_slotted(P, K, N):
     assert torch.allclose(d[K:], (g * xhat).sum(0), rtol=1e-5, atol=1e-5 * P ** 0.5)
 
 
+@pytest.mark.parametrize("P,K,N", SHAPES)
+@pytest.mark.parametrize("variant", ["plain", "bn_aff", "bn_aff_bf16"])
+def test_gemm_dgrad_wgrad_one_call_equals_the_two_single_calls(P, K, N, variant):
+    """gb_gemm_dgrad_wgrad (few-row shapes: ONE launch carrying both products, csrc/gemm_ring.hip pair kernel) against the
+    fp64 products and against gb_gemm_dgrad + gb_gemm_wgrad; GB_GEMM_NO_PAIR must give the single calls' bits in dX."""
+    L = _lib()
+    torch.manual_seed(P * 11 + K + N)
+    bn = variant != "plain"
+    prec = 1 if variant.endswith("bf16") else 0
+    slots = 2
+    X = torch.randn(P, K, device=DEV)
+    W = torch.randn(N, K, device=DEV)
+    dY = torch.randn(P, N, device=DEV)
+    aff = torch.cat([torch.randn(K, device=DEV), torch.randn(K, device=DEV)]) if bn else None
+    ab = torch.cat([aff, torch.randn(K, device=DEV), torch.rand(K, device=DEV) + 0.5]) if bn else None
+
+    def run(flags, single):
+        dX = torch.empty(P, K, device=DEV)
+        dW = torch.zeros(N, K, device=DEV)
+        dst = torch.zeros(slots, 2 * K, dtype=torch.float64, device=DEV) if bn else None
+        tot = torch.zeros(2 * K, dtype=torch.float64, device=DEV) if bn else None
+        dbeta = torch.zeros(K, device=DEV) if bn else None
+        dgamma = torch.zeros(K, device=DEV) if bn else None
+        o = _opts(precision=prec)
+        o.contents.flags = flags
+        if single:
+            L.check(L.lib().gb_gemm_wgrad(L.ptr(dY), L.ptr(X), L.ptr(aff), L.ptr(dW), P, K, N, o, None), "wgrad")
+            L.check(L.lib().gb_gemm_dgrad(L.ptr(dY), L.ptr(W), L.ptr(dX), L.ptr(X if bn else None), L.ptr(ab), L.ptr(dst),
+                                          slots if bn else 0, P, K, N, L.ptr(tot), L.ptr(dbeta), L.ptr(dgamma), o, None), "dgrad")
+        else:
+            L.check(L.lib().gb_gemm_dgrad_wgrad(L.ptr(dY), L.ptr(W), L.ptr(dX), L.ptr(X if bn else None), L.ptr(ab),
+                                                L.ptr(dst), slots if bn else 0, P, K, N, L.ptr(tot), L.ptr(dbeta),
+                                                L.ptr(dgamma), L.ptr(X), L.ptr(aff), L.ptr(dW), o, None), "pair")
+        torch.cuda.synchronize()
+        return dX, dW, tot, dbeta, dgamma
+
+    one = run(0, False)
+    two = run(0, True)
+    off = run(L.GEMM_NO_PAIR, False)
+    assert torch.equal(off[0], two[0])                      # the switch: exactly the single calls
+    tol_x, tol_w = (2e-2, 2e-2) if prec else (2e-6, 1e-5)
+    rx = dY.double() @ W.double()
+    fx = torch.relu(aff[:K] * X + aff[K:]).double() if bn else X.double()
+    rw = dY.double().t() @ fx
+    for dX, dW, tot, dbeta, dgamma in (one, two):
+        assert float((dX.double() - rx).abs().max()) / (float(rx.abs().max()) + 1e-12) < tol_x
+        assert float((dW.double() - rw).abs().max()) / (float(rw.abs().max()) + 1e-12) < tol_w
+    if bn:
+        a, b, mean, rstd = ab[:K], ab[K:2 * K], ab[2 * K:3 * K], ab[3 * K:]
+        for dX, dW, tot, dbeta, dgamma in (one, two):   # the sums of THIS run's dX (bf16 runs differ in dX itself)
+            g = torch.where(a * X + b > 0, dX, torch.zeros_like(dX)).double()
+            xhat = ((X - mean) * rstd).double()
+            assert torch.allclose(tot[:K], g.sum(0), rtol=1e-5, atol=1e-5 * P ** 0.5)
+            assert torch.allclose(tot[K:], (g * xhat).sum(0), rtol=1e-5, atol=1e-5 * P ** 0.5)
+            assert torch.allclose(dbeta.double(), tot[:K], rtol=1e-6, atol=1e-6)
+            assert torch.allclose(dgamma.double(), tot[K:], rtol=1e-6, atol=1e-6)
+    # fp32: the paired launch uses the tile plan the single dgrad would have used -> the same bits in dX
+    if not prec:
+        assert torch.equal(one[0], two[0])
+
+
+@pytest.mark.parametrize("P,K,N", [(65536, 64, 128), (65537, 64, 64), (100001, 128, 128), (131072, 128, 256), (70000, 256, 128),
+                                   (90002, 64, 256), (65536, 128, 64), (300007, 64, 128), (66000, 512, 64), (66000, 192, 128)])
+@pytest.mark.parametrize("mode", ["plain", "aff", "gen3", "rows_dev", "rows_dev_zero"])
+def test_tall_wgrad_register_direct_kernel(P, K, N, mode):
+    """csrc/gemm_wg.hip (tall fp32 wgrads: operands straight from global memory into the matrix cores) against the fp64
+    product and against the LDS-tile path (GB_GEMM_NO_DIRECT); odd row counts, a device-side row count below the capacity
+    (rows beyond it hold NaN: they must not be read into the sums), zero rows."""
+    L = _lib()
+    if mode == "gen3" and K != 64:
+        pytest.skip("the folded first layers have 64 outputs")
+    torch.manual_seed(P + 5 * K + N)
+    dY = torch.randn(P, N, device=DEV)
+    aff = torch.cat([torch.randn(K, device=DEV), torch.randn(K, device=DEV)]) if mode in ("aff", "gen3", "rows_dev") else None
+    rows = P
+    rows_dev = None
+    if mode == "gen3":
+        x0 = torch.randn(P, 3, device=DEV)
+        w1 = torch.randn(K, 3, device=DEV)
+        X = ((x0[:, 0:1] * w1[:, 0]) + (x0[:, 1:2] * w1[:, 1])) + (x0[:, 2:3] * w1[:, 2])
+    else:
+        X = torch.randn(P, K, device=DEV)
+    if mode.startswith("rows_dev"):
+        rows = 0 if mode.endswith("zero") else P - 12345
+        rows_dev = torch.tensor([rows], dtype=torch.int64, device=DEV)
+        dY[rows:] = float("nan")
+        X[rows:] = float("nan")
+    fx = torch.relu(aff[:K] * X + aff[K:]) if aff is not None else X
+    ref = dY[:rows].double().t() @ fx[:rows].double()
+
+    def run(flags):
+        dW = torch.zeros(N, K, device=DEV)
+        ws = _WS.setdefault("t", torch.empty(L.GEMM_SCRATCH_BYTES, dtype=torch.uint8, device=DEV))
+        o = ctypes.pointer(L.GemmOpts(L.PREC_F32, 0, ws.data_ptr(), ws.numel(), L.ptr(rows_dev), flags))
+        if mode == "gen3":
+            L.check(L.lib().gb_gemm_wgrad_gen3(L.ptr(dY), L.ptr(x0), L.ptr(w1), L.ptr(aff), L.ptr(dW), P, K, N, o, None), "wgrad_gen3")
+        else:
+            L.check(L.lib().gb_gemm_wgrad(L.ptr(dY), L.ptr(X), L.ptr(aff), L.ptr(dW), P, K, N, o, None), "wgrad")
+        torch.cuda.synchronize()
+        return dW
+
+    w42, w22 = ((N // 128) * (K // 64) if N % 128 == 0 else 0), (N // 64) * (K // 64)
+    direct = N * K <= 32768 and (w42 in (1, 2, 4, 8) or w22 in (1, 2, 4, 8))   # 8 waves tile the output
+    assert (L.lib().gb_gemm_kernel_for(2, P, K, N, 0, int(aff is not None)) == 4) == direct
+    scale = float(ref.abs().max()) + 1e-12
+    for flags in (0, L.GEMM_NO_DIRECT):
+        dW = run(flags)
+        assert bool(torch.isfinite(dW).all())
+        assert float((dW.double() - ref).abs().max()) / scale < 1e-5 if rows else float(dW.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("P,K,N", [(1024, 1024, 256), (1024, 256, 1024), (4096, 512, 128), (2048, 1024, 256)])
 def test_split_reduction_products_are_bit_reproducible(P, K, N):
     """Few-tile / long-reduction forward and dgrad products split the reduction over workgroups when the CALLER hands

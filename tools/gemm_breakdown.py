@@ -13,7 +13,7 @@ batch = make_training_batch(range(4), 20000, device="cuda:0")
 tr = Trainer("cuda:0", graph=False)   # (events around single launches: not under graph replay)
 for _ in range(3):
     tr.train_step(batch)
-names = ["gb_gemm_fwd", "gb_gemm_fwd_w", "gb_gemm_fwd_pool", "gb_gemm_fwd_gen3", "gb_gemm_dgrad", "gb_gemm_dgrad_first", "gb_gemm_dgrad_first_gen3", "gb_gemm_wgrad", "gb_gemm_wgrad_gen3"]
+names = ["gb_gemm_fwd", "gb_gemm_fwd_w", "gb_gemm_fwd_pool", "gb_gemm_fwd_gen3", "gb_gemm_dgrad", "gb_gemm_dgrad_first", "gb_gemm_dgrad_first_gen3", "gb_gemm_wgrad", "gb_gemm_wgrad_gen3", "gb_gemm_dgrad_wgrad"]
 with _lib.KernelTimer(names) as kt:
     for _ in range(3):
         tr.train_step(batch)

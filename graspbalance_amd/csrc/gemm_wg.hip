@@ -18,8 +18,9 @@
 //
 // A workgroup = 8 waves over one contiguous run of rows: WN x WK waves tile the N x K output (each 128 x 64 or 64 x 64),
 // the other factor PS = 8 / (WN * WK) splits the run of rows.  At the end the PS partial outputs are added through LDS
-// (N*K floats in the output's own layout, one round per partial) and leave as N*K coalesced fp32 atomics per workgroup,
-// each workgroup starting at a different offset.  One workgroup per CU.
+// (a pairwise tree), the totals are laid out as the output is and leave as N*K coalesced fp32 atomics per workgroup, each
+// workgroup starting at a different offset - 256 x N*K atomics at the 1.3 TB/s the chip sustains for them: 7 - 26 us of
+// the launch, its largest overhead (measured with the epilogue compiled out).  One workgroup per CU.
 #include "gb_common.h"
 #include "gemm_wg.h"
 
@@ -45,6 +46,7 @@ struct WgArgs {
   long long P;
   int N, K;
   const long long *rows_dev;
+  int qn, qk;   // the output is cut into qn x qk sub-blocks, one per workgroup of a run of rows
 };
 
 __device__ __forceinline__ float wg_lin3(float x, float y, float z, float w0, float w1, float w2) {
@@ -93,12 +95,19 @@ __global__ __launch_bounds__(WG_TPB) void wgrad_direct_kernel(WgArgs g) {
     gP = pd < g.P ? (pd > 0 ? (int)pd : 0) : (int)g.P;
   }
   const int N = g.N, K = g.K;
-  const int WK = K / (32 * KTW), WNK = (N / (32 * NTW)) * WK, PS = WG_WAVES / WNK;
+  // A workgroup owns ONE of the qn x qk sub-blocks (SN x SK) of the output over a run of rows; the Q workgroups of a run
+  // are 8 apart in the grid - the same XCD, started together: the rows they share meet in that XCD's L2.  Fewer, longer
+  // runs: Q times fewer atomics at the end.
+  const int Q = g.qn * g.qk, SN = N / g.qn, SK = K / g.qk;
+  const int WK = SK / (32 * KTW), WNK = (SN / (32 * NTW)) * WK, PS = WG_WAVES / WNK;
   const int sub = wave % WNK, ps = wave / WNK;
-  const int nb = (sub / WK) * 32 * NTW, kb = (sub % WK) * 32 * KTW;
+  const int bq = (int)(blockIdx.x >> 3) % Q, run = ((int)(blockIdx.x >> 3) / Q) * 8 + (int)(blockIdx.x & 7);
+  const int n0 = (bq / g.qk) * SN, k0 = (bq % g.qk) * SK;
+  const int nb = n0 + (sub / WK) * 32 * NTW, kb = k0 + (sub % WK) * 32 * KTW;
   // rows of this workgroup (an even number each), then of this wave's share of them
-  const int per_wg = (((gP + (int)gridDim.x - 1) / (int)gridDim.x) + 1) & ~1;
-  const int c0 = (int)blockIdx.x * per_wg;
+  const int runs = (int)gridDim.x / Q;    // (the host launches a multiple of 8 Q workgroups when Q > 1)
+  const int per_wg = (((gP + runs - 1) / runs) + 1) & ~1;
+  const int c0 = run * per_wg;
   if (c0 >= gP) return;  // (the whole workgroup: nothing to add)
   const int c1 = c0 + per_wg < gP ? c0 + per_wg : gP;
   const int per_ps = (((c1 - c0 + PS - 1) / PS) + 1) & ~1;
@@ -255,29 +264,62 @@ __global__ __launch_bounds__(WG_TPB) void wgrad_direct_kernel(WgArgs g) {
     trip(std::true_type{}, base);
   }
 
-  // acc[a][b][r] = dW[nb + NTW*((r&3) + 8*(r>>2) + 4*h) + a][kb + KTW*j + b]; the PS partials of an output tile meet in LDS
-  for (int round = 0; round < PS; ++round) {
-    if (ps == round && (round == 0 || r0 < r1)) {
+  // The PS partial outputs are added pairwise through LDS (a tree: PS/2, PS/4 .. 1 writers per round, everybody else adds
+  // its partner's block into its registers; blocks in the accumulators' own layout, 16-byte accesses without bank
+  // conflicts).  The PS sequential rounds of read-modify-write this replaces took 15 us of a 95 us launch at PS = 8.
+  {
+    constexpr int BLK = NTW * KTW * 16 * 64;   // floats of one wave's accumulators
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    for (int s2 = PS / 2; s2 >= 1; s2 >>= 1) {
+      if (ps >= s2 && ps < 2 * s2) {
+        f32x4 *blk = reinterpret_cast<f32x4 *>(s_out + (size_t)((ps - s2) * WNK + sub) * BLK) + lane;
 #pragma unroll
-      for (int a = 0; a < NTW; ++a)
+        for (int a = 0; a < NTW; ++a)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float *row = s_out + (nb + NTW * ((r & 3) + 8 * (r >> 2) + 4 * h) + a) * K + kb + KTW * j;
+          for (int b = 0; b < KTW; ++b)
 #pragma unroll
-          for (int b = 0; b < KTW; ++b) {
-            if (round == 0) row[b] = acc[a][b][r];
-            else row[b] += acc[a][b][r];
-          }
-        }
+            for (int r4 = 0; r4 < 4; ++r4)
+              blk[((a * KTW + b) * 4 + r4) * 64] =
+                  f32x4{acc[a][b][4 * r4], acc[a][b][4 * r4 + 1], acc[a][b][4 * r4 + 2], acc[a][b][4 * r4 + 3]};
+      }
+      __syncthreads();
+      if (ps < s2) {
+        const f32x4 *blk = reinterpret_cast<const f32x4 *>(s_out + (size_t)(ps * WNK + sub) * BLK) + lane;
+#pragma unroll
+        for (int a = 0; a < NTW; ++a)
+#pragma unroll
+          for (int b = 0; b < KTW; ++b)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+              const f32x4 v = blk[((a * KTW + b) * 4 + r4) * 64];
+              acc[a][b][4 * r4] += v[0];
+              acc[a][b][4 * r4 + 1] += v[1];
+              acc[a][b][4 * r4 + 2] += v[2];
+              acc[a][b][4 * r4 + 3] += v[3];
+            }
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
-  const int total = N * K;
-  const int rot = (int)(((unsigned)blockIdx.x * 1024u) % (unsigned)total);  // workgroups finish together: not all on one line
+  // the totals (waves with ps = 0) in the sub-block's layout [SN][SK]:
+  // acc[a][b][r] = dW[nb + NTW*((r&3) + 8*(r>>2) + 4*h) + a][kb + KTW*j + b]
+  if (ps == 0) {
+#pragma unroll
+    for (int a = 0; a < NTW; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float *row = s_out + (nb - n0 + NTW * ((r & 3) + 8 * (r >> 2) + 4 * h) + a) * SK + (kb - k0) + KTW * j;
+#pragma unroll
+        for (int b = 0; b < KTW; ++b) row[b] = acc[a][b][r];
+      }
+  }
+  __syncthreads();
+  const int total = SN * SK, sk_log2 = 31 - __builtin_clz((unsigned)SK);   // (SK is a power of two: the host checks)
+  const int rot = (int)(((unsigned)run * 1024u) % (unsigned)total);  // workgroups finish together: not all on one line
   for (int i = t; i < total; i += WG_TPB) {
     int idx = i + rot;
     if (idx >= total) idx -= total;
-    atomicAdd(g.dw + idx, s_out[idx]);
+    atomicAdd(g.dw + (size_t)(n0 + (idx >> sk_log2)) * K + k0 + (idx & (SK - 1)), s_out[idx]);
   }
 }
 
@@ -299,6 +341,7 @@ static int wg_form(long long P, int K, int N, bool gen) {
   if ((long long)N * K > 32768) return 0;                                  // the output in LDS: 128 KB
   if (P * (long long)(N > K ? N : K) >= (1LL << 30) - (1 << 16)) return 0;   // 32-bit byte offsets (+ the look-ahead)
   if (gen && K != 64) return 0;
+  if ((K & (K - 1)) != 0) return 0;                                        // the closing loop splits an index by shifts
   const int w42 = N % 128 == 0 ? (N / 128) * (K / 64) : 0, w22 = (N / 64) * (K / 64);
   if (w42 == 1 || w42 == 2 || w42 == 4 || w42 == 8) return 1;
   if (w22 == 1 || w22 == 2 || w22 == 4 || w22 == 8) return 2;
@@ -307,16 +350,35 @@ static int wg_form(long long P, int K, int N, bool gen) {
 
 bool wg_wgrad_suits(long long P, int K, int N, bool gen) { return wg_form(P, K, N, gen) != 0; }
 
+#ifndef GB_WG_MAXQ
+#define GB_WG_MAXQ 4
+#endif
+
 template <int NTW, int KTW, int MODE>
-static void wg_launch(const WgArgs &g, int reserved, hipStream_t s) {
+static void wg_launch(WgArgs g, int reserved, hipStream_t s) {
   static std::atomic<unsigned long long> attr_set{0};
   auto kern = wgrad_direct_kernel<NTW, KTW, MODE>;
   allow_dynamic_lds(kern, 160 * 1024, attr_set);
-  const size_t lds = (size_t)g.N * g.K * sizeof(float);
   long long blocks = wg_num_cus(reserved);
   const long long most = (g.P + 2 * WG_WAVES * WG_DEPTH - 1) / (2 * WG_WAVES * WG_DEPTH);  // >= one loop trip per wave
   if (blocks > most) blocks = most;
   if (blocks < 1) blocks = 1;
+  // sub-blocks: as many as still leave a wave its 128 x 64 (64 x 64) tiles, the grid a multiple of 8 Q, and runs long
+  // enough to be worth their prologue; halve N first (dY is the wider operand of the shapes this serves)
+  g.qn = g.qk = 1;
+  while (g.qn * g.qk * 2 <= GB_WG_MAXQ) {
+    const int q2 = g.qn * g.qk * 2;
+    const bool cut_n = (g.N / g.qn) % (2 * 32 * NTW) == 0 && g.qn <= g.qk;
+    const bool cut_k = (g.K / g.qk) % (2 * 32 * KTW) == 0;
+    if (!cut_n && !cut_k) break;
+    if (blocks < 8 * q2 || g.P / (blocks / q2) < 512) break;
+    if (cut_n) g.qn *= 2; else g.qk *= 2;
+  }
+  const int Q = g.qn * g.qk;
+  if (Q > 1) blocks = blocks / (8 * Q) * (8 * Q);
+  const int wnk = (g.N / g.qn / (32 * NTW)) * (g.K / g.qk / (32 * KTW)), half_ps = WG_WAVES / wnk / 2;
+  // the sub-block in its own layout, or the PS/2 blocks of the first round of the closing tree (never more than 128 KB)
+  const size_t lds = (size_t)(g.N / g.qn) * (g.K / g.qk) * sizeof(float) * (half_ps > 1 ? half_ps : 1);
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WG_TPB), lds, s, g);
 }
 
@@ -327,7 +389,7 @@ bool wg_wgrad_try(const float *dy, const float *x, const float *aff, const float
   if (!form || !dy || !dw || (gen ? (!gen_w || !aff || x) : !x)) return false;
   auto al16 = [](const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
   if (!al16(dy) || (x && !al16(x)) || !al16(dw)) return false;
-  WgArgs g = {dy, x, aff, gen_x, gen_w, dw, P, N, K, rows_dev};
+  WgArgs g = {dy, x, aff, gen_x, gen_w, dw, P, N, K, rows_dev, 1, 1};
   const int mode = gen ? WG_GEN3 : (aff ? WG_AFF : WG_PLAIN);
 #define GB_WG(NTW_, KTW_)                                              \
   do {                                                                 \

@@ -3,10 +3,10 @@ still writing.
 
 The kernel requests its operands with inline-asm loads and waits with inline-asm `s_waitcnt vmcnt(N)`; the compiler does
 not know those registers are in flight, so a register copy (loop-carried value, coalescing decision) placed between a
-request and its wait would read stale data - silently.  This script walks the assembly of every wgrad_direct_kernel
-instantiation in program order, (loops: every block is walked as it is laid out, twice, so state carries over back
-edges that jump upwards), keeps the queue of outstanding asm loads, retires all but the youngest N at each asm
-`s_waitcnt vmcnt(N)`, and reports any other instruction that reads or writes an in-flight register.
+request and its wait would read stale data - silently.  This script walks every path of the control-flow graph of every
+wgrad_direct_kernel instantiation (basic blocks at the labels, edges from s_branch / s_cbranch / fall-through; a block is
+revisited for every distinct queue it is entered with), keeps the queue of outstanding asm loads, retires all but the
+youngest N at each asm `s_waitcnt vmcnt(N)`, and reports any other instruction that reads or writes an in-flight register.
 
 usage: wg_check_isa.py <gemm_wg .s file>      (hipcc -S / -save-temps output for gfx950); exit status 1 on a finding
 """
@@ -26,32 +26,56 @@ def regs(text):
     return out
 
 
-def check_kernel(name, lines):
-    findings = []
-    inflight = []          # [(set of registers, text)]
+def split_blocks(lines):
+    """[(label or None, [(line number, code, in_asm)])] in layout order; inline-asm markers folded into a flag."""
+    blocks = [(None, [])]
     in_asm = False
-    for rep in range(2):   # second pass: state carried over the loop back edges
-        for ln, raw in lines:
-            t = raw.strip()
-            if t.startswith(";;#ASMSTART"):
-                in_asm = True
-                continue
-            if t.startswith(";;#ASMEND"):
-                in_asm = False
-                continue
-            if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
-                continue
-            code = t.split(";")[0].strip()
-            if not code:
-                continue
+    for ln, raw in lines:
+        t = raw.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not t or t.startswith(";"):
+            continue
+        m = re.match(r"^(\.LBB\w+):", t)
+        if m:
+            blocks.append((m.group(1), []))
+            continue
+        if t.startswith(".") or t.endswith(":"):
+            continue
+        code = t.split(";")[0].strip()
+        if code:
+            blocks[-1][1].append((ln, code, in_asm))
+    return blocks
+
+
+def check_kernel(name, lines):
+    """Walk every path of the control-flow graph (states = the queue of outstanding asm loads; each (block, state) once)."""
+    blocks = split_blocks(lines)
+    index = {lab: i for i, (lab, _) in enumerate(blocks) if lab}
+    findings = []
+    seen = set()
+    work = [(0, ())]
+    while work:
+        bi, state = work.pop()
+        key = (bi, state)
+        if key in seen or len(seen) > 20000:
+            continue
+        seen.add(key)
+        inflight = [set(r) for r in state]
+        fall = True
+        for ln, code, in_asm in blocks[bi][1]:
             op = code.split()[0]
             if in_asm and op.startswith("global_load"):
                 dst = code.split(None, 1)[1].split(",")[0]
-                used = regs(code.split(",", 1)[1])
-                bad = used & set().union(*[r for r, _ in inflight]) if inflight else set()
+                busy = set().union(*inflight) if inflight else set()
+                bad = regs(code.split(",", 1)[1]) & busy
                 if bad and (ln, code, sorted(bad)) not in findings:
                     findings.append((ln, code, sorted(bad)))
-                inflight.append((regs(dst), code))
+                inflight.append(regs(dst))
                 continue
             if in_asm and op == "s_waitcnt":
                 m = re.search(r"vmcnt\((\d+)\)", code)
@@ -63,15 +87,25 @@ def check_kernel(name, lines):
                 inflight = []
                 continue
             if op == "s_endpgm":
-                inflight = []
+                fall = False
+                break
+            if op == "s_branch":
+                tgt = code.split()[1]
+                work.append((index[tgt], tuple(frozenset(r) for r in inflight)))
+                fall = False
+                break
+            if op.startswith("s_cbranch"):
+                tgt = code.split()[1]
+                work.append((index[tgt], tuple(frozenset(r) for r in inflight)))
                 continue
-            if not inflight:
-                continue
-            busy = set().union(*[r for r, _ in inflight])
-            bad = regs(code) & busy
-            if bad and (ln, code, sorted(bad)) not in findings:
-                findings.append((ln, code, sorted(bad)))
-    return findings
+            if inflight:
+                busy = set().union(*inflight)
+                bad = regs(code) & busy
+                if bad and (ln, code, sorted(bad)) not in findings:
+                    findings.append((ln, code, sorted(bad)))
+        if fall and bi + 1 < len(blocks):
+            work.append((bi + 1, tuple(frozenset(r) for r in inflight)))
+    return sorted(findings)
 
 
 def main(path):

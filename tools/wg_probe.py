@@ -8,8 +8,19 @@ P_ = ctypes.c_void_p
 so.gb_gemm_wgrad.argtypes = [P_, P_, P_, P_, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, P_, P_]
 so.gb_gemm_wgrad_gen3.argtypes = [P_, P_, P_, P_, P_, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, P_, P_]
 dev = "cuda:0"
+import ctypes as _c
+
+
+class GemmOpts(_c.Structure):
+    _fields_ = [("precision", _c.c_int), ("reserved_cus", _c.c_int), ("scratch", _c.c_void_p), ("scratch_bytes", _c.c_ulonglong),
+                ("rows_dev", _c.c_void_p), ("flags", _c.c_int)]
+
+
+flags = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # 4 = GB_GEMM_NO_DIRECT
+opts = _c.pointer(GemmOpts(0, 0, None, 0, None, flags))
 shapes = [(400000, 128, 256, "aff"), (400000, 64, 128, "gen3"), (524288, 64, 128, "aff"), (524288, 64, 64, "gen3"),
-          (131072, 128, 256, "aff"), (131072, 128, 128, "aff"), (400000, 128, 256, "plain")]
+          (131072, 128, 256, "aff"), (131072, 128, 128, "aff"), (400000, 128, 256, "plain"), (65536, 128, 256, "aff"),
+          (32768, 128, 256, "aff"), (32768, 128, 128, "aff"), (16384, 128, 256, "aff"), (32768, 64, 128, "aff")]
 for P, K, N, mode in shapes:
     dY = torch.randn(P, N, device=dev)
     X = torch.randn(P, K, device=dev)
@@ -21,9 +32,9 @@ for P, K, N, mode in shapes:
 
     def run():
         if mode == "gen3":
-            rc = so.gb_gemm_wgrad_gen3(dY.data_ptr(), x0.data_ptr(), w1.data_ptr(), aff.data_ptr(), dW.data_ptr(), P, K, N, None, st)
+            rc = so.gb_gemm_wgrad_gen3(dY.data_ptr(), x0.data_ptr(), w1.data_ptr(), aff.data_ptr(), dW.data_ptr(), P, K, N, opts, st)
         else:
-            rc = so.gb_gemm_wgrad(dY.data_ptr(), X.data_ptr(), aff.data_ptr() if mode == "aff" else None, dW.data_ptr(), P, K, N, None, st)
+            rc = so.gb_gemm_wgrad(dY.data_ptr(), X.data_ptr(), aff.data_ptr() if mode == "aff" else None, dW.data_ptr(), P, K, N, opts, st)
         assert rc == 0, rc
     for _ in range(3):
         run()

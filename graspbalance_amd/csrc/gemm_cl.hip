@@ -505,10 +505,10 @@ static int finalize_after(int rc, const GbBnFinalize *fin, const double *stats, 
 // 17.60 ms; configs[4] 25.83 / 25.65).  Products that NEED that kernel - a device-side row count, the generated first-layer
 // operand, the pooled epilogue - go there from 16 384 rows as before (rs_shape_ok).
 static constexpr long long RS_PAYS_FROM = 65536;
-// the register-direct wgrad (csrc/gemm_wg.hip): fp32, from WG_PAYS_FROM rows (or a device-side row count)
+// the register-direct wgrad (csrc/gemm_wg.hip): from WG_PAYS_FROM rows (or a device-side row count)
 constexpr long long WG_PAYS_FROM = 65536;
 static bool wg_pays(long long P, const GbGemmOpts *opts) {
-  return !opts_bf16(opts) && !(opts && (opts->flags & GB_GEMM_NO_DIRECT)) && (P >= WG_PAYS_FROM || opts_rows(opts) != nullptr);
+  return !(opts && (opts->flags & GB_GEMM_NO_DIRECT)) && (P >= WG_PAYS_FROM || opts_rows(opts) != nullptr);
 }
 static bool rs_pays(long long P, const GbGemmOpts *opts) { return P >= RS_PAYS_FROM || opts_rows(opts) != nullptr; }
 
@@ -652,7 +652,7 @@ extern "C" int gb_gemm_wgrad_gen3(const float *dy, const float *x0, const float 
   if (P < 0 || K < 1 || N < 1 || !dy || !x0 || !w1 || !ab1 || !dw || opts_bad(opts)) return GB_EINVAL;
   if (P == 0) return GB_OK;
   if (wg_pays(P, opts) && wg_wgrad_try(dy, nullptr, ab1, x0, w1, dw, P, K, N, opts_rows(opts), opts_reserved(opts),
-                                       as_stream(stream)))
+                                       as_stream(stream), opts_bf16(opts)))
     return check_launch("gb_gemm_wgrad_gen3");
   Operand a = {dy, N, P, N, nullptr, nullptr, nullptr};
   Operand b = {nullptr, K, P, K, ab1, x0, w1};
@@ -766,7 +766,7 @@ extern "C" int gb_gemm_wgrad(const float *dy, const float *x, const float *x_aff
   }
   // many rows: both operands straight from global memory into the matrix cores (csrc/gemm_wg.hip)
   if (wg_pays(P, opts) && wg_wgrad_try(dy, x, x_aff, nullptr, nullptr, dw, P, K, N, opts_rows(opts), opts_reserved(opts),
-                                       as_stream(stream)))
+                                       as_stream(stream), opts_bf16(opts)))
     return check_launch("gb_gemm_wgrad");
   if (!opts_rows(opts) && !opts_no_ring(opts) && P <= 131072) {
     // few-row products: split the P reduction for ~one round of workgroups (fp32 atomics into dW, as below)

@@ -83,9 +83,29 @@ __device__ __forceinline__ void wg_wait(A &a, B &b) {
   else asm volatile("s_waitcnt vmcnt(14)" : "+v"(a), "+v"(b));
 }
 
-template <int NTW, int KTW, int MODE>
-__global__ __launch_bounds__(WG_TPB) void wgrad_direct_kernel(WgArgs g) {
+// BF: both operands rounded to bf16 on their way into v_mfma_f32_32x32x16_bf16 (GbGemmOpts.precision = GB_PREC_BF16; fp32
+// accumulation).  That instruction takes 8 reduction indices per lane - lane (j, h) supplies rows p + 8h .. p + 8h + 7 of its
+// columns - so a step is 16 rows: 8 + 8 loads per lane and slot, 8 MFMAs of 32 cycles.  The product is then bound by
+// reading dY and X once (the matrix pipe is ~10 % busy): 4 waves per workgroup with up to 512 registers each keep 2 slots
+// (24 KB per wave) in flight.
+// ... and of a bf16 slot (8 + 8 loads): every register of the slot passes through the wait
+template <int N, typename A, typename B>
+__device__ __forceinline__ void wg_wait16(A (&a)[8], B (&b)[8]) {
+  static_assert(N == 0 || N == 16 || N == 32 || N == 48, "s_waitcnt immediates");
+#define GB_WG_SLOT_REGS "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), \
+                        "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7])
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" : GB_WG_SLOT_REGS);
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" : GB_WG_SLOT_REGS);
+  else if constexpr (N == 32) asm volatile("s_waitcnt vmcnt(32)" : GB_WG_SLOT_REGS);
+  else asm volatile("s_waitcnt vmcnt(48)" : GB_WG_SLOT_REGS);
+#undef GB_WG_SLOT_REGS
+}
+
+template <int NTW, int KTW, int MODE, bool BF>
+__global__ __launch_bounds__(BF ? 256 : WG_TPB) void wgrad_direct_kernel(WgArgs g) {
   extern __shared__ __attribute__((aligned(16))) float s_out[];  // [N][K]
+  constexpr int WAVES = BF ? 4 : WG_WAVES, TPB = 64 * WAVES;
+  constexpr int RSTEP = BF ? 16 : 2;   // rows of one step of a wave
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int j = lane & 31, h = lane >> 5;
@@ -99,18 +119,18 @@ __global__ __launch_bounds__(WG_TPB) void wgrad_direct_kernel(WgArgs g) {
   // are 8 apart in the grid - the same XCD, started together: the rows they share meet in that XCD's L2.  Fewer, longer
   // runs: Q times fewer atomics at the end.
   const int Q = g.qn * g.qk, SN = N / g.qn, SK = K / g.qk;
-  const int WK = SK / (32 * KTW), WNK = (SN / (32 * NTW)) * WK, PS = WG_WAVES / WNK;
+  const int WK = SK / (32 * KTW), WNK = (SN / (32 * NTW)) * WK, PS = WAVES / WNK;
   const int sub = wave % WNK, ps = wave / WNK;
   const int bq = (int)(blockIdx.x >> 3) % Q, run = ((int)(blockIdx.x >> 3) / Q) * 8 + (int)(blockIdx.x & 7);
   const int n0 = (bq / g.qk) * SN, k0 = (bq % g.qk) * SK;
   const int nb = n0 + (sub / WK) * 32 * NTW, kb = k0 + (sub % WK) * 32 * KTW;
-  // rows of this workgroup (an even number each), then of this wave's share of them
+  // rows of this workgroup (whole steps each), then of this wave's share of them
   const int runs = (int)gridDim.x / Q;    // (the host launches a multiple of 8 Q workgroups when Q > 1)
-  const int per_wg = (((gP + runs - 1) / runs) + 1) & ~1;
+  const int per_wg = (((gP + runs - 1) / runs) + RSTEP - 1) / RSTEP * RSTEP;
   const int c0 = run * per_wg;
   if (c0 >= gP) return;  // (the whole workgroup: nothing to add)
   const int c1 = c0 + per_wg < gP ? c0 + per_wg : gP;
-  const int per_ps = (((c1 - c0 + PS - 1) / PS) + 1) & ~1;
+  const int per_ps = (((c1 - c0 + PS - 1) / PS) + RSTEP - 1) / RSTEP * RSTEP;
   const int r0 = c0 + ps * per_ps;
   const int r1 = r0 + per_ps < c1 ? r0 + per_ps : c1;
   const int last = gP - 1;
@@ -149,6 +169,79 @@ __global__ __launch_bounds__(WG_TPB) void wgrad_direct_kernel(WgArgs g) {
       for (int q = 0; q < KTW; ++q) asm volatile("" : "+v"(gw[q][0]), "+v"(gw[q][1]), "+v"(gw[q][2]));
     }
     constexpr int BV = MODE == WG_GEN3 ? 3 : KTW;
+    if constexpr (BF) {
+      constexpr int D = 3;   // slots of 16 rows: 2 in flight while one is multiplied (a fourth slot spilled registers)
+      typedef typename WgVec<NTW>::T AV;
+      typedef typename WgVec<BV>::T BVT;
+      AV abuf[D][8];
+      BVT bbuf[D][8];
+#pragma unroll
+      for (int u = 0; u < D; ++u)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          abuf[u][i] = 0.f;
+          bbuf[u][i] = 0.f;
+        }
+      const unsigned a_pitch = (unsigned)N * 4u, b_pitch = (MODE == WG_GEN3 ? 3u : (unsigned)K) * 4u;
+      const unsigned a_lane = (unsigned)(nb + NTW * j) * 4u, b_lane = MODE == WG_GEN3 ? 0u : (unsigned)(kb + KTW * j) * 4u;
+      int next_row = r0 + 8 * h;   // this lane's first row of the next slot to request (its rows: + 0 .. 7)
+      auto request = [&](AV (&a)[8], BVT (&b)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const unsigned rc = (unsigned)(next_row + i < last ? next_row + i : last);
+          wg_load<NTW>(a[i], g.dy, rc * a_pitch + a_lane);
+          if constexpr (MODE == WG_GEN3) wg_load<3>(b[i], g.gen_x, rc * b_pitch);
+          else wg_load<KTW>(b[i], g.x, rc * b_pitch + b_lane);
+        }
+        next_row += 16;
+      };
+      // one step: wait for the slot (N younger loads may stay in flight), operands to bf16, 8 MFMAs
+      auto multiply = [&](auto younger, AV (&a)[8], BVT (&b)[8], int base, bool masked) {
+        constexpr int YOUNGER = decltype(younger)::value;
+        wg_wait16<YOUNGER>(a, b);
+#pragma unroll
+        for (int qb = 0; qb < KTW; ++qb) {
+          bf16x8 b8;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            float v;
+            if constexpr (MODE == WG_GEN3) v = wg_lin3(b[i][0], b[i][1], b[i][2], gw[qb][0], gw[qb][1], gw[qb][2]);
+            else v = b[i][qb];
+            if constexpr (MODE != WG_PLAIN) {
+              const float z = fa[qb] * v + fb[qb];
+              v = z > 0.f ? z : 0.f;
+            }
+            b8[i] = (__bf16)v;
+          }
+#pragma unroll
+          for (int qa = 0; qa < NTW; ++qa) {
+            bf16x8 a8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              float v = a[i][qa];
+              if (masked && base + 8 * h + i >= r1) v = 0.f;
+              a8[i] = (__bf16)v;
+            }
+            acc[qa][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc[qa][qb], 0, 0, 0);
+          }
+        }
+      };
+#pragma unroll
+      for (int u = 0; u < D; ++u) request(abuf[u], bbuf[u]);
+      int base = r0;
+      // every trip but the last requests again what it has multiplied; the last one counts its waits down (see below)
+      for (; base + 16 * D < r1; base += 16 * D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+          multiply(std::integral_constant<int, 16 * (D - 1)>{}, abuf[u], bbuf[u], base + 16 * u, false);
+          request(abuf[u], bbuf[u]);
+        }
+      }
+      multiply(std::integral_constant<int, 32>{}, abuf[0], bbuf[0], base, true);
+      multiply(std::integral_constant<int, 16>{}, abuf[1], bbuf[1], base + 16, true);
+      multiply(std::integral_constant<int, 0>{}, abuf[2], bbuf[2], base + 32, true);
+      static_assert(D == 3, "the last trip is written out for three slots");
+    } else {
     constexpr int D = WG_DEPTH;
     typedef typename WgVec<NTW>::T AV;
     typedef typename WgVec<BV>::T BVT;
@@ -262,6 +355,7 @@ __global__ __launch_bounds__(WG_TPB) void wgrad_direct_kernel(WgArgs g) {
     int base = r0;
     for (; base + 2 * D < r1; base += 2 * D) trip(std::false_type{}, base);
     trip(std::true_type{}, base);
+    }
   }
 
   // The PS partial outputs are added pairwise through LDS (a tree: PS/2, PS/4 .. 1 writers per round, everybody else adds
@@ -316,7 +410,7 @@ __global__ __launch_bounds__(WG_TPB) void wgrad_direct_kernel(WgArgs g) {
   __syncthreads();
   const int total = SN * SK, sk_log2 = 31 - __builtin_clz((unsigned)SK);   // (SK is a power of two: the host checks)
   const int rot = (int)(((unsigned)run * 1024u) % (unsigned)total);  // workgroups finish together: not all on one line
-  for (int i = t; i < total; i += WG_TPB) {
+  for (int i = t; i < total; i += TPB) {
     int idx = i + rot;
     if (idx >= total) idx -= total;
     atomicAdd(g.dw + (size_t)(n0 + (idx >> sk_log2)) * K + k0 + (idx & (SK - 1)), s_out[idx]);
@@ -335,70 +429,95 @@ static int wg_num_cus(int reserved) {
   return (reserved > 0 && n - reserved >= 16) ? n - reserved : n;
 }
 
-// 0: no; 1: 128 x 64 wave tiles (NTW 4, KTW 2); 2: 64 x 64 (NTW 2, KTW 2)
-static int wg_form(long long P, int K, int N, bool gen) {
-  if (P < 1 || N < 64 || K < 64 || N % 64 != 0 || K % 64 != 0) return 0;
-  if ((long long)N * K > 32768) return 0;                                  // the output in LDS: 128 KB
-  if (P * (long long)(N > K ? N : K) >= (1LL << 30) - (1 << 16)) return 0;   // 32-bit byte offsets (+ the look-ahead)
-  if (gen && K != 64) return 0;
-  if ((K & (K - 1)) != 0) return 0;                                        // the closing loop splits an index by shifts
-  const int w42 = N % 128 == 0 ? (N / 128) * (K / 64) : 0, w22 = (N / 64) * (K / 64);
-  if (w42 == 1 || w42 == 2 || w42 == 4 || w42 == 8) return 1;
-  if (w22 == 1 || w22 == 2 || w22 == 4 || w22 == 8) return 2;
-  return 0;
-}
-
-bool wg_wgrad_suits(long long P, int K, int N, bool gen) { return wg_form(P, K, N, gen) != 0; }
-
 #ifndef GB_WG_MAXQ
 #define GB_WG_MAXQ 4
 #endif
 
-template <int NTW, int KTW, int MODE>
-static void wg_launch(WgArgs g, int reserved, hipStream_t s) {
-  static std::atomic<unsigned long long> attr_set{0};
-  auto kern = wgrad_direct_kernel<NTW, KTW, MODE>;
-  allow_dynamic_lds(kern, 160 * 1024, attr_set);
-  long long blocks = wg_num_cus(reserved);
-  const long long most = (g.P + 2 * WG_WAVES * WG_DEPTH - 1) / (2 * WG_WAVES * WG_DEPTH);  // >= one loop trip per wave
-  if (blocks > most) blocks = most;
-  if (blocks < 1) blocks = 1;
-  // sub-blocks: as many as still leave a wave its 128 x 64 (64 x 64) tiles, the grid a multiple of 8 Q, and runs long
-  // enough to be worth their prologue; halve N first (dY is the wider operand of the shapes this serves)
-  g.qn = g.qk = 1;
-  while (g.qn * g.qk * 2 <= GB_WG_MAXQ) {
-    const int q2 = g.qn * g.qk * 2;
-    const bool cut_n = (g.N / g.qn) % (2 * 32 * NTW) == 0 && g.qn <= g.qk;
-    const bool cut_k = (g.K / g.qk) % (2 * 32 * KTW) == 0;
-    if (!cut_n && !cut_k) break;
-    if (blocks < 8 * q2 || g.P / (blocks / q2) < 512) break;
-    if (cut_n) g.qn *= 2; else g.qk *= 2;
+// How a product is cut: wave tiles of 128 x 64 (form 1: NTW 4, KTW 2) or 64 x 64 (form 2), the output in qn x qk
+// sub-blocks (one per workgroup of a run of rows), a sub-block's wave tiles a divisor of the workgroup's waves.
+struct WgCut {
+  int form, qn, qk;
+};
+
+static bool wg_cut(long long P, int K, int N, bool gen, int waves, long long blocks, WgCut *cut) {
+  if (P < 1 || N < 64 || K < 64 || N % 64 != 0 || K % 64 != 0) return false;
+  if (P * (long long)(N > K ? N : K) >= (1LL << 30) - (1 << 16)) return false;   // 32-bit byte offsets (+ the look-ahead)
+  if (gen && K != 64) return false;
+  if ((K & (K - 1)) != 0) return false;                                        // the closing loop splits an index by shifts
+  for (int form = 1; form <= 2; ++form) {
+    const int ntw = form == 1 ? 4 : 2, ktw = 2;
+    if (N % (32 * ntw) != 0) continue;
+    int qn = 1, qk = 1;
+    auto sets = [&]() { return (N / qn / (32 * ntw)) * (K / qk / (32 * ktw)); };
+    auto cut_once = [&]() {   // halve N first (dY is the wider operand of the shapes this serves)
+      if ((N / qn) % (2 * 32 * ntw) == 0 && qn <= qk) { qn *= 2; return true; }
+      if ((K / qk) % (2 * 32 * ktw) == 0) { qk *= 2; return true; }
+      if ((N / qn) % (2 * 32 * ntw) == 0) { qn *= 2; return true; }
+      return false;
+    };
+    // as many sub-blocks as leave a run of rows worth its prologue, the grid a multiple of 8 Q ...
+    while (qn * qk * 2 <= GB_WG_MAXQ && blocks >= 8 * qn * qk * 2 && P / (blocks / (qn * qk * 2)) >= 512)
+      if (!cut_once()) break;
+    // ... and at least as many as make a sub-block fit a workgroup (its wave tiles, its 128 KB of LDS)
+    while (sets() > waves || (long long)(N / qn) * (K / qk) > 32768)
+      if (qn * qk * 2 > 64 || blocks < 8 * qn * qk * 2 || !cut_once()) break;
+    const int t = sets();
+    if (t > waves || waves % t != 0 || (long long)(N / qn) * (K / qk) > 32768) continue;
+    *cut = {form, qn, qk};
+    return true;
   }
+  return false;
+}
+
+bool wg_wgrad_suits(long long P, int K, int N, bool gen) {
+  WgCut c;
+  return wg_cut(P, K, N, gen, WG_WAVES, 256, &c);
+}
+
+template <int NTW, int KTW, int MODE, bool BF>
+static void wg_launch(WgArgs g, long long blocks, hipStream_t s) {
+  static std::atomic<unsigned long long> attr_set{0};
+  auto kern = wgrad_direct_kernel<NTW, KTW, MODE, BF>;
+  allow_dynamic_lds(kern, 160 * 1024, attr_set);
+  constexpr int WAVES = BF ? 4 : WG_WAVES;
   const int Q = g.qn * g.qk;
   if (Q > 1) blocks = blocks / (8 * Q) * (8 * Q);
-  const int wnk = (g.N / g.qn / (32 * NTW)) * (g.K / g.qk / (32 * KTW)), half_ps = WG_WAVES / wnk / 2;
+  const int wnk = (g.N / g.qn / (32 * NTW)) * (g.K / g.qk / (32 * KTW)), half_ps = WAVES / wnk / 2;
   // the sub-block in its own layout, or the PS/2 blocks of the first round of the closing tree (never more than 128 KB)
   const size_t lds = (size_t)(g.N / g.qn) * (g.K / g.qk) * sizeof(float) * (half_ps > 1 ? half_ps : 1);
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WG_TPB), lds, s, g);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * WAVES), lds, s, g);
 }
 
 bool wg_wgrad_try(const float *dy, const float *x, const float *aff, const float *gen_x, const float *gen_w, float *dw,
-                  long long P, int K, int N, const long long *rows_dev, int reserved_cus, hipStream_t s) {
+                  long long P, int K, int N, const long long *rows_dev, int reserved_cus, hipStream_t s, bool bf16) {
   const bool gen = gen_x != nullptr;
-  const int form = wg_form(P, K, N, gen);
-  if (!form || !dy || !dw || (gen ? (!gen_w || !aff || x) : !x)) return false;
+  if (!dy || !dw || (gen ? (!gen_w || !aff || x) : !x)) return false;
   auto al16 = [](const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
   if (!al16(dy) || (x && !al16(x)) || !al16(dw)) return false;
-  WgArgs g = {dy, x, aff, gen_x, gen_w, dw, P, N, K, rows_dev, 1, 1};
+  const int waves = bf16 ? 4 : WG_WAVES;
+  long long blocks = wg_num_cus(reserved_cus);
+  const long long rows_per_trip = (bf16 ? 16 * 3 : 2 * WG_DEPTH) * waves;   // >= one loop trip per wave
+  const long long most = (P + rows_per_trip - 1) / rows_per_trip;
+  if (blocks > most) blocks = most;
+  if (blocks < 1) blocks = 1;
+  WgCut cut;
+  if (!wg_cut(P, K, N, gen, waves, blocks, &cut)) return false;
+  WgArgs g = {dy, x, aff, gen_x, gen_w, dw, P, N, K, rows_dev, cut.qn, cut.qk};
   const int mode = gen ? WG_GEN3 : (aff ? WG_AFF : WG_PLAIN);
-#define GB_WG(NTW_, KTW_)                                              \
-  do {                                                                 \
-    if (mode == WG_GEN3) wg_launch<NTW_, KTW_, WG_GEN3>(g, reserved_cus, s);      \
-    else if (mode == WG_AFF) wg_launch<NTW_, KTW_, WG_AFF>(g, reserved_cus, s);   \
-    else wg_launch<NTW_, KTW_, WG_PLAIN>(g, reserved_cus, s);                     \
+#define GB_WG3(NTW_, KTW_, BF_)                                                \
+  do {                                                                         \
+    if (mode == WG_GEN3) wg_launch<NTW_, KTW_, WG_GEN3, BF_>(g, blocks, s);    \
+    else if (mode == WG_AFF) wg_launch<NTW_, KTW_, WG_AFF, BF_>(g, blocks, s); \
+    else wg_launch<NTW_, KTW_, WG_PLAIN, BF_>(g, blocks, s);                   \
   } while (0)
-  if (form == 1) GB_WG(4, 2); else GB_WG(2, 2);
+#define GB_WG(NTW_, KTW_)                    \
+  do {                                       \
+    if (bf16) GB_WG3(NTW_, KTW_, true);      \
+    else GB_WG3(NTW_, KTW_, false);          \
+  } while (0)
+  if (cut.form == 1) GB_WG(4, 2); else GB_WG(2, 2);
 #undef GB_WG
+#undef GB_WG3
   return true;
 }
 

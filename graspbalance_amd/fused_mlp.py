@@ -353,8 +353,8 @@ def _gemm_meta(kind, P, K, N, fused=False, aff=False, rows_dev=None, prec=None):
         which = 1      # a device-side row count: the row-streaming kernel whatever the capacity
     if which == 2 and (_GEMM_FLAGS & _lib.GEMM_NO_RING or rows_dev is not None):   # (round 5: the ring kernel has a bf16 form)
         which = 0
-    if which == 4 and (_GEMM_FLAGS & _lib.GEMM_NO_DIRECT or (_prec() if prec is None else prec) == _lib.PREC_BF16):
-        which = 0      # (prec: a backward node multiplies at its forward's precision, not at the thread's current one)
+    if which == 4 and _GEMM_FLAGS & _lib.GEMM_NO_DIRECT:
+        which = 0
     kernel = ("gemm_cl_kernel", "gemm_rs_kernel", "gemm_ring_kernel", "wgrad_smallk_kernel", "wgrad_direct_kernel")[which]
     return {"flop": 2.0 * P * K * N, "pkn": (P, K, N), "kernel": kernel}
 

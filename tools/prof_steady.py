@@ -15,7 +15,7 @@ from prof_summary import category, short
 def main(path, nsteps=3, top=30):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    marks = [i for i, r in enumerate(rows) if "fps_reg_kernel<1024, 20>" in r["Kernel_Name"] or "fps_rows_kernel<12, 32" in r["Kernel_Name"]
+    marks = [i for i, r in enumerate(rows) if "fps_reg_kernel<1024, 20>" in r["Kernel_Name"] or "fps_rows_kernel" in r["Kernel_Name"]
              or "fps_pruned_kernel<1024, 20>" in r["Kernel_Name"] or "fps_pruned_big_kernel" in r["Kernel_Name"]
              or "fps_multi_kernel<1024, 20>" in r["Kernel_Name"]]
     if len(marks) < nsteps + 1:

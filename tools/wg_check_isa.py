@@ -125,6 +125,13 @@ def main(path):
         print("no wgrad_direct_kernel in", path)
         return 1
     status = 0
+    # no scratch memory either: a spill is a store of a register - possibly of one still in flight
+    text = open(path).read()
+    for m in re.finditer(r"\.amdhsa_kernel (_ZN2gb19wgrad_direct_kernel\w+)(.*?)\.end_amdhsa_kernel", text, flags=re.S):
+        sz = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m.group(2))
+        if sz and int(sz.group(1)) != 0:
+            print("%s: %s bytes of scratch per lane (spilled registers)" % (m.group(1), sz.group(1)))
+            status = 1
     for name, lines in kernels.items():
         f = check_kernel(name, lines)
         print("%s: %d instructions, %s" % (name, len(lines), "ok" if not f else "%d finding(s)" % len(f)))

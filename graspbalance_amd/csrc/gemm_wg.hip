@@ -1,4 +1,4 @@
-// Tall weight-gradient products without LDS staging (gfx950, fp32 MFMA).
+// Tall weight-gradient products without LDS staging (gfx950; fp32 MFMA, or bf16 MFMA with fp32 accumulation).
 //
 //   dW (N,K) += dY (P,N)^T f(X (P,K)),   P >> N, K        (the reference reaches it as the weight gradient of its 1x1
 //   convolutions through torch autograd: pytorch_utils.py:61-113 under pointnet2_modules.py:176-188 and modules.py:104-124)
@@ -10,17 +10,24 @@
 // (one 16-byte load) and KTW consecutive X columns (one 8-byte load) of its row, which are the operands of NTW x KTW
 // MFMAs (column c of a lane's vector belongs to tile c: tile qn holds the output rows n = nb + NTW*m + qn - a permutation
 // of the output that only the final write has to know).  Per pair of rows a wave issues 2 loads and 8 MFMAs (512 cycles
-// of the matrix pipe); 8 row pairs are in flight per wave (48 registers), two waves per SIMD.  No LDS, no barriers and no
-// ds_read in the loop; every element of dY and X leaves HBM once (waves that share rows sit in one workgroup: L1 / L2).
+// of the matrix pipe); 6 row pairs are requested ahead per wave (36 registers), two waves per SIMD.  No LDS, no barriers
+// and no ds_read in the loop; every element of dY and X leaves HBM once (rows shared by workgroups meet in an XCD's L2).
 // f: the previous layer's BatchNorm + ReLU applied in registers (2 VALU operations per X element); or X is GENERATED from
 // the row's xyz (the folded 3-input first layer, gemm_rs.hip's lin3) - 5 operations per element against 4 x 64 cycles
 // of MFMA that consume it.
 //
-// A workgroup = 8 waves over one contiguous run of rows: WN x WK waves tile the N x K output (each 128 x 64 or 64 x 64),
-// the other factor PS = 8 / (WN * WK) splits the run of rows.  At the end the PS partial outputs are added through LDS
-// (a pairwise tree), the totals are laid out as the output is and leave as N*K coalesced fp32 atomics per workgroup, each
-// workgroup starting at a different offset - 256 x N*K atomics at the 1.3 TB/s the chip sustains for them: 7 - 26 us of
-// the launch, its largest overhead (measured with the epilogue compiled out).  One workgroup per CU.
+// A workgroup = 8 waves over a run of rows of ONE sub-block of the output (the output is cut into up to four): WN x WK
+// waves tile the sub-block (each 128 x 64 or 64 x 64), the other factor PS = 8 / (WN * WK) splits the run of rows.  At the
+// end the PS partial outputs are added through LDS (a pairwise tree), the totals are laid out as the sub-block is and
+// leave as coalesced fp32 atomics, each workgroup starting at a different offset - the chip retires those at 1.3 TB/s:
+// 256 x N*K of them were 26 us of a 250 us launch (measured with the epilogue compiled out), the sub-blocks cut that by
+// four.  One workgroup per CU.
+//
+// BF (GbGemmOpts.precision = GB_PREC_BF16): both operands rounded to bf16 on their way into v_mfma_f32_32x32x16_bf16, fp32
+// accumulation.  That instruction takes 8 reduction indices per lane - lane (j, h) supplies rows p + 8h .. p + 8h + 7 of
+// its columns - so a step is 16 rows: 8 + 8 loads per lane and slot, 8 MFMAs of 32 cycles.  The product is then bound by
+// reading dY and X once (the matrix pipe is ~10 % busy): 4 waves per workgroup with up to 512 registers each keep 2 slots
+// (24 KB per wave) in flight.
 #include "gb_common.h"
 #include "gemm_wg.h"
 
@@ -83,11 +90,6 @@ __device__ __forceinline__ void wg_wait(A &a, B &b) {
   else asm volatile("s_waitcnt vmcnt(14)" : "+v"(a), "+v"(b));
 }
 
-// BF: both operands rounded to bf16 on their way into v_mfma_f32_32x32x16_bf16 (GbGemmOpts.precision = GB_PREC_BF16; fp32
-// accumulation).  That instruction takes 8 reduction indices per lane - lane (j, h) supplies rows p + 8h .. p + 8h + 7 of its
-// columns - so a step is 16 rows: 8 + 8 loads per lane and slot, 8 MFMAs of 32 cycles.  The product is then bound by
-// reading dY and X once (the matrix pipe is ~10 % busy): 4 waves per workgroup with up to 512 registers each keep 2 slots
-// (24 KB per wave) in flight.
 // ... and of a bf16 slot (8 + 8 loads): every register of the slot passes through the wait
 template <int N, typename A, typename B>
 __device__ __forceinline__ void wg_wait16(A (&a)[8], B (&b)[8]) {

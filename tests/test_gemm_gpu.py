@@ -235,6 +235,31 @@ def test_tall_wgrad_register_direct_kernel(P, K, N, mode):
         assert float((dW.double() - ref).abs().max()) / scale < (2e-2 if bf16 else 1e-5) if rows else float(dW.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("reserved", [0, 8, 37, 128])
+@pytest.mark.parametrize("rows", [1, 17, 1000, 65535, 200001])
+def test_tall_wgrad_direct_with_reserved_cus_and_few_actual_rows(reserved, rows):
+    """The direct wgrad sizes its grid from (CUs - reserved) and cuts the output into sub-blocks only when the grid is a
+    multiple of 8 per sub-block; the actual row count may be tiny against the capacity (a device-side count): every
+    combination must give the fp64 product of exactly the first `rows` rows."""
+    L = _lib()
+    P, K, N = 200001, 128, 256
+    torch.manual_seed(rows + reserved)
+    dY = torch.randn(P, N, device=DEV)
+    X = torch.randn(P, K, device=DEV)
+    dY[rows:] = float("nan")
+    X[rows:] = float("nan")
+    aff = torch.cat([torch.randn(K, device=DEV), torch.randn(K, device=DEV)])
+    rows_dev = torch.tensor([rows], dtype=torch.int64, device=DEV)
+    ref = dY[:rows].double().t() @ torch.relu(aff[:K] * X[:rows] + aff[K:]).double()
+    for prec, tol in ((L.PREC_F32, 1e-5), (L.PREC_BF16, 2e-2)):
+        dW = torch.zeros(N, K, device=DEV)
+        o = ctypes.pointer(L.GemmOpts(prec, reserved, None, 0, L.ptr(rows_dev), 0))
+        L.check(L.lib().gb_gemm_wgrad(L.ptr(dY), L.ptr(X), L.ptr(aff), L.ptr(dW), P, K, N, o, None), "wgrad")
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(dW).all())
+        assert float((dW.double() - ref).abs().max()) / (float(ref.abs().max()) + 1e-12) < tol
+
+
 @pytest.mark.parametrize("P,K,N", [(1024, 1024, 256), (1024, 256, 1024), (4096, 512, 128), (2048, 1024, 256)])
 def test_split_reduction_products_are_bit_reproducible(P, K, N):
     """Few-tile / long-reduction forward and dgrad products split the reduction over workgroups when the CALLER hands

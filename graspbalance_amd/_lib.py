@@ -69,6 +69,7 @@ SIGNATURES = {
     "gb_la_col_stats": [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P],
     "gb_la_pool": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
     "gb_la_pool_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
+    "gb_la_pool_bwd_perm": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
     "gb_la_point_grad": [_P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _P, _P],
     "gb_la_wx_grad": [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P],
     "gb_la_wx_grad_g": [_P, _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P],

@@ -341,6 +341,152 @@ __global__ __launch_bounds__(LA_TPB) void la_pool_bwd_kernel(const float *__rest
   }
 }
 
+// The same with the scatter pre-aggregated in LDS (round 5).  The launch above is bound by its atomics: a lane's update
+// goes to the winner point's row of sg - a different cache line for almost every lane - and the chip retires ~11 G
+// atomic line transactions per second whether a line carries one float or 32.  Here a workgroup takes LA_GB rows that are
+// NEIGHBOURS IN SPACE (`perm`: gb_fps_row_order of the stage's centres, one launch per stage): their neighbourhoods
+// overlap, so their winners are few distinct points.  The winners get a slot each (LDS hash of the point ids), the
+// contributions are added into acc[slot][c] by the thread that owns column c (plain read-modify-write: one thread per
+// column and row group, the groups take turns), and every touched slot leaves as one DENSE row of atomics: 8 lines per
+// point instead of one line per (row, column).  Slots beyond the table's capacity fall back to the direct scatter.
+constexpr int LA_AG_ACC_MAX = 32768;   // acc [umax][C] floats: 64 KB (two workgroups per CU) or 128 KB, the host's choice
+template <int ROWS>   // rows of a workgroup: 16, or 32 for narrow layers (two row groups: as many rows per thread)
+__global__ __launch_bounds__(LA_TPB) void la_pool_bwd_agg_kernel(const float *__restrict__ dout, const float *__restrict__ out,
+                                                                  const int32_t *__restrict__ arg,
+                                                                  const float *__restrict__ G, const float *__restrict__ xyz,
+                                                                  const float *__restrict__ centres,
+                                                                  const int32_t *__restrict__ idx,
+                                                                  const float *__restrict__ wx, const float *__restrict__ ab,
+                                                                  const int32_t *__restrict__ perm,
+                                                                  float *__restrict__ sg, double *__restrict__ red, int n,
+                                                                  int m, int ns, int C, int mode, float scale,
+                                                                  int acc_floats) {
+  extern __shared__ float la_lds[];
+  constexpr int LA_AG_HS = ROWS * 64;   // hash slots: >= ROWS * LA_MAX_NS entries can be distinct
+  constexpr int HS_SHIFT = ROWS == 32 ? 21 : 22;   // 32 - log2(LA_AG_HS)
+  static_assert(ROWS == 16 || ROWS == 32, "hash shift");
+  const int umax = acc_floats / C;
+  float *acc = la_lds;                                              // [umax][C]
+  int *hkey = reinterpret_cast<int *>(la_lds + acc_floats);         // [LA_AG_HS] point id or -1
+  int *hval = hkey + LA_AG_HS;                                      // [LA_AG_HS] slot of that point
+  int *ids = hval + LA_AG_HS;                                       // [umax] point id of a slot
+  int *counter = ids + umax;
+  const int t = threadIdx.x;
+  for (int i = t; i < LA_AG_HS; i += LA_TPB) hkey[i] = -1;
+  if (t == 0) *counter = 0;
+  const int lanes_c = C < LA_TPB ? C : LA_TPB;   // (C <= LA_TPB here: the host checks)
+  int groups = LA_TPB / lanes_c;
+  if (groups > ROWS / LA_U) groups = ROWS / LA_U;   // (a thread takes whole batches of LA_U rows)
+  while (ROWS % groups != 0) --groups;
+  const int grp = t / lanes_c, c = t % lanes_c;
+  const bool worker = grp < groups;
+  constexpr int RMAX = 16;      // rows of one thread at most
+  const int per = ROWS / groups;   // (<= RMAX: the host pairs ROWS = 32 with two or more row groups)
+  // the rows of this workgroup: ROWS consecutive entries of the cloud's spatial order (m % ROWS == 0: one cloud)
+  const long long e0 = (long long)blockIdx.x * ROWS;
+  const int bi = (int)(e0 / m);
+  float gsave[RMAX];
+  int idsave[RMAX];
+#pragma unroll
+  for (int i = 0; i < RMAX; ++i) { gsave[i] = 0.f; idsave[i] = 0; }
+  __syncthreads();
+  if (worker) {
+    const float w0 = wx[c * 3], w1 = wx[c * 3 + 1], w2 = wx[c * 3 + 2];
+    const float mean = ab[2 * C + c], rstd = ab[3 * C + c];
+    double accr[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i0 = 0; i0 < RMAX; i0 += LA_U) {
+      if (i0 < per) {
+        long long rr[LA_U];
+        float g[LA_U];
+        int ar[LA_U], id[LA_U];
+#pragma unroll
+        for (int u = 0; u < LA_U; ++u) {
+          const bool live = i0 + u < per;
+          rr[u] = (long long)bi * m + perm[e0 + grp * per + (live ? i0 + u : 0)];
+          const float o = out[rr[u] * C + c];
+          const float dv = dout[rr[u] * C + c];
+          ar[u] = arg[rr[u] * C + c];
+          g[u] = (live && o > 0.f) ? dv : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < LA_U; ++u) id[u] = idx[rr[u] * ns + ar[u]];
+        float d[LA_U][3], gv[LA_U];
+#pragma unroll
+        for (int u = 0; u < LA_U; ++u) {
+          la_dp(xyz, centres, bi, n, rr[u], id[u], mode, scale, d[u]);
+          gv[u] = G[((size_t)bi * n + id[u]) * C + c];
+        }
+#pragma unroll
+        for (int u = 0; u < LA_U; ++u) {
+          gsave[i0 + u] = g[u];
+          idsave[i0 + u] = id[u];
+          if (g[u] != 0.f) {
+            const float y = ((gv[u] + d[u][0] * w0) + d[u][1] * w1) + d[u][2] * w2;
+            const float xhat = (y - mean) * rstd;
+            accr[0] += g[u];
+            accr[1] += g[u] * xhat;
+            accr[2] += g[u] * d[u][0];
+            accr[3] += g[u] * d[u][1];
+            accr[4] += g[u] * d[u][2];
+            // claim a hash slot for the winner (keys only: the slot numbers are dealt once all keys are in)
+            unsigned hsl = ((unsigned)id[u] * 2654435761u) >> HS_SHIFT;
+            while (true) {
+              const int old = atomicCAS(hkey + hsl, -1, id[u]);
+              if (old == -1 || old == id[u]) break;
+              hsl = (hsl + 1) & (LA_AG_HS - 1);
+            }
+          }
+        }
+      }
+    }
+    // the column sums: one atomic per column and WORKGROUP (same-address fp64 atomics serialise, ~47 ns each: with the
+    // scatter out of the way 1024 contributions per address were the first stage's whole launch) - the row groups meet in
+    // LDS first (acc is not in use yet)
+    double *gsum = reinterpret_cast<double *>(acc);   // [groups][5][C]
+#pragma unroll
+    for (int i = 0; i < 5; ++i) gsum[((size_t)grp * 5 + i) * C + c] = accr[i];
+  }
+  __syncthreads();
+  if (worker && grp == 0) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      double v = 0.0;
+      for (int gi = 0; gi < groups; ++gi) v += reinterpret_cast<double *>(acc)[((size_t)gi * 5 + i) * C + c];
+      atomicAdd(red + (size_t)i * C + c, v);
+    }
+  }
+  for (int i = t; i < LA_AG_HS; i += LA_TPB)
+    if (hkey[i] != -1) {
+      const int tk = atomicAdd(counter, 1);
+      hval[i] = tk;
+      if (tk < umax) ids[tk] = hkey[i];
+    }
+  __syncthreads();
+  const int used = *counter < umax ? *counter : umax;
+  for (int i = t; i < used * C; i += LA_TPB) acc[i] = 0.f;
+  __syncthreads();
+  for (int turn = 0; turn < groups; ++turn) {
+    if (worker && grp == turn) {
+#pragma unroll
+      for (int i = 0; i < RMAX; ++i) {
+        if (i < per && gsave[i] != 0.f) {
+          unsigned hsl = ((unsigned)idsave[i] * 2654435761u) >> HS_SHIFT;
+          while (hkey[hsl] != idsave[i]) hsl = (hsl + 1) & (LA_AG_HS - 1);
+          const int tk = hval[hsl];
+          if (tk < umax) acc[tk * C + c] += gsave[i];
+          else atomicAdd(sg + ((size_t)bi * n + idsave[i]) * C + c, gsave[i]);   // (table full: the direct scatter)
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = t; i < used * C; i += LA_TPB) {
+    const float v = acc[i];
+    if (v != 0.f) atomicAdd(sg + ((size_t)bi * n + ids[i / C]) * C + (i % C), v);
+  }
+}
+
 // dG[i, c] = a (sg - cnt m1 - m2 rstd (cnt (G - mean) + D.Wx))      (training: m1 = dbeta/P, m2 = dgamma/P; eval: 0)
 __global__ __launch_bounds__(LA_TPB) void la_point_grad_kernel(const float *__restrict__ sg, const float *__restrict__ G,
                                                                 const float *__restrict__ cnt,
@@ -494,6 +640,33 @@ extern "C" int gb_la_pool_bwd(const float *dout, const float *out, const int32_t
   hipLaunchKernelGGL(la_pool_bwd_kernel, dim3((unsigned)((R + LA_GB - 1) / LA_GB)), dim3(LA_TPB), 0, as_stream(stream),
                      dout, out, arg, G, xyz, centres, idx, wx, ab, sg, red, n, m, ns, C, mode, scale, R);
   return check_launch("gb_la_pool_bwd");
+}
+
+extern "C" int gb_la_pool_bwd_perm(const float *dout, const float *out, const int32_t *arg, const float *G,
+                                   const float *xyz, const float *centres, const int32_t *idx, const float *wx,
+                                   const float *ab, const int32_t *perm, float *sg, double *red, int b, int n, int m,
+                                   int ns, int C, int mode, float scale, void *stream) {
+  const int rows_wg = (C <= LA_TPB / 2) ? 32 : 16;   // narrow layers: two row groups, 32 rows - half as many workgroups
+  if (!perm || C > LA_TPB || LA_TPB % C != 0 || m % rows_wg != 0 || C < 16)   // (what the LDS form needs; else the direct scatter)
+    return gb_la_pool_bwd(dout, out, arg, G, xyz, centres, idx, wx, ab, sg, red, b, n, m, ns, C, mode, scale, stream);
+  if (!la_geom_ok(b, n, m, ns) || !dout || !out || !arg || !G || !xyz || !centres || !idx || !wx || !ab || !sg || !red)
+    return GB_EINVAL;
+  if (mode != 0 && mode != 1) return GB_EINVAL;
+  const long long R = (long long)b * m;
+  if (R == 0) return GB_OK;
+  static std::atomic<unsigned long long> attr_set16{0}, attr_set32{0};
+  allow_dynamic_lds(la_pool_bwd_agg_kernel<16>, 160 * 1024, attr_set16);
+  allow_dynamic_lds(la_pool_bwd_agg_kernel<32>, 160 * 1024, attr_set32);
+  // slots for the distinct winners of 16 rows: ns = 64 neighbourhoods (the first stage) need more than 128 of them
+  const int acc_floats = (ns > 32 || C <= 64) ? LA_AG_ACC_MAX : LA_AG_ACC_MAX / 2;
+  const size_t lds = (size_t)acc_floats * sizeof(float) + (2 * rows_wg * 64 + acc_floats / C + 4) * sizeof(int);
+  if (rows_wg == 32)
+    hipLaunchKernelGGL(la_pool_bwd_agg_kernel<32>, dim3((unsigned)(R / 32)), dim3(LA_TPB), lds, as_stream(stream), dout, out,
+                       arg, G, xyz, centres, idx, wx, ab, perm, sg, red, n, m, ns, C, mode, scale, acc_floats);
+  else
+    hipLaunchKernelGGL(la_pool_bwd_agg_kernel<16>, dim3((unsigned)(R / 16)), dim3(LA_TPB), lds, as_stream(stream), dout, out,
+                       arg, G, xyz, centres, idx, wx, ab, perm, sg, red, n, m, ns, C, mode, scale, acc_floats);
+  return check_launch("gb_la_pool_bwd_perm");
 }
 
 extern "C" int gb_la_point_grad(const float *sg, const float *G, const float *cnt, const float *dsum, const float *wx,

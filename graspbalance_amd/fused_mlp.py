@@ -77,6 +77,8 @@ _RESERVED_CUS = 0
 _GEMM_FLAGS = _lib.GEMM_NO_RING if os.environ.get("GB_RING", "1") == "0" else 0   # A/B switch: few-row GEMM kernel
 if os.environ.get("GB_DIRECT", "1") == "0":   # A/B switch: tall wgrads on the LDS tiles instead of csrc/gemm_wg.hip
     _GEMM_FLAGS |= _lib.GEMM_NO_DIRECT
+_LA_AGG_MIN_M = int(os.environ.get("GB_LA_AGG_MIN_M", "512"))   # smaller stages: the order costs what it saves
+_LA_AGG = os.environ.get("GB_LA_AGG", "1") != "0"   # A/B switch: la_pool_bwd's scatter pre-aggregated in LDS over spatially adjacent rows
 _PAIR = os.environ.get("GB_PAIR", "1") != "0"   # A/B switch: dgrad + wgrad of a layer through gb_gemm_dgrad_wgrad
 _WORKSPACES = {}
 _OPTS = {}
@@ -983,6 +985,7 @@ class LocalGeometry:
         self.b, self.n = self.xyz.shape[0], self.xyz.shape[1]
         self.m, self.ns = self.idx.shape[1], self.idx.shape[2]
         self.mode, self.scale = int(mode), float(scale)
+        self._perm = None
         dev = xyz.device
         pts = _zeros32(self.b * self.n * 4, dev)
         self.cnt, self.dsum = pts[:self.b * self.n], pts[self.b * self.n:]
@@ -994,6 +997,15 @@ class LocalGeometry:
     @property
     def rows(self):
         return self.b * self.m * self.ns
+
+    def row_perm(self):
+        """(b, m) int32: a spatially coherent order of each cloud's centres (csrc/fps.hip gb_fps_row_order: consecutive
+        entries are neighbours in space) for gb_la_pool_bwd_perm - one launch per stage, shared by its blocks' backwards."""
+        if self._perm is None and _LA_AGG and self.m % 32 == 0 and _LA_AGG_MIN_M <= self.m <= 24576:
+            self._perm = torch.empty((self.b, self.m), dtype=torch.int32, device=self.centres.device)
+            _call("gb_fps_row_order", self.centres.device, _lib.ptr(self.centres), _lib.ptr(self._perm), self.b, self.m,
+                  _s(self.centres))
+        return self._perm
 
 
 def local_agg_supported(C_out, ns):
@@ -1053,9 +1065,9 @@ class LocalAggPool(Function):
         zbuf = _zeros32(rows * N + (N * C if ctx.needs_input_grad[1] else 0), dev)
         sg = zbuf[:rows * N].view(rows, N)
         red = _zeros64(5 * N, dev)  # [dbeta, dgamma, T0, T1, T2]
-        _call("gb_la_pool_bwd", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(G), _lib.ptr(geo.xyz),
-              _lib.ptr(geo.centres), _lib.ptr(geo.idx), _lib.ptr(Wx), _lib.ptr(ab), _lib.ptr(sg), _lib.ptr(red), geo.b,
-              geo.n, geo.m, geo.ns, N, geo.mode, geo.scale, st)
+        _call("gb_la_pool_bwd_perm", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(G), _lib.ptr(geo.xyz),
+              _lib.ptr(geo.centres), _lib.ptr(geo.idx), _lib.ptr(Wx), _lib.ptr(ab), _lib.ptr(geo.row_perm()), _lib.ptr(sg),
+              _lib.ptr(red), geo.b, geo.n, geo.m, geo.ns, N, geo.mode, geo.scale, st)
         small = torch.empty(5 * N + N * C, dtype=torch.float32, device=dev)  # dbeta, dgamma, dWx (N,3), then dWf
         dbeta, dgamma, dWx = small[:N], small[N:2 * N], small[2 * N:5 * N].view(N, 3)
         if not ctx.needs_input_grad[1]:   # (otherwise gb_la_wx_grad_g below converts the two sums: one launch less)

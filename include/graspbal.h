@@ -510,6 +510,14 @@ int gb_la_pool(const float *G, const float *xyz, const float *centres, const int
 int gb_la_pool_bwd(const float *dout, const float *out, const int32_t *arg, const float *G, const float *xyz,
                    const float *centres, const int32_t *idx, const float *wx, const float *ab, float *sg,
                    double *red, int b, int n, int m, int ns, int C, int mode, float scale, void *stream);
+/* gb_la_pool_bwd with the scatter pre-aggregated in LDS: perm (b,m) int32 = a spatially coherent order of each cloud's
+ * centres (gb_fps_row_order(centres, perm, b, m)); a workgroup takes 16 consecutive entries, gives the few distinct winner
+ * points of those rows a slot each and adds one dense row of atomics per point instead of one scattered atomic per
+ * (row, column).  Same sums up to the order of the fp32 additions.  perm = NULL, m % 16 != 0 or a C that does not divide
+ * 256: exactly gb_la_pool_bwd.                                                                                    */
+int gb_la_pool_bwd_perm(const float *dout, const float *out, const int32_t *arg, const float *G, const float *xyz,
+                        const float *centres, const int32_t *idx, const float *wx, const float *ab, const int32_t *perm,
+                        float *sg, double *red, int b, int n, int m, int ns, int C, int mode, float scale, void *stream);
 /* dG (rows = b*n, C): gradient of G through BatchNorm (training: batch statistics over P rows; else a*sg). */
 int gb_la_point_grad(const float *sg, const float *G, const float *cnt, const float *dsum, const float *wx,
                      const float *ab, const double *red, long long P, long long rows, int C, int training,

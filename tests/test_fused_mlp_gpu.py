@@ -222,6 +222,46 @@ def test_local_aggregation_without_grouped_tensor(C, ns, train):
         _close(a[3][k], b[3][k], 1e-5, "buffer " + k)
 
 
+@pytest.mark.parametrize("B,n,ns,C,radius", [(4, 2048, 64, 128, 0.08), (4, 1024, 32, 256, 0.2), (2, 512, 16, 256, 0.4),
+                                             (3, 256, 16, 256, 0.6), (1, 1024, 64, 64, 0.02), (2, 1024, 32, 256, 5.0)])
+def test_la_pool_bwd_aggregated_in_lds_equals_the_direct_scatter(B, n, ns, C, radius):
+    """gb_la_pool_bwd_perm (winners of 16 spatially adjacent rows get an LDS slot each, one dense row of atomics per point)
+    against gb_la_pool_bwd: the same sg and column sums up to the order of the fp32 additions - the stages' shapes, a radius
+    so small that every row has one distinct winner (table overflow -> the direct scatter inside the kernel) and one so large
+    that every row shares its candidates."""
+    from graspbalance_amd import _lib
+    from graspbalance_amd.pointnet2 import _ext
+    from graspbalance_amd.scene import make_batch
+    torch.manual_seed(n + C)
+    xyz = torch.from_numpy(make_batch(range(B), n)).to(DEV)
+    idx = _ext.ball_query(xyz, xyz, radius, ns)
+    G = torch.randn(B * n, C, device=DEV)
+    wx = torch.randn(C, 3, device=DEV)
+    ab = torch.cat([torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV), torch.randn(C, device=DEV),
+                    torch.rand(C, device=DEV) + 0.5])
+    out = torch.randn(B * n, C, device=DEV)          # > 0 on about half of the entries: the ReLU mask
+    arg = torch.randint(0, ns, (B * n, C), dtype=torch.int32, device=DEV)
+    dout = torch.randn(B * n, C, device=DEV)
+    perm = torch.empty(B, n, dtype=torch.int32, device=DEV)
+    L = _lib.lib()
+    _lib.check(L.gb_fps_row_order(_lib.ptr(xyz), _lib.ptr(perm), B, n, None), "order")
+    res = []
+    for use_perm in (False, True):
+        sg = torch.zeros(B * n, C, device=DEV)
+        red = torch.zeros(5 * C, dtype=torch.float64, device=DEV)
+        _lib.check(L.gb_la_pool_bwd_perm(_lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(G), _lib.ptr(xyz),
+                                         _lib.ptr(xyz), _lib.ptr(idx), _lib.ptr(wx), _lib.ptr(ab),
+                                         _lib.ptr(perm) if use_perm else None, _lib.ptr(sg), _lib.ptr(red), B, n, n, ns, C, 0,
+                                         1.0, None), "bwd")
+        torch.cuda.synchronize()
+        res.append((sg, red))
+    assert sorted(perm[0].tolist()) == list(range(n))
+    scale = float(res[0][0].abs().max())
+    assert float((res[0][0] - res[1][0]).abs().max()) <= 1e-5 * scale
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-9, atol=1e-9 * float(res[0][1].abs().max()))
+    assert float(res[0][0].abs().sum()) > 0
+
+
 @pytest.mark.parametrize("widths", [(64, 128), (64, 64, 128), (64, 128, 256)])
 @pytest.mark.parametrize("train", [True, False])
 def test_first_layer_closed_form_backward(train, widths):

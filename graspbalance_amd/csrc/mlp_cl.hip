@@ -80,6 +80,62 @@ __global__ __launch_bounds__(CL_TPB) void group_concat_cl_grad_kernel(
   atomicAdd(dfeat + ((size_t)bi * n + id) * c + col, dx0[row * cw + 3 + col]);
 }
 
+// Feature propagation's front end, channel-last (reference pointnet2_modules.py:402-435: three_interpolate of the coarse
+// level's features, torch.cat with the skip features, then the SharedMLP): row j of the MLP's input
+//   X0[j] = [ (k[i0]*w0 + k[i1]*w1) + k[i2]*w2 (C2 columns) , skip[j] (C1 columns) ]
+// written once, straight from the channel-last buffers the neighbouring stacks keep (three_interpolate_kernel's
+// expression: the same values as interpolate -> cat -> transpose, which cost four launches and three passes).
+__global__ __launch_bounds__(CL_TPB) void interp_concat_cl_kernel(const float *__restrict__ known, const int32_t *__restrict__ idx,
+                                                                   const float *__restrict__ weight,
+                                                                   const float *__restrict__ skip, float *__restrict__ out,
+                                                                   int n, int m, int c2, int c1, long long total_rows) {
+  const int cw = c2 + c1;
+  const int parts = (cw + 3) / 4;
+  const long long gid = (long long)blockIdx.x * CL_TPB + threadIdx.x;
+  const long long row = gid / parts;
+  const int col0 = (int)(gid % parts) * 4;
+  if (row >= total_rows) return;
+  const int bi = (int)(row / n);
+  const int32_t *ix = idx + row * 3;
+  const float *w = weight + row * 3;
+  const float *kb = known + (size_t)bi * m * c2;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int col = col0 + t;
+    if (col >= cw) break;
+    float v;
+    if (col < c2) v = ((kb[(size_t)ix[0] * c2 + col] * w[0]) + (kb[(size_t)ix[1] * c2 + col] * w[1])) + (kb[(size_t)ix[2] * c2 + col] * w[2]);
+    else v = skip[row * c1 + (col - c2)];
+    out[row * cw + col] = v;
+  }
+}
+
+// ... and its backward: dknown[b, i_k, :] += dX0[j, :C2] * w_k - a row of C2 consecutive floats per (j, k): dense atomics
+// (the channel-major three_interpolate_grad scatters single floats) - and dskip[j] = dX0[j, C2:]
+__global__ __launch_bounds__(CL_TPB) void interp_concat_cl_grad_kernel(const float *__restrict__ dx0, const int32_t *__restrict__ idx,
+                                                                        const float *__restrict__ weight,
+                                                                        float *__restrict__ dknown, float *__restrict__ dskip,
+                                                                        int n, int m, int c2, int c1, long long total_rows) {
+  const int cw = c2 + c1;
+  const long long gid = (long long)blockIdx.x * CL_TPB + threadIdx.x;
+  const long long row = gid / cw;
+  const int col = (int)(gid % cw);
+  if (row >= total_rows) return;
+  const float g = dx0[row * cw + col];
+  if (col >= c2) {
+    if (dskip) dskip[row * c1 + (col - c2)] = g;
+    return;
+  }
+  if (!dknown) return;
+  const int bi = (int)(row / n);
+  const int32_t *ix = idx + row * 3;
+  const float *w = weight + row * 3;
+  float *kb = dknown + (size_t)bi * m * c2;
+  atomicAdd(kb + (size_t)ix[0] * c2 + col, g * w[0]);   // (three_interpolate_grad_kernel's products)
+  atomicAdd(kb + (size_t)ix[1] * c2 + col, g * w[1]);
+  atomicAdd(kb + (size_t)ix[2] * c2 + col, g * w[2]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Column reductions over a (P, C) row-major matrix.  A block owns ROWS_PER_BLOCK rows; threads are
 // laid out (row lane, column) so a wave reads contiguous row segments; per-thread fp64 partials,
@@ -845,6 +901,30 @@ extern "C" int gb_group_concat_cl_grad(const float *dx0, const int32_t *idx, flo
   hipLaunchKernelGGL(group_concat_cl_grad_kernel, dim3(blocks_for(rows * c)), dim3(CL_TPB), 0, as_stream(stream),
                      dx0, idx, dfeat, n, m, ns, c, rows);
   return check_launch("gb_group_concat_cl_grad");
+}
+
+extern "C" int gb_interp_concat_cl(const float *known, const int32_t *idx, const float *weight, const float *skip,
+                                   float *out, int b, int n, int m, int c2, int c1, void *stream) {
+  if (b < 0 || n < 0 || m < 1 || c2 < 1 || c1 < 0 || !known || !idx || !weight || !out || (c1 > 0 && !skip)) return GB_EINVAL;
+  const long long rows = (long long)b * n;
+  if (rows == 0) return GB_OK;
+  const long long threads = rows * ((c2 + c1 + 3) / 4);
+  if (threads / CL_TPB > 0x7fffffffLL) return GB_ERANGE;
+  hipLaunchKernelGGL(interp_concat_cl_kernel, dim3(blocks_for(threads)), dim3(CL_TPB), 0, as_stream(stream), known, idx,
+                     weight, skip, out, n, m, c2, c1, rows);
+  return check_launch("gb_interp_concat_cl");
+}
+
+extern "C" int gb_interp_concat_cl_grad(const float *dx0, const int32_t *idx, const float *weight, float *dknown,
+                                        float *dskip, int b, int n, int m, int c2, int c1, void *stream) {
+  if (b < 0 || n < 0 || m < 1 || c2 < 1 || c1 < 0 || !dx0 || !idx || !weight) return GB_EINVAL;
+  const long long rows = (long long)b * n;
+  if (rows == 0 || (!dknown && !dskip)) return GB_OK;
+  const long long threads = rows * (c2 + c1);
+  if (threads / CL_TPB > 0x7fffffffLL) return GB_ERANGE;
+  hipLaunchKernelGGL(interp_concat_cl_grad_kernel, dim3(blocks_for(threads)), dim3(CL_TPB), 0, as_stream(stream), dx0, idx,
+                     weight, dknown, dskip, n, m, c2, c1, rows);
+  return check_launch("gb_interp_concat_cl_grad");
 }
 
 static bool fin_ok(const GbBnFinalize *fin) {

@@ -418,6 +418,40 @@ class GroupConcatCL(Function):
         return None, None, None, dfeat, None, None, None
 
 
+class InterpConcatCL(Function):
+    """(known_cl (B,m,C2), idx (B,n,3) int32, weight (B,n,3), skip_cl (B,n,C1)|None) -> X0 (B*n, C2+C1): the rows a feature
+    propagation stack starts from (csrc/mlp_cl.hip interp_concat_cl_kernel)."""
+
+    @staticmethod
+    def forward(ctx, known_cl, idx, weight, skip_cl):
+        B, m, C2 = known_cl.shape
+        n = idx.shape[1]
+        C1 = 0 if skip_cl is None else skip_cl.shape[2]
+        out = torch.empty((B * n, C2 + C1), dtype=torch.float32, device=known_cl.device)
+        _call("gb_interp_concat_cl", known_cl.device, _lib.ptr(known_cl), _lib.ptr(idx), _lib.ptr(weight), _lib.ptr(skip_cl),
+              _lib.ptr(out), B, n, m, C2, C1, _s(known_cl))
+        ctx.dims = (B, n, m, C2, C1)
+        ctx.save_for_backward(idx, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, dx0):
+        B, n, m, C2, C1 = ctx.dims
+        idx, weight = ctx.saved_tensors
+        dx0 = dx0.contiguous()
+        dev = dx0.device
+        dknown = _zeros32(B * m * C2, dev).view(B, m, C2) if ctx.needs_input_grad[0] else None
+        dskip = torch.empty((B, n, C1), dtype=torch.float32, device=dev) if (C1 and ctx.needs_input_grad[3]) else None
+        _call("gb_interp_concat_cl_grad", dev, _lib.ptr(dx0), _lib.ptr(idx), _lib.ptr(weight), _lib.ptr(dknown),
+              _lib.ptr(dskip), B, n, m, C2, C1, _s(dx0))
+        return dknown, None, None, dskip
+
+
+def interp_concat_cl(known_cl, idx, weight, skip_cl=None):
+    return InterpConcatCL.apply(known_cl.contiguous(), idx.contiguous(), weight.contiguous(),
+                                None if skip_cl is None else skip_cl.contiguous())
+
+
 def group_concat_cl(xyz, new_xyz, idx, feat_cl=None, mode=0, scale=1.0, rot=None):
     return GroupConcatCL.apply(xyz.contiguous(), new_xyz.contiguous(), idx.contiguous(),
                                None if feat_cl is None else feat_cl.contiguous(), mode, scale, rot)

@@ -22,6 +22,7 @@ from . import pytorch_utils as pt_utils
 
 
 _FP_FUSED = os.environ.get("GB_FP_FUSED", "1") != "0"  # A/B switch: feature-propagation MLPs on the fused stack
+_FP_ROWS = os.environ.get("GB_FP_ROWS", "1") != "0"    # A/B switch: interpolation + concatenation written as channel-last rows (one launch)
 
 
 def _sample_centres(xyz, npoint, inds=None):
@@ -258,6 +259,17 @@ class PointnetFPModule(nn.Module):
 
     def forward(self, unknown: torch.Tensor, known: torch.Tensor, unknow_feats: torch.Tensor,
                 known_feats: torch.Tensor) -> torch.Tensor:
+        if (_FP_FUSED and _FP_ROWS and known is not None and unknown.is_cuda and unknown.dtype == torch.float32
+                and known.dtype == torch.float32 and not (unknown.requires_grad or known.requires_grad)
+                and fused_mlp.enabled(known_feats) and fused_mlp.supports(self.mlp)):
+            # interpolation + concatenation written once as the channel-last rows the fused stack reads (the (B,C,n) inputs
+            # are transposed views of channel-last buffers on this path: .transpose(1, 2) costs nothing); same values as
+            # three_interpolate -> cat -> transpose
+            weight, idx = pointnet2_utils.three_nn_weights(unknown, known)
+            rows = fused_mlp.interp_concat_cl(known_feats.transpose(1, 2), idx, weight,
+                                              None if unknow_feats is None else unknow_feats.transpose(1, 2))
+            out = fused_mlp.shared_mlp_cl(rows, self.mlp)
+            return out.view(unknown.shape[0], unknown.shape[1], -1).transpose(1, 2)
         if known is not None:
             if (unknown.is_cuda and unknown.dtype == torch.float32 and known.dtype == torch.float32
                     and not (unknown.requires_grad or known.requires_grad)):

@@ -292,6 +292,16 @@ int gb_group_concat_cl(const float *xyz, const float *new_xyz, const int32_t *id
 /* dfeat[b, idx[p], :] += dx0[p, 3:]   (accumulates into dfeat (b,n,c)) */
 int gb_group_concat_cl_grad(const float *dx0, const int32_t *idx, float *dfeat, int b, int n, int m,
                             int ns, int c, void *stream);
+/* Feature propagation's front end on channel-last rows (reference pointnet2_modules.py:402-435: three_interpolate ->
+ * torch.cat with the skip features -> SharedMLP): out (b*n, c2 + c1), row j = [ (known[i0]*w0 + known[i1]*w1) +
+ * known[i2]*w2 , skip[j] ] with known (b,m,c2), skip (b,n,c1) (NULL when c1 == 0) channel-last, idx / weight (b,n,3) as
+ * gb_three_nn / the reference's weights: the values of gb_three_interpolate, written once where the MLP reads them.
+ * _grad: dknown (b,m,c2) += the interpolation's transpose (caller-zeroed; a row of c2 consecutive floats per (j, k)),
+ * dskip (b,n,c1) = dx0[:, c2:]; either may be NULL.                                                              */
+int gb_interp_concat_cl(const float *known, const int32_t *idx, const float *weight, const float *skip, float *out, int b,
+                        int n, int m, int c2, int c1, void *stream);
+int gb_interp_concat_cl_grad(const float *dx0, const int32_t *idx, const float *weight, float *dknown, float *dskip, int b,
+                             int n, int m, int c2, int c1, void *stream);
 /* Per-call options of the gb_gemm_* entry points (NULL = all defaults).  The library keeps NO state between calls:
  * what used to be process-wide switches travels with every call, so two threads (autograd workers, two trainers)
  * may use different settings concurrently.

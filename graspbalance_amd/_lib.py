@@ -51,6 +51,7 @@ SIGNATURES = {
     "gb_knn": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gb_group_concat_cl": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
     "gb_group_concat_cl_grad": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "gb_copy_segments": [_P, _I, _P, _P],
     "gb_interp_concat_cl": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gb_interp_concat_cl_grad": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gb_col_stats": [_P, _L, _I, _P, _P, _P],

@@ -11,9 +11,13 @@ are views of the flat buffers) and ``load_state_dict`` copies into them.  A para
 part with a zero gradient (torch skips it); every GraspBalance parameter receives a gradient in every step.
 """
 import math
+import os
 
 import torch
 from torch.optim import Optimizer
+
+_SEGMENT_PACK = os.environ.get("GB_SEGMENT_PACK", "1") != "0"   # A/B switch: the gradient gather as one own launch
+_SEG = 8192   # elements per workgroup of gb_copy_segments
 
 
 class FlatAdam(Optimizer):
@@ -50,6 +54,11 @@ class FlatAdam(Optimizer):
                              'exp_avg_sq': self._exp_avg_sq[off:off + n].view_as(p)}
             off += n
         self._fused = dev.type == "cuda" and hasattr(torch, "_fused_adam_")
+        # the gather's tables (pack): pinned buffers allocated HERE - a capture must not allocate host memory
+        self._seg_tables, self._seg_captured = {}, []
+        self._seg_rows = total // _SEG + len(ps) + 1
+        self._seg_pool = ([torch.empty((self._seg_rows, 3), dtype=torch.int64).pin_memory() for _ in range(24)]
+                          if (dev.type == "cuda" and _SEGMENT_PACK) else [])
 
     @torch.no_grad()
     def pack(self, lo=0, hi=None):
@@ -65,7 +74,60 @@ class FlatAdam(Optimizer):
                 have_v.append(v)
                 have_g.append(p.grad)
         if have_v:
-            torch._foreach_copy_(have_v, have_g)
+            if _SEGMENT_PACK and have_v[0].is_cuda:
+                self._pack_segments(have_v, have_g)
+            else:
+                torch._foreach_copy_(have_v, have_g)
+
+    def _pack_segments(self, views, grads):
+        """The gather as ONE launch (csrc/mlp_cl.hip copy_segments_kernel) instead of torch's nine multi-tensor launches
+        for 253 tensors: a device table of (source address, destination element, count) per 8192-element piece, sent
+        through a pinned buffer.  Launch by launch the table is rebuilt only when an address changed (the allocator hands
+        the same blocks out step after step); a capture gets a pinned buffer of its own out of a pool allocated up front
+        (its copy node reads that buffer at every replay) - with the pool used up the gather falls back to torch's."""
+        import numpy as np
+        from . import _lib
+        dev = views[0].device
+        base = self._flat_g.data_ptr()
+        ok = [g.is_contiguous() and g.dtype == torch.float32 and g.device == dev for g in grads]
+        if not all(ok):   # (exotic gradients - strided, another dtype - keep torch's copy)
+            torch._foreach_copy_([v for v, o in zip(views, ok) if not o], [g for g, o in zip(grads, ok) if not o])
+            views = [v for v, o in zip(views, ok) if o]
+            grads = [g for g, o in zip(grads, ok) if o]
+            if not views:
+                return
+        capturing = torch.cuda.is_current_stream_capturing()
+        key = (tuple(g.data_ptr() for g in grads), tuple(v.data_ptr() for v in views))
+        slot = None if capturing else self._seg_tables.get((len(grads), views[0].data_ptr()))
+        if slot is None or slot["key"] != key:
+            if slot is None:
+                if not self._seg_pool:
+                    torch._foreach_copy_(views, grads)
+                    return
+                slot = {"host": self._seg_pool.pop(), "table": None}
+                if not capturing:
+                    self._seg_tables[(len(grads), views[0].data_ptr())] = slot
+                else:
+                    self._seg_captured.append(slot)   # (kept alive with the optimizer: a graph replays its copy node)
+            else:
+                torch.cuda.current_stream(dev).synchronize()   # the previous table's copy may still read the pinned buffer
+            src = np.array([g.data_ptr() for g in grads], dtype=np.int64)
+            off = np.array([(v.data_ptr() - base) // 4 for v in views], dtype=np.int64)
+            num = np.array([g.numel() for g in grads], dtype=np.int64)
+            pieces = (num + _SEG - 1) // _SEG
+            seg = np.repeat(np.arange(len(grads)), pieces)
+            first = np.cumsum(pieces) - pieces
+            k = np.arange(int(pieces.sum())) - first[seg]          # piece number within its tensor
+            tab = np.stack([src[seg] + 4 * _SEG * k, off[seg] + _SEG * k, np.minimum(num[seg] - _SEG * k, _SEG)], 1)
+            rows = int(tab.shape[0])
+            slot["host"][:rows].copy_(torch.from_numpy(np.ascontiguousarray(tab)))
+            if slot["table"] is None:
+                slot["table"] = torch.empty((self._seg_rows, 3), dtype=torch.int64, device=dev)
+            slot["table"][:rows].copy_(slot["host"][:rows], non_blocking=True)   # (a copy node when capturing)
+            slot["key"], slot["rows"] = key, rows
+        with _lib.device_ctx(dev):
+            _lib.check(_lib.lib().gb_copy_segments(_lib.ptr(slot["table"]), slot["rows"], _lib.ptr(self._flat_g),
+                                                   _lib.current_stream(dev)), "gb_copy_segments")
 
     def set_lr_tensor(self, lr=None):
         """Write the group's (or the given) learning rate into the device scalar the tensor_lr update reads."""

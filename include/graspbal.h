@@ -292,6 +292,11 @@ int gb_group_concat_cl(const float *xyz, const float *new_xyz, const int32_t *id
 /* dfeat[b, idx[p], :] += dx0[p, 3:]   (accumulates into dfeat (b,n,c)) */
 int gb_group_concat_cl_grad(const float *dx0, const int32_t *idx, float *dfeat, int b, int n, int m,
                             int ns, int c, void *stream);
+/* `segments` independent copies in one launch: table = DEVICE array of {const float *src; long long dst_element;
+ * long long count (<= 8192)} (24 bytes each, 8-byte aligned); dst[dst_element .. + count) = src[0 .. count).  What a
+ * flat-buffer optimizer needs to gather its parameters' gradients (the reference's torch.optim.Adam walks the
+ * parameters one by one, train.py:94); source and destination ranges must not overlap.                       */
+int gb_copy_segments(const void *table, int segments, float *dst, void *stream);
 /* Feature propagation's front end on channel-last rows (reference pointnet2_modules.py:402-435: three_interpolate ->
  * torch.cat with the skip features -> SharedMLP): out (b*n, c2 + c1), row j = [ (known[i0]*w0 + known[i1]*w1) +
  * known[i2]*w2 , skip[j] ] with known (b,m,c2), skip (b,n,c1) (NULL when c1 == 0) channel-last, idx / weight (b,n,3) as

@@ -64,6 +64,75 @@ __device__ __forceinline__ float lin3(float x, float y, float z, float w0, float
   return ((x * w0) + (y * w1)) + (z * w2);   // the ONE evaluation order every consumer of the folded layer uses
 }
 
+// ---- the B operand's LDS reads of the fp32 MFMA loop, software-pipelined by hand -----------------------------------
+// Left to the compiler the loop came out as  ds_read2_b32 -> s_waitcnt lgkmcnt(0) -> 2 MFMAs  through ONE register pair:
+// every pair of MFMAs waited for a full LDS round trip (PMC: 32-34 % of a wave's cycles in s_waitcnt, MFMA pipe 50-60 %
+// busy).  Here the NT values of reduction step J+1 are requested BEFORE the NT MFMAs of step J are issued, as inline
+// asm with immediate offsets (the compiler sinks a plain load to its first use), and the wait is a counted
+// `s_waitcnt lgkmcnt(NT)` whose operands are tied in/out ("+v"): the values the MFMAs read come out of the wait, so no
+// use can move above it, and the registers stay allocated while the read is in flight.  LDS returns in order, so any
+// LDS / scalar-memory operation of the compiler's own in between only makes the counted wait stricter.
+// tools/rs_check_isa.py (run by a CPU test on every build) walks the generated code for any instruction that touches
+// a register between its asm read and the asm wait that retires it.
+template <int NT, int J, int Q = 0>
+__device__ __forceinline__ void rs_b_request(float (&b)[NT], unsigned addr) {
+  if constexpr (Q < NT) {
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(b[Q]) : "v"(addr), "n"((J * NT * 32 + Q * 32) * 4));
+    rs_b_request<NT, J, Q + 1>(b, addr);
+  }
+}
+
+#define RS_LGKM(N, ...) asm volatile("s_waitcnt lgkmcnt(" #N ")" : __VA_ARGS__)
+template <int NT, bool MORE>   // MORE: the next step's NT reads were issued behind the ones waited for
+__device__ __forceinline__ void rs_b_wait(float (&b)[NT]) {
+  static_assert(NT == 2 || NT == 4 || NT == 5 || NT == 8, "add the operand list");
+  if constexpr (NT == 2) {
+    if constexpr (MORE) RS_LGKM(2, "+v"(b[0]), "+v"(b[1]));
+    else RS_LGKM(0, "+v"(b[0]), "+v"(b[1]));
+  } else if constexpr (NT == 4) {
+    if constexpr (MORE) RS_LGKM(4, "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+    else RS_LGKM(0, "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+  } else if constexpr (NT == 5) {
+    if constexpr (MORE) RS_LGKM(5, "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]));
+    else RS_LGKM(0, "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]));
+  } else {
+    if constexpr (MORE)
+      RS_LGKM(8, "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
+    else
+      RS_LGKM(0, "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
+  }
+}
+
+// steps J..15 of a chunk: `cur` holds step J's values (in flight), `nxt` receives step J+1's
+template <int NT, int J>
+__device__ __forceinline__ void rs_b_steps(f32x16 (&acc)[NT], const float (&av)[16], float (&cur)[NT], float (&nxt)[NT],
+                                           unsigned addr) {
+  if constexpr (J + 1 < 16) rs_b_request<NT, J + 1>(nxt, addr);
+  rs_b_wait<NT, (J + 1 < 16)>(cur);
+#pragma unroll
+  for (int q = 0; q < NT; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[J], cur[q], acc[q], 0, 0, 0);
+  if constexpr (J + 1 < 16) rs_b_steps<NT, J + 1>(acc, av, nxt, cur, addr);
+}
+
+// ---- the A operand's global loads, requested one chunk ahead by hand -------------------------------------------------
+// The plain form - four loads, each under its own (row < P && k < R) branch - could not be counted by the compiler's
+// s_waitcnt pass: the chunk's first use of `cur` came out as s_waitcnt vmcnt(0) placed BEHIND the requests for `nxt`, so
+// every chunk waited for the loads it had just issued (the "one chunk ahead" of the design never overlapped anything).
+// Here the four loads are unconditional inline asm from clamped, always valid addresses, and the wait is ONE
+// `s_waitcnt vmcnt(0)` behind the chunk's MFMAs - in front of the tile's epilogue, so a tile's stores are not waited
+// for - with the registers tied through it like the B operand's.
+typedef float rs_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void rs_a_request(rs_f32x4 (&d)[4], const float *p0, const float *p1, const float *p2,
+                                             const float *p3) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d[0]) : "v"(p0));
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d[1]) : "v"(p1));
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d[2]) : "v"(p2));
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d[3]) : "v"(p3));
+}
+__device__ __forceinline__ void rs_a_wait(rs_f32x4 (&d)[4]) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
+}
+
 template <int NT, int EPI, bool BF = false, bool GEN3 = false>
 __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_BNBWD_X) ? 4 : 2)) void gemm_rs_kernel(RsArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -73,6 +142,7 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
   float *s_aff = lds + (size_t)rpad * C32 / (BF ? 2 : 1);  // [2][rpad]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int m = lane & 31, h = lane >> 5;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lds;
   auto put_b = [&](int r, int c, float v) {
     if constexpr (BF) reinterpret_cast<__bf16 *>(lds)[((size_t)(r >> 3) * C32 + c) * 8 + (r & 7)] = (__bf16)v;
     else Bs[(size_t)r * C32 + c] = v;
@@ -230,6 +300,17 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
       dst[i] = (row < gP && k + 4 * i < g.R) ? *reinterpret_cast<const float4 *>(p + 4 * i)
                                               : make_float4(0.f, 0.f, 0.f, 0.f);
   };
+  // (asm form, not GEN3) rows past the end read the last row - every epilogue masks them; reduction indices past R read
+  // the row's first floats and are zeroed at use (a_tail: R % 32 != 0 only)
+  const bool a_tail = g.R % RS_CH != 0;
+  auto request_chunk = [&](rs_f32x4 (&dst)[4], long long tl, int kc) {
+    long long row = tl * 32 + m;
+    row = row < gP ? row : gP - 1;
+    const int k = kc * RS_CH + h * 16;
+    const float *p = g.a + row * g.lda;
+    rs_a_request(dst, p + (k < g.R ? k : 0), p + (k + 4 < g.R ? k + 4 : 0), p + (k + 8 < g.R ? k + 8 : 0),
+                 p + (k + 12 < g.R ? k + 12 : 0));
+  };
   // The two waves that share a SIMD (w and w+4) run the same program from the same start and would reach their
   // MFMA phases and their epilogues together; delaying the upper four by half a tile's worth of MFMA time lets one
   // partner's epilogue (stores, statistics) run under the other's MFMAs (+2-4 % on the 1 M-row layers).
@@ -262,8 +343,24 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    // (not the bf16 instantiations: in two of them the allocator still copied in-flight tuples in front of the wait)
+    constexpr bool A_ASM = !GEN3 && !BF;
     float4 cur[4], nxt[4];
-    load_chunk(cur, tile, 0);
+    // The chunk in flight lives in `afl` only between its request and its wait INSIDE one loop trip; what is carried
+    // round the loop are the 16 plain values taken out of it behind the wait.  (Carrying the tuples themselves made the
+    // register allocator satisfy the wait's tied operands with copies of the in-flight registers - tools/wg_check_isa.py.)
+    rs_f32x4 afl[4];
+    float anext[16];
+    if constexpr (A_ASM) {
+      request_chunk(afl, tile, 0);
+      rs_a_wait(afl);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) anext[4 * i + e] = afl[i][e];
+    } else {
+      load_chunk(cur, tile, 0);
+    }
     int kc = 0;
     while (true) {
       int nkc = kc + 1;
@@ -275,9 +372,19 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
 #ifndef GB_DEFER
 #define GB_DEFER 1
 #endif
-      const bool defer = GB_DEFER && EPI == RS_STATS_POOL_V && kc == g.nch - 1;
-      if (more && !defer) load_chunk(nxt, ntile, nkc);
+      // (the asm form does not defer: without the per-load branches and with the fp64 sums in LDS the 16 registers fit)
+      const bool defer = GB_DEFER && !A_ASM && EPI == RS_STATS_POOL_V && kc == g.nch - 1;
+      if constexpr (!A_ASM) {
+        if (more && !defer) load_chunk(nxt, ntile, nkc);
+      }
 
+      // (fp32, whole tiles) the B values of the chunk's first step are requested here, ahead of the operand's prologue
+      float bq0[BF || PART ? 1 : NT], bq1[BF || PART ? 1 : NT];
+      const unsigned baddr = lds0 + (unsigned)(((kc * RS_CH + h * 16) * C32 + m) * 4);
+      // (not where the prologue is long vector code of the compiler's own - the generated operand, the 3-channel rows'
+      // address arithmetic: the checker found it reading undefined high halves out of registers in flight there)
+      constexpr bool B_EARLY = !BF && !PART && !GEN3 && EPI != RS_BNBWD_X;
+      if constexpr (B_EARLY) rs_b_request<NT, 0>(bq0, baddr);
       float av[16];
       if constexpr (GEN3) {
         const float4 *gw = reinterpret_cast<const float4 *>(s_gen) + kc * RS_CH + h * 16;
@@ -288,7 +395,18 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
         }
       } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { av[4 * i] = cur[i].x; av[4 * i + 1] = cur[i].y; av[4 * i + 2] = cur[i].z; av[4 * i + 3] = cur[i].w; }
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if constexpr (A_ASM) av[4 * i + e] = anext[4 * i + e];
+            else av[4 * i + e] = e == 0 ? cur[i].x : e == 1 ? cur[i].y : e == 2 ? cur[i].z : cur[i].w;
+          }
+        if (A_ASM && a_tail) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) av[4 * i + e] = (kc * RS_CH + h * 16 + 4 * i < g.R) ? av[4 * i + e] : 0.f;
+        }
       }
       if (g.aff) {  // previous layer's BatchNorm + ReLU; channels >= R have a = b = 0 and stay zero
         const float *ca = s_aff + kc * RS_CH + h * 16;
@@ -335,6 +453,10 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
             }
         }
       }
+      // the next chunk's request: behind the prologue and the epilogue's early requests - the compiler guards the
+      // registers it reuses there with s_waitcnt vmcnt(N) of its own book-keeping (it cannot see these loads), and one of
+      // those behind the request would wait for it at once.  Unconditional: past the end it re-reads the last row.
+      if constexpr (A_ASM) request_chunk(afl, ntile, nkc);
       if constexpr (BF) {
         // this lane's 16 reduction indices kc*32 + h*16 + (0..15) = the two k-groups kc*4 + 2h + {0, 1}
         bf16x8 a8[2];
@@ -353,6 +475,9 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
           for (int q = 0; q < NT; ++q)
             if (in(q)) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[u], b8[q], acc[q], 0, 0, 0);
         }
+      } else if constexpr (!PART) {
+        if constexpr (!B_EARLY) rs_b_request<NT, 0>(bq0, baddr);
+        rs_b_steps<NT, 0>(acc, av, bq0, bq1, baddr);
       } else {
       const float *bp = Bs + (size_t)(kc * RS_CH + h * 16) * C32 + m;
 #pragma unroll
@@ -367,6 +492,15 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
       }
       }
 
+      // the next chunk's values: waited for behind this chunk's MFMAs and IN FRONT of the tile's epilogue (its stores
+      // are then not waited for by anything until the next chunk's wait, a chunk of MFMAs later)
+      if constexpr (A_ASM) {
+        rs_a_wait(afl);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) anext[4 * i + e] = afl[i][e];
+      }
       if (kc == g.nch - 1) {
         // acc[q][r] = D[tile*32 + (r&3) + 8*(r>>2) + 4*h][q*32 + m]
         const long long row0 = tile * 32 + 4 * h;
@@ -453,10 +587,15 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
 #pragma unroll
               for (int q = 0; q < NT; ++q) {
                 if (!in(q)) continue;
+                // (v_max3_f32 by hand: fmaxf() of a select's result is preceded by a canonicalising v_max x, x - 216
+                // v_max + 32 v_max3 per (seed, crop) where 64 v_max3 do; vector ALU time adds to MFMA time on this chip,
+                // tools/mfma_valu_overlap.hip)
                 float best = -INFINITY;
 #pragma unroll
-                for (int r = 0; r < 16; r += 2)
-                  best = fmaxf(best, fmaxf(mem[r] ? acc[q][r] : -INFINITY, mem[r + 1] ? acc[q][r + 1] : -INFINITY));
+                for (int r = 0; r < 16; r += 2) {
+                  const float x0 = mem[r] ? acc[q][r] : -INFINITY, x1 = mem[r + 1] ? acc[q][r + 1] : -INFINITY;
+                  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(best) : "v"(best), "v"(x0), "v"(x1));
+                }
                 const auto sb = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
                 best = fmaxf(best, __uint_as_float(h ? sb[0] : sb[1]));   // the other 16 rows sit in lane ^ 32
                 if (h == 0) slot[q * 32] = best;
@@ -597,9 +736,11 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
         }
       }
       if (!more) break;
-      if (defer) load_chunk(nxt, ntile, nkc);
+      if constexpr (!A_ASM) {
+        if (defer) load_chunk(nxt, ntile, nkc);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
+        for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
+      }
       kc = nkc;
       tile = ntile;
     }

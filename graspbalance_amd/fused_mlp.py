@@ -1235,6 +1235,10 @@ def _stack(X, convs_bns, pool_ns=0, residual=None, relu_last=True, rows=None):
             else:
                 cfg.running_mean = bn.running_mean - conv.bias.detach()
         layers.append(cfg)
+    if not torch.is_grad_enabled():
+        # needs_input_grad reports the parameters' requires_grad whatever the grad mode: without this a no_grad call
+        # (Predictor) would still store the crop stack's last output and gather the eval tables for a backward
+        params = [p.detach() for p in params]
     out = MLPStack.apply(X, residual, layers, pool_ns, relu_last, rows, *params)
     if shifts:   # (one launch for the stack's layers)
         torch._foreach_add_([s[0] for s in shifts], [s[1] for s in shifts], alpha=shifts[0][2])

@@ -68,26 +68,33 @@ def test_cpu_tensors_raise_like_the_reference():
         _ext.three_nn(torch.rand(1, 2, 3), torch.rand(1, 8, 3))
 
 
-@pytest.mark.timeout(600)
-def test_direct_wgrad_never_touches_a_register_in_flight(tmp_path):
-    """csrc/gemm_wg.hip requests its operands with inline-asm loads the compiler cannot see as pending: a register copy
-    (or reuse) between a request and its wait would multiply stale data - or, as happened once, overwrite an address.
-    tools/wg_check_isa.py walks the generated gfx950 code of every instantiation for exactly that (hipcc -S, no GPU)."""
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("source,family,symbol,at_least", [("gemm_wg.hip", "wgrad_direct", "wgrad_direct_kernel", 6),
+                                                           ("gemm_rs.hip", "gemm_rs", "gemm_rs_kernel", 30)])
+def test_hand_pipelined_loads_never_touch_a_register_in_flight(tmp_path, source, family, symbol, at_least):
+    """csrc/gemm_wg.hip requests its operands with inline-asm global loads, csrc/gemm_rs.hip its B operand with inline-asm
+    LDS reads - neither visible to the compiler as pending: a register copy (or reuse) between a request and its wait
+    would multiply stale data - or, as happened once, overwrite an address.  tools/wg_check_isa.py walks the generated
+    gfx950 code of every instantiation for exactly that (hipcc -S, no GPU)."""
     import shutil
     import subprocess
     import sys
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
-    src = os.path.join(ROOT, "graspbalance_amd", "csrc", "gemm_wg.hip")
+    src = os.path.join(ROOT, "graspbalance_amd", "csrc", source)
     mk = open(os.path.join(ROOT, "graspbalance_amd", "csrc", "Makefile")).read()
     flags = re.search(r"^FLAGS\s*:=\s*(.*?)(?<!\\)\n", mk, flags=re.S | re.M).group(1).replace("\\\n", " ").split()
     flags = [f.replace("$(ARCH)", "gfx950") for f in flags]
-    out = str(tmp_path / "gemm_wg.s")
+    out = str(tmp_path / (source[:-4] + ".s"))
     subprocess.run([hipcc] + flags + ["--cuda-device-only", "-S", src, "-o", out], check=True, cwd=str(tmp_path))
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "wg_check_isa.py"), out], capture_output=True, text=True)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "wg_check_isa.py"), out, family],
+                         capture_output=True, text=True)
     assert res.returncode == 0, res.stdout + res.stderr
-    assert res.stdout.count(", ok") == res.stdout.count("wgrad_direct_kernel") >= 6, res.stdout
+    assert res.stdout.count(", ok") == res.stdout.count(symbol) >= at_least, res.stdout
+    if family == "gemm_rs":   # ... and the reads really are the asm ones (a build that lost them would pass vacuously)
+        text = open(out).read()
+        assert text.count("ds_read_b32") > 1000 and "s_waitcnt lgkmcnt(8)" in text
 
 
 def test_the_in_flight_checker_sees_a_planted_hazard(tmp_path):
@@ -101,3 +108,20 @@ def test_the_in_flight_checker_sees_a_planted_hazard(tmp_path):
                    "\t;;#ASMSTART\n\ts_waitcnt vmcnt(0)\n\t;;#ASMEND\n\tv_mov_b32_e32 v31, v12\n\ts_endpgm\n")
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "wg_check_isa.py"), str(bad)], capture_output=True, text=True)
     assert res.returncode == 1 and "v_mov_b32_e32 v30, v11" in res.stdout and "v31" not in res.stdout, res.stdout
+
+
+def test_the_in_flight_checker_sees_a_planted_lds_hazard(tmp_path):
+    import subprocess
+    import sys
+    bad = tmp_path / "bad.s"
+    bad.write_text("_ZN2gb14gemm_rs_kernelILi9ELi9ELb0ELb0EEEvNS_6RsArgsE:\n"
+                   "\t;;#ASMSTART\n\tds_read_b32 v10, v1 offset:128\n\t;;#ASMEND\n"
+                   "\t;;#ASMSTART\n\tds_read_b32 v11, v1 offset:256\n\t;;#ASMEND\n"
+                   "\t;;#ASMSTART\n\ts_waitcnt lgkmcnt(1)\n\t;;#ASMEND\n"
+                   "\tv_mfma_f32_32x32x2_f32 v[32:47], v2, v10, v[32:47]\n"     # retired: fine
+                   "\tv_mfma_f32_32x32x2_f32 v[48:63], v2, v11, v[48:63]\n"     # the younger read is still out
+                   "\t;;#ASMSTART\n\ts_waitcnt lgkmcnt(0)\n\t;;#ASMEND\n\tv_mov_b32_e32 v31, v11\n\ts_endpgm\n")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "wg_check_isa.py"), str(bad), "gemm_rs"],
+                         capture_output=True, text=True)
+    assert res.returncode == 1 and "v[48:63], v2, v11" in res.stdout and "v2, v10" not in res.stdout \
+        and "v31" not in res.stdout, res.stdout

@@ -8,7 +8,8 @@ wgrad_direct_kernel instantiation (basic blocks at the labels, edges from s_bran
 revisited for every distinct queue it is entered with), keeps the queue of outstanding asm loads, retires all but the
 youngest N at each asm `s_waitcnt vmcnt(N)`, and reports any other instruction that reads or writes an in-flight register.
 
-usage: wg_check_isa.py <gemm_wg .s file>      (hipcc -S / -save-temps output for gfx950); exit status 1 on a finding
+usage: wg_check_isa.py <.s file> [wgrad_direct | gemm_rs]   (hipcc -S output for gfx950); exit status 1 on a finding.
+The same walk checks csrc/gemm_rs.hip's asm LDS reads of the B operand against their asm `s_waitcnt lgkmcnt(N)`.
 """
 import re
 import sys
@@ -52,7 +53,7 @@ def split_blocks(lines):
     return blocks
 
 
-def check_kernel(name, lines):
+def check_kernel(name, lines, load_op="global_load", counter="vmcnt"):
     """Walk every path of the control-flow graph (states = the queue of outstanding asm loads; each (block, state) once)."""
     blocks = split_blocks(lines)
     index = {lab: i for i, (lab, _) in enumerate(blocks) if lab}
@@ -69,21 +70,21 @@ def check_kernel(name, lines):
         fall = True
         for ln, code, in_asm in blocks[bi][1]:
             op = code.split()[0]
-            if in_asm and op.startswith("global_load"):
+            if in_asm and op.startswith(load_op):
                 dst = code.split(None, 1)[1].split(",")[0]
                 busy = set().union(*inflight) if inflight else set()
                 bad = regs(code.split(",", 1)[1]) & busy
-                if bad and (ln, code, sorted(bad)) not in findings:
-                    findings.append((ln, code, sorted(bad)))
+                if bad and (ln, code, tuple(sorted(bad))) not in findings:
+                    findings.append((ln, code, tuple(sorted(bad))))
                 inflight.append(regs(dst))
                 continue
             if in_asm and op == "s_waitcnt":
-                m = re.search(r"vmcnt\((\d+)\)", code)
+                m = re.search(counter + r"\((\d+)\)", code)
                 if m:
                     n = int(m.group(1))
                     inflight = inflight[len(inflight) - n:] if n else []
                 continue
-            if op == "s_waitcnt" and "vmcnt(0)" in code:   # the compiler's own full wait retires everything too
+            if op == "s_waitcnt" and counter + "(0)" in code:   # the compiler's own full wait retires everything too
                 inflight = []
                 continue
             if op == "s_endpgm":
@@ -101,39 +102,49 @@ def check_kernel(name, lines):
             if inflight:
                 busy = set().union(*inflight)
                 bad = regs(code) & busy
-                if bad and (ln, code, sorted(bad)) not in findings:
-                    findings.append((ln, code, sorted(bad)))
+                if bad and (ln, code, tuple(sorted(bad))) not in findings:
+                    findings.append((ln, code, tuple(sorted(bad))))
         if fall and bi + 1 < len(blocks):
             work.append((bi + 1, tuple(frozenset(r) for r in inflight)))
     return sorted(findings)
 
 
-def main(path):
+def main(path, family="wgrad_direct"):
+    # family "wgrad_direct": csrc/gemm_wg.hip (asm global loads, vmcnt; no scratch allowed at all);
+    # family "gemm_rs": csrc/gemm_rs.hip's fp32 MFMA loop (asm ds_read_b32 of the B operand, lgkmcnt; a few instantiations
+    # spill other registers - a spill of an in-flight one is found as an instruction that touches it)
+    sym = {"wgrad_direct": "_ZN2gb19wgrad_direct_kernel", "gemm_rs": "_ZN2gb14gemm_rs_kernel"}[family]
+    load_op, counter = ("global_load", "vmcnt") if family == "wgrad_direct" else ("ds_read", "lgkmcnt")
     kernels = {}
     cur = None
     for i, raw in enumerate(open(path), 1):
-        m = re.match(r"^(_ZN2gb19wgrad_direct_kernel\w+):", raw)
+        m = re.match(r"^(" + sym + r"\w+):", raw)
         if m:
             cur = m.group(1)
             kernels[cur] = []
             continue
         if cur is not None:
-            kernels[cur].append((i, raw))
-            if "s_endpgm" in raw:
+            if raw.startswith(".Lfunc_end"):   # (a kernel may hold several s_endpgm)
                 cur = None
+                continue
+            kernels[cur].append((i, raw))
     if not kernels:
-        print("no wgrad_direct_kernel in", path)
+        print("no %s kernel in" % family, path)
         return 1
     status = 0
-    # no scratch memory either: a spill is a store of a register - possibly of one still in flight
-    text = open(path).read()
-    for m in re.finditer(r"\.amdhsa_kernel (_ZN2gb19wgrad_direct_kernel\w+)(.*?)\.end_amdhsa_kernel", text, flags=re.S):
-        sz = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m.group(2))
-        if sz and int(sz.group(1)) != 0:
-            print("%s: %s bytes of scratch per lane (spilled registers)" % (m.group(1), sz.group(1)))
-            status = 1
+    if family == "wgrad_direct":
+        # no scratch memory either: a spill is a store of a register - possibly of one still in flight
+        text = open(path).read()
+        for m in re.finditer(r"\.amdhsa_kernel (" + sym + r"\w+)(.*?)\.end_amdhsa_kernel", text, flags=re.S):
+            sz = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m.group(2))
+            if sz and int(sz.group(1)) != 0:
+                print("%s: %s bytes of scratch per lane (spilled registers)" % (m.group(1), sz.group(1)))
+                status = 1
     for name, lines in kernels.items():
-        f = check_kernel(name, lines)
+        n_asm = sum(1 for _, raw in lines if raw.strip().startswith(load_op) )
+        f = check_kernel(name, lines, load_op, counter)
+        if family == "gemm_rs":   # ... and its A operand's asm global loads against their asm `s_waitcnt vmcnt(0)`
+            f = sorted(set(f) | set(check_kernel(name, lines, "global_load", "vmcnt")), key=lambda x: x[0])
         print("%s: %d instructions, %s" % (name, len(lines), "ok" if not f else "%d finding(s)" % len(f)))
         for ln, code, bad in f[:20]:
             print("   line %d: %s   <- in flight: %s" % (ln, code, ", ".join("v%d" % r for r in bad)))
@@ -143,4 +154,4 @@ def main(path):
 
 
 if __name__ == "__main__":
-    sys.exit(main(sys.argv[1]))
+    sys.exit(main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "wgrad_direct"))

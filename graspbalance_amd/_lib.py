@@ -163,7 +163,7 @@ class GemmOpts(_c.Structure):
                 ("scratch_bytes", _c.c_ulonglong), ("rows_dev", _c.c_void_p), ("flags", _c.c_int)]
 
 
-PREC_F32, PREC_BF16 = 0, 1
+PREC_F32, PREC_BF16, PREC_F32_SPLIT3 = 0, 1, 2
 GEMM_NO_RING = 1   # GbGemmOpts.flags
 GEMM_NO_PAIR = 2
 GEMM_NO_DIRECT = 4

@@ -122,11 +122,12 @@ __device__ __forceinline__ void bn_finalize_column(const BnFinalize &f, double s
 // Reductions shorter than 16 (the xyz-only first layers) stay on the fp32 instruction.  Per call.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 inline bool opts_bf16(const GbGemmOpts *o) { return o && o->precision == GB_PREC_BF16; }
+inline bool opts_split3(const GbGemmOpts *o) { return o && o->precision == GB_PREC_F32_SPLIT3; }
 inline int opts_reserved(const GbGemmOpts *o) { return o ? o->reserved_cus : 0; }
 inline const long long *opts_rows(const GbGemmOpts *o) { return o ? o->rows_dev : nullptr; }
 inline bool opts_no_ring(const GbGemmOpts *o) { return o && (o->flags & GB_GEMM_NO_RING); }
 inline bool opts_bad(const GbGemmOpts *o) {
-  return o && ((o->precision != GB_PREC_F32 && o->precision != GB_PREC_BF16) || o->reserved_cus < 0 ||
+  return o && ((o->precision != GB_PREC_F32 && o->precision != GB_PREC_BF16 && o->precision != GB_PREC_F32_SPLIT3) || o->reserved_cus < 0 ||
                o->reserved_cus > 128 || (o->scratch && reinterpret_cast<uintptr_t>(o->scratch) % 16 != 0) ||
                (o->rows_dev && reinterpret_cast<uintptr_t>(o->rows_dev) % 8 != 0) ||
                (o->flags & ~(GB_GEMM_NO_RING | GB_GEMM_NO_PAIR | GB_GEMM_NO_DIRECT)));

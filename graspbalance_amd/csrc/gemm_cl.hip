@@ -524,7 +524,7 @@ static int gemm_fwd_impl(const float *x, const float *w, const float *aff, const
   if (rs_pays(P, opts) &&
       rs_gemm_try(x, w, y, aff, stats, stat_slots, nullptr, nullptr, P, K, N, 1, stats ? RS_STATS : RS_STORE,
                   as_stream(stream), bf16, opts_reserved(opts), nullptr, stats ? row_w16 : nullptr, nullptr,
-                  opts_rows(opts)))
+                  opts_rows(opts), opts_split3(opts)))
     return finalize_after(check_launch("gb_gemm_fwd"), fin, stats, stat_slots, N, stream);
   if (opts_rows(opts)) return GB_EINVAL;  // a device-side row count: row-streaming kernel only
   if (!(row_w16 && stats) && !opts_no_ring(opts)) {
@@ -621,7 +621,7 @@ extern "C" int gb_gemm_fwd_pool(const float *x, const float *w, const float *aff
   pool.D = D;
   // no Y: a forward-only caller (inference) - nothing can find the arg-max rows afterwards
   if (!rs_gemm_try(x, w, y, aff, stats, stat_slots, nullptr, nullptr, P, K, N, 1, RS_STATS_POOL_V, as_stream(stream),
-                   opts_bf16(opts), opts_reserved(opts), nullptr, nullptr, &pool, opts_rows(opts)))
+                   opts_bf16(opts), opts_reserved(opts), nullptr, nullptr, &pool, opts_rows(opts), opts_split3(opts)))
     return GB_EINVAL;
   return finalize_after(check_launch("gb_gemm_fwd_pool"), fin, stats, stat_slots, N, stream);
 }
@@ -694,7 +694,8 @@ extern "C" int gb_gemm_dgrad(const float *dy, const float *w, float *dx, const f
   if (P / 64 * ((K + 63) / 64) > 0x7fffffffLL) return GB_ERANGE;
   if (rs_pays(P, opts) &&
       rs_gemm_try(dy, w, dx, nullptr, dstats, stat_slots, y_prev, ab_prev, P, N, K, 0, dstats ? RS_BNBWD : RS_STORE,
-                  as_stream(stream), bf16, opts_reserved(opts), nullptr, nullptr, nullptr, opts_rows(opts)))
+                  as_stream(stream), bf16, opts_reserved(opts), nullptr, nullptr, nullptr, opts_rows(opts),
+                  opts_split3(opts)))
     return done(check_launch("gb_gemm_dgrad"));
   if (opts_rows(opts)) return GB_EINVAL;  // a device-side row count: row-streaming kernel only
   if (!opts_no_ring(opts)) {

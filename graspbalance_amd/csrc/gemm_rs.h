@@ -29,6 +29,7 @@ struct RsPool {
 bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, double *stats, int slots,
                  const float *epi_y, const float *epi_ab, long long P, int R, int C, int w_kc, int epi,
                  hipStream_t s, bool bf16, int reserved_cus, const float *epi_x = nullptr,
-                 const uint16_t *epi_w16 = nullptr, const RsPool *pool = nullptr, const long long *rows_dev = nullptr);
+                 const uint16_t *epi_w16 = nullptr, const RsPool *pool = nullptr, const long long *rows_dev = nullptr,
+                 bool split3 = false);   // split3: GB_PREC_F32_SPLIT3 where an instantiation fits, fp32 MFMA otherwise
 
 }  // namespace gb

@@ -133,18 +133,58 @@ __device__ __forceinline__ void rs_a_wait(rs_f32x4 (&d)[4]) {
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
 }
 
-template <int NT, int EPI, bool BF = false, bool GEN3 = false>
-__global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_BNBWD_X) ? 4 : 2)) void gemm_rs_kernel(RsArgs g) {
+// SP (GB_PREC_F32_SPLIT3, round 5): fp32 products through the bf16 matrix cores.  a = a_hi + a_mid + a_lo EXACTLY (three
+// 8-bit slices of the 24-bit mantissa, by truncation), likewise the weights - three bf16 images [k / 8][C32][8] in LDS -
+// and the six products of weight >= 2^-16 (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid) on v_mfma_f32_32x32x16_bf16,
+// smallest first, fp32 accumulate: the error against fp64 is that of the fp32 MFMA (tools/split3_probe.hip: 1.7e-7
+// against 2.0e-7 relative L2) at twice the inner loop's rate.
+// CGS: column groups.  Three images of a 128 x 256 matrix are 192 KB, so a workgroup owns C32 = NT*32 of the CGS*C32
+// output columns; the CGS groups of a row range sit on workgroups 8 apart (one XCD: the second read of A is an L2 hit).
+__device__ __forceinline__ float rs_trunc16(float x) { return __uint_as_float(__float_as_uint(x) & 0xFFFF0000u); }
+__device__ __forceinline__ unsigned rs_pack_hi(float lo_elem, float hi_elem) {   // two exactly-bf16 floats -> one register
+  return __builtin_amdgcn_perm(__float_as_uint(hi_elem), __float_as_uint(lo_elem), 0x07060302u);
+}
+
+template <int NT, int EPI, bool BF = false, bool GEN3 = false, bool SP = false, int CGS = 1>
+__global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_BNBWD_X && !SP) ? 4 : 2)) void gemm_rs_kernel(RsArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  static_assert(!(SP && (BF || GEN3)), "the split is an fp32 mode of the plain operand");
+  static_assert(CGS == 1 || SP, "column groups exist for the split's three images");
   constexpr int C32 = NT * 32;
+  constexpr int LDD = C32 * CGS;          // packed row pitch of the whole product
   const int rpad = g.nch * RS_CH;
-  float *Bs = lds;                        // fp32: [rpad][C32] ; bf16: [rpad / 8][C32][8] (half the bytes)
-  float *s_aff = lds + (size_t)rpad * C32 / (BF ? 2 : 1);  // [2][rpad]
+  float *Bs = lds;                        // fp32: [rpad][C32] ; bf16: [rpad / 8][C32][8] (half the bytes) ; split: three of those
+  float *s_aff = lds + (size_t)rpad * C32 * (SP ? 3 : BF ? 1 : 2) / 2;  // [2][rpad]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int m = lane & 31, h = lane >> 5;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lds;
+  // column group: this workgroup's C32 columns of the ctot; every global array is rebased to its first column, what is
+  // left to the code below are the strides (weights, tables, statistics, pairs) - ctot instead of g.C
+  const int ctot = g.C;
+  unsigned bid = blockIdx.x, nwg = gridDim.x;
+  if constexpr (CGS > 1) {
+    const int cg = (int)((blockIdx.x >> 3) % CGS);
+    bid = ((blockIdx.x >> 3) / CGS) * 8 + (blockIdx.x & 7);
+    nwg = gridDim.x / CGS;
+    const int col0 = cg * C32;
+    g.C = C32;                            // (the host launches CGS > 1 only for ctot == CGS * C32)
+    g.w += g.w_kc ? (size_t)col0 * g.R : (size_t)col0;
+    if (g.d) g.d += col0;
+    if (g.epi_y) g.epi_y += col0;
+    if (g.stats) g.stats += col0;
+    if (g.epi_ab) g.epi_ab += col0;
+    if (g.epi_gamma) g.epi_gamma += col0;
+    if (g.pairs) g.pairs = reinterpret_cast<float2 *>(reinterpret_cast<float *>(g.pairs) + col0);
+  }
   auto put_b = [&](int r, int c, float v) {
-    if constexpr (BF) reinterpret_cast<__bf16 *>(lds)[((size_t)(r >> 3) * C32 + c) * 8 + (r & 7)] = (__bf16)v;
+    if constexpr (SP) {
+      __bf16 *img = reinterpret_cast<__bf16 *>(lds);
+      const size_t o = ((size_t)(r >> 3) * C32 + c) * 8 + (r & 7), one = (size_t)rpad * C32;
+      const float hi = rs_trunc16(v), r1 = v - hi, mid = rs_trunc16(r1), lo = r1 - mid;   // all exact
+      img[o] = (__bf16)hi;
+      img[one + o] = (__bf16)mid;
+      img[2 * one + o] = (__bf16)lo;      // (<= 8 significant bits)
+    } else if constexpr (BF) reinterpret_cast<__bf16 *>(lds)[((size_t)(r >> 3) * C32 + c) * 8 + (r & 7)] = (__bf16)v;
     else Bs[(size_t)r * C32 + c] = v;
   };
 
@@ -175,7 +215,7 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
         }
       }
     }
-  } else if (g.C % 4 == 0 && reinterpret_cast<uintptr_t>(g.w) % 16 == 0) {
+  } else if (ctot % 4 == 0 && reinterpret_cast<uintptr_t>(g.w) % 16 == 0) {
     constexpr int Q = C32 / 4;  // float4 per LDS row
     const int total = rpad * Q;
     for (int i0 = t; i0 < total; i0 += 4 * RS_TPB) {
@@ -185,14 +225,14 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
         const int i = i0 + u * RS_TPB;
         const int r = i / Q, c = (i % Q) * 4;
         const bool ok = i < total && r < g.R && c < g.C;
-        v[u] = *reinterpret_cast<const float4 *>(g.w + (ok ? (size_t)r * g.C + c : 0));
+        v[u] = *reinterpret_cast<const float4 *>(g.w + (ok ? (size_t)r * ctot + c : 0));
         if (!ok) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int i = i0 + u * RS_TPB;
         if (i < total) {
-          if constexpr (BF) {
+          if constexpr (BF || SP) {
             put_b(i / Q, (i % Q) * 4 + 0, v[u].x);
             put_b(i / Q, (i % Q) * 4 + 1, v[u].y);
             put_b(i / Q, (i % Q) * 4 + 2, v[u].z);
@@ -206,7 +246,7 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
   } else {
     for (int i = t; i < rpad * C32; i += RS_TPB) {
       const int c = i % C32, r = i / C32;
-      put_b(r, c, (r < g.R && c < g.C) ? g.w[(size_t)r * g.C + c] : 0.f);
+      put_b(r, c, (r < g.R && c < g.C) ? g.w[(size_t)r * ctot + c] : 0.f);
     }
   }
   if (g.aff)
@@ -222,7 +262,8 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
   // registers of fp64 sums the pooled epilogue spilled 130 registers (0.25 GB of scratch written per launch).
   // Round 5: the 256-wide RS_STATS instantiations as well (NT = 8: 128 accumulators + 32 registers of fp64 sums + the
   // chunk double buffer; the bf16 one spilled 78 registers - the stress configuration's dominant launches)
-  constexpr bool LSTAT = EPI == RS_STATS_POOL_V || (EPI == RS_STATS && NT == 8) || (EPI == RS_BNBWD && BF);
+  constexpr bool LSTAT = EPI == RS_STATS_POOL_V || (EPI == RS_STATS && NT == 8) || (EPI == RS_BNBWD && BF) ||
+                         (SP && (EPI == RS_STATS || EPI == RS_BNBWD));   // (the split's operands take the registers)
   static_assert(!(LSTAT && GEN3), "s_gen and s_st would share the LDS behind the tables");
   double *s_st = reinterpret_cast<double *>(s_aff + (g.aff ? 2 * rpad : 0));
   if constexpr (LSTAT)
@@ -236,10 +277,10 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
     gP = pd < g.P ? (pd > 0 ? pd : 0) : g.P;
   }
   const long long ntiles = (gP + 31) / 32;
-  const long long nw = (long long)gridDim.x * RS_WAVES;
+  const long long nw = (long long)nwg * RS_WAVES;
   // wave w of every workgroup before wave w+1 of any: with fewer tiles than waves the work spreads over all CUs
   // (and over the four SIMDs of each) instead of filling the 8 waves of the first workgroups
-  long long tile = (long long)wave * gridDim.x + blockIdx.x;
+  long long tile = (long long)wave * nwg + bid;
 
   constexpr bool BNB = EPI == RS_BNBWD || EPI == RS_BNBWD_X;
   constexpr int NS = EPI == RS_BNBWD_X ? 5 : 2;  // column sums per column: [g, g*xhat (, g*x0, g*x1, g*x2)] / [y, y^2]
@@ -257,9 +298,9 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
       const int col = j * 32 + m;
       const bool ok = col < g.C;
       ea[j] = ok ? g.epi_ab[col] : 0.f;
-      eb[j] = ok ? g.epi_ab[g.C + col] : 0.f;
-      em[j] = ok ? g.epi_ab[2 * g.C + col] : 0.f;
-      er[j] = ok ? g.epi_ab[3 * g.C + col] : 0.f;
+      eb[j] = ok ? g.epi_ab[ctot + col] : 0.f;
+      em[j] = ok ? g.epi_ab[2 * ctot + col] : 0.f;
+      er[j] = ok ? g.epi_ab[3 * ctot + col] : 0.f;
     }
   }
 
@@ -344,7 +385,8 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     // (not the bf16 instantiations: in two of them the allocator still copied in-flight tuples in front of the wait)
-    constexpr bool A_ASM = !GEN3 && !BF;
+    // (nor the split's dgrad: the same copies, found by the same check)
+    constexpr bool A_ASM = !GEN3 && !BF && !(SP && EPI == RS_BNBWD);
     float4 cur[4], nxt[4];
     // The chunk in flight lives in `afl` only between its request and its wait INSIDE one loop trip; what is carried
     // round the loop are the 16 plain values taken out of it behind the wait.  (Carrying the tuples themselves made the
@@ -379,11 +421,11 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
       }
 
       // (fp32, whole tiles) the B values of the chunk's first step are requested here, ahead of the operand's prologue
-      float bq0[BF || PART ? 1 : NT], bq1[BF || PART ? 1 : NT];
+      float bq0[BF || SP || PART ? 1 : NT], bq1[BF || SP || PART ? 1 : NT];
       const unsigned baddr = lds0 + (unsigned)(((kc * RS_CH + h * 16) * C32 + m) * 4);
       // (not where the prologue is long vector code of the compiler's own - the generated operand, the 3-channel rows'
       // address arithmetic: the checker found it reading undefined high halves out of registers in flight there)
-      constexpr bool B_EARLY = !BF && !PART && !GEN3 && EPI != RS_BNBWD_X;
+      constexpr bool B_EARLY = !BF && !SP && !PART && !GEN3 && EPI != RS_BNBWD_X;
       if constexpr (B_EARLY) rs_b_request<NT, 0>(bq0, baddr);
       float av[16];
       if constexpr (GEN3) {
@@ -457,7 +499,54 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
       // registers it reuses there with s_waitcnt vmcnt(N) of its own book-keeping (it cannot see these loads), and one of
       // those behind the request would wait for it at once.  Unconditional: past the end it re-reads the last row.
       if constexpr (A_ASM) request_chunk(afl, ntile, nkc);
-      if constexpr (BF) {
+      if constexpr (SP) {
+        // the lane's 16 values as three exact 8-bit slices each (vector ALU: and, subtract, and, subtract, three packs
+        // per pair of values - paid in full beside the MFMAs, tools/mfma_valu_overlap.hip), then per k-group of 8 the
+        // six products, term-major over the NT accumulators: a chain's next link is NT MFMAs later (with the six
+        // products of one accumulator back to back the probe ran 2.5x slower)
+        unsigned ph[8], pm[8], pl[8];
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+          const float x0 = av[i], x1 = av[i + 1];
+          const float h0 = rs_trunc16(x0), h1 = rs_trunc16(x1), r0 = x0 - h0, r1 = x1 - h1;
+          const float m0 = rs_trunc16(r0), m1 = rs_trunc16(r1), l0 = r0 - m0, l1 = r1 - m1;
+          ph[i / 2] = rs_pack_hi(h0, h1);
+          pm[i / 2] = rs_pack_hi(m0, m1);
+          pl[i / 2] = rs_pack_hi(l0, l1);
+        }
+        const bf16x8 *img = reinterpret_cast<const bf16x8 *>(lds);
+        const size_t one = (size_t)(rpad / 8) * C32;   // bf16x8 elements per image
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          bf16x8 ah, am, al;
+          __builtin_memcpy(&ah, &ph[4 * u], 16);
+          __builtin_memcpy(&am, &pm[4 * u], 16);
+          __builtin_memcpy(&al, &pl[4 * u], 16);
+          const bf16x8 *bp8 = img + (size_t)(kc * 4 + 2 * h + u) * C32 + m;
+          bf16x8 bh[NT], bm[NT], bl[NT];
+#pragma unroll
+          for (int q = 0; q < NT; ++q)
+            if (in(q)) { bh[q] = bp8[q * 32]; bm[q] = bp8[one + q * 32]; bl[q] = bp8[2 * one + q * 32]; }
+#pragma unroll
+          for (int q = 0; q < NT; ++q)
+            if (in(q)) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[q], acc[q], 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < NT; ++q)
+            if (in(q)) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[q], acc[q], 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < NT; ++q)
+            if (in(q)) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm[q], acc[q], 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < NT; ++q)
+            if (in(q)) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[q], acc[q], 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < NT; ++q)
+            if (in(q)) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[q], acc[q], 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < NT; ++q)
+            if (in(q)) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[q], acc[q], 0, 0, 0);
+        }
+      } else if constexpr (BF) {
         // this lane's 16 reduction indices kc*32 + h*16 + (0..15) = the two k-groups kc*4 + 2h + {0, 1}
         bf16x8 a8[2];
 #pragma unroll
@@ -525,7 +614,7 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
           }
           const unsigned lane_off = (unsigned)(4 * h) * (unsigned)g.ldd + (unsigned)m;
           const int nrow = (int)(gP - trow) - 4 * h;    // rows (r&3) + 8(r>>2) below this are valid
-          const bool dense_tile = trow + 32 <= gP && g.ldd == C32;   // (wave-uniform)
+          const bool dense_tile = trow + 32 <= gP && g.ldd == LDD;   // (wave-uniform)
           float *pv = reinterpret_cast<float *>(g.pairs);
           // Pass 1, column tile by column tile: weighted BatchNorm sums, the Y store, then the accumulators are turned
           // into sign(gamma) * y IN PLACE (no second copy of the tile's 128 registers).
@@ -558,10 +647,10 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
                 // immediate field up to 3 rows + 7 column tiles; four uniform bases cover the rest).  With a run-time
                 // pitch and a per-row guard every one of the 128 stores sat in its own branch with its own spilled
                 // address: 152 spilled registers, 0.25 GB of scratch written per launch.
-                float *tb = g.d + trow * C32;
-                const unsigned lo = (unsigned)(4 * h) * (unsigned)C32 + (unsigned)m;
+                float *tb = g.d + trow * LDD;
+                const unsigned lo = (unsigned)(4 * h) * (unsigned)LDD + (unsigned)m;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) tb[lo + (unsigned)(((r & 3) + 8 * (r >> 2)) * C32 + q * 32)] = acc[q][r];
+                for (int r = 0; r < 16; ++r) tb[lo + (unsigned)(((r & 3) + 8 * (r >> 2)) * LDD + q * 32)] = acc[q][r];
               } else {
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
@@ -583,7 +672,7 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
               bool mem[16];
 #pragma unroll
               for (int r = 0; r < 16; ++r) mem[r] = (rk[r] >> 13) == sd && ((rk[r] >> d) & 1);
-              float *slot = pv + ((size_t)(tile + sd) * g.pool_d + d) * C32 + m;
+              float *slot = pv + ((size_t)(tile + sd) * g.pool_d + d) * LDD + m;
 #pragma unroll
               for (int q = 0; q < NT; ++q) {
                 if (!in(q)) continue;
@@ -621,9 +710,9 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
             if constexpr (BNB && !COEF_REGS) {
               const int col = q * 32 + m;
               ea[q] = g.epi_ab[col];
-              eb[q] = g.epi_ab[g.C + col];
-              em[q] = g.epi_ab[2 * g.C + col];
-              er[q] = g.epi_ab[3 * g.C + col];
+              eb[q] = g.epi_ab[ctot + col];
+              em[q] = g.epi_ab[2 * ctot + col];
+              er[q] = g.epi_ab[3 * ctot + col];
             }
             float yq[16];
             if constexpr (BNB && !YPRE) {
@@ -681,9 +770,9 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
           float cs = 0.f, cq = 0.f, ct[3] = {0.f, 0.f, 0.f};
           if constexpr (BNB && !COEF_REGS) {
             ea[q] = colok ? g.epi_ab[col] : 0.f;
-            eb[q] = colok ? g.epi_ab[g.C + col] : 0.f;
-            em[q] = colok ? g.epi_ab[2 * g.C + col] : 0.f;
-            er[q] = colok ? g.epi_ab[3 * g.C + col] : 0.f;
+            eb[q] = colok ? g.epi_ab[ctot + col] : 0.f;
+            em[q] = colok ? g.epi_ab[2 * ctot + col] : 0.f;
+            er[q] = colok ? g.epi_ab[3 * ctot + col] : 0.f;
           }
           float yq[16];
           if constexpr (BNB && !YPRE) {
@@ -748,7 +837,7 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
   };
   walk(std::false_type{}, tile, main_end, 0, NT);
   if (G >= 2) {
-    const long long u = (long long)wave * gridDim.x + blockIdx.x;
+    const long long u = (long long)wave * nwg + bid;
     const int cg = (int)(u % G), per = NT / G;
     walk(std::true_type{}, main_end + u / G, (u / G) < (ntiles - main_end) ? main_end + u / G + 1 : 0, cg * per, (cg + 1) * per);
   }
@@ -757,13 +846,13 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
     // per-column totals: lanes l / l+32 share a column, then the 8 waves through LDS (B is dead now)
     __syncthreads();
     if constexpr (LSTAT) {
-      double *st = g.stats + (size_t)(blockIdx.x % g.slots) * 2 * g.C;
+      double *st = g.stats + (size_t)(blockIdx.x % g.slots) * 2 * ctot;
       for (int i = t; i < 2 * C32; i += RS_TPB) {
         const int which = i / C32, col = i % C32;
         double sum = 0.0;
 #pragma unroll
         for (int w = 0; w < RS_WAVES / 2; ++w) sum += s_st[(size_t)(w * 2 + which) * C32 + col];
-        if (col < g.C) atomicAdd(st + which * g.C + col, sum);
+        if (col < g.C) atomicAdd(st + which * ctot + col, sum);
       }
       return;
     }
@@ -781,14 +870,14 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
       }
     }
     __syncthreads();
-    double *st = g.stats + (size_t)(blockIdx.x % g.slots) * NS * g.C;
+    double *st = g.stats + (size_t)(blockIdx.x % g.slots) * NS * ctot;
     for (int i = t; i < NS * C32; i += RS_TPB) {
       const int which = i / C32, col = i % C32;
       if (col < g.C) {
         double sum = 0.0;
 #pragma unroll
         for (int w = 0; w < RS_WAVES; ++w) sum += sd[(w * NS + which) * C32 + col];
-        atomicAdd(st + which * g.C + col, sum);
+        atomicAdd(st + which * ctot + col, sum);
       }
     }
   }
@@ -810,16 +899,45 @@ static int num_cus(int reserved) {
   return (reserved > 0 && n - reserved >= 16) ? n - reserved : n;
 }
 
-template <int NT, int EPI, bool BF, bool GEN3 = false>
+template <int NT, int EPI, bool BF, bool GEN3 = false, bool SP = false, int CGS = 1>
 static void rs_launch_p(const RsArgs &g, size_t lds_bytes, int blocks_per_cu, hipStream_t s, int reserved) {
   static std::atomic<unsigned long long> attr_set{0};
-  auto kern = gemm_rs_kernel<NT, EPI, BF, GEN3>;
+  auto kern = gemm_rs_kernel<NT, EPI, BF, GEN3, SP, CGS>;
   allow_dynamic_lds(kern, 160 * 1024, attr_set);
   const long long ntiles = (g.P + 31) / 32;   // (with rows_dev: of the row CAPACITY - the grid does not depend on the count)
   long long blocks = ntiles;  // at least one tile per workgroup; all 512 threads stage B either way
-  const long long cap = (long long)num_cus(reserved) * blocks_per_cu;
+  const long long cap = (long long)num_cus(reserved) * blocks_per_cu / CGS;
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(RS_TPB), lds_bytes, s, g);
+  if (CGS > 1) blocks = blocks >= 8 ? blocks / 8 * 8 : 8;   // the kernel finds a workgroup's column group in bits 3.. of its index
+  hipLaunchKernelGGL(kern, dim3((unsigned)(blocks * CGS)), dim3(RS_TPB), lds_bytes, s, g);
+}
+
+// GB_PREC_F32_SPLIT3: which instantiation runs the product as a three-way bf16 split, if any.  nt * 32 columns per
+// workgroup, cgs column groups; the three bf16 images of the group's weights must fit the LDS beside the tables.
+static bool rs_split_shape(long long P, int R, int C, int epi, bool has_aff, int *nt_out, int *cgs_out, size_t *lds_out) {
+  if (P < 16384 || R % 4 != 0 || R < 32 || C % 64 != 0) return false;
+  if (epi != RS_STATS && epi != RS_BNBWD && epi != RS_STATS_POOL_V && epi != RS_STORE) return false;
+  const int nch = (R + RS_CH - 1) / RS_CH;
+  for (int nt = (epi == RS_BNBWD ? 2 : 4); nt >= 2; nt -= 2) {   // (dgrad: the y prefetch takes the registers of two column tiles)
+    if (C % (nt * 32) != 0) continue;
+    const int cgs = C / (nt * 32);
+    if (cgs != 1 && cgs != 2) continue;
+    size_t lds = (size_t)nch * RS_CH * nt * 32 * 6 + (has_aff ? (size_t)2 * nch * RS_CH * sizeof(float) : 0);
+    if (epi != RS_STORE) lds += (size_t)(RS_WAVES / 2) * 2 * nt * 32 * sizeof(double);   // the fp64 column sums (LSTAT)
+    if (lds > 150 * 1024) continue;
+    *nt_out = nt; *cgs_out = cgs; *lds_out = lds;
+    return true;
+  }
+  return false;
+}
+
+template <int NT, int CGS>
+static void rs_launch_split(const RsArgs &g, size_t lds, int epi, hipStream_t s, int reserved) {
+  if (epi == RS_STATS_POOL_V) rs_launch_p<NT, RS_STATS_POOL_V, false, false, true, CGS>(g, lds, 1, s, reserved);
+  else if (epi == RS_STATS) rs_launch_p<NT, RS_STATS, false, false, true, CGS>(g, lds, 1, s, reserved);
+  else if (epi == RS_BNBWD) {
+    if constexpr (NT == 2) rs_launch_p<NT, RS_BNBWD, false, false, true, CGS>(g, lds, 1, s, reserved);   // (rs_split_shape)
+  } else rs_launch_p<NT, RS_STORE, false, false, true, CGS>(g, lds, 1, s, reserved);
 }
 
 template <int NT, int EPI, bool GEN3 = false>
@@ -859,9 +977,24 @@ static bool rs_shape_ok(long long P, int R, int C, int epi, bool has_aff, int *n
 bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, double *stats, int slots,
                  const float *epi_y, const float *epi_ab, long long P, int R, int C, int w_kc, int epi,
                  hipStream_t s, bool bf16, int reserved_cus, const float *epi_x, const uint16_t *epi_w16,
-                 const RsPool *pool, const long long *rows_dev) {
+                 const RsPool *pool, const long long *rows_dev, bool split3) {
   int nt = 0;
   size_t lds_bytes = 0;
+  if (split3 && !bf16 && !(pool && pool->gen_x) && !epi_x && reinterpret_cast<uintptr_t>(a) % 16 == 0 &&
+      (!w_kc || reinterpret_cast<uintptr_t>(w) % 16 == 0) && !(epi == RS_STATS_POOL_V && (!pool || pool->D < 1 || pool->D > 4))) {
+    int cgs = 0;
+    if (rs_split_shape(P, R, C, epi, aff != nullptr, &nt, &cgs, &lds_bytes)) {
+      const int nch = (R + RS_CH - 1) / RS_CH;
+      RsArgs g = {a, w, d, aff, stats, epi_y, epi_ab, epi_x, epi_w16, pool ? pool->key : nullptr,
+                  pool ? pool->gamma : nullptr, pool ? pool->pairs : nullptr, pool ? pool->D : 0, nullptr, nullptr,
+                  rows_dev, P, R, C, R, C, w_kc, slots < 1 ? 1 : slots, nch, 1, 1};
+      if (nt == 4 && cgs == 1) rs_launch_split<4, 1>(g, lds_bytes, epi, s, reserved_cus);
+      else if (nt == 4) rs_launch_split<4, 2>(g, lds_bytes, epi, s, reserved_cus);
+      else if (cgs == 1) rs_launch_split<2, 1>(g, lds_bytes, epi, s, reserved_cus);
+      else rs_launch_split<2, 2>(g, lds_bytes, epi, s, reserved_cus);
+      return true;
+    }
+  }
   if (!rs_shape_ok(P, R, C, epi, aff != nullptr, &nt, &lds_bytes)) return false;
   if (epi == RS_STATS_POOL_V && (!pool || C != nt * 32 || pool->D < 1 || pool->D > 4)) return false;
   if (reinterpret_cast<uintptr_t>(a) % 16 != 0 || (w_kc && reinterpret_cast<uintptr_t>(w) % 16 != 0)) return false;

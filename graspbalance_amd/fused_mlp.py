@@ -69,9 +69,15 @@ def set_enabled(flag):
 #   * reserved CUs: set by prefetch.SamplingPrefetch while a side-stream sampling is in flight, 0 otherwise.
 #   * workspace: one GEMM_SCRATCH_BYTES tensor per (device, stream) from torch's caching allocator, allocated on first
 #     use and never resized; only kernels on that stream touch it, so the calls of a stream share it.
-_PREC_CODE = {"f32": _lib.PREC_F32, "fp32": _lib.PREC_F32, "float32": _lib.PREC_F32, "bf16": _lib.PREC_BF16,
-              "bfloat16": _lib.PREC_BF16}
-_PREC_NAME = {_lib.PREC_F32: "f32", _lib.PREC_BF16: "bf16"}
+# "f32" is the fp32 mode this package runs by default: GB_PREC_F32_SPLIT3 (the tall row-streaming products as three-way
+# exact bf16 splits on the matrix cores - fp32 MFMA's error against fp64, twice its inner-loop rate; every other product
+# fp32 MFMA) unless GB_SPLIT3=0 (A/B switch), when it is GB_PREC_F32.  "f32_mfma" / "f32_split3" name the two explicitly.
+_SPLIT3 = os.environ.get("GB_SPLIT3", "1") != "0"
+_F32 = _lib.PREC_F32_SPLIT3 if _SPLIT3 else _lib.PREC_F32
+_PREC_CODE = {"f32": _F32, "fp32": _F32, "float32": _F32, "bf16": _lib.PREC_BF16, "bfloat16": _lib.PREC_BF16,
+              "f32_mfma": _lib.PREC_F32, "f32_split3": _lib.PREC_F32_SPLIT3}
+_PREC_NAME = {_lib.PREC_F32: "f32_mfma", _lib.PREC_BF16: "bf16", _lib.PREC_F32_SPLIT3: "f32_split3"}
+_PREC_NAME[_F32] = "f32"
 _tls = threading.local()
 _RESERVED_CUS = 0
 _GEMM_FLAGS = _lib.GEMM_NO_RING if os.environ.get("GB_RING", "1") == "0" else 0   # A/B switch: few-row GEMM kernel
@@ -89,9 +95,12 @@ def _prec_code(precision):
 
 
 def set_precision(precision):
-    """'f32' (default: exact fp32 MFMA) or 'bf16' (BASELINE configs[4], "mixed bf16 MLP / fp32 geometry"): every GEMM
+    """'f32' (default, see _F32 above) or 'bf16' (BASELINE configs[4], "mixed bf16 MLP / fp32 geometry"): every GEMM
     of the fused SharedMLP path rounds its operands to bf16 on the way into the matrix cores and accumulates in fp32;
-    BatchNorm statistics, element-wise passes, geometry and all tensors in HBM stay fp32.  Applies to fused nodes whose
+    BatchNorm statistics, element-wise passes, geometry and all tensors in HBM stay fp32.  'f32_mfma' / 'f32_split3' name
+    the two fp32 modes explicitly (include/graspbal.h GB_PREC_F32 / GB_PREC_F32_SPLIT3: the tall row-streaming products on the
+    bf16 matrix cores as a three-way exact split of both operands, six products, fp32 accumulation - fp32 MFMA's error
+    against fp64, not its bits).  Applies to fused nodes whose
     forward runs on THIS thread from now on (their backward follows the forward); returns the previous setting."""
     prev = get_precision()
     _tls.prec = _prec_code(precision)
@@ -99,7 +108,7 @@ def set_precision(precision):
 
 
 def get_precision():
-    return _PREC_NAME[getattr(_tls, "prec", _lib.PREC_F32)]
+    return _PREC_NAME[getattr(_tls, "prec", _F32)]
 
 
 class precision:
@@ -126,7 +135,7 @@ def set_reserved_cus(count):
 
 
 def _prec():
-    return getattr(_tls, "prec", _lib.PREC_F32)
+    return getattr(_tls, "prec", _F32)
 
 
 def _opts(dev, st, prec, rows_dev=None):

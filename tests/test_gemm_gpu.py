@@ -22,6 +22,12 @@ SHAPES = [(1000, 3, 64), (4096, 64, 64), (5000, 131, 128), (777, 259, 256), (204
           (96, 1024, 64), (4064, 32, 64)]
 
 
+# ... and every tall shape again under GB_PREC_F32_SPLIT3 (precision code 2: the row-streaming products as three-way bf16
+# splits, csrc/gemm_rs.hip SP; same tolerances - it is an fp32 mode; shapes no split instantiation fits run as fp32)
+SHAPES_PREC = [(P, K, N, 0) for P, K, N in SHAPES] + [(P, K, N, 2) for P, K, N in SHAPES if P >= 16384] + \
+              [(70000, 128, 128, 2), (65536, 128, 64, 2), (20000, 256, 64, 2)]
+
+
 def _lib():
     from graspbalance_amd import _lib
     return _lib
@@ -42,15 +48,15 @@ def _opts(precision=0, reserved=0, scratch=True):
     return ctypes.pointer(o)
 
 
-@pytest.mark.parametrize("P,K,N", SHAPES)
-def test_gemm_fwd_stats_and_affine(P, K, N):
+@pytest.mark.parametrize("P,K,N,prec", SHAPES_PREC)
+def test_gemm_fwd_stats_and_affine(P, K, N, prec):
     L = _lib()
     torch.manual_seed(P + K + N)
     X = torch.randn(P, K, device=DEV)
     W = torch.randn(N, K, device=DEV) / K ** 0.5
     Y = torch.empty(P, N, device=DEV)
     stats = torch.zeros(2 * N, dtype=torch.float64, device=DEV)
-    L.check(L.lib().gb_gemm_fwd(L.ptr(X), L.ptr(W), None, L.ptr(Y), L.ptr(stats), 1, P, K, N, None, _opts(), None), "fwd")
+    L.check(L.lib().gb_gemm_fwd(L.ptr(X), L.ptr(W), None, L.ptr(Y), L.ptr(stats), 1, P, K, N, None, _opts(prec), None), "fwd")
     torch.cuda.synchronize()
     ref = X.double() @ W.double().t()
     scale = float(ref.abs().max()) + 1e-12
@@ -60,21 +66,21 @@ def test_gemm_fwd_stats_and_affine(P, K, N):
     # fused BatchNorm+ReLU prologue of the next layer
     aff = torch.cat([torch.randn(K, device=DEV), torch.randn(K, device=DEV)])
     Y2 = torch.empty(P, N, device=DEV)
-    L.check(L.lib().gb_gemm_fwd(L.ptr(X), L.ptr(W), L.ptr(aff), L.ptr(Y2), None, 1, P, K, N, None, None, None), "fwd aff")
+    L.check(L.lib().gb_gemm_fwd(L.ptr(X), L.ptr(W), L.ptr(aff), L.ptr(Y2), None, 1, P, K, N, None, _opts(prec), None), "fwd aff")
     torch.cuda.synchronize()
     ref2 = torch.relu(aff[:K] * X + aff[K:]).double() @ W.double().t()
     assert float((Y2.double() - ref2).abs().max()) / (float(ref2.abs().max()) + 1e-12) < 2e-6
 
 
-@pytest.mark.parametrize("P,K,N", SHAPES)
-def test_gemm_dgrad_and_wgrad(P, K, N):
+@pytest.mark.parametrize("P,K,N,prec", SHAPES_PREC)
+def test_gemm_dgrad_and_wgrad(P, K, N, prec):
     L = _lib()
     torch.manual_seed(P * 3 + K + N)
     X = torch.randn(P, K, device=DEV)
     W = torch.randn(N, K, device=DEV)
     dY = torch.randn(P, N, device=DEV)
     dX = torch.empty(P, K, device=DEV)
-    L.check(L.lib().gb_gemm_dgrad(L.ptr(dY), L.ptr(W), L.ptr(dX), None, None, None, 0, P, K, N, None, None, None, _opts(), None), "dgrad")
+    L.check(L.lib().gb_gemm_dgrad(L.ptr(dY), L.ptr(W), L.ptr(dX), None, None, None, 0, P, K, N, None, None, None, _opts(prec), None), "dgrad")
     dW = torch.zeros(N, K, device=DEV)
     L.check(L.lib().gb_gemm_wgrad(L.ptr(dY), L.ptr(X), None, L.ptr(dW), P, K, N, None, None), "wgrad")
     torch.cuda.synchronize()
@@ -84,8 +90,8 @@ def test_gemm_dgrad_and_wgrad(P, K, N):
     assert float((dW.double() - rw).abs().max()) / (float(rw.abs().max()) + 1e-12) < 1e-5
 
 
-@pytest.mark.parametrize("P,K,N", SHAPES)
-def test_gemm_fused_epilogues_slotted(P, K, N):
+@pytest.mark.parametrize("P,K,N,prec", SHAPES_PREC)
+def test_gemm_fused_epilogues_slotted(P, K, N, prec):
     """forward: prologue affine + statistics spread over slot rows; dgrad: BatchNorm-backward sums."""
     L = _lib()
     torch.manual_seed(P * 7 + K + N)
@@ -95,7 +101,7 @@ def test_gemm_fused_epilogues_slotted(P, K, N):
     aff = torch.cat([torch.randn(K, device=DEV), torch.randn(K, device=DEV)])
     Y = torch.empty(P, N, device=DEV)
     stats = torch.zeros(slots, 2 * N, dtype=torch.float64, device=DEV)
-    L.check(L.lib().gb_gemm_fwd(L.ptr(X), L.ptr(W), L.ptr(aff), L.ptr(Y), L.ptr(stats), slots, P, K, N, None, _opts(), None), "fwd")
+    L.check(L.lib().gb_gemm_fwd(L.ptr(X), L.ptr(W), L.ptr(aff), L.ptr(Y), L.ptr(stats), slots, P, K, N, None, _opts(prec), None), "fwd")
     torch.cuda.synchronize()
     ref = torch.relu(aff[:K] * X + aff[K:]).double() @ W.double().t()
     assert float((Y.double() - ref).abs().max()) / (float(ref.abs().max()) + 1e-12) < 2e-6
@@ -110,7 +116,7 @@ def test_gemm_fused_epilogues_slotted(P, K, N):
     dX = torch.empty(P, K, device=DEV)
     dst = torch.zeros(slots, 2 * K, dtype=torch.float64, device=DEV)
     L.check(L.lib().gb_gemm_dgrad(L.ptr(dY), L.ptr(W), L.ptr(dX), L.ptr(yprev), L.ptr(ab), L.ptr(dst), slots, P, K, N,
-                                  None, None, None, _opts(reserved=8), None), "dgrad bn")
+                                  None, None, None, _opts(prec, reserved=8), None), "dgrad bn")
     torch.cuda.synchronize()
     rx = dY.double() @ W.double()
     assert float((dX.double() - rx).abs().max()) / (float(rx.abs().max()) + 1e-12) < 2e-6
@@ -401,6 +407,7 @@ def test_fused_nodes_keep_their_forward_precision_in_backward():
     assert float((a[1] - f32[1]).norm() / f32[1].norm()) > 1e-4     # and it is not the fp32 result
 
 
+@pytest.mark.parametrize("prec", [0, 2])
 @pytest.mark.parametrize("P,D,sizes,cap_extra", [
     (20000, 4, "mixed", 0),
     (16400, 2, "tiny", 0),            # up to 32 seeds inside one 32-row tile
@@ -410,7 +417,7 @@ def test_fused_nodes_keep_their_forward_precision_in_backward():
     (17000, 4, "empty", 4000),        # ... and the first, the last and some inner seeds have no rows at all
     (16900, 2, "empty", 0),
 ])
-def test_pooled_gemm_epilogue_against_torch(P, D, sizes, cap_extra):
+def test_pooled_gemm_epilogue_against_torch(P, D, sizes, cap_extra, prec):
     """gb_gemm_fwd_pool + gb_pool_pairs on synthetic row sets (random seed sizes, random member bits, some crops of a
     seed empty, seeds without rows, negative BatchNorm weights, a ragged last tile) against plain torch: Y =
     relu(a*x+b) W^T, weighted BatchNorm sums, per-(seed, crop, column) max of relu(a3*y+b3) over the member rows and
@@ -458,7 +465,7 @@ def test_pooled_gemm_epilogue_against_torch(P, D, sizes, cap_extra):
     Pc = X.shape[0]                                            # the P argument: the capacity when the count is on the device
     rows_dev = torch.tensor([P], dtype=torch.int64, device=DEV) if cap_extra else None
     ws = torch.empty(L.GEMM_SCRATCH_BYTES, dtype=torch.uint8, device=DEV)
-    opts = ctypes.pointer(L.GemmOpts(L.PREC_F32, 0, ws.data_ptr(), ws.numel(), L.ptr(rows_dev)))
+    opts = ctypes.pointer(L.GemmOpts(prec, 0, ws.data_ptr(), ws.numel(), L.ptr(rows_dev)))
     tiles = (Pc + 31) // 32
     pairs = torch.full(((tiles + R) * D * N,), float("nan"), device=DEV)
     Y = torch.full((Pc, N), 12345.0, device=DEV)

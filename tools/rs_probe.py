@@ -1,5 +1,5 @@
 """Kernel-only timing of the row-streaming products (csrc/gemm_rs.hip) through a given build of the library.
-usage: rs_probe.py <lib.so> [iters]     (an ablation build: make -C graspbalance_amd/csrc OUT=... FLAGS+=-DRS_ABL=n)"""
+usage: rs_probe.py <lib.so> [iters] [precision]     (precision: 0 = fp32 MFMA, 2 = GB_PREC_F32_SPLIT3)"""
 import ctypes, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,6 +11,14 @@ so.gb_gemm_dgrad.argtypes = [P_, P_, P_, P_, P_, P_, I, LL, I, I, P_, P_, P_, P_
 so.gb_gemm_fwd_pool.argtypes = [P_, P_, P_, P_, P_, P_, LL, LL, P_, P_, I, LL, I, I, I, P_, P_, P_]
 dev = "cuda:0"
 st = torch.cuda.current_stream().cuda_stream
+
+
+class GemmOpts(ctypes.Structure):
+    _fields_ = [("precision", ctypes.c_int), ("reserved_cus", ctypes.c_int), ("scratch", ctypes.c_void_p),
+                ("scratch_bytes", ctypes.c_ulonglong), ("rows_dev", ctypes.c_void_p), ("flags", ctypes.c_int)]
+
+
+OPTS = ctypes.pointer(GemmOpts(int(sys.argv[3]) if len(sys.argv) > 3 else 0, 0, None, 0, None, 0))
 SLOTS = 32
 
 
@@ -36,7 +44,7 @@ for P, K, N in [(400000, 128, 256), (524288, 64, 128), (131072, 128, 256), (1310
     stats = torch.zeros(SLOTS * 2 * N, dtype=torch.float64, device=dev)
 
     def fwd():
-        rc = so.gb_gemm_fwd(x.data_ptr(), w.data_ptr(), aff.data_ptr(), y.data_ptr(), stats.data_ptr(), SLOTS, P, K, N, None, None, st)
+        rc = so.gb_gemm_fwd(x.data_ptr(), w.data_ptr(), aff.data_ptr(), y.data_ptr(), stats.data_ptr(), SLOTS, P, K, N, None, OPTS, st)
         assert rc == 0, rc
     timed("fwd+affine+stats %d x %d -> %d" % (P, K, N), 2.0 * P * K * N, fwd)
 
@@ -51,7 +59,7 @@ for P, K, N in [(400000, 128, 256), (524288, 64, 128), (131072, 128, 256)]:
 
     def dgrad():
         rc = so.gb_gemm_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), yp.data_ptr(), ab.data_ptr(), ds.data_ptr(), SLOTS, P, K, N,
-                              None, None, None, None, st)
+                              None, None, None, OPTS, st)
         assert rc == 0, rc
     timed("dgrad+BN-backward sums %d x %d -> %d" % (P, N, K), 2.0 * P * K * N, dgrad)
 
@@ -78,7 +86,7 @@ stats = torch.zeros(SLOTS * 2 * N, dtype=torch.float64, device=dev)
 def pool(keep_y):
     def run():
         rc = so.gb_gemm_fwd_pool(x.data_ptr(), w.data_ptr(), aff.data_ptr(), key.data_ptr(), gamma.data_ptr(), pairs.data_ptr(),
-                                 pairs.numel(), R, y.data_ptr() if keep_y else None, stats.data_ptr(), SLOTS, P, K, N, D, None, None, st)
+                                 pairs.numel(), R, y.data_ptr() if keep_y else None, stats.data_ptr(), SLOTS, P, K, N, D, None, OPTS, st)
         assert rc == 0, rc
     return run
 

@@ -645,7 +645,7 @@ def main():
                         "ms_per_step": round(ms / sampled, 3), "tflops": round(achieved, 1),
                         "mfma_bf16_frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4)}
             traffic, traffic_source = pmc_traffic(kernel, with_source=True)
-            split = kernel == "gemm_rs_kernel" and prec == "f32" and _fm._SPLIT3
+            split = kernel in ("gemm_rs_kernel", "wgrad_direct_kernel") and prec == "f32" and _fm._SPLIT3
             isa = ("v_mfma_f32_32x32x2_f32, and v_mfma_f32_32x32x16_bf16 for the products run as three-way exact bf16 splits "
                    "(GB_PREC_F32_SPLIT3: fp32 MFMA's error against fp64; ALGORITHMIC fp32 FLOP against the fp32 MFMA peak)"
                    if split else "v_mfma_f32_32x32x2_f32")
@@ -759,7 +759,7 @@ def main():
             "roofline_gemm2": roofline_second,
             "roofline_gemm3": roofline_third,
             "roofline_gemm4": roofline_fourth,
-            "fp32_products": ("tall row-streaming products as three-way exact bf16 splits on the matrix cores (GB_PREC_F32_SPLIT3: "
+            "fp32_products": ("tall products (row-streaming forward / dgrad, register-direct wgrad) as three-way exact bf16 splits on the matrix cores (GB_PREC_F32_SPLIT3: "
                               "six bf16 products per fp32 product, fp32 accumulation, same error against fp64 as fp32 MFMA - "
                               "tests/test_gemm_gpu.py, tools/split3_probe.hip); every other product fp32 MFMA; GB_SPLIT3=0 "
                               "runs all of them on fp32 MFMA") if (prec == "f32" and _fm._SPLIT3) else "fp32 MFMA",

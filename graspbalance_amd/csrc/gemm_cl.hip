@@ -652,7 +652,7 @@ extern "C" int gb_gemm_wgrad_gen3(const float *dy, const float *x0, const float 
   if (P < 0 || K < 1 || N < 1 || !dy || !x0 || !w1 || !ab1 || !dw || opts_bad(opts)) return GB_EINVAL;
   if (P == 0) return GB_OK;
   if (wg_pays(P, opts) && wg_wgrad_try(dy, nullptr, ab1, x0, w1, dw, P, K, N, opts_rows(opts), opts_reserved(opts),
-                                       as_stream(stream), opts_bf16(opts)))
+                                       as_stream(stream), opts_bf16(opts), opts_split3(opts)))
     return check_launch("gb_gemm_wgrad_gen3");
   Operand a = {dy, N, P, N, nullptr, nullptr, nullptr};
   Operand b = {nullptr, K, P, K, ab1, x0, w1};
@@ -767,7 +767,7 @@ extern "C" int gb_gemm_wgrad(const float *dy, const float *x, const float *x_aff
   }
   // many rows: both operands straight from global memory into the matrix cores (csrc/gemm_wg.hip)
   if (wg_pays(P, opts) && wg_wgrad_try(dy, x, x_aff, nullptr, nullptr, dw, P, K, N, opts_rows(opts), opts_reserved(opts),
-                                       as_stream(stream), opts_bf16(opts)))
+                                       as_stream(stream), opts_bf16(opts), opts_split3(opts)))
     return check_launch("gb_gemm_wgrad");
   if (!opts_rows(opts) && !opts_no_ring(opts) && P <= 131072) {
     // few-row products: split the P reduction for ~one round of workgroups (fp32 atomics into dW, as below)

@@ -13,7 +13,8 @@ namespace gb {
 //   rows_dev: optional device-side row count (<= P)
 // Returns false (nothing launched) when the shape does not suit the kernel.
 bool wg_wgrad_try(const float *dy, const float *x, const float *aff, const float *gen_x, const float *gen_w, float *dw,
-                  long long P, int K, int N, const long long *rows_dev, int reserved_cus, hipStream_t s, bool bf16 = false);
+                  long long P, int K, int N, const long long *rows_dev, int reserved_cus, hipStream_t s, bool bf16 = false,
+                  bool split3 = false);   // split3: GB_PREC_F32_SPLIT3 (an fp32 mode on the bf16 skeleton)
 // shape test only (no launch): what wg_wgrad_try accepts for 16-byte aligned operands
 bool wg_wgrad_suits(long long P, int K, int N, bool gen);
 

@@ -103,8 +103,35 @@ __device__ __forceinline__ void wg_wait16(A (&a)[8], B (&b)[8]) {
 #undef GB_WG_SLOT_REGS
 }
 
-template <int NTW, int KTW, int MODE, bool BF>
+// SP (GbGemmOpts.precision = GB_PREC_F32_SPLIT3): an fp32 mode on the bf16 skeleton (BF).  Both operands are cut EXACTLY into
+// three 8-bit slices of their 24-bit mantissas in registers and the six products of weight >= 2^-16 go to
+// v_mfma_f32_32x32x16_bf16, smallest first, term-major over the step's accumulators (csrc/gemm_rs.hip has the account).
+__device__ __forceinline__ float wg_trunc16(float x) { return __uint_as_float(__float_as_uint(x) & 0xFFFF0000u); }
+__device__ __forceinline__ unsigned wg_pack_hi(float lo_elem, float hi_elem) {   // two exactly-bf16 floats -> one register
+  return __builtin_amdgcn_perm(__float_as_uint(hi_elem), __float_as_uint(lo_elem), 0x07060302u);
+}
+struct WgSplit8 { bf16x8 hi, mid, lo; };
+__device__ __forceinline__ WgSplit8 wg_split8(const float (&v)[8]) {
+  unsigned ph[4], pm[4], pl[4];
+#pragma unroll
+  for (int i = 0; i < 8; i += 2) {
+    const float x0 = v[i], x1 = v[i + 1];
+    const float h0 = wg_trunc16(x0), h1 = wg_trunc16(x1), r0 = x0 - h0, r1 = x1 - h1;
+    const float m0 = wg_trunc16(r0), m1 = wg_trunc16(r1), l0 = r0 - m0, l1 = r1 - m1;
+    ph[i / 2] = wg_pack_hi(h0, h1);
+    pm[i / 2] = wg_pack_hi(m0, m1);
+    pl[i / 2] = wg_pack_hi(l0, l1);
+  }
+  WgSplit8 o;
+  __builtin_memcpy(&o.hi, ph, 16);
+  __builtin_memcpy(&o.mid, pm, 16);
+  __builtin_memcpy(&o.lo, pl, 16);
+  return o;
+}
+
+template <int NTW, int KTW, int MODE, bool BF, bool SP = false>
 __global__ __launch_bounds__(BF ? 256 : WG_TPB) void wgrad_direct_kernel(WgArgs g) {
+  static_assert(!SP || BF, "the split runs on the 16-row skeleton");
   extern __shared__ __attribute__((aligned(16))) float s_out[];  // [N][K]
   constexpr int WAVES = BF ? 4 : WG_WAVES, TPB = 64 * WAVES;
   constexpr int RSTEP = BF ? 16 : 2;   // rows of one step of a wave
@@ -172,7 +199,9 @@ __global__ __launch_bounds__(BF ? 256 : WG_TPB) void wgrad_direct_kernel(WgArgs 
     }
     constexpr int BV = MODE == WG_GEN3 ? 3 : KTW;
     if constexpr (BF) {
-      constexpr int D = 3;   // slots of 16 rows: 2 in flight while one is multiplied (a fourth slot spilled registers)
+      // slots of 16 rows: 2 in flight while one is multiplied (a fourth slot spilled registers); the split keeps its three
+      // slices of the A operand in 48 registers and a step of it is 6x the MFMAs: one slot in flight under each step
+      constexpr int D = SP ? 2 : 3;
       typedef typename WgVec<NTW>::T AV;
       typedef typename WgVec<BV>::T BVT;
       AV abuf[D][8];
@@ -201,6 +230,43 @@ __global__ __launch_bounds__(BF ? 256 : WG_TPB) void wgrad_direct_kernel(WgArgs 
       auto multiply = [&](auto younger, AV (&a)[8], BVT (&b)[8], int base, bool masked) {
         constexpr int YOUNGER = decltype(younger)::value;
         wg_wait16<YOUNGER>(a, b);
+        if constexpr (SP) {
+          WgSplit8 as[NTW];
+#pragma unroll
+          for (int qa = 0; qa < NTW; ++qa) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (masked && base + 8 * h + i >= r1) ? 0.f : a[i][qa];
+            as[qa] = wg_split8(v);
+          }
+#pragma unroll
+          for (int qb = 0; qb < KTW; ++qb) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              if constexpr (MODE == WG_GEN3) v[i] = wg_lin3(b[i][0], b[i][1], b[i][2], gw[qb][0], gw[qb][1], gw[qb][2]);
+              else v[i] = b[i][qb];
+              if constexpr (MODE != WG_PLAIN) {
+                const float z = fa[qb] * v[i] + fb[qb];
+                v[i] = z > 0.f ? z : 0.f;
+              }
+            }
+            const WgSplit8 bs = wg_split8(v);
+#pragma unroll
+            for (int qa = 0; qa < NTW; ++qa) acc[qa][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[qa].lo, bs.hi, acc[qa][qb], 0, 0, 0);
+#pragma unroll
+            for (int qa = 0; qa < NTW; ++qa) acc[qa][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[qa].hi, bs.lo, acc[qa][qb], 0, 0, 0);
+#pragma unroll
+            for (int qa = 0; qa < NTW; ++qa) acc[qa][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[qa].mid, bs.mid, acc[qa][qb], 0, 0, 0);
+#pragma unroll
+            for (int qa = 0; qa < NTW; ++qa) acc[qa][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[qa].mid, bs.hi, acc[qa][qb], 0, 0, 0);
+#pragma unroll
+            for (int qa = 0; qa < NTW; ++qa) acc[qa][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[qa].hi, bs.mid, acc[qa][qb], 0, 0, 0);
+#pragma unroll
+            for (int qa = 0; qa < NTW; ++qa) acc[qa][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[qa].hi, bs.hi, acc[qa][qb], 0, 0, 0);
+          }
+          return;
+        }
 #pragma unroll
         for (int qb = 0; qb < KTW; ++qb) {
           bf16x8 b8;
@@ -239,10 +305,15 @@ __global__ __launch_bounds__(BF ? 256 : WG_TPB) void wgrad_direct_kernel(WgArgs 
           request(abuf[u], bbuf[u]);
         }
       }
-      multiply(std::integral_constant<int, 32>{}, abuf[0], bbuf[0], base, true);
-      multiply(std::integral_constant<int, 16>{}, abuf[1], bbuf[1], base + 16, true);
-      multiply(std::integral_constant<int, 0>{}, abuf[2], bbuf[2], base + 32, true);
-      static_assert(D == 3, "the last trip is written out for three slots");
+      if constexpr (D == 3) {
+        multiply(std::integral_constant<int, 32>{}, abuf[0], bbuf[0], base, true);
+        multiply(std::integral_constant<int, 16>{}, abuf[1], bbuf[1], base + 16, true);
+        multiply(std::integral_constant<int, 0>{}, abuf[2], bbuf[2], base + 32, true);
+      } else {
+        multiply(std::integral_constant<int, 16>{}, abuf[0], bbuf[0], base, true);
+        multiply(std::integral_constant<int, 0>{}, abuf[1], bbuf[1], base + 16, true);
+      }
+      static_assert(D == 2 || D == 3, "the last trip is written out");
     } else {
     constexpr int D = WG_DEPTH;
     typedef typename WgVec<NTW>::T AV;
@@ -476,10 +547,10 @@ bool wg_wgrad_suits(long long P, int K, int N, bool gen) {
   return wg_cut(P, K, N, gen, WG_WAVES, 256, &c);
 }
 
-template <int NTW, int KTW, int MODE, bool BF>
+template <int NTW, int KTW, int MODE, bool BF, bool SP = false>
 static void wg_launch(WgArgs g, long long blocks, hipStream_t s) {
   static std::atomic<unsigned long long> attr_set{0};
-  auto kern = wgrad_direct_kernel<NTW, KTW, MODE, BF>;
+  auto kern = wgrad_direct_kernel<NTW, KTW, MODE, BF, SP>;
   allow_dynamic_lds(kern, 160 * 1024, attr_set);
   constexpr int WAVES = BF ? 4 : WG_WAVES;
   const int Q = g.qn * g.qk;
@@ -491,8 +562,11 @@ static void wg_launch(WgArgs g, long long blocks, hipStream_t s) {
 }
 
 bool wg_wgrad_try(const float *dy, const float *x, const float *aff, const float *gen_x, const float *gen_w, float *dw,
-                  long long P, int K, int N, const long long *rows_dev, int reserved_cus, hipStream_t s, bool bf16) {
+                  long long P, int K, int N, const long long *rows_dev, int reserved_cus, hipStream_t s, bool bf16,
+                  bool split3) {
   const bool gen = gen_x != nullptr;
+  if (split3 && !bf16) bf16 = true;   // the 16-row skeleton (4 waves, 3 slots); the arithmetic is chosen at the launch below
+  else split3 = false;
   if (!dy || !dw || (gen ? (!gen_w || !aff || x) : !x)) return false;
   auto al16 = [](const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
   if (!al16(dy) || (x && !al16(x)) || !al16(dw)) return false;
@@ -512,13 +586,21 @@ bool wg_wgrad_try(const float *dy, const float *x, const float *aff, const float
     else if (mode == WG_AFF) wg_launch<NTW_, KTW_, WG_AFF, BF_>(g, blocks, s); \
     else wg_launch<NTW_, KTW_, WG_PLAIN, BF_>(g, blocks, s);                   \
   } while (0)
+#define GB_WG3S(NTW_, KTW_)                                                          \
+  do {                                                                              \
+    if (mode == WG_GEN3) wg_launch<NTW_, KTW_, WG_GEN3, true, true>(g, blocks, s);    \
+    else if (mode == WG_AFF) wg_launch<NTW_, KTW_, WG_AFF, true, true>(g, blocks, s); \
+    else wg_launch<NTW_, KTW_, WG_PLAIN, true, true>(g, blocks, s);                   \
+  } while (0)
 #define GB_WG(NTW_, KTW_)                    \
   do {                                       \
-    if (bf16) GB_WG3(NTW_, KTW_, true);      \
+    if (split3) GB_WG3S(NTW_, KTW_);         \
+    else if (bf16) GB_WG3(NTW_, KTW_, true); \
     else GB_WG3(NTW_, KTW_, false);          \
   } while (0)
   if (cut.form == 1) GB_WG(4, 2); else GB_WG(2, 2);
 #undef GB_WG
+#undef GB_WG3S
 #undef GB_WG3
   return true;
 }

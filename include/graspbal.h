@@ -327,8 +327,9 @@ int gb_interp_concat_cl_grad(const float *dx0, const int32_t *idx, const float *
  *                 wrappers allocate, its launchers never do (ball_query.cpp:13-37) - same split here.           */
 #define GB_PREC_F32 0
 #define GB_PREC_BF16 1
-/* GB_PREC_F32_SPLIT3 (round 5): an fp32 mode.  The tall row-streaming products (gb_gemm_fwd, gb_gemm_fwd_pool,
- * gb_gemm_dgrad from 65 536 rows / with a device-side row count) run through the bf16 matrix cores as a three-way split:
+/* GB_PREC_F32_SPLIT3 (round 5): an fp32 mode.  The tall products (gb_gemm_fwd, gb_gemm_fwd_pool, gb_gemm_dgrad on the
+ * row-streaming kernel, gb_gemm_wgrad / gb_gemm_wgrad_gen3 on the register-direct kernel: from 65 536 rows / with a
+ * device-side row count) run through the bf16 matrix cores as a three-way split:
  * every operand is cut EXACTLY into three 8-bit slices of its 24-bit mantissa and the six products of weight >= 2^-16 are
  * accumulated in fp32 - the error against fp64 is that of the fp32 MFMA (what is dropped is <= 2^-23 relative), the results
  * are not bit-identical to GB_PREC_F32's.  Every other product, and every shape no split instantiation fits, runs exactly

@@ -191,14 +191,16 @@ def test_gemm_dgrad_wgrad_one_call_equals_the_two_single_calls(P, K, N, variant)
 
 @pytest.mark.parametrize("P,K,N", [(65536, 64, 128), (65537, 64, 64), (100001, 128, 128), (131072, 128, 256), (70000, 256, 128),
                                    (90002, 64, 256), (65536, 128, 64), (300007, 64, 128), (66000, 512, 64), (66000, 192, 128)])
-@pytest.mark.parametrize("mode", ["plain", "aff", "gen3", "rows_dev", "rows_dev_zero", "aff_bf16", "gen3_bf16", "rows_dev_bf16"])
+@pytest.mark.parametrize("mode", ["plain", "aff", "gen3", "rows_dev", "rows_dev_zero", "aff_bf16", "gen3_bf16", "rows_dev_bf16",
+                                  "plain_split3", "aff_split3", "gen3_split3", "rows_dev_split3", "rows_dev_zero_split3"])
 def test_tall_wgrad_register_direct_kernel(P, K, N, mode):
     """csrc/gemm_wg.hip (tall fp32 wgrads: operands straight from global memory into the matrix cores) against the fp64
     product and against the LDS-tile path (GB_GEMM_NO_DIRECT); odd row counts, a device-side row count below the capacity
     (rows beyond it hold NaN: they must not be read into the sums), zero rows."""
     L = _lib()
     bf16 = mode.endswith("_bf16")   # operands rounded to bf16 on their way into the matrix cores (fp32 accumulation)
-    mode = mode[:-5] if bf16 else mode
+    split3 = mode.endswith("_split3")   # GB_PREC_F32_SPLIT3: an fp32 mode (three-way exact split of both operands) - fp32's bound
+    mode = mode[:-5] if bf16 else mode[:-7] if split3 else mode
     if mode == "gen3" and K != 64:
         pytest.skip("the folded first layers have 64 outputs")
     torch.manual_seed(P + 5 * K + N)
@@ -223,7 +225,8 @@ def test_tall_wgrad_register_direct_kernel(P, K, N, mode):
     def run(flags):
         dW = torch.zeros(N, K, device=DEV)
         ws = _WS.setdefault("t", torch.empty(L.GEMM_SCRATCH_BYTES, dtype=torch.uint8, device=DEV))
-        o = ctypes.pointer(L.GemmOpts(L.PREC_BF16 if bf16 else L.PREC_F32, 0, ws.data_ptr(), ws.numel(), L.ptr(rows_dev), flags))
+        o = ctypes.pointer(L.GemmOpts(L.PREC_BF16 if bf16 else L.PREC_F32_SPLIT3 if split3 else L.PREC_F32, 0, ws.data_ptr(),
+                                      ws.numel(), L.ptr(rows_dev), flags))
         if mode == "gen3":
             L.check(L.lib().gb_gemm_wgrad_gen3(L.ptr(dY), L.ptr(x0), L.ptr(w1), L.ptr(aff), L.ptr(dW), P, K, N, o, None), "wgrad_gen3")
         else:
@@ -257,7 +260,7 @@ def test_tall_wgrad_direct_with_reserved_cus_and_few_actual_rows(reserved, rows)
     aff = torch.cat([torch.randn(K, device=DEV), torch.randn(K, device=DEV)])
     rows_dev = torch.tensor([rows], dtype=torch.int64, device=DEV)
     ref = dY[:rows].double().t() @ torch.relu(aff[:K] * X[:rows] + aff[K:]).double()
-    for prec, tol in ((L.PREC_F32, 1e-5), (L.PREC_BF16, 2e-2)):
+    for prec, tol in ((L.PREC_F32, 1e-5), (L.PREC_BF16, 2e-2), (L.PREC_F32_SPLIT3, 1e-5)):
         dW = torch.zeros(N, K, device=DEV)
         o = ctypes.pointer(L.GemmOpts(prec, reserved, None, 0, L.ptr(rows_dev), 0))
         L.check(L.lib().gb_gemm_wgrad(L.ptr(dY), L.ptr(X), L.ptr(aff), L.ptr(dW), P, K, N, o, None), "wgrad")

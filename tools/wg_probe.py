@@ -17,7 +17,8 @@ class GemmOpts(_c.Structure):
 
 
 flags = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # 4 = GB_GEMM_NO_DIRECT
-opts = _c.pointer(GemmOpts(0, 0, None, 0, None, flags))
+prec = int(sys.argv[4]) if len(sys.argv) > 4 else 0        # 2 = GB_PREC_F32_SPLIT3
+opts = _c.pointer(GemmOpts(prec, 0, None, 0, None, flags))
 shapes = [(400000, 128, 256, "aff"), (400000, 64, 128, "gen3"), (524288, 64, 128, "aff"), (524288, 64, 64, "gen3"),
           (131072, 128, 256, "aff"), (131072, 128, 128, "aff"), (400000, 128, 256, "plain"), (65536, 128, 256, "aff"),
           (32768, 128, 256, "aff"), (32768, 128, 128, "aff"), (16384, 128, 256, "aff"), (32768, 64, 128, "aff")]

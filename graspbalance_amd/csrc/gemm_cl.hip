@@ -641,7 +641,7 @@ extern "C" int gb_gemm_fwd_gen3(const float *x0, const float *w1, const float *a
   gen.gen_w = w1;
   if (!stats) return GB_EINVAL;  // (the eval-mode caller passes a scratch sum buffer: the kernel always forms the sums)
   if (!rs_gemm_try(nullptr, w, y, ab1, stats, stat_slots, nullptr, nullptr, P, K, N, 1, RS_STATS, as_stream(stream),
-                   opts_bf16(opts), opts_reserved(opts), nullptr, row_w16, &gen, opts_rows(opts)))
+                   opts_bf16(opts), opts_reserved(opts), nullptr, row_w16, &gen, opts_rows(opts), opts_split3(opts)))
     return GB_EINVAL;
   return finalize_after(check_launch("gb_gemm_fwd_gen3"), fin, stats, stat_slots, N, stream);
 }
@@ -810,7 +810,7 @@ extern "C" int gb_gemm_dgrad_first(const float *dy, const float *w, const float 
     return GB_EINVAL;
   if (P == 0) return GB_OK;
   if (!rs_gemm_try(dy, w, nullptr, nullptr, sums, slots, y_prev, ab_prev, P, N, K, 0, RS_BNBWD_X, as_stream(stream),
-                   opts_bf16(opts), opts_reserved(opts), x_in, nullptr, nullptr, opts_rows(opts)))
+                   opts_bf16(opts), opts_reserved(opts), x_in, nullptr, nullptr, opts_rows(opts), opts_split3(opts)))
     return GB_EINVAL;
   return check_launch("gb_gemm_dgrad_first");
 }
@@ -826,7 +826,7 @@ extern "C" int gb_gemm_dgrad_first_gen3(const float *dy, const float *w, const f
   RsPool gen = {};
   gen.gen_w = w_in;
   if (!rs_gemm_try(dy, w, nullptr, nullptr, sums, slots, nullptr, ab_prev, P, N, K, 0, RS_BNBWD_X, as_stream(stream),
-                   opts_bf16(opts), opts_reserved(opts), x_in, nullptr, &gen, opts_rows(opts)))
+                   opts_bf16(opts), opts_reserved(opts), x_in, nullptr, &gen, opts_rows(opts), opts_split3(opts)))
     return GB_EINVAL;
   return check_launch("gb_gemm_dgrad_first_gen3");
 }

@@ -148,7 +148,7 @@ __device__ __forceinline__ unsigned rs_pack_hi(float lo_elem, float hi_elem) {  
 template <int NT, int EPI, bool BF = false, bool GEN3 = false, bool SP = false, int CGS = 1>
 __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_BNBWD_X && !SP) ? 4 : 2)) void gemm_rs_kernel(RsArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  static_assert(!(SP && (BF || GEN3)), "the split is an fp32 mode of the plain operand");
+  static_assert(!(SP && BF), "the split is an fp32 mode");
   static_assert(CGS == 1 || SP, "column groups exist for the split's three images");
   constexpr int C32 = NT * 32;
   constexpr int LDD = C32 * CGS;          // packed row pitch of the whole product
@@ -264,8 +264,8 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
   // chunk double buffer; the bf16 one spilled 78 registers - the stress configuration's dominant launches)
   constexpr bool LSTAT = EPI == RS_STATS_POOL_V || (EPI == RS_STATS && NT == 8) || (EPI == RS_BNBWD && BF) ||
                          (SP && (EPI == RS_STATS || EPI == RS_BNBWD));   // (the split's operands take the registers)
-  static_assert(!(LSTAT && GEN3), "s_gen and s_st would share the LDS behind the tables");
-  double *s_st = reinterpret_cast<double *>(s_aff + (g.aff ? 2 * rpad : 0));
+  static_assert(!(LSTAT && GEN3 && !SP), "s_gen and s_st would share the LDS behind the tables");
+  double *s_st = reinterpret_cast<double *>(s_aff + (g.aff ? 2 * rpad : 0) + (GEN3 ? 4 * rpad : 0));
   if constexpr (LSTAT)
     for (int i = t; i < (RS_WAVES / 2) * 2 * C32; i += RS_TPB) s_st[i] = 0.0;
   __syncthreads();
@@ -584,6 +584,9 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
       // the next chunk's values: waited for behind this chunk's MFMAs and IN FRONT of the tile's epilogue (its stores
       // are then not waited for by anything until the next chunk's wait, a chunk of MFMAs later)
       if constexpr (A_ASM) {
+        // (the MFMAs are not volatile: without the fence the scheduler may sink them below this wait - in one build of
+        // the split 46 of a chunk's 48 went there and the request had nothing to run under)
+        __builtin_amdgcn_sched_barrier(0);
         rs_a_wait(afl);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -914,15 +917,24 @@ static void rs_launch_p(const RsArgs &g, size_t lds_bytes, int blocks_per_cu, hi
 
 // GB_PREC_F32_SPLIT3: which instantiation runs the product as a three-way bf16 split, if any.  nt * 32 columns per
 // workgroup, cgs column groups; the three bf16 images of the group's weights must fit the LDS beside the tables.
-static bool rs_split_shape(long long P, int R, int C, int epi, bool has_aff, int *nt_out, int *cgs_out, size_t *lds_out) {
+static bool rs_split_shape(long long P, int R, int C, int epi, bool has_aff, bool gen3, int *nt_out, int *cgs_out,
+                           size_t *lds_out) {
   if (P < 16384 || R % 4 != 0 || R < 32 || C % 64 != 0) return false;
-  if (epi != RS_STATS && epi != RS_BNBWD && epi != RS_STATS_POOL_V && epi != RS_STORE) return false;
+  if (epi != RS_STATS && epi != RS_BNBWD && epi != RS_STATS_POOL_V && epi != RS_STORE && epi != RS_BNBWD_X) return false;
+  if (epi == RS_BNBWD_X && C != 64) return false;   // (the 3-channel epilogue: 64-wide first layers, one column group)
+  if (gen3 && (epi != RS_STATS || !has_aff)) return false;
   const int nch = (R + RS_CH - 1) / RS_CH;
-  for (int nt = (epi == RS_BNBWD ? 2 : 4); nt >= 2; nt -= 2) {   // (dgrad: the y prefetch takes the registers of two column tiles)
+  for (int nt = ((epi == RS_BNBWD || epi == RS_BNBWD_X) ? 2 : 4); nt >= 2; nt -= 2) {   // (dgrad: the y prefetch takes the registers of two column tiles)
     if (C % (nt * 32) != 0) continue;
     const int cgs = C / (nt * 32);
     if (cgs != 1 && cgs != 2) continue;
+    if (gen3 && cgs != 1) continue;
     size_t lds = (size_t)nch * RS_CH * nt * 32 * 6 + (has_aff ? (size_t)2 * nch * RS_CH * sizeof(float) : 0);
+    if (gen3) lds += (size_t)nch * RS_CH * 4 * sizeof(float);   // the per-k first-layer weights
+    if (epi == RS_BNBWD_X) {   // the closing reduction's [waves][5][C32] doubles live in the images' LDS
+      const size_t red = (size_t)RS_WAVES * 5 * nt * 32 * sizeof(double);
+      if (lds < red) lds = red;
+    } else
     if (epi != RS_STORE) lds += (size_t)(RS_WAVES / 2) * 2 * nt * 32 * sizeof(double);   // the fp64 column sums (LSTAT)
     if (lds > 150 * 1024) continue;
     *nt_out = nt; *cgs_out = cgs; *lds_out = lds;
@@ -932,7 +944,12 @@ static bool rs_split_shape(long long P, int R, int C, int epi, bool has_aff, int
 }
 
 template <int NT, int CGS>
-static void rs_launch_split(const RsArgs &g, size_t lds, int epi, hipStream_t s, int reserved) {
+static void rs_launch_split(const RsArgs &g, size_t lds, int epi, bool gen3, hipStream_t s, int reserved) {
+  if constexpr (CGS == 1) {
+    if (gen3) { rs_launch_p<NT, RS_STATS, false, true, true, 1>(g, lds, 1, s, reserved); return; }
+    if constexpr (NT == 2)
+      if (epi == RS_BNBWD_X) { rs_launch_p<2, RS_BNBWD_X, false, false, true, 1>(g, lds, 1, s, reserved); return; }
+  }
   if (epi == RS_STATS_POOL_V) rs_launch_p<NT, RS_STATS_POOL_V, false, false, true, CGS>(g, lds, 1, s, reserved);
   else if (epi == RS_STATS) rs_launch_p<NT, RS_STATS, false, false, true, CGS>(g, lds, 1, s, reserved);
   else if (epi == RS_BNBWD) {
@@ -980,18 +997,20 @@ bool rs_gemm_try(const float *a, const float *w, float *d, const float *aff, dou
                  const RsPool *pool, const long long *rows_dev, bool split3) {
   int nt = 0;
   size_t lds_bytes = 0;
-  if (split3 && !bf16 && !(pool && pool->gen_x) && !epi_x && reinterpret_cast<uintptr_t>(a) % 16 == 0 &&
+  const bool sp_gen3 = pool && pool->gen_x && epi == RS_STATS;   // (the generated operand; RS_BNBWD_X carries gen_x for its epilogue)
+  if (split3 && !bf16 && (sp_gen3 ? (aff && pool->gen_w) : reinterpret_cast<uintptr_t>(a) % 16 == 0) && (epi == RS_BNBWD_X) == (epi_x != nullptr) &&
       (!w_kc || reinterpret_cast<uintptr_t>(w) % 16 == 0) && !(epi == RS_STATS_POOL_V && (!pool || pool->D < 1 || pool->D > 4))) {
     int cgs = 0;
-    if (rs_split_shape(P, R, C, epi, aff != nullptr, &nt, &cgs, &lds_bytes)) {
+    if (rs_split_shape(P, R, C, epi, aff != nullptr, sp_gen3, &nt, &cgs, &lds_bytes)) {
       const int nch = (R + RS_CH - 1) / RS_CH;
       RsArgs g = {a, w, d, aff, stats, epi_y, epi_ab, epi_x, epi_w16, pool ? pool->key : nullptr,
-                  pool ? pool->gamma : nullptr, pool ? pool->pairs : nullptr, pool ? pool->D : 0, nullptr, nullptr,
+                  pool ? pool->gamma : nullptr, pool ? pool->pairs : nullptr, pool ? pool->D : 0,
+                  pool ? pool->gen_x : nullptr, pool ? pool->gen_w : nullptr,
                   rows_dev, P, R, C, R, C, w_kc, slots < 1 ? 1 : slots, nch, 1, 1};
-      if (nt == 4 && cgs == 1) rs_launch_split<4, 1>(g, lds_bytes, epi, s, reserved_cus);
-      else if (nt == 4) rs_launch_split<4, 2>(g, lds_bytes, epi, s, reserved_cus);
-      else if (cgs == 1) rs_launch_split<2, 1>(g, lds_bytes, epi, s, reserved_cus);
-      else rs_launch_split<2, 2>(g, lds_bytes, epi, s, reserved_cus);
+      if (nt == 4 && cgs == 1) rs_launch_split<4, 1>(g, lds_bytes, epi, sp_gen3, s, reserved_cus);
+      else if (nt == 4) rs_launch_split<4, 2>(g, lds_bytes, epi, sp_gen3, s, reserved_cus);
+      else if (cgs == 1) rs_launch_split<2, 1>(g, lds_bytes, epi, sp_gen3, s, reserved_cus);
+      else rs_launch_split<2, 2>(g, lds_bytes, epi, sp_gen3, s, reserved_cus);
       return true;
     }
   }

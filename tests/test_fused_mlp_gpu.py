@@ -16,6 +16,19 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(params=["f32_mfma", "f32"])
+def arith(request):
+    """"f32_mfma": one arithmetic on every path - the tight statement (see one_arithmetic).  "f32", the default mode: the
+    folded path's generated-operand products and its 3-channel-epilogue dgrad run as three-way bf16 splits
+    (csrc/gemm_rs.hip SP with GEN3 / RS_BNBWD_X), the plain path's as fp32 MFMA - equally accurate, other last bits: the
+    paths then differ by what a flipped ReLU mask or arg-max row moves, and the bound is that noise.  Yields
+    (forward tolerance, gradient tolerance, bit-identical paths expected)."""
+    from graspbalance_amd import fused_mlp
+    prev = fused_mlp.set_precision(request.param)
+    yield (1e-5, 2e-4, True) if request.param == "f32_mfma" else (2e-5, 3e-3, False)
+    fused_mlp.set_precision(prev)
+
+
 @pytest.fixture
 def one_arithmetic():
     """Tests that state "two code paths are the same computation" pin the products to ONE arithmetic (fp32 MFMA): under
@@ -277,7 +290,7 @@ def test_la_pool_bwd_aggregated_in_lds_equals_the_direct_scatter(B, n, ns, C, ra
 
 @pytest.mark.parametrize("widths", [(64, 128), (64, 64, 128), (64, 128, 256)])
 @pytest.mark.parametrize("train", [True, False])
-def test_first_layer_closed_form_backward(train, widths, one_arithmetic):
+def test_first_layer_closed_form_backward(train, widths, arith):
     """xyz-only stacks (3 -> 64 -> ... [-> max]): the backward that never writes the first layer's dZ
     (gb_gemm_dgrad_first + moments + closed-form dW) against the layer-by-layer backward.  (64, 64, 128) is SA1's
     stack: its 64 -> 64 second layer is the shape whose closing LDS reduction once overran the allocation.)
@@ -319,13 +332,14 @@ def test_first_layer_closed_form_backward(train, widths, one_arithmetic):
             fused_mlp._FIRST_FUSE = True
             fused_mlp.set_first_fold(prev)
     b = res["plain"]
-    assert torch.equal(res["fuse"][0], b[0])
-    _close(res["fold"][0], b[0], 1e-5, "folded forward", True, 1e-3 * float(b[0].abs().max()))
+    tol_fwd, tol_grad, same_bits = arith
+    assert not same_bits or torch.equal(res["fuse"][0], b[0])
+    _close(res["fold"][0], b[0], tol_fwd, "folded forward", True, 1e-3 * float(b[0].abs().max()))
     assert torch.allclose(res["fold"][2], b[2], rtol=1e-5, atol=1e-8) and torch.allclose(res["fold"][3], b[3], rtol=1e-5)
     floor = 1e-2 * max(float(v.norm()) for v in b[1].values())
     for name in ("fuse", "fold"):
         for k in b[1]:
-            _close(res[name][1][k], b[1][k], 2e-4, name + " grad " + k, True, floor)
+            _close(res[name][1][k], b[1][k], tol_grad, name + " grad " + k, True, floor)
 
 
 def test_cylinder_distinct_rows_against_torch_unique():

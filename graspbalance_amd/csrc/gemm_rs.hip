@@ -132,6 +132,19 @@ __device__ __forceinline__ void rs_a_request(rs_f32x4 (&d)[4], const float *p0, 
 __device__ __forceinline__ void rs_a_wait(rs_f32x4 (&d)[4]) {
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
 }
+// The same wait for the instantiations in which the allocator satisfied the tied operands above with copies of the
+// registers in flight (the BatchNorm-backward dgrads in bf16 and as split): no tie - the 16 values leave the asm
+// statement in FRESH registers (early-clobber outputs), moved there behind the wait inside the statement itself.
+__device__ __forceinline__ void rs_a_wait_mov(const rs_f32x4 (&d)[4], float (&o)[16]) {
+  asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, %8\n\tv_mov_b32 %1, %9\n\tv_mov_b32 %2, %10\n\tv_mov_b32 %3, %11\n\t"
+               "v_mov_b32 %4, %12\n\tv_mov_b32 %5, %13\n\tv_mov_b32 %6, %14\n\tv_mov_b32 %7, %15"
+               : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+               : "v"(d[0][0]), "v"(d[0][1]), "v"(d[0][2]), "v"(d[0][3]), "v"(d[1][0]), "v"(d[1][1]), "v"(d[1][2]), "v"(d[1][3]));
+  asm volatile("v_mov_b32 %0, %8\n\tv_mov_b32 %1, %9\n\tv_mov_b32 %2, %10\n\tv_mov_b32 %3, %11\n\t"
+               "v_mov_b32 %4, %12\n\tv_mov_b32 %5, %13\n\tv_mov_b32 %6, %14\n\tv_mov_b32 %7, %15"
+               : "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14]), "=&v"(o[15])
+               : "v"(d[2][0]), "v"(d[2][1]), "v"(d[2][2]), "v"(d[2][3]), "v"(d[3][0]), "v"(d[3][1]), "v"(d[3][2]), "v"(d[3][3]));
+}
 
 // SP (GB_PREC_F32_SPLIT3, round 5): fp32 products through the bf16 matrix cores.  a = a_hi + a_mid + a_lo EXACTLY (three
 // 8-bit slices of the 24-bit mantissa, by truncation), likewise the weights - three bf16 images [k / 8][C32][8] in LDS -
@@ -385,8 +398,9 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     // (not the bf16 instantiations: in two of them the allocator still copied in-flight tuples in front of the wait)
-    // (nor the split's dgrad: the same copies, found by the same check)
-    constexpr bool A_ASM = !GEN3 && !BF && !(SP && EPI == RS_BNBWD);
+    // (the split's dgrad: the same copies, found by the same check - those two take the untied wait, A_MOV)
+    constexpr bool A_MOV = (SP || BF) && EPI == RS_BNBWD && !GEN3;
+    constexpr bool A_ASM = !GEN3 && (!BF || A_MOV);
     float4 cur[4], nxt[4];
     // The chunk in flight lives in `afl` only between its request and its wait INSIDE one loop trip; what is carried
     // round the loop are the 16 plain values taken out of it behind the wait.  (Carrying the tuples themselves made the
@@ -395,11 +409,14 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
     float anext[16];
     if constexpr (A_ASM) {
       request_chunk(afl, tile, 0);
-      rs_a_wait(afl);
+      if constexpr (A_MOV) rs_a_wait_mov(afl, anext);
+      else {
+        rs_a_wait(afl);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) anext[4 * i + e] = afl[i][e];
+          for (int e = 0; e < 4; ++e) anext[4 * i + e] = afl[i][e];
+      }
     } else {
       load_chunk(cur, tile, 0);
     }
@@ -587,11 +604,14 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
         // (the MFMAs are not volatile: without the fence the scheduler may sink them below this wait - in one build of
         // the split 46 of a chunk's 48 went there and the request had nothing to run under)
         __builtin_amdgcn_sched_barrier(0);
-        rs_a_wait(afl);
+        if constexpr (A_MOV) rs_a_wait_mov(afl, anext);
+        else {
+          rs_a_wait(afl);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) anext[4 * i + e] = afl[i][e];
+            for (int e = 0; e < 4; ++e) anext[4 * i + e] = afl[i][e];
+        }
       }
       if (kc == g.nch - 1) {
         // acc[q][r] = D[tile*32 + (r&3) + 8*(r>>2) + 4*h][q*32 + m]

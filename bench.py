@@ -241,7 +241,7 @@ def cpu_baseline(num_threads, device, repeats=5):
             loss = trainer.train_step(batch)
             dt = time.perf_counter() - t0
             if first is None:
-                first = float(loss)
+                first = float(loss.detach())
             if i:
                 times.append(dt)
             assert bool(torch.isfinite(loss))

@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libgraspbal_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 GB_OK = 0
 _ERRNAMES = {-1: "GB_EINVAL", -2: "GB_ELAUNCH", -3: "GB_ERANGE"}
@@ -96,6 +96,7 @@ SIGNATURES = {
     "gb_gemm_dgrad_wgrad": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "gb_gemm_uses_rs": [_L, _I, _I, _I, _I, _I],
     "gb_gemm_kernel_for": [_I, _L, _I, _I, _I, _I],
+    "gb_gemm_kernel_for2": [_I, _L, _I, _I, _I, _I, _I, _I, _U],
     "gb_gemm_dgrad_first": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P],
     "gb_moments3": [_P, _P, _L, _P, _P, _P],
     "gb_cyl_unique": [_P, _I, _I, _L, _I, _P, _P, _P, _P],

@@ -935,16 +935,24 @@ extern "C" int gb_gemm_dgrad_wgrad(const float *dy, const float *w, float *dx, c
 // (csrc/gemm_rs.hip), 2 = the LDS-DMA ring kernel (csrc/gemm_ring.hip), 3 = the column-reduction wgrad, 4 = the
 // register-direct tall wgrad (csrc/gemm_wg.hip).  Pure host-side
 // introspection (no launch), used by bench.py to attribute timings per kernel.
-extern "C" int gb_gemm_kernel_for(int kind, long long P, int K, int N, int fused_stats, int has_aff) {
+extern "C" int gb_gemm_kernel_for2(int kind, long long P, int K, int N, int fused_stats, int has_aff, int precision,
+                                   int reserved_cus, unsigned flags) {
+  const bool bf16 = precision == GB_PREC_BF16, skeleton16 = bf16 || precision == GB_PREC_F32_SPLIT3;
+  const bool no_ring = flags & GB_GEMM_NO_RING, no_direct = flags & GB_GEMM_NO_DIRECT;
   if (kind == 3)  // gb_gemm_dgrad_wgrad: 2 = ONE launch of the ring kernel carries both products, 0 = the two single calls
-    return (P < RS_PAYS_FROM && P < WG_PAYS_FROM && P > 0 && K > 0 &&
-            pair_shape(P, K, N, (long long)(GB_GEMM_SCRATCH_BYTES / sizeof(float)) / (P * K), false)) ? 2 : 0;
+    return (!(flags & GB_GEMM_NO_PAIR) && !no_ring && P < RS_PAYS_FROM && (no_direct || P < WG_PAYS_FROM) && P > 0 && K > 0 &&
+            pair_shape(P, K, N, (long long)(GB_GEMM_SCRATCH_BYTES / sizeof(float)) / (P * K), bf16)) ? 2 : 0;
   if (kind == 2) {
     if (K <= 4 && !has_aff && N % 4 == 0 && N / 4 <= GTPB && P >= 4096) return 3;
-    if (P >= WG_PAYS_FROM && wg_wgrad_suits(P, K, N, false)) return 4;
-    return (P % 32 == 0 && K % 4 == 0 && N % 4 == 0 && K >= 4 && N >= 4 && P <= 131072) ? 2 : 0;
+    if (!no_direct && P >= WG_PAYS_FROM && wg_wgrad_suits(P, K, N, false, skeleton16, reserved_cus)) return 4;
+    return (!no_ring && P % 32 == 0 && K % 4 == 0 && N % 4 == 0 && K >= 4 && N >= 4 && P <= 131072) ? 2 : 0;
   }
   if ((P >= RS_PAYS_FROM || fused_stats >= 2) && gb_gemm_uses_rs(P, K, N, kind, fused_stats, has_aff)) return 1;
+  if (no_ring) return 0;
   if (kind == 0) return K % 32 == 0 ? 2 : 0;
   return (N % 32 == 0 && K % 4 == 0) ? 2 : 0;
+}
+
+extern "C" int gb_gemm_kernel_for(int kind, long long P, int K, int N, int fused_stats, int has_aff) {
+  return gb_gemm_kernel_for2(kind, P, K, N, fused_stats, has_aff, GB_PREC_F32, 0, 0u);
 }

@@ -72,7 +72,7 @@ __device__ __forceinline__ float lin3(float x, float y, float z, float w0, float
 // `s_waitcnt lgkmcnt(NT)` whose operands are tied in/out ("+v"): the values the MFMAs read come out of the wait, so no
 // use can move above it, and the registers stay allocated while the read is in flight.  LDS returns in order, so any
 // LDS / scalar-memory operation of the compiler's own in between only makes the counted wait stricter.
-// tools/rs_check_isa.py (run by a CPU test on every build) walks the generated code for any instruction that touches
+// tools/wg_check_isa.py (family `gemm_rs`; run by `make check-isa` as part of the library build and by a CPU test) walks the generated code for any instruction that touches
 // a register between its asm read and the asm wait that retires it.
 template <int NT, int J, int Q = 0>
 __device__ __forceinline__ void rs_b_request(float (&b)[NT], unsigned addr) {

@@ -15,7 +15,8 @@ namespace gb {
 bool wg_wgrad_try(const float *dy, const float *x, const float *aff, const float *gen_x, const float *gen_w, float *dw,
                   long long P, int K, int N, const long long *rows_dev, int reserved_cus, hipStream_t s, bool bf16 = false,
                   bool split3 = false);   // split3: GB_PREC_F32_SPLIT3 (an fp32 mode on the bf16 skeleton)
-// shape test only (no launch): what wg_wgrad_try accepts for 16-byte aligned operands
-bool wg_wgrad_suits(long long P, int K, int N, bool gen);
+// shape test only (no launch): what wg_wgrad_try accepts for 16-byte aligned operands - with the SAME wave count and grid
+// it would launch (skeleton16: bf16 or split3, the 4-wave 16-row skeleton), so introspection and dispatch cannot disagree
+bool wg_wgrad_suits(long long P, int K, int N, bool gen, bool skeleton16, int reserved_cus);
 
 }  // namespace gb

@@ -542,9 +542,22 @@ static bool wg_cut(long long P, int K, int N, bool gen, int waves, long long blo
   return false;
 }
 
-bool wg_wgrad_suits(long long P, int K, int N, bool gen) {
+// The grid and wave count wg_wgrad_try launches a product with: the 16-row skeleton (bf16 and GB_PREC_F32_SPLIT3) runs 4
+// waves per workgroup, the fp32 MFMA form WG_WAVES; one workgroup per CU, never more than the rows give a loop trip each.
+static long long wg_grid(long long P, bool skeleton16, int reserved_cus, int *waves) {
+  *waves = skeleton16 ? 4 : WG_WAVES;
+  long long blocks = wg_num_cus(reserved_cus);
+  const long long rows_per_trip = (skeleton16 ? 16 * 3 : 2 * WG_DEPTH) * *waves;   // >= one loop trip per wave
+  const long long most = (P + rows_per_trip - 1) / rows_per_trip;
+  if (blocks > most) blocks = most;
+  return blocks < 1 ? 1 : blocks;
+}
+
+bool wg_wgrad_suits(long long P, int K, int N, bool gen, bool skeleton16, int reserved_cus) {
   WgCut c;
-  return wg_cut(P, K, N, gen, WG_WAVES, 256, &c);
+  int waves;
+  const long long blocks = wg_grid(P, skeleton16, reserved_cus, &waves);
+  return wg_cut(P, K, N, gen, waves, blocks, &c);
 }
 
 template <int NTW, int KTW, int MODE, bool BF, bool SP = false>
@@ -570,12 +583,8 @@ bool wg_wgrad_try(const float *dy, const float *x, const float *aff, const float
   if (!dy || !dw || (gen ? (!gen_w || !aff || x) : !x)) return false;
   auto al16 = [](const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
   if (!al16(dy) || (x && !al16(x)) || !al16(dw)) return false;
-  const int waves = bf16 ? 4 : WG_WAVES;
-  long long blocks = wg_num_cus(reserved_cus);
-  const long long rows_per_trip = (bf16 ? 16 * 3 : 2 * WG_DEPTH) * waves;   // >= one loop trip per wave
-  const long long most = (P + rows_per_trip - 1) / rows_per_trip;
-  if (blocks > most) blocks = most;
-  if (blocks < 1) blocks = 1;
+  int waves;
+  const long long blocks = wg_grid(P, bf16, reserved_cus, &waves);
   WgCut cut;
   if (!wg_cut(P, K, N, gen, waves, blocks, &cut)) return false;
   WgArgs g = {dy, x, aff, gen_x, gen_w, dw, P, N, K, rows_dev, cut.qn, cut.qk};

@@ -33,7 +33,9 @@ class FlatGradAllReduce:
     it, no second copy).  A bucket is a contiguous run of parameters taken from the END of that order (backward
     produces gradients roughly in reverse registration order), so bucket 0 is complete first.  With ``cut`` (the
     index of the first parameter behind the network's gradient cut, drp.grad_cut_param_index) there are exactly two:
-    [cut, end) - 94 % of GraspBalance's parameters, reached first - and [0, cut).
+    [cut, end) - 94 % of GraspBalance's parameters, reached first - and [0, cut).  Without a cut, ``bucket_mb=None``
+    makes the whole buffer ONE bucket (train.Trainer passes that for graph execution, whose collectives run behind the
+    backward anyway); a number cuts buckets of that size for the hooks to overlap with a launch-by-launch backward.
 
     **One collective schedule for every way a step can run** (ADVICE round 4): per step every rank issues
     ``all_reduce(flat[0]), all_reduce(flat[1]), ...`` - the same sizes in the same order - whether the step is
@@ -63,6 +65,11 @@ class FlatGradAllReduce:
         self.ranges = []
         if self.cut is not None:
             self.ranges = [(self.cut, len(self.params)), (0, self.cut)]
+        elif bucket_mb is None:
+            # ONE collective over the whole flat buffer: what a step that runs its collectives behind the backward
+            # (reduce_flat: the HIP-graph step without a gradient cut) should issue - several back-to-back collectives
+            # with nothing to hide under only add their latencies over xGMI
+            self.ranges = [(0, len(self.params))]
         else:
             cap = int(bucket_mb * 1024 * 1024 / 4)
             hi, n = len(self.params), 0

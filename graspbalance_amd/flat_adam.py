@@ -109,8 +109,11 @@ class FlatAdam(Optimizer):
                     self._seg_tables[(len(grads), views[0].data_ptr())] = slot
                 else:
                     self._seg_captured.append(slot)   # (kept alive with the optimizer: a graph replays its copy node)
-            else:
-                torch.cuda.current_stream(dev).synchronize()   # the previous table's copy may still read the pinned buffer
+            elif slot.get("event") is not None:
+                # the slot's previous host -> device copy may still read the pinned buffer, and it may have been enqueued
+                # on ANOTHER stream than the current one (the capture warm-up stream, a second trainer's): wait for the
+                # copy's own event, not for whatever stream is current now
+                slot["event"].synchronize()
             src = np.array([g.data_ptr() for g in grads], dtype=np.int64)
             off = np.array([(v.data_ptr() - base) // 4 for v in views], dtype=np.int64)
             num = np.array([g.numel() for g in grads], dtype=np.int64)
@@ -124,6 +127,10 @@ class FlatAdam(Optimizer):
             if slot["table"] is None:
                 slot["table"] = torch.empty((self._seg_rows, 3), dtype=torch.int64, device=dev)
             slot["table"][:rows].copy_(slot["host"][:rows], non_blocking=True)   # (a copy node when capturing)
+            if not capturing:
+                if slot.get("event") is None:
+                    slot["event"] = torch.cuda.Event()
+                slot["event"].record(torch.cuda.current_stream(dev))
             slot["key"], slot["rows"] = key, rows
         with _lib.device_ctx(dev):
             _lib.check(_lib.lib().gb_copy_segments(_lib.ptr(slot["table"]), slot["rows"], _lib.ptr(self._flat_g),

@@ -359,12 +359,13 @@ def _gemm_meta(kind, P, K, N, fused=False, aff=False, rows_dev=None, prec=None):
     cap = P
     if rows_dev is not None:
         P = int(rows_dev)
-    which = _lib.lib().gb_gemm_kernel_for({"fwd": 0, "dgrad": 1, "wgrad": 2}[kind], cap, K, N, int(fused), int(aff))
+    # asked with the call's own options: the direct wgrad cuts a product with the skeleton its precision selects, the
+    # A/B flags veto kernels (with the default options the answer could name another kernel)
+    which = _lib.lib().gb_gemm_kernel_for2({"fwd": 0, "dgrad": 1, "wgrad": 2}[kind], cap, K, N, int(fused), int(aff),
+                                           _prec() if prec is None else prec, _RESERVED_CUS, _GEMM_FLAGS)
     if rows_dev is not None and kind != "wgrad":
         which = 1      # a device-side row count: the row-streaming kernel whatever the capacity
-    if which == 2 and (_GEMM_FLAGS & _lib.GEMM_NO_RING or rows_dev is not None):   # (round 5: the ring kernel has a bf16 form)
-        which = 0
-    if which == 4 and _GEMM_FLAGS & _lib.GEMM_NO_DIRECT:
+    if which == 2 and rows_dev is not None:
         which = 0
     kernel = ("gemm_cl_kernel", "gemm_rs_kernel", "gemm_ring_kernel", "wgrad_smallk_kernel", "wgrad_direct_kernel")[which]
     return {"flop": 2.0 * P * K * N, "pkn": (P, K, N), "kernel": kernel}
@@ -837,7 +838,7 @@ class MLPStack(Function):
             pair = (_PAIR and need_w[l] and l >= 1 and fused[l - 1] and rdev is None and not (ctx.fold and l == 1)
                     and not (l == 1 and _FIRST_FUSE and X0.shape[1] == 3 and not ctx.needs_input_grad[0] and need_w[0]
                              and _lib.lib().gb_gemm_uses_rs(P, K, N, 1, 2, 0))
-                    and _lib.lib().gb_gemm_kernel_for(3, P, K, N, 1, 1) == 2)   # (else two calls: per-kernel timing)
+                    and _lib.lib().gb_gemm_kernel_for2(3, P, K, N, 1, 1, ctx.prec, _RESERVED_CUS, _GEMM_FLAGS) == 2)   # (else two calls: per-kernel timing)
             if need_w[l] and not pair:
                 dW = w_arena[w_off[l]:w_off[l + 1]]
                 if ctx.fold and l == 1:   # the x operand relu(a*y1 + b) is re-formed from the xyz rows

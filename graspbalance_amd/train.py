@@ -44,6 +44,7 @@ _MAX_SIGNATURES = int(os.environ.get("GB_GRAPH_MAX_SIGNATURES", "4"))
 _HOST_SIDE_ORDER = os.environ.get("GB_HOST_SIDE_ORDER", "1") != "0"   # A/B switch: 0 = the side stream waits on the GPU
 _LABEL_TABLES = os.environ.get("GB_LABEL_TABLES", "1") != "0"   # A/B switch: 0 = the label tensors are copied into static buffers
 _LABEL_CAPACITY = os.environ.get("GB_LABEL_CAPACITY", "1") != "0"   # A/B switch: 0 = a captured step is keyed on every label tensor's shape
+MAX_LABEL_SOURCES = 128   # entries of the label kernels' source-pointer tables (csrc/group.hip LG_MAX_SRC)
 _NO_CONTEXT = contextlib.nullcontext()
 
 BN_MOMENTUM_INIT = 0.5
@@ -94,7 +95,11 @@ class Trainer:
         from .drp import grad_cut_param_index
         self._cut = grad_cut_param_index(self.net) if distributed and os.environ.get("GB_GRAD_CUT", "1") != "0" else None
         with (torch.cuda.stream(self._cstream) if self._cstream is not None else _NO_CONTEXT):
-            self.grads = FlatGradAllReduce(self.net, bucket_mb=bucket_mb, timing=time_collectives,
+            # no cut (GB_GRAD_CUT=0, a net without the DRP backbone): a graph step's collectives run behind its whole
+            # backward, so it issues ONE over the flat buffer; only a launch-by-launch trainer has hooks to overlap
+            # size-capped buckets with.  Decided by construction-time state that is the same on every rank.
+            self.grads = FlatGradAllReduce(self.net, bucket_mb=(None if (self._cut is None and self.graph) else bucket_mb),
+                                           timing=time_collectives,
                                            flat=(self.optimizer._flat_g, self.optimizer._grad_views,
                                                  self.optimizer._params), cut=self._cut)
         # the stream the first slice's all-reduce runs on beside the second part of the backward (graph execution)
@@ -166,7 +171,7 @@ class Trainer:
         after every epoch; the optimizer entry has torch.optim.Adam's layout (FlatAdam.state_dict), so the file loads
         into the reference's own script and vice versa."""
         torch.save({'epoch': int(epoch), 'optimizer_state_dict': self.optimizer.state_dict(),
-                    'loss': float(loss) if loss is not None else None,
+                    'loss': float(loss.detach() if torch.is_tensor(loss) else loss) if loss is not None else None,
                     'model_state_dict': self.net.state_dict()}, path)
 
     def load_checkpoint(self, path):
@@ -202,9 +207,15 @@ class Trainer:
     def _capacity_form(self, batch):
         """Can this batch's label lists be held at capacity (label_generation.LabelGeometry)?  What the lean label
         matching needs of them anyway + the switch."""
-        from .label_generation import LIST_KEYS, tables_ok
-        return (self.lean_labels and _LABEL_TABLES and _LABEL_CAPACITY and all(k in batch for k in LIST_KEYS)
-                and tables_ok(batch))
+        from .label_generation import LIST_KEYS, tables_ok, label_needs
+        if not (self.lean_labels and _LABEL_TABLES and _LABEL_CAPACITY and all(k in batch for k in LIST_KEYS)
+                and tables_ok(batch)):
+            return False
+        # the capacity form addresses the pointer tables at slot b*kc + j with kc >= the LARGEST cloud's object count, so
+        # it needs B*max_per_cloud table entries where the packed form needs the total: an unbalanced batch (40+10+10+10
+        # objects at B = 4) fits the tables' 128 entries packed and not at capacity -> it keeps the shape-keyed form
+        # (ADVICE round 5; csrc/group.hip LG_MAX_SRC)
+        return len(batch['grasp_points_list']) * label_needs(batch)[0] <= MAX_LABEL_SOURCES
 
     def _sig(self, batch):
         """What a captured step is keyed on.  Capacity form: the label lists' own shapes are NOT part of it (only their

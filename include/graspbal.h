@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GB_ABI_VERSION 6
+#define GB_ABI_VERSION 7
 
 enum {
   GB_OK = 0,
@@ -598,6 +598,13 @@ int gb_gemm_uses_rs(long long P, int K, int N, int dgrad, int fused_stats, int h
  * register-direct tall wgrad (csrc/gemm_wg.hip).  kind 3 = gb_gemm_dgrad_wgrad: 2 when ONE launch of the ring kernel
  * carries both products, 0 when the call issues the two single products.                                          */
 int gb_gemm_kernel_for(int kind, long long P, int K, int N, int fused_stats, int has_aff);
+/* ... the same for a call that carries GbGemmOpts {precision, reserved_cus, flags} (ABI v7): the
+ * register-direct wgrad cuts a product with the wave count and grid of the skeleton the PRECISION selects (fp32 MFMA:
+ * 8 waves; bf16 and GB_PREC_F32_SPLIT3: 4 waves, the grid clamped by the rows) and the A/B flags veto kernels, so the
+ * answer for the default options can differ from the kernel a call with other options launches.  gb_gemm_kernel_for
+ * is this function at (GB_PREC_F32, 0, 0).                                                                          */
+int gb_gemm_kernel_for2(int kind, long long P, int K, int N, int fused_stats, int has_aff, int precision,
+                        int reserved_cus, unsigned flags);
 /* dgrad into the first layer of a stack whose input x_in (P,3) has 3 channels: dZ = dY (P,N) W (N,K) is formed
  * but not stored; sums fp64 [slots][5K] (caller-zeroed) += column sums of [g, g*xhat, g*x_0, g*x_1, g*x_2] with
  * g = dZ*[a*y+b > 0], xhat = (y - mean)*rstd, y = y_prev (P,K) the layer's pre-BatchNorm output, ab_prev =

@@ -41,7 +41,7 @@ for p, want in zip(tr.net.parameters(), local):
     assert p.grad.shape == want.shape and torch.equal(p.grad, want)
 plain = _tiny_net().to(dev).train()
 loss2, _ = get_loss(plain(dict(batch)))
-assert abs(float(loss) - float(loss2)) < 1e-3 * abs(float(loss2))
+assert abs(float(loss.detach()) - float(loss2.detach())) < 1e-3 * abs(float(loss2.detach()))
 tr.grads.zero_grad()
 before = [p.detach().clone() for p in tr.net.parameters()]
 for _ in range(2):

@@ -225,6 +225,33 @@ def test_one_captured_step_serves_batches_whose_label_sizes_vary():
     assert big.geometry.pc == 128 and graph._static is graph._statics[min(graph._statics, key=lambda kk: kk[2])]
 
 
+def test_an_unbalanced_batch_whose_largest_cloud_overflows_the_capacity_tables_runs_on_the_packed_form():
+    """the capacity form addresses the label kernels' 128-entry pointer tables at slot cloud*kc + object
+    with kc >= the LARGEST cloud's object count.  A batch of 66 + 2 objects fits the tables packed (68 entries) but not
+    at capacity (2 * 66 = 132): gb_label_*_dt returned GB_ERANGE inside the capture warm-up and train_step raised.  Such a
+    batch now keeps the shape-keyed (packed) form - captured and replayed like any other - and its loss follows the
+    launch-by-launch trainer's; a balanced batch afterwards is back on the capacity form."""
+    from graspbalance_amd import train
+    from graspbalance_amd.label_generation import LIST_KEYS, label_needs
+    eager, graph = _pair()
+    b = _varied_batch([0, 1], (2, 2), (20, 20))
+    for key in LIST_KEYS:                                 # cloud 0: its two objects 33 times over (the same tensors)
+        b[key][0] = [b[key][0][k % 2] for k in range(66)]
+    assert len(b['grasp_points_list']) * label_needs(b)[0] > train.MAX_LABEL_SOURCES
+    assert not graph._capacity_form(b) and graph._sig(b)[0] != "capacity"
+    for i in range(2):
+        le = float(eager.train_step(b).detach())
+        lg = float(graph.train_step(b))
+        torch.cuda.synchronize()
+        assert abs(le - lg) < (_TOL0 if i == 0 else _TOL) * abs(le), (i, le, lg)
+    assert graph.graph_replays == 2 and graph._static.geometry is None
+    small = _varied_batch([2, 3], (2, 1), (20, 11))
+    assert graph._capacity_form(small)
+    graph.train_step(small)
+    torch.cuda.synchronize()
+    assert graph.graph_replays == 3 and graph._static.geometry is not None
+
+
 def test_fresh_batches_every_step_are_staged_even_when_the_allocator_reuses_their_addresses():
     """a static buffer used to recognise its source by (address, shape, version) - a new batch built in
     the block the previous one just freed looked like the old one and was never copied.  Now the source tensor's identity

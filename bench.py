@@ -538,7 +538,7 @@ def main():
     # events on its stream (the brackets cost ~2 us per launch, and a replayed graph cannot be bracketed at all): AFTER the
     # timed region, same trainer, same resident batch, same kernels
     gemm_names = ["gb_gemm_fwd", "gb_gemm_fwd_w", "gb_gemm_fwd_pool", "gb_gemm_fwd_gen3", "gb_gemm_dgrad", "gb_gemm_dgrad_first",
-                  "gb_gemm_dgrad_first_gen3", "gb_gemm_wgrad", "gb_gemm_wgrad_gen3", "gb_gemm_dgrad_wgrad"]
+                  "gb_gemm_dgrad_first_gen3", "gb_gemm_wgrad", "gb_gemm_wgrad_gen3", "gb_gemm_dgrad_wgrad", "gb_gemm_wgrad_group"]
     # GB_BENCH_TIMED_ONLY=1 (profiling runs: tools/refresh_profiles.sh): nothing but warm-up and the timed replays, so that
     # a kernel trace's last steps ARE the timed ones
     timed_only = os.environ.get("GB_BENCH_TIMED_ONLY") == "1"
@@ -636,8 +636,8 @@ def main():
             if prec == "bf16":
                 # bf16 matrix cores (2.5 PFLOP/s dense) with fp32 tensors in memory: the contraction is bound by
                 # reading X once and writing Y once - algorithmic bytes 4 (P K + P N + K N) per launch
-                byt = sum(4.0 * (m["pkn"][0] * (m["pkn"][1] + m["pkn"][2]) + m["pkn"][1] * m["pkn"][2])
-                          for n in gemm_names for a, b, m in kt.events[n] if m["kernel"] == kernel)
+                byt = sum(4.0 * (P * (K + N) + K * N) for n in gemm_names for a, b, m in kt.events[n] if m["kernel"] == kernel
+                          for P, K, N in m.get("pkn_list", [m["pkn"]]))   # (a grouped wgrad launch lists its products)
                 gbs = byt / (ms * 1e-3) / 1e9
                 return {"kernel": "%s (v_mfma_f32_32x32x16_bf16, fp32 operands in HBM; %s)" % (kernel, what), "bound": "hbm",
                         "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),

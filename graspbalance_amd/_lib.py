@@ -94,6 +94,8 @@ SIGNATURES = {
     "gb_gemm_dgrad": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P, _P, _P, _P],
     "gb_gemm_wgrad": [_P, _P, _P, _P, _L, _I, _I, _P, _P],
     "gb_gemm_dgrad_wgrad": [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "gb_gemm_wgrad_group": [_P, _I, _P, _P],
+    "gb_gemm_wgrad_groups": [_L, _I, _I, _I, _I, _U],
     "gb_gemm_uses_rs": [_L, _I, _I, _I, _I, _I],
     "gb_gemm_kernel_for": [_I, _L, _I, _I, _I, _I],
     "gb_gemm_kernel_for2": [_I, _L, _I, _I, _I, _I, _I, _I, _U],
@@ -162,6 +164,12 @@ class GemmOpts(_c.Structure):
     side-stream kernel, caller-owned split-reduction workspace)."""
     _fields_ = [("precision", _c.c_int), ("reserved_cus", _c.c_int), ("scratch", _c.c_void_p),
                 ("scratch_bytes", _c.c_ulonglong), ("rows_dev", _c.c_void_p), ("flags", _c.c_int)]
+
+
+class WgradItem(_c.Structure):
+    """GbWgradItem: one weight gradient of a gb_gemm_wgrad_group call."""
+    _fields_ = [("dy", _c.c_void_p), ("x", _c.c_void_p), ("x_aff", _c.c_void_p), ("dw", _c.c_void_p),
+                ("P", _c.c_longlong), ("K", _c.c_int), ("N", _c.c_int), ("ldw", _c.c_int)]
 
 
 PREC_F32, PREC_BF16, PREC_F32_SPLIT3 = 0, 1, 2

@@ -930,6 +930,55 @@ extern "C" int gb_gemm_dgrad_wgrad(const float *dy, const float *w, float *dx, c
   return gb_gemm_dgrad(dy, w, dx, y_prev, ab_prev, dstats, stat_slots, P, K, N, dstats_total, dbeta, dgamma, opts, stream);
 }
 
+// Many weight gradients in one call (round 6): items[i] is a gb_gemm_wgrad {dy, x, x_aff, dw, P, K, N} whose dW may sit in a
+// wider matrix (ldw >= K floats between its rows).  The few-row ones that suit the LDS-DMA ring kernel leave as ONE grid
+// per 32 products (csrc/gemm_ring.hip gemm_ring_group_kernel); anything else (tall products for the register-direct
+// kernel, <= 4 input channels, unaligned shapes) runs exactly as its own gb_gemm_wgrad - those need ldw == K.
+extern "C" int gb_gemm_wgrad_group(const GbWgradItem *items, int count, const GbGemmOpts *opts, void *stream) {
+  if (count < 0 || (count && !items) || opts_bad(opts) || opts_rows(opts)) return GB_EINVAL;
+  for (int i = 0; i < count; ++i) {
+    const GbWgradItem &w = items[i];
+    if (w.P < 0 || w.K < 1 || w.N < 1 || !w.dy || !w.x || !w.dw || w.ldw < w.K) return GB_EINVAL;
+  }
+  RingWgrad ring[64];
+  int nr = 0;
+  auto flush = [&]() {
+    if (nr) ring_group_launch(ring, nr, as_stream(stream), opts_bf16(opts));
+    nr = 0;
+    return check_launch("gb_gemm_wgrad_group");
+  };
+  for (int i = 0; i < count; ++i) {
+    const GbWgradItem &w = items[i];
+    if (w.P == 0) continue;
+    const bool smallk = w.K <= 4 && !w.x_aff && w.N % 4 == 0 && w.N / 4 <= GTPB && w.P >= 4096;
+    const bool tall = wg_pays(w.P, opts) && wg_wgrad_suits(w.P, w.K, w.N, false, opts_bf16(opts) || opts_split3(opts),
+                                                           opts_reserved(opts));
+    if (!smallk && !tall && !opts_no_ring(opts) && w.P <= 131072 &&
+        ring_group_suits(w.dy, w.x, w.x_aff, w.dw, w.P, w.K, w.N, w.ldw)) {
+      ring[nr++] = {w.dy, w.x, w.x_aff, w.dw, w.P, w.K, w.N, w.ldw};
+      if (nr == 64) {
+        const int rc = flush();
+        if (rc != GB_OK) return rc;
+      }
+      continue;
+    }
+    if (w.ldw != w.K) return GB_EINVAL;
+    const int rc = gb_gemm_wgrad(w.dy, w.x, w.x_aff, w.dw, w.P, w.K, w.N, opts, stream);
+    if (rc != GB_OK) return rc;
+  }
+  return flush();
+}
+
+// Would gb_gemm_wgrad_group put this product into a grouped launch (16-byte aligned operands assumed)?  What a caller
+// needs to know before it relies on ldw != K.
+extern "C" int gb_gemm_wgrad_groups(long long P, int K, int N, int precision, int reserved_cus, unsigned flags) {
+  const bool skeleton16 = precision == GB_PREC_BF16 || precision == GB_PREC_F32_SPLIT3;
+  if (P < 32 || P % 32 != 0 || K % 4 != 0 || N % 4 != 0 || K < 4 || N < 4 || P > 131072 || (flags & GB_GEMM_NO_RING)) return 0;
+  if (K <= 4) return 0;
+  if (!(flags & GB_GEMM_NO_DIRECT) && P >= WG_PAYS_FROM && wg_wgrad_suits(P, K, N, false, skeleton16, reserved_cus)) return 0;
+  return 1;
+}
+
 // Which kernel a gb_gemm_fwd (kind 0) / gb_gemm_dgrad (1) / gb_gemm_wgrad (2) call of this shape launches for 16-byte
 // aligned fp32 operands and default options: 0 = the register-staged tiles of this file, 1 = the row-streaming kernel
 // (csrc/gemm_rs.hip), 2 = the LDS-DMA ring kernel (csrc/gemm_ring.hip), 3 = the column-reduction wgrad, 4 = the

@@ -36,4 +36,14 @@ bool ring_pair_try(const float *dy, const float *w, float *dx, double *dstats, i
                    const float *ab_prev, const float *x, const float *x_aff, float *dw, long long P, int K, int N,
                    hipStream_t s, bool bf16);
 
+// many wgrads in one launch (gemm_ring_group_kernel): dW (N, ldw) += dY (P,N)^T f(X (P,K)) per item
+struct RingWgrad {
+  const float *dy, *x, *aff;
+  float *dw;
+  long long P;
+  int K, N, ldw;
+};
+bool ring_group_suits(const float *dy, const float *x, const float *aff, const float *dw, long long P, int K, int N, int ldw);
+void ring_group_launch(const RingWgrad *items, int count, hipStream_t s, bool bf16);
+
 }  // namespace gb

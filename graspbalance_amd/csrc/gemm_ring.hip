@@ -513,7 +513,121 @@ __global__ __launch_bounds__(RG_TPB, 2) void gemm_ring_pair_kernel(RingArgs gd, 
   else ring_tile<RK_RC, RK_RC, 64, 64, RG_ATOMIC, false, AFFB_W, BF>(gw, (id - nd) % nw_x, (id - nd) / nw_x, lds);
 }
 
+// Round 6 (VERDICT round 5 #1 i): the weight gradients of MANY layers in ONE launch.  A wgrad depends on nothing but the
+// stored X and the dY its layer's backward has formed - it is not on the backward's dependency chain - yet the few-row
+// ones (the 15 InvResMLP blocks' C -> 4C -> C pairs and aggregation convs on 1 024 .. 8 192 rows, the feature-propagation
+// stacks and heads on 4 096 .. 32 768) were launched one layer at a time in the middle of it: 45 launches of 64 - 1 024
+// workgroups living 10 - 30 us each, 5 - 7 us of which are fixed cost, at 0.14 - 0.42 of the matrix cores.  The caller
+// now records them (fused_mlp.WgradQueue) and this kernel runs up to RG_GROUP_MAX of them as one grid: workgroup `id`
+// finds its product in a table that travels BY VALUE in the kernel arguments (scalar loads; nothing to stage, and a
+// captured graph replays it as is), then runs the ring kernel's 64 x 64 wgrad tile on one chunk of that product's
+// reduction.  The host cuts every product's rows into chunks of about the same number of steps and deals the longest
+// workgroups first, so the grid is a few thousand equal-sized pieces of work with no tail.
+constexpr int RG_GROUP_MAX = 32;
+struct RingGroupItem {
+  const float *dy, *x, *aff;   // dY (P,N), X (P,K), optional [a(K), b(K)]: X is used as relu(a x + b)
+  float *dw;                   // dW (N, ldw >= K) += dY^T f(X)  (fp32 atomics)
+  long long red;               // P
+  int N, K, ldw;
+  int kchunk;                  // reduction rows per workgroup (multiple of 32)
+  unsigned first;              // first workgroup of this product
+  unsigned tiles;              // 64 x 64 output tiles
+  int tiles_n;                 // ... per row of tiles
+};
+struct RingGroup {
+  RingGroupItem it[RG_GROUP_MAX];
+  int count;
+};
+
+template <bool BF>
+__global__ __launch_bounds__(RG_TPB, 2) void gemm_ring_group_kernel(RingGroup grp) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const unsigned id = blockIdx.x;
+  int i = 0;
+  for (int j = 1; j < grp.count; ++j)   // (items ascend in `first`; <= 32 scalar compares)
+    if (id >= grp.it[j].first) i = j;
+  const RingGroupItem &e = grp.it[i];
+  RingArgs g = {};
+  g.a = {e.dy, e.N, e.N, nullptr};
+  g.b = {e.x, e.K, e.K, e.aff};
+  g.d = e.dw;
+  g.ldd = e.ldw;
+  g.red = e.red;
+  g.kchunk = e.kchunk;
+  g.stat_slots = 1;
+  g.tiles_n = e.tiles_n;
+  const unsigned local = id - e.first;
+  const unsigned bx = local % e.tiles, by = local / e.tiles;
+  if (e.aff) ring_tile<RK_RC, RK_RC, 64, 64, RG_ATOMIC, false, true, BF>(g, bx, by, lds);
+  else ring_tile<RK_RC, RK_RC, 64, 64, RG_ATOMIC, false, false, BF>(g, bx, by, lds);
+}
+
 static inline bool rg_aligned16(const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
+
+bool ring_group_suits(const float *dy, const float *x, const float *aff, const float *dw, long long P, int K, int N, int ldw) {
+  return rg_aligned16(dy) && rg_aligned16(x) && (!aff || rg_aligned16(aff)) && dw && ldw >= K && P >= RG_BK &&
+         P % RG_BK == 0 && K % 4 == 0 && N % 4 == 0 && K >= 4 && N >= 4 && P <= (1LL << 24);
+}
+
+// Launch the wgrads items[0 .. count) (every one ring_group_suits) in as few grids as the argument table allows.
+void ring_group_launch(const RingWgrad *items, int count, hipStream_t s, bool bf16) {
+  // cost of a workgroup of `steps` 32-row steps: ring_plan's constants for 64 x 64 tiles sharing a CU's matrix pipes
+  const double FIXED = 5.0, STEP = 0.98, SLOTS = 512.0;
+  for (int base = 0; base < count; base += RG_GROUP_MAX) {
+    const int n = count - base < RG_GROUP_MAX ? count - base : RG_GROUP_MAX;
+    const RingWgrad *it = items + base;
+    // one step target for the whole grid: the largest chunk length whose modelled time is (nearly) the best one
+    int best_target = 16;
+    double best = 1e30;
+    for (int target = 256; target >= 8; target /= 2) {
+      double work = 0, bytes = 0;
+      long long longest = 0;
+      for (int i = 0; i < n; ++i) {
+        const long long steps = it[i].P / RG_BK;
+        const long long chunks = (steps + target - 1) / target, per = (steps + chunks - 1) / chunks;
+        const long long tiles = (long long)((it[i].N + 63) / 64) * ((it[i].K + 63) / 64);
+        work += (double)(tiles * chunks) * (FIXED + per * STEP);
+        bytes += (double)(tiles * chunks) * 64 * 64 * 4;
+        if (per > longest) longest = per;
+      }
+      const double t = work / SLOTS + bytes / 1.3e6 + 0.5 * (FIXED + longest * STEP);
+      if (t < best * 0.97) { best = t; best_target = target; }
+    }
+    RingGroup grp = {};
+    int order[RG_GROUP_MAX];
+    long long per_of[RG_GROUP_MAX];
+    for (int i = 0; i < n; ++i) {
+      const long long steps = it[i].P / RG_BK, chunks = (steps + best_target - 1) / best_target;
+      per_of[i] = (steps + chunks - 1) / chunks;
+      order[i] = i;
+    }
+    for (int a = 1; a < n; ++a)   // longest workgroups first (insertion sort: n <= 32)
+      for (int b = a; b > 0 && per_of[order[b]] > per_of[order[b - 1]]; --b) { const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
+    unsigned first = 0;
+    for (int k = 0; k < n; ++k) {
+      const RingWgrad &w = it[order[k]];
+      RingGroupItem &e = grp.it[k];
+      const long long per = per_of[order[k]], chunks = (w.P / RG_BK + per - 1) / per;
+      e.dy = w.dy; e.x = w.x; e.aff = w.aff; e.dw = w.dw;
+      e.red = w.P; e.N = w.N; e.K = w.K; e.ldw = w.ldw;
+      e.kchunk = (int)(per * RG_BK);
+      e.first = first;
+      e.tiles_n = (w.K + 63) / 64;
+      e.tiles = (unsigned)(((w.N + 63) / 64) * e.tiles_n);
+      first += e.tiles * (unsigned)chunks;
+    }
+    grp.count = n;
+    const size_t lds = (size_t)RG_STAGES * (64 + 64) * RG_BK * sizeof(float) + 2 * 256 * sizeof(float);
+    static std::atomic<unsigned long long> attr_set[2] = {{0}, {0}};
+    if (bf16) {
+      allow_dynamic_lds(gemm_ring_group_kernel<true>, 160 * 1024, attr_set[1]);
+      hipLaunchKernelGGL(gemm_ring_group_kernel<true>, dim3(first), dim3(RG_TPB), lds, s, grp);
+    } else {
+      allow_dynamic_lds(gemm_ring_group_kernel<false>, 160 * 1024, attr_set[0]);
+      hipLaunchKernelGGL(gemm_ring_group_kernel<false>, dim3(first), dim3(RG_TPB), lds, s, grp);
+    }
+  }
+}
 
 template <int KA, int KB, int BM, int BN, int EPI, bool AFFA, bool AFFB, bool BF>
 static void rg_launch(const RingArgs &g, long long tiles_m, unsigned chunks, hipStream_t s) {

@@ -387,6 +387,89 @@ def _first_meta(P, K, N, rows_dev):
     return {"flop": 2.0 * P * K * N, "pkn": (P, K, N), "kernel": "gemm_rs_kernel"}
 
 
+# ---- deferred, grouped weight gradients (round 6; VERDICT round 5 #1 i) ----------------------------------------------
+# A weight gradient reads its layer's stored input and the dY the layer's backward has formed; nothing reads IT before the
+# optimizer.  The few-row ones (the InvResMLP blocks, the feature-propagation stacks, the heads: ~45 per step) used to be
+# launched one at a time in the middle of the backward's dependency chain - 10 - 30 us launches a third of which is fixed
+# cost.  Inside a WgradQueue the backward functions below only RECORD them; flush() hands the stream's whole list to
+# gb_gemm_wgrad_group, which runs 32 of them per grid (csrc/gemm_ring.hip gemm_ring_group_kernel).  The queue keeps the
+# operands alive until then.  Keyed by (device, stream): autograd runs the backward functions on its own worker thread,
+# so a thread-local would not be seen there.
+_WGQ = {}
+_WGRAD_GROUP = os.environ.get("GB_WGRAD_GROUP", "1") != "0"   # A/B switch: 0 = every wgrad where its layer's backward runs
+
+
+class WgradQueue:
+    """``with WgradQueue(device): loss.backward()`` - the few-row weight gradients of the backward passes that run on
+    this device's CURRENT stream inside the block are recorded and leave together on exit (or at flush()).  The
+    gradients autograd hands to the parameters inside the block are views of buffers the grouped launch has not
+    written yet: whoever reads them (an optimizer, a gradient all-reduce, a hook) must come after flush() on the same
+    stream - train.Trainer flushes before it packs / reduces / steps, and does not defer at all while post-accumulate
+    hooks issue collectives from inside the backward."""
+
+    def __init__(self, device):
+        self.dev = torch.device(device)
+        self.items, self.keep, self.prec, self.key, self.launches = [], [], None, None, 0
+
+    def __enter__(self):
+        idx = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+        self.st = _lib.current_stream(self.dev)
+        self.key = (idx, self.st.value)
+        self.outer = _WGQ.get(self.key)
+        _WGQ[self.key] = self
+        return self
+
+    def __exit__(self, exc_type, *exc):
+        if self.outer is not None:
+            _WGQ[self.key] = self.outer
+        else:
+            _WGQ.pop(self.key, None)
+        if exc_type is None:
+            self.flush()
+        else:
+            self.items, self.keep = [], []
+        return False
+
+    def push(self, dY, X, aff, dW, P, K, N, ldw, prec):
+        if self.prec is not None and prec != self.prec:
+            self.flush()
+        self.prec = prec
+        self.items.append((dY.data_ptr(), X.data_ptr(), aff.data_ptr() if aff is not None else None, dW.data_ptr(), P, K, N, ldw))
+        self.keep.append((dY, X, aff, dW))
+
+    def flush(self):
+        if not self.items:
+            return
+        arr = (_lib.WgradItem * len(self.items))(*self.items)
+        meta = None
+        if _lib.KernelTimer.active is not None:
+            meta = {"flop": sum(2.0 * i[4] * i[5] * i[6] for i in self.items), "kernel": "gemm_ring_kernel",
+                    "products": len(self.items), "pkn_list": [(i[4], i[5], i[6]) for i in self.items],
+                    "pkn": (sum(i[4] for i in self.items), 0, 0)}
+        _call("gb_gemm_wgrad_group", self.dev, ctypes.cast(arr, ctypes.c_void_p), len(self.items),
+              _opts(self.dev, self.st, self.prec), self.st, meta=meta)
+        self.launches += 1
+        self.items, self.keep = [], []
+
+
+def _wgrad_call(dev, st, dY, X, aff, dW, P, K, N, prec, opts, ldw=None, aff_flag=None):
+    """dW += dY^T f(X): recorded when a WgradQueue collects this stream's few-row weight gradients, launched here
+    otherwise.  ldw (a dW that sits in a wider matrix) is only legal when the caller has checked wgrad_groups()."""
+    q = _WGQ.get((dev.index, st.value)) if _WGQ else None
+    if q is not None and _lib.lib().gb_gemm_wgrad_groups(P, K, N, prec, _RESERVED_CUS, _GEMM_FLAGS):
+        q.push(dY, X, aff, dW, P, K, N, K if ldw is None else ldw, prec)
+        return
+    assert ldw is None or ldw == K
+    _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(X), _lib.ptr(aff), _lib.ptr(dW), P, K, N, opts, st,
+          meta=_gemm_meta("wgrad", P, K, N, aff=aff is not None, prec=prec))
+
+
+def wgrad_deferred(dev, st, P, K, N, prec):
+    """Will _wgrad_call record (rather than launch) this product right now?"""
+    return bool(_WGQ and (dev.index, st.value) in _WGQ
+                and _lib.lib().gb_gemm_wgrad_groups(P, K, N, prec, _RESERVED_CUS, _GEMM_FLAGS))
+
+
 def _wgrad(dY, X):
     """dW (Cout,Cin) = dY^T X with the reduction over P rows split into S batched slices: a plain
     (Cout x P) x (P x Cin) GEMM has only Cout*Cin/tile^2 output tiles (4 for 64x64), i.e. 4 busy CUs."""
@@ -835,7 +918,9 @@ class MLPStack(Function):
             N, K = W.shape
             src, aff = (X0, None) if l == 0 else (Ys[l - 1], abs_[l - 1])
             # both gradient products of the layer from ONE C call (few-row shapes: one launch, csrc/gemm_ring.hip pair kernel)
-            pair = (_PAIR and need_w[l] and l >= 1 and fused[l - 1] and rdev is None and not (ctx.fold and l == 1)
+            # (a weight gradient that a WgradQueue records is not paired: it leaves later, with the others)
+            defer = need_w[l] and rdev is None and not (ctx.fold and l == 1) and wgrad_deferred(dev, st, P, K, N, ctx.prec)
+            pair = (_PAIR and need_w[l] and not defer and l >= 1 and fused[l - 1] and rdev is None and not (ctx.fold and l == 1)
                     and not (l == 1 and _FIRST_FUSE and X0.shape[1] == 3 and not ctx.needs_input_grad[0] and need_w[0]
                              and _lib.lib().gb_gemm_uses_rs(P, K, N, 1, 2, 0))
                     and _lib.lib().gb_gemm_kernel_for2(3, P, K, N, 1, 1, ctx.prec, _RESERVED_CUS, _GEMM_FLAGS) == 2)   # (else two calls: per-kernel timing)
@@ -844,9 +929,11 @@ class MLPStack(Function):
                 if ctx.fold and l == 1:   # the x operand relu(a*y1 + b) is re-formed from the xyz rows
                     _call("gb_gemm_wgrad_gen3", dev, _lib.ptr(dY), _lib.ptr(X0), _lib.ptr(Ws[0]), _lib.ptr(aff), _lib.ptr(dW), P,
                           K, N, opts, st, meta=_gemm_meta("wgrad", P, K, N, aff=True, rows_dev=rdev, prec=ctx.prec))
-                else:
+                elif rdev is not None:
                     _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(src), _lib.ptr(aff), _lib.ptr(dW), P, K, N, opts, st,
                           meta=_gemm_meta("wgrad", P, K, N, aff=aff is not None, rows_dev=rdev, prec=ctx.prec))
+                else:
+                    _wgrad_call(dev, st, dY, src, aff, dW, P, K, N, ctx.prec, opts)
                 grads[3 * l] = dW.view(N, K)
             if l == 0:
                 if ctx.needs_input_grad[0]:
@@ -1106,7 +1193,7 @@ class LocalAggPool(Function):
         N, C = Wf.shape
         rows, P = geo.b * geo.n, geo.rows
         # one zero fill for the two atomic-add targets: sg (rows, N) and, when the weight gradient is wanted, dWf (N, C)
-        zbuf = _zeros32(rows * N + (N * C if ctx.needs_input_grad[1] else 0), dev)
+        zbuf = _zeros32(rows * N + (N * (3 + C) if ctx.needs_input_grad[1] else 0), dev)
         sg = zbuf[:rows * N].view(rows, N)
         red = _zeros64(5 * N, dev)  # [dbeta, dgamma, T0, T1, T2]
         _call("gb_la_pool_bwd_perm", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(G), _lib.ptr(geo.xyz),
@@ -1123,11 +1210,18 @@ class LocalAggPool(Function):
         if ctx.needs_input_grad[1]:
             _call("gb_la_wx_grad_g", dev, _lib.ptr(red), 1, _lib.ptr(u), _lib.ptr(geo.mom), _lib.ptr(Wx), _lib.ptr(ab), P, N,
                   training, _lib.ptr(dWx), _lib.ptr(dbeta), _lib.ptr(dgamma), st)
-            dWf = zbuf[rows * N:].view(N, C)
-            _call("gb_gemm_wgrad", dev, _lib.ptr(dG), _lib.ptr(f), None, _lib.ptr(dWf), rows, C, N,
-                  _opts(dev, st, ctx.prec), st, meta=_gemm_meta("wgrad", rows, C, N, prec=ctx.prec))
-            dW = torch.empty((N, 3 + C), dtype=torch.float32, device=dev)
-            _call("gb_la_join_w", dev, _lib.ptr(dWx), _lib.ptr(dWf), _lib.ptr(dW), N, C, st)
+            if wgrad_deferred(dev, st, rows, C, N, ctx.prec):
+                # recorded (WgradQueue): the grouped launch adds dG^T f straight into columns 3.. of the joined (N, 3 + C)
+                # gradient (its rows lie 3 + C floats apart), the xyz columns are written here - no join launch
+                dW = zbuf[rows * N:rows * N + N * (3 + C)].view(N, 3 + C)
+                dW[:, :3].copy_(dWx)
+                _wgrad_call(dev, st, dG, f, None, dW[:, 3:], rows, C, N, ctx.prec, None, ldw=3 + C)
+            else:
+                dWf = zbuf[rows * N:rows * N + N * C].view(N, C)
+                _call("gb_gemm_wgrad", dev, _lib.ptr(dG), _lib.ptr(f), None, _lib.ptr(dWf), rows, C, N,
+                      _opts(dev, st, ctx.prec), st, meta=_gemm_meta("wgrad", rows, C, N, prec=ctx.prec))
+                dW = torch.empty((N, 3 + C), dtype=torch.float32, device=dev)
+                _call("gb_la_join_w", dev, _lib.ptr(dWx), _lib.ptr(dWf), _lib.ptr(dW), N, C, st)
         df = None
         if ctx.needs_input_grad[0]:
             df = torch.empty((rows, C), dtype=torch.float32, device=dev)
@@ -1293,8 +1387,7 @@ class LinearBias(Function):
                   None, _opts(dev, st, ctx.prec), st, meta=_gemm_meta("dgrad", P, K, N))
         if ctx.needs_input_grad[1]:
             dW = _zeros32(N * K, dev).view(N, K)
-            _call("gb_gemm_wgrad", dev, _lib.ptr(dY), _lib.ptr(X), None, _lib.ptr(dW), P, K, N,
-                  _opts(dev, st, ctx.prec), st, meta=_gemm_meta("wgrad", P, K, N, prec=ctx.prec))
+            _wgrad_call(dev, st, dY, X, None, dW, P, K, N, ctx.prec, _opts(dev, st, ctx.prec))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             sums = _zeros64(2 * N, dev)
             _call("gb_col_stats", dev, _lib.ptr(dY), P, N, _lib.ptr(sums), None, st)

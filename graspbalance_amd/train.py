@@ -158,7 +158,8 @@ class Trainer:
         if self.prefetch is not None and next_batch is not None and self.prefetch.pending is None:
             self.prefetch.launch(next_batch['point_clouds'])  # a backbone without the hook: start it now
         loss, end_points = get_loss(end_points)
-        loss.backward()
+        with self._wgrad_queue(hooks_live=True):
+            loss.backward()
         self.grads.reduce()
         self.optimizer.step()
         self.grads.zero_grad()  # .grad = None: the next backward assigns instead of accumulating
@@ -264,6 +265,17 @@ class Trainer:
                                                    capacity=capacity)
         self._static = st
         return st
+
+    def _wgrad_queue(self, hooks_live):
+        """The context a backward of this trainer runs in: a fused_mlp.WgradQueue on the current stream (the few-row
+        weight gradients recorded and launched together when it ends), or nothing - on the CPU, with GB_WGRAD_GROUP=0,
+        and whenever post-accumulate hooks may issue a bucket's all-reduce from INSIDE the backward (launch-by-launch
+        data-parallel execution: a hook would pack gradients the grouped launch has not written yet)."""
+        import torch.distributed as dist
+        if (self.device.type != "cuda" or not fused_mlp._WGRAD_GROUP
+                or (hooks_live and self.distributed and dist.is_available() and dist.is_initialized())):
+            return _NO_CONTEXT
+        return fused_mlp.WgradQueue(self.device)
 
     def _bn_momentum(self):
         for m in self.net.modules():
@@ -500,10 +512,13 @@ class Trainer:
         if announced and _SAMPLE_AT != "start" and part != "all":
             fused_mlp.set_reserved_cus(_reserve(st.next_clouds.shape[0]))
         try:
-            if part != "bwd_pack2":
-                loss_t.backward()
-            if cut is not None and part in ("all", "bwd_step", "bwd_pack2"):
-                cut[0].backward(cut[1].grad)      # the part of the network in front of the gradient cut
+            # the few-row weight gradients of the backward passes below leave as grouped launches when the block ends
+            # (fused_mlp.WgradQueue): before anything packs, reduces or applies them
+            with self._wgrad_queue(hooks_live=False):
+                if part != "bwd_pack2":
+                    loss_t.backward()
+                if cut is not None and part in ("all", "bwd_step", "bwd_pack2"):
+                    cut[0].backward(cut[1].grad)      # the part of the network in front of the gradient cut
         finally:
             fused_mlp.set_reserved_cus(0)
             self.grads.hold = False

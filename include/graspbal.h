@@ -586,6 +586,25 @@ int gb_gemm_dgrad_wgrad(const float *dy, const float *w, float *dx, const float 
                         double *dstats, int stat_slots, long long P, int K, int N, double *dstats_total, float *dbeta,
                         float *dgamma, const float *x, const float *x_aff, float *dw, const GbGemmOpts *opts,
                         void *stream);
+/* Many weight gradients in ONE call (ABI v7, round 6).  A weight gradient reads its layer's stored input and the gradient
+ * the layer's backward has formed and nothing depends on it until the optimizer: the reference issues each as its own
+ * cuBLAS call in the middle of backward (the 1x1 convolutions of pytorch_utils.py:61-113 under drp.py:97-117,
+ * pointnet2_modules.py:402-435, modules.py:49-175); a caller of this library may instead record them and hand them over
+ * together.  Item i: dW_i (N, ldw >= K; caller-zeroed, accumulated with fp32 atomics) += dY_i (P,N)^T f(X_i (P,K)), x_aff
+ * as gb_gemm_wgrad.  The few-row products (P <= 131 072 rows, P % 32 == 0, K and N multiples of 4, 16-byte aligned dY / X)
+ * run as one grid per 32 items on the LDS-DMA ring kernel's tiles (csrc/gemm_ring.hip); every other item runs exactly
+ * as its own gb_gemm_wgrad call and needs ldw == K (GB_EINVAL otherwise).  `items` is HOST memory, read during the
+ * call only.  opts: precision / reserved_cus / flags as the single entry; rows_dev is not supported (GB_EINVAL).      */
+typedef struct GbWgradItem {
+  const float *dy, *x, *x_aff;
+  float *dw;
+  long long P;
+  int K, N, ldw;
+} GbWgradItem;
+int gb_gemm_wgrad_group(const GbWgradItem *items, int count, const GbGemmOpts *opts, void *stream);
+/* 1 when gb_gemm_wgrad_group runs a product of this shape (16-byte aligned operands) inside a grouped launch - the case
+ * that accepts ldw != K -, 0 when it issues it as a single gb_gemm_wgrad.  Host-side introspection, no launch.       */
+int gb_gemm_wgrad_groups(long long P, int K, int N, int precision, int reserved_cus, unsigned flags);
 /* Which kernel gb_gemm_fwd (dgrad = 0) / gb_gemm_dgrad (dgrad = 1) launches for 16-byte aligned operands of
  * this shape: 1 = the row-streaming kernel CAN run it (csrc/gemm_rs.hip: what the generated-operand, pooled and
  * device-row-count entries require), 0 = it cannot.  The plain gb_gemm_fwd / gb_gemm_dgrad additionally prefer the tiled

@@ -209,7 +209,10 @@ def frozen_routing_train_step(base, batch, views, prior=None, tamper=None):
     with tape.recording(), probed(net, tape) as recs:
         ep = net(dict(batch))
     loss, ep = get_loss(ep) if prior is None else get_loss(ep, prior)
-    loss.backward()
+    # as train.Trainer runs it: on the GPU the few-row weight gradients are recorded and launched together at the end
+    dev = batch['point_clouds'].device
+    with (fused_mlp.WgradQueue(dev) if (dev.type == "cuda" and fused_mlp._WGRAD_GROUP) else contextlib.nullcontext()):
+        loss.backward()
     net64 = f64_truth.double_model(base)
     report = {}
     was = fused_mlp._ENABLED

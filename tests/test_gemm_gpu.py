@@ -244,6 +244,98 @@ def test_tall_wgrad_register_direct_kernel(P, K, N, mode):
         assert float((dW.double() - ref).abs().max()) / scale < (2e-2 if bf16 else 1e-5) if rows else float(dW.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("prec", [0, 2, 1])
+def test_grouped_wgrads_equal_the_single_calls_and_the_fp64_products(prec):
+    """gb_gemm_wgrad_group (round 6): the weight gradients of many layers in one call.  The list mixes what a train step
+    records - the InvResMLP blocks' C -> 4C -> C pairs on 1 024 .. 8 192 rows with and without the relu(a x + b) operand
+    prologue, an aggregation conv whose dW sits in a wider (N, 3 + C) matrix (ldw > K: columns 0..2 must stay untouched),
+    16 384- and 32 768-row stacks, a ragged 4100 x 256 x 260 - with products the grouped kernel does NOT take and the call
+    issues singly (a tall one for the register-direct kernel, a 3-channel one for the column reduction, a row count that is
+    no multiple of 32).  Every dW equals the fp64 product at the single call's bound, and 40 items (two grids) work."""
+    L = _lib()
+    lib = L.lib()
+    bf16 = prec == L.PREC_BF16
+    g = torch.Generator(device=DEV).manual_seed(11 + prec)
+    shapes = [(4096, 256, 1024, True, 0), (4096, 1024, 256, True, 0), (4096, 256, 256, False, 3), (8192, 128, 512, False, 0),
+              (8192, 512, 128, True, 0), (2048, 1024, 256, True, 0), (1024, 256, 1024, False, 0), (1024, 256, 256, False, 3),
+              (16384, 128, 128, True, 0), (32768, 128, 256, True, 0), (4100 // 32 * 32, 256, 260, False, 0), (64, 64, 64, False, 0),
+              (96, 1024, 64, True, 5),
+              (70000, 128, 256, True, 0), (9001, 3, 64, False, 0), (4100, 256, 260, False, 0)]   # ... the three single ones
+    shapes = shapes + shapes[:12] * 2                                                             # 40 items
+    items, keep, refs = [], [], []
+    for P, K, N, has_aff, pad in shapes:
+        dY = torch.randn(P, N, device=DEV, generator=g)
+        X = torch.randn(P, K, device=DEV, generator=g)
+        aff = torch.cat([torch.rand(K, device=DEV, generator=g) + 0.5, torch.randn(K, device=DEV, generator=g) * 0.3]) if has_aff else None
+        full = torch.zeros(N, pad + K, device=DEV)
+        if pad:
+            full[:, :pad] = 7.0
+        dW = full[:, pad:]
+        fx = torch.relu(aff[:K] * X + aff[K:]) if has_aff else X
+        refs.append(dY.double().t() @ fx.double())
+        keep.append((dY, X, aff, full, dW))
+        items.append((dY.data_ptr(), X.data_ptr(), aff.data_ptr() if has_aff else None, dW.data_ptr(), P, K, N, pad + K))
+        grouped = lib.gb_gemm_wgrad_groups(P, K, N, prec, 0, 0)
+        assert grouped == int(P % 32 == 0 and K > 4 and P < 65536), (P, K, N)
+        assert grouped or pad == 0
+    arr = (L.WgradItem * len(items))(*items)
+    L.check(lib.gb_gemm_wgrad_group(ctypes.cast(arr, ctypes.c_void_p), len(items), _opts(prec), None), "wgrad_group")
+    torch.cuda.synchronize()
+    for (P, K, N, has_aff, pad), (dY, X, aff, full, dW), ref in zip(shapes, keep, refs):
+        scale = float(ref.abs().max())
+        assert float((dW.double() - ref).abs().max()) / scale < (2e-2 if bf16 else 1e-5), (P, K, N)
+        if pad:
+            assert bool((full[:, :pad] == 7.0).all()), "the columns in front of a dW inside a wider matrix were written"
+        single = torch.zeros(N, K, device=DEV)
+        L.check(lib.gb_gemm_wgrad(L.ptr(dY), L.ptr(X), L.ptr(aff), L.ptr(single), P, K, N, _opts(prec), None), "wgrad")
+        assert float((dW - single).abs().max()) / scale < 1e-5, (P, K, N)   # (same arithmetic; another cut of the reduction and order of fp32 atomics)
+    # argument checks: a device-side row count is refused, an item that must run singly cannot have ldw != K
+    rows_dev = torch.tensor([5], dtype=torch.int64, device=DEV)
+    ws = _WS["t"]
+    bad = ctypes.pointer(L.GemmOpts(prec, 0, ws.data_ptr(), ws.numel(), rows_dev.data_ptr()))
+    assert lib.gb_gemm_wgrad_group(ctypes.cast(arr, ctypes.c_void_p), 2, bad, None) == -1
+    P, K, N = 70000, 128, 256
+    one = (L.WgradItem * 1)((keep[13][0].data_ptr(), keep[13][1].data_ptr(), None, keep[13][3].data_ptr(), P, K, N, K + 4))
+    assert lib.gb_gemm_wgrad_group(ctypes.cast(one, ctypes.c_void_p), 1, _opts(prec), None) == -1
+    assert lib.gb_gemm_wgrad_group(None, 0, _opts(prec), None) == 0
+
+
+def test_a_backward_inside_a_wgrad_queue_gives_the_gradients_of_a_backward_outside_one():
+    """fused_mlp.WgradQueue: the stacks', aggregation convs' and heads' few-row weight gradients recorded during backward
+    and launched together at the end - same parameter gradients (to the order of fp32 atomics), same input gradients bit
+    for bit, and fewer launches: one grouped launch for the lot."""
+    from graspbalance_amd import fused_mlp
+    torch.manual_seed(3)
+    convs = [torch.nn.Conv1d(256, 1024, 1, bias=False), torch.nn.Conv1d(1024, 256, 1, bias=False)]
+    bns = [torch.nn.BatchNorm1d(1024), torch.nn.BatchNorm1d(256)]
+    head = torch.nn.Conv1d(256, 48, 1)
+    mods = torch.nn.ModuleList(convs + bns + [head]).to(DEV).train()
+    X = torch.randn(4096, 256, device=DEV)
+
+    def run(queue):
+        for p in mods.parameters():
+            p.grad = None
+        x = X.clone().requires_grad_(True)
+        h = fused_mlp.conv_bn_act_chain(x, list(zip(convs, bns)), residual=x, relu_last=True)
+        out = fused_mlp.linear_bias(h, head)
+        loss = out.square().mean()
+        if queue:
+            with fused_mlp.WgradQueue(DEV) as q:
+                loss.backward()
+                assert len(q.items) == 3 and q.launches == 0      # recorded, not launched yet
+            assert q.launches == 1 and not q.items
+        else:
+            loss.backward()
+        torch.cuda.synchronize()
+        return x.grad.clone(), [p.grad.clone() for p in mods.parameters()]
+    gx0, gp0 = run(False)
+    gx1, gp1 = run(True)
+    assert torch.equal(gx0, gx1)
+    for a, b in zip(gp0, gp1):
+        assert float((a - b).norm()) <= 2e-6 * float(a.norm()) + 1e-12
+    assert all(float(g.abs().max()) > 0 for g in gp1[:2])
+
+
 @pytest.mark.parametrize("reserved", [0, 8, 37, 128])
 @pytest.mark.parametrize("rows", [1, 17, 1000, 65535, 200001])
 def test_tall_wgrad_direct_with_reserved_cus_and_few_actual_rows(reserved, rows):

@@ -424,3 +424,40 @@ def test_predictor_call_between_backward_and_step_leaves_the_gradients_alone():
     torch.cuda.synchronize()
     assert all(torch.equal(a, p.grad) for a, p in zip(before, net.parameters()))
     fused_mlp.end_arena(torch.device(DEV))
+
+
+def test_whole_network_backward_inside_a_wgrad_queue_gives_the_same_253_gradients():
+    """Round 6: train.Trainer runs its backward inside fused_mlp.WgradQueue - the few-row weight gradients (InvResMLP
+    blocks, aggregation convs written straight into their joined (N, 3 + C) gradient, feature propagation, heads) are
+    recorded and leave as grouped launches at the end.  ONE forward (so the routing is the same), the backward twice -
+    outside a queue and inside one: every one of the 253 parameter gradients agrees to the order of the fp32 atomics, the
+    gradients autograd handed out inside the queue ALIAS the buffers the grouped launch wrote (no clone in between: a
+    clone would have frozen zeros), and the recorded products really were many."""
+    from tests.test_model_cpu import _tiny_net
+    from graspbalance_amd import fused_mlp
+    from graspbalance_amd.loss import get_loss
+    from graspbalance_amd.synthetic import make_training_batch
+    net = _tiny_net().to(DEV).train()
+    batch = make_training_batch(range(2), num_point=3000, num_objects=2, grasp_points_per_object=20, num_view=30,
+                                device=DEV)
+    loss, _ = get_loss(net(dict(batch)))
+    loss.backward(retain_graph=True)
+    torch.cuda.synchronize()
+    plain = [p.grad.clone() for p in net.parameters()]
+    for p in net.parameters():
+        p.grad = None
+    with fused_mlp.WgradQueue(DEV) as q:
+        loss.backward()
+        recorded = [(k[3], i[3], i[4:8]) for k, i in zip(q.keep, q.items)]
+        assert len(recorded) >= 30 and q.launches == 0
+        ptrs = {p.grad.data_ptr() for p in net.parameters()}
+        # a recorded dW is a parameter's .grad itself, or columns 3.. of one (an aggregation conv's joined gradient)
+        assert all(dw_ptr in ptrs or dw_ptr - 12 in ptrs for _, dw_ptr, _ in recorded)
+    torch.cuda.synchronize()
+    assert q.launches >= 1
+    worst = 0.0
+    for (name, p), g0 in zip(net.named_parameters(), plain):
+        err = float((p.grad - g0).norm()) / max(float(g0.norm()), 1e-12)
+        worst = max(worst, err)
+        assert err < 1e-5, (name, err)
+    print("253 gradients, queue vs plain: worst relative difference %.2e over %d recorded products" % (worst, len(recorded)))

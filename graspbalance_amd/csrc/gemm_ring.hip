@@ -31,6 +31,8 @@
 //
 // Eligibility (ring_gemm_try returns false otherwise and the caller uses csrc/gemm_cl.hip): fp32 precision, reduction
 // length a multiple of 32, leading dimensions and tile-row counts multiples of 4, 16-byte aligned operands, no row weights.
+#include <type_traits>
+
 #include "gb_common.h"
 #include "gemm_ring.h"
 
@@ -104,6 +106,18 @@ __device__ __forceinline__ f32x4 rg_ds128(unsigned addr) {
 __device__ __forceinline__ float rg_ds32(unsigned addr) {
   float v;
   asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+
+// ... with the offset as an instruction immediate: the row-contiguous (RK_RC) operands' fragments are 16 single reads per
+// 32 x 32 block and step at compile-time distances from ONE per-lane address - left as computed addresses each read cost
+// a v_add_u32 (32 vector instructions per step of a 64 x 64 wgrad tile beside its 16 MFMAs, and vector-ALU time ADDS to
+// matrix time on this chip: the tile saturated at 0.67 of the matrix cores however long the reduction)
+template <int OFF>
+__device__ __forceinline__ float rg_ds32o(unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
+  float v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
   return v;
 }
 
@@ -252,7 +266,10 @@ __device__ __forceinline__ void ring_tile(const RingArgs &g, const unsigned bx, 
 
   // one group = MFMA slices 4cq .. 4cq+3 of a step: MT (+2 table) + NT 16-byte reads, or 4 single reads per RC block
   struct Frag { f32x4 a[MT], b[NT], ta, tb; };
-  auto read_group = [&](Frag &f, unsigned sbase, int cq, int kk) {
+  unsigned a_rcs[KA == RK_RC ? MT : 1], b_rcs[KB == RK_RC ? NT : 1];   // a_rc / b_rc + this step's stage (set per step)
+  (void)a_rcs; (void)b_rcs;
+  auto read_group = [&](Frag &f, unsigned sbase, auto cq_c, int kk) {
+    constexpr int cq = decltype(cq_c)::value;
     if constexpr (KA == RK_KC) {
 #pragma unroll
       for (int i = 0; i < MT; ++i) f.a[i] = rg_ds128(sbase + a_kc[i][cq]);
@@ -262,20 +279,30 @@ __device__ __forceinline__ void ring_tile(const RingArgs &g, const unsigned bx, 
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) f.a[i][e] = rg_ds32(sbase + a_rc[i] + (unsigned)((8 * cq + 2 * e) * BM * 4));
+      for (int i = 0; i < MT; ++i) {
+        f.a[i][0] = rg_ds32o<(8 * cq + 0) * BM * 4>(a_rcs[i]);
+        f.a[i][1] = rg_ds32o<(8 * cq + 2) * BM * 4>(a_rcs[i]);
+        f.a[i][2] = rg_ds32o<(8 * cq + 4) * BM * 4>(a_rcs[i]);
+        f.a[i][3] = rg_ds32o<(8 * cq + 6) * BM * 4>(a_rcs[i]);
+      }
     }
     if constexpr (KB == RK_KC) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) f.b[j] = rg_ds128(sbase + b_kc[j][cq]);
     } else {
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) f.b[j][e] = rg_ds32(sbase + b_rc[j] + (unsigned)((8 * cq + RC_E * e) * BN * 4));
+      for (int j = 0; j < NT; ++j) {
+        f.b[j][0] = rg_ds32o<(8 * cq + RC_E * 0) * BN * 4>(b_rcs[j]);
+        f.b[j][1] = rg_ds32o<(8 * cq + RC_E * 1) * BN * 4>(b_rcs[j]);
+        f.b[j][2] = rg_ds32o<(8 * cq + RC_E * 2) * BN * 4>(b_rcs[j]);
+        f.b[j][3] = rg_ds32o<(8 * cq + RC_E * 3) * BN * 4>(b_rcs[j]);
+      }
     }
   };
+  using CQ0 = std::integral_constant<int, 0>;
+  using CQ1 = std::integral_constant<int, 1>;
+  using CQ2 = std::integral_constant<int, 2>;
+  using CQ3 = std::integral_constant<int, 3>;
   constexpr int READS = (KA == RK_KC ? MT + (AFFA ? 2 : 0) : 4 * MT) + (KB == RK_KC ? NT : 4 * NT);   // per group
   auto prologue_group = [&](Frag &f) {
     if constexpr (AFFA) {
@@ -404,14 +431,22 @@ __device__ __forceinline__ void ring_tile(const RingArgs &g, const unsigned bx, 
     if (EPI == RG_BNBWD && step == T - 1) prefetch_epilogue();
     const unsigned sbase = lds0 + (unsigned)((step % RG_STAGES) * ST_FL * 4);
     const int kk = step * RG_BK;   // offset of this step inside the chunk (table index)
+    if constexpr (KA == RK_RC) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a_rcs[i] = sbase + a_rc[i];
+    }
+    if constexpr (KB == RK_RC) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b_rcs[j] = sbase + b_rc[j];
+    }
     // two fragment sets: the reads of group cq+1 are in flight under the MFMAs of group cq
     Frag f0, f1;
     if constexpr (BF) {
       Frag f2, f3;
-      read_group(f0, sbase, 0, kk);
-      read_group(f1, sbase, 1, kk);
-      read_group(f2, sbase, 2, kk);
-      read_group(f3, sbase, 3, kk);
+      read_group(f0, sbase, CQ0{}, kk);
+      read_group(f1, sbase, CQ1{}, kk);
+      read_group(f2, sbase, CQ2{}, kk);
+      read_group(f3, sbase, CQ3{}, kk);
       rg_wait_lgkm<2 * READS>();      // groups 0 and 1 have arrived (LDS operations retire in order)
       __builtin_amdgcn_sched_barrier(0);
       mfma_pair_bf16(f0, f1, dma, nslot, 0);
@@ -420,16 +455,16 @@ __device__ __forceinline__ void ring_tile(const RingArgs &g, const unsigned bx, 
       mfma_pair_bf16(f2, f3, dma, nslot, 2);
       continue;
     }
-    read_group(f0, sbase, 0, kk);
-    read_group(f1, sbase, 1, kk);
+    read_group(f0, sbase, CQ0{}, kk);
+    read_group(f1, sbase, CQ1{}, kk);
     rg_wait_lgkm<READS>();            // group 0 has arrived (LDS operations retire in order)
     __builtin_amdgcn_sched_barrier(0);
     mfma_group(f0, dma, nslot, 0);
-    read_group(f0, sbase, 2, kk);
+    read_group(f0, sbase, CQ2{}, kk);
     rg_wait_lgkm<READS>();            // group 1
     __builtin_amdgcn_sched_barrier(0);
     mfma_group(f1, dma, nslot, 1);
-    read_group(f1, sbase, 3, kk);
+    read_group(f1, sbase, CQ3{}, kk);
     rg_wait_lgkm<READS>();            // group 2
     __builtin_amdgcn_sched_barrier(0);
     mfma_group(f0, dma, nslot, 2);

@@ -5,8 +5,6 @@
 L=graspbalance_amd/libgraspbal_hip
 for v in ${VARIANTS:-A B A B}; do
   cp ${L}_$v.so $L.so
-  python bench.py --no-cpu-baseline "$@" 2>/dev/null | python -c "
-import json,sys
-d=json.loads([l for l in sys.stdin if l.startswith('{')][-1])
-print('$v', d['ms_per_step'], 'cl', d['roofline']['ms_per_step'] if 'cl' in d['roofline']['kernel'] else d['roofline_gemm2']['ms_per_step'], 'rs', d['roofline_gemm2']['ms_per_step'] if 'rs' in d['roofline_gemm2']['kernel'] else d['roofline']['ms_per_step'])"
+  echo -n "$v: "; python bench.py --no-cpu-baseline --no-extra-configs "$@" 2>/dev/null | python tools/ab_line.py
 done
+cp ${L}_${KEEP:-B}.so $L.so

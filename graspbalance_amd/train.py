@@ -44,6 +44,8 @@ _MAX_SIGNATURES = int(os.environ.get("GB_GRAPH_MAX_SIGNATURES", "4"))
 _HOST_SIDE_ORDER = os.environ.get("GB_HOST_SIDE_ORDER", "1") != "0"   # A/B switch: 0 = the side stream waits on the GPU
 _LABEL_TABLES = os.environ.get("GB_LABEL_TABLES", "1") != "0"   # A/B switch: 0 = the label tensors are copied into static buffers
 _LABEL_CAPACITY = os.environ.get("GB_LABEL_CAPACITY", "1") != "0"   # A/B switch: 0 = a captured step is keyed on every label tensor's shape
+_RETAIN_GRAPH = False   # tests only: a captured step keeps its autograd graph (_StepGraph.live), so that the SAME forward
+                        # state can be differentiated again launch by launch (tests/test_graph_step_gpu.py)
 MAX_LABEL_SOURCES = 128   # entries of the label kernels' source-pointer tables (csrc/group.hip LG_MAX_SRC)
 _NO_CONTEXT = contextlib.nullcontext()
 
@@ -120,6 +122,7 @@ class Trainer:
         self._statics = {}       # signature -> _StaticBatch (a graph reads the buffers it was captured on: kept with it)
         self._eager_signatures = set()
         self.graph_replays = 0
+        self.enqueue_log = []    # the last replayed step's enqueue order (see _graph_step)
 
     def train_step(self, batch, next_batch=None):
         """forward -> loss -> backward -> gradient all-reduce -> Adam step -> LR step.  Returns the
@@ -349,6 +352,10 @@ class Trainer:
         if announced and _SAMPLE_AT != "start":
             slot = sample_next()                         # beside the backward: see _SAMPLE_AT
         g.bwd.replay()
+        # what this step enqueued behind the forward, in host order (bench.py prints it with the collective schedule: the
+        # position of slice A's all-reduce relative to the second backward graph is the overlap the design claims)
+        log = self.enqueue_log = ["graph: forward + loss", "graph: backward" + (" part 1 + pack slice A" if g.bwd2 is not None else
+                                  " + pack" if g.update is not None else " + Adam")]
         if g.update is not None:                         # data parallel: the collectives sit between the graphs
             if g.bwd2 is not None:
                 # the backward is two graphs, cut where 94 % of the gradient (everything behind level 2 of the backbone)
@@ -358,6 +365,9 @@ class Trainer:
                 # the main queue works is what costs 0.7 ms on this stack, a satisfied one is free.
                 self._cut_event.record(cur)
                 g.bwd2.replay()
+                log += ["event behind part 1 (main stream)", "graph: backward part 2 + pack slice B (main stream)",
+                        "host waits for the event", "all_reduce slice A (comm stream, beside part 2)",
+                        "all_reduce slice B (main stream, behind part 2)", "main stream joins the comm stream"]
                 if not self._cut_event.query():
                     t0 = time.perf_counter()
                     self._cut_event.synchronize()
@@ -375,7 +385,9 @@ class Trainer:
                 self.grads.timing = tm
             else:
                 self.grads.reduce_flat()
+                log.append("all_reduce of the whole flat gradient (main stream)")
             g.update.replay()
+            log.append("graph: Adam")
         self.optimizer.count_step()
         self.scheduler.step()
         self.graph_replays += 1
@@ -455,6 +467,8 @@ class Trainer:
             g.update = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g.update, pool=self._pool, stream=cs, capture_error_mode=mode):
                 self._body(st, announced, part="update")
+        if _RETAIN_GRAPH:
+            g.live = loss
         del loss
         # (capture launches nothing, but the python side effects of the step ran: undo them)
         self.grads.zero_grad()
@@ -516,9 +530,9 @@ class Trainer:
             # (fused_mlp.WgradQueue): before anything packs, reduces or applies them
             with self._wgrad_queue(hooks_live=False):
                 if part != "bwd_pack2":
-                    loss_t.backward()
+                    loss_t.backward(retain_graph=_RETAIN_GRAPH)
                 if cut is not None and part in ("all", "bwd_step", "bwd_pack2"):
-                    cut[0].backward(cut[1].grad)      # the part of the network in front of the gradient cut
+                    cut[0].backward(cut[1].grad, retain_graph=_RETAIN_GRAPH)      # the part of the network in front of the gradient cut
         finally:
             fused_mlp.set_reserved_cus(0)
             self.grads.hold = False
@@ -538,10 +552,10 @@ def _reserve(clouds):
 
 
 class _StepGraph:
-    __slots__ = ("fwd", "bwd", "bwd2", "update", "loss")
+    __slots__ = ("fwd", "bwd", "bwd2", "update", "loss", "live")
 
     def __init__(self):
-        self.fwd = self.bwd = self.bwd2 = self.update = self.loss = None
+        self.fwd = self.bwd = self.bwd2 = self.update = self.loss = self.live = None
 
 
 def _leaves(obj, path=()):

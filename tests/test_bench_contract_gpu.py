@@ -39,6 +39,16 @@ def test_bench_line_contract(monkeypatch, capsys):
     assert 1.0 < d["max_memory_allocated_gb"] < 288.0
     src = r["traffic_source"]
     assert src["file"].startswith("profiles/") and (r["traffic"] is None) == (not src["valid"])
+    # round 6: a kernel that issues six bf16 MFMAs per fp32 product is priced against the roof that
+    # binds it - the bf16 matrix cores on EXECUTED flop or HBM on its bytes - not against the fp32 MFMA peak
+    split = [d[k] for k in ("roofline", "roofline_gemm2", "roofline_gemm3", "roofline_gemm4")
+             if d.get(k) and "fp32_equivalent_frac" in d[k]]
+    assert len(split) == 2, [x["kernel"][:24] for x in split]     # gemm_rs_kernel and wgrad_direct_kernel
+    for x in split:
+        assert abs(x["frac"] - max(x["mfma_executed_frac"], x["hbm_frac"])) < 1e-3 and 0 < x["frac"] < 1
+        assert abs(x["frac"] - x["achieved"] / x["peak"]) < 2e-3 and x["unit"] in ("GB/s", "TFLOP/s")
+        assert abs(x["mfma_executed_frac"] - 6 * x["tflops_fp32_equivalent"] / 2500.0) < 1e-3
+        assert x["bound"] == ("hbm" if x["hbm_frac"] >= x["mfma_executed_frac"] else "mfma")
 
 
 def test_bench_line_carries_the_other_two_configurations():

@@ -91,7 +91,7 @@ def _schedule_worker(rank, world, port, out_dir, modes):
     from graspbalance_amd.flat_adam import FlatAdam
     from graspbalance_amd.loss import get_loss
     cpu_backend.install()
-    mine = shard_batch(_tiny_batch(B=2), rank, world)
+    mine = shard_batch(_tiny_batch(B=max(2, world)), rank, world)
     results = []
     for round_modes in modes:
         mode = round_modes[rank]
@@ -158,6 +158,24 @@ def test_one_collective_schedule_for_every_execution_mode_world2(tmp_path):
         assert torch.equal(r0[k]["reduced"], r0[0]["reduced"]), modes[k]
         assert torch.equal(r0[k]["params"], r0[0]["params"]), modes[k]
     assert float(r0[0]["reduced"].abs().sum()) > 0
+
+
+@pytest.mark.timeout(1200)
+def test_one_collective_schedule_world4_with_one_rank_running_launch_by_launch(tmp_path):
+    """four ranks, and in one step ONE of them executes launch by launch (post-accumulate hooks) while
+    the other three run the split backward of the HIP-graph step - what happens when a rank's batch signature is new or
+    beyond GB_GRAPH_MAX_SIGNATURES while its peers replay.  Same collectives in the same order on every rank, reduced
+    gradients and parameters bit-identical across ranks and equal to the all-hooks and all-split executions."""
+    port = _free_port()
+    modes = [("hooks",) * 4, ("split", "split", "hooks", "split"), ("split",) * 4]
+    mp.spawn(_schedule_worker, args=(4, port, str(tmp_path), modes), nprocs=4, join=True)
+    rs = [torch.load(os.path.join(tmp_path, "rank%d.pt" % r)) for r in range(4)]
+    for k in range(len(modes)):
+        for r in range(1, 4):
+            assert rs[r][k]["schedule"] == rs[0][k]["schedule"] and len(rs[0][k]["schedule"]) == 2
+            assert torch.equal(rs[r][k]["reduced"], rs[0][k]["reduced"]) and torch.equal(rs[r][k]["params"], rs[0][k]["params"])
+        assert torch.equal(rs[0][k]["reduced"], rs[0][0]["reduced"]) and torch.equal(rs[0][k]["params"], rs[0][0]["params"]), modes[k]
+    assert [x["mode"] for x in rs[2]] == ["hooks", "hooks", "split"] and float(rs[0][0]["reduced"].abs().sum()) > 0
 
 
 def test_shard_batch_chunks_like_list_scatter():

@@ -44,8 +44,6 @@ _MAX_SIGNATURES = int(os.environ.get("GB_GRAPH_MAX_SIGNATURES", "4"))
 _HOST_SIDE_ORDER = os.environ.get("GB_HOST_SIDE_ORDER", "1") != "0"   # A/B switch: 0 = the side stream waits on the GPU
 _LABEL_TABLES = os.environ.get("GB_LABEL_TABLES", "1") != "0"   # A/B switch: 0 = the label tensors are copied into static buffers
 _LABEL_CAPACITY = os.environ.get("GB_LABEL_CAPACITY", "1") != "0"   # A/B switch: 0 = a captured step is keyed on every label tensor's shape
-_RETAIN_GRAPH = False   # tests only: a captured step keeps its autograd graph (_StepGraph.live), so that the SAME forward
-                        # state can be differentiated again launch by launch (tests/test_graph_step_gpu.py)
 MAX_LABEL_SOURCES = 128   # entries of the label kernels' source-pointer tables (csrc/group.hip LG_MAX_SRC)
 _NO_CONTEXT = contextlib.nullcontext()
 
@@ -467,8 +465,6 @@ class Trainer:
             g.update = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g.update, pool=self._pool, stream=cs, capture_error_mode=mode):
                 self._body(st, announced, part="update")
-        if _RETAIN_GRAPH:
-            g.live = loss
         del loss
         # (capture launches nothing, but the python side effects of the step ran: undo them)
         self.grads.zero_grad()
@@ -530,9 +526,9 @@ class Trainer:
             # (fused_mlp.WgradQueue): before anything packs, reduces or applies them
             with self._wgrad_queue(hooks_live=False):
                 if part != "bwd_pack2":
-                    loss_t.backward(retain_graph=_RETAIN_GRAPH)
+                    loss_t.backward()
                 if cut is not None and part in ("all", "bwd_step", "bwd_pack2"):
-                    cut[0].backward(cut[1].grad, retain_graph=_RETAIN_GRAPH)      # the part of the network in front of the gradient cut
+                    cut[0].backward(cut[1].grad)      # the part of the network in front of the gradient cut
         finally:
             fused_mlp.set_reserved_cus(0)
             self.grads.hold = False
@@ -552,10 +548,10 @@ def _reserve(clouds):
 
 
 class _StepGraph:
-    __slots__ = ("fwd", "bwd", "bwd2", "update", "loss", "live")
+    __slots__ = ("fwd", "bwd", "bwd2", "update", "loss")
 
     def __init__(self):
-        self.fwd = self.bwd = self.bwd2 = self.update = self.loss = self.live = None
+        self.fwd = self.bwd = self.bwd2 = self.update = self.loss = None
 
 
 def _leaves(obj, path=()):

@@ -333,7 +333,15 @@ int gb_interp_concat_cl_grad(const float *dx0, const int32_t *idx, const float *
  * every operand is cut EXACTLY into three 8-bit slices of its 24-bit mantissa and the six products of weight >= 2^-16 are
  * accumulated in fp32 - the error against fp64 is that of the fp32 MFMA (what is dropped is <= 2^-23 relative), the results
  * are not bit-identical to GB_PREC_F32's.  Every other product, and every shape no split instantiation fits, runs exactly
- * as under GB_PREC_F32. */
+ * as under GB_PREC_F32.
+ * Range (round 6, tests/test_gemm_gpu.py::test_split_products_on_extreme_operands): any FINITE operands of magnitude
+ * >= 2^-110 give the fp32 bound whatever their spread (columns 120 binades apart: measured).  Below that the lower slices
+ * fall into bf16's denormal range, which the matrix cores flush: the product is still right to 2^-15 at 2^-115 and to
+ * 2^-8 at 2^-126 (1e-38; fp32 MFMA keeps its 5e-7 there).  NON-FINITE operands: an output that is +-inf or NaN under
+ * GB_PREC_F32 is non-finite here too and vice versa, but it may be NaN where the fp32 product says +-inf - the slices of
+ * inf are (inf, NaN, NaN), and an exact fix-up would need every output row / column with a non-finite operand recomputed
+ * on the fp32 path; one BatchNorm later both are NaN in the reference's network and in this one.  Finite outputs next to
+ * them meet the usual bound. */
 #define GB_PREC_F32_SPLIT3 2
 #define GB_GEMM_SCRATCH_BYTES (320ull * 64 * 128 * 4)
 /*   rows_dev    : optional DEVICE pointer (8-byte aligned) to the actual row count of this call, 0 <= *rows_dev <= P.  The

@@ -158,6 +158,15 @@ __device__ __forceinline__ unsigned rs_pack_hi(float lo_elem, float hi_elem) {  
   return __builtin_amdgcn_perm(__float_as_uint(hi_elem), __float_as_uint(lo_elem), 0x07060302u);
 }
 
+#ifndef GB_RS_NT_STORE
+#define GB_RS_NT_STORE 1
+#endif
+#if GB_RS_NT_STORE
+#define RS_STORE_Y(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define RS_STORE_Y(ptr, val) (*(ptr) = (val))
+#endif
+
 template <int NT, int EPI, bool BF = false, bool GEN3 = false, bool SP = false, int CGS = 1>
 __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_BNBWD_X && !SP) ? 4 : 2)) void gemm_rs_kernel(RsArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -673,7 +682,7 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
                 float *tb = g.d + trow * LDD;
                 const unsigned lo = (unsigned)(4 * h) * (unsigned)LDD + (unsigned)m;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) tb[lo + (unsigned)(((r & 3) + 8 * (r >> 2)) * LDD + q * 32)] = acc[q][r];
+                for (int r = 0; r < 16; ++r) RS_STORE_Y(&tb[lo + (unsigned)(((r & 3) + 8 * (r >> 2)) * LDD + q * 32)], acc[q][r]);
               } else {
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
@@ -749,7 +758,7 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
               float v = acc[q][r];
               if constexpr (EPI != RS_BNBWD_X) {
                 float *dp = g.d + (trow + (r & 3) + 8 * (r >> 2)) * (long long)g.ldd + q * 32;  // wave-uniform
-                dp[lane_off] = v;
+                RS_STORE_Y(&dp[lane_off], v);
               }
               if constexpr (EPI == RS_STATS) {
                 if (weighted) {

@@ -375,7 +375,7 @@ def test_first_layer_closed_form_backward(train, widths, arith):
         assert tape.done() == L + 1
         out64 = out64[0].t()
         (out64 * wsum.double()).sum().backward()
-        assert float((out.double() - out64).abs().max()) <= 1e-5 * float(out64.abs().max()), name
+        assert float((out.detach().double() - out64.detach()).abs().max()) <= 1e-5 * float(out64.detach().abs().max()), name
         top = max(float(p.grad.norm()) for p in m64.parameters())
         for (k, p), p64 in zip(m.named_parameters(), m64.parameters()):
             err = float((p.grad.double() - p64.grad).norm()) / max(float(p64.grad.norm()), 1e-3 * top)

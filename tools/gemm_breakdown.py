@@ -13,7 +13,7 @@ batch = make_training_batch(range(4), 20000, device="cuda:0")
 tr = Trainer("cuda:0", graph=False)   # (events around single launches: not under graph replay)
 for _ in range(3):
     tr.train_step(batch)
-names = ["gb_gemm_fwd", "gb_gemm_fwd_w", "gb_gemm_fwd_pool", "gb_gemm_fwd_gen3", "gb_gemm_dgrad", "gb_gemm_dgrad_first", "gb_gemm_dgrad_first_gen3", "gb_gemm_wgrad", "gb_gemm_wgrad_gen3", "gb_gemm_dgrad_wgrad"]
+names = ["gb_gemm_fwd", "gb_gemm_fwd_w", "gb_gemm_fwd_pool", "gb_gemm_fwd_gen3", "gb_gemm_dgrad", "gb_gemm_dgrad_first", "gb_gemm_dgrad_first_gen3", "gb_gemm_wgrad", "gb_gemm_wgrad_gen3", "gb_gemm_dgrad_wgrad", "gb_gemm_wgrad_group"]
 with _lib.KernelTimer(names) as kt:
     for _ in range(3):
         tr.train_step(batch)
@@ -21,7 +21,10 @@ torch.cuda.synchronize()
 acc = defaultdict(lambda: [0, 0.0])
 for n in names:
     for a, b, meta in kt.events[n]:
-        key = (n[8:] + ("*" if meta["kernel"] == "gemm_rs_kernel" else ""),) + tuple(meta["pkn"])
+        if n == "gb_gemm_wgrad_group":   # one grouped launch: P = the rows of all its products, K = N = 0 (FLOP from the meta)
+            key = ("wgrad_group(%d)" % meta["products"], int(meta["flop"] / 2e6), 1000, 1000)
+        else:
+            key = (n[8:] + ("*" if meta["kernel"] == "gemm_rs_kernel" else ""),) + tuple(meta["pkn"])
         acc[key][0] += 1
         acc[key][1] += a.elapsed_time(b)
 tot = sum(v[1] for v in acc.values()) / 3

@@ -110,9 +110,10 @@ def fps_algorithmic_bytes(b, n, m):
 
 
 KERNEL_SOURCES = {"gemm_rs_kernel": ("gemm_rs.hip", "gemm_rs.h"), "gemm_ring_kernel": ("gemm_ring.hip", "gemm_ring.h"),
+                  "gemm_ring_group_kernel": ("gemm_ring.hip", "gemm_ring.h"),
                   "gemm_cl_kernel": ("gemm_cl.hip",), "wgrad_direct_kernel": ("gemm_wg.hip", "gemm_wg.h"), "fps_rows_kernel": ("fps.hip",), "fps_pruned_kernel": ("fps.hip",),
                   "fps_reg_kernel<1024, 20>": ("fps.hip",)}
-PMC_FILE = "r05_pmc_traffic.json"
+PMC_FILE = "r06_pmc_traffic.json"
 
 
 def git_blob_hash(path):
@@ -695,11 +696,14 @@ def main():
         rl_rs = gemm_roofline("gemm_rs_kernel", "row-streaming: tall fwd+BN-stats and dgrad+BN-backward sums")
         rl_ring = gemm_roofline("gemm_ring_kernel", "LDS-DMA ring: the few-row fwd / dgrad / wgrad products")
         rl_wg = gemm_roofline("wgrad_direct_kernel", "register-direct: the tall wgrads, operands straight from HBM into the matrix cores")
-        both = sorted([r for r in (rl_cl, rl_rs, rl_ring, rl_wg) if r], key=lambda r: -r["ms_per_step"])
+        rl_grp = gemm_roofline("gemm_ring_group_kernel", "the step's few-row weight gradients recorded during backward and "
+                               "run as grouped launches of up to 63 products on the ring kernel's 64 x 64 tiles")
+        both = sorted([r for r in (rl_cl, rl_rs, rl_ring, rl_wg, rl_grp) if r], key=lambda r: -r["ms_per_step"])
         roofline = both[0] if both else None
         roofline_second = both[1] if len(both) > 1 else None
         roofline_third = both[2] if len(both) > 2 else None
         roofline_fourth = both[3] if len(both) > 3 else None
+        roofline_fifth = both[4] if len(both) > 4 else None
         # largest single launch of the step: the first-level FPS (HBM class, streaming-model bytes)
         roofline_fps = None
         fps_ms = 0.0
@@ -791,6 +795,7 @@ def main():
             "roofline_gemm2": roofline_second,
             "roofline_gemm3": roofline_third,
             "roofline_gemm4": roofline_fourth,
+            "roofline_gemm5": roofline_fifth,
             "fp32_products": ("tall products (row-streaming forward / dgrad, register-direct wgrad) as three-way exact bf16 splits on the matrix cores (GB_PREC_F32_SPLIT3: "
                               "six bf16 products per fp32 product, fp32 accumulation, same error against fp64 as fp32 MFMA - "
                               "tests/test_gemm_gpu.py, tools/split3_probe.hip); every other product fp32 MFMA; GB_SPLIT3=0 "
@@ -819,7 +824,7 @@ def main():
             "max_memory_allocated_gb": peak_mem_gb,
             "cpu_affinity": affinity,
         }
-        for r in (out["roofline"], out["roofline_gemm2"], out["roofline_gemm3"], out["roofline_gemm4"], out["roofline_fps"], out["roofline_ball"], out["roofline_fps_ball"],
+        for r in (out["roofline"], out["roofline_gemm2"], out["roofline_gemm3"], out["roofline_gemm4"], out["roofline_gemm5"], out["roofline_fps"], out["roofline_ball"], out["roofline_fps_ball"],
                   out["roofline_cyl"]):
             if r:
                 r["measured_on"] = ("%d eager steps of the same trainer right after the timed region (HIP events around every "

@@ -932,7 +932,7 @@ extern "C" int gb_gemm_dgrad_wgrad(const float *dy, const float *w, float *dx, c
 
 // Many weight gradients in one call (round 6): items[i] is a gb_gemm_wgrad {dy, x, x_aff, dw, P, K, N} whose dW may sit in a
 // wider matrix (ldw >= K floats between its rows).  The few-row ones that suit the LDS-DMA ring kernel leave as ONE grid
-// per 56 products (csrc/gemm_ring.hip gemm_ring_group_kernel); anything else (tall products for the register-direct
+// per 63 products (csrc/gemm_ring.hip gemm_ring_group_kernel); anything else (tall products for the register-direct
 // kernel, <= 4 input channels, unaligned shapes) runs exactly as its own gb_gemm_wgrad - those need ldw == K.
 extern "C" int gb_gemm_wgrad_group(const GbWgradItem *items, int count, const GbGemmOpts *opts, void *stream) {
   if (count < 0 || (count && !items) || opts_bad(opts) || opts_rows(opts)) return GB_EINVAL;
@@ -940,7 +940,7 @@ extern "C" int gb_gemm_wgrad_group(const GbWgradItem *items, int count, const Gb
     const GbWgradItem &w = items[i];
     if (w.P < 0 || w.K < 1 || w.N < 1 || !w.dy || !w.x || !w.dw || w.ldw < w.K) return GB_EINVAL;
   }
-  RingWgrad ring[112];
+  RingWgrad ring[126];
   int nr = 0;
   auto flush = [&]() {
     if (nr) ring_group_launch(ring, nr, as_stream(stream), opts_bf16(opts));
@@ -956,7 +956,7 @@ extern "C" int gb_gemm_wgrad_group(const GbWgradItem *items, int count, const Gb
     if (!smallk && !tall && !opts_no_ring(opts) && w.P <= 131072 &&
         ring_group_suits(w.dy, w.x, w.x_aff, w.dw, w.P, w.K, w.N, w.ldw)) {
       ring[nr++] = {w.dy, w.x, w.x_aff, w.dw, w.P, w.K, w.N, w.ldw};
-      if (nr == 112) {
+      if (nr == 126) {
         const int rc = flush();
         if (rc != GB_OK) return rc;
       }

@@ -558,7 +558,7 @@ __global__ __launch_bounds__(RG_TPB, 2) void gemm_ring_pair_kernel(RingArgs gd, 
 // captured graph replays it as is), then runs the ring kernel's 64 x 64 wgrad tile on one chunk of that product's
 // reduction.  The host cuts every product's rows into chunks of about the same number of steps and deals the longest
 // workgroups first, so the grid is a few thousand equal-sized pieces of work with no tail.
-constexpr int RG_GROUP_MAX = 56;   // 56 x 64 bytes + the count: inside the 4 KB a kernel's arguments may take
+constexpr int RG_GROUP_MAX = 63;   // 63 x 64 bytes + the count = 4040: inside the 4 KB a kernel's arguments may take
 struct RingGroupItem {
   const float *dy, *x, *aff;   // dY (P,N), X (P,K), optional [a(K), b(K)]: X is used as relu(a x + b)
   float *dw;                   // dW (N, ldw >= K) += dY^T f(X)  (fp32 atomics)
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(RG_TPB, 2) void gemm_ring_group_kernel(RingGroup gr
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const unsigned id = blockIdx.x;
   int i = 0;
-  for (int j = 1; j < grp.count; ++j)   // (items ascend in `first`; <= 56 scalar compares)
+  for (int j = 1; j < grp.count; ++j)   // (items ascend in `first`; <= 63 scalar compares)
     if (id >= grp.it[j].first) i = j;
   const RingGroupItem &e = grp.it[i];
   RingArgs g = {};
@@ -637,7 +637,7 @@ void ring_group_launch(const RingWgrad *items, int count, hipStream_t s, bool bf
       per_of[i] = (steps + chunks - 1) / chunks;
       order[i] = i;
     }
-    for (int a = 1; a < n; ++a)   // longest workgroups first (insertion sort: n <= 56)
+    for (int a = 1; a < n; ++a)   // longest workgroups first (insertion sort: n <= 63)
       for (int b = a; b > 0 && per_of[order[b]] > per_of[order[b - 1]]; --b) { const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
     unsigned first = 0;
     for (int k = 0; k < n; ++k) {

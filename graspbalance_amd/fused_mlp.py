@@ -392,7 +392,7 @@ def _first_meta(P, K, N, rows_dev):
 # optimizer.  The few-row ones (the InvResMLP blocks, the feature-propagation stacks, the heads: ~45 per step) used to be
 # launched one at a time in the middle of the backward's dependency chain - 10 - 30 us launches a third of which is fixed
 # cost.  Inside a WgradQueue the backward functions below only RECORD them; flush() hands the stream's whole list to
-# gb_gemm_wgrad_group, which runs up to 56 of them per grid (csrc/gemm_ring.hip gemm_ring_group_kernel).  The queue keeps the
+# gb_gemm_wgrad_group, which runs up to 63 of them per grid (csrc/gemm_ring.hip gemm_ring_group_kernel).  The queue keeps the
 # operands alive until then.  Keyed by (device, stream): autograd runs the backward functions on its own worker thread,
 # so a thread-local would not be seen there.
 _WGQ = {}
@@ -443,7 +443,7 @@ class WgradQueue:
         arr = (_lib.WgradItem * len(self.items))(*self.items)
         meta = None
         if _lib.KernelTimer.active is not None:
-            meta = {"flop": sum(2.0 * i[4] * i[5] * i[6] for i in self.items), "kernel": "gemm_ring_kernel",
+            meta = {"flop": sum(2.0 * i[4] * i[5] * i[6] for i in self.items), "kernel": "gemm_ring_group_kernel",
                     "products": len(self.items), "pkn_list": [(i[4], i[5], i[6]) for i in self.items],
                     "pkn": (sum(i[4] for i in self.items), 0, 0)}
         _call("gb_gemm_wgrad_group", self.dev, ctypes.cast(arr, ctypes.c_void_p), len(self.items),

@@ -600,7 +600,7 @@ int gb_gemm_dgrad_wgrad(const float *dy, const float *w, float *dx, const float 
  * pointnet2_modules.py:402-435, modules.py:49-175); a caller of this library may instead record them and hand them over
  * together.  Item i: dW_i (N, ldw >= K; caller-zeroed, accumulated with fp32 atomics) += dY_i (P,N)^T f(X_i (P,K)), x_aff
  * as gb_gemm_wgrad.  The few-row products (P <= 131 072 rows, P % 32 == 0, K and N multiples of 4, 16-byte aligned dY / X)
- * run as one grid per 56 items on the LDS-DMA ring kernel's tiles (csrc/gemm_ring.hip); every other item runs exactly
+ * run as one grid per 63 items on the LDS-DMA ring kernel's tiles (csrc/gemm_ring.hip); every other item runs exactly
  * as its own gb_gemm_wgrad call and needs ldw == K (GB_EINVAL otherwise).  `items` is HOST memory, read during the
  * call only.  opts: precision / reserved_cus / flags as the single entry; rows_dev is not supported (GB_EINVAL).      */
 typedef struct GbWgradItem {

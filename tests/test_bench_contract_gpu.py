@@ -41,7 +41,7 @@ def test_bench_line_contract(monkeypatch, capsys):
     assert src["file"].startswith("profiles/") and (r["traffic"] is None) == (not src["valid"])
     # round 6: a kernel that issues six bf16 MFMAs per fp32 product is priced against the roof that
     # binds it - the bf16 matrix cores on EXECUTED flop or HBM on its bytes - not against the fp32 MFMA peak
-    split = [d[k] for k in ("roofline", "roofline_gemm2", "roofline_gemm3", "roofline_gemm4")
+    split = [d[k] for k in ("roofline", "roofline_gemm2", "roofline_gemm3", "roofline_gemm4", "roofline_gemm5")
              if d.get(k) and "fp32_equivalent_frac" in d[k]]
     assert len(split) == 2, [x["kernel"][:24] for x in split]     # gemm_rs_kernel and wgrad_direct_kernel
     for x in split:

@@ -322,7 +322,7 @@ def test_grouped_wgrads_equal_the_single_calls_and_the_fp64_products(prec):
     prologue, an aggregation conv whose dW sits in a wider (N, 3 + C) matrix (ldw > K: columns 0..2 must stay untouched),
     16 384- and 32 768-row stacks, a ragged 4100 x 256 x 260 - with products the grouped kernel does NOT take and the call
     issues singly (a tall one for the register-direct kernel, a 3-channel one for the column reduction, a row count that is
-    no multiple of 32).  Every dW equals the fp64 product at the single call's bound, and 40 items (two grids) work."""
+    no multiple of 32).  Every dW equals the fp64 product at the single call's bound, and 76 items (more than one grid's 63) work."""
     L = _lib()
     lib = L.lib()
     bf16 = prec == L.PREC_BF16
@@ -332,7 +332,7 @@ def test_grouped_wgrads_equal_the_single_calls_and_the_fp64_products(prec):
               (16384, 128, 128, True, 0), (32768, 128, 256, True, 0), (4100 // 32 * 32, 256, 260, False, 0), (64, 64, 64, False, 0),
               (96, 1024, 64, True, 5),
               (70000, 128, 256, True, 0), (9001, 3, 64, False, 0), (4100, 256, 260, False, 0)]   # ... the three single ones
-    shapes = shapes + shapes[:12] * 2                                                             # 40 items
+    shapes = shapes + shapes[:12] * 5                                                             # 76 items: two grids
     items, keep, refs = [], [], []
     for P, K, N, has_aff, pad in shapes:
         dY = torch.randn(P, N, device=DEV, generator=g)

@@ -58,7 +58,7 @@ def check_loss_against_reference(g13, ep, preds, rtol):
         if name == "graspable_mask":
             assert np.array_equal(ep[name].float().cpu().numpy().reshape(-1)[::int(g13[k[:-7] + "::step"])], want)
             continue
-        got = float(ep[name])
+        got = float(ep[name].detach() if torch.is_tensor(ep[name]) else ep[name])
         assert abs(got - float(want[0])) <= rtol * max(1.0, abs(float(want[0]))), (name, got, float(want[0]))
     for k, p in preds.items():
         check_summary(g13, "grad/" + k, p.grad, rtol * 10, what="d loss / d " + k)

@@ -452,7 +452,7 @@ class WgradQueue:
         self.items, self.keep = [], []
 
 
-def _wgrad_call(dev, st, dY, X, aff, dW, P, K, N, prec, opts, ldw=None, aff_flag=None):
+def _wgrad_call(dev, st, dY, X, aff, dW, P, K, N, prec, opts, ldw=None):
     """dW += dY^T f(X): recorded when a WgradQueue collects this stream's few-row weight gradients, launched here
     otherwise.  ldw (a dW that sits in a wider matrix) is only legal when the caller has checked wgrad_groups()."""
     q = _WGQ.get((dev.index, st.value)) if _WGQ else None
@@ -1199,7 +1199,7 @@ class LocalAggPool(Function):
         _call("gb_la_pool_bwd_perm", dev, _lib.ptr(dout), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(G), _lib.ptr(geo.xyz),
               _lib.ptr(geo.centres), _lib.ptr(geo.idx), _lib.ptr(Wx), _lib.ptr(ab), _lib.ptr(geo.row_perm()), _lib.ptr(sg),
               _lib.ptr(red), geo.b, geo.n, geo.m, geo.ns, N, geo.mode, geo.scale, st)
-        small = torch.empty(5 * N + N * C, dtype=torch.float32, device=dev)  # dbeta, dgamma, dWx (N,3), then dWf
+        small = torch.empty(5 * N, dtype=torch.float32, device=dev)  # dbeta, dgamma, dWx (N,3)
         dbeta, dgamma, dWx = small[:N], small[N:2 * N], small[2 * N:5 * N].view(N, 3)
         if not ctx.needs_input_grad[1]:   # (otherwise gb_la_wx_grad_g below converts the two sums: one launch less)
             _call("gb_bn_bwd_reduce", dev, _lib.ptr(red), 1, N, None, _lib.ptr(dbeta), _lib.ptr(dgamma), st)

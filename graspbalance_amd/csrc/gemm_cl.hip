@@ -266,6 +266,7 @@ __global__ __launch_bounds__(GTPB, ((GM == 128 && GN == 128 && (EPI == 0 || EPI 
   }
 
   // epilogue: acc[mt][nt][reg] is D[m0 + wm*64 + mt*32 + (reg&3) + 8*(reg>>2) + 4*(lane>>5)][n0 + wn*64 + nt*32 + (lane&31)]
+  const bool whole = m0 + GM <= a.rows && n0 + GN <= b.rows && (long long)ldd * GM < (1LL << 30);   // (wave-uniform)
   float csum[NT], csq[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
@@ -279,6 +280,38 @@ __global__ __launch_bounds__(GTPB, ((GM == 128 && GN == 128 && (EPI == 0 || EPI 
         if (col < b.rows) {
           ea = epi_ab[col]; eb = epi_ab[b.rows + col]; emean = epi_ab[2 * b.rows + col]; erstd = epi_ab[3 * b.rows + col];
         }
+      }
+      if (whole) {
+        // (a whole tile: one wave-uniform pointer per row, a 32-bit lane offset - the generic form below spends ~12 vector
+        // instructions per element on bounds checks and 64-bit index arithmetic: csrc/gemm_ring.hip has the account)
+        const long long r0 = m0 + wm * (GM / 2) + mt * 32, c0 = n0 + wn * (GN / 2) + nt * 32;
+        float *tp = d + r0 * ldd + c0;                                     // uniform
+        const float *yp = EPI == EPI_STORE_BNBWD ? epi_y + r0 * ldd + c0 : nullptr;
+        const unsigned pitch = (unsigned)ldd, lo = (unsigned)(4 * (lane >> 5)) * pitch + (unsigned)(lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[mt][nt][r];
+          const unsigned ro = (unsigned)((r & 3) + 8 * (r >> 2)) * pitch;   // uniform
+          if constexpr (EPI == EPI_ATOMIC) atomicAdd(tp + ro + lo, v);
+          else (tp + ro)[lo] = v;
+          if constexpr (EPI == EPI_STORE_BNBWD) {
+            const float y = (yp + ro)[lo];
+            const float g = (ea * y + eb) > 0.f ? v : 0.f;
+            csum[nt] += g;
+            csq[nt] += g * ((y - emean) * erstd);
+          }
+          if constexpr (EPI == EPI_STORE_STATS) {
+            if (epi_w16) {
+              const float wv = (float)epi_w16[r0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] * v;
+              csum[nt] += wv;
+              csq[nt] += wv * v;
+            } else {
+              csum[nt] += v;
+              csq[nt] += v * v;
+            }
+          }
+        }
+        continue;
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {

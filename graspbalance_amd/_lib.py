@@ -76,6 +76,7 @@ SIGNATURES = {
     "gb_la_point_grad": [_P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _P, _P],
     "gb_la_wx_grad": [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P],
     "gb_la_wx_grad_g": [_P, _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P],
+    "gb_la_wx_grad_gs": [_P, _I, _P, _P, _P, _P, _L, _I, _I, _P, _I, _P, _P, _P],
     "gb_frame_cloud": [_P, _I, _P, _P, _P, _I, _I, _P, _P, _P],
     "gb_frame_mask": [_P, _I, _P, _P, _I, _I, _P, _c.c_double, _P, _P, _P],
     "gb_frame_compact": [_P, _I, _P, _P, _I, _I, _P, _c.c_double, _P, _P, _P],

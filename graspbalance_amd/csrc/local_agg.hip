@@ -515,7 +515,7 @@ __global__ void la_wx_grad_kernel(const double *__restrict__ red, const double *
                                   const double *__restrict__ mom, const float *__restrict__ wx,
                                   const float *__restrict__ ab, double invP, int C, int training,
                                   float *__restrict__ dwx, float *__restrict__ dbeta, float *__restrict__ dgamma,
-                                  int slots) {
+                                  int slots, int ldw) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   // red: `slots` rows of [5][C] partial sums (the dgrad epilogue's slot rows), added here in slot order
@@ -535,7 +535,7 @@ __global__ void la_wx_grad_kernel(const double *__restrict__ red, const double *
 #pragma unroll
     for (int q = 0; q < 3; ++q) wm += (double)wx[c * 3 + q] * mom[3 + 3 * q + j];
     const double v = rs[2 + j] - m1 * mom[j] - m2 * rstd * (u[(size_t)j * C + c] - mean * mom[j] + wm);
-    dwx[c * 3 + j] = (float)(a * v);
+    dwx[(size_t)c * ldw + j] = (float)(a * v);   // ldw = 3, or the pitch of a joined (C, 3 + Cf) gradient
   }
 }
 
@@ -685,7 +685,7 @@ extern "C" int gb_la_wx_grad(const double *red, const double *u, const double *m
                              long long P, int C, int training, float *dwx, void *stream) {
   if (C < 1 || P < 1 || !red || !u || !mom || !wx || !ab || !dwx) return GB_EINVAL;
   hipLaunchKernelGGL(la_wx_grad_kernel, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), red, u, mom, wx, ab,
-                     1.0 / (double)P, C, training, dwx, nullptr, nullptr, 1);
+                     1.0 / (double)P, C, training, dwx, nullptr, nullptr, 1, 3);
   return check_launch("gb_la_wx_grad");
 }
 
@@ -696,6 +696,18 @@ extern "C" int gb_la_wx_grad_g(const double *red, int slots, const double *u, co
                                float *dgamma, void *stream) {
   if (C < 1 || P < 1 || slots < 1 || !red || !u || !mom || !wx || !ab || !dwx || !dbeta || !dgamma) return GB_EINVAL;
   hipLaunchKernelGGL(la_wx_grad_kernel, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), red, u, mom, wx, ab,
-                     1.0 / (double)P, C, training, dwx, dbeta, dgamma, slots);
+                     1.0 / (double)P, C, training, dwx, dbeta, dgamma, slots, 3);
   return check_launch("gb_la_wx_grad_g");
+}
+
+// gb_la_wx_grad_g writing dwx into a wider matrix: row c of the gradient starts at dwx + c * ldw (ldw >= 3) - the xyz
+// columns of an aggregation conv's joined (C, 3 + Cf) weight gradient, whose feature columns a (grouped) weight-gradient
+// product adds into; no separate join or strided copy launch (round 6)
+extern "C" int gb_la_wx_grad_gs(const double *red, int slots, const double *u, const double *mom, const float *wx,
+                                const float *ab, long long P, int C, int training, float *dwx, int ldw, float *dbeta,
+                                float *dgamma, void *stream) {
+  if (C < 1 || P < 1 || slots < 1 || ldw < 3 || !red || !u || !mom || !wx || !ab || !dwx || !dbeta || !dgamma) return GB_EINVAL;
+  hipLaunchKernelGGL(la_wx_grad_kernel, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), red, u, mom, wx, ab,
+                     1.0 / (double)P, C, training, dwx, dbeta, dgamma, slots, ldw);
+  return check_launch("gb_la_wx_grad_gs");
 }

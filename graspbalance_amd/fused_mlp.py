@@ -1208,15 +1208,17 @@ class LocalAggPool(Function):
               _lib.ptr(ab), _lib.ptr(red), P, rows, N, training, _lib.ptr(dG), st)
         dW = None
         if ctx.needs_input_grad[1]:
-            _call("gb_la_wx_grad_g", dev, _lib.ptr(red), 1, _lib.ptr(u), _lib.ptr(geo.mom), _lib.ptr(Wx), _lib.ptr(ab), P, N,
-                  training, _lib.ptr(dWx), _lib.ptr(dbeta), _lib.ptr(dgamma), st)
             if wgrad_deferred(dev, st, rows, C, N, ctx.prec):
                 # recorded (WgradQueue): the grouped launch adds dG^T f straight into columns 3.. of the joined (N, 3 + C)
-                # gradient (its rows lie 3 + C floats apart), the xyz columns are written here - no join launch
+                # gradient (its rows lie 3 + C floats apart), the xyz columns are written by the closed-form kernel at
+                # that pitch - no join launch, no strided copy
                 dW = zbuf[rows * N:rows * N + N * (3 + C)].view(N, 3 + C)
-                dW[:, :3].copy_(dWx)
+                _call("gb_la_wx_grad_gs", dev, _lib.ptr(red), 1, _lib.ptr(u), _lib.ptr(geo.mom), _lib.ptr(Wx), _lib.ptr(ab), P,
+                      N, training, _lib.ptr(dW), 3 + C, _lib.ptr(dbeta), _lib.ptr(dgamma), st)
                 _wgrad_call(dev, st, dG, f, None, dW[:, 3:], rows, C, N, ctx.prec, None, ldw=3 + C)
             else:
+                _call("gb_la_wx_grad_g", dev, _lib.ptr(red), 1, _lib.ptr(u), _lib.ptr(geo.mom), _lib.ptr(Wx), _lib.ptr(ab), P,
+                      N, training, _lib.ptr(dWx), _lib.ptr(dbeta), _lib.ptr(dgamma), st)
                 dWf = zbuf[rows * N:rows * N + N * C].view(N, C)
                 _call("gb_gemm_wgrad", dev, _lib.ptr(dG), _lib.ptr(f), None, _lib.ptr(dWf), rows, C, N,
                       _opts(dev, st, ctx.prec), st, meta=_gemm_meta("wgrad", rows, C, N, prec=ctx.prec))

@@ -560,6 +560,10 @@ int gb_la_wx_grad(const double *red, const double *u, const double *mom, const f
  * red may be `slots` rows of [5][C] partial sums (a dgrad epilogue's slot rows), added in slot order. */
 int gb_la_wx_grad_g(const double *red, int slots, const double *u, const double *mom, const float *wx, const float *ab,
                     long long P, int C, int training, float *dwx, float *dbeta, float *dgamma, void *stream);
+/* ... with dwx inside a wider matrix: row c at dwx + c * ldw, ldw >= 3 (ABI v7): the xyz columns of the joined
+ * (C, 3 + Cf) gradient of LocalAggregation's conv (drp.py:32-67), whose feature columns gb_gemm_wgrad_group adds into. */
+int gb_la_wx_grad_gs(const double *red, int slots, const double *u, const double *mom, const float *wx, const float *ab,
+                     long long P, int C, int training, float *dwx, int ldw, float *dbeta, float *dgamma, void *stream);
 
 /* ---- fp32 MFMA GEMMs of the channel-last SharedMLP (csrc/gemm_cl.hip) — replace the cuBLAS/cuDNN
  * 1x1 convolutions the reference reaches through torch (pytorch_utils.py:61-113) ------------------- */

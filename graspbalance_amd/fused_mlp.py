@@ -405,11 +405,17 @@ class WgradQueue:
     gradients autograd hands to the parameters inside the block are views of buffers the grouped launch has not
     written yet: whoever reads them (an optimizer, a gradient all-reduce, a hook) must come after flush() on the same
     stream - train.Trainer flushes before it packs / reduces / steps, and does not defer at all while post-accumulate
-    hooks issue collectives from inside the backward."""
+    hooks issue collectives from inside the backward.  For the same reason the backward must ASSIGN the gradients, not
+    accumulate them: a parameter that already holds a .grad gets `grad += incoming` from autograd at once, i.e. the zeros of a
+    buffer not written yet (likewise a weight used twice, whose two gradients the engine adds).  With `params` the
+    queue CHECKS this when it flushes: every recorded gradient buffer must BE some parameter's .grad (same address) by
+    then - else autograd copied or added zeros - and it raises instead of training on them.  (Gradient accumulation over
+    micro-steps therefore runs its backward passes outside a queue.)"""
 
-    def __init__(self, device):
+    def __init__(self, device, params=None):
         self.dev = torch.device(device)
         self.items, self.keep, self.prec, self.key, self.launches = [], [], None, None, 0
+        self.params = params
 
     def __enter__(self):
         idx = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
@@ -437,9 +443,21 @@ class WgradQueue:
         self.items.append((dY.data_ptr(), X.data_ptr(), aff.data_ptr() if aff is not None else None, dW.data_ptr(), P, K, N, ldw))
         self.keep.append((dY, X, aff, dW))
 
+    def _check_assigned(self):
+        """Every recorded dW is (columns of) some parameter's .grad: the address autograd was handed is the address it
+        kept.  A dW inside a wider matrix (ldw > K: an aggregation conv's columns 3..) starts ldw - K floats in."""
+        held = {p.grad.data_ptr() for p in self.params if p.grad is not None}
+        for (_, _, _, dw, P, K, N, ldw) in self.items:
+            if dw not in held and dw - 4 * (ldw - K) not in held:
+                raise RuntimeError("fused_mlp.WgradQueue: a deferred weight gradient (%d x %d, %d rows) is not the .grad of "
+                                   "any parameter - it was accumulated into an existing gradient or summed with another "
+                                   "use of its weight BEFORE it was computed; run such a backward outside the queue" % (N, K, P))
+
     def flush(self):
         if not self.items:
             return
+        if self.params is not None:
+            self._check_assigned()
         arr = (_lib.WgradItem * len(self.items))(*self.items)
         meta = None
         if _lib.KernelTimer.active is not None:

@@ -276,7 +276,7 @@ class Trainer:
         if (self.device.type != "cuda" or not fused_mlp._WGRAD_GROUP
                 or (hooks_live and self.distributed and dist.is_available() and dist.is_initialized())):
             return _NO_CONTEXT
-        return fused_mlp.WgradQueue(self.device)
+        return fused_mlp.WgradQueue(self.device, params=self.grads.params)
 
     def _bn_momentum(self):
         for m in self.net.modules():

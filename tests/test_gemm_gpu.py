@@ -405,6 +405,16 @@ def test_a_backward_inside_a_wgrad_queue_gives_the_gradients_of_a_backward_outsi
     for a, b in zip(gp0, gp1):
         assert float((a - b).norm()) <= 2e-6 * float(a.norm()) + 1e-12
     assert all(float(g.abs().max()) > 0 for g in gp1[:2])
+    # ... and the misuse the queue can see: a backward that ACCUMULATES into existing gradients (autograd adds the incoming
+    # buffer at once - zeros at that point).  With `params` the queue notices at flush that its buffers are nobody's .grad.
+    x = X.clone().requires_grad_(True)
+    h = fused_mlp.conv_bn_act_chain(x, list(zip(convs, bns)), residual=x, relu_last=True)
+    loss = fused_mlp.linear_bias(h, head).square().mean()
+    assert all(p.grad is not None for p in mods.parameters())         # (left by run(True): the next backward accumulates)
+    with pytest.raises(RuntimeError, match="not the .grad of any parameter"):
+        with fused_mlp.WgradQueue(DEV, params=list(mods.parameters())):
+            loss.backward()
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("reserved", [0, 8, 37, 128])

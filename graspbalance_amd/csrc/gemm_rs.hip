@@ -378,8 +378,13 @@ __global__ __launch_bounds__(RS_TPB, ((NT <= 2 && EPI != RS_BNBWD && EPI != RS_B
   // MFMA phases and their epilogues together; delaying the upper four by half a tile's worth of MFMA time lets one
   // partner's epilogue (stores, statistics) run under the other's MFMAs (+2-4 % on the 1 M-row layers).
   if (g.stagger && wave >= RS_WAVES / 2) {
-    int units = g.nch * NT * 8;  // half a tile = nch*16*NT MFMAs * 64 cycles / 2, in s_sleep units of 64 cycles
-    for (; units > 0; units -= 100) __builtin_amdgcn_s_sleep(100);
+    // half a tile's MFMA time in s_sleep units of 64 cycles: fp32 nch*16*NT MFMAs of 64 cycles; bf16 nch*2*NT of 32; the
+    // split nch*12*NT of 32 (round 6: the split instantiations slept the fp32 figure - 1.3 tile times, a third of a
+    // 131 072-row launch's four tiles per wave - and every remainder was rounded up to 100 units)
+    int units = SP ? g.nch * NT * 3 : BF ? (g.nch * NT + 1) / 2 : g.nch * NT * 8;
+    for (; units >= 100; units -= 100) __builtin_amdgcn_s_sleep(100);
+    for (; units >= 10; units -= 10) __builtin_amdgcn_s_sleep(10);
+    for (; units > 0; --units) __builtin_amdgcn_s_sleep(1);
   }
   // Tail balance: ntiles is rarely a multiple of the nw waves, and a last round with a few tiles costs a whole tile
   // time (6.06 rounds run as 7).  When the remainder is small, its tiles are cut into G column groups handled by G
